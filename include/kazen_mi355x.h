@@ -1,0 +1,252 @@
+/*
+ * kazen_mi355x.h — C ABI of the MI355X-native path-tracing core for nano-kazen.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference: the region
+ * src/kazen/renderer.cpp:85-133 (tbb::parallel_for over blocks -> renderBlock ->
+ * renderSample -> PathMisIntegrator::Li -> Accel::rayIntersect -> ImageBlock::put)
+ * that sits behind  void kazen::renderer::render(Scene*, const std::string&)
+ * (include/kazen/renderer.h:10, src/kazen/renderer.cpp:72).
+ *
+ * A per-ray virtual Integrator::Li() cannot be a GPU boundary, so the plugin
+ * surface is kept as a *description*: the same type strings, property names and
+ * defaults as the reference's KAZEN_REGISTER_CLASS registry, flattened to PODs.
+ * Plain pointers and sizes only; no C++/torch types; errors are int codes plus a
+ * thread-local message (kz_last_error), never exceptions.
+ *
+ * All host pointers inside KzSceneDesc are BORROWED for the duration of
+ * kz_scene_create() only (the library copies what it needs, reference analogue:
+ * Accel::build shares Mesh buffers with Embree, src/kazen/accel.cpp:45-46).
+ * Output buffers are caller-owned.
+ */
+#ifndef KAZEN_MI355X_H
+#define KAZEN_MI355X_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KZ_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+    KZ_OK = 0,
+    KZ_ERR_INVALID_ARG = 1,   /* null pointer, bad size, index out of range     */
+    KZ_ERR_UNSUPPORTED = 2,   /* plugin type outside the hot path (never a silent fallback) */
+    KZ_ERR_NO_DEVICE = 3,     /* no HIP device / HIP extension not usable        */
+    KZ_ERR_HIP = 4,           /* a HIP runtime call failed (message has details) */
+    KZ_ERR_STATE = 5,         /* call order violated (e.g. render before upload) */
+    KZ_ERR_OOM = 6
+};
+
+/* ---- plugin type tags (reference registry names in comments) ------------ */
+enum { KZ_BSDF_DIFFUSE = 0        /* "diffuse"       src/kazen/bsdf.cpp:20-92     */,
+       KZ_BSDF_KAZENSTANDARD = 1  /* "kazenstandard" src/kazen/bsdf.cpp:1157-1418 */ };
+enum { KZ_SAMPLER_INDEPENDENT = 0 /* "independent"   src/kazen/sampler.cpp:18-71   */,
+       KZ_SAMPLER_PMJ02BN = 1     /* "pmj02bn"       src/kazen/sampler.cpp:273-390 */ };
+enum { KZ_CAMERA_PERSPECTIVE = 0  /* "perspective"   src/kazen/camera.cpp:14-131   */ };
+enum { KZ_INTEGRATOR_PATH_MIS = 0 /* "path_mis"      src/kazen/integrator.cpp:185-355 */ };
+enum { KZ_FILTER_GAUSSIAN = 0     /* "gaussian"      src/kazen/rfilter.cpp:10-31   */,
+       KZ_FILTER_MITCHELL = 1     /* "mitchell"      src/kazen/rfilter.cpp:39-70   */,
+       KZ_FILTER_TENT = 2         /* "tent"          src/kazen/rfilter.cpp:73-88   */,
+       KZ_FILTER_BOX = 3          /* "box"           src/kazen/rfilter.cpp:90-102  */ };
+
+#define KZ_FILTER_RESOLUTION 32          /* KAZEN_FILTER_RESOLUTION, include/kazen/rfilter.h:6 */
+#define KZ_PMJ02BN_SETS 5                /* include/kazen/pmj02table.h:10 */
+#define KZ_PMJ02BN_SAMPLES 65536         /* include/kazen/pmj02table.h:11 */
+#define KZ_BLUENOISE_TEXTURES 48         /* include/kazen/bluenoise.h:9 */
+#define KZ_BLUENOISE_RES 128             /* include/kazen/bluenoise.h:8 */
+
+/* ---- scene description -------------------------------------------------- */
+
+/* BSDF row. Replaces BSDF subclasses Diffuse / KazenStandardSurface with their
+ * constant-texture parameters folded (texture.cpp "constanttexture" only).
+ * Defaults are the reference's PropertyList defaults (bsdf.cpp:23, :1160-1167). */
+typedef struct KzBSDF {
+    int32_t type;               /* KZ_BSDF_*                                          */
+    float albedo[3];            /* diffuse: "albedo"       (default 0.5)              */
+    float baseColor[3];         /* kiss: nested texture id "baseColor"                */
+    float roughness;            /* kiss: texture id "roughness" (.r())                */
+    float metallic;             /* kiss: texture id "metallic"  (.r())                */
+    float anisotropy;           /* default 0                                          */
+    float specular;             /* default 0.5                                        */
+    float specularTint;         /* default 0.5                                        */
+    float clearcoat;            /* default 0                                          */
+    float clearcoatRoughness;   /* default 0.5                                        */
+    float sheen;                /* default 0                                          */
+    float sheenTint;            /* default 0.5                                        */
+} KzBSDF;
+
+/* "area" light (src/kazen/light.cpp:7-66). radiance = intensity * color. */
+typedef struct KzLight {
+    float color[3];             /* default 1                                          */
+    float intensity;            /* default 1                                          */
+    int32_t primaryVisibility;  /* "lightPrimaryVisibility", default 0 (false)        */
+} KzLight;
+
+/* Triangle mesh, buffer layout of kazen::Mesh (include/kazen/mesh.h:176-179):
+ * V = Eigen col-major 3 x nV floats (xyz stride 12 B), N same (may be NULL),
+ * UV = 2 x nV (may be NULL), F = 3 x nF uint32 (stride 12 B). */
+typedef struct KzMesh {
+    const float *V;
+    const float *N;             /* NULL: geometric frame, no terminator offset (the reference is UB here, accel.cpp:136) */
+    const float *UV;            /* NULL: prim (u,v) kept in its.uv, Frame(n) tangents  */
+    const uint32_t *F;
+    uint32_t nV;
+    uint32_t nF;
+    int32_t bsdf;               /* index into KzSceneDesc.bsdfs; -1 = default Diffuse(albedo 0.5), mesh.cpp:25-28 */
+    int32_t light;              /* index into KzSceneDesc.lights; -1 = not an emitter  */
+} KzMesh;
+
+/* Reconstruction filter child of the camera (camera.cpp:64-67: default gaussian). */
+typedef struct KzFilter {
+    int32_t type;               /* KZ_FILTER_*                                         */
+    float radius;               /* gaussian/mitchell default 2; tent 1; box 0.5        */
+    float stddev;               /* gaussian, default 0.5                               */
+    float B, C;                 /* mitchell, default 1/3                               */
+} KzFilter;
+
+/* "perspective" camera (src/kazen/camera.cpp:16-33). */
+typedef struct KzCamera {
+    int32_t type;               /* KZ_CAMERA_PERSPECTIVE                               */
+    int32_t width, height;      /* default 1280 x 720                                  */
+    float toWorld[16];          /* row-major 4x4 camera-to-world ("toWorld")           */
+    float fov;                  /* horizontal, degrees, default 30                     */
+    float nearClip, farClip;    /* defaults 1e-4, 1e4                                  */
+    const float *sampleToCamera;/* optional row-major 4x4 override (an adapter inside a kazen tree may hand over
+                                   Eigen's own inverse, camera.cpp:60-62); NULL = computed by the library */
+    KzFilter rfilter;
+} KzCamera;
+
+/* Sampler (src/kazen/sampler.cpp). The table pointers are what the reference links
+ * from pmj02table.cpp / bluenoise.cpp (missing from the checkout): the adapter passes
+ * kazen::pmj02bnSamples and kazen::BlueNoiseTextures verbatim. */
+typedef struct KzSampler {
+    int32_t type;               /* KZ_SAMPLER_*                                        */
+    uint32_t sampleCount;       /* "sampleCount"                                       */
+    uint64_t seed;              /* "seed" (independent: the reference never initialises it; we define 0) */
+    const uint32_t *pmj02bnSamples; /* [5][65536][2] fixed-point 2^-32, pmj02bn only   */
+    const uint16_t *blueNoise;      /* [48][128][128], indexed [tex][x][y], pmj02bn only */
+} KzSampler;
+
+/* "path_mis" (src/kazen/integrator.cpp:187-193). */
+typedef struct KzIntegrator {
+    int32_t type;               /* KZ_INTEGRATOR_PATH_MIS                              */
+    int32_t maxDepth;           /* default 5, capped at 512                            */
+    float traceBias;            /* default 1e-3                                        */
+    int32_t regularization;     /* default 0                                           */
+    float accumulatedRoughness; /* default 0.5                                         */
+} KzIntegrator;
+
+/* "background" texture with one nested "constanttexture" (texture.cpp:104-145). */
+typedef struct KzBackground {
+    int32_t present;            /* 0: Scene::getBackgroundColor returns 0 (scene.cpp:55-56) */
+    float color[3];
+    float intensity;            /* default 1                                           */
+} KzBackground;
+
+typedef struct KzSceneDesc {
+    uint32_t abiVersion;        /* KZ_ABI_VERSION                                      */
+    const KzMesh *meshes;   uint32_t nMeshes;
+    const KzBSDF *bsdfs;    uint32_t nBsdfs;
+    const KzLight *lights;  uint32_t nLights;
+    KzCamera camera;
+    KzSampler sampler;
+    KzIntegrator integrator;
+    KzBackground background;
+} KzSceneDesc;
+
+/* ---- rendering ---------------------------------------------------------- */
+
+/* A rectangle of pixels [x0,x0+w) x [y0,y0+h): the sharding unit (multiples of the
+ * reference's 32x32 KAZEN_BLOCK_SIZE, include/kazen/block.h:8, are natural). */
+typedef struct KzTile { int32_t x0, y0, w, h; } KzTile;
+
+typedef struct KzRenderOpts {
+    uint32_t sampleBegin;       /* render sample indices [sampleBegin, sampleEnd) of every pixel;       */
+    uint32_t sampleEnd;         /* 0,0 = all of sampler.sampleCount                                      */
+    const KzTile *tiles;        /* NULL = whole image                                                    */
+    uint32_t nTiles;
+    int32_t pipeline;           /* 0 = library default, 1 = megakernel, 2 = wavefront                    */
+    int32_t accumulate;         /* 0 = clear the device film first, 1 = add to what is there             */
+    void *stream;               /* hipStream_t to launch on (NULL = the null stream)                     */
+} KzRenderOpts;
+
+/* Counters the kernels keep (all optional; zero unless requested with kz_set_stats). */
+typedef struct KzStats {
+    uint64_t samples;           /* (pixel,sample) pairs rendered                        */
+    uint64_t rays;              /* closest-hit queries (Accel::rayIntersect calls)      */
+    uint64_t nodeVisits;        /* 64-B BVH2 node packets fetched                       */
+    uint64_t triTests;          /* 48-B leaf triangles tested (Moeller-Trumbore)        */
+    uint64_t shadedHits;        /* post-intersection gathers (accel.cpp:113-236)        */
+    uint64_t lightSamples;      /* Mesh::sample calls (mesh.cpp:108-133)                */
+    uint64_t droppedSamples;    /* invalid radiance dropped by ImageBlock::put (block.cpp:57-61) */
+} KzStats;
+
+/* Ray-level record mirroring what Accel::rayIntersect fills (accel.cpp:99-110 + 113-236). */
+typedef struct KzHit {
+    float t;                    /* +inf on miss                                          */
+    float u, v;                 /* prim barycentrics, P=(1-u-v)p0+u p1+v p2 (accel.cpp:122-123) */
+    int32_t mesh;               /* geomID, -1 on miss                                    */
+    int32_t prim;               /* primID within the mesh                                */
+    float p[3];                 /* its.p after the terminator offset                     */
+    float uv[2];                /* its.uv                                                */
+    float sh_s[3], sh_t[3], sh_n[3];  /* its.shFrame                                     */
+    float geo_n[3];             /* its.geoFrame.n                                        */
+} KzHit;
+
+typedef struct KzScene KzScene;
+
+/* Build the immutable scene: copy + flatten the description, build the BVH on the host
+ * (replaces Accel::build, accel.cpp:25-61, and Mesh::activate's light CDF, mesh.cpp:24-45,
+ * and PerspectiveCamera::activate, camera.cpp:35-68). No GPU needed. */
+int kz_scene_create(const KzSceneDesc *desc, KzScene **out);
+void kz_scene_destroy(KzScene *scene);
+
+/* Host BVH statistics (node count, leaf count, max depth, SAH cost) for reports. */
+typedef struct KzBvhInfo { uint32_t nNodes, nLeaves, nTris, maxDepth, maxLeafSize; float sahCost; double buildSeconds; } KzBvhInfo;
+int kz_scene_bvh_info(const KzScene *scene, KzBvhInfo *out);
+
+/* Upload node/triangle/attribute/material/light/sampler tables to the HBM of `device`
+ * and allocate the device film. Fails with KZ_ERR_NO_DEVICE when no GPU is usable. */
+int kz_scene_upload(KzScene *scene, int device);
+
+/* The replacement for renderer.cpp:85-133: accumulate samples into the DEVICE film
+ * ((h+2b) x (w+2b) float4 = rgb*w, w; ImageBlock convention, block.cpp:30,56-85).
+ * Asynchronous on opts->stream. */
+int kz_render(KzScene *scene, const KzRenderOpts *opts);
+
+/* Blocking copy of the device film to the host: film = (h+2b)*(w+2b)*4 floats. */
+int kz_film_download(KzScene *scene, float *film, size_t nFloats);
+int kz_film_clear(KzScene *scene, void *stream);
+/* Film geometry: border = ceil(radius-0.5) (block.cpp:14). */
+int kz_film_dims(const KzScene *scene, int32_t *width, int32_t *height, int32_t *border);
+/* ImageBlock::toBitmap (block.cpp:39-45): rgb = film.rgb / film.w (0 when w == 0). */
+int kz_film_to_rgb(const float *film, int32_t width, int32_t height, int32_t border, float *rgb);
+
+/* Ray-level entry mirroring Accel::rayIntersect(ray, its, shadowRay=false) for n rays
+ * (host arrays; o,d = n x 3 floats). For parity tests of traversal + post-intersection. */
+int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d,
+                  const float *tmin, const float *tmax, KzHit *hits);
+
+/* Statistics: enable=1 switches to the counting kernel variant (slower). */
+int kz_set_stats(KzScene *scene, int enable);
+int kz_get_stats(KzScene *scene, KzStats *out, int reset);
+
+/* Wait for everything queued on the scene's stream. */
+int kz_sync(KzScene *scene);
+
+/* Average device time of the dominant kernel(s) of the last kz_render, in ms,
+ * from hipEvents recorded on the launch stream (0 if none). */
+int kz_last_kernel_ms(KzScene *scene, float *ms);
+
+const char *kz_last_error(void);
+int kz_abi_version(void);
+int kz_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAZEN_MI355X_H */

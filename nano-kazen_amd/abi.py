@@ -1,0 +1,153 @@
+"""ctypes mirror of include/kazen_mi355x.h and the loader of libkazen_mi355x.so.
+
+Plumbing only: every structure here is a field-for-field copy of the C header (which cites
+the reference interface each one replaces). The loader FAILS LOUDLY when the HIP extension
+is missing: there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+KZ_ABI_VERSION = 1
+
+KZ_OK, KZ_ERR_INVALID_ARG, KZ_ERR_UNSUPPORTED, KZ_ERR_NO_DEVICE, KZ_ERR_HIP, KZ_ERR_STATE, KZ_ERR_OOM = range(7)
+KZ_BSDF_DIFFUSE, KZ_BSDF_KAZENSTANDARD = 0, 1
+KZ_SAMPLER_INDEPENDENT, KZ_SAMPLER_PMJ02BN = 0, 1
+KZ_CAMERA_PERSPECTIVE = 0
+KZ_INTEGRATOR_PATH_MIS = 0
+KZ_FILTER_GAUSSIAN, KZ_FILTER_MITCHELL, KZ_FILTER_TENT, KZ_FILTER_BOX = 0, 1, 2, 3
+KZ_FILTER_RESOLUTION = 32
+KZ_PMJ02BN_SETS, KZ_PMJ02BN_SAMPLES = 5, 65536
+KZ_BLUENOISE_TEXTURES, KZ_BLUENOISE_RES = 48, 128
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
+
+
+class KzBSDF(C.Structure):
+    _fields_ = [("type", C.c_int32), ("albedo", C.c_float * 3), ("baseColor", C.c_float * 3),
+                ("roughness", C.c_float), ("metallic", C.c_float), ("anisotropy", C.c_float),
+                ("specular", C.c_float), ("specularTint", C.c_float), ("clearcoat", C.c_float),
+                ("clearcoatRoughness", C.c_float), ("sheen", C.c_float), ("sheenTint", C.c_float)]
+
+
+class KzLight(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("intensity", C.c_float), ("primaryVisibility", C.c_int32)]
+
+
+class KzMesh(C.Structure):
+    _fields_ = [("V", f32p), ("N", f32p), ("UV", f32p), ("F", u32p), ("nV", C.c_uint32), ("nF", C.c_uint32),
+                ("bsdf", C.c_int32), ("light", C.c_int32)]
+
+
+class KzFilter(C.Structure):
+    _fields_ = [("type", C.c_int32), ("radius", C.c_float), ("stddev", C.c_float), ("B", C.c_float), ("C", C.c_float)]
+
+
+class KzCamera(C.Structure):
+    _fields_ = [("type", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("toWorld", C.c_float * 16),
+                ("fov", C.c_float), ("nearClip", C.c_float), ("farClip", C.c_float),
+                ("sampleToCamera", f32p), ("rfilter", KzFilter)]
+
+
+class KzSampler(C.Structure):
+    _fields_ = [("type", C.c_int32), ("sampleCount", C.c_uint32), ("seed", C.c_uint64),
+                ("pmj02bnSamples", u32p), ("blueNoise", u16p)]
+
+
+class KzIntegrator(C.Structure):
+    _fields_ = [("type", C.c_int32), ("maxDepth", C.c_int32), ("traceBias", C.c_float),
+                ("regularization", C.c_int32), ("accumulatedRoughness", C.c_float)]
+
+
+class KzBackground(C.Structure):
+    _fields_ = [("present", C.c_int32), ("color", C.c_float * 3), ("intensity", C.c_float)]
+
+
+class KzSceneDesc(C.Structure):
+    _fields_ = [("abiVersion", C.c_uint32),
+                ("meshes", C.POINTER(KzMesh)), ("nMeshes", C.c_uint32),
+                ("bsdfs", C.POINTER(KzBSDF)), ("nBsdfs", C.c_uint32),
+                ("lights", C.POINTER(KzLight)), ("nLights", C.c_uint32),
+                ("camera", KzCamera), ("sampler", KzSampler), ("integrator", KzIntegrator),
+                ("background", KzBackground)]
+
+
+class KzTile(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class KzRenderOpts(C.Structure):
+    _fields_ = [("sampleBegin", C.c_uint32), ("sampleEnd", C.c_uint32), ("tiles", C.POINTER(KzTile)),
+                ("nTiles", C.c_uint32), ("pipeline", C.c_int32), ("accumulate", C.c_int32), ("stream", C.c_void_p)]
+
+
+class KzStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("nodeVisits", C.c_uint64), ("triTests", C.c_uint64),
+                ("shadedHits", C.c_uint64), ("lightSamples", C.c_uint64), ("droppedSamples", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class KzHit(C.Structure):
+    _fields_ = [("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("mesh", C.c_int32), ("prim", C.c_int32),
+                ("p", C.c_float * 3), ("uv", C.c_float * 2), ("sh_s", C.c_float * 3), ("sh_t", C.c_float * 3),
+                ("sh_n", C.c_float * 3), ("geo_n", C.c_float * 3)]
+
+
+class KzBvhInfo(C.Structure):
+    _fields_ = [("nNodes", C.c_uint32), ("nLeaves", C.c_uint32), ("nTris", C.c_uint32), ("maxDepth", C.c_uint32),
+                ("maxLeafSize", C.c_uint32), ("sahCost", C.c_float), ("buildSeconds", C.c_double)]
+
+
+# every symbol include/kazen_mi355x.h declares (checked by tests/test_abi_cpu.py)
+EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
+           "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
+           "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
+           "kz_device_count"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
+_lib = None
+
+
+class KzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("kazen_mi355x error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load_library():
+    """Load the HIP extension. No fallback: a missing build is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the product path has no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.kz_last_error.restype = C.c_char_p
+    lib.kz_scene_create.argtypes = [C.POINTER(KzSceneDesc), C.POINTER(C.c_void_p)]
+    lib.kz_scene_destroy.argtypes = [C.c_void_p]
+    lib.kz_scene_destroy.restype = None
+    lib.kz_scene_bvh_info.argtypes = [C.c_void_p, C.POINTER(KzBvhInfo)]
+    lib.kz_scene_upload.argtypes = [C.c_void_p, C.c_int]
+    lib.kz_render.argtypes = [C.c_void_p, C.POINTER(KzRenderOpts)]
+    lib.kz_film_download.argtypes = [C.c_void_p, f32p, C.c_size_t]
+    lib.kz_film_clear.argtypes = [C.c_void_p, C.c_void_p]
+    lib.kz_film_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.kz_film_to_rgb.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, f32p]
+    lib.kz_trace_rays.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, f32p, f32p, C.POINTER(KzHit)]
+    lib.kz_set_stats.argtypes = [C.c_void_p, C.c_int]
+    lib.kz_get_stats.argtypes = [C.c_void_p, C.POINTER(KzStats), C.c_int]
+    lib.kz_sync.argtypes = [C.c_void_p]
+    lib.kz_last_kernel_ms.argtypes = [C.c_void_p, f32p]
+    _lib = lib
+    return lib
+
+
+def check(lib, rc):
+    if rc != KZ_OK:
+        msg = lib.kz_last_error()
+        raise KzError(rc, msg.decode() if msg else "")

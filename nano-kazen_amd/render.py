@@ -1,0 +1,108 @@
+"""Thin handle around a KzScene* (the library's immutable scene + device tables + device film)."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class Scene:
+    """kz_scene_create -> [kz_scene_upload] -> kz_render* -> kz_film_download."""
+
+    def __init__(self, desc, device=None):
+        self.lib = abi.load_library()
+        self.desc = desc
+        cdesc = desc.to_c()
+        h = C.c_void_p()
+        abi.check(self.lib, self.lib.kz_scene_create(C.byref(cdesc), C.byref(h)))
+        self.h = h
+        self.device = None
+        w, hh, b = C.c_int32(), C.c_int32(), C.c_int32()
+        abi.check(self.lib, self.lib.kz_film_dims(self.h, C.byref(w), C.byref(hh), C.byref(b)))
+        self.width, self.height, self.border = w.value, hh.value, b.value
+        if device is not None:
+            self.upload(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kz_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bvh_info(self):
+        info = abi.KzBvhInfo()
+        abi.check(self.lib, self.lib.kz_scene_bvh_info(self.h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_}
+
+    def upload(self, device=0):
+        abi.check(self.lib, self.lib.kz_scene_upload(self.h, int(device)))
+        self.device = int(device)
+
+    def render(self, sample_begin=0, sample_end=0, tiles=None, accumulate=False, pipeline=0, stream=None):
+        o = abi.KzRenderOpts()
+        o.sampleBegin, o.sampleEnd = sample_begin, sample_end
+        keep = None
+        if tiles is not None:
+            keep = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
+            o.tiles, o.nTiles = keep, len(tiles)
+        o.pipeline = pipeline
+        o.accumulate = 1 if accumulate else 0
+        o.stream = stream
+        abi.check(self.lib, self.lib.kz_render(self.h, C.byref(o)))
+
+    def sync(self):
+        abi.check(self.lib, self.lib.kz_sync(self.h))
+
+    def film(self):
+        n = (self.height + 2 * self.border) * (self.width + 2 * self.border) * 4
+        out = np.empty(n, np.float32)
+        abi.check(self.lib, self.lib.kz_film_download(self.h, out.ctypes.data_as(abi.f32p), n))
+        return out.reshape(self.height + 2 * self.border, self.width + 2 * self.border, 4)
+
+    def film_clear(self, stream=None):
+        abi.check(self.lib, self.lib.kz_film_clear(self.h, stream))
+
+    def rgb(self, film=None):
+        film = self.film() if film is None else np.ascontiguousarray(film, np.float32)
+        out = np.empty((self.height, self.width, 3), np.float32)
+        abi.check(self.lib, self.lib.kz_film_to_rgb(film.ctypes.data_as(abi.f32p), self.width, self.height, self.border,
+                                                     out.ctypes.data_as(abi.f32p)))
+        return out
+
+    def trace_rays(self, o, d, tmin, tmax):
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        n = o.shape[0]
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float32), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)))
+        hits = (abi.KzHit * n)()
+        abi.check(self.lib, self.lib.kz_trace_rays(self.h, n, o.ctypes.data_as(abi.f32p), d.ctypes.data_as(abi.f32p),
+                                                   tmin.ctypes.data_as(abi.f32p), tmax.ctypes.data_as(abi.f32p), hits))
+        return hits_to_arrays(hits, n)
+
+    def set_stats(self, enable=True):
+        abi.check(self.lib, self.lib.kz_set_stats(self.h, 1 if enable else 0))
+
+    def stats(self, reset=False):
+        s = abi.KzStats()
+        abi.check(self.lib, self.lib.kz_get_stats(self.h, C.byref(s), 1 if reset else 0))
+        return s.as_dict()
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        abi.check(self.lib, self.lib.kz_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+
+def hits_to_arrays(hits, n):
+    raw = np.frombuffer(hits, dtype=np.uint8).reshape(n, C.sizeof(abi.KzHit))
+    f = raw.view(np.float32).reshape(n, -1)
+    i = raw.view(np.int32).reshape(n, -1)
+    return {"t": f[:, 0].copy(), "u": f[:, 1].copy(), "v": f[:, 2].copy(), "mesh": i[:, 3].copy(), "prim": i[:, 4].copy(),
+            "p": f[:, 5:8].copy(), "uv": f[:, 8:10].copy(), "sh_s": f[:, 10:13].copy(), "sh_t": f[:, 13:16].copy(),
+            "sh_n": f[:, 16:19].copy(), "geo_n": f[:, 19:22].copy()}

@@ -1,0 +1,1417 @@
+// =====================================================================================
+// kz_oracle.cpp — CPU restatement of nano-kazen's path_mis hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE. Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load it. The shipped library
+// (nano-kazen_amd/csrc) never includes, links or calls anything in this directory.
+//
+// Parity status: the integer functions (MurmurHash64A / Hash / MixBits / pcg32) are
+// PINNED against the reference's own headers compiled where they lie
+// (oracle/build_ref.sh -> oracle/_ref/kat_ref -> tests/golden/int_kats.json).
+// Everything floating point is a restatement from the source text: the reference
+// ships no test, golden vector or fixture for this path (src/kazen/test.cpp:1-6 is an
+// empty main) and cannot be built here (Eigen, Embree, TBB, OpenImageIO absent), so
+// for those functions the header says it plainly: PARITY UNPINNED (text-only).
+// Embree 3.13.0 (CMakeLists.txt:12) does the reference's BVH build + traversal; it is
+// replaced by a brute-force Moeller-Trumbore search (mesh.cpp:55-92) and a scalar BVH2
+// that is checked against that brute force.
+//
+// Every function cites the reference file:line it follows. Paths are relative to
+// /root/reference. Draw order hazards H1..H11 are listed in SURVEY.md section 7.
+// Compile: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+// =====================================================================================
+#include "../include/kazen_mi355x.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+
+namespace kzo {
+
+// ---------------------------------------------------------------------------------
+// constants (include/kazen/common.h:27-40)
+// ---------------------------------------------------------------------------------
+static const float Epsilon = 1e-5f;
+static const float OneMinusEpsilon = float(0x1.fffffep-1);
+static const float INV_PI = 0.31830988618379067154f;
+static const float kInf = std::numeric_limits<float>::infinity();
+
+struct V3 {
+    float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(float a) : x(a), y(a), z(a) {}
+    V3(float a, float b, float c) : x(a), y(b), z(c) {}
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+static inline V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline V3 operator*(V3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline V3 operator*(float s, V3 a) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline V3 operator*(V3 a, V3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline V3 operator/(V3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+static inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V3 cross(V3 a, V3 b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float norm(V3 a) { return std::sqrt(dot(a, a)); }
+// Eigen's normalized(): v / sqrt(squaredNorm) when squaredNorm > 0, else v.
+static inline V3 normalized(V3 a) {
+    float n2 = dot(a, a);
+    if (n2 > 0.f) return a / std::sqrt(n2);
+    return a;
+}
+static inline float maxCoeff(V3 a) { return std::max(a.x, std::max(a.y, a.z)); }
+
+// ---------------------------------------------------------------------------------
+// a6  Hash / MurmurHash64A / MixBits  (include/kazen/hash.h:15-65, :71-78, :100-108)
+// ---------------------------------------------------------------------------------
+static inline uint64_t MurmurHash64A(const unsigned char *key, size_t len, uint64_t seed) {
+    const uint64_t m = 0xc6a4a7935bd1e995ull;
+    const int r = 47;
+    uint64_t h = seed ^ (len * m);
+    const unsigned char *end = key + 8 * (len / 8);
+    while (key != end) {
+        uint64_t k;
+        std::memcpy(&k, key, 8);
+        key += 8;
+        k *= m; k ^= k >> r; k *= m;
+        h ^= k; h *= m;
+    }
+    size_t tail = len & 7;
+    if (tail) {
+        for (size_t i = tail; i-- > 0;) h ^= uint64_t(key[i]) << (8 * i);
+        h *= m;
+    }
+    h ^= h >> r; h *= m; h ^= h >> r;
+    return h;
+}
+static inline uint64_t MixBits(uint64_t v) {
+    v ^= (v >> 31); v *= 0x7fb5d329728ea185ull;
+    v ^= (v >> 27); v *= 0x81dadef4bc2dd44dull;
+    v ^= (v >> 33);
+    return v;
+}
+// Hash(Point2i p, uint64_t seed): 16-byte key (sampler.cpp:44)
+static inline uint64_t HashPixelSeed(int32_t px, int32_t py, uint64_t seed) {
+    unsigned char buf[16];
+    std::memcpy(buf, &px, 4); std::memcpy(buf + 4, &py, 4); std::memcpy(buf + 8, &seed, 8);
+    return MurmurHash64A(buf, 16, 0);
+}
+// Hash(Point2i p, uint32_t dim, uint64_t seed): 20-byte key (sampler.cpp:341,355)
+static inline uint64_t HashPixelDimSeed(int32_t px, int32_t py, uint32_t dim, uint64_t seed) {
+    unsigned char buf[24];
+    std::memcpy(buf, &px, 4); std::memcpy(buf + 4, &py, 4); std::memcpy(buf + 8, &dim, 4);
+    std::memcpy(buf + 12, &seed, 8);
+    return MurmurHash64A(buf, 20, 0);
+}
+
+// ---------------------------------------------------------------------------------
+// a7  pcg32 (include/kazen/pcg32.h:54-64 seed, :67-73 nextUInt, :108-117 nextFloat,
+//            :145-166 advance)
+// ---------------------------------------------------------------------------------
+struct Pcg32 {
+    uint64_t state, inc;
+    static constexpr uint64_t MULT = 0x5851f42d4c957f2dULL;
+    Pcg32() : state(0x853c49e6748fea9bULL), inc(0xda3e39cb94b95bdbULL) {}
+    void seed(uint64_t initstate, uint64_t initseq) {
+        state = 0u; inc = (initseq << 1u) | 1u;
+        nextUInt(); state += initstate; nextUInt();
+    }
+    void seed(uint64_t initseq) { seed(MixBits(initseq), initseq); }
+    uint32_t nextUInt() {
+        uint64_t old = state;
+        state = old * MULT + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    float nextFloat() {
+        union { uint32_t u; float f; } x;
+        x.u = (nextUInt() >> 9) | 0x3f800000u;
+        return x.f - 1.0f;
+    }
+    void advance(int64_t delta_) {
+        uint64_t cur_mult = MULT, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+        uint64_t delta = (uint64_t)delta_;
+        while (delta > 0) {
+            if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+            cur_plus = (cur_mult + 1) * cur_plus;
+            cur_mult *= cur_mult;
+            delta /= 2;
+        }
+        state = acc_mult * state + acc_plus;
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// a8  random::permute (src/kazen/common.cpp:316-344) — p is uint32 (callers truncate)
+// ---------------------------------------------------------------------------------
+static inline uint32_t permute(uint32_t i, uint32_t l, uint32_t p) {
+    uint32_t w = l - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= p; i *= 0xe170893d; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8;
+        i *= 0x0929eb3f; i ^= p >> 23; i ^= (i & w) >> 1; i *= 1 | p >> 27;
+        i *= 0x6935fa69; i ^= (i & w) >> 11; i *= 0x74dcb303; i ^= (i & w) >> 2;
+        i *= 0x9e501cc3; i ^= (i & w) >> 2; i *= 0xc860a3df; i &= w; i ^= i >> 5;
+    } while (i >= l);
+    return (i + p) % l;
+}
+// src/kazen/common.cpp:304-314
+static inline uint64_t sampleTEA32(uint32_t v0, uint32_t v1, int rounds) {
+    uint32_t sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9;
+        v0 += ((v1 << 4) + 0xa341316c) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4);
+        v1 += ((v0 << 4) + 0xad90777d) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761e);
+    }
+    return ((uint64_t)v1 << 32) + v0;
+}
+
+// include/kazen/common.h:271-320 (isPowerOf4 / log2i / log4i / roundUpPow4)
+static inline bool isPowerOf4(int n) {
+    if (n <= 0) return false;
+    int x = (int)std::sqrt((double)n);
+    if (x * x != n) return false;
+    return !(n & (n - 1));
+}
+static inline int log2i(uint32_t v) { return 31 - __builtin_clz(v); }
+static inline int log4i(uint32_t v) { return log2i(v) / 2; }
+static inline int roundUpPow4(int v) { return isPowerOf4(v) ? v : (1 << (2 * (1 + log4i((uint32_t)v)))); }
+
+// ---------------------------------------------------------------------------------
+// a17  Frame / coordinateSystem (include/kazen/frame.h:14-51, src/kazen/common.cpp:436-445)
+// ---------------------------------------------------------------------------------
+static inline void coordinateSystem(const V3 &a, V3 &b, V3 &c) {
+    if (std::fabs(a.x) > std::fabs(a.y)) {
+        float invLen = 1.0f / std::sqrt(a.x * a.x + a.z * a.z);
+        c = V3(a.z * invLen, 0.0f, -a.x * invLen);
+    } else {
+        float invLen = 1.0f / std::sqrt(a.y * a.y + a.z * a.z);
+        c = V3(0.0f, a.z * invLen, -a.y * invLen);
+    }
+    b = cross(c, a);
+}
+struct Frame {
+    V3 s, t, n;
+    Frame() {}
+    explicit Frame(const V3 &n_) : n(n_) { coordinateSystem(n, s, t); }
+    V3 toLocal(const V3 &v) const { return V3(dot(v, s), dot(v, t), dot(v, n)); }
+    V3 toWorld(const V3 &v) const { return s * v.x + t * v.y + n * v.z; }
+};
+
+struct Ray {
+    V3 o, d;
+    float mint, maxt;
+    Ray() : mint(Epsilon), maxt(kInf) {}                       // ray.h:31-32
+    Ray(V3 o_, V3 d_) : o(o_), d(d_), mint(Epsilon), maxt(kInf) {}   // ray.h:35-38
+    Ray(V3 o_, V3 d_, float a, float b) : o(o_), d(d_), mint(a), maxt(b) {}
+};
+
+// ---------------------------------------------------------------------------------
+// scene tables
+// ---------------------------------------------------------------------------------
+struct MeshData {
+    std::vector<float> V, N, UV;
+    std::vector<uint32_t> F;
+    uint32_t nV = 0, nF = 0;
+    int bsdf = -1, light = -1;
+    // light CDF (mesh.cpp:24-45, dpdf.h)
+    std::vector<float> cdf;
+    float normalization = 0.f;   // DiscretePDF::m_normalization == Mesh::pdf()
+    uint32_t triOffset = 0;      // global triangle id of face 0
+    V3 v(uint32_t i) const { return V3(V[3 * i], V[3 * i + 1], V[3 * i + 2]); }
+    V3 nrm(uint32_t i) const { return V3(N[3 * i], N[3 * i + 1], N[3 * i + 2]); }
+};
+
+struct Intersection {
+    V3 p;
+    float t = 0;
+    float uvx = 0, uvy = 0;
+    Frame shFrame, geoFrame;
+    int mesh = -1;
+    float accumulatedRoughness = 0.f;   // mesh.h:40
+    // extra (not in the reference record): prim ids for ray-level tests
+    int prim = -1;
+    float bu = 0, bv = 0;
+};
+
+struct Stats {
+    std::atomic<uint64_t> samples{0}, rays{0}, nodeVisits{0}, triTests{0}, shadedHits{0}, lightSamples{0}, dropped{0};
+};
+struct LocalStats {
+    uint64_t samples = 0, rays = 0, nodeVisits = 0, triTests = 0, shadedHits = 0, lightSamples = 0, dropped = 0;
+};
+
+// scalar BVH2, node = both children's boxes (the 64-B packet of SURVEY 8d)
+struct BNode {
+    float lo[2][3], hi[2][3];
+    uint32_t child[2];    // bit31 set: leaf -> (start<<3 | count-1... see encode)
+};
+static inline uint32_t leafRef(uint32_t start, uint32_t count) { return 0x80000000u | (start << 3) | (count - 1); }
+
+struct Tri { V3 p0, e1, e2; uint32_t mesh, prim, gid; };
+
+struct Scene {
+    std::vector<MeshData> meshes;
+    std::vector<KzBSDF> bsdfs;
+    std::vector<KzLight> lights;
+    std::vector<int> lightMeshes;            // Scene::m_lights (scene.cpp:42-46), mesh order
+    KzCamera cam;
+    KzSampler smp;
+    KzIntegrator integ;
+    KzBackground bg;
+    std::vector<uint32_t> pmjTable;
+    std::vector<uint16_t> bnTable;
+    // camera (camera.cpp:35-68)
+    float s2c[16];
+    float invW, invH;
+    // filter table (block.cpp:13-21)
+    float filterRadius = 2.f; int border = 2; float filter[KZ_FILTER_RESOLUTION + 1]; float lookupFactor = 16.f;
+    // pmj02bn pixel samples (sampler.cpp:291-309)
+    int pixelTileSize = 0; std::vector<float> pixelSamples;
+    uint32_t sampleCount = 1;
+    // geometry
+    std::vector<Tri> tris;        // leaf order
+    std::vector<BNode> nodes;
+    uint32_t rootRef = 0;         // for degenerate 1-leaf scenes
+    bool useBrute = false;
+    uint32_t maxDepth = 0;
+    Stats stats;
+};
+
+// ---------------------------------------------------------------------------------
+// a15  Mesh::rayIntersect — Moeller-Trumbore (src/kazen/mesh.cpp:55-92)
+// edge1/edge2 are the same float values the reference computes per call (p1-p0, p2-p0).
+// ---------------------------------------------------------------------------------
+static inline bool triIntersect(const Tri &tr, const V3 &o, const V3 &d, float mint, float maxt,
+                                float &u, float &v, float &t) {
+    V3 pvec = cross(d, tr.e2);
+    float det = dot(tr.e1, pvec);
+    if (det > -1e-8f && det < 1e-8f) return false;
+    float inv_det = 1.0f / det;
+    V3 tvec = o - tr.p0;
+    u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0 || u > 1.0) return false;
+    V3 qvec = cross(tvec, tr.e1);
+    v = dot(d, qvec) * inv_det;
+    if (v < 0.0 || u + v > 1.0) return false;
+    t = dot(tr.e2, qvec) * inv_det;
+    return t >= mint && t <= maxt;
+}
+
+// Closest-hit record of rtcIntersect1 (accel.cpp:98-110). Ties on t are broken by the lower
+// global triangle id so that the answer does not depend on traversal order (Embree's own
+// tie behaviour is unspecified; parity there is unpinned).
+struct RawHit { float t, u, v; uint32_t ti; bool hit; };
+
+static inline void considerTri(const Scene &sc, uint32_t ti, const V3 &o, const V3 &d, float mint, RawHit &best,
+                               float &maxt, LocalStats &ls) {
+    float u, v, t;
+    ls.triTests++;
+    const Tri &tr = sc.tris[ti];
+    if (triIntersect(tr, o, d, mint, maxt, u, v, t)) {
+        if (!best.hit || t < best.t || (t == best.t && tr.gid < sc.tris[best.ti].gid)) {
+            best.hit = true; best.t = t; best.u = u; best.v = v; best.ti = ti; maxt = t;
+        }
+    }
+}
+
+// a16 TBoundingBox::rayIntersect slab test (include/kazen/bbox.h:316-343), returning nearT.
+static inline bool slab(const float lo[3], const float hi[3], const V3 &o, const V3 &d, const V3 &rcp,
+                        float mint, float maxt, float &nearOut) {
+    float nearT = -kInf, farT = kInf;
+    for (int i = 0; i < 3; i++) {
+        float origin = o[i], minVal = lo[i], maxVal = hi[i];
+        if (d[i] == 0) {
+            if (origin < minVal || origin > maxVal) return false;
+        } else {
+            float t1 = (minVal - origin) * rcp[i];
+            float t2 = (maxVal - origin) * rcp[i];
+            if (t1 > t2) std::swap(t1, t2);
+            nearT = std::max(t1, nearT);
+            farT = std::min(t2, farT);
+            if (!(nearT <= farT)) return false;
+        }
+    }
+    nearOut = nearT;
+    return mint <= farT && nearT <= maxt;
+}
+
+static RawHit closestHit(const Scene &sc, const V3 &o, const V3 &d, float mint, float maxt, LocalStats &ls) {
+    RawHit best; best.hit = false; best.t = kInf; best.u = best.v = 0; best.ti = 0;
+    ls.rays++;
+    if (sc.tris.empty()) return best;
+    if (sc.useBrute) {
+        for (uint32_t i = 0; i < sc.tris.size(); ++i) considerTri(sc, i, o, d, mint, best, maxt, ls);
+        return best;
+    }
+    V3 rcp(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);     // ray.h:56-58 cwiseInverse
+    uint32_t stack[128]; int sp = 0;
+    uint32_t cur = sc.rootRef;
+    for (;;) {
+        if (cur & 0x80000000u) {
+            uint32_t start = (cur & 0x7fffffffu) >> 3, count = (cur & 7u) + 1;
+            for (uint32_t i = 0; i < count; ++i) considerTri(sc, start + i, o, d, mint, best, maxt, ls);
+            if (sp == 0) break;
+            cur = stack[--sp];
+            continue;
+        }
+        const BNode &n = sc.nodes[cur];
+        ls.nodeVisits++;
+        float n0 = 0.f, n1 = 0.f;
+        bool h0 = slab(n.lo[0], n.hi[0], o, d, rcp, mint, maxt, n0);
+        bool h1 = slab(n.lo[1], n.hi[1], o, d, rcp, mint, maxt, n1);
+        if (h0 && h1) {
+            int nearIdx = (n1 < n0) ? 1 : 0;
+            stack[sp++] = n.child[1 - nearIdx];
+            cur = n.child[nearIdx];
+        } else if (h0) cur = n.child[0];
+        else if (h1) cur = n.child[1];
+        else { if (sp == 0) break; cur = stack[--sp]; }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------------
+// host BVH build for the oracle: plain binned-SAH BVH2, <= 4 tris per leaf. Boxes are
+// padded by a few ulps so the slab test (different rounding than Moeller-Trumbore) can
+// never cull a triangle the brute force would report.
+// ---------------------------------------------------------------------------------
+struct BuildPrim { float lo[3], hi[3], c[3]; uint32_t tri; };
+struct Builder {
+    Scene &sc; std::vector<BuildPrim> prims; std::vector<Tri> src; uint32_t maxDepth = 0;
+    Builder(Scene &s) : sc(s) {}
+    static void padBox(float lo[3], float hi[3]) {
+        for (int a = 0; a < 3; ++a) {
+            float m = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+            float e = m * 4e-7f + 1e-30f;
+            lo[a] -= e; hi[a] += e;
+        }
+    }
+    void bounds(uint32_t b, uint32_t e, float lo[3], float hi[3]) {
+        for (int a = 0; a < 3; ++a) { lo[a] = kInf; hi[a] = -kInf; }
+        for (uint32_t i = b; i < e; ++i)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], prims[i].lo[a]); hi[a] = std::max(hi[a], prims[i].hi[a]); }
+    }
+    static float area(const float lo[3], const float hi[3]) {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+    // returns child ref; writes box of the subtree
+    uint32_t build(uint32_t b, uint32_t e, float lo[3], float hi[3], uint32_t depth) {
+        bounds(b, e, lo, hi);
+        maxDepth = std::max(maxDepth, depth);
+        uint32_t n = e - b;
+        if (n <= 4) {
+            uint32_t start = (uint32_t)sc.tris.size();
+            for (uint32_t i = b; i < e; ++i) sc.tris.push_back(src[prims[i].tri]);
+            padBox(lo, hi);
+            return leafRef(start, n);
+        }
+        // centroid bounds
+        float clo[3] = {kInf, kInf, kInf}, chi[3] = {-kInf, -kInf, -kInf};
+        for (uint32_t i = b; i < e; ++i)
+            for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], prims[i].c[a]); chi[a] = std::max(chi[a], prims[i].c[a]); }
+        const int NB = 16;
+        float bestCost = kInf; int bestAxis = -1, bestSplit = 0;
+        for (int a = 0; a < 3; ++a) {
+            float ext = chi[a] - clo[a];
+            if (!(ext > 0.f)) continue;
+            float blo[NB][3], bhi[NB][3]; uint32_t cnt[NB];
+            for (int k = 0; k < NB; ++k) { cnt[k] = 0; for (int c = 0; c < 3; ++c) { blo[k][c] = kInf; bhi[k][c] = -kInf; } }
+            float scale = NB / ext;
+            for (uint32_t i = b; i < e; ++i) {
+                int k = std::min(NB - 1, (int)((prims[i].c[a] - clo[a]) * scale));
+                cnt[k]++;
+                for (int c = 0; c < 3; ++c) { blo[k][c] = std::min(blo[k][c], prims[i].lo[c]); bhi[k][c] = std::max(bhi[k][c], prims[i].hi[c]); }
+            }
+            float rA[NB]; uint32_t rC[NB];
+            float rlo[3] = {kInf, kInf, kInf}, rhi[3] = {-kInf, -kInf, -kInf}; uint32_t rc = 0;
+            for (int k = NB - 1; k > 0; --k) {
+                for (int c = 0; c < 3; ++c) { rlo[c] = std::min(rlo[c], blo[k][c]); rhi[c] = std::max(rhi[c], bhi[k][c]); }
+                rc += cnt[k]; rA[k] = area(rlo, rhi); rC[k] = rc;
+            }
+            float llo[3] = {kInf, kInf, kInf}, lhi[3] = {-kInf, -kInf, -kInf}; uint32_t lc = 0;
+            for (int k = 0; k < NB - 1; ++k) {
+                for (int c = 0; c < 3; ++c) { llo[c] = std::min(llo[c], blo[k][c]); lhi[c] = std::max(lhi[c], bhi[k][c]); }
+                lc += cnt[k];
+                if (lc == 0 || rC[k + 1] == 0) continue;
+                float cost = area(llo, lhi) * lc + rA[k + 1] * rC[k + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = k; }
+            }
+        }
+        uint32_t mid;
+        if (bestAxis < 0 || depth > 90) {
+            mid = b + n / 2;   // all centroids coincide (or runaway depth): split the list in half
+        } else {
+            float ext = chi[bestAxis] - clo[bestAxis]; float scale = NB / ext; int a = bestAxis;
+            auto it = std::partition(prims.begin() + b, prims.begin() + e, [&](const BuildPrim &p) {
+                int k = std::min(NB - 1, (int)((p.c[a] - clo[a]) * scale));
+                return k <= bestSplit;
+            });
+            mid = (uint32_t)(it - prims.begin());
+            if (mid == b || mid == e) mid = b + n / 2;
+        }
+        uint32_t idx = (uint32_t)sc.nodes.size();
+        sc.nodes.push_back(BNode());
+        float l0[3], h0[3], l1[3], h1[3];
+        uint32_t c0 = build(b, mid, l0, h0, depth + 1);
+        uint32_t c1 = build(mid, e, l1, h1, depth + 1);
+        BNode &nd = sc.nodes[idx];
+        for (int a = 0; a < 3; ++a) { nd.lo[0][a] = l0[a]; nd.hi[0][a] = h0[a]; nd.lo[1][a] = l1[a]; nd.hi[1][a] = h1[a]; }
+        nd.child[0] = c0; nd.child[1] = c1;
+        // parents of leaves carry padded boxes already; inner boxes are unions of padded boxes
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(l0[a], l1[a]); hi[a] = std::max(h0[a], h1[a]); }
+        return idx;
+    }
+    void run() {
+        // gather triangles in (mesh, face) order = Embree geomID/primID order (accel.cpp:40-55)
+        uint32_t gid = 0;
+        for (size_t m = 0; m < sc.meshes.size(); ++m) {
+            MeshData &md = sc.meshes[m];
+            md.triOffset = gid;
+            for (uint32_t f = 0; f < md.nF; ++f, ++gid) {
+                uint32_t i0 = md.F[3 * f], i1 = md.F[3 * f + 1], i2 = md.F[3 * f + 2];
+                Tri t; t.p0 = md.v(i0); V3 p1 = md.v(i1), p2 = md.v(i2);
+                t.e1 = p1 - t.p0; t.e2 = p2 - t.p0; t.mesh = (uint32_t)m; t.prim = f; t.gid = gid;
+                src.push_back(t);
+                BuildPrim bp; bp.tri = gid;
+                for (int a = 0; a < 3; ++a) {
+                    float x0 = t.p0[a], x1 = p1[a], x2 = p2[a];
+                    bp.lo[a] = std::min(x0, std::min(x1, x2)); bp.hi[a] = std::max(x0, std::max(x1, x2));
+                    bp.c[a] = 0.5f * (bp.lo[a] + bp.hi[a]);
+                }
+                prims.push_back(bp);
+            }
+        }
+        sc.tris.clear(); sc.nodes.clear();
+        if (prims.empty()) return;
+        float lo[3], hi[3];
+        sc.tris.reserve(prims.size());
+        sc.rootRef = build(0, (uint32_t)prims.size(), lo, hi, 0);
+        sc.maxDepth = maxDepth;
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// a13/a14  Accel::rayIntersect (src/kazen/accel.cpp:63-239)
+// ---------------------------------------------------------------------------------
+static bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its, bool shadowRay, LocalStats &ls) {
+    RawHit rh = closestHit(sc, ray.o, ray.d, ray.mint, ray.maxt, ls);
+    if (!rh.hit) return false;
+    const Tri &tr = sc.tris[rh.ti];
+    if (shadowRay) {                                   // accel.cpp:100-104
+        its.t = rh.t; its.mesh = (int)tr.mesh;
+        return true;
+    }
+    ls.shadedHits++;
+    its.t = rh.t; its.uvx = rh.u; its.uvy = rh.v; its.mesh = (int)tr.mesh;      // accel.cpp:105-108
+    its.prim = (int)tr.prim; its.bu = rh.u; its.bv = rh.v;
+    const MeshData &md = sc.meshes[tr.mesh];
+    uint32_t f = tr.prim;
+    float bx = 1 - (its.uvx + its.uvy), by = its.uvx, bz = its.uvy;              // accel.cpp:122-123
+    uint32_t idx0 = md.F[3 * f], idx1 = md.F[3 * f + 1], idx2 = md.F[3 * f + 2];
+    V3 p0 = md.v(idx0), p1 = md.v(idx1), p2 = md.v(idx2);
+    bool hasN = !md.N.empty(), hasUV = !md.UV.empty();
+    V3 orignP = bx * p0 + by * p1 + bz * p2;                                     // accel.cpp:142
+    if (hasN) {
+        V3 n0 = md.nrm(idx0), n1 = md.nrm(idx1), n2 = md.nrm(idx2);
+        V3 tmpu = orignP - p0, tmpv = orignP - p1, tmpw = orignP - p2;           // accel.cpp:144
+        float dotu = std::min(0.f, dot(tmpu, n0));
+        float dotv = std::min(0.f, dot(tmpv, n1));
+        float dotw = std::min(0.f, dot(tmpw, n2));
+        tmpu = tmpu - dotu * n0; tmpv = tmpv - dotv * n1; tmpw = tmpw - dotw * n2;
+        its.p = orignP + bx * tmpu + by * tmpv + bz * tmpw;                      // accel.cpp:153
+    } else {
+        its.p = orignP;   // reference reads N.col() of an empty matrix here (UB, H4); defined as "no offset"
+    }
+    V3 dp0 = p1 - p0, dp1 = p2 - p0;
+    its.geoFrame = Frame(normalized(cross(dp0, dp1)));                           // accel.cpp:156-158
+    float uv0x = 0, uv0y = 0, uv1x = 0, uv1y = 0, uv2x = 0, uv2y = 0;
+    if (hasUV) {                                                                 // accel.cpp:161-164
+        uv0x = md.UV[2 * idx0]; uv0y = md.UV[2 * idx0 + 1];
+        uv1x = md.UV[2 * idx1]; uv1y = md.UV[2 * idx1 + 1];
+        uv2x = md.UV[2 * idx2]; uv2y = md.UV[2 * idx2 + 1];
+        its.uvx = bx * uv0x + by * uv1x + bz * uv2x;
+        its.uvy = bx * uv0y + by * uv1y + bz * uv2y;
+    }
+    if (hasN && hasUV) {                                                         // accel.cpp:166-217
+        V3 n0 = md.nrm(idx0), n1 = md.nrm(idx1), n2 = md.nrm(idx2);
+        float duv0x = uv1x - uv0x, duv0y = uv1y - uv0y, duv1x = uv2x - uv0x, duv1y = uv2y - uv0y;
+        V3 shNormal = bx * n0 + by * n1 + bz * n2;
+        float length = norm(cross(dp0, dp1));
+        if (length > 0.f) {
+            float determinant = duv0x * duv1y - duv0y * duv1x;
+            if (determinant > 0.f) {
+                float invDet = 1.0f / determinant;
+                V3 dpdu = (duv1y * dp0 - duv0y * dp1) * invDet;
+                its.shFrame.n = normalized(shNormal);
+                its.shFrame.s = normalized(dpdu - shNormal * dot(shNormal, dpdu));
+                its.shFrame.t = normalized(cross(its.shFrame.n, its.shFrame.s));
+            } else {
+                its.shFrame = Frame(normalized(shNormal));
+            }
+        } else {
+            its.shFrame = Frame(normalized(shNormal));
+        }
+    } else if (hasN) {                                                           // accel.cpp:219-229
+        V3 n0 = md.nrm(idx0), n1 = md.nrm(idx1), n2 = md.nrm(idx2);
+        its.shFrame = Frame(normalized(bx * n0 + by * n1 + bz * n2));
+    } else {
+        its.shFrame = its.geoFrame;                                              // accel.cpp:231-233
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------
+// a23  Warp::squareToCosineHemisphere (src/kazen/warp.cpp:85-115). M_PI is a double in
+// the reference, so phi is evaluated in double and narrowed on assignment.
+// ---------------------------------------------------------------------------------
+static V3 squareToCosineHemisphere(float sx, float sy) {
+    float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f;
+    float phi, r;
+    if (r1 == 0 && r2 == 0) { r = phi = 0; }
+    else if (r1 * r1 > r2 * r2) { r = r1; phi = (float)((M_PI / 4.0f) * (r2 / r1)); }
+    else { r = r2; phi = (float)((M_PI / 2.0f) - (r1 / r2) * (M_PI / 4.0f)); }
+    float sinPhi = std::sin(phi), cosPhi = std::cos(phi);     // common.h:228-231 math::sincosf
+    float px = r * cosPhi, py = r * sinPhi;
+    float z = std::sqrt(1.0f - px * px - py * py);
+    if (z == 0) z = 1e-10f;
+    return V3(px, py, z);
+}
+// Warp::squareToUniformDisk (warp.cpp:41-50) — thin-lens, "next" row
+static void squareToUniformDisk(float sx, float sy, float &ox, float &oy) {
+    float r = std::sqrt(sx);
+    float a = (float)(2.0f * M_PI * sy);
+    ox = std::cos(a) * r; oy = std::sin(a) * r;
+}
+
+// ---------------------------------------------------------------------------------
+// a22  GGX helpers (include/kazen/ggx_brdf.h). H3: unqualified abs/pow/cos/sin are taken
+// with float semantics; M_PI expressions are evaluated in double as the text says.
+// ---------------------------------------------------------------------------------
+static inline float sqr(float x) { return x * x; }
+struct A2 { float x, y; };
+static inline V3 schlickFresnel(V3 f0, float cosTheta) {                 // ggx_brdf.h:15-24
+    float t = std::pow(1.0f - cosTheta, 5.0f);
+    return f0 * 1.0f + (V3(1.f) - f0) * t;
+}
+static inline A2 roughnessToAlpha(float roughness, float anisotropy) {   // ggx_brdf.h:28-37
+    float alpha = std::max(0.001f, sqr(roughness));
+    return A2{alpha * (1.0f + anisotropy), alpha * (1.0f - anisotropy)};
+}
+static inline float lambda(V3 v, A2 a) {                                 // ggx_brdf.h:41-45
+    float squared = (sqr(a.x) * sqr(v.x) + sqr(a.y) * sqr(v.y)) / sqr(v.z);
+    return (-1.0f + std::sqrt(1.0f + squared)) * 0.5f;
+}
+static inline float smithG1(V3 V, V3 H, A2 a) {                          // ggx_brdf.h:49-55
+    if (dot(V, H) <= 0.0f) return 0.0f;
+    return 1.0f / (1.0f + lambda(V, a));
+}
+static inline float smithG2(V3 V, V3 L, V3 H, A2 a) {                    // ggx_brdf.h:60-67
+    if (dot(V, H) <= 0.0f || dot(L, H) < 0.0f) return 0.0f;
+    return 1.0f / (1.0f + lambda(V, a) + lambda(L, a));
+}
+static inline float ggxNDF(V3 H, A2 a) {                                 // ggx_brdf.h:71-75
+    float ellipse = sqr(H.x) / sqr(a.x) + sqr(H.y) / sqr(a.y) + sqr(H.z);
+    return (float)(1.0f / (M_PI * a.x * a.y * sqr(ellipse)));
+}
+static inline float ggxSmithVNDF(V3 V, V3 H, A2 a) {                     // ggx_brdf.h:80-91
+    float VDotH = dot(V, H);
+    if (VDotH <= 0.0f) return 0.0f;
+    float D = ggxNDF(H, a);
+    float G1 = smithG1(V, H, a);
+    return D * G1 * VDotH / V.z;
+}
+static V3 sampleGGXSmithVNDF(V3 V, A2 a, float rx, float ry) {           // ggx_brdf.h:96-120
+    V3 Vh = normalized(V3(a.x * V.x, a.y * V.y, V.z));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    V3 T1 = lensq > 0.0f ? V3(-Vh.y, Vh.x, 0.0f) / std::sqrt(lensq) : V3(1.0f, 0.0f, 0.0f);
+    V3 T2 = normalized(cross(Vh, T1));
+    float r = std::sqrt(rx);
+    float phi = (float)(2.0f * M_PI * ry);
+    float t1 = r * std::cos(phi);
+    float t2 = r * std::sin(phi);
+    float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * std::sqrt(1.0f - t1 * t1) + s * t2;
+    V3 Nh = t1 * T1 + t2 * T2 + std::sqrt(std::max(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
+    return normalized(V3(a.x * Nh.x, a.y * Nh.y, std::max(1e-6f, Nh.z)));
+}
+static V3 evaluateGGXSmithBRDF(V3 V, V3 L, V3 f0, float roughness, float anisotropy) {   // ggx_brdf.h:151-170
+    if (V.z * L.z < 0.0f) return V3(0.0f);
+    A2 a = roughnessToAlpha(roughness, anisotropy);
+    V3 H = normalized(V + L);
+    float D = ggxNDF(H, a);
+    float G = smithG2(V, L, H, a);
+    V3 F = schlickFresnel(f0, dot(V, H));
+    float denom = 4.0f * std::fabs(V.z) * std::fabs(L.z);
+    return (D * G) * F / denom;
+}
+
+// ---------------------------------------------------------------------------------
+// BSDFs. BSDFQueryRecord: wi, wo local; measure; eta (bsdf.h:20-53).
+// ---------------------------------------------------------------------------------
+enum { EUnknownMeasure = 0, ESolidAngle = 1, EDiscrete = 2 };
+struct BRec { V3 wi, wo; float eta = 1.f; int measure = EUnknownMeasure; float accumulatedRoughness = 0.f; };
+
+static inline float lerpf(float t, float v1, float v2) { return (1.f - t) * v1 + t * v2; }   // common.h:255-257
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float schlickWeight(float x) {                               // bsdf.cpp:1175-1179
+    x = clampf(1.f - x, 0.f, 1.f);
+    float x2 = x * x;
+    return x2 * x2 * x;
+}
+static inline V3 lerp3(V3 c1, V3 c2, float t) { return (1.f - t) * c1 + t * c2; }   // bsdf.cpp:1181-1183
+static inline float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }   // common.cpp:393-395
+
+// a20 Diffuse (bsdf.cpp:27-75)
+static V3 diffuseEval(const KzBSDF &m, const BRec &b) {
+    if (b.measure != ESolidAngle || b.wi.z <= 0 || b.wo.z <= 0) return V3(0.f);
+    return V3(m.albedo[0], m.albedo[1], m.albedo[2]) * INV_PI * b.wo.z;
+}
+static float diffusePdf(const KzBSDF &, const BRec &b) {
+    if (b.measure != ESolidAngle || b.wi.z <= 0 || b.wo.z <= 0) return 0.f;
+    return INV_PI * b.wo.z;
+}
+static V3 diffuseSample(const KzBSDF &m, BRec &b, float, float s2x, float s2y, bool &ok) {
+    if (b.wi.z <= 0) { ok = false; return V3(0.f); }
+    ok = true;
+    b.measure = ESolidAngle;
+    b.wo = squareToCosineHemisphere(s2x, s2y);
+    b.eta = 1.0f;
+    return V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+}
+
+// a21 KazenStandardSurface (bsdf.cpp:1215-1267 eval, :1269-1299 pdf, :1301-1371 sample)
+static V3 kissEval(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z <= 0 || b.wo.z <= 0) return V3(0.f);
+    V3 V = b.wi, L = b.wo, H = normalized(V + L);
+    V3 Cdlin(m.baseColor[0], m.baseColor[1], m.baseColor[2]);
+    float metallic = m.metallic;
+    float roughness = std::min(1.f, m.roughness + b.accumulatedRoughness);
+    float Cdlum = luminance(Cdlin);
+    V3 Ctint = Cdlum > 0.f ? Cdlin / Cdlum : V3(1.f);
+    V3 Ctintmix = 0.08f * m.specular * lerp3(V3(1.f), Ctint, m.specularTint);
+    V3 Cspec0 = lerp3(Ctintmix, Cdlin, metallic);
+    float FL = schlickWeight(L.z), FV = schlickWeight(V.z), FH = schlickWeight(dot(L, H));
+    float cosThetaD = dot(V, H);
+    float Lambert = (1.f - 0.5f * FL) * (1.f - 0.5f * FV);
+    float RR = 2.f * roughness * cosThetaD * cosThetaD;
+    float retro = RR * (FL + FV + FL * FV * (RR - 1.f));
+    V3 Csheen = lerp3(V3(1.f), Ctint, m.sheenTint);
+    V3 Fsheen = FH * m.sheen * Csheen;
+    V3 specTerm = evaluateGGXSmithBRDF(V, L, Cspec0, roughness, m.anisotropy);
+    float ccR = lerpf(m.clearcoatRoughness, .01f, .3f);
+    V3 coatTerm = 0.25f * m.clearcoat * evaluateGGXSmithBRDF(V, L, V3(0.04f), ccR, m.anisotropy);
+    return ((1.f - metallic) * (Cdlin * INV_PI * (Lambert + retro) + Fsheen) + (specTerm + coatTerm)) * b.wo.z;
+}
+static float kissPdf(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z <= 0 || b.wo.z <= 0) return 0.f;
+    float diffuse = (1.f - m.metallic) * 0.5f;
+    float GTR2 = 1.f / (1.f + m.clearcoat);
+    V3 H = normalized(b.wi + b.wo);
+    float jacobian = 4.0f * dot(b.wi, H);
+    float roughness = std::min(1.f, m.roughness + b.accumulatedRoughness);
+    A2 alpha = roughnessToAlpha(roughness, m.anisotropy);
+    float specPdf = ggxSmithVNDF(b.wi, H, alpha) / jacobian;
+    A2 coatalpha = roughnessToAlpha(lerpf(m.clearcoatRoughness, .01f, .3f), 0.f);
+    float coatPdf = ggxSmithVNDF(b.wi, H, coatalpha) / jacobian;
+    return diffuse * INV_PI * b.wo.z + (1.f - diffuse) * (GTR2 * specPdf + (1.f - GTR2) * coatPdf);
+}
+static inline V3 reflect(V3 wi, V3 n) { return 2 * dot(n, wi) * n - wi; }    // common.cpp:536-538
+static V3 kissSample(const KzBSDF &m, BRec &b, float sample1, float s2x, float s2y, bool &ok) {
+    if (b.wi.z <= 0) { ok = false; return V3(0.f); }
+    ok = true;
+    b.measure = ESolidAngle; b.eta = 1.0f;
+    float diffuse = (1.f - m.metallic) * 0.5f;
+    if (sample1 < diffuse) {
+        b.wo = squareToCosineHemisphere(s2x, s2y);
+    } else {
+        float sample = (sample1 - diffuse) / (1.f - diffuse);
+        float GTR2 = 1.f / (1.f + m.clearcoat);
+        V3 H; bool flip = b.wi.z <= 0.f;
+        A2 alpha = (sample < GTR2) ? roughnessToAlpha(m.roughness, m.anisotropy)             // H7: no accumulatedRoughness
+                                   : roughnessToAlpha(lerpf(m.clearcoatRoughness, 0.01f, .3f), 0.f);
+        H = sampleGGXSmithVNDF(flip ? -b.wi : b.wi, alpha, s2x, s2y);
+        H = flip ? -H : H;
+        b.wo = normalized(reflect(b.wi, H));
+    }
+    bool invalid = std::isnan(b.wo.x) || std::isnan(b.wo.y) || std::isnan(b.wo.z);
+    float pdf = kissPdf(m, b);
+    if (b.wo.z <= 0 || pdf <= Epsilon || invalid) return V3(0.f);
+    return kissEval(m, b) / pdf;
+}
+
+static const KzBSDF &meshBsdf(const Scene &sc, int mesh) {
+    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f};
+    int b = sc.meshes[mesh].bsdf;
+    return b < 0 ? dflt : sc.bsdfs[b];
+}
+static V3 bsdfEval(const KzBSDF &m, const BRec &b) { return m.type == KZ_BSDF_DIFFUSE ? diffuseEval(m, b) : kissEval(m, b); }
+static float bsdfPdf(const KzBSDF &m, const BRec &b) { return m.type == KZ_BSDF_DIFFUSE ? diffusePdf(m, b) : kissPdf(m, b); }
+static V3 bsdfSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {
+    return m.type == KZ_BSDF_DIFFUSE ? diffuseSample(m, b, s1, s2x, s2y, ok) : kissSample(m, b, s1, s2x, s2y, ok);
+}
+static float bsdfRegularize(const KzBSDF &m) { return m.type == KZ_BSDF_KAZENSTANDARD ? m.roughness : 0.f; }   // bsdf.cpp:1397-1399, bsdf.h:125
+
+// ---------------------------------------------------------------------------------
+// a4/a5/a9 samplers (src/kazen/sampler.cpp). H1: GCC evaluates call arguments right to
+// left, so Independent::next2D draws y first, and bsdf->sample(bRec, next1D(), next2D())
+// draws the 2-D sample first. Written here as sequenced statements.
+// ---------------------------------------------------------------------------------
+struct Sampler {
+    const Scene *sc;
+    int type;
+    Pcg32 rng;
+    int32_t px = 0, py = 0; uint32_t sampleIndex = 0, dim = 0;
+    void generateSample(int32_t x, int32_t y, uint32_t idx) {
+        px = x; py = y; sampleIndex = idx;
+        if (type == KZ_SAMPLER_INDEPENDENT) {                            // sampler.cpp:43-46
+            rng.seed(HashPixelSeed(x, y, sc->smp.seed));
+            rng.advance((int64_t)(idx * 65536ull + 0));
+        } else {
+            dim = 2;                                                     // sampler.cpp:333-337 max(2, 0)
+        }
+    }
+    float bluenoise(uint32_t texIndex) const {                           // bluenoise.h:16-23
+        int t = (int)texIndex % KZ_BLUENOISE_TEXTURES;
+        int x = px % KZ_BLUENOISE_RES, y = py % KZ_BLUENOISE_RES;
+        return sc->bnTable[((size_t)t * KZ_BLUENOISE_RES + x) * KZ_BLUENOISE_RES + y] / 65535.f;
+    }
+    void pmjSample(int setIndex, int sampleIdx, float &x, float &y) const {   // pmj02table.h:17-30
+        setIndex %= KZ_PMJ02BN_SETS; sampleIdx %= KZ_PMJ02BN_SAMPLES;
+        const uint32_t *e = &sc->pmjTable[((size_t)setIndex * KZ_PMJ02BN_SAMPLES + sampleIdx) * 2];
+        x = (float)(e[0] * 0x1p-32); y = (float)(e[1] * 0x1p-32);
+    }
+    float next1D() {
+        if (type == KZ_SAMPLER_INDEPENDENT) return rng.nextFloat();      // sampler.cpp:48-50
+        uint64_t hash = HashPixelDimSeed(px, py, dim, sc->smp.seed);     // sampler.cpp:339-347
+        int index = (int)permute(sampleIndex, sc->sampleCount, (uint32_t)hash);
+        float delta = bluenoise(dim);
+        ++dim;
+        return std::min((index + delta) / sc->sampleCount, OneMinusEpsilon);
+    }
+    void next2D(float &x, float &y) {
+        if (type == KZ_SAMPLER_INDEPENDENT) {                            // sampler.cpp:52-57, H1
+            y = rng.nextFloat();
+            x = rng.nextFloat();
+            return;
+        }
+        int index = (int)sampleIndex;                                    // sampler.cpp:349-371
+        int pmjInstance = (int)(dim / 2);
+        if (pmjInstance >= KZ_PMJ02BN_SETS) {
+            uint64_t hash = HashPixelDimSeed(px, py, dim, sc->smp.seed);
+            index = (int)permute(sampleIndex, sc->sampleCount, (uint32_t)hash);
+        }
+        float ux, uy; pmjSample(pmjInstance, index, ux, uy);
+        ux += bluenoise(dim); uy += bluenoise(dim + 1);
+        if (ux >= 1) ux -= 1;
+        if (uy >= 1) uy -= 1;
+        dim += 2;
+        x = std::min(ux, OneMinusEpsilon); y = std::min(uy, OneMinusEpsilon);
+    }
+    void nextPixel2D(float &x, float &y) {
+        if (type == KZ_SAMPLER_INDEPENDENT) { next2D(x, y); return; }    // sampler.cpp:59-61
+        int tile = sc->pixelTileSize;                                    // sampler.cpp:373-377
+        int tx = px % tile, ty = py % tile;
+        size_t offset = (size_t)(tx + ty * tile) * sc->sampleCount + sampleIndex;
+        x = sc->pixelSamples[2 * offset]; y = sc->pixelSamples[2 * offset + 1];
+    }
+};
+
+// PMJ02BN ctor (sampler.cpp:275-315)
+static int preparePmj(Scene &sc) {
+    uint32_t spp = sc.smp.sampleCount;
+    if (spp > KZ_PMJ02BN_SAMPLES) spp = KZ_PMJ02BN_SAMPLES;              // sampler.cpp:284-287
+    sc.sampleCount = spp;
+    int tile = 1 << (log4i(KZ_PMJ02BN_SAMPLES) - log4i((uint32_t)roundUpPow4((int)spp)));
+    sc.pixelTileSize = tile;
+    size_t nPix = (size_t)tile * tile * spp;
+    sc.pixelSamples.assign(nPix * 2, 0.f);
+    std::vector<int> nStored((size_t)tile * tile, 0);
+    Sampler tmp; tmp.sc = &sc; tmp.type = KZ_SAMPLER_PMJ02BN;
+    for (int i = 0; i < KZ_PMJ02BN_SAMPLES; ++i) {
+        float x, y; tmp.pmjSample(0, i, x, y);
+        x *= tile; y *= tile;
+        int ix = (int)x, iy = (int)y;
+        if (ix >= tile || iy >= tile) return KZ_ERR_INVALID_ARG;        // table value rounds to 1.0f: the reference would index out of range
+        int pixelOffset = ix + iy * tile;
+        if (nStored[pixelOffset] == (int)spp) continue;
+        size_t so = (size_t)pixelOffset * spp + nStored[pixelOffset];
+        sc.pixelSamples[2 * so] = x - std::floor(x);
+        sc.pixelSamples[2 * so + 1] = y - std::floor(y);
+        ++nStored[pixelOffset];
+    }
+    return KZ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// a3 camera (src/kazen/camera.cpp:35-68, :70-91; transform.h:49-62)
+// ---------------------------------------------------------------------------------
+static void mat4mul(const double *a, const double *b, double *c) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        double s = 0; for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+        c[i * 4 + j] = s;
+    }
+}
+static bool mat4inv(const double *m, double *out) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = m[i * 4 + j]; a[i][j + 4] = (i == j); }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c; for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[piv][j]);
+        double inv = 1.0 / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) if (r != c) { double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = a[i][j + 4];
+    return true;
+}
+static int prepareCamera(Scene &sc) {
+    const KzCamera &c = sc.cam;
+    sc.invW = 1.0f / (float)c.width; sc.invH = 1.0f / (float)c.height;         // camera.cpp:20
+    if (c.sampleToCamera) { std::memcpy(sc.s2c, c.sampleToCamera, 64); return KZ_OK; }
+    float aspect = c.width / (float)c.height;
+    float recip = 1.0f / (c.farClip - c.nearClip);
+    float cot = 1.0f / std::tan((float)((c.fov / 2.0f) * (M_PI / 180.0f)));    // common.h:222 degToRad
+    // Eigen's Matrix4f::inverse() is not available here; the product and inverse are formed in
+    // double and narrowed once (differences to Eigen's float cofactor inverse are last-ulp).
+    double P[16] = {cot, 0, 0, 0, 0, cot, 0, 0, 0, 0, (double)(c.farClip * recip), (double)(-c.nearClip * c.farClip * recip), 0, 0, 1, 0};
+    double T[16] = {1, 0, 0, -1, 0, 1, 0, (double)(-1.0f / aspect), 0, 0, 1, 0, 0, 0, 0, 1};
+    double D[16] = {-0.5, 0, 0, 0, 0, (double)(-0.5f * aspect), 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double TP[16], M[16], Mi[16];
+    mat4mul(T, P, TP); mat4mul(D, TP, M);
+    if (!mat4inv(M, Mi)) return KZ_ERR_INVALID_ARG;
+    for (int i = 0; i < 16; ++i) sc.s2c[i] = (float)Mi[i];
+    return KZ_OK;
+}
+static void cameraSampleRay(const Scene &sc, float sx, float sy, Ray &ray) {
+    const float *m = sc.s2c;
+    float x = sx * sc.invW, y = sy * sc.invH;
+    float rx = m[0] * x + m[1] * y + m[2] * 0.0f + m[3];                         // transform.h:59-62
+    float ry = m[4] * x + m[5] * y + m[6] * 0.0f + m[7];
+    float rz = m[8] * x + m[9] * y + m[10] * 0.0f + m[11];
+    float rw = m[12] * x + m[13] * y + m[14] * 0.0f + m[15];
+    V3 nearP(rx / rw, ry / rw, rz / rw);
+    V3 d = normalized(nearP);
+    float invZ = 1.0f / d.z;
+    const float *w = sc.cam.toWorld;
+    float ow = w[15];
+    ray.o = V3(w[3] / ow, w[7] / ow, w[11] / ow);                                // toWorld * Point3f(0,0,0)
+    ray.d = V3(w[0] * d.x + w[1] * d.y + w[2] * d.z, w[4] * d.x + w[5] * d.y + w[6] * d.z,
+               w[8] * d.x + w[9] * d.y + w[10] * d.z);                           // transform.h:49-51
+    ray.mint = sc.cam.nearClip * invZ; ray.maxt = sc.cam.farClip * invZ;
+}
+
+// ---------------------------------------------------------------------------------
+// a26 filters (src/kazen/rfilter.cpp) + a25 table (block.cpp:13-21)
+// ---------------------------------------------------------------------------------
+static float filterEval(const KzFilter &f, float x) {
+    switch (f.type) {
+    case KZ_FILTER_GAUSSIAN: {
+        float alpha = -1.0f / (2.0f * f.stddev * f.stddev);
+        return std::max(0.0f, std::exp(alpha * x * x) - std::exp(alpha * f.radius * f.radius));
+    }
+    case KZ_FILTER_MITCHELL: {
+        float B = f.B, C = f.C;
+        x = std::fabs(2.0f * x / f.radius);
+        float x2 = x * x, x3 = x2 * x;
+        if (x < 1) return 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+        else if (x < 2) return 1.0f / 6.0f * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+        return 0.0f;
+    }
+    case KZ_FILTER_TENT: return std::max(0.0f, 1.0f - std::fabs(x));
+    default: return 1.0f;
+    }
+}
+static void prepareFilter(Scene &sc) {
+    const KzFilter &f = sc.cam.rfilter;
+    sc.filterRadius = f.radius;
+    sc.border = (int)std::ceil(f.radius - 0.5f);
+    for (int i = 0; i < KZ_FILTER_RESOLUTION; ++i) {
+        float pos = (f.radius * i) / KZ_FILTER_RESOLUTION;
+        sc.filter[i] = filterEval(f, pos);
+    }
+    sc.filter[KZ_FILTER_RESOLUTION] = 0.0f;
+    sc.lookupFactor = KZ_FILTER_RESOLUTION / f.radius;
+}
+
+// a25 ImageBlock::put (block.cpp:56-85) on a film with its border. `film` is
+// (h+2b) x (w+2b) float4 at offset (0,0); block-relative and image-relative positions
+// are the same exact floats (see DESIGN.md "film").
+struct Film { int w, h, b; std::vector<float> px; int cols() const { return w + 2 * b; } int rows() const { return h + 2 * b; } };
+static inline bool colorValid(V3 c) {                                            // common.cpp:384-391
+    for (int i = 0; i < 3; ++i) { float v = c[i]; if (v < 0 || !std::isfinite(v)) return false; }
+    return true;
+}
+static bool filmPut(const Scene &sc, float *film, int cols, int rows, int offx, int offy, float sx, float sy, V3 value) {
+    if (!colorValid(value)) return false;
+    float posx = sx - 0.5f - (float)(offx - sc.border);
+    float posy = sy - 0.5f - (float)(offy - sc.border);
+    int x0 = (int)std::ceil(posx - sc.filterRadius), y0 = (int)std::ceil(posy - sc.filterRadius);
+    int x1 = (int)std::floor(posx + sc.filterRadius), y1 = (int)std::floor(posy + sc.filterRadius);
+    x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, cols - 1); y1 = std::min(y1, rows - 1);
+    float wx[32], wy[32];
+    for (int x = x0, i = 0; x <= x1; ++x) wx[i++] = sc.filter[(int)(std::fabs(x - posx) * sc.lookupFactor)];
+    for (int y = y0, i = 0; y <= y1; ++y) wy[i++] = sc.filter[(int)(std::fabs(y - posy) * sc.lookupFactor)];
+    for (int y = y0, yr = 0; y <= y1; ++y, ++yr)
+        for (int x = x0, xr = 0; x <= x1; ++x, ++xr) {
+            float *p = film + ((size_t)y * cols + x) * 4;
+            // Color4f(value) * wx * wy : ((c * wx) * wy), block.cpp:84
+            p[0] += value.x * wx[xr] * wy[yr];
+            p[1] += value.y * wx[xr] * wy[yr];
+            p[2] += value.z * wx[xr] * wy[yr];
+            p[3] += 1.0f * wx[xr] * wy[yr];
+        }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------
+// a18/a19 lights (src/kazen/light.cpp, src/kazen/mesh.cpp:24-53,108-133, dpdf.h)
+// ---------------------------------------------------------------------------------
+static void prepareLightMesh(MeshData &md) {
+    md.cdf.clear(); md.cdf.push_back(0.0f);                                      // dpdf.h:23-27
+    for (uint32_t i = 0; i < md.nF; ++i) {
+        uint32_t i0 = md.F[3 * i], i1 = md.F[3 * i + 1], i2 = md.F[3 * i + 2];
+        V3 p0 = md.v(i0), p1 = md.v(i1), p2 = md.v(i2);
+        float area = 0.5f * norm(cross(p1 - p0, p2 - p0));                       // mesh.cpp:47-53
+        md.cdf.push_back(md.cdf.back() + area);                                  // dpdf.h:35-37
+    }
+    float sum = md.cdf.back();                                                   // dpdf.h:77-89
+    if (sum > 0) {
+        md.normalization = 1.0f / sum;
+        for (size_t i = 1; i < md.cdf.size(); ++i) md.cdf[i] *= md.normalization;
+        md.cdf.back() = 1.0f;
+    } else md.normalization = 0.f;
+}
+static size_t dpdfSample(const MeshData &md, float v) {                          // dpdf.h:99-104
+    auto entry = std::lower_bound(md.cdf.begin(), md.cdf.end(), v);
+    ptrdiff_t idx = std::max((ptrdiff_t)0, (ptrdiff_t)(entry - md.cdf.begin()) - 1);
+    return std::min((size_t)idx, md.cdf.size() - 2);
+}
+struct LRec { V3 ref, wi, p, n; Ray shadowRay; float pdf = 0; };
+static inline V3 lightRadiance(const KzLight &l) { return l.intensity * V3(l.color[0], l.color[1], l.color[2]); }   // light.cpp:13
+static V3 lightEval(const KzLight &l, const LRec &r) {                            // light.cpp:16-19
+    float cosTheta = dot(r.n, -r.wi);
+    return cosTheta > 0.f ? lightRadiance(l) : V3(0.f);
+}
+static float lightPdf(const MeshData &md, const LRec &r) {                        // light.cpp:36-51
+    float pdf = md.normalization;
+    float cosTheta = dot(r.n, -r.wi);
+    if (cosTheta > 0.f) {
+        V3 dd = r.p - r.ref;
+        return pdf * dot(dd, dd) / cosTheta;
+    }
+    return 0.f;
+}
+static V3 lightSample(const Scene &sc, const KzLight &l, const MeshData &md, LRec &r, Sampler &s, LocalStats &ls) {   // light.cpp:21-34
+    (void)sc;
+    ls.lightSamples++;
+    size_t index = dpdfSample(md, s.next1D());                                   // mesh.cpp:109
+    float su0 = std::sqrt(s.next1D());
+    float u = 1 - su0;
+    float v = s.next1D() * su0;
+    uint32_t i0 = md.F[3 * index], i1 = md.F[3 * index + 1], i2 = md.F[3 * index + 2];
+    V3 p0 = md.v(i0), p1 = md.v(i1), p2 = md.v(i2);
+    r.p = p0 + u * (p1 - p0) + v * (p2 - p0);
+    if (!md.N.empty()) {
+        V3 n0 = md.nrm(i0), n1 = md.nrm(i1), n2 = md.nrm(i2);
+        r.n = n0 + u * (n1 - n0) + v * (n2 - n0);                                // H8: NOT normalised (mesh.cpp:129)
+    } else r.n = normalized(cross(p1 - p0, p2 - p0));
+    r.wi = normalized(r.p - r.ref);
+    r.shadowRay = Ray(r.ref, r.wi, 0.f, norm(r.p - r.ref));
+    r.pdf = lightPdf(md, r);
+    if (r.pdf > 0.f && !std::isnan(r.pdf) && !std::isinf(r.pdf)) return lightEval(l, r) / r.pdf;
+    return V3(0.f);
+}
+
+static V3 backgroundColor(const Scene &sc, V3 dir) {                              // scene.cpp:54-79, texture.cpp:121-126
+    if (!sc.bg.present) return V3(0.f);
+    if (std::isnan(dir.x) || std::isnan(dir.y) || std::isnan(dir.z)) return V3(0.f);
+    return sc.bg.intensity * V3(sc.bg.color[0], sc.bg.color[1], sc.bg.color[2]);
+}
+
+static inline float powerHeuristic(float a, float b) {                            // integrator.cpp:340-344
+    a *= a; b *= b;
+    return a > 0.f ? a / (a + b) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------
+// a10  PathMisIntegrator::Li (src/kazen/integrator.cpp:195-338)
+// ---------------------------------------------------------------------------------
+static V3 Li(const Scene &sc, Sampler &sampler, const Ray &ray_, LocalStats &ls) {
+    const int maxDepth = std::min(512, sc.integ.maxDepth);
+    const float eps = sc.integ.traceBias;
+    Ray ray = ray_;
+    V3 L(0.f), throughput(1.f);
+    float eta = 1.f, bsdfWeight = 1.f;
+    Intersection its;
+    if (!rayIntersect(sc, ray, its, false, ls)) return L;                          // H5
+    if (sc.meshes[its.mesh].light >= 0 && !sc.lights[sc.meshes[its.mesh].light].primaryVisibility) {
+        Ray newRay(its.p + eps * ray.d, ray.d);                                    // H6: result ignored on a miss
+        rayIntersect(sc, newRay, its, false, ls);
+    }
+    int depth = 0;
+    while (depth < maxDepth) {
+        const MeshData &hitMesh = sc.meshes[its.mesh];
+        if (hitMesh.light >= 0) {                                                  // integrator.cpp:226-231
+            LRec lr; lr.ref = ray.o; lr.p = its.p; lr.n = its.shFrame.n; lr.wi = normalized(its.p - ray.o);
+            L = L + bsdfWeight * throughput * lightEval(sc.lights[hitMesh.light], lr);
+            break;
+        }
+        if (depth >= 3) {                                                          // integrator.cpp:237-244
+            float probability = std::min(maxCoeff(throughput) * eta * eta, 0.95f);
+            if (probability <= sampler.next1D()) break;
+            throughput = throughput / probability;
+        }
+        const KzBSDF &bsdf = meshBsdf(sc, its.mesh);
+        // ---- light sampling (integrator.cpp:247-295); the pick is drawn even with no lights (scene.h:45-53)
+        float pick = sampler.next1D();
+        size_t nl = sc.lightMeshes.size();
+        if (nl > 0) {
+            size_t li = std::min((size_t)std::floor(nl * pick), nl - 1);
+            const MeshData &lm = sc.meshes[sc.lightMeshes[li]];
+            const KzLight &light = sc.lights[lm.light];
+            LRec lr; lr.ref = its.p;
+            float lightPickPdf = 1.f / nl;                                         // scene.h:56
+            V3 Ls = lightSample(sc, light, lm, lr, sampler, ls) / lightPickPdf;
+            float lpdf = lightPdf(lm, lr);
+            lr.shadowRay.mint = eps; lr.shadowRay.maxt -= eps;
+            bool occluded = false;
+            Ray tempRay = lr.shadowRay;
+            for (;;) {                                                             // integrator.cpp:262-278
+                Intersection sh;
+                if (rayIntersect(sc, tempRay, sh, true, ls)) {
+                    const MeshData &om = sc.meshes[sh.mesh];
+                    if (om.light < 0) { occluded = true; break; }
+                    if (sc.lights[om.light].primaryVisibility) { occluded = true; break; }
+                    tempRay = Ray(tempRay.o + tempRay.d * (sh.t + eps), tempRay.d, eps, tempRay.maxt - sh.t);
+                } else break;
+            }
+            if (!occluded) {
+                BRec b; b.wi = its.shFrame.toLocal(-ray.d); b.wo = its.shFrame.toLocal(lr.wi); b.measure = ESolidAngle;
+                b.accumulatedRoughness = its.accumulatedRoughness;
+                V3 f = bsdfEval(bsdf, b);
+                float bpdf = bsdfPdf(bsdf, b);
+                float lightWeight = powerHeuristic(lpdf, bpdf);
+                L = L + throughput * Ls * f * lightWeight;
+            }
+        }
+        if (sc.integ.regularization)                                               // integrator.cpp:298-301
+            its.accumulatedRoughness += bsdfRegularize(bsdf) * sc.integ.accumulatedRoughness;
+        // ---- BSDF sampling (integrator.cpp:304-309). H1: next2D is drawn before next1D.
+        BRec b; b.wi = its.shFrame.toLocal(-ray.d); b.accumulatedRoughness = its.accumulatedRoughness;
+        float s2x, s2y; sampler.next2D(s2x, s2y);
+        float s1 = sampler.next1D();
+        bool ok;
+        V3 bsdfColor = bsdfSample(bsdf, b, s1, s2x, s2y, ok);
+        throughput = throughput * bsdfColor;
+        eta *= b.eta;
+        // A zero weight kills the path: the reference keeps iterating with throughput 0 (and, when
+        // sample() bailed out early, an uninitialised bRec.wo), which contributes exactly 0 and stops
+        // at the next roulette. Terminating here is the defined equivalent.
+        if (!ok || (bsdfColor.x == 0.f && bsdfColor.y == 0.f && bsdfColor.z == 0.f)) break;
+        ray = Ray(its.p, its.shFrame.toWorld(b.wo));                                // H9: not re-normalised
+        ray.mint = eps;
+        float bpdf = bsdfPdf(bsdf, b);
+        if (!rayIntersect(sc, ray, its, false, ls)) {
+            L = L + throughput * backgroundColor(sc, ray.d);
+            break;
+        }
+        const MeshData &nm = sc.meshes[its.mesh];
+        if (nm.light >= 0) {                                                       // integrator.cpp:322-327
+            LRec lr; lr.ref = ray.o; lr.p = its.p; lr.n = its.shFrame.n; lr.wi = normalized(its.p - ray.o);
+            float lpdf = lightPdf(nm, lr);
+            bsdfWeight = powerHeuristic(bpdf, lpdf);
+        }
+        if (b.measure == EDiscrete) bsdfWeight = 1.f;
+        depth++;
+    }
+    return L;
+}
+
+// a2 renderSample (renderer.cpp:20-40) -> (pixelSample, value)
+static V3 renderSample(const Scene &sc, Sampler &sampler, int px, int py, uint32_t j, float &sx, float &sy, LocalStats &ls) {
+    sampler.generateSample(px, py, j);
+    float jx, jy; sampler.nextPixel2D(jx, jy);
+    sx = (float)px + jx; sy = (float)py + jy;
+    float ax, ay; sampler.next2D(ax, ay);      // aperture sample: always drawn (renderer.cpp:28)
+    Ray ray; cameraSampleRay(sc, sx, sy, ray);
+    ls.samples++;
+    return Li(sc, sampler, ray, ls);           // camera weight is Color3f(1) (camera.cpp:90)
+}
+
+static void mergeStats(Scene &sc, const LocalStats &ls) {
+    sc.stats.samples += ls.samples; sc.stats.rays += ls.rays; sc.stats.nodeVisits += ls.nodeVisits;
+    sc.stats.triTests += ls.triTests; sc.stats.shadedHits += ls.shadedHits; sc.stats.lightSamples += ls.lightSamples;
+    sc.stats.dropped += ls.dropped;
+}
+
+} // namespace kzo
+
+// =====================================================================================
+// C entry points (prefix kzo_). Loaded with ctypes by tests/ and bench.py only.
+// =====================================================================================
+using namespace kzo;
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char *msg) { std::snprintf(g_err, sizeof g_err, "%s", msg); return code; }
+
+extern "C" {
+
+const char *kzo_last_error() { return g_err; }
+
+int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) {
+    if (!d || !out) return fail(KZ_ERR_INVALID_ARG, "null argument");
+    if (d->abiVersion != KZ_ABI_VERSION) return fail(KZ_ERR_INVALID_ARG, "abi version mismatch");
+    if (d->camera.type != KZ_CAMERA_PERSPECTIVE) return fail(KZ_ERR_UNSUPPORTED, "camera type");
+    if (d->integrator.type != KZ_INTEGRATOR_PATH_MIS) return fail(KZ_ERR_UNSUPPORTED, "integrator type");
+    if (d->sampler.type != KZ_SAMPLER_INDEPENDENT && d->sampler.type != KZ_SAMPLER_PMJ02BN) return fail(KZ_ERR_UNSUPPORTED, "sampler type");
+    Scene *sc = new Scene();
+    sc->cam = d->camera; sc->smp = d->sampler; sc->integ = d->integrator; sc->bg = d->background;
+    sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->nBsdfs);
+    sc->lights.assign(d->lights, d->lights + d->nLights);
+    for (auto &b : sc->bsdfs) if (b.type != KZ_BSDF_DIFFUSE && b.type != KZ_BSDF_KAZENSTANDARD) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "bsdf type"); }
+    sc->meshes.resize(d->nMeshes);
+    for (uint32_t m = 0; m < d->nMeshes; ++m) {
+        const KzMesh &km = d->meshes[m]; MeshData &md = sc->meshes[m];
+        if (!km.V || !km.F) { delete sc; return fail(KZ_ERR_INVALID_ARG, "mesh without V/F"); }
+        md.nV = km.nV; md.nF = km.nF; md.bsdf = km.bsdf; md.light = km.light;
+        if (km.bsdf >= (int)d->nBsdfs || km.light >= (int)d->nLights) { delete sc; return fail(KZ_ERR_INVALID_ARG, "bsdf/light index"); }
+        md.V.assign(km.V, km.V + 3 * (size_t)km.nV);
+        if (km.N) md.N.assign(km.N, km.N + 3 * (size_t)km.nV);
+        if (km.UV) md.UV.assign(km.UV, km.UV + 2 * (size_t)km.nV);
+        md.F.assign(km.F, km.F + 3 * (size_t)km.nF);
+        for (uint32_t i = 0; i < 3 * km.nF; ++i) if (md.F[i] >= km.nV) { delete sc; return fail(KZ_ERR_INVALID_ARG, "face index out of range"); }
+        if (md.light >= 0) { prepareLightMesh(md); sc->lightMeshes.push_back((int)m); }
+    }
+    sc->sampleCount = d->sampler.sampleCount;
+    if (d->sampler.type == KZ_SAMPLER_PMJ02BN) {
+        if (!d->sampler.pmj02bnSamples || !d->sampler.blueNoise) { delete sc; return fail(KZ_ERR_INVALID_ARG, "pmj02bn tables missing"); }
+        sc->pmjTable.assign(d->sampler.pmj02bnSamples, d->sampler.pmj02bnSamples + (size_t)KZ_PMJ02BN_SETS * KZ_PMJ02BN_SAMPLES * 2);
+        sc->bnTable.assign(d->sampler.blueNoise, d->sampler.blueNoise + (size_t)KZ_BLUENOISE_TEXTURES * KZ_BLUENOISE_RES * KZ_BLUENOISE_RES);
+        int rc = preparePmj(*sc);
+        if (rc) { delete sc; return fail(rc, "pmj02bn table value rounds to 1.0f"); }
+    }
+    sc->smp.pmj02bnSamples = nullptr; sc->smp.blueNoise = nullptr; sc->cam.sampleToCamera = d->camera.sampleToCamera;
+    int rc = prepareCamera(*sc);
+    sc->cam.sampleToCamera = nullptr;
+    if (rc) { delete sc; return fail(rc, "singular camera matrix"); }
+    prepareFilter(*sc);
+    sc->useBrute = useBrute != 0;
+    Builder b(*sc); b.run();
+    *out = sc;
+    return KZ_OK;
+}
+void kzo_scene_destroy(void *s) { delete (Scene *)s; }
+void kzo_set_brute(void *s, int brute) { ((Scene *)s)->useBrute = brute != 0; }
+
+int kzo_film_dims(void *s, int *w, int *h, int *b) { Scene *sc = (Scene *)s; *w = sc->cam.width; *h = sc->cam.height; *b = sc->border; return 0; }
+
+int kzo_bvh_info(void *s, KzBvhInfo *o) {
+    Scene *sc = (Scene *)s; std::memset(o, 0, sizeof *o);
+    o->nNodes = (uint32_t)sc->nodes.size(); o->nTris = (uint32_t)sc->tris.size(); o->maxDepth = sc->maxDepth;
+    return 0;
+}
+
+// Render sample indices [s0,s1) of the tiles (or the whole image) into `film`
+// ((h+2b) x (w+2b) float4, ADDED to its contents). Decomposition follows
+// renderer.cpp:94-127: 32x32 blocks, one local ImageBlock each, rendered by `threads`
+// std::threads; blocks are merged in row-major block order (H10: the reference's merge
+// order is nondeterministic).
+int kzo_render(void *s, uint32_t s0, uint32_t s1, const KzTile *tiles, uint32_t nTiles, int threads, float *film) {
+    Scene *scp = (Scene *)s; if (!scp || !film) return fail(KZ_ERR_INVALID_ARG, "null");
+    Scene &sc = *scp;
+    if (s0 == 0 && s1 == 0) s1 = sc.sampleCount;
+    const int W = sc.cam.width, H = sc.cam.height, B = sc.border;
+    const int cols = W + 2 * B, rows = H + 2 * B;
+    struct Blk { int x0, y0, w, h; };
+    std::vector<Blk> blocks;
+    KzTile whole = {0, 0, W, H};
+    if (!tiles) { tiles = &whole; nTiles = 1; }
+    const int BS = 32;
+    for (uint32_t t = 0; t < nTiles; ++t) {
+        KzTile tl = tiles[t];
+        if (tl.x0 < 0 || tl.y0 < 0 || tl.x0 + tl.w > W || tl.y0 + tl.h > H) return fail(KZ_ERR_INVALID_ARG, "tile out of image");
+        for (int by = tl.y0; by < tl.y0 + tl.h; by += BS)
+            for (int bx = tl.x0; bx < tl.x0 + tl.w; bx += BS)
+                blocks.push_back(Blk{bx, by, std::min(BS, tl.x0 + tl.w - bx), std::min(BS, tl.y0 + tl.h - by)});
+    }
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    threads = std::max(1, std::min(threads, (int)blocks.size()));
+    const int bc = BS + 2 * B;
+    std::vector<std::vector<float>> local(blocks.size());
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);          // main.cpp:22-23 (H11)
+        _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+        Sampler sampler; sampler.sc = &sc; sampler.type = sc.smp.type;
+        LocalStats ls;
+        for (;;) {
+            size_t bi = next.fetch_add(1);
+            if (bi >= blocks.size()) break;
+            const Blk &bk = blocks[bi];
+            std::vector<float> &lf = local[bi];
+            lf.assign((size_t)bc * bc * 4, 0.f);
+            uint32_t pixelCount = (uint32_t)(bk.w * bk.h);
+            for (uint32_t i = 0; i < pixelCount; ++i) {                        // renderer.cpp:52-68
+                int px = (int)(i % bk.w) + bk.x0, py = (int)(i / bk.w) + bk.y0;
+                for (uint32_t j = s0; j < s1; ++j) {
+                    float sx, sy;
+                    V3 value = renderSample(sc, sampler, px, py, j, sx, sy, ls);
+                    if (!filmPut(sc, lf.data(), bc, bc, bk.x0, bk.y0, sx, sy, value)) ls.dropped++;
+                }
+            }
+        }
+        mergeStats(sc, ls);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {                             // ImageBlock::put(ImageBlock&), block.cpp:87-96
+        const Blk &bk = blocks[bi];
+        int sw = bk.w + 2 * B, sh = bk.h + 2 * B;
+        for (int y = 0; y < sh; ++y)
+            for (int x = 0; x < sw; ++x) {
+                const float *src = &local[bi][((size_t)y * bc + x) * 4];
+                float *dst = &film[((size_t)(bk.y0 + y) * cols + (bk.x0 + x)) * 4];
+                dst[0] += src[0]; dst[1] += src[1]; dst[2] += src[2]; dst[3] += src[3];
+            }
+        (void)rows;
+    }
+    return KZ_OK;
+}
+
+// ImageBlock::toBitmap (block.cpp:39-45) + Color4f::divideByFilterWeight (color.h:94-99)
+int kzo_film_to_rgb(const float *film, int w, int h, int b, float *rgb) {
+    int cols = w + 2 * b;
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        const float *p = &film[((size_t)(y + b) * cols + (x + b)) * 4];
+        float *o = &rgb[((size_t)y * w + x) * 3];
+        if (p[3] != 0) { o[0] = p[0] / p[3]; o[1] = p[1] / p[3]; o[2] = p[2] / p[3]; }
+        else { o[0] = o[1] = o[2] = 0.f; }
+    }
+    return 0;
+}
+
+int kzo_get_stats(void *s, KzStats *o, int reset) {
+    Scene *sc = (Scene *)s;
+    o->samples = sc->stats.samples; o->rays = sc->stats.rays; o->nodeVisits = sc->stats.nodeVisits; o->triTests = sc->stats.triTests;
+    o->shadedHits = sc->stats.shadedHits; o->lightSamples = sc->stats.lightSamples; o->droppedSamples = sc->stats.dropped;
+    if (reset) { sc->stats.samples = 0; sc->stats.rays = 0; sc->stats.nodeVisits = 0; sc->stats.triTests = 0; sc->stats.shadedHits = 0; sc->stats.lightSamples = 0; sc->stats.dropped = 0; }
+    return 0;
+}
+
+// Accel::rayIntersect(ray, its, false) for n rays.
+int kzo_trace_rays(void *s, uint32_t n, const float *o, const float *d, const float *tmin, const float *tmax, KzHit *hits) {
+    Scene &sc = *(Scene *)s; LocalStats ls;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin[i], tmax[i]);
+        Intersection its; KzHit &h = hits[i]; std::memset(&h, 0, sizeof h);
+        if (!rayIntersect(sc, r, its, false, ls)) { h.t = kInf; h.mesh = -1; h.prim = -1; continue; }
+        h.t = its.t; h.u = its.bu; h.v = its.bv; h.mesh = its.mesh; h.prim = its.prim;
+        h.p[0] = its.p.x; h.p[1] = its.p.y; h.p[2] = its.p.z; h.uv[0] = its.uvx; h.uv[1] = its.uvy;
+        h.sh_s[0] = its.shFrame.s.x; h.sh_s[1] = its.shFrame.s.y; h.sh_s[2] = its.shFrame.s.z;
+        h.sh_t[0] = its.shFrame.t.x; h.sh_t[1] = its.shFrame.t.y; h.sh_t[2] = its.shFrame.t.z;
+        h.sh_n[0] = its.shFrame.n.x; h.sh_n[1] = its.shFrame.n.y; h.sh_n[2] = its.shFrame.n.z;
+        h.geo_n[0] = its.geoFrame.n.x; h.geo_n[1] = its.geoFrame.n.y; h.geo_n[2] = its.geoFrame.n.z;
+    }
+    mergeStats(sc, ls);
+    return 0;
+}
+
+// ---- function-level known-answer entry points ------------------------------------
+uint64_t kzo_hash_pixel_seed(int32_t x, int32_t y, uint64_t seed) { return HashPixelSeed(x, y, seed); }
+uint64_t kzo_hash_pixel_dim_seed(int32_t x, int32_t y, uint32_t dim, uint64_t seed) { return HashPixelDimSeed(x, y, dim, seed); }
+uint64_t kzo_murmur64a(const unsigned char *key, size_t len, uint64_t seed) { return MurmurHash64A(key, len, seed); }
+uint64_t kzo_mixbits(uint64_t v) { return MixBits(v); }
+uint32_t kzo_permute(uint32_t i, uint32_t l, uint32_t p) { return permute(i, l, p); }
+uint64_t kzo_tea32(uint32_t v0, uint32_t v1, int rounds) { return sampleTEA32(v0, v1, rounds); }
+// pcg32: seed(initseq) [1-arg form], advance(delta), then n draws -> uints and floats
+void kzo_pcg32_stream(uint64_t initseq, int64_t delta, int n, uint32_t *u, float *f, uint64_t *stateOut) {
+    Pcg32 a; a.seed(initseq); a.advance(delta);
+    Pcg32 b = a;
+    for (int i = 0; i < n; ++i) { u[i] = a.nextUInt(); f[i] = b.nextFloat(); }
+    if (stateOut) { stateOut[0] = a.state; stateOut[1] = a.inc; }
+}
+void kzo_pcg32_seed2(uint64_t initstate, uint64_t initseq, int n, uint32_t *u) {
+    Pcg32 a; a.seed(initstate, initseq);
+    for (int i = 0; i < n; ++i) u[i] = a.nextUInt();
+}
+// sampler stream of one (pixel, sample): nextPixel2D, next2D, then n1 x next1D
+void kzo_sampler_stream(void *s, int32_t px, int32_t py, uint32_t idx, int n1, float *out) {
+    Scene &sc = *(Scene *)s; Sampler sm; sm.sc = &sc; sm.type = sc.smp.type;
+    sm.generateSample(px, py, idx);
+    sm.nextPixel2D(out[0], out[1]); sm.next2D(out[2], out[3]);
+    for (int i = 0; i < n1; ++i) out[4 + i] = sm.next1D();
+}
+void kzo_camera_ray(void *s, float sx, float sy, float *o6, float *mint, float *maxt) {
+    Scene &sc = *(Scene *)s; Ray r; cameraSampleRay(sc, sx, sy, r);
+    o6[0] = r.o.x; o6[1] = r.o.y; o6[2] = r.o.z; o6[3] = r.d.x; o6[4] = r.d.y; o6[5] = r.d.z; *mint = r.mint; *maxt = r.maxt;
+}
+void kzo_filter_table(void *s, float *tab33, float *radius, int *border) {
+    Scene &sc = *(Scene *)s; std::memcpy(tab33, sc.filter, sizeof sc.filter); *radius = sc.filterRadius; *border = sc.border;
+}
+void kzo_cosine_hemisphere(float sx, float sy, float *o3) { V3 v = squareToCosineHemisphere(sx, sy); o3[0] = v.x; o3[1] = v.y; o3[2] = v.z; }
+void kzo_uniform_disk(float sx, float sy, float *o2) { squareToUniformDisk(sx, sy, o2[0], o2[1]); }
+void kzo_frame(const float *n, float *s3, float *t3) { Frame f(V3(n[0], n[1], n[2])); s3[0] = f.s.x; s3[1] = f.s.y; s3[2] = f.s.z; t3[0] = f.t.x; t3[1] = f.t.y; t3[2] = f.t.z; }
+// BSDF: which = 0 eval (3 floats), 1 pdf (1 float), 2 sample (weight 3 + wo 3 + ok 1)
+void kzo_bsdf(const KzBSDF *m, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float *out) {
+    BRec b; b.wi = V3(wi[0], wi[1], wi[2]); b.accumulatedRoughness = accRough;
+    if (which == 2) {
+        bool ok; V3 w = bsdfSample(*m, b, s1, s2x, s2y, ok);
+        out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = b.wo.x; out[4] = b.wo.y; out[5] = b.wo.z; out[6] = ok ? 1.f : 0.f;
+        return;
+    }
+    b.wo = V3(wo[0], wo[1], wo[2]); b.measure = ESolidAngle;
+    if (which == 0) { V3 f = bsdfEval(*m, b); out[0] = f.x; out[1] = f.y; out[2] = f.z; }
+    else out[0] = bsdfPdf(*m, b);
+}
+void kzo_ggx_sample_vndf(const float *V, float ax, float ay, float rx, float ry, float *H) {
+    V3 h = sampleGGXSmithVNDF(V3(V[0], V[1], V[2]), A2{ax, ay}, rx, ry); H[0] = h.x; H[1] = h.y; H[2] = h.z;
+}
+// light: sample the light mesh `lightIdx` (index into Scene::m_lights order) from `ref` with the
+// three Mesh::sample draws given explicitly: out = p(3) n(3) wi(3) pdf(1) Ls(3) (Ls = eval/pdf)
+void kzo_light_sample(void *s, int lightIdx, const float *ref, float u0, float u1, float u2, float *out) {
+    Scene &sc = *(Scene *)s; const MeshData &md = sc.meshes[sc.lightMeshes[lightIdx]]; const KzLight &l = sc.lights[md.light];
+    LRec r; r.ref = V3(ref[0], ref[1], ref[2]);
+    size_t index = dpdfSample(md, u0);
+    float su0 = std::sqrt(u1); float u = 1 - su0; float v = u2 * su0;
+    uint32_t i0 = md.F[3 * index], i1 = md.F[3 * index + 1], i2 = md.F[3 * index + 2];
+    V3 p0 = md.v(i0), p1 = md.v(i1), p2 = md.v(i2);
+    r.p = p0 + u * (p1 - p0) + v * (p2 - p0);
+    if (!md.N.empty()) { V3 n0 = md.nrm(i0), n1 = md.nrm(i1), n2 = md.nrm(i2); r.n = n0 + u * (n1 - n0) + v * (n2 - n0); }
+    else r.n = normalized(cross(p1 - p0, p2 - p0));
+    r.wi = normalized(r.p - r.ref);
+    r.pdf = lightPdf(md, r);
+    V3 Ls = (r.pdf > 0.f && !std::isnan(r.pdf) && !std::isinf(r.pdf)) ? lightEval(l, r) / r.pdf : V3(0.f);
+    out[0] = r.p.x; out[1] = r.p.y; out[2] = r.p.z; out[3] = r.n.x; out[4] = r.n.y; out[5] = r.n.z;
+    out[6] = r.wi.x; out[7] = r.wi.y; out[8] = r.wi.z; out[9] = r.pdf; out[10] = Ls.x; out[11] = Ls.y; out[12] = Ls.z;
+    out[13] = (float)index;
+}
+// Radiance of single samples (no film): out = n x (sx, sy, r, g, b)
+void kzo_render_samples(void *s, uint32_t n, const int32_t *pxy, const uint32_t *idx, float *out) {
+    Scene &sc = *(Scene *)s; Sampler sm; sm.sc = &sc; sm.type = sc.smp.type; LocalStats ls;
+    _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+    for (uint32_t i = 0; i < n; ++i) {
+        float sx, sy; V3 v = renderSample(sc, sm, pxy[2 * i], pxy[2 * i + 1], idx[i], sx, sy, ls);
+        out[5 * i] = sx; out[5 * i + 1] = sy; out[5 * i + 2] = v.x; out[5 * i + 3] = v.y; out[5 * i + 4] = v.z;
+    }
+    mergeStats(sc, ls);
+}
+
+} // extern "C"
