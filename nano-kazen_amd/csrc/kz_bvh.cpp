@@ -1,0 +1,203 @@
+// kz_bvh.cpp — host BVH builder of the MI355X core (replaces Embree's build behind Accel::build,
+// src/kazen/accel.cpp:25-61; Embree 3.13.0 itself is not vendored in the reference).
+//
+// Binned-SAH BVH2 (32 bins), <= KZ_MAX_LEAF triangles per leaf, built top-down with std::async tasks
+// on the upper levels, then flattened breadth-first into 64-B node packets that carry BOTH children's
+// boxes (one packet fetch per traversal step) and 48-B Moeller-Trumbore leaf triangles (p0, e1, e2:
+// the same float differences Mesh::rayIntersect forms per call, src/kazen/mesh.cpp:60).
+// The tree depth is capped at KZ_STACK_DEPTH-2 (median splits take over when the SAH tree gets too
+// deep) because the traversal kernels keep a fixed per-lane stack in LDS.
+#include "kz_internal.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <limits>
+
+namespace {
+
+const float kInf = std::numeric_limits<float>::infinity();
+const int NBINS = 32;
+const int DEPTH_CAP = KZ_STACK_DEPTH - 2;
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = kInf; hi[a] = -kInf; } }
+    void grow(const Box &b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    void grow(const float p[3]) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0) || !(dy >= 0) || !(dz >= 0)) return 0.f;
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+struct Ref { Box b; float c[3]; uint32_t tri; };
+struct Tmp { Box b; uint32_t left, right; uint32_t start, count; uint32_t depth; };   // count>0: leaf
+
+struct Ctx {
+    std::vector<Ref> refs;
+    std::vector<Tmp> tmp;
+    std::atomic<uint32_t> nTmp{0};
+    std::atomic<uint32_t> maxDepth{0};
+    uint32_t alloc() { return nTmp.fetch_add(1); }
+};
+
+static int ceilLog2(uint32_t n) { int l = 0; while ((1u << l) < n) ++l; return l; }
+
+static void build(Ctx &cx, uint32_t node, uint32_t b, uint32_t e, uint32_t depth) {
+    Tmp &t = cx.tmp[node];
+    t.depth = depth;
+    t.b.reset();
+    Box cb; cb.reset();
+    for (uint32_t i = b; i < e; ++i) { t.b.grow(cx.refs[i].b); cb.grow(cx.refs[i].c); }
+    uint32_t n = e - b;
+    if (n <= KZ_MAX_LEAF) {
+        t.start = b; t.count = n; t.left = t.right = 0;
+        uint32_t md = cx.maxDepth.load();
+        while (depth > md && !cx.maxDepth.compare_exchange_weak(md, depth)) {}
+        return;
+    }
+    t.count = 0;
+    uint32_t mid = b;
+    bool forceMedian = (int)depth + ceilLog2(n) >= DEPTH_CAP;
+    int bestAxis = -1, bestSplit = 0;
+    if (!forceMedian) {
+        float bestCost = kInf;
+        for (int a = 0; a < 3; ++a) {
+            float ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0.f)) continue;
+            Box bb[NBINS]; uint32_t cnt[NBINS];
+            for (int k = 0; k < NBINS; ++k) { bb[k].reset(); cnt[k] = 0; }
+            float scale = NBINS / ext;
+            for (uint32_t i = b; i < e; ++i) {
+                int k = std::min(NBINS - 1, (int)((cx.refs[i].c[a] - cb.lo[a]) * scale));
+                cnt[k]++; bb[k].grow(cx.refs[i].b);
+            }
+            float rA[NBINS]; uint32_t rC[NBINS];
+            Box acc; acc.reset(); uint32_t c = 0;
+            for (int k = NBINS - 1; k > 0; --k) { acc.grow(bb[k]); c += cnt[k]; rA[k] = acc.area(); rC[k] = c; }
+            acc.reset(); c = 0;
+            for (int k = 0; k < NBINS - 1; ++k) {
+                acc.grow(bb[k]); c += cnt[k];
+                if (c == 0 || rC[k + 1] == 0) continue;
+                float cost = acc.area() * c + rA[k + 1] * rC[k + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = k; }
+            }
+        }
+        if (bestAxis >= 0) {
+            int a = bestAxis; float lo = cb.lo[a], scale = NBINS / (cb.hi[a] - cb.lo[a]);
+            auto it = std::partition(cx.refs.begin() + b, cx.refs.begin() + e, [&](const Ref &r) {
+                return std::min(NBINS - 1, (int)((r.c[a] - lo) * scale)) <= bestSplit;
+            });
+            mid = (uint32_t)(it - cx.refs.begin());
+        }
+    }
+    if (mid == b || mid == e) {
+        // median object split along the widest centroid axis (also the depth-cap fallback)
+        int a = 0; float best = -1.f;
+        for (int k = 0; k < 3; ++k) { float ext = cb.hi[k] - cb.lo[k]; if (ext > best) { best = ext; a = k; } }
+        mid = b + n / 2;
+        std::nth_element(cx.refs.begin() + b, cx.refs.begin() + mid, cx.refs.begin() + e,
+                         [a](const Ref &x, const Ref &y) { return x.c[a] < y.c[a]; });
+    }
+    uint32_t l = cx.alloc(), r = cx.alloc();
+    cx.tmp[node].left = l; cx.tmp[node].right = r;
+    if (n > 32768 && depth < 8) {
+        auto fut = std::async(std::launch::async, [&cx, l, b, mid, depth]() { build(cx, l, b, mid, depth + 1); });
+        build(cx, r, mid, e, depth + 1);
+        fut.get();
+    } else {
+        build(cx, l, b, mid, depth + 1);
+        build(cx, r, mid, e, depth + 1);
+    }
+}
+
+// A few ulps of slack: the slab test rounds differently from the triangle test, and the parity target is
+// "never cull a triangle the brute-force Moeller-Trumbore search would report".
+static void padBox(Box &b) {
+    for (int a = 0; a < 3; ++a) {
+        float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+        float e = m * 4e-7f + 1e-30f;
+        b.lo[a] -= e; b.hi[a] += e;
+    }
+}
+
+} // namespace
+
+int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, std::vector<KzTri> &tris,
+                 uint32_t &rootRef, KzBvhInfo &info, std::string &err) {
+    auto t0 = std::chrono::steady_clock::now();
+    std::memset(&info, 0, sizeof info);
+    nodes.clear(); tris.clear();
+    rootRef = 0xFFFFFFFFu;     // empty scene
+    Ctx cx;
+    cx.refs.reserve(in.size());
+    for (uint32_t i = 0; i < in.size(); ++i) {
+        const KzBuildTri &t = in[i];
+        bool finite = true;
+        for (int v = 0; v < 3; ++v) for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(t.v[v][a]);
+        if (!finite) continue;      // never hit (Embree also drops non-finite primitives)
+        Ref r; r.b.reset(); r.tri = i;
+        for (int v = 0; v < 3; ++v) r.b.grow(t.v[v]);
+        for (int a = 0; a < 3; ++a) r.c[a] = 0.5f * (r.b.lo[a] + r.b.hi[a]);
+        cx.refs.push_back(r);
+    }
+    uint32_t n = (uint32_t)cx.refs.size();
+    if (n >= (1u << 28)) { err = "more than 2^28 triangles"; return KZ_ERR_UNSUPPORTED; }
+    info.nTris = n;
+    if (n == 0) return KZ_OK;
+    cx.tmp.resize(2 * (size_t)n + 2);
+    uint32_t root = cx.alloc();
+    build(cx, root, 0, n, 0);
+    if (cx.maxDepth.load() > KZ_STACK_DEPTH) { err = "BVH deeper than the traversal stack"; return KZ_ERR_STATE; }
+
+    // leaf triangles in ref order
+    tris.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const KzBuildTri &s = in[cx.refs[i].tri];
+        KzTri &d = tris[i];
+        for (int a = 0; a < 3; ++a) { d.p0[a] = s.v[0][a]; d.e1[a] = s.v[1][a] - s.v[0][a]; d.e2[a] = s.v[2][a] - s.v[0][a]; }
+        d.mesh = s.mesh; d.prim = s.prim; d.gid = s.gid;
+    }
+    auto refOf = [&](uint32_t tn) -> uint32_t { const Tmp &t = cx.tmp[tn]; return 0x80000000u | (t.start << 3) | (t.count - 1); };
+    // breadth-first numbering of the inner nodes (top of the tree is contiguous at the front of the array)
+    std::vector<uint32_t> order;        // tmp index of inner nodes in BFS order
+    std::vector<uint32_t> newIndex(cx.nTmp.load(), 0xFFFFFFFFu);
+    double sah = 0.0; uint32_t nLeaves = 0, maxLeaf = 0;
+    float rootArea = cx.tmp[root].b.area();
+    if (cx.tmp[root].count > 0) {
+        rootRef = refOf(root); nLeaves = 1; maxLeaf = cx.tmp[root].count;
+    } else {
+        order.push_back(root); newIndex[root] = 0;
+        for (size_t h = 0; h < order.size(); ++h) {
+            const Tmp &t = cx.tmp[order[h]];
+            for (uint32_t c : {t.left, t.right})
+                if (cx.tmp[c].count == 0) { newIndex[c] = (uint32_t)order.size(); order.push_back(c); }
+        }
+        nodes.resize(order.size());
+        for (size_t h = 0; h < order.size(); ++h) {
+            const Tmp &t = cx.tmp[order[h]];
+            KzNode &nd = nodes[h];
+            std::memset(&nd, 0, sizeof nd);
+            uint32_t ch[2] = {t.left, t.right};
+            Box cb[2];
+            for (int k = 0; k < 2; ++k) {
+                const Tmp &c = cx.tmp[ch[k]];
+                cb[k] = c.b; padBox(cb[k]);
+                if (c.count > 0) { nd.child[k] = refOf(ch[k]); nLeaves++; maxLeaf = std::max(maxLeaf, c.count); sah += (double)c.b.area() * c.count; }
+                else { nd.child[k] = newIndex[ch[k]]; sah += (double)c.b.area() * 1.0; }
+            }
+            nd.q[0] = cb[0].lo[0]; nd.q[1] = cb[0].lo[1]; nd.q[2] = cb[0].lo[2]; nd.q[3] = cb[0].hi[0];
+            nd.q[4] = cb[0].hi[1]; nd.q[5] = cb[0].hi[2]; nd.q[6] = cb[1].lo[0]; nd.q[7] = cb[1].lo[1];
+            nd.q[8] = cb[1].lo[2]; nd.q[9] = cb[1].hi[0]; nd.q[10] = cb[1].hi[1]; nd.q[11] = cb[1].hi[2];
+        }
+        rootRef = 0;
+    }
+    info.nNodes = (uint32_t)nodes.size(); info.nLeaves = nLeaves; info.maxDepth = cx.maxDepth.load(); info.maxLeafSize = maxLeaf;
+    info.sahCost = rootArea > 0 ? (float)(sah / rootArea) : 0.f;
+    info.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return KZ_OK;
+}

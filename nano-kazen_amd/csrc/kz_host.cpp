@@ -1,0 +1,306 @@
+// kz_host.cpp — C-ABI shim, scene validation and flattening (host side of the MI355X core).
+//
+// kz_scene_create does what Scene::activate + Accel::build + Mesh::activate + PerspectiveCamera::activate
+// + the ImageBlock / PMJ02BN constructors do in the reference (scene.cpp:29-52, accel.cpp:25-61,
+// mesh.cpp:24-45, camera.cpp:35-68, block.cpp:9-31, sampler.cpp:275-315) and leaves behind flat tables
+// that kz_scene_upload copies to HBM once. Nothing here renders: there is no CPU fallback for the
+// kernels in kz_device.hip.
+#include "kz_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+int kz_fail(int code, const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    std::vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
+// include/kazen/common.h:271-320
+bool isPowerOf4(int n) {
+    if (n <= 0) return false;
+    int x = (int)std::sqrt((double)n);
+    if (x * x != n) return false;
+    return !(n & (n - 1));
+}
+int log2i(uint32_t v) { return 31 - __builtin_clz(v); }
+int log4i(uint32_t v) { return log2i(v) / 2; }
+int roundUpPow4(int v) { return isPowerOf4(v) ? v : (1 << (2 * (1 + log4i((uint32_t)v)))); }
+
+void mat4mul(const double *a, const double *b, double *c) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        double s = 0; for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+        c[i * 4 + j] = s;
+    }
+}
+bool mat4inv(const double *m, double *out) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = m[i * 4 + j]; a[i][j + 4] = (i == j); }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c; for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[piv][j]);
+        double inv = 1.0 / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) if (r != c) { double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = a[i][j + 4];
+    return true;
+}
+
+// src/kazen/rfilter.cpp:19-24, :50-63, :79-81, :95-97
+float filterEval(const KzFilter &f, float x) {
+    switch (f.type) {
+    case KZ_FILTER_GAUSSIAN: {
+        float alpha = -1.0f / (2.0f * f.stddev * f.stddev);
+        return std::max(0.0f, std::exp(alpha * x * x) - std::exp(alpha * f.radius * f.radius));
+    }
+    case KZ_FILTER_MITCHELL: {
+        float B = f.B, C = f.C;
+        x = std::fabs(2.0f * x / f.radius);
+        float x2 = x * x, x3 = x2 * x;
+        if (x < 1) return 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+        if (x < 2) return 1.0f / 6.0f * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+        return 0.0f;
+    }
+    case KZ_FILTER_TENT: return std::max(0.0f, 1.0f - std::fabs(x));
+    default: return 1.0f;
+    }
+}
+
+const uint64_t PCG32_MULT = 0x5851f42d4c957f2dULL;
+
+} // namespace
+
+extern "C" {
+
+const char *kz_last_error(void) { return g_err; }
+int kz_abi_version(void) { return KZ_ABI_VERSION; }
+
+int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
+    if (!d || !out) return kz_fail(KZ_ERR_INVALID_ARG, "kz_scene_create: null argument");
+    *out = nullptr;
+    if (d->abiVersion != KZ_ABI_VERSION) return kz_fail(KZ_ERR_INVALID_ARG, "ABI version %u, library is %u", d->abiVersion, KZ_ABI_VERSION);
+    // plugin types outside the hot path are an error, never a silent fallback
+    if (d->camera.type != KZ_CAMERA_PERSPECTIVE) return kz_fail(KZ_ERR_UNSUPPORTED, "camera type %d is not on the hot path (only \"perspective\")", d->camera.type);
+    if (d->integrator.type != KZ_INTEGRATOR_PATH_MIS) return kz_fail(KZ_ERR_UNSUPPORTED, "integrator type %d is not on the hot path (only \"path_mis\")", d->integrator.type);
+    if (d->sampler.type != KZ_SAMPLER_INDEPENDENT && d->sampler.type != KZ_SAMPLER_PMJ02BN)
+        return kz_fail(KZ_ERR_UNSUPPORTED, "sampler type %d is not on the hot path (\"independent\", \"pmj02bn\")", d->sampler.type);
+    if (d->camera.rfilter.type < KZ_FILTER_GAUSSIAN || d->camera.rfilter.type > KZ_FILTER_BOX) return kz_fail(KZ_ERR_UNSUPPORTED, "rfilter type %d", d->camera.rfilter.type);
+    if (d->camera.width <= 0 || d->camera.height <= 0 || d->camera.width > 65535 || d->camera.height > 65535) return kz_fail(KZ_ERR_INVALID_ARG, "image size %dx%d", d->camera.width, d->camera.height);
+    if (d->sampler.sampleCount == 0) return kz_fail(KZ_ERR_INVALID_ARG, "sampleCount is 0");
+    if (!(d->camera.rfilter.radius > 0.f) || d->camera.rfilter.radius > 4.0f) return kz_fail(KZ_ERR_UNSUPPORTED, "filter radius %g (supported: (0, 4])", d->camera.rfilter.radius);
+    if ((d->nMeshes && !d->meshes) || (d->nBsdfs && !d->bsdfs) || (d->nLights && !d->lights)) return kz_fail(KZ_ERR_INVALID_ARG, "null table with non-zero count");
+    for (uint32_t i = 0; i < d->nBsdfs; ++i)
+        if (d->bsdfs[i].type != KZ_BSDF_DIFFUSE && d->bsdfs[i].type != KZ_BSDF_KAZENSTANDARD)
+            return kz_fail(KZ_ERR_UNSUPPORTED, "bsdf %u has type %d (only \"diffuse\" and \"kazenstandard\" are on the hot path)", i, d->bsdfs[i].type);
+
+    KzScene *sc = new KzScene();
+    std::memset(&sc->prm, 0, sizeof sc->prm);
+    sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->nBsdfs);
+    int defaultBsdf = -1;
+
+    // ---- geometry: (mesh, face) order = Embree geomID / primID order (accel.cpp:40-55)
+    std::vector<KzBuildTri> bt;
+    size_t totalF = 0;
+    for (uint32_t m = 0; m < d->nMeshes; ++m) totalF += d->meshes[m].nF;
+    if (totalF >= (1ull << 28)) { delete sc; return kz_fail(KZ_ERR_UNSUPPORTED, "%zu triangles (limit 2^28)", totalF); }
+    bt.reserve(totalF); sc->shade.reserve(totalF);
+    uint32_t gid = 0;
+    for (uint32_t m = 0; m < d->nMeshes; ++m) {
+        const KzMesh &km = d->meshes[m];
+        if (!km.V || !km.F) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "mesh %u has no V/F", m); }
+        if (km.bsdf >= (int)d->nBsdfs || km.light >= (int)d->nLights || km.bsdf < -1 || km.light < -1) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "mesh %u: bsdf/light index out of range", m); }
+        KzMeshRow row; std::memset(&row, 0, sizeof row);
+        row.bsdf = km.bsdf; row.light = -1;
+        if (km.bsdf < 0) {      // Mesh::activate instantiates a default Diffuse (mesh.cpp:25-28, albedo 0.5 bsdf.cpp:23)
+            if (defaultBsdf < 0) {
+                KzBSDF b; std::memset(&b, 0, sizeof b);
+                b.type = KZ_BSDF_DIFFUSE; b.albedo[0] = b.albedo[1] = b.albedo[2] = 0.5f;
+                defaultBsdf = (int)sc->bsdfs.size(); sc->bsdfs.push_back(b);
+            }
+            row.bsdf = defaultBsdf;
+        }
+        row.flags = (km.N ? 1u : 0u) | (km.UV ? 2u : 0u);
+        row.triOffset = gid; row.nF = km.nF;
+        for (uint32_t f = 0; f < km.nF; ++f, ++gid) {
+            uint32_t idx[3] = {km.F[3 * f], km.F[3 * f + 1], km.F[3 * f + 2]};
+            KzBuildTri t; t.mesh = m; t.prim = f; t.gid = gid;
+            KzTriShade s; std::memset(&s, 0, sizeof s);
+            for (int v = 0; v < 3; ++v) {
+                if (idx[v] >= km.nV) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "mesh %u face %u: vertex index %u >= %u", m, f, idx[v], km.nV); }
+                for (int a = 0; a < 3; ++a) {
+                    t.v[v][a] = km.V[3 * (size_t)idx[v] + a];
+                    s.p[3 * v + a] = t.v[v][a];
+                    if (km.N) s.n[3 * v + a] = km.N[3 * (size_t)idx[v] + a];
+                }
+                if (km.UV) { s.uv[2 * v] = km.UV[2 * (size_t)idx[v]]; s.uv[2 * v + 1] = km.UV[2 * (size_t)idx[v] + 1]; }
+            }
+            bt.push_back(t); sc->shade.push_back(s);
+        }
+        // ---- light rows + area CDF (scene.cpp:42-46, mesh.cpp:24-45, dpdf.h:35-37,77-89)
+        if (km.light >= 0) {
+            const KzLight &kl = d->lights[km.light];
+            KzLightRow lr; std::memset(&lr, 0, sizeof lr);
+            for (int a = 0; a < 3; ++a) lr.radiance[a] = kl.intensity * kl.color[a];
+            lr.primaryVisibility = kl.primaryVisibility ? 1 : 0;
+            lr.mesh = m; lr.triOffset = row.triOffset; lr.nF = km.nF; lr.cdfOffset = (uint32_t)sc->cdf.size();
+            size_t base = sc->cdf.size();
+            sc->cdf.push_back(0.0f);
+            for (uint32_t f = 0; f < km.nF; ++f) {
+                const KzTriShade &s = sc->shade[row.triOffset + f];
+                float e1[3], e2[3];
+                for (int a = 0; a < 3; ++a) { e1[a] = s.p[3 + a] - s.p[a]; e2[a] = s.p[6 + a] - s.p[a]; }
+                float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                float area = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);          // mesh.cpp:47-53
+                sc->cdf.push_back(sc->cdf.back() + area);
+            }
+            float sum = sc->cdf.back();
+            if (sum > 0) {
+                lr.normalization = 1.0f / sum;
+                for (size_t i = base + 1; i < sc->cdf.size(); ++i) sc->cdf[i] *= lr.normalization;
+                sc->cdf.back() = 1.0f;
+            } else lr.normalization = 0.0f;
+            row.light = (int32_t)sc->lightRows.size();
+            sc->lightRows.push_back(lr);
+        }
+        sc->meshRows.push_back(row);
+    }
+    std::string berr;
+    uint32_t rootRef = 0xFFFFFFFFu;
+    int rc = kz_build_bvh(bt, sc->nodes, sc->tris, rootRef, sc->bvh, berr);
+    if (rc != KZ_OK) { delete sc; return kz_fail(rc, "BVH build: %s", berr.c_str()); }
+
+    KzParams &p = sc->prm;
+    p.rootRef = rootRef;
+    // ---- camera (camera.cpp:35-68). Eigen is not available: the 4x4 product and inverse are formed in
+    // double and narrowed once, unless the caller hands over Eigen's own m_sampleToCamera.
+    const KzCamera &c = d->camera;
+    p.width = c.width; p.height = c.height;
+    p.invW = 1.0f / (float)c.width; p.invH = 1.0f / (float)c.height;
+    p.nearClip = c.nearClip; p.farClip = c.farClip;
+    std::memcpy(p.c2w, c.toWorld, sizeof p.c2w);
+    if (c.sampleToCamera) std::memcpy(p.s2c, c.sampleToCamera, sizeof p.s2c);
+    else {
+        float aspect = c.width / (float)c.height;
+        float recip = 1.0f / (c.farClip - c.nearClip);
+        float cot = 1.0f / std::tan((float)((c.fov / 2.0f) * (M_PI / 180.0f)));
+        double P[16] = {cot, 0, 0, 0, 0, cot, 0, 0, 0, 0, (double)(c.farClip * recip), (double)(-c.nearClip * c.farClip * recip), 0, 0, 1, 0};
+        double T[16] = {1, 0, 0, -1, 0, 1, 0, (double)(-1.0f / aspect), 0, 0, 1, 0, 0, 0, 0, 1};
+        double D[16] = {-0.5, 0, 0, 0, 0, (double)(-0.5f * aspect), 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        double TP[16], M[16], Mi[16];
+        mat4mul(T, P, TP); mat4mul(D, TP, M);
+        if (!mat4inv(M, Mi)) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "singular projection (fov %g, clip %g..%g)", c.fov, c.nearClip, c.farClip); }
+        for (int i = 0; i < 16; ++i) p.s2c[i] = (float)Mi[i];
+    }
+    // ---- film filter table (block.cpp:13-21)
+    const KzFilter &rf = c.rfilter;
+    p.filterRadius = rf.radius;
+    p.border = (int)std::ceil(rf.radius - 0.5f);
+    for (int i = 0; i < KZ_FILTER_RESOLUTION; ++i) sc->filter[i] = filterEval(rf, (rf.radius * i) / KZ_FILTER_RESOLUTION);
+    sc->filter[KZ_FILTER_RESOLUTION] = 0.0f;
+    p.lookupFactor = KZ_FILTER_RESOLUTION / rf.radius;
+    // source pixels px that can reach film pixel fx satisfy px-(fx-border) in (-r-0.5, r+0.5]
+    p.tapLo = (int)std::floor(-rf.radius - 0.5f) + 1;
+    p.tapHi = (int)std::floor(rf.radius + 0.5f);
+    if (p.tapHi - p.tapLo + 1 > KZ_MAX_FILTER_TAPS) { delete sc; return kz_fail(KZ_ERR_UNSUPPORTED, "filter radius %g needs too many taps", rf.radius); }
+    // ---- integrator (integrator.cpp:187-193)
+    p.maxDepth = std::min(512, d->integrator.maxDepth);
+    p.traceBias = d->integrator.traceBias;
+    p.regularization = d->integrator.regularization ? 1 : 0;
+    p.accumulatedRoughness = d->integrator.accumulatedRoughness;
+    // ---- lights / background (scene.h:45-56, texture.cpp:121-126)
+    p.nLights = (uint32_t)sc->lightRows.size();
+    p.lightPickPdf = p.nLights ? 1.f / (float)p.nLights : 0.f;
+    p.bgPresent = d->background.present ? 1 : 0;
+    for (int a = 0; a < 3; ++a) p.bgRadiance[a] = d->background.present ? d->background.intensity * d->background.color[a] : 0.f;
+    // ---- sampler
+    p.samplerType = d->sampler.type;
+    p.seed = d->sampler.seed;
+    p.sampleCount = d->sampler.sampleCount;
+    if (d->sampler.type == KZ_SAMPLER_PMJ02BN) {
+        if (!d->sampler.pmj02bnSamples || !d->sampler.blueNoise) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "pmj02bn sampler without its tables"); }
+        if (p.sampleCount > KZ_PMJ02BN_SAMPLES) p.sampleCount = KZ_PMJ02BN_SAMPLES;               // sampler.cpp:284-287
+        sc->pmj.assign(d->sampler.pmj02bnSamples, d->sampler.pmj02bnSamples + (size_t)KZ_PMJ02BN_SETS * KZ_PMJ02BN_SAMPLES * 2);
+        sc->bn.assign(d->sampler.blueNoise, d->sampler.blueNoise + (size_t)KZ_BLUENOISE_TEXTURES * KZ_BLUENOISE_RES * KZ_BLUENOISE_RES);
+        // PMJ02BN constructor: sort set 0 into a tile x tile x spp pixel table (sampler.cpp:291-309)
+        uint32_t spp = p.sampleCount;
+        int tile = 1 << (log4i(KZ_PMJ02BN_SAMPLES) - log4i((uint32_t)roundUpPow4((int)spp)));
+        p.pixelTileSize = tile;
+        sc->pixelSamples.assign((size_t)tile * tile * spp * 2, 0.f);
+        std::vector<uint32_t> nStored((size_t)tile * tile, 0);
+        for (int i = 0; i < KZ_PMJ02BN_SAMPLES; ++i) {
+            float x = (float)(sc->pmj[2 * (size_t)i] * 0x1p-32), y = (float)(sc->pmj[2 * (size_t)i + 1] * 0x1p-32);   // pmj02table.h:28-29
+            x *= tile; y *= tile;
+            int ix = (int)x, iy = (int)y;
+            if (ix >= tile || iy >= tile) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "pmj02bn table entry %d rounds to 1.0f (the reference would index out of range)", i); }
+            size_t po = (size_t)ix + (size_t)iy * tile;
+            if (nStored[po] == spp) continue;
+            size_t so = po * spp + nStored[po];
+            sc->pixelSamples[2 * so] = x - std::floor(x);
+            sc->pixelSamples[2 * so + 1] = y - std::floor(y);
+            ++nStored[po];
+        }
+    } else {
+        // pcg32::advance(sampleIndex*65536) as an affine map state' = mult*state + inc*plus (pcg32.h:145-166)
+        sc->jump.resize(p.sampleCount);
+        for (uint32_t s = 0; s < p.sampleCount; ++s) {
+            uint64_t cur_mult = PCG32_MULT, cur_plus = 1u, acc_mult = 1u, acc_plus = 0u;
+            uint64_t delta = (uint64_t)s * 65536ull;
+            while (delta > 0) {
+                if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+                cur_plus = (cur_mult + 1) * cur_plus;
+                cur_mult *= cur_mult;
+                delta /= 2;
+            }
+            sc->jump[s].mult = acc_mult; sc->jump[s].plus = acc_plus;
+        }
+    }
+    *out = sc;
+    return KZ_OK;
+}
+
+void kz_scene_destroy(KzScene *scene) {
+    if (!scene) return;
+    kz_device_release(scene);
+    delete scene;
+}
+
+int kz_scene_bvh_info(const KzScene *scene, KzBvhInfo *out) {
+    if (!scene || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
+    *out = scene->bvh;
+    return KZ_OK;
+}
+
+int kz_film_dims(const KzScene *scene, int32_t *width, int32_t *height, int32_t *border) {
+    if (!scene) return kz_fail(KZ_ERR_INVALID_ARG, "null scene");
+    if (width) *width = scene->prm.width;
+    if (height) *height = scene->prm.height;
+    if (border) *border = scene->prm.border;
+    return KZ_OK;
+}
+
+// ImageBlock::toBitmap + Color4f::divideByFilterWeight (block.cpp:39-45, color.h:94-99). Host utility on a
+// downloaded film; the per-sample work all happened on the GPU.
+int kz_film_to_rgb(const float *film, int32_t width, int32_t height, int32_t border, float *rgb) {
+    if (!film || !rgb || width <= 0 || height <= 0 || border < 0) return kz_fail(KZ_ERR_INVALID_ARG, "kz_film_to_rgb: bad argument");
+    size_t cols = (size_t)width + 2 * (size_t)border;
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const float *px = film + ((size_t)(y + border) * cols + (size_t)(x + border)) * 4;
+            float *o = rgb + ((size_t)y * width + x) * 3;
+            if (px[3] != 0) { o[0] = px[0] / px[3]; o[1] = px[1] / px[3]; o[2] = px[2] / px[3]; }
+            else { o[0] = o[1] = o[2] = 0.f; }
+        }
+    return KZ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,118 @@
+// kz_internal.h — host-side scene object and the flat device tables of the MI355X path-tracing core.
+// Not part of the ABI (that is include/kazen_mi355x.h).
+#pragma once
+#include "../../include/kazen_mi355x.h"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#define KZ_STACK_DEPTH 32        // per-lane traversal stack entries (LDS); the builder caps the tree depth to this
+#define KZ_MAX_LEAF 4            // triangles per leaf
+#define KZ_MAX_FILTER_TAPS 9     // candidates per axis the film kernel supports (filter radius <= 4)
+
+// ---- device formats (DESIGN.md "data layout in HBM") ---------------------------------------------
+// BVH2 node, 64 B, four 16-B quads -> four global_load_dwordx4 per lane:
+//   q0 = lo0.x lo0.y lo0.z hi0.x | q1 = hi0.y hi0.z lo1.x lo1.y | q2 = lo1.z hi1.x hi1.y hi1.z | q3 = child0 child1 - -
+// child: bit31 set -> leaf, bits[30:3] = first triangle, bits[2:0] = count-1; else node index.
+struct KzNode { float q[12]; uint32_t child[2]; uint32_t pad[2]; };
+static_assert(sizeof(KzNode) == 64, "node packet must be 64 B");
+
+// Leaf triangle in Moeller-Trumbore form, 48 B, three quads: p0.xyz e1.x | e1.y e1.z e2.x e2.y | e2.z mesh prim gid
+struct KzTri { float p0[3]; float e1[3]; float e2[3]; uint32_t mesh, prim, gid; };
+static_assert(sizeof(KzTri) == 48, "leaf triangle must be 48 B");
+
+// Shading record per triangle (indexed by gid), 96 B, six quads: p0 p1 p2 n0 n1 n2 uv0 uv1 uv2.
+// One hop replaces the reference's F -> V/N/UV double gather (accel.cpp:133-136,167-169).
+struct KzTriShade { float p[9]; float n[9]; float uv[6]; };
+static_assert(sizeof(KzTriShade) == 96, "shading record must be 96 B");
+
+// Per-mesh row, 32 B.
+struct KzMeshRow {
+    int32_t bsdf;          // index into bsdfs (never -1 on device: the default diffuse is materialised)
+    int32_t light;         // index into lightRows or -1
+    uint32_t flags;        // bit0 hasN, bit1 hasUV
+    uint32_t triOffset;    // gid of face 0
+    uint32_t nF;
+    uint32_t pad[3];
+};
+// Per-light row (Scene::m_lights order, scene.cpp:42-46), 48 B.
+struct KzLightRow {
+    float radiance[3];     // intensity * color (light.cpp:13)
+    int32_t primaryVisibility;
+    uint32_t mesh;
+    uint32_t triOffset;    // gid of the light mesh's face 0
+    uint32_t nF;
+    uint32_t cdfOffset;    // into cdf[] (nF+1 floats, dpdf.h)
+    float normalization;   // DiscretePDF::m_normalization = Mesh::pdf() (mesh.h:165-168)
+    uint32_t pad[3];
+};
+// pcg32 jump-ahead pair for advance(sampleIndex * 65536): state' = mult*state + inc*plus (pcg32.h:145-166 is
+// linear in `inc`, so the pair is pixel independent and tabulated once per sample index).
+struct KzPcgJump { uint64_t mult, plus; };
+
+// Render constants, passed to kernels by value.
+struct KzParams {
+    // camera (camera.cpp:35-91)
+    float s2c[16];
+    float c2w[16];
+    float invW, invH, nearClip, farClip;
+    int32_t width, height, border;
+    // integrator (integrator.cpp:187-193)
+    int32_t maxDepth; float traceBias; int32_t regularization; float accumulatedRoughness;
+    // sampler
+    int32_t samplerType; uint32_t sampleCount; uint64_t seed; int32_t pixelTileSize;
+    // lights / background
+    uint32_t nLights; float lightPickPdf;
+    int32_t bgPresent; float bgRadiance[3];
+    // film (block.cpp:13-21)
+    float filterRadius, lookupFactor; int32_t tapLo, tapHi;
+    uint32_t rootRef;
+};
+
+// Device pointers (all HBM-resident after kz_scene_upload).
+struct KzDevTables {
+    const KzNode *nodes;
+    const KzTri *tris;
+    const KzTriShade *shade;
+    const KzMeshRow *meshes;
+    const KzBSDF *bsdfs;
+    const KzLightRow *lights;
+    const float *cdf;
+    const uint32_t *pmj;        // [5][65536][2]
+    const uint16_t *bn;         // [48][128][128]
+    const float *pixelSamples;  // pmj02bn pixel table (sampler.cpp:291-309), 2 floats per entry
+    const KzPcgJump *jump;      // [sampleCount]
+    const float *filter;        // [33]
+};
+
+struct KzScene {
+    // flattened host tables
+    std::vector<KzNode> nodes;
+    std::vector<KzTri> tris;
+    std::vector<KzTriShade> shade;
+    std::vector<KzMeshRow> meshRows;
+    std::vector<KzBSDF> bsdfs;
+    std::vector<KzLightRow> lightRows;
+    std::vector<float> cdf;
+    std::vector<uint32_t> pmj;
+    std::vector<uint16_t> bn;
+    std::vector<float> pixelSamples;
+    std::vector<KzPcgJump> jump;
+    float filter[KZ_FILTER_RESOLUTION + 1];
+    KzParams prm;
+    KzBvhInfo bvh;
+    // device state (owned by kz_device.hip)
+    void *dev = nullptr;
+};
+
+// kz_bvh.cpp
+struct KzBuildTri { float v[3][3]; uint32_t mesh, prim, gid; };
+int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, std::vector<KzTri> &tris,
+                 uint32_t &rootRef, KzBvhInfo &info, std::string &err);
+
+// kz_host.cpp
+int kz_fail(int code, const char *fmt, ...);
+
+// kz_device.hip
+void kz_device_release(KzScene *scene);
