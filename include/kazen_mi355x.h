@@ -231,6 +231,16 @@ int kz_film_to_rgb(const float *film, int32_t width, int32_t height, int32_t bor
 int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d,
                   const float *tmin, const float *tmax, KzHit *hits);
 
+/* Debug / known-answer entry points (used by the parity tests, not by a renderer):
+ * kz_render_samples: radiance of explicit (pixel, sample index) pairs = renderSample (renderer.cpp:20-40) without
+ * the block.put; pxy = n x (x,y), out = n x (pixelSample.x, pixelSample.y, r, g, b).
+ * kz_bsdf_query: BSDF::eval / pdf / sample (bsdf.h:80-108) of row bsdf[i] for local directions wi/wo (n x 3), with
+ * its.accumulatedRoughness accRough[i] and the (sample1, sample2.x, sample2.y) triple s3; evalOut n x 3,
+ * pdfOut n, sampleOut n x 7 = (weight rgb, sampled wo xyz, alive). */
+int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint32_t *idx, float *out);
+int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *wi, const float *wo, const float *accRough,
+                  const float *s3, float *evalOut, float *pdfOut, float *sampleOut);
+
 /* Statistics: enable=1 switches to the counting kernel variant (slower). */
 int kz_set_stats(KzScene *scene, int enable);
 int kz_get_stats(KzScene *scene, KzStats *out, int reset);

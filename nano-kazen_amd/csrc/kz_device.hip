@@ -176,6 +176,9 @@ __device__ __forceinline__ bool closestHit(const KzDevTables &T, uint32_t rootRe
     best.t = KZ_INF; best.u = best.v = 0.f; best.tri = 0; best.gid = 0;
     if (STATS) cn.rays++;
     if (rootRef == 0xFFFFFFFFu) return false;
+    // A ray with a non-finite origin or direction can hit nothing (every Moeller-Trumbore comparison fails on NaN),
+    // but fminf/fmaxf would let it pass EVERY slab test: one such lane would walk the whole tree. Miss at once.
+    if (!(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z) < KZ_INF)) return false;
     const float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;      // ray.h:56-58 cwiseInverse
     uint32_t cur = rootRef;
     int sp = 0;
@@ -602,7 +605,7 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
 // a1/a2 renderBlock + renderSample (renderer.cpp:20-69): item = pixLinear * S + sampleOffset
 template <bool STATS>
 __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDevTables T, const uint32_t *__restrict__ pixList,
-                                                               uint32_t nItems, uint32_t S, uint32_t sampleBegin,
+                                                               uint32_t nItems, uint32_t S, uint32_t sampleBegin, const uint32_t *__restrict__ itemSample,
                                                                float *__restrict__ outJx, float *__restrict__ outJy, float *__restrict__ outR,
                                                                float *__restrict__ outG, float *__restrict__ outB,
                                                                unsigned long long *__restrict__ stats) {
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDev
         const uint32_t pxy = pixList[pl];
         const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
         Sampler smp; smp.type = P.samplerType;
-        smp.generateSample(P, T, px, py, sampleBegin + so);
+        smp.generateSample(P, T, px, py, itemSample ? itemSample[item] : sampleBegin + so);
         float jx, jy; smp.nextPixel2D(P, T, jx, jy);
         const float sx = (float)px + jx, sy = (float)py + jy;
         float ax, ay; smp.next2D(P, T, ax, ay);                  // aperture sample, always consumed (renderer.cpp:28)
@@ -639,49 +642,87 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDev
 }
 
 // ============================================================================================
-// a25 ImageBlock::put as a deterministic gather (block.cpp:56-85): one thread per film pixel sums, in a fixed
-// order, every sample of this pass whose filter footprint covers it. Positions are formed block-relative
-// exactly as the reference does (32x32 blocks at multiples of KAZEN_BLOCK_SIZE), so weights are bit-identical.
+// a25 ImageBlock::put as a deterministic gather (block.cpp:56-85). One workgroup = 16x16 film pixels. The
+// samples of the (16+taps-1)^2 source pixels that can reach them are staged through LDS in chunks (coalesced
+// global reads, each sample record read once per workgroup instead of once per film pixel), then every thread
+// sums, in a fixed order, the samples whose filter footprint covers its pixel. Positions are formed
+// block-relative exactly as the reference does (32x32 blocks at multiples of KAZEN_BLOCK_SIZE), so the weights
+// are bit-identical to ImageBlock::put; only the order of the float additions differs (H10).
 // ============================================================================================
+#define KZ_FILM_TILE 16
+#define KZ_FILM_CHUNK 8
+#define KZ_FILM_RMAX (KZ_FILM_TILE + KZ_MAX_FILTER_TAPS - 1)
 __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *__restrict__ filter, const int32_t *__restrict__ pixIndex,
                                                       uint32_t S, const float *__restrict__ inJx, const float *__restrict__ inJy,
                                                       const float *__restrict__ inR, const float *__restrict__ inG, const float *__restrict__ inB,
                                                       float4 *__restrict__ film) {
     __shared__ float s_filter[KZ_FILTER_RESOLUTION + 1];
-    if (threadIdx.x <= KZ_FILTER_RESOLUTION) s_filter[threadIdx.x] = filter[threadIdx.x];
-    __syncthreads();
+    __shared__ int32_t s_pl[KZ_FILM_RMAX * KZ_FILM_RMAX];
+    extern __shared__ float s_samp[];              // [5][KZ_FILM_CHUNK][R*R]
+    const int tid = threadIdx.x;
+    if (tid <= KZ_FILTER_RESOLUTION) s_filter[tid] = filter[tid];
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border;
-    const int fx = blockIdx.x * 16 + (threadIdx.x & 15), fy = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (fx >= cols || fy >= rows) return;
+    const int taps = P.tapHi - P.tapLo + 1;
+    const int R = KZ_FILM_TILE + taps - 1, RR = R * R;
+    // film tile origin (film coordinates) and the image-space origin of the source region
+    const int fx0 = blockIdx.x * KZ_FILM_TILE, fy0 = blockIdx.y * KZ_FILM_TILE;
+    const int sx0 = fx0 - P.border + P.tapLo, sy0 = fy0 - P.border + P.tapLo;
+    bool anySrc = false;
+    for (int q = tid; q < RR; q += 256) {
+        const int x = sx0 + q % R, y = sy0 + q / R;
+        int pl = -1;
+        if (x >= 0 && x < P.width && y >= 0 && y < P.height) pl = pixIndex[y * P.width + x];
+        s_pl[q] = pl;
+        anySrc |= pl >= 0;
+    }
+    if (!__syncthreads_or(anySrc)) return;        // nothing of this pass can reach the tile
+    const int lx = tid & 15, ly = tid >> 4;
+    const int fx = fx0 + lx, fy = fy0 + ly;
+    const bool inFilm = fx < cols && fy < rows;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool any = false;
     const float r = P.filterRadius, lf = P.lookupFactor;
-    for (int dy = P.tapLo; dy <= P.tapHi; ++dy) {
-        const int py = fy - P.border + dy;
-        if (py < 0 || py >= P.height) continue;
-        for (int dx = P.tapLo; dx <= P.tapHi; ++dx) {
-            const int px = fx - P.border + dx;
-            if (px < 0 || px >= P.width) continue;
-            const int pl = pixIndex[py * P.width + px];
-            if (pl < 0) continue;
-            const int bx0 = px & ~31, by0 = py & ~31;                      // the reference block this sample is rendered in
-            const float xb = (float)(fx - bx0), yb = (float)(fy - by0);     // film pixel in that block's (bordered) coordinates
-            const float offx = (float)(bx0 - P.border), offy = (float)(by0 - P.border);
-            for (uint32_t s = 0; s < S; ++s) {
-                const size_t i = (size_t)pl * S + s;
-                const float cr = inR[i], cg = inG[i], cb = inB[i];
-                if (!(cr >= 0.f && cg >= 0.f && cb >= 0.f && isfinite(cr) && isfinite(cg) && isfinite(cb))) continue;   // Color3f::isValid
-                const float sx = (float)px + inJx[i], sy = (float)py + inJy[i];
-                const float posx = sx - 0.5f - offx, posy = sy - 0.5f - offy;            // block.cpp:64-67
-                if (xb < ceilf(posx - r) || xb > floorf(posx + r) || yb < ceilf(posy - r) || yb > floorf(posy + r)) continue;   // block.cpp:70-73
-                const float wx = s_filter[(int)(fabsf(xb - posx) * lf)];                // block.cpp:77-80
-                const float wy = s_filter[(int)(fabsf(yb - posy) * lf)];
-                acc.x += cr * wx * wy; acc.y += cg * wx * wy; acc.z += cb * wx * wy; acc.w += 1.0f * wx * wy;   // block.cpp:84
-                any = true;
+    const int plane = KZ_FILM_CHUNK * RR;
+    for (uint32_t sBase = 0; sBase < S; sBase += KZ_FILM_CHUNK) {
+        const int ch = (int)min((uint32_t)KZ_FILM_CHUNK, S - sBase);
+        __syncthreads();
+        for (int i = tid; i < RR * KZ_FILM_CHUNK; i += 256) {
+            const int q = i / KZ_FILM_CHUNK, s = i - q * KZ_FILM_CHUNK;
+            const int pl = s_pl[q];
+            float jx = 0.f, jy = 0.f, cr = -1.f, cg = 0.f, cb = 0.f;     // r = -1: "no sample" (fails Color3f::isValid)
+            if (pl >= 0 && s < ch) {
+                const size_t gi = (size_t)pl * S + sBase + s;
+                jx = inJx[gi]; jy = inJy[gi]; cr = inR[gi]; cg = inG[gi]; cb = inB[gi];
+            }
+            const int o = s * RR + q;
+            s_samp[o] = jx; s_samp[plane + o] = jy; s_samp[2 * plane + o] = cr; s_samp[3 * plane + o] = cg; s_samp[4 * plane + o] = cb;
+        }
+        __syncthreads();
+        if (!inFilm) continue;
+        for (int dy = 0; dy < taps; ++dy) {
+            const int py = fy - P.border + P.tapLo + dy;
+            const int by0 = py & ~31;
+            const float yb = (float)(fy - by0), offy = (float)(by0 - P.border);
+            for (int dx = 0; dx < taps; ++dx) {
+                const int q = (ly + dy) * R + (lx + dx);
+                if (s_pl[q] < 0) continue;
+                const int px = fx - P.border + P.tapLo + dx;
+                const int bx0 = px & ~31;                                    // the reference block this sample is rendered in
+                const float xb = (float)(fx - bx0), offx = (float)(bx0 - P.border);
+                for (int s = 0; s < ch; ++s) {
+                    const int o = s * RR + q;
+                    const float cr = s_samp[2 * plane + o], cg = s_samp[3 * plane + o], cb = s_samp[4 * plane + o];
+                    if (!(cr >= 0.f && cg >= 0.f && cb >= 0.f && isfinite(cr) && isfinite(cg) && isfinite(cb))) continue;   // Color3f::isValid
+                    const float sx = (float)px + s_samp[o], sy = (float)py + s_samp[plane + o];
+                    const float posx = sx - 0.5f - offx, posy = sy - 0.5f - offy;            // block.cpp:64-67
+                    if (xb < ceilf(posx - r) || xb > floorf(posx + r) || yb < ceilf(posy - r) || yb > floorf(posy + r)) continue;   // block.cpp:70-73
+                    const float wx = s_filter[(int)(fabsf(xb - posx) * lf)];                // block.cpp:77-80
+                    const float wy = s_filter[(int)(fabsf(yb - posy) * lf)];
+                    acc.x += cr * wx * wy; acc.y += cg * wx * wy; acc.z += cb * wx * wy; acc.w += 1.0f * wx * wy;   // block.cpp:84
+                }
             }
         }
     }
-    if (any) {
+    if (inFilm) {
         float4 *dst = film + (size_t)fy * cols + fx;
         float4 o = *dst;
         o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
@@ -712,6 +753,24 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_trace_kernel(KzParams P, KzDevTab
         h.geo_n[0] = its.geoN.x; h.geo_n[1] = its.geoN.y; h.geo_n[2] = its.geoN.z;
     }
     hits[i] = h;
+}
+
+
+// Function-level query kernel for the BSDF tables (parity tests of a20/a21/a22/a23 on the device)
+__global__ void kz_bsdf_kernel(KzDevTables T, uint32_t n, const int32_t *__restrict__ bsdf, const float *__restrict__ wi, const float *__restrict__ wo,
+                               const float *__restrict__ acc, const float *__restrict__ s3, float *__restrict__ evalOut, float *__restrict__ pdfOut,
+                               float *__restrict__ sampleOut) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const KzBSDF m = T.bsdfs[bsdf[i]];
+    const V3 a = mk(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), b = mk(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
+    V3 e = bsdfEval(m, a, b, acc[i]);
+    evalOut[3 * i] = e.x; evalOut[3 * i + 1] = e.y; evalOut[3 * i + 2] = e.z;
+    pdfOut[i] = bsdfPdf(m, a, b, acc[i]);
+    V3 d; bool alive;
+    V3 w = bsdfSample(m, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive);
+    float *o = sampleOut + 7 * i;
+    o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = d.x; o[4] = d.y; o[5] = d.z; o[6] = alive ? 1.f : 0.f;
 }
 
 // ============================================================================================
@@ -799,6 +858,7 @@ int kz_scene_upload(KzScene *scene, int device) {
     HIP_TRY(hipMemset(ds->film, 0, ds->filmPixels * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&ds->stats, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ds->stats, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipFuncSetAttribute((const void *)kz_film_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIP_TRY(hipDeviceSynchronize());
     return KZ_OK;
 }
@@ -895,15 +955,17 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
         const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
         HIP_TRY(hipEventRecord(ep.a, stream));
         if (ds->statsOn)
-            hipLaunchKernelGGL(kz_path_megakernel<true>, grid, dim3(KZ_BLOCK), 0, stream, P, ds->T, ds->pixList, (uint32_t)items, Sp, s,
+            hipLaunchKernelGGL(kz_path_megakernel<true>, grid, dim3(KZ_BLOCK), 0, stream, P, ds->T, ds->pixList, (uint32_t)items, Sp, s, (const uint32_t *)nullptr,
                                ds->sJx, ds->sJy, ds->sR, ds->sG, ds->sB, ds->stats);
         else
-            hipLaunchKernelGGL(kz_path_megakernel<false>, grid, dim3(KZ_BLOCK), 0, stream, P, ds->T, ds->pixList, (uint32_t)items, Sp, s,
+            hipLaunchKernelGGL(kz_path_megakernel<false>, grid, dim3(KZ_BLOCK), 0, stream, P, ds->T, ds->pixList, (uint32_t)items, Sp, s, (const uint32_t *)nullptr,
                                ds->sJx, ds->sJy, ds->sR, ds->sG, ds->sB, ds->stats);
         HIP_TRY(hipEventRecord(ep.b, stream));
         HIP_TRY(hipGetLastError());
-        const dim3 fgrid((cols + 15) / 16, (rows + 15) / 16);
-        hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), 0, stream, P, ds->T.filter, ds->pixIndex, Sp, ds->sJx, ds->sJy, ds->sR, ds->sG,
+        const dim3 fgrid((cols + KZ_FILM_TILE - 1) / KZ_FILM_TILE, (rows + KZ_FILM_TILE - 1) / KZ_FILM_TILE);
+        const int fr = KZ_FILM_TILE + (P.tapHi - P.tapLo);
+        const size_t fshm = (size_t)5 * KZ_FILM_CHUNK * fr * fr * sizeof(float);
+        hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, stream, P, ds->T.filter, ds->pixIndex, Sp, ds->sJx, ds->sJy, ds->sR, ds->sG,
                            ds->sB, ds->film);
         HIP_TRY(hipGetLastError());
     }
@@ -979,6 +1041,60 @@ int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d, co
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hits, dH, (size_t)n * sizeof(KzHit), hipMemcpyDeviceToHost));
     (void)hipFree(dO); (void)hipFree(dD); (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dH);
+    return KZ_OK;
+}
+
+// Radiance of explicit (pixel, sample index) pairs without touching the film: out = n x (sx, sy, r, g, b).
+int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint32_t *idx, float *out) {
+    KzDeviceState *ds; int rc;
+    if ((rc = requireDevice(scene, &ds))) return rc;
+    if (n == 0) return KZ_OK;
+    if (!pxy || !idx || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
+    const KzParams &P = scene->prm;
+    std::vector<uint32_t> pl(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (pxy[2 * i] < 0 || pxy[2 * i] >= P.width || pxy[2 * i + 1] < 0 || pxy[2 * i + 1] >= P.height || idx[i] >= P.sampleCount)
+            return kz_fail(KZ_ERR_INVALID_ARG, "sample %u: pixel (%d,%d) index %u out of range", i, pxy[2 * i], pxy[2 * i + 1], idx[i]);
+        pl[i] = (uint32_t)pxy[2 * i] | ((uint32_t)pxy[2 * i + 1] << 16);
+    }
+    uint32_t *dP = nullptr, *dI = nullptr; float *dO = nullptr;
+    HIP_TRY(hipMalloc((void **)&dP, (size_t)n * 4)); HIP_TRY(hipMalloc((void **)&dI, (size_t)n * 4)); HIP_TRY(hipMalloc((void **)&dO, (size_t)n * 20));
+    HIP_TRY(hipMemcpy(dP, pl.data(), (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dI, idx, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_path_megakernel<false>, dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, P, ds->T, dP, n, 1u, 0u, dI,
+                       dO, dO + n, dO + 2 * (size_t)n, dO + 3 * (size_t)n, dO + 4 * (size_t)n, ds->stats);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> h((size_t)n * 5);
+    HIP_TRY(hipMemcpy(h.data(), dO, (size_t)n * 20, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        out[5 * i] = (float)pxy[2 * i] + h[i]; out[5 * i + 1] = (float)pxy[2 * i + 1] + h[n + i];
+        out[5 * i + 2] = h[2 * (size_t)n + i]; out[5 * i + 3] = h[3 * (size_t)n + i]; out[5 * i + 4] = h[4 * (size_t)n + i];
+    }
+    (void)hipFree(dP); (void)hipFree(dI); (void)hipFree(dO);
+    return KZ_OK;
+}
+
+// BSDF::eval / pdf / sample of bsdf rows on the device: evalOut 3n, pdfOut n, sampleOut 7n (weight, wo, alive).
+int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *wi, const float *wo, const float *accRough, const float *s3,
+                  float *evalOut, float *pdfOut, float *sampleOut) {
+    KzDeviceState *ds; int rc;
+    if ((rc = requireDevice(scene, &ds))) return rc;
+    if (n == 0) return KZ_OK;
+    if (!bsdf || !wi || !wo || !accRough || !s3 || !evalOut || !pdfOut || !sampleOut) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
+    for (uint32_t i = 0; i < n; ++i) if (bsdf[i] < 0 || (size_t)bsdf[i] >= scene->bsdfs.size()) return kz_fail(KZ_ERR_INVALID_ARG, "bsdf index %d", bsdf[i]);
+    float *d = nullptr; int32_t *dB = nullptr;
+    const size_t fl = (size_t)n * (3 + 3 + 1 + 3 + 3 + 1 + 7);
+    HIP_TRY(hipMalloc((void **)&d, fl * 4)); HIP_TRY(hipMalloc((void **)&dB, (size_t)n * 4));
+    float *dWi = d, *dWo = d + 3 * (size_t)n, *dAcc = d + 6 * (size_t)n, *dS = d + 7 * (size_t)n, *dE = d + 10 * (size_t)n, *dP = d + 13 * (size_t)n, *dSm = d + 14 * (size_t)n;
+    HIP_TRY(hipMemcpy(dB, bsdf, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dWi, wi, (size_t)n * 12, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dWo, wo, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dAcc, accRough, (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dS, s3, (size_t)n * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_bsdf_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, ds->T, n, dB, dWi, dWo, dAcc, dS, dE, dP, dSm);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(evalOut, dE, (size_t)n * 12, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(pdfOut, dP, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sampleOut, dSm, (size_t)n * 28, hipMemcpyDeviceToHost));
+    (void)hipFree(d); (void)hipFree(dB);
     return KZ_OK;
 }
 

@@ -85,6 +85,26 @@ class Scene:
                                                    tmin.ctypes.data_as(abi.f32p), tmax.ctypes.data_as(abi.f32p), hits))
         return hits_to_arrays(hits, n)
 
+    def render_samples(self, pxy, idx):
+        pxy = np.ascontiguousarray(pxy, np.int32)
+        idx = np.ascontiguousarray(idx, np.uint32)
+        n = idx.shape[0]
+        out = np.zeros((n, 5), np.float32)
+        abi.check(self.lib, self.lib.kz_render_samples(self.h, n, pxy.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                       idx.ctypes.data_as(abi.u32p), out.ctypes.data_as(abi.f32p)))
+        return out
+
+    def bsdf_query(self, bsdf, wi, wo, acc, s3):
+        bsdf = np.ascontiguousarray(bsdf, np.int32)
+        n = bsdf.shape[0]
+        wi, wo, s3 = (np.ascontiguousarray(a, np.float32) for a in (wi, wo, s3))
+        acc = np.ascontiguousarray(acc, np.float32)
+        ev, pd, sm = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 7), np.float32)
+        f = lambda a: a.ctypes.data_as(abi.f32p)
+        abi.check(self.lib, self.lib.kz_bsdf_query(self.h, n, bsdf.ctypes.data_as(C.POINTER(C.c_int32)), f(wi), f(wo), f(acc), f(s3),
+                                                   f(ev), f(pd), f(sm)))
+        return ev, pd, sm
+
     def set_stats(self, enable=True):
         abi.check(self.lib, self.lib.kz_set_stats(self.h, 1 if enable else 0))
 

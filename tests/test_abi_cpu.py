@@ -1,0 +1,120 @@
+"""No-GPU tests of the product library: it loads, exports every symbol of include/kazen_mi355x.h, validates
+descriptions, builds the BVH on the host, and refuses to render without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(kz):
+    lib = kz.abi.load_library()
+    hdr = open(os.path.join(ROOT, "include", "kazen_mi355x.h")).read()
+    declared = set(re.findall(r"\b(kz_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(kz.abi.EXPORTS), declared ^ set(kz.abi.EXPORTS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.kz_abi_version() == kz.abi.KZ_ABI_VERSION
+
+
+def test_struct_sizes_match_the_header(kz):
+    a = kz.abi
+    assert C.sizeof(a.KzBSDF) == 64 and C.sizeof(a.KzLight) == 20 and C.sizeof(a.KzTile) == 16
+    assert C.sizeof(a.KzHit) == 88 and C.sizeof(a.KzStats) == 56 and C.sizeof(a.KzMesh) == 48
+
+
+def test_scene_create_and_bvh_on_host(kz):
+    sc = kz.Scene(kz.scenes.random_triangles(20000, 64, 64, 4, sampler="independent"))
+    info = sc.bvh_info()
+    assert info["nTris"] == 20000 + 12 + 16 and info["maxLeafSize"] <= 4 and 0 < info["maxDepth"] <= 30
+    assert info["nLeaves"] == info["nNodes"] + 1
+    assert (sc.width, sc.height, sc.border) == (64, 64, 2)
+
+
+def test_depth_cap_on_adversarial_input(kz):
+    """A geometric progression of triangle sizes makes plain SAH trees degenerate; the builder must stay
+    within the traversal stack."""
+    s = kz.scenes.SceneDescription()
+    n = 4000
+    k = np.arange(n, dtype=np.float64)
+    x = 1.0002 ** (k * 8) - 1.0
+    V = np.zeros((n, 3, 3), np.float32)
+    V[:, 0, 0], V[:, 1, 0], V[:, 2, 0] = x, x + 1e-3, x
+    V[:, 2, 1] = 1e-3
+    s.add_mesh(V.reshape(-1, 3), np.arange(3 * n, dtype=np.uint32).reshape(n, 3), np.tile([0, 0, 1], (3 * n, 1)).astype(np.float32))
+    s.camera.update(width=32, height=32)
+    assert kz.Scene(s).bvh_info()["maxDepth"] <= 30
+
+
+def test_no_device_is_a_loud_error(kz):
+    lib = kz.abi.load_library()
+    if lib.kz_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    sc = kz.Scene(kz.scenes.cornell_box(16, 16, 1))
+    with pytest.raises(kz.abi.KzError) as e:
+        sc.upload(0)
+    assert e.value.code == kz.abi.KZ_ERR_NO_DEVICE
+    with pytest.raises(kz.abi.KzError) as e:
+        sc.render()
+    assert e.value.code == kz.abi.KZ_ERR_STATE
+
+
+@pytest.mark.parametrize("mutate,code", [
+    (lambda s: s.sampler.update(type="stratified"), 2),
+    (lambda s: s.integrator.update(type="whitted"), 2),
+    (lambda s: s.camera.update(type="thinlens"), 2),
+    (lambda s: s.meshes[0].update(bsdf={"type": "mirror"}), 2),
+    (lambda s: s.sampler.update(sampleCount=0), 1),
+    (lambda s: s.camera.update(width=0), 1),
+    (lambda s: s.meshes[0]["F"].__setitem__((0, 0), 999), 1),
+])
+def test_invalid_descriptions(kz, mutate, code):
+    s = kz.scenes.cornell_box(16, 16, 1)
+    mutate(s)
+    with pytest.raises(kz.abi.KzError) as e:
+        kz.Scene(s)
+    assert e.value.code == code
+    assert len(str(e.value)) > 25        # carries a message
+
+
+def test_null_arguments(kz):
+    lib = kz.abi.load_library()
+    h = C.c_void_p()
+    assert lib.kz_scene_create(None, C.byref(h)) == kz.abi.KZ_ERR_INVALID_ARG
+    assert b"null" in lib.kz_last_error()
+    assert lib.kz_film_to_rgb(None, 4, 4, 2, None) == kz.abi.KZ_ERR_INVALID_ARG
+
+
+def test_film_to_rgb_divides_by_weight(kz):
+    lib = kz.abi.load_library()
+    film = np.zeros((8, 8, 4), np.float32)
+    film[2:6, 2:6] = (2.0, 4.0, 6.0, 2.0)
+    film[3, 3] = (1.0, 1.0, 1.0, 0.0)             # zero weight -> black (color.h:94-99)
+    rgb = np.zeros((4, 4, 3), np.float32)
+    assert lib.kz_film_to_rgb(film.ctypes.data_as(kz.abi.f32p), 4, 4, 2, rgb.ctypes.data_as(kz.abi.f32p)) == 0
+    assert np.allclose(rgb[0, 0], (1, 2, 3)) and np.allclose(rgb[1, 1], 0)
+
+
+def test_scene_generators(kz):
+    S = kz.scenes
+    assert S.sphere_env(8, 8, 1).n_tris() == 9800
+    c = S.cornell_box(8, 8, 1)
+    assert c.n_tris() == 36
+    for m in c.meshes:                            # vertex normals are unit length and every face index is valid
+        assert np.allclose(np.linalg.norm(m["N"], axis=1), 1, atol=1e-6) and m["F"].max() < len(m["V"])
+    r = S.random_triangles(800, 8, 8, 1)
+    assert r.n_tris() == 800 + 12 + 16 and sum(1 for m in r.meshes if m["light"]) == 8
+    P, N, UV, F = S.box((-1, -1, -1), (1, 1, 1), inward=True)
+    ctr = P[F].mean(axis=1)
+    assert (np.einsum("ij,ij->i", N[F[:, 0]], -ctr) > 0).all()        # inward normals point at the centre
+    pmj, bn = S.make_pmj02bn_tables()
+    assert pmj.shape == (5, 65536, 2) and bn.shape == (48, 128, 128)
+    for k in (4, 16, 64, 256, 1024):                                   # every 4^k prefix... first set: (0,2) net per axis
+        g = int(np.sqrt(k))
+        x = (pmj[0, :k, 0].astype(np.float64) / 2 ** 32 * g).astype(int)
+        y = (pmj[0, :k, 1].astype(np.float64) / 2 ** 32 * g).astype(int)
+        assert len(set(zip(x, y))) == k
+    assert float((pmj.astype(np.float64) * 2.0 ** -32).astype(np.float32).max()) < 1.0

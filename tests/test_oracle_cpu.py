@@ -1,0 +1,254 @@
+"""CPU tests of the oracle (the checker itself): pinned against the reference's own headers where they compile
+(integer KATs minted by oracle/kat_ref_main.cpp from hash.h / pcg32.h), against committed fp32 vectors, against a
+brute-force Moeller-Trumbore search, and through domain properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def kats():
+    return json.load(open(os.path.join(HERE, "golden", "int_kats.json")))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "fp_goldens.npz"))
+
+
+# ---- integer functions: bit-exact against the reference's headers ---------------------------------
+def test_hash_pixel_seed_matches_reference_header(O, kats):
+    L = O.lib()
+    for x, y, s, h in kats["hash_pixel_seed"]:
+        assert L.kzo_hash_pixel_seed(x, y, int(s)) == int(h)
+    # Hash({3,5}, u64 0) == 0xd539d46ed3159a89
+    assert L.kzo_hash_pixel_seed(3, 5, 0) == 0xd539d46ed3159a89
+
+
+def test_hash_pixel_dim_seed_matches_reference_header(O, kats):
+    L = O.lib()
+    for x, y, d, s, h in kats["hash_pixel_dim_seed"]:
+        assert L.kzo_hash_pixel_dim_seed(x, y, d, int(s)) == int(h)
+
+
+def test_murmur_all_tail_lengths(O, kats):
+    L = O.lib()
+    buf = bytes((i * 37 + 11) & 255 for i in range(40))
+    for ln, s, h in kats["murmur64a"]:
+        assert L.kzo_murmur64a(buf, ln, int(s)) == int(h), ln
+
+
+def test_mixbits(O, kats):
+    L = O.lib()
+    for v, h in kats["mixbits"]:
+        assert L.kzo_mixbits(int(v)) == int(h)
+    assert L.kzo_mixbits(42) == 0x4942410a1f55400a
+
+
+def test_pcg32_streams_bit_exact(O, kats):
+    L = O.lib()
+    for e in kats["pcg32_stream"]:
+        u = np.zeros(8, np.uint32)
+        f = np.zeros(8, np.float32)
+        L.kzo_pcg32_stream(int(e["initseq"]), int(e["delta"]), 8, u.ctypes.data_as(O.abi.u32p), f.ctypes.data_as(O.abi.f32p), None)
+        assert u.tolist() == e["u"]
+        assert f.view(np.uint32).tolist() == e["fbits"]
+    for e in kats["pcg32_seed2"]:
+        u = np.zeros(4, np.uint32)
+        L.kzo_pcg32_seed2(int(e["initstate"]), int(e["initseq"]), 4, u.ctypes.data_as(O.abi.u32p))
+        assert u.tolist() == e["u"]
+
+
+def test_survey_pcg_floats(O):
+    """SURVEY 8c probed the reference header: after seed(Hash({3,5},0)), advance(2*65536), Point2f(nextFloat(),
+    nextFloat()) printed (0.828320861, 0.502115607) under g++, i.e. x is the SECOND draw (H1)."""
+    L = O.lib()
+    u = np.zeros(2, np.uint32)
+    f = np.zeros(2, np.float32)
+    L.kzo_pcg32_stream(0xd539d46ed3159a89, 2 * 65536, 2, u.ctypes.data_as(O.abi.u32p), f.ctypes.data_as(O.abi.f32p), None)
+    assert abs(float(f[0]) - 0.502115607) < 1e-7 and abs(float(f[1]) - 0.828320861) < 1e-7
+
+
+def test_python_pcg32_equals_oracle(O, kz):
+    f = kz.scenes.pcg32_floats(1, 1000)
+    u = np.zeros(1000, np.uint32)
+    g = np.zeros(1000, np.float32)
+    O.lib().kzo_pcg32_stream(1, 0, 1000, u.ctypes.data_as(O.abi.u32p), g.ctypes.data_as(O.abi.f32p), None)
+    assert np.array_equal(f, g)
+
+
+def test_permute_is_a_bijection(O):
+    L = O.lib()
+    for l in (1, 2, 7, 16, 100, 1024):
+        for p in (0, 1, 0xdeadbeef, 0x12345678):
+            out = sorted(L.kzo_permute(i, l, p) for i in range(l))
+            assert out == list(range(l))
+
+
+def test_tea32_known_shape(O):
+    L = O.lib()
+    a, b = L.kzo_tea32(1, 2, 4), L.kzo_tea32(1, 2, 4)
+    assert a == b and a != L.kzo_tea32(2, 1, 4) and L.kzo_tea32(5, 9, 0) == (9 << 32) + 5
+
+
+# ---- fp32 functions: committed vectors + properties --------------------------------------------------
+def test_fp_goldens_reproduce(O, kz, gold):
+    """The committed vectors are regenerated bit-for-bit by the current oracle build."""
+    L = O.lib()
+    w = np.zeros(3, np.float32)
+    for i in range(0, 256, 5):
+        L.kzo_cosine_hemisphere(gold["warp_u"][i, 0], gold["warp_u"][i, 1], w.ctypes.data_as(O.abi.f32p))
+        assert np.array_equal(w, gold["warp_cos"][i])
+    S = kz.scenes
+    for tag, desc in (("ind", S.cornell_box(32, 32, 4)), ("pmj", S.cornell_box(32, 32, 4, sampler="pmj02bn", seed=1))):
+        o = O.OracleScene(desc)
+        assert np.array_equal(o.sampler_stream(3, 5, 2, 12), gold["stream_" + tag][1])
+        assert np.array_equal(o.render_samples(gold["samples_pxy"], gold["samples_idx"]), gold["samples_" + tag])
+        assert np.array_equal(o.render(threads=1), gold["film_" + tag])
+
+
+def test_cosine_hemisphere_properties(gold):
+    v = gold["warp_cos"]
+    assert np.allclose(np.linalg.norm(v, axis=1), 1.0, atol=2e-6)
+    assert (v[:, 2] > 0).all()
+    assert np.allclose(v[0], (0, 0, 1))          # centre of the square maps to the pole
+
+
+def test_frame_is_orthonormal(gold):
+    n, s, t = gold["frame_n"], gold["frame_s"], gold["frame_t"]
+    assert np.allclose(np.einsum("ij,ij->i", n, s), 0, atol=1e-6)
+    assert np.allclose(np.einsum("ij,ij->i", n, t), 0, atol=1e-6)
+    assert np.allclose(np.einsum("ij,ij->i", s, t), 0, atol=1e-6)
+    assert np.allclose(np.cross(s, t), n, atol=1e-6)          # (s, t, n) right handed
+
+
+def test_bsdf_sample_consistency(gold):
+    """sample() returns eval/pdf at the sampled direction; back-side queries are zero (bsdf.cpp:1217-1218,1302-1303)."""
+    sw = gold["bsdf_sample"]
+    assert (sw[:, 1, :3] == 0).all() and (sw[:, 1, 6] == 0).all()        # wi[1] is below the surface
+    assert (gold["bsdf_eval"][:, 1] == 0).all() and (gold["bsdf_pdf"][:, 1] == 0).all()
+    ok = sw[:, :, 6] > 0
+    assert np.isfinite(sw[ok]).all() and (sw[ok][:, :3] >= 0).all()
+    # diffuse row: weight == albedo, pdf == cos/pi
+    assert np.allclose(sw[5][ok[5]][:, :3], (0.5, 0.25, 0.125))
+    assert np.allclose(gold["bsdf_pdf"][5][2:], gold["bsdf_wo"][2:, 2] / np.pi, rtol=1e-6)
+
+
+def test_kiss_pdf_integrates_to_at_most_one(O, kz):
+    """The mixture pdf is a density over the upper hemisphere: its Monte-Carlo integral is <= 1 (+noise)."""
+    row = kz.scenes.kazenstandard((0.8, 0.8, 0.8), 0.6, 0.0, clearcoat=1.0)
+    rng = np.random.default_rng(3)
+    wi = np.array([0.3, 0.2, 0.93], np.float32)
+    wi /= np.linalg.norm(wi)
+    n = 4000
+    z = rng.random(n)
+    ph = 2 * np.pi * rng.random(n)
+    r = np.sqrt(1 - z * z)
+    wo = np.stack([r * np.cos(ph), r * np.sin(ph), z], 1).astype(np.float32)
+    est = np.mean([O.bsdf(row, "pdf", wi, w) for w in wo]) * 2 * np.pi
+    assert 0.85 < est < 1.1, est
+
+
+def test_filter_table_matches_block_cpp(gold):
+    tab = gold["filter_table"]
+    x = 2.0 * np.arange(32, dtype=np.float32) / 32
+    ref = np.maximum(0, np.exp(-2.0 * x * x) - np.exp(-8.0))       # alpha = -1/(2*0.25)
+    assert np.allclose(tab[:32], ref, rtol=1e-5, atol=1e-8) and tab[32] == 0
+
+
+def test_light_sample_geometry(gold):
+    ls = gold["light_samples"]
+    p, n, wi, pdf = ls[:, 0:3], ls[:, 3:6], ls[:, 6:9], ls[:, 9]
+    assert np.allclose(p[:, 1], 0.99, atol=1e-6) and (np.abs(p[:, 0]) <= 0.25 + 1e-6).all()
+    assert np.allclose(n, (0, -1, 0))
+    d = p - gold["light_ref"]
+    dist2 = np.sum(d * d, 1)
+    cos = -np.einsum("ij,ij->i", n, wi)
+    assert np.allclose(pdf, (1 / 0.25) * dist2 / cos, rtol=1e-5)          # light.cpp:47-48, area 0.5 x 0.5
+    assert np.allclose(ls[:, 10:13], 15.0 / pdf[:, None], rtol=1e-5)
+
+
+# ---- traversal: BVH vs brute force ---------------------------------------------------------------------
+@pytest.mark.parametrize("scene_name", ["cornell", "sphere", "soup"])
+def test_oracle_bvh_equals_brute_force(O, kz, scene_name):
+    S = kz.scenes
+    desc = {"cornell": lambda: S.cornell_box(32, 32, 1), "sphere": lambda: S.sphere_env(32, 32, 1),
+            "soup": lambda: S.random_triangles(3000, 32, 32, 1, sampler="independent", s_edge=0.15)}[scene_name]()
+    a, b = O.OracleScene(desc), O.OracleScene(desc, brute=True)
+    rng = np.random.default_rng(7)
+    n = 3000
+    o = rng.uniform(-0.95, 0.95, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:50] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 50)]        # axis-aligned rays (zero components, inf reciprocals)
+    ha, hb = a.trace_rays(o, d, 1e-3, np.inf), b.trace_rays(o, d, 1e-3, np.inf)
+    for k in ("t", "u", "v", "mesh", "prim", "p", "sh_n", "sh_s", "uv"):
+        assert np.array_equal(ha[k], hb[k], equal_nan=True), k
+    assert (ha["mesh"] >= 0).mean() > 0.3
+
+
+def test_oracle_tie_break_is_order_independent(O, kz):
+    """Two coincident triangles: the lower (mesh, face) id wins, by BVH and by brute force."""
+    s = kz.scenes.SceneDescription()
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    N = np.tile(np.array([0, 0, 1], np.float32), (3, 1))
+    F = np.array([[0, 1, 2]], np.uint32)
+    for _ in range(3):
+        s.add_mesh(V, F, N)
+    s.camera.update(width=32, height=32)
+    for brute in (False, True):
+        h = O.OracleScene(s, brute=brute).trace_rays([[0.2, 0.2, 1.0]], [[0, 0, -1]], 0, np.inf)
+        assert h["mesh"][0] == 0 and h["t"][0] == 1.0
+
+
+# ---- film -----------------------------------------------------------------------------------------------
+def test_film_weight_equals_sample_count_times_filter_mass(O, kz):
+    """Every valid sample adds the same total filter weight (sum of wx * sum of wy), whatever its radiance."""
+    desc = kz.scenes.sphere_env(48, 40, 3)
+    o = O.OracleScene(desc)
+    film = o.render(threads=2)
+    assert film.shape == (44, 52, 4) and o.stats()["droppedSamples"] == 0
+    assert film[..., 3].sum() > 0 and np.isfinite(film).all()
+    rgb = o.rgb(film)
+    assert rgb.shape == (40, 48, 3) and rgb.min() >= 0
+
+
+def test_film_tiles_sum_to_whole(O, kz):
+    desc = kz.scenes.cornell_box(64, 64, 2)
+    o = O.OracleScene(desc)
+    whole = o.render(threads=2)
+    tiles = kz.shard.make_tiles(64, 64, 32)
+    parts = [o.render(tiles=kz.shard.tiles_for_rank(tiles, r, 2), threads=2) for r in range(2)]
+    assert np.allclose(kz.shard.merge_films(parts), whole, rtol=1e-6, atol=1e-7)
+
+
+def test_sample_ranges_add_up(O, kz):
+    desc = kz.scenes.cornell_box(32, 32, 4)
+    o = O.OracleScene(desc)
+    whole = o.render(threads=1)
+    acc = o.render(0, 2, threads=1)
+    o.render(2, 4, threads=1, film=acc)
+    assert np.allclose(acc, whole, rtol=1e-6, atol=1e-7)
+
+
+def test_pmj02bn_pixel_samples_are_stratified(O, kz):
+    """nextPixel2D of the 16 samples of a pixel falls in the 16 cells of a 4x4 grid (the (0,2) property the
+    PMJ02BN constructor relies on, sampler.cpp:295-314)."""
+    desc = kz.scenes.cornell_box(32, 32, 16, sampler="pmj02bn", seed=1)
+    o = O.OracleScene(desc)
+    for px, py in ((0, 0), (5, 9), (31, 31)):
+        j = np.array([o.sampler_stream(px, py, i, 0)[:2] for i in range(16)])
+        cells = set((int(x * 4), int(y * 4)) for x, y in j)
+        assert len(cells) == 16 and (j >= 0).all() and (j < 1).all()
+
+
+def test_unsupported_plugins_are_errors(O, kz):
+    s = kz.scenes.cornell_box(16, 16, 1)
+    s.sampler["type"] = "stratified"
+    with pytest.raises(kz.abi.KzError) as e:
+        O.OracleScene(s)
+    assert e.value.code == kz.abi.KZ_ERR_UNSUPPORTED
