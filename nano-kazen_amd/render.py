@@ -121,8 +121,9 @@ class Scene:
 
 def hits_to_arrays(hits, n):
     raw = np.frombuffer(hits, dtype=np.uint8).reshape(n, C.sizeof(abi.KzHit))
-    f = raw.view(np.float32).reshape(n, -1)
-    i = raw.view(np.int32).reshape(n, -1)
+    w = C.sizeof(abi.KzHit) // 4
+    f = raw.view(np.float32).reshape(n, w)
+    i = raw.view(np.int32).reshape(n, w)
     return {"t": f[:, 0].copy(), "u": f[:, 1].copy(), "v": f[:, 2].copy(), "mesh": i[:, 3].copy(), "prim": i[:, 4].copy(),
             "p": f[:, 5:8].copy(), "uv": f[:, 8:10].copy(), "sh_s": f[:, 10:13].copy(), "sh_t": f[:, 13:16].copy(),
             "sh_n": f[:, 16:19].copy(), "geo_n": f[:, 19:22].copy()}
