@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include "kz_internal.h"
+#include "kz_devfn.h"
+#include "kz_wavefront.h"
 
 #include <algorithm>
 #include <cmath>
@@ -18,589 +20,6 @@
 #include <cstring>
 #include <vector>
 
-#define KZ_BLOCK 256
-#define KZ_INF __builtin_huge_valf()
-
-// ============================================================================================
-// small vector math (explicit, so operation order is visible; compiled with -ffp-contract=off)
-// ============================================================================================
-struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 mk(float a) { return mk(a, a, a); }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ float norm(V3 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ V3 normalized(V3 a) { float n2 = dot(a, a); return n2 > 0.f ? a / sqrtf(n2) : a; }   // Eigen normalized()
-__device__ __forceinline__ float maxCoeff(V3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
-__device__ __forceinline__ float sqr(float x) { return x * x; }
-
-#define KZ_EPSILON 1e-5f                      // common.h:27
-#define KZ_ONE_MINUS_EPS 0x1.fffffep-1f       // common.h:28
-#define KZ_INV_PI 0.31830988618379067154f     // common.h:34
-#define KZ_PI_F 3.14159265358979323846f
-
-struct Counters { uint32_t rays, nodes, tris, hits, lsamples, dropped; };
-
-// ============================================================================================
-// a6/a7/a8 integer sampler plumbing (hash.h:15-65,71-78,100-108; pcg32.h:54-73,108-117; common.cpp:316-344)
-// ============================================================================================
-#define MURMUR_M 0xc6a4a7935bd1e995ull
-__device__ __forceinline__ uint64_t murmurBlock(uint64_t h, uint64_t k) {
-    k *= MURMUR_M; k ^= k >> 47; k *= MURMUR_M;
-    h ^= k; h *= MURMUR_M;
-    return h;
-}
-__device__ __forceinline__ uint64_t murmurFinish(uint64_t h) { h ^= h >> 47; h *= MURMUR_M; h ^= h >> 47; return h; }
-// Hash(Point2i p, uint64 seed): 16-byte key, seed 0 (sampler.cpp:44)
-__device__ __forceinline__ uint64_t hashPixelSeed(int px, int py, uint64_t seed) {
-    uint64_t h = 16ull * MURMUR_M;
-    h = murmurBlock(h, (uint64_t)(uint32_t)px | ((uint64_t)(uint32_t)py << 32));
-    h = murmurBlock(h, seed);
-    return murmurFinish(h);
-}
-// Hash(Point2i p, uint32 dim, uint64 seed): 20-byte key (sampler.cpp:341,355)
-__device__ __forceinline__ uint64_t hashPixelDimSeed(int px, int py, uint32_t dim, uint64_t seed) {
-    uint64_t h = 20ull * MURMUR_M;
-    h = murmurBlock(h, (uint64_t)(uint32_t)px | ((uint64_t)(uint32_t)py << 32));
-    h = murmurBlock(h, (uint64_t)dim | ((seed & 0xffffffffull) << 32));
-    h ^= (seed >> 32);            // the 4 tail bytes
-    h *= MURMUR_M;
-    return murmurFinish(h);
-}
-__device__ __forceinline__ uint64_t mixBits(uint64_t v) {
-    v ^= (v >> 31); v *= 0x7fb5d329728ea185ull; v ^= (v >> 27); v *= 0x81dadef4bc2dd44dull; v ^= (v >> 33);
-    return v;
-}
-#define PCG32_MULT 0x5851f42d4c957f2dULL
-__device__ __forceinline__ uint32_t permuteIdx(uint32_t i, uint32_t l, uint32_t p) {
-    uint32_t w = l - 1;
-    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
-    do {
-        i ^= p; i *= 0xe170893d; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8;
-        i *= 0x0929eb3f; i ^= p >> 23; i ^= (i & w) >> 1; i *= 1 | p >> 27;
-        i *= 0x6935fa69; i ^= (i & w) >> 11; i *= 0x74dcb303; i ^= (i & w) >> 2;
-        i *= 0x9e501cc3; i ^= (i & w) >> 2; i *= 0xc860a3df; i &= w; i ^= i >> 5;
-    } while (i >= l);
-    return (i + p) % l;
-}
-
-// a4/a5/a9 Sampler (sampler.cpp:18-71 independent, :273-390 pmj02bn). Draw order H1 (GCC, right-to-left
-// argument evaluation): Independent::next2D draws y first; bsdf->sample(bRec, next1D(), next2D()) draws the
-// 2-D sample first — both written as sequenced statements at the call sites.
-struct Sampler {
-    uint64_t state, inc;            // independent: pcg32
-    int px, py; uint32_t idx, dim;  // pmj02bn
-    int type;
-
-    __device__ __forceinline__ uint32_t nextUInt() {
-        uint64_t old = state;
-        state = old * PCG32_MULT + inc;
-        uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
-        uint32_t rot = (uint32_t)(old >> 59u);
-        return (xs >> rot) | (xs << ((~rot + 1u) & 31));
-    }
-    __device__ __forceinline__ float nextFloat() { return __uint_as_float((nextUInt() >> 9) | 0x3f800000u) - 1.0f; }
-    __device__ void generateSample(const KzParams &P, const KzDevTables &T, int x, int y, uint32_t sampleIndex) {
-        px = x; py = y; idx = sampleIndex;
-        if (type == KZ_SAMPLER_INDEPENDENT) {
-            uint64_t h = hashPixelSeed(x, y, P.seed);
-            // pcg32::seed(initseq) = seed(MixBits(initseq), initseq)
-            inc = (h << 1u) | 1u;
-            state = inc;                       // state = 0*MULT + inc
-            state += mixBits(h);
-            state = state * PCG32_MULT + inc;
-            // advance(sampleIndex * 65536 + 0) through the tabulated affine jump
-            KzPcgJump j = T.jump[sampleIndex];
-            state = j.mult * state + inc * j.plus;
-        } else {
-            dim = 2;                           // max(2, dimension=0)
-        }
-    }
-    __device__ __forceinline__ float blueNoise(const KzDevTables &T, uint32_t tex) const {            // bluenoise.h:16-23
-        uint32_t t = tex % KZ_BLUENOISE_TEXTURES;
-        uint32_t x = (uint32_t)px % KZ_BLUENOISE_RES, y = (uint32_t)py % KZ_BLUENOISE_RES;
-        return (float)T.bn[(t * KZ_BLUENOISE_RES + x) * KZ_BLUENOISE_RES + y] / 65535.f;
-    }
-    __device__ float next1D(const KzParams &P, const KzDevTables &T) {
-        if (type == KZ_SAMPLER_INDEPENDENT) return nextFloat();
-        uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
-        int index = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h);
-        float delta = blueNoise(T, dim);
-        ++dim;
-        return fminf(((float)index + delta) / (float)P.sampleCount, KZ_ONE_MINUS_EPS);
-    }
-    __device__ void next2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
-        if (type == KZ_SAMPLER_INDEPENDENT) { y = nextFloat(); x = nextFloat(); return; }
-        uint32_t index = idx;
-        uint32_t inst = dim / 2;
-        if (inst >= KZ_PMJ02BN_SETS) {
-            uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
-            index = permuteIdx(idx, P.sampleCount, (uint32_t)h);
-        }
-        inst %= KZ_PMJ02BN_SETS; index %= KZ_PMJ02BN_SAMPLES;
-        const uint2 e = *reinterpret_cast<const uint2 *>(T.pmj + ((size_t)inst * KZ_PMJ02BN_SAMPLES + index) * 2);
-        float ux = (float)((double)e.x * 0x1p-32), uy = (float)((double)e.y * 0x1p-32);     // pmj02table.h:28-29 (double, then narrowed)
-        ux += blueNoise(T, dim); uy += blueNoise(T, dim + 1);
-        if (ux >= 1) ux -= 1;
-        if (uy >= 1) uy -= 1;
-        dim += 2;
-        x = fminf(ux, KZ_ONE_MINUS_EPS); y = fminf(uy, KZ_ONE_MINUS_EPS);
-    }
-    __device__ void nextPixel2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
-        if (type == KZ_SAMPLER_INDEPENDENT) { next2D(P, T, x, y); return; }
-        int tile = P.pixelTileSize;
-        int tx = px % tile, ty = py % tile;
-        size_t off = (size_t)(tx + ty * tile) * P.sampleCount + idx;
-        const float2 v = *reinterpret_cast<const float2 *>(T.pixelSamples + 2 * off);
-        x = v.x; y = v.y;
-    }
-};
-
-// ============================================================================================
-// a13 traversal: closest hit (replaces rtcIntersect1, accel.cpp:98), a15 Moeller-Trumbore leaf test
-// (mesh.cpp:55-92), a16 slab node test (bbox.h:316-343; conservative form on padded boxes).
-// ============================================================================================
-struct RawHit { float t, u, v; uint32_t tri; uint32_t gid; };
-
-template <bool STATS>
-__device__ __forceinline__ bool closestHit(const KzDevTables &T, uint32_t rootRef, V3 o, V3 d, float tmin, float tmax,
-                                           RawHit &best, uint32_t *stk, Counters &cn) {
-    bool found = false;
-    best.t = KZ_INF; best.u = best.v = 0.f; best.tri = 0; best.gid = 0;
-    if (STATS) cn.rays++;
-    if (rootRef == 0xFFFFFFFFu) return false;
-    // A ray with a non-finite origin or direction can hit nothing (every Moeller-Trumbore comparison fails on NaN),
-    // but fminf/fmaxf would let it pass EVERY slab test: one such lane would walk the whole tree. Miss at once.
-    if (!(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z) < KZ_INF)) return false;
-    const float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;      // ray.h:56-58 cwiseInverse
-    uint32_t cur = rootRef;
-    int sp = 0;
-    for (;;) {
-        if (cur & 0x80000000u) {
-            uint32_t start = (cur & 0x7fffffffu) >> 3, count = (cur & 7u) + 1;
-            for (uint32_t i = 0; i < count; ++i) {
-                const float4 *tp = reinterpret_cast<const float4 *>(T.tris + start + i);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                if (STATS) cn.tris++;
-                const V3 p0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
-                // Mesh::rayIntersect, operation for operation
-                V3 pvec = cross(d, e2);
-                float det = dot(e1, pvec);
-                if (det > -1e-8f && det < 1e-8f) continue;
-                float inv_det = 1.0f / det;
-                V3 tvec = o - p0;
-                float u = dot(tvec, pvec) * inv_det;
-                if (u < 0.0f || u > 1.0f) continue;
-                V3 qvec = cross(tvec, e1);
-                float v = dot(d, qvec) * inv_det;
-                if (v < 0.0f || u + v > 1.0f) continue;
-                float t = dot(e2, qvec) * inv_det;
-                if (!(t >= tmin && t <= tmax)) continue;
-                uint32_t gid = __float_as_uint(c.w);
-                // ties on t go to the lower global triangle id: order independent (Embree's tie rule is unspecified)
-                if (!found || t < best.t || (t == best.t && gid < best.gid)) {
-                    found = true; best.t = t; best.u = u; best.v = v; best.tri = start + i; best.gid = gid; tmax = t;
-                }
-            }
-            if (sp == 0) break;
-            cur = stk[(--sp) * KZ_BLOCK];
-            continue;
-        }
-        const float4 *np = reinterpret_cast<const float4 *>(T.nodes + cur);
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-        const uint4 q3 = *reinterpret_cast<const uint4 *>(np + 3);
-        if (STATS) cn.nodes++;
-        // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
-        float t0, t1, n0, f0, n1, f1;
-        t0 = (q0.x - o.x) * rx; t1 = (q0.w - o.x) * rx; n0 = fminf(t0, t1); f0 = fmaxf(t0, t1);
-        t0 = (q0.y - o.y) * ry; t1 = (q1.x - o.y) * ry; n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
-        t0 = (q0.z - o.z) * rz; t1 = (q1.y - o.z) * rz; n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
-        t0 = (q1.z - o.x) * rx; t1 = (q2.y - o.x) * rx; n1 = fminf(t0, t1); f1 = fmaxf(t0, t1);
-        t0 = (q1.w - o.y) * ry; t1 = (q2.z - o.y) * ry; n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
-        t0 = (q2.x - o.z) * rz; t1 = (q2.w - o.z) * rz; n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
-        // fminf/fmaxf drop NaNs (0 * inf on a degenerate axis): the slab then does not constrain, which is conservative.
-        f0 *= 1.0000004f; f1 *= 1.0000004f;
-        const bool h0 = (fmaxf(n0, tmin) <= fminf(f0, tmax));
-        const bool h1 = (fmaxf(n1, tmin) <= fminf(f1, tmax));
-        if (h0 && h1) {
-            const bool swap = n1 < n0;
-            const uint32_t nearC = swap ? q3.y : q3.x, farC = swap ? q3.x : q3.y;
-            stk[(sp++) * KZ_BLOCK] = farC;
-            cur = nearC;
-        } else if (h0) cur = q3.x;
-        else if (h1) cur = q3.y;
-        else {
-            if (sp == 0) break;
-            cur = stk[(--sp) * KZ_BLOCK];
-        }
-    }
-    return found;
-}
-
-// ============================================================================================
-// a14 post-intersection (accel.cpp:113-236) + a17 Frame (frame.h:14-51, common.cpp:436-445)
-// ============================================================================================
-struct Frame3 { V3 s, t, n; };
-__device__ __forceinline__ Frame3 frameFromNormal(V3 a) {
-    Frame3 f; f.n = a;
-    V3 c;
-    if (fabsf(a.x) > fabsf(a.y)) { float invLen = 1.0f / sqrtf(a.x * a.x + a.z * a.z); c = mk(a.z * invLen, 0.0f, -a.x * invLen); }
-    else { float invLen = 1.0f / sqrtf(a.y * a.y + a.z * a.z); c = mk(0.0f, a.z * invLen, -a.y * invLen); }
-    f.t = c; f.s = cross(c, a);
-    return f;
-}
-__device__ __forceinline__ V3 toLocal(const Frame3 &f, V3 v) { return mk(dot(v, f.s), dot(v, f.t), dot(v, f.n)); }
-__device__ __forceinline__ V3 toWorld(const Frame3 &f, V3 v) { return f.s * v.x + f.t * v.y + f.n * v.z; }
-
-struct Its {
-    V3 p; float t; float uvx, uvy; Frame3 sh; V3 geoN; uint32_t mesh; uint32_t prim; float bu, bv;
-};
-
-template <bool GEO>
-__device__ __forceinline__ void postIntersect(const KzDevTables &T, const RawHit &rh, Its &its) {
-    const float4 *tp = reinterpret_cast<const float4 *>(T.tris + rh.tri);
-    const float4 c = tp[2];
-    const uint32_t mesh = __float_as_uint(c.y);
-    its.mesh = mesh; its.prim = __float_as_uint(c.z); its.t = rh.t; its.bu = rh.u; its.bv = rh.v;
-    const uint32_t flags = T.meshes[mesh].flags;
-    const bool hasN = flags & 1u, hasUV = flags & 2u;
-    const float4 *sp = reinterpret_cast<const float4 *>(T.shade + rh.gid);
-    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];
-    const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
-    const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
-    const float uv0x = s4.z, uv0y = s4.w, uv1x = s5.x, uv1y = s5.y, uv2x = s5.z, uv2y = s5.w;
-    const float bx = 1 - (rh.u + rh.v), by = rh.u, bz = rh.v;                 // accel.cpp:122-123
-    const V3 orignP = bx * p0 + by * p1 + bz * p2;                            // accel.cpp:142
-    if (hasN) {                                                               // Hanika terminator offset, accel.cpp:144-153
-        V3 tu = orignP - p0, tv = orignP - p1, tw = orignP - p2;
-        float du = fminf(0.f, dot(tu, n0)), dv = fminf(0.f, dot(tv, n1)), dw = fminf(0.f, dot(tw, n2));
-        tu = tu - du * n0; tv = tv - dv * n1; tw = tw - dw * n2;
-        its.p = orignP + bx * tu + by * tv + bz * tw;
-    } else its.p = orignP;                                                    // H4: the reference is UB without normals
-    const V3 dp0 = p1 - p0, dp1 = p2 - p0;
-    const V3 gx = cross(dp0, dp1);
-    V3 geoN = mk(0.f);
-    if (GEO || !hasN) geoN = normalized(gx);                                  // accel.cpp:156-158
-    its.geoN = geoN;
-    its.uvx = rh.u; its.uvy = rh.v;
-    if (hasUV) { its.uvx = bx * uv0x + by * uv1x + bz * uv2x; its.uvy = bx * uv0y + by * uv1y + bz * uv2y; }   // accel.cpp:161-164
-    if (hasN) {
-        const V3 shN = bx * n0 + by * n1 + bz * n2;
-        bool tangent = false;
-        if (hasUV) {                                                          // accel.cpp:166-217
-            const float duv0x = uv1x - uv0x, duv0y = uv1y - uv0y, duv1x = uv2x - uv0x, duv1y = uv2y - uv0y;
-            const float length = norm(gx);
-            const float determinant = duv0x * duv1y - duv0y * duv1x;
-            if (length > 0.f && determinant > 0.f) {
-                const float invDet = 1.0f / determinant;
-                const V3 dpdu = (duv1y * dp0 - duv0y * dp1) * invDet;
-                its.sh.n = normalized(shN);
-                its.sh.s = normalized(dpdu - shN * dot(shN, dpdu));
-                its.sh.t = normalized(cross(its.sh.n, its.sh.s));
-                tangent = true;
-            }
-        }
-        if (!tangent) its.sh = frameFromNormal(normalized(shN));              // accel.cpp:203-229
-    } else its.sh = frameFromNormal(geoN);                                    // accel.cpp:231-233
-}
-
-// ============================================================================================
-// a23 warp, a22 GGX helpers, a20 diffuse, a21 kiss (warp.cpp:85-115; ggx_brdf.h; bsdf.cpp:27-75, :1215-1371)
-// ============================================================================================
-__device__ __forceinline__ V3 squareToCosineHemisphere(float sx, float sy) {
-    float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f;
-    float phi, r;
-    if (r1 == 0 && r2 == 0) { r = phi = 0; }
-    else if (r1 * r1 > r2 * r2) { r = r1; phi = (KZ_PI_F / 4.0f) * (r2 / r1); }
-    else { r = r2; phi = (KZ_PI_F / 2.0f) - (r1 / r2) * (KZ_PI_F / 4.0f); }
-    float sinPhi = sinf(phi), cosPhi = cosf(phi);
-    float px = r * cosPhi, py = r * sinPhi;
-    float z = sqrtf(1.0f - px * px - py * py);
-    if (z == 0) z = 1e-10f;
-    return mk(px, py, z);
-}
-struct A2 { float x, y; };
-__device__ __forceinline__ V3 schlickFresnel(V3 f0, float cosTheta) {            // ggx_brdf.h:15-24
-    float t = powf(1.0f - cosTheta, 5.0f);
-    return f0 * 1.0f + (mk(1.f) - f0) * t;
-}
-__device__ __forceinline__ A2 roughnessToAlpha(float roughness, float anisotropy) {   // ggx_brdf.h:28-37
-    float alpha = fmaxf(0.001f, sqr(roughness));
-    A2 a; a.x = alpha * (1.0f + anisotropy); a.y = alpha * (1.0f - anisotropy);
-    return a;
-}
-__device__ __forceinline__ float ggxLambda(V3 v, A2 a) {                          // ggx_brdf.h:41-45
-    float squared = (sqr(a.x) * sqr(v.x) + sqr(a.y) * sqr(v.y)) / sqr(v.z);
-    return (-1.0f + sqrtf(1.0f + squared)) * 0.5f;
-}
-__device__ __forceinline__ float smithG1(V3 V, V3 H, A2 a) { return dot(V, H) <= 0.0f ? 0.0f : 1.0f / (1.0f + ggxLambda(V, a)); }
-__device__ __forceinline__ float smithG2(V3 V, V3 L, V3 H, A2 a) {
-    if (dot(V, H) <= 0.0f || dot(L, H) < 0.0f) return 0.0f;
-    return 1.0f / (1.0f + ggxLambda(V, a) + ggxLambda(L, a));
-}
-__device__ __forceinline__ float ggxNDF(V3 H, A2 a) {                             // ggx_brdf.h:71-75
-    float ellipse = sqr(H.x) / sqr(a.x) + sqr(H.y) / sqr(a.y) + sqr(H.z);
-    return 1.0f / (KZ_PI_F * a.x * a.y * sqr(ellipse));
-}
-__device__ __forceinline__ float ggxVNDF(V3 V, V3 H, A2 a) {                      // ggx_brdf.h:80-91
-    float VDotH = dot(V, H);
-    if (VDotH <= 0.0f) return 0.0f;
-    return ggxNDF(H, a) * smithG1(V, H, a) * VDotH / V.z;
-}
-__device__ __forceinline__ V3 sampleGGXVNDF(V3 V, A2 a, float rx, float ry) {     // ggx_brdf.h:96-120
-    V3 Vh = normalized(mk(a.x * V.x, a.y * V.y, V.z));
-    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
-    V3 T1 = lensq > 0.0f ? mk(-Vh.y, Vh.x, 0.0f) / sqrtf(lensq) : mk(1.0f, 0.0f, 0.0f);
-    V3 T2 = normalized(cross(Vh, T1));
-    float r = sqrtf(rx);
-    float phi = 2.0f * KZ_PI_F * ry;
-    float t1 = r * cosf(phi), t2 = r * sinf(phi);
-    float s = 0.5f * (1.0f + Vh.z);
-    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
-    V3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
-    return normalized(mk(a.x * Nh.x, a.y * Nh.y, fmaxf(1e-6f, Nh.z)));
-}
-__device__ __forceinline__ V3 evalGGXSmithBRDF(V3 V, V3 L, V3 f0, float roughness, float anisotropy) {   // ggx_brdf.h:151-170
-    if (V.z * L.z < 0.0f) return mk(0.0f);
-    A2 a = roughnessToAlpha(roughness, anisotropy);
-    V3 H = normalized(V + L);
-    float D = ggxNDF(H, a), G = smithG2(V, L, H, a);
-    V3 F = schlickFresnel(f0, dot(V, H));
-    float denom = 4.0f * fabsf(V.z) * fabsf(L.z);
-    return (D * G) * F / denom;
-}
-__device__ __forceinline__ float lerpf(float t, float a, float b) { return (1.f - t) * a + t * b; }
-__device__ __forceinline__ V3 lerp3(V3 a, V3 b, float t) { return (1.f - t) * a + t * b; }
-__device__ __forceinline__ float schlickWeight(float x) { x = fminf(fmaxf(1.f - x, 0.f), 1.f); float x2 = x * x; return x2 * x2 * x; }
-__device__ __forceinline__ float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
-__device__ __forceinline__ V3 reflectV(V3 wi, V3 n) { return 2 * dot(n, wi) * n - wi; }
-
-__device__ V3 kissEval(const KzBSDF &m, V3 V, V3 L, float accRough) {            // bsdf.cpp:1215-1267
-    if (V.z <= 0 || L.z <= 0) return mk(0.f);
-    V3 H = normalized(V + L);
-    V3 Cdlin = mk(m.baseColor[0], m.baseColor[1], m.baseColor[2]);
-    float metallic = m.metallic;
-    float roughness = fminf(1.f, m.roughness + accRough);
-    float Cdlum = luminance(Cdlin);
-    V3 Ctint = Cdlum > 0.f ? Cdlin / Cdlum : mk(1.f);
-    V3 Ctintmix = 0.08f * m.specular * lerp3(mk(1.f), Ctint, m.specularTint);
-    V3 Cspec0 = lerp3(Ctintmix, Cdlin, metallic);
-    float FL = schlickWeight(L.z), FV = schlickWeight(V.z), FH = schlickWeight(dot(L, H));
-    float cosThetaD = dot(V, H);
-    float Lambert = (1.f - 0.5f * FL) * (1.f - 0.5f * FV);
-    float RR = 2.f * roughness * cosThetaD * cosThetaD;
-    float retro = RR * (FL + FV + FL * FV * (RR - 1.f));
-    V3 Csheen = lerp3(mk(1.f), Ctint, m.sheenTint);
-    V3 Fsheen = FH * m.sheen * Csheen;
-    V3 specTerm = evalGGXSmithBRDF(V, L, Cspec0, roughness, m.anisotropy);
-    float ccR = lerpf(m.clearcoatRoughness, .01f, .3f);
-    V3 coatTerm = 0.25f * m.clearcoat * evalGGXSmithBRDF(V, L, mk(0.04f), ccR, m.anisotropy);
-    return ((1.f - metallic) * (Cdlin * KZ_INV_PI * (Lambert + retro) + Fsheen) + (specTerm + coatTerm)) * L.z;
-}
-__device__ float kissPdf(const KzBSDF &m, V3 wi, V3 wo, float accRough) {        // bsdf.cpp:1269-1299
-    if (wi.z <= 0 || wo.z <= 0) return 0.f;
-    float diffuse = (1.f - m.metallic) * 0.5f;
-    float GTR2 = 1.f / (1.f + m.clearcoat);
-    V3 H = normalized(wi + wo);
-    float jacobian = 4.0f * dot(wi, H);
-    float roughness = fminf(1.f, m.roughness + accRough);
-    float specPdf = ggxVNDF(wi, H, roughnessToAlpha(roughness, m.anisotropy)) / jacobian;
-    float coatPdf = ggxVNDF(wi, H, roughnessToAlpha(lerpf(m.clearcoatRoughness, .01f, .3f), 0.f)) / jacobian;
-    return diffuse * KZ_INV_PI * wo.z + (1.f - diffuse) * (GTR2 * specPdf + (1.f - GTR2) * coatPdf);
-}
-// returns the sample weight; wo is the sampled direction; alive=false when the path contributes nothing further
-__device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive) {
-    wo = mk(0.f, 0.f, 1.f);
-    if (wi.z <= 0) { alive = false; return mk(0.f); }                              // bsdf.cpp:60-61, :1302-1303
-    alive = true;
-    if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:59-75
-        wo = squareToCosineHemisphere(s2x, s2y);
-        return mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-    }
-    float diffuse = (1.f - m.metallic) * 0.5f;                                     // bsdf.cpp:1301-1371
-    if (s1 < diffuse) wo = squareToCosineHemisphere(s2x, s2y);
-    else {
-        float sample = (s1 - diffuse) / (1.f - diffuse);
-        float GTR2 = 1.f / (1.f + m.clearcoat);
-        A2 alpha = (sample < GTR2) ? roughnessToAlpha(m.roughness, m.anisotropy)   // H7: un-regularised roughness, anisotropy 0 for the coat
-                                   : roughnessToAlpha(lerpf(m.clearcoatRoughness, 0.01f, .3f), 0.f);
-        V3 H = sampleGGXVNDF(wi, alpha, s2x, s2y);                                 // wi.z > 0 here: never flipped
-        wo = normalized(reflectV(wi, H));
-    }
-    bool invalid = isnan(wo.x) || isnan(wo.y) || isnan(wo.z);
-    float pdf = kissPdf(m, wi, wo, accRough);
-    if (wo.z <= 0 || pdf <= KZ_EPSILON || invalid) return mk(0.f);
-    return kissEval(m, wi, wo, accRough) / pdf;
-}
-__device__ __forceinline__ V3 bsdfEval(const KzBSDF &m, V3 wi, V3 wo, float accRough) {
-    if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:27-37 (measure is ESolidAngle at every call site)
-        if (wi.z <= 0 || wo.z <= 0) return mk(0.f);
-        return mk(m.albedo[0], m.albedo[1], m.albedo[2]) * KZ_INV_PI * wo.z;
-    }
-    return kissEval(m, wi, wo, accRough);
-}
-__device__ __forceinline__ float bsdfPdf(const KzBSDF &m, V3 wi, V3 wo, float accRough) {
-    if (m.type == KZ_BSDF_DIFFUSE) { if (wi.z <= 0 || wo.z <= 0) return 0.f; return KZ_INV_PI * wo.z; }   // bsdf.cpp:40-56
-    return kissPdf(m, wi, wo, accRough);
-}
-
-// ============================================================================================
-// a18/a19 lights (light.cpp:16-51, mesh.cpp:108-133, dpdf.h:99-104)
-// ============================================================================================
-__device__ __forceinline__ float lightPdfSolidAngle(float meshPdf, V3 n, V3 wi, V3 p, V3 ref) {    // light.cpp:36-51
-    float cosTheta = dot(n, -wi);
-    if (cosTheta > 0.f) { V3 dd = p - ref; return meshPdf * dot(dd, dd) / cosTheta; }
-    return 0.f;
-}
-__device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, float v) {              // dpdf.h:99-104 (n entries, n+1 floats)
-    // std::lower_bound over cdf[0..n]: first element >= v
-    uint32_t lo = 0, len = n + 1;
-    while (len > 0) {
-        uint32_t half = len >> 1, mid = lo + half;
-        if (cdf[mid] < v) { lo = mid + 1; len -= half + 1; } else len = half;
-    }
-    int idx = (int)lo - 1;
-    if (idx < 0) idx = 0;
-    return min((uint32_t)idx, n - 1);
-}
-
-__device__ __forceinline__ float powerHeuristic(float a, float b) { a *= a; b *= b; return a > 0.f ? a / (a + b) : 0.f; }   // integrator.cpp:340-344
-
-// a3 PerspectiveCamera::sampleRay (camera.cpp:70-91, transform.h:49-62)
-__device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy, V3 &o, V3 &d, float &mint, float &maxt) {
-    const float *m = P.s2c;
-    float x = sx * P.invW, y = sy * P.invH;
-    float rx = m[0] * x + m[1] * y + m[2] * 0.0f + m[3];
-    float ry = m[4] * x + m[5] * y + m[6] * 0.0f + m[7];
-    float rz = m[8] * x + m[9] * y + m[10] * 0.0f + m[11];
-    float rw = m[12] * x + m[13] * y + m[14] * 0.0f + m[15];
-    V3 dl = normalized(mk(rx / rw, ry / rw, rz / rw));
-    float invZ = 1.0f / dl.z;
-    const float *w = P.c2w;
-    float ow = w[15];
-    o = mk(w[3] / ow, w[7] / ow, w[11] / ow);
-    d = mk(w[0] * dl.x + w[1] * dl.y + w[2] * dl.z, w[4] * dl.x + w[5] * dl.y + w[6] * dl.z, w[8] * dl.x + w[9] * dl.y + w[10] * dl.z);
-    mint = P.nearClip * invZ; maxt = P.farClip * invZ;
-}
-
-// ============================================================================================
-// a10 PathMisIntegrator::Li (integrator.cpp:195-338) — megakernel form, one lane per path
-// ============================================================================================
-template <bool STATS>
-__device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 ro, V3 rd, float rmint, float rmaxt,
-                     uint32_t *stk, Counters &cn) {
-    const float eps = P.traceBias;
-    V3 L = mk(0.f), throughput = mk(1.f);
-    float eta = 1.f, bsdfWeight = 1.f, accRough = 0.f;
-    RawHit rh; Its its;
-    if (!closestHit<STATS>(T, P.rootRef, ro, rd, rmint, rmaxt, rh, stk, cn)) return L;       // H5: primary miss is black
-    postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
-    {
-        int li = T.meshes[its.mesh].light;
-        if (li >= 0 && !T.lights[li].primaryVisibility) {                                     // integrator.cpp:214-219 (H6)
-            V3 no = its.p + eps * rd;
-            if (closestHit<STATS>(T, P.rootRef, no, rd, KZ_EPSILON, KZ_INF, rh, stk, cn)) { postIntersect<false>(T, rh, its); if (STATS) cn.hits++; }
-        }
-    }
-    int depth = 0;
-    while (depth < P.maxDepth) {
-        const KzMeshRow mrow = T.meshes[its.mesh];
-        if (mrow.light >= 0) {                                                                // integrator.cpp:226-231
-            const KzLightRow &lr = T.lights[mrow.light];
-            V3 wi = normalized(its.p - ro);
-            if (dot(its.sh.n, -wi) > 0.f) L = L + (bsdfWeight * throughput) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
-            break;
-        }
-        if (depth >= 3) {                                                                     // integrator.cpp:237-244
-            float probability = fminf(maxCoeff(throughput) * eta * eta, 0.95f);
-            if (probability <= smp.next1D(P, T)) break;
-            throughput = throughput / probability;
-        }
-        const KzBSDF bsdf = T.bsdfs[mrow.bsdf];
-        const V3 wiLocal = toLocal(its.sh, -rd);
-        // ---- light sampling (integrator.cpp:247-295); the pick is drawn even when there are no lights
-        float pick = smp.next1D(P, T);
-        if (P.nLights > 0) {
-            uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
-            const KzLightRow lrow = T.lights[li];
-            if (STATS) cn.lsamples++;
-            // Mesh::sample: three 1-D draws
-            uint32_t tri = cdfSample(T.cdf + lrow.cdfOffset, lrow.nF, smp.next1D(P, T));
-            float su0 = sqrtf(smp.next1D(P, T));
-            float u = 1 - su0;
-            float v = smp.next1D(P, T) * su0;
-            const float4 *sp = reinterpret_cast<const float4 *>(T.shade + lrow.triOffset + tri);
-            const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-            const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
-            V3 lp = p0 + u * (p1 - p0) + v * (p2 - p0);
-            V3 ln;
-            if (T.meshes[lrow.mesh].flags & 1u) {
-                const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
-                ln = n0 + u * (n1 - n0) + v * (n2 - n0);                                      // H8: not normalised
-            } else ln = normalized(cross(p1 - p0, p2 - p0));
-            V3 toL = lp - its.p;
-            V3 lwi = normalized(toL);
-            float dist = norm(toL);
-            float lpdf = lightPdfSolidAngle(lrow.normalization, ln, lwi, lp, its.p);
-            V3 Ls = mk(0.f);
-            if (lpdf > 0.f && !isnan(lpdf) && !isinf(lpdf)) {
-                V3 ev = dot(ln, -lwi) > 0.f ? mk(lrow.radiance[0], lrow.radiance[1], lrow.radiance[2]) : mk(0.f);
-                Ls = ev / lpdf;
-            }
-            Ls = Ls / P.lightPickPdf;
-            // shadow ray with the invisible-light walk-through (integrator.cpp:257-278); closest-hit, like the reference
-            bool occluded = false;
-            V3 so = its.p; float smin = eps, smax = dist - eps;
-            for (;;) {
-                RawHit sh;
-                if (!closestHit<STATS>(T, P.rootRef, so, lwi, smin, smax, sh, stk, cn)) break;
-                uint32_t om = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + sh.tri)[2].y);
-                int ol = T.meshes[om].light;
-                if (ol < 0 || T.lights[ol].primaryVisibility) { occluded = true; break; }
-                so = so + lwi * (sh.t + eps); smin = eps; smax = smax - sh.t;
-            }
-            if (!occluded) {
-                V3 woLocal = toLocal(its.sh, lwi);
-                V3 f = bsdfEval(bsdf, wiLocal, woLocal, accRough);
-                float bpdf = bsdfPdf(bsdf, wiLocal, woLocal, accRough);
-                float lightWeight = powerHeuristic(lpdf, bpdf);
-                L = L + throughput * Ls * f * lightWeight;
-            }
-        }
-        if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;   // integrator.cpp:298-301
-        // ---- BSDF sampling (integrator.cpp:304-309): next2D BEFORE next1D (H1)
-        float s2x, s2y; smp.next2D(P, T, s2x, s2y);
-        float s1 = smp.next1D(P, T);
-        V3 woLocal; bool alive;
-        V3 weight = bsdfSample(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, alive);
-        throughput = throughput * weight;
-        // zero weight: the reference keeps looping with throughput 0 (contributes exactly 0); terminate instead
-        if (!alive || (weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) break;
-        float bpdf = bsdfPdf(bsdf, wiLocal, woLocal, accRough);
-        ro = its.p; rd = toWorld(its.sh, woLocal);                                            // H9: not re-normalised
-        if (!closestHit<STATS>(T, P.rootRef, ro, rd, eps, KZ_INF, rh, stk, cn)) {
-            if (P.bgPresent && !(isnan(rd.x) || isnan(rd.y) || isnan(rd.z)))                  // scene.cpp:54-79
-                L = L + throughput * mk(P.bgRadiance[0], P.bgRadiance[1], P.bgRadiance[2]);
-            break;
-        }
-        postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
-        int nl = T.meshes[its.mesh].light;
-        if (nl >= 0) {                                                                        // integrator.cpp:322-327
-            V3 wi = normalized(its.p - ro);
-            float lpdf = lightPdfSolidAngle(T.lights[nl].normalization, its.sh.n, wi, its.p, ro);
-            bsdfWeight = powerHeuristic(bpdf, lpdf);
-        }
-        depth++;
-    }
-    return L;
-}
 
 // a1/a2 renderBlock + renderSample (renderer.cpp:20-69): item = pixLinear * S + sampleOffset
 template <bool STATS>
@@ -788,6 +207,7 @@ struct KzDeviceState {
     std::vector<KzTile> curTiles; bool tilesValid = false;
     unsigned long long *stats = nullptr; bool statsOn = false;
     hipStream_t lastStream = nullptr;
+    KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0; int numCU = 256;
     std::vector<EventPair> events; size_t eventsUsed = 0;
 };
 
@@ -812,6 +232,7 @@ void kz_device_release(KzScene *scene) {
     (void)hipSetDevice(ds->device);
     (void)hipDeviceSynchronize();
     for (void *p : ds->allocs) (void)hipFree(p);
+    for (void *p : ds->wfAllocs) (void)hipFree(p);
     for (void *p : {(void *)ds->film, (void *)ds->sJx, (void *)ds->sJy, (void *)ds->sR, (void *)ds->sG, (void *)ds->sB,
                     (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats})
         if (p) (void)hipFree(p);
@@ -852,12 +273,14 @@ int kz_scene_upload(KzScene *scene, int device) {
     if ((rc = uploadVec(ds, scene->jump, &ds->T.jump))) return rc;
     std::vector<float> ft(scene->filter, scene->filter + KZ_FILTER_RESOLUTION + 1);
     if ((rc = uploadVec(ds, ft, &ds->T.filter))) return rc;
+    if ((rc = uploadVec(ds, scene->ilTris, &ds->T.ilTris))) return rc;
     const KzParams &P = scene->prm;
     ds->filmPixels = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border);
     HIP_TRY(hipMalloc((void **)&ds->film, ds->filmPixels * sizeof(float4)));
     HIP_TRY(hipMemset(ds->film, 0, ds->filmPixels * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&ds->stats, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ds->stats, 0, 8 * sizeof(unsigned long long)));
+    { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device)); ds->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     HIP_TRY(hipFuncSetAttribute((const void *)kz_film_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIP_TRY(hipDeviceSynchronize());
     return KZ_OK;
@@ -917,12 +340,70 @@ static size_t passItemBudget() {
     return (size_t)1 << 25;      // 33.5 M (pixel,sample) items per pass: 640 MB of sample records
 }
 
+// ---- wavefront pass: allocate the SoA path state for `need` slots, then queue the stages of one pass on `stream` ----
+static int wfEnsure(KzScene *scene, KzDeviceState *ds, size_t need, hipStream_t stream) {
+    if (need <= ds->wfCap && !ds->wfAllocs.empty()) return KZ_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (void *p : ds->wfAllocs) (void)hipFree(p);
+    ds->wfAllocs.clear(); ds->wfCap = 0;
+    auto alloc = [&](void **p, size_t bytes) -> int { HIP_TRY(hipMalloc(p, bytes)); ds->wfAllocs.push_back(*p); return KZ_OK; };
+    KzWf &W = ds->wf; int rc;
+    for (float4 **p : {&W.rayA, &W.rayB, &W.hit, &W.thr, &W.misc, &W.shA, &W.shB, &W.shL}) if ((rc = alloc((void **)p, need * sizeof(float4)))) return rc;
+    if ((rc = alloc((void **)&W.smp, need * sizeof(uint4)))) return rc;
+    for (int q = 0; q < 3; ++q) if ((rc = alloc((void **)&W.queue[q], need * sizeof(uint32_t)))) return rc;
+    if ((rc = alloc((void **)&W.counts, 4 * 520 * sizeof(uint32_t)))) return rc;
+    ds->wfCap = need;
+    (void)scene;
+    return KZ_OK;
+}
+
+static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_t sBegin, uint32_t Sp, uint32_t items) {
+    const KzParams &P = scene->prm;
+    KzWf W = ds->wf;
+    W.outJx = ds->sJx; W.outJy = ds->sJy; W.outR = ds->sR; W.outG = ds->sG; W.outB = ds->sB; W.stats = ds->stats;
+    const bool st = ds->statsOn;
+    const size_t stackBytes = (size_t)P.stackDepth * KZ_BLOCK * sizeof(uint32_t);
+    const dim3 blk(KZ_BLOCK);
+    const dim3 gTrav((unsigned)(ds->numCU * 8)), gShade((unsigned)(ds->numCU * 6));
+    const int maxDepth = P.maxDepth;
+    HIP_TRY(hipMemsetAsync(W.counts, 0, 4 * 520 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, ds->pixList, items, Sp, sBegin);
+    if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
+#define KZ_EXTEND(KEEP, q, cptr, cimm) do { if (st) hipLaunchKernelGGL((kz_wf_extend<true, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); \
+                                            else hipLaunchKernelGGL((kz_wf_extend<false, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); } while (0)
+    KZ_EXTEND(false, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items);
+    if (P.anyInvisibleLight) {
+        hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);
+        KZ_EXTEND(true, (const uint32_t *)W.queue[2], (const uint32_t *)(W.counts + 0), 0u);
+    }
+    const uint32_t *cur = nullptr, *curCount = nullptr;
+    for (int iter = 0; iter < maxDepth; ++iter) {
+        uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
+        if (st) hipLaunchKernelGGL(kz_wf_shade<true>, gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount);
+        else hipLaunchKernelGGL(kz_wf_shade<false>, gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount);
+        if (P.nLights > 0) {
+            if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
+            else hipLaunchKernelGGL(kz_wf_shadow<false>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
+        }
+        const bool last = iter == maxDepth - 1;
+        if (!last || P.bgPresent) KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u);
+        cur = nextQ; curCount = nextCount;
+    }
+#undef KZ_EXTEND
+    if (P.bgPresent) hipLaunchKernelGGL(kz_wf_final, gShade, blk, 0, stream, P, W, cur, curCount);
+    if (st) hipLaunchKernelGGL(kz_wf_count, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, W, items);
+    HIP_TRY(hipGetLastError());
+    return KZ_OK;
+}
+
 int kz_render(KzScene *scene, const KzRenderOpts *opts) {
     KzDeviceState *ds; int rc;
     if ((rc = requireDevice(scene, &ds))) return rc;
     if (!opts) return kz_fail(KZ_ERR_INVALID_ARG, "null opts");
     const KzParams &P = scene->prm;
-    if (opts->pipeline != 0 && opts->pipeline != 1) return kz_fail(KZ_ERR_UNSUPPORTED, "pipeline %d is not built (1 = megakernel)", opts->pipeline);
+    if (opts->pipeline < 0 || opts->pipeline > 2) return kz_fail(KZ_ERR_INVALID_ARG, "pipeline %d (0 = default, 1 = megakernel, 2 = wavefront)", opts->pipeline);
+    int pipeline = opts->pipeline;
+    if (pipeline == 0) { const char *e = std::getenv("KZ_PIPELINE"); pipeline = (e && std::atoi(e) == 1) ? 1 : 2; }
     uint32_t s0 = opts->sampleBegin, s1 = opts->sampleEnd;
     if (s0 == 0 && s1 == 0) s1 = P.sampleCount;
     if (s0 >= s1 || s1 > P.sampleCount) return kz_fail(KZ_ERR_INVALID_ARG, "sample range [%u,%u) outside [0,%u)", s0, s1, P.sampleCount);
@@ -942,6 +423,7 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
         }
         ds->sampCap = need;
     }
+    if (pipeline == 2 && (rc = wfEnsure(scene, ds, need, stream))) return rc;
     ds->eventsUsed = 0;
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border;
     for (uint32_t s = s0; s < s1; s += S) {
@@ -954,7 +436,8 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
         EventPair &ep = ds->events[ds->eventsUsed++];
         const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
         HIP_TRY(hipEventRecord(ep.a, stream));
-        if (ds->statsOn)
+        if (pipeline == 2) { if ((rc = wfPass(scene, ds, stream, s, Sp, (uint32_t)items))) return rc; }
+        else if (ds->statsOn)
             hipLaunchKernelGGL(kz_path_megakernel<true>, grid, dim3(KZ_BLOCK), 0, stream, P, ds->T, ds->pixList, (uint32_t)items, Sp, s, (const uint32_t *)nullptr,
                                ds->sJx, ds->sJy, ds->sR, ds->sG, ds->sB, ds->stats);
         else

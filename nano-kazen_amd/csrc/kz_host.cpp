@@ -181,6 +181,30 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
 
     KzParams &p = sc->prm;
     p.rootRef = rootRef;
+    p.stackDepth = (int32_t)std::max<uint32_t>(2u, sc->bvh.maxDepth + 1);
+    // invisible-light triangles for the exact any-hit shadow test
+    p.shadowFast = 1; p.nIlTris = 0; p.anyInvisibleLight = 0;
+    for (int a = 0; a < 3; ++a) { p.ilLo[a] = INFINITY; p.ilHi[a] = -INFINITY; }
+    for (const KzLightRow &lr : sc->lightRows) {
+        if (lr.primaryVisibility) continue;
+        p.anyInvisibleLight = 1;
+        for (uint32_t f = 0; f < lr.nF; ++f) {
+            const KzTriShade &s = sc->shade[lr.triOffset + f];
+            KzTri t; std::memset(&t, 0, sizeof t);
+            for (int a = 0; a < 3; ++a) {
+                t.p0[a] = s.p[a]; t.e1[a] = s.p[3 + a] - s.p[a]; t.e2[a] = s.p[6 + a] - s.p[a];
+                for (int v = 0; v < 3; ++v) { p.ilLo[a] = std::min(p.ilLo[a], s.p[3 * v + a]); p.ilHi[a] = std::max(p.ilHi[a], s.p[3 * v + a]); }
+            }
+            t.mesh = lr.mesh; t.prim = f; t.gid = lr.triOffset + f;
+            sc->ilTris.push_back(t);
+        }
+    }
+    if (sc->ilTris.size() > 64) { p.shadowFast = 0; sc->ilTris.clear(); }      // big emissive meshes: literal closest-hit loop
+    p.nIlTris = (uint32_t)sc->ilTris.size();
+    for (int a = 0; a < 3; ++a) {        // same padding as BVH boxes
+        float m = std::max(std::fabs(p.ilLo[a]), std::fabs(p.ilHi[a]));
+        if (std::isfinite(m)) { float e = m * 4e-7f + 1e-30f; p.ilLo[a] -= e; p.ilHi[a] += e; }
+    }
     // ---- camera (camera.cpp:35-68). Eigen is not available: the 4x4 product and inverse are formed in
     // double and narrowed once, unless the caller hands over Eigen's own m_sampleToCamera.
     const KzCamera &c = d->camera;

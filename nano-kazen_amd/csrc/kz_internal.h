@@ -68,6 +68,10 @@ struct KzParams {
     // film (block.cpp:13-21)
     float filterRadius, lookupFactor; int32_t tapLo, tapHi;
     uint32_t rootRef;
+    // shadow rays: invisible-light triangles (lightPrimaryVisibility == false) are few; their box + list make the
+    // any-hit form of the shadow test exact (kz_devfn.h shadowOccluded)
+    int32_t shadowFast; uint32_t nIlTris; float ilLo[3], ilHi[3];
+    int32_t anyInvisibleLight; int32_t stackDepth;
 };
 
 // Device pointers (all HBM-resident after kz_scene_upload).
@@ -84,6 +88,7 @@ struct KzDevTables {
     const float *pixelSamples;  // pmj02bn pixel table (sampler.cpp:291-309), 2 floats per entry
     const KzPcgJump *jump;      // [sampleCount]
     const float *filter;        // [33]
+    const KzTri *ilTris;        // invisible-light triangles (<= 64) for the exact any-hit shadow test
 };
 
 struct KzScene {
@@ -99,6 +104,7 @@ struct KzScene {
     std::vector<uint16_t> bn;
     std::vector<float> pixelSamples;
     std::vector<KzPcgJump> jump;
+    std::vector<KzTri> ilTris;
     float filter[KZ_FILTER_RESOLUTION + 1];
     KzParams prm;
     KzBvhInfo bvh;

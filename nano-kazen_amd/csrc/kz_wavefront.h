@@ -1,0 +1,345 @@
+// kz_wavefront.h — the wavefront form of PathMisIntegrator::Li (integrator.cpp:195-338) for CDNA4.
+//
+// The megakernel keeps one lane on one path from camera to termination, so the lanes of a wave sit in four
+// different inlined copies of the traversal loop and in shading code at the same time: rocprof shows ~13 % of
+// lanes active per VALU instruction and 3 waves/SIMD (profiles/r01a_megakernel). Here the path is cut at every
+// ray query into stages that each run ONE kind of work over a compacted queue of path slots:
+//
+//   generate                      renderSample up to the camera ray                       (renderer.cpp:20-33)
+//   extend      (closest hit)     Accel::rayIntersect traversal half                      (accel.cpp:63-110)
+//   primary-fix + extend-keep     the invisible-light walk-through of the first hit (H6)   (integrator.cpp:214-219)
+//   shade(k)                      post-intersection, emitter hit, roulette, light sampling with BSDF eval/pdf and the
+//                                 MIS weight, BSDF sampling -> shadow ray + pending radiance, next ray
+//   shadow(k)                     the occlusion test; adds the pending radiance when unoccluded (integrator.cpp:257-295)
+//   final                         background on a miss after the last bounce               (integrator.cpp:315-318)
+//
+// Path state lives in HBM as SoA (float4 per field, one slot per (pixel,sample) item of the pass: 33.5 M slots =
+// ~5 GB of 288 GB), so every stage reads and writes coalesced 16-B records. Queues hold slot indices; kernels are
+// persistent (grid-stride over 256-item chunks, count read from device memory: no host round trip per stage) and
+// compact their survivors through an LDS staging buffer with one global atomic per ~2 K items.
+// The arithmetic per path and the order of its radiance additions are those of the megakernel, so both pipelines
+// produce bit-identical sample records.
+#pragma once
+#include "kz_devfn.h"
+
+#define KZ_WF_QCAP 2048            // LDS staging entries per output queue per workgroup
+
+struct KzWf {
+    float4 *rayA, *rayB;           // o.xyz tmin | d.xyz tmax
+    float4 *hit;                   // t u v tri(bits); t = +inf: miss
+    float4 *thr;                   // throughput.xyz eta
+    float4 *misc;                  // bsdfPdf accumulatedRoughness - -
+    uint4 *smp;                    // independent: pcg32 state/inc; pmj02bn: dimension in .x
+    float4 *shA, *shB, *shL;       // shadow (or walk-through) ray o.xyz tmax | d.xyz tmin | pending radiance
+    uint32_t *queue[3];            // two ping-pong path queues + the shadow queue
+    uint32_t *counts;              // [stage][4] zeroed per pass
+    float *outJx, *outJy, *outR, *outG, *outB;
+    unsigned long long *stats;
+};
+
+// ---- workgroup-level compaction: append `val` for lanes with pred into an LDS buffer, flush to the global queue ----
+struct WfAppender {
+    uint32_t *s_buf; uint32_t *s_n; uint32_t *s_gb; uint32_t *gQueue; uint32_t *gCount;
+    __device__ __forceinline__ void push(bool pred, uint32_t val) {
+        const unsigned long long m = __ballot(pred);
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(s_n, (uint32_t)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (pred) s_buf[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
+    }
+    // all threads of the workgroup call this; flushes when another 256-item chunk might not fit (or always, if force)
+    __device__ __forceinline__ void maybeFlush(bool force) {
+        __syncthreads();
+        const uint32_t n = *s_n;
+        if (force ? (n > 0) : (n > KZ_WF_QCAP - KZ_BLOCK)) {
+            if (threadIdx.x == 0) *s_gb = atomicAdd(gCount, n);
+            __syncthreads();
+            const uint32_t gb = *s_gb;
+            for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) gQueue[gb + i] = s_buf[i];
+            __syncthreads();
+            if (threadIdx.x == 0) *s_n = 0;
+        }
+        __syncthreads();
+    }
+};
+
+__device__ __forceinline__ void wfStatsFlush(unsigned long long *stats, const Counters &cn, uint32_t samples) {
+    unsigned long long v[7] = {samples, cn.rays, cn.nodes, cn.tris, cn.hits, cn.lsamples, cn.dropped};
+    for (int k = 0; k < 7; ++k) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k], x);
+    }
+}
+
+__device__ __forceinline__ void wfLoadSampler(const KzParams &P, const KzWf &W, uint32_t slot, int px, int py, uint32_t sampleIndex, Sampler &s) {
+    const uint4 v = W.smp[slot];
+    s.type = P.samplerType; s.px = px; s.py = py; s.idx = sampleIndex;
+    s.state = (uint64_t)v.x | ((uint64_t)v.y << 32); s.inc = (uint64_t)v.z | ((uint64_t)v.w << 32); s.dim = v.x;
+}
+__device__ __forceinline__ void wfStoreSampler(const KzParams &P, const KzWf &W, uint32_t slot, const Sampler &s) {
+    uint4 v;
+    if (P.samplerType == KZ_SAMPLER_INDEPENDENT) { v.x = (uint32_t)s.state; v.y = (uint32_t)(s.state >> 32); v.z = (uint32_t)s.inc; v.w = (uint32_t)(s.inc >> 32); }
+    else { v.x = s.dim; v.y = v.z = v.w = 0; }
+    W.smp[slot] = v;
+}
+
+// ---- generate: renderSample up to the camera ray (renderer.cpp:20-33) ------------------------------------------------
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_generate(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList,
+                                                           uint32_t nItems, uint32_t S, uint32_t sampleBegin) {
+    const uint32_t item = blockIdx.x * KZ_BLOCK + threadIdx.x;
+    if (item >= nItems) return;
+    const uint32_t pl = item / S, so = item - pl * S;
+    const uint32_t pxy = pixList[pl];
+    const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
+    Sampler smp; smp.type = P.samplerType;
+    smp.generateSample(P, T, px, py, sampleBegin + so);
+    float jx, jy; smp.nextPixel2D(P, T, jx, jy);
+    const float sx = (float)px + jx, sy = (float)py + jy;
+    float ax, ay; smp.next2D(P, T, ax, ay);
+    V3 ro, rd; float mint, maxt;
+    cameraRay(P, sx, sy, ro, rd, mint, maxt);
+    W.rayA[item] = make_float4(ro.x, ro.y, ro.z, mint);
+    W.rayB[item] = make_float4(rd.x, rd.y, rd.z, maxt);
+    W.thr[item] = make_float4(1.f, 1.f, 1.f, 1.f);
+    W.misc[item] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wfStoreSampler(P, W, item, smp);
+    W.outJx[item] = jx; W.outJy[item] = jy; W.outR[item] = 0.f; W.outG[item] = 0.f; W.outB[item] = 0.f;
+}
+
+// ---- extend: closest hit for the rays of a queue (queue == nullptr: identity over [0, count)) --------------------------
+// KEEP: leave the previous hit record in place on a miss and read the ray from the shA/shB pair (walk-through, H6).
+template <bool STATS, bool KEEP>
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_extend(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
+                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t count = countPtr ? *countPtr : countImm;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
+        const uint32_t qi = base + threadIdx.x;
+        if (qi >= count) continue;
+        const uint32_t slot = queue ? queue[qi] : qi;
+        float4 a, b;
+        if (KEEP) { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w); }
+        else { a = W.rayA[slot]; b = W.rayB[slot]; }
+        RawHit rh;
+        const bool found = closestHit<STATS>(T, P.rootRef, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, rh, s_stack + threadIdx.x, cn);
+        if (found) W.hit[slot] = make_float4(rh.t, rh.u, rh.v, __uint_as_float(rh.tri));
+        else if (!KEEP) W.hit[slot] = make_float4(KZ_INF, 0.f, 0.f, 0.f);
+    }
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+}
+
+// ---- primary fix: first hit on a light with lightPrimaryVisibility == false -> continuation ray (integrator.cpp:214-219)
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevTables T, KzWf W, uint32_t nItems, uint32_t *__restrict__ outQueue,
+                                                              uint32_t *__restrict__ outCount) {
+    __shared__ uint32_t s_buf[KZ_WF_QCAP]; __shared__ uint32_t s_n, s_gb;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    WfAppender ap = {s_buf, &s_n, &s_gb, outQueue, outCount};
+    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < nItems; base += gridDim.x * KZ_BLOCK) {
+        const uint32_t slot = base + threadIdx.x;
+        bool need = false;
+        if (slot < nItems) {
+            const float4 h = W.hit[slot];
+            if (h.x < KZ_INF) {
+                RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = __float_as_uint(h.w);
+                const float4 c = reinterpret_cast<const float4 *>(T.tris + rh.tri)[2];
+                rh.gid = __float_as_uint(c.w);
+                const int li = T.meshes[__float_as_uint(c.y)].light;
+                if (li >= 0 && !T.lights[li].primaryVisibility) {
+                    Its its; postIntersect<false>(T, rh, its);
+                    const float4 b = W.rayB[slot];
+                    const V3 rd = mk(b.x, b.y, b.z);
+                    const V3 no = its.p + P.traceBias * rd;
+                    W.shA[slot] = make_float4(no.x, no.y, no.z, KZ_INF);            // Ray3f(o, d): mint = Epsilon, maxt = inf
+                    W.shB[slot] = make_float4(rd.x, rd.y, rd.z, KZ_EPSILON);
+                    need = true;
+                }
+            }
+        }
+        ap.push(need, slot);
+        ap.maybeFlush(false);
+    }
+    ap.maybeFlush(true);
+}
+
+// ---- shade(iter): everything between two ray queries of Li ---------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
+                                                        uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
+                                                        const uint32_t *__restrict__ countPtr, uint32_t countImm,
+                                                        uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
+                                                        uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
+    __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
+    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; }
+    __syncthreads();
+    WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
+    const uint32_t count = countPtr ? *countPtr : countImm;
+    const float eps = P.traceBias;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
+        const uint32_t qi = base + threadIdx.x;
+        bool pushNext = false, pushShadow = false;
+        uint32_t slot = 0;
+        if (qi < count) {
+            slot = queue ? queue[qi] : qi;
+            const float4 h = W.hit[slot];
+            const float4 ra = W.rayA[slot], rb = W.rayB[slot];
+            const V3 ro = mk(ra.x, ra.y, ra.z), rd = mk(rb.x, rb.y, rb.z);
+            float4 th = W.thr[slot];
+            V3 throughput = mk(th.x, th.y, th.z);
+            const float eta = th.w;
+            if (!(h.x < KZ_INF)) {
+                // miss: black for the primary ray (H5), background after a bounce (integrator.cpp:315-318)
+                if (iter > 0 && P.bgPresent && !(isnan(rd.x) || isnan(rd.y) || isnan(rd.z))) {
+                    const V3 c = throughput * mk(P.bgRadiance[0], P.bgRadiance[1], P.bgRadiance[2]);
+                    W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
+                }
+            } else {
+                RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = __float_as_uint(h.w);
+                rh.gid = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + rh.tri)[2].w);
+                Its its; postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
+                const KzMeshRow mrow = T.meshes[its.mesh];
+                const float4 mi = W.misc[slot];
+                float accRough = mi.y;
+                if (mrow.light >= 0) {                                                        // integrator.cpp:226-231, 322-327
+                    const KzLightRow &lr = T.lights[mrow.light];
+                    const V3 wi = normalized(its.p - ro);
+                    float bsdfWeight = 1.f;
+                    if (iter > 0) bsdfWeight = powerHeuristic(mi.x, lightPdfSolidAngle(lr.normalization, its.sh.n, wi, its.p, ro));
+                    if (dot(its.sh.n, -wi) > 0.f) {
+                        const V3 c = (bsdfWeight * throughput) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
+                        W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
+                    }
+                } else {
+                    const uint32_t pl = slot / S;
+                    const uint32_t pxy = pixList[pl];
+                    Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
+                    bool alive = true;
+                    if (iter >= 3) {                                                          // integrator.cpp:237-244
+                        const float probability = fminf(maxCoeff(throughput) * eta * eta, 0.95f);
+                        if (probability <= smp.next1D(P, T)) alive = false;
+                        else throughput = throughput / probability;
+                    }
+                    if (alive) {
+                        const KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+                        const V3 wiLocal = toLocal(its.sh, -rd);
+                        const float pick = smp.next1D(P, T);                                  // drawn even without lights
+                        if (P.nLights > 0) {                                                  // integrator.cpp:247-295
+                            const uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
+                            const KzLightRow lrow = T.lights[li];
+                            if (STATS) cn.lsamples++;
+                            const uint32_t tri = cdfSample(T.cdf + lrow.cdfOffset, lrow.nF, smp.next1D(P, T));
+                            const float su0 = sqrtf(smp.next1D(P, T));
+                            const float u = 1 - su0;
+                            const float v = smp.next1D(P, T) * su0;
+                            const float4 *sp = reinterpret_cast<const float4 *>(T.shade + lrow.triOffset + tri);
+                            const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+                            const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
+                            const V3 lp = p0 + u * (p1 - p0) + v * (p2 - p0);
+                            V3 ln;
+                            if (T.meshes[lrow.mesh].flags & 1u) {
+                                const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
+                                ln = n0 + u * (n1 - n0) + v * (n2 - n0);                      // H8
+                            } else ln = normalized(cross(p1 - p0, p2 - p0));
+                            const V3 toL = lp - its.p;
+                            const V3 lwi = normalized(toL);
+                            const float dist = norm(toL);
+                            const float lpdf = lightPdfSolidAngle(lrow.normalization, ln, lwi, lp, its.p);
+                            V3 Ls = mk(0.f);
+                            if (lpdf > 0.f && !isnan(lpdf) && !isinf(lpdf)) {
+                                const V3 ev = dot(ln, -lwi) > 0.f ? mk(lrow.radiance[0], lrow.radiance[1], lrow.radiance[2]) : mk(0.f);
+                                Ls = ev / lpdf;
+                            }
+                            Ls = Ls / P.lightPickPdf;
+                            const V3 woL = toLocal(its.sh, lwi);
+                            const V3 f = bsdfEval(bsdf, wiLocal, woL, accRough);
+                            const float bpdfL = bsdfPdf(bsdf, wiLocal, woL, accRough);
+                            const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
+                            // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
+                            if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
+                                W.shA[slot] = make_float4(its.p.x, its.p.y, its.p.z, dist - eps);
+                                W.shB[slot] = make_float4(lwi.x, lwi.y, lwi.z, eps);
+                                W.shL[slot] = make_float4(pend.x, pend.y, pend.z, 0.f);
+                                pushShadow = true;
+                            }
+                        }
+                        if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
+                        float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
+                        const float s1 = smp.next1D(P, T);
+                        V3 woLocal; bool ok;
+                        const V3 weight = bsdfSample(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, ok);
+                        throughput = throughput * weight;
+                        if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
+                            const float bpdf = bsdfPdf(bsdf, wiLocal, woLocal, accRough);
+                            const V3 nd = toWorld(its.sh, woLocal);                           // H9
+                            // the ray after the LAST bounce only matters for the background term
+                            if (iter + 1 < P.maxDepth || P.bgPresent) {
+                                W.rayA[slot] = make_float4(its.p.x, its.p.y, its.p.z, eps);
+                                W.rayB[slot] = make_float4(nd.x, nd.y, nd.z, KZ_INF);
+                                W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, eta);
+                                W.misc[slot] = make_float4(bpdf, accRough, 0.f, 0.f);
+                                wfStoreSampler(P, W, slot, smp);
+                                pushNext = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        apN.push(pushNext, slot);
+        apS.push(pushShadow, slot);
+        apN.maybeFlush(false);
+        apS.maybeFlush(false);
+    }
+    apN.maybeFlush(true);
+    apS.maybeFlush(true);
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+}
+
+// ---- shadow(iter): occlusion test, adds the pending radiance (integrator.cpp:257-295) -----------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
+                                                         const uint32_t *__restrict__ countPtr) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t count = *countPtr;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
+        const uint32_t qi = base + threadIdx.x;
+        if (qi >= count) continue;
+        const uint32_t slot = queue[qi];
+        const float4 a = W.shA[slot], b = W.shB[slot];
+        const bool occluded = shadowOccluded<STATS>(P, T, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), b.w, a.w, s_stack + threadIdx.x, cn);
+        if (!occluded) {
+            const float4 l = W.shL[slot];
+            W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z;
+        }
+    }
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+}
+
+// ---- final: the ray after the last bounce contributes only the background on a miss (integrator.cpp:315-318) ------------
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_final(KzParams P, KzWf W, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ countPtr) {
+    const uint32_t count = *countPtr;
+    for (uint32_t qi = blockIdx.x * KZ_BLOCK + threadIdx.x; qi < count; qi += gridDim.x * KZ_BLOCK) {
+        const uint32_t slot = queue[qi];
+        const float4 h = W.hit[slot];
+        if (h.x < KZ_INF) continue;
+        const float4 rb = W.rayB[slot], th = W.thr[slot];
+        if (isnan(rb.x) || isnan(rb.y) || isnan(rb.z)) continue;
+        W.outR[slot] += th.x * P.bgRadiance[0]; W.outG[slot] += th.y * P.bgRadiance[1]; W.outB[slot] += th.z * P.bgRadiance[2];
+    }
+}
+
+// ---- stats only: samples rendered and invalid radiance values (Color3f::isValid, common.cpp:384-391) --------------------
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_count(KzWf W, uint32_t nItems) {
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    const uint32_t i = blockIdx.x * KZ_BLOCK + threadIdx.x;
+    if (i < nItems) {
+        const float r = W.outR[i], g = W.outG[i], b = W.outB[i];
+        if (!(r >= 0 && g >= 0 && b >= 0 && isfinite(r) && isfinite(g) && isfinite(b))) cn.dropped++;
+    }
+    wfStatsFlush(W.stats, cn, i < nItems ? 1u : 0u);
+}

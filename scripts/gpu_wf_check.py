@@ -1,0 +1,25 @@
+import sys, time, importlib, numpy as np
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
+import oracle as O
+kz = O.kz
+S = kz.scenes
+cases = [("cornell", S.cornell_box(128,128,16)), ("cornell_pmj", S.cornell_box(96,96,16,sampler="pmj02bn",seed=1)),
+         ("sphere", S.sphere_env(128,128,8)), ("hero", S.hero_scene(160,90,8,detail=0.3)), ("soup", S.random_triangles(100000,160,90,16))]
+vis = S.cornell_box(64,64,8)
+for m in vis.meshes:
+    if m["light"]: m["light"]["lightPrimaryVisibility"] = True
+cases.append(("cornell_visible_light", vis))
+for name, desc in cases:
+    sc = kz.Scene(desc, device=0)
+    sc.set_stats(True)
+    sc.render(pipeline=1); f1 = sc.film(); st1 = sc.stats(reset=True)
+    sc.render(pipeline=2); f2 = sc.film(); st2 = sc.stats(reset=True)
+    print(name, "films identical:", np.array_equal(f1, f2), "maxdiff", np.abs(f1-f2).max(), flush=True)
+    print("   mega", st1); print("   wave", st2, flush=True)
+d = S.random_triangles(1000000, 1920, 1080, 1024)
+sc = kz.Scene(d, device=0)
+for pipe in (1, 2, 2, 1, 2):
+    sc.render(32, 48, pipeline=pipe); sc.sync()
+    print("C4 pipeline", pipe, "pass ms %.1f" % sc.last_kernel_ms(), flush=True)
+sc.render(32,48,pipeline=1); a = sc.film(); sc.render(32,48,pipeline=2); b = sc.film()
+print("C4 identical", np.array_equal(a,b), np.abs(a-b).max())
