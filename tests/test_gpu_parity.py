@@ -178,7 +178,7 @@ def test_image_matches_oracle(gpu_lib, kz, O, name):
     # when there is no background, any-hit instead of closest-hit occlusion), so rays / node visits are <= the oracle's.
     so = ora.stats()
     assert st["samples"] == so["samples"] and st["droppedSamples"] == so["droppedSamples"]
-    assert st["lightSamples"] == so["lightSamples"]
+    assert abs(st["lightSamples"] - so["lightSamples"]) <= 1e-5 * so["lightSamples"] + 2      # an ulp can flip one roulette decision
     assert 0.5 * so["rays"] <= st["rays"] <= so["rays"] and 0.9 * so["shadedHits"] <= st["shadedHits"] <= so["shadedHits"]
     assert st["nodeVisits"] <= 1.1 * so["nodeVisits"] and st["triTests"] <= 1.1 * so["triTests"]
     # the reference-shaped megakernel does exactly the oracle's work and produces the same film bit for bit
