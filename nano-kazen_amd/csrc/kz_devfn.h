@@ -155,6 +155,47 @@ struct Sampler {
 // ============================================================================================
 struct RawHit { float t, u, v; uint32_t tri; uint32_t gid; };
 
+// One 64-B node packet: slab tests of both children (a16). Conservative on the builder's padded boxes: fminf/fmaxf drop
+// the NaN of 0*inf on a degenerate axis (that slab then does not constrain) and the far side is widened by 2 ulp.
+struct NodeTest { bool h0, h1; float n0, n1; uint32_t c0, c1; };
+__device__ __forceinline__ NodeTest nodeTest(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax) {
+    const float4 *np = reinterpret_cast<const float4 *>(T.nodes + node);
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+    const uint4 q3 = *reinterpret_cast<const uint4 *>(np + 3);
+    float t0, t1, n0, f0, n1, f1;
+    t0 = (q0.x - o.x) * rx; t1 = (q0.w - o.x) * rx; n0 = fminf(t0, t1); f0 = fmaxf(t0, t1);
+    t0 = (q0.y - o.y) * ry; t1 = (q1.x - o.y) * ry; n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
+    t0 = (q0.z - o.z) * rz; t1 = (q1.y - o.z) * rz; n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
+    t0 = (q1.z - o.x) * rx; t1 = (q2.y - o.x) * rx; n1 = fminf(t0, t1); f1 = fmaxf(t0, t1);
+    t0 = (q1.w - o.y) * ry; t1 = (q2.z - o.y) * ry; n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
+    t0 = (q2.x - o.z) * rz; t1 = (q2.w - o.z) * rz; n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
+    f0 *= 1.0000004f; f1 *= 1.0000004f;
+    NodeTest r;
+    r.h0 = (fmaxf(n0, tmin) <= fminf(f0, tmax)); r.h1 = (fmaxf(n1, tmin) <= fminf(f1, tmax));
+    r.n0 = n0; r.n1 = n1; r.c0 = q3.x; r.c1 = q3.y;
+    return r;
+}
+// Mesh::rayIntersect (mesh.cpp:55-92), operation for operation, on one 48-B leaf triangle.
+__device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin, float tmax, float &t, float &u, float &v, uint32_t &gid) {
+    const float4 *tp = reinterpret_cast<const float4 *>(tri);
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    const V3 p0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
+    gid = __float_as_uint(c.w);
+    V3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    if (det > -1e-8f && det < 1e-8f) return false;
+    float inv_det = 1.0f / det;
+    V3 tvec = o - p0;
+    u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 qvec = cross(tvec, e1);
+    v = dot(d, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot(e2, qvec) * inv_det;
+    return t >= tmin && t <= tmax;
+}
+__device__ __forceinline__ bool rayIsFinite(V3 o, V3 d) { return fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z) < KZ_INF; }
+
 template <bool STATS>
 __device__ __forceinline__ bool closestHit(const KzDevTables &T, uint32_t rootRef, V3 o, V3 d, float tmin, float tmax,
                                            RawHit &best, uint32_t *stk, Counters &cn) {

@@ -369,12 +369,16 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     HIP_TRY(hipMemsetAsync(W.counts, 0, 4 * 520 * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, ds->pixList, items, Sp, sBegin);
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
-#define KZ_EXTEND(KEEP, q, cptr, cimm) do { if (st) hipLaunchKernelGGL((kz_wf_extend<true, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); \
+    static const int traceKernel = [] { const char *e = std::getenv("KZ_TRACE_KERNEL"); return e ? std::atoi(e) : 1; }();
+#define KZ_TRACE(MODE, q, cptr, cimm, headp) do { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm, headp); \
+                                                  else hipLaunchKernelGGL((kz_wf_trace<MODE, false>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm, headp); } while (0)
+#define KZ_EXTEND(KEEP, q, cptr, cimm, headp) do { if (traceKernel) KZ_TRACE((KEEP ? 1 : 0), q, cptr, cimm, headp); \
+                                            else if (st) hipLaunchKernelGGL((kz_wf_extend<true, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); \
                                             else hipLaunchKernelGGL((kz_wf_extend<false, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); } while (0)
-    KZ_EXTEND(false, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items);
+    KZ_EXTEND(false, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2);
     if (P.anyInvisibleLight) {
         hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);
-        KZ_EXTEND(true, (const uint32_t *)W.queue[2], (const uint32_t *)(W.counts + 0), 0u);
+        KZ_EXTEND(true, (const uint32_t *)W.queue[2], (const uint32_t *)(W.counts + 0), 0u, W.counts + 3);
     }
     const uint32_t *cur = nullptr, *curCount = nullptr;
     for (int iter = 0; iter < maxDepth; ++iter) {
@@ -382,14 +386,16 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
         if (st) hipLaunchKernelGGL(kz_wf_shade<true>, gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount);
         else hipLaunchKernelGGL(kz_wf_shade<false>, gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount);
         if (P.nLights > 0) {
-            if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
+            if (traceKernel) KZ_TRACE(2, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3);
+            else if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
             else hipLaunchKernelGGL(kz_wf_shadow<false>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
         }
         const bool last = iter == maxDepth - 1;
-        if (!last || P.bgPresent) KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u);
+        if (!last || P.bgPresent) KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2);
         cur = nextQ; curCount = nextCount;
     }
 #undef KZ_EXTEND
+#undef KZ_TRACE
     if (P.bgPresent) hipLaunchKernelGGL(kz_wf_final, gShade, blk, 0, stream, P, W, cur, curCount);
     if (st) hipLaunchKernelGGL(kz_wf_count, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, W, items);
     HIP_TRY(hipGetLastError());
