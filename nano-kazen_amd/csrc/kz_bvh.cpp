@@ -16,6 +16,7 @@
 #include <cstring>
 #include <future>
 #include <limits>
+#include <array>
 
 namespace {
 
@@ -117,10 +118,12 @@ static void build(Ctx &cx, uint32_t node, uint32_t b, uint32_t e, uint32_t depth
 
 // A few ulps of slack: the slab test rounds differently from the triangle test, and the parity target is
 // "never cull a triangle the brute-force Moeller-Trumbore search would report".
-static void padBox(Box &b) {
+// `absPad` = 1e-6 x the scene extent: the slab arithmetic (and the FMA form used on the quantised BVH4) has an error
+// proportional to |box - ray origin|, not to the box coordinates, so boxes near the world origin need an absolute term.
+static void padBox(Box &b, float absPad) {
     for (int a = 0; a < 3; ++a) {
         float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
-        float e = m * 4e-7f + 1e-30f;
+        float e = std::max(m * 4e-7f, absPad) + 1e-30f;
         b.lo[a] -= e; b.hi[a] += e;
     }
 }
@@ -168,6 +171,8 @@ int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, 
     std::vector<uint32_t> newIndex(cx.nTmp.load(), 0xFFFFFFFFu);
     double sah = 0.0; uint32_t nLeaves = 0, maxLeaf = 0;
     float rootArea = cx.tmp[root].b.area();
+    float absPad = 0.f;
+    for (int a = 0; a < 3; ++a) absPad = std::max(absPad, 1e-6f * std::max(cx.tmp[root].b.hi[a] - cx.tmp[root].b.lo[a], std::max(std::fabs(cx.tmp[root].b.hi[a]), std::fabs(cx.tmp[root].b.lo[a]))));
     if (cx.tmp[root].count > 0) {
         rootRef = refOf(root); nLeaves = 1; maxLeaf = cx.tmp[root].count;
     } else {
@@ -186,7 +191,7 @@ int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, 
             Box cb[2];
             for (int k = 0; k < 2; ++k) {
                 const Tmp &c = cx.tmp[ch[k]];
-                cb[k] = c.b; padBox(cb[k]);
+                cb[k] = c.b; padBox(cb[k], absPad);
                 if (c.count > 0) { nd.child[k] = refOf(ch[k]); nLeaves++; maxLeaf = std::max(maxLeaf, c.count); sah += (double)c.b.area() * c.count; }
                 else { nd.child[k] = newIndex[ch[k]]; sah += (double)c.b.area() * 1.0; }
             }
@@ -199,5 +204,96 @@ int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, 
     info.nNodes = (uint32_t)nodes.size(); info.nLeaves = nLeaves; info.maxDepth = cx.maxDepth.load(); info.maxLeafSize = maxLeaf;
     info.sahCost = rootArea > 0 ? (float)(sah / rootArea) : 0.f;
     info.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return KZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BVH2 -> BVH4 collapse with 8-bit quantised child boxes (KzNode4). Children of a BVH4 node are found by repeatedly
+// opening the inner child with the largest surface area until four slots are used. Nodes are numbered breadth-first.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct ChildBox { float lo[3], hi[3]; uint32_t ref; };
+
+void childBoxesOf(const std::vector<KzNode> &nodes, uint32_t n, ChildBox out[2]) {
+    const KzNode &nd = nodes[n];
+    out[0].ref = nd.child[0]; out[1].ref = nd.child[1];
+    out[0].lo[0] = nd.q[0]; out[0].lo[1] = nd.q[1]; out[0].lo[2] = nd.q[2]; out[0].hi[0] = nd.q[3]; out[0].hi[1] = nd.q[4]; out[0].hi[2] = nd.q[5];
+    out[1].lo[0] = nd.q[6]; out[1].lo[1] = nd.q[7]; out[1].lo[2] = nd.q[8]; out[1].hi[0] = nd.q[9]; out[1].hi[1] = nd.q[10]; out[1].hi[2] = nd.q[11];
+}
+float boxArea(const ChildBox &c) {
+    float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+// the kernel's dequantisation, evaluated identically on the host (no contraction: q * s is exact, one rounding in the add)
+inline float deq(float p, uint32_t q, float s) { volatile float prod = (float)q * s; return p + prod; }
+}
+
+int kz_collapse_bvh4(const std::vector<KzNode> &nodes, uint32_t rootRef, std::vector<KzNode4> &out, uint32_t &rootRef4, int &stackBound) {
+    out.clear(); stackBound = 1;
+    rootRef4 = rootRef;                      // empty scene or single-leaf root: same reference
+    if (rootRef == 0xFFFFFFFFu || (rootRef & 0x80000000u)) return KZ_OK;
+    struct Item { uint32_t bvh2; };
+    std::vector<uint32_t> order; order.push_back(rootRef);       // BVH2 node that roots each BVH4 node, BFS
+    std::vector<std::array<ChildBox, 4>> kids; std::vector<int> nk;
+    for (size_t h = 0; h < order.size(); ++h) {
+        ChildBox cb[4]; int n = 2;
+        childBoxesOf(nodes, order[h], cb);
+        while (n < 4) {
+            int best = -1; float bestA = -1.f;
+            for (int i = 0; i < n; ++i) if (!(cb[i].ref & 0x80000000u)) { float a = boxArea(cb[i]); if (a > bestA) { bestA = a; best = i; } }
+            if (best < 0) break;
+            ChildBox two[2]; childBoxesOf(nodes, cb[best].ref, two);
+            cb[best] = two[0]; cb[n++] = two[1];
+        }
+        std::array<ChildBox, 4> arr;
+        for (int i = 0; i < 4; ++i) arr[i] = cb[i < n ? i : 0];
+        for (int i = 0; i < n; ++i) if (!(arr[i].ref & 0x80000000u)) { uint32_t idx = (uint32_t)order.size(); order.push_back(arr[i].ref); arr[i].ref = idx; }
+        kids.push_back(arr); nk.push_back(n);
+    }
+    if (order.size() >= (1u << 31)) return KZ_ERR_UNSUPPORTED;
+    out.resize(order.size());
+    for (size_t h = 0; h < order.size(); ++h) {
+        KzNode4 &nd = out[h]; std::memset(&nd, 0, sizeof nd);
+        const int n = nk[h]; const auto &cb = kids[h];
+        float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+        for (int i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], cb[i].lo[a]); hi[a] = std::max(hi[a], cb[i].hi[a]); }
+        uint32_t exps = 0; float scale[3];
+        for (int a = 0; a < 3; ++a) {
+            nd.p[a] = lo[a];
+            float ext = hi[a] - lo[a];
+            int e = 0;
+            if (ext > 0.f) { std::frexp(ext / 255.0f, &e); }            // ext/255 = m * 2^e, m in [0.5,1) -> 2^e >= ext/255
+            else e = -126;
+            e = std::max(-126, std::min(127, e));
+            // make sure 255 steps reach hi even after the rounding of p + 255*s
+            while (e < 127 && deq(lo[a], 255u, std::ldexp(1.0f, e)) < hi[a]) ++e;
+            scale[a] = std::ldexp(1.0f, e);
+            exps |= (uint32_t)(e + 127) << (8 * a);
+        }
+        nd.exps = exps;
+        for (int i = 0; i < 4; ++i) {
+            if (i >= n) { for (int a = 0; a < 3; ++a) { nd.qlo[a] |= 255u << (8 * i); } nd.child[i] = 0; continue; }     // qhi = 0: inverted, never hit
+            nd.child[i] = cb[i].ref;
+            for (int a = 0; a < 3; ++a) {
+                int ql = (int)std::floor((cb[i].lo[a] - lo[a]) / scale[a]);
+                ql = std::max(0, std::min(255, ql));
+                while (ql > 0 && deq(lo[a], (uint32_t)ql, scale[a]) > cb[i].lo[a]) --ql;
+                int qh = (int)std::ceil((cb[i].hi[a] - lo[a]) / scale[a]);
+                qh = std::max(0, std::min(255, qh));
+                while (qh < 255 && deq(lo[a], (uint32_t)qh, scale[a]) < cb[i].hi[a]) ++qh;
+                nd.qlo[a] |= (uint32_t)ql << (8 * i);
+                nd.qhi[a] |= (uint32_t)qh << (8 * i);
+            }
+        }
+    }
+    // worst-case stack depth of the traversal: a node pushes (children - 1) entries before descending
+    std::vector<int> need(out.size(), 0);
+    for (size_t h = out.size(); h-- > 0;) {
+        int m = 0;
+        for (int i = 0; i < nk[h]; ++i) { uint32_t c = out[h].child[i]; if (!(c & 0x80000000u)) m = std::max(m, need[c]); }
+        need[h] = (nk[h] - 1) + m;
+    }
+    stackBound = need[0] + 1;
+    rootRef4 = 0;
     return KZ_OK;
 }

@@ -194,6 +194,41 @@ __device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin
     t = dot(e2, qvec) * inv_det;
     return t >= tmin && t <= tmax;
 }
+// One 64-B BVH4 packet (KzNode4): four quantised child boxes, slab tests in the FMA form t = q * (s * rcp) + (p - o) * rcp
+// (s is a power of two, so s * rcp is exact; the leaf boxes carry an absolute pad that covers the rounding of the rest).
+// Returns the four children as sortable keys: (bits of max(tnear, tmin) with the two low bits replaced by the child slot),
+// 0xFFFFFFFF for a miss, sorted ascending, so key[0] is the nearest hit child.
+struct Node4Test { uint32_t k0, k1, k2, k3; uint4 refs; };
+__device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax) {
+    const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + node);
+    const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
+    Node4Test r; r.refs = np[3];
+    const float ax = __uint_as_float((q0.w & 0xffu) << 23) * rx, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * ry,
+                az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * rz;
+    const float bx = (__uint_as_float(q0.x) - o.x) * rx, by = (__uint_as_float(q0.y) - o.y) * ry, bz = (__uint_as_float(q0.z) - o.z) * rz;
+    uint32_t key[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lx = (float)((q1.x >> (8 * i)) & 0xffu), ly = (float)((q1.y >> (8 * i)) & 0xffu), lz = (float)((q1.z >> (8 * i)) & 0xffu);
+        const float hx = (float)((q1.w >> (8 * i)) & 0xffu), hy = (float)((q2.x >> (8 * i)) & 0xffu), hz = (float)((q2.y >> (8 * i)) & 0xffu);
+        const bool empty = lx > hx;                       // unused slot: qlo = 255, qhi = 0
+        float t0 = fmaf(lx, ax, bx), t1 = fmaf(hx, ax, bx);
+        float n = fminf(t0, t1), f = fmaxf(t0, t1);
+        t0 = fmaf(ly, ay, by); t1 = fmaf(hy, ay, by); n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
+        t0 = fmaf(lz, az, bz); t1 = fmaf(hz, az, bz); n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
+        f *= 1.0000004f;
+        n = fmaxf(n, tmin);
+        const bool hit = !empty && (n <= fminf(f, tmax));
+        key[i] = hit ? ((__float_as_uint(n) & ~3u) | (uint32_t)i) : 0xFFFFFFFFu;
+    }
+    // 5-comparator sorting network on unsigned keys
+    uint32_t a = min(key[0], key[1]), b = max(key[0], key[1]), c = min(key[2], key[3]), d = max(key[2], key[3]);
+    uint32_t lo = min(a, c), m1 = max(a, c), m2 = min(b, d), hi = max(b, d);
+    r.k0 = lo; r.k1 = min(m1, m2); r.k2 = max(m1, m2); r.k3 = hi;
+    return r;
+}
+__device__ __forceinline__ uint32_t pick4(const uint4 &v, uint32_t i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
 __device__ __forceinline__ bool rayIsFinite(V3 o, V3 d) { return fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z) < KZ_INF; }
 
 template <bool STATS>

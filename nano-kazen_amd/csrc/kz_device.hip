@@ -208,6 +208,7 @@ struct KzDeviceState {
     unsigned long long *stats = nullptr; bool statsOn = false;
     hipStream_t lastStream = nullptr;
     KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0; int numCU = 256;
+    uint32_t *ovf = nullptr; size_t ovfCap = 0;
     std::vector<EventPair> events; size_t eventsUsed = 0;
 };
 
@@ -234,7 +235,7 @@ void kz_device_release(KzScene *scene) {
     for (void *p : ds->allocs) (void)hipFree(p);
     for (void *p : ds->wfAllocs) (void)hipFree(p);
     for (void *p : {(void *)ds->film, (void *)ds->sJx, (void *)ds->sJy, (void *)ds->sR, (void *)ds->sG, (void *)ds->sB,
-                    (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats})
+                    (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->ovf})
         if (p) (void)hipFree(p);
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ds;
@@ -261,6 +262,7 @@ int kz_scene_upload(KzScene *scene, int device) {
     scene->dev = ds;
     int rc;
     if ((rc = uploadVec(ds, scene->nodes, &ds->T.nodes))) return rc;
+    if ((rc = uploadVec(ds, scene->nodes4, &ds->T.nodes4))) return rc;
     if ((rc = uploadVec(ds, scene->tris, &ds->T.tris))) return rc;
     if ((rc = uploadVec(ds, scene->shade, &ds->T.shade))) return rc;
     if ((rc = uploadVec(ds, scene->meshRows, &ds->T.meshes))) return rc;
@@ -364,14 +366,35 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     const bool st = ds->statsOn;
     const size_t stackBytes = (size_t)P.stackDepth * KZ_BLOCK * sizeof(uint32_t);
     const dim3 blk(KZ_BLOCK);
-    const dim3 gTrav((unsigned)(ds->numCU * 8)), gShade((unsigned)(ds->numCU * 6));
+    auto envInt = [](const char *n, int dflt) { const char *e = std::getenv(n); return e ? std::atoi(e) : dflt; };
+    KzTune tune = {envInt("KZ_TUNE_REFILL", 40), envInt("KZ_TUNE_POSTPONE", 20), envInt("KZ_TUNE_BATCH", 128), envInt("KZ_TUNE_TRAV_BLOCKS", 8), envInt("KZ_TUNE_SHADE_BLOCKS", 6),
+                   envInt("KZ_TUNE_LDS_STACK", 12), envInt("KZ_TUNE_WIDE", 1), nullptr, 0};
+    const dim3 gTrav((unsigned)(ds->numCU * tune.travBlocksPerCU)), gShade((unsigned)(ds->numCU * tune.shadeBlocksPerCU));
+    // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
+    const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
+    tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
+    const size_t traceLds = (size_t)tune.ldsStack * KZ_BLOCK * sizeof(uint32_t);
+    {
+        const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack);
+        if (needOvf > ds->ovfCap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (ds->ovf) HIP_TRY(hipFree(ds->ovf));
+            ds->ovf = nullptr;
+            HIP_TRY(hipMalloc((void **)&ds->ovf, needOvf * sizeof(uint32_t)));
+            ds->ovfCap = needOvf;
+        }
+        tune.ovf = ds->ovf; tune.ovfStride = (uint32_t)stride;
+    }
     const int maxDepth = P.maxDepth;
     HIP_TRY(hipMemsetAsync(W.counts, 0, 4 * 520 * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, ds->pixList, items, Sp, sBegin);
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
     static const int traceKernel = [] { const char *e = std::getenv("KZ_TRACE_KERNEL"); return e ? std::atoi(e) : 1; }();
-#define KZ_TRACE(MODE, q, cptr, cimm, headp) do { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm, headp); \
-                                                  else hipLaunchKernelGGL((kz_wf_trace<MODE, false>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm, headp); } while (0)
+#define KZ_TRACE(MODE, q, cptr, cimm, headp) do { \
+        if (tune.wide) { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune); \
+                         else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune); } \
+        else { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune); \
+               else hipLaunchKernelGGL((kz_wf_trace<MODE, false, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune); } } while (0)
 #define KZ_EXTEND(KEEP, q, cptr, cimm, headp) do { if (traceKernel) KZ_TRACE((KEEP ? 1 : 0), q, cptr, cimm, headp); \
                                             else if (st) hipLaunchKernelGGL((kz_wf_extend<true, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); \
                                             else hipLaunchKernelGGL((kz_wf_extend<false, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); } while (0)

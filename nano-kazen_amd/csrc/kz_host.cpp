@@ -181,6 +181,10 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
 
     KzParams &p = sc->prm;
     p.rootRef = rootRef;
+    { int sb = 1; uint32_t r4 = rootRef;
+      rc = kz_collapse_bvh4(sc->nodes, rootRef, sc->nodes4, r4, sb);
+      if (rc != KZ_OK) { delete sc; return kz_fail(rc, "BVH4 collapse failed"); }
+      p.rootRef4 = r4; p.stackBound4 = sb; }
     p.stackDepth = (int32_t)std::max<uint32_t>(2u, sc->bvh.maxDepth + 1);
     // invisible-light triangles for the exact any-hit shadow test
     p.shadowFast = 1; p.nIlTris = 0; p.anyInvisibleLight = 0;

@@ -18,6 +18,17 @@
 struct KzNode { float q[12]; uint32_t child[2]; uint32_t pad[2]; };
 static_assert(sizeof(KzNode) == 64, "node packet must be 64 B");
 
+// BVH4 node with 8-bit quantised child boxes, 64 B (the wavefront traversal kernels use this tree; the megakernel and
+// kz_trace_rays keep the BVH2): one packet fetch tests FOUR children, which halves both the number of per-lane 16-B
+// gathers (the L1 tag rate is what bounds incoherent traversal on CDNA4) and the length of the dependent-load chain.
+//   q0 = p.x p.y p.z | ex,ey,ez (biased float exponents, one byte each)   child box = p + q * 2^(e-127)
+//   q1 = qlo.x[4] qlo.y[4] qlo.z[4] qhi.x[4]   (4 x u8 per word, child i in byte i)
+//   q2 = qhi.y[4] qhi.z[4] - -
+//   q3 = child[4] (same encoding as KzNode::child; an empty slot has qlo = 255, qhi = 0)
+// Quantisation rounds outward against the SAME float expression the kernel evaluates, so the boxes stay conservative.
+struct KzNode4 { float p[3]; uint32_t exps; uint32_t qlo[3]; uint32_t qhi[3]; uint32_t pad[2]; uint32_t child[4]; };
+static_assert(sizeof(KzNode4) == 64, "BVH4 packet must be 64 B");
+
 // Leaf triangle in Moeller-Trumbore form, 48 B, three quads: p0.xyz e1.x | e1.y e1.z e2.x e2.y | e2.z mesh prim gid
 struct KzTri { float p0[3]; float e1[3]; float e2[3]; uint32_t mesh, prim, gid; };
 static_assert(sizeof(KzTri) == 48, "leaf triangle must be 48 B");
@@ -68,6 +79,7 @@ struct KzParams {
     // film (block.cpp:13-21)
     float filterRadius, lookupFactor; int32_t tapLo, tapHi;
     uint32_t rootRef;
+    uint32_t rootRef4; int32_t stackBound4;     // BVH4 root and the worst-case traversal stack depth
     // shadow rays: invisible-light triangles (lightPrimaryVisibility == false) are few; their box + list make the
     // any-hit form of the shadow test exact (kz_devfn.h shadowOccluded)
     int32_t shadowFast; uint32_t nIlTris; float ilLo[3], ilHi[3];
@@ -77,6 +89,7 @@ struct KzParams {
 // Device pointers (all HBM-resident after kz_scene_upload).
 struct KzDevTables {
     const KzNode *nodes;
+    const KzNode4 *nodes4;
     const KzTri *tris;
     const KzTriShade *shade;
     const KzMeshRow *meshes;
@@ -94,6 +107,7 @@ struct KzDevTables {
 struct KzScene {
     // flattened host tables
     std::vector<KzNode> nodes;
+    std::vector<KzNode4> nodes4;
     std::vector<KzTri> tris;
     std::vector<KzTriShade> shade;
     std::vector<KzMeshRow> meshRows;
@@ -116,6 +130,7 @@ struct KzScene {
 struct KzBuildTri { float v[3][3]; uint32_t mesh, prim, gid; };
 int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, std::vector<KzTri> &tris,
                  uint32_t &rootRef, KzBvhInfo &info, std::string &err);
+int kz_collapse_bvh4(const std::vector<KzNode> &nodes, uint32_t rootRef, std::vector<KzNode4> &out, uint32_t &rootRef4, int &stackBound);
 
 // kz_host.cpp
 int kz_fail(int code, const char *fmt, ...);

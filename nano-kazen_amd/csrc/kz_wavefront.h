@@ -322,40 +322,72 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 
 // ---- persistent traversal kernel -----------------------------------------------------------------------------------------
 // One wave keeps 64 rays in flight. Lanes whose ray has finished are refilled from a wave-local pool of queue entries
-// (one global atomic per KZ_TRACE_BATCH rays) once fewer than KZ_TRACE_REFILL lanes are busy, so a long ray no longer
+// (one global atomic per tune.batch rays) once fewer than tune.refill lanes are busy, so a long ray no longer
 // idles the other 63 lanes until the end of its chunk. The loop is "while-while": all lanes descend inner nodes together,
 // then all lanes at a leaf test triangles together; a few stragglers still descending do not hold up the leaf phase.
+// WIDE selects the quantised BVH4 (KzNode4) instead of the BVH2. The per-lane stack keeps tune.ldsStack entries in LDS
+// ([entry][lane] columns, conflict free) and spills deeper entries to a global overflow area sized from the builder's
+// worst-case bound, so LDS no longer caps occupancy.
 // MODE 0: closest hit -> W.hit; 1: same on the shA/shB ray, previous hit kept on a miss (H6); 2: shadow test -> adds W.shL.
-#define KZ_TRACE_BATCH 256
-#define KZ_TRACE_REFILL 44
-#define KZ_TRACE_POSTPONE 20
-template <int MODE, bool STATS>
+// Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment; such
+// a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide; uint32_t *ovf; uint32_t ovfStride; };
+
+template <int MODE, bool STATS, bool WIDE>
 __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
-                                                        const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head) {
+                                                        const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune) {
     extern __shared__ uint32_t s_stack[];
     uint32_t *stk = s_stack + threadIdx.x;
     const uint32_t count = countPtr ? *countPtr : countImm;
     const int lane = threadIdx.x & 63;
+    const int LS = tune.ldsStack;
+    uint32_t *ovf = tune.ovf + (size_t)blockIdx.x * KZ_BLOCK + threadIdx.x;
+    const size_t ovfStride = tune.ovfStride;
+    auto push = [&](int &sp_, uint32_t v) { if (sp_ < LS) stk[sp_ * KZ_BLOCK] = v; else ovf[(size_t)(sp_ - LS) * ovfStride] = v; ++sp_; };
+    auto pop = [&](int &sp_) -> uint32_t { --sp_; return sp_ < LS ? stk[sp_ * KZ_BLOCK] : ovf[(size_t)(sp_ - LS) * ovfStride]; };
+    const uint32_t root = WIDE ? P.rootRef4 : P.rootRef;
+    const float eps = P.traceBias;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     Counters cn = {0, 0, 0, 0, 0, 0};
     uint32_t poolNext = 0, poolEnd = 0;
     bool exhausted = false;
-    bool active = false;
+    bool active = false, literal = false;
     V3 o = mk(0.f), d = mk(0.f);
-    float rx = 0.f, ry = 0.f, rz = 0.f, tmin = 0.f, tmax = 0.f;
+    float rx = 0.f, ry = 0.f, rz = 0.f, tmin = 0.f, tmax = 0.f, segMax = 0.f;
     uint32_t cur = 0, slot = 0; int sp = 0;
     bool found = false; float bt = 0.f, bu = 0.f, bv = 0.f; uint32_t btri = 0, bgid = 0;
+
+    auto addPending = [&]() { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; };
+    // the lane's stack ran empty: publish the result (or, for a literal shadow lane, decide / walk through the light)
+    auto finish = [&]() {
+        active = false;
+        if (MODE == 0) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+        if (MODE == 1) { if (found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(btri)); }
+        if (MODE == 2) {
+            if (!literal || !found) addPending();                                    // nothing on the segment
+            else {
+                const uint32_t om = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + btri)[2].y);
+                const int ol = T.meshes[om].light;
+                if (ol >= 0 && !T.lights[ol].primaryVisibility) {                     // walk through (integrator.cpp:273-274)
+                    o = o + d * (bt + eps); tmin = eps; segMax = segMax - bt; tmax = segMax;
+                    found = false; bt = KZ_INF; cur = root; sp = 0; active = true;
+                    if (STATS) cn.rays++;
+                }
+            }
+        }
+    };
+
     for (;;) {
         // ---- refill idle lanes
         const unsigned long long act = __ballot(active);
         const int nAct = __popcll(act);
-        if (nAct < KZ_TRACE_REFILL && !exhausted) {
+        if (nAct < tune.refill && !exhausted) {
             if (poolNext >= poolEnd) {
                 uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(head, (uint32_t)KZ_TRACE_BATCH);
+                if (lane == 0) b = atomicAdd(head, (uint32_t)tune.batch);
                 b = __builtin_amdgcn_readfirstlane(b);
                 if (b >= count) { exhausted = true; poolNext = poolEnd = 0; }
-                else { poolNext = b; poolEnd = min(b + (uint32_t)KZ_TRACE_BATCH, count); }
+                else { poolNext = b; poolEnd = min(b + (uint32_t)tune.batch, count); }
             }
             if (!exhausted) {
                 const uint32_t take = min((uint32_t)(64 - nAct), poolEnd - poolNext);
@@ -366,39 +398,31 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
                     float4 a, b;
                     if (MODE == 0) { a = W.rayA[slot]; b = W.rayB[slot]; }
                     else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w); }
-                    o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); tmin = a.w; tmax = b.w;
-                    found = false; bt = KZ_INF; bu = bv = 0.f; btri = 0; bgid = 0;
+                    o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); tmin = a.w; tmax = b.w; segMax = b.w;
+                    found = false; bt = KZ_INF; bu = bv = 0.f; btri = 0; bgid = 0; literal = false;
                     if (STATS) cn.rays++;
-                    bool go = (P.rootRef != 0xFFFFFFFFu) && rayIsFinite(o, d);
-                    if (MODE == 2 && go) {
-                        // exact any-hit test only when no invisible-light triangle lies on the segment (kz_devfn.h shadowOccluded)
-                        bool literal = !P.shadowFast;
-                        if (!literal && P.nIlTris > 0) {
-                            const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-                            float t0 = (P.ilLo[0] - o.x) * ix, t1 = (P.ilHi[0] - o.x) * ix;
-                            float n = fminf(t0, t1), f = fmaxf(t0, t1);
-                            t0 = (P.ilLo[1] - o.y) * iy; t1 = (P.ilHi[1] - o.y) * iy; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
-                            t0 = (P.ilLo[2] - o.z) * iz; t1 = (P.ilHi[2] - o.z) * iz; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
-                            f *= 1.0000004f;
-                            if (fmaxf(n, tmin) <= fminf(f, tmax))
-                                for (uint32_t i = 0; i < P.nIlTris && !literal; ++i) {
-                                    float t, u, v; uint32_t g;
-                                    if (triTest(T.ilTris + i, o, d, tmin, tmax, t, u, v, g)) literal = true;
-                                }
-                        }
-                        if (literal) {
-                            if (STATS) cn.rays--;      // the literal loop counts its own queries
-                            if (!shadowOccludedLiteral<STATS>(P, T, o, d, tmin, tmax, stk, cn)) {
-                                const float4 l = W.shL[slot];
-                                W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z;
+                    if ((root != 0xFFFFFFFFu) && rayIsFinite(o, d)) {
+                        rx = 1.0f / d.x; ry = 1.0f / d.y; rz = 1.0f / d.z; cur = root; sp = 0; active = true;
+                        if (MODE == 2) {
+                            literal = !P.shadowFast;
+                            if (!literal && P.nIlTris > 0) {
+                                float t0 = (P.ilLo[0] - o.x) * rx, t1 = (P.ilHi[0] - o.x) * rx;
+                                float n = fminf(t0, t1), f = fmaxf(t0, t1);
+                                t0 = (P.ilLo[1] - o.y) * ry; t1 = (P.ilHi[1] - o.y) * ry; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
+                                t0 = (P.ilLo[2] - o.z) * rz; t1 = (P.ilHi[2] - o.z) * rz; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
+                                f *= 1.0000004f;
+                                if (fmaxf(n, tmin) <= fminf(f, tmax))
+                                    for (uint32_t i = 0; i < P.nIlTris && !literal; ++i) {
+                                        float t, u, v; uint32_t g;
+                                        if (triTest(T.ilTris + i, o, d, tmin, tmax, t, u, v, g)) literal = true;
+                                    }
                             }
-                            go = false;
                         }
-                    } else if (!go) {
+                    } else {
+                        // a ray that cannot hit anything (empty scene, non-finite origin/direction)
                         if (MODE == 0) W.hit[slot] = make_float4(KZ_INF, 0.f, 0.f, 0.f);
-                        if (MODE == 2) { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; }
+                        if (MODE == 2) addPending();
                     }
-                    if (go) { rx = 1.0f / d.x; ry = 1.0f / d.y; rz = 1.0f / d.z; cur = P.rootRef; sp = 0; active = true; }
                 }
                 poolNext += take;
             }
@@ -409,46 +433,45 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
             const bool inner = active && !(cur & 0x80000000u);
             const unsigned long long im = __ballot(inner);
             if (im == 0) break;
-            if (__popcll(im) < KZ_TRACE_POSTPONE && __ballot(active && (cur & 0x80000000u)) != 0) break;
+            if (__popcll(im) < tune.postpone && __ballot(active && (cur & 0x80000000u)) != 0) break;
             if (inner) {
-                const NodeTest nt = nodeTest(T, cur, o, rx, ry, rz, tmin, tmax);
+                bool empty = false;
                 if (STATS) cn.nodes++;
-                if (nt.h0 && nt.h1) {
-                    const bool swap = nt.n1 < nt.n0;
-                    stk[(sp++) * KZ_BLOCK] = swap ? nt.c0 : nt.c1;
-                    cur = swap ? nt.c1 : nt.c0;
-                } else if (nt.h0) cur = nt.c0;
-                else if (nt.h1) cur = nt.c1;
-                else if (sp > 0) cur = stk[(--sp) * KZ_BLOCK];
-                else {
-                    active = false;
-                    if (MODE == 0) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
-                    if (MODE == 1 && found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(btri));
-                    if (MODE == 2) { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; }
+                if (WIDE) {
+                    const Node4Test nt = node4Test(T, cur, o, rx, ry, rz, tmin, tmax);
+                    if (nt.k0 != 0xFFFFFFFFu) {
+                        if (nt.k3 != 0xFFFFFFFFu) push(sp, pick4(nt.refs, nt.k3 & 3u));
+                        if (nt.k2 != 0xFFFFFFFFu) push(sp, pick4(nt.refs, nt.k2 & 3u));
+                        if (nt.k1 != 0xFFFFFFFFu) push(sp, pick4(nt.refs, nt.k1 & 3u));
+                        cur = pick4(nt.refs, nt.k0 & 3u);
+                    } else empty = true;
+                } else {
+                    const NodeTest nt = nodeTest(T, cur, o, rx, ry, rz, tmin, tmax);
+                    if (nt.h0 && nt.h1) {
+                        const bool swap = nt.n1 < nt.n0;
+                        push(sp, swap ? nt.c0 : nt.c1);
+                        cur = swap ? nt.c1 : nt.c0;
+                    } else if (nt.h0) cur = nt.c0;
+                    else if (nt.h1) cur = nt.c1;
+                    else empty = true;
                 }
+                if (empty) { if (sp > 0) cur = pop(sp); else finish(); }
             }
         }
         // ---- leaf phase
         if (active && (cur & 0x80000000u)) {
             const uint32_t start = (cur & 0x7fffffffu) >> 3, cnt = (cur & 7u) + 1;
-            bool done = false;
+            bool occluded = false;
             for (uint32_t i = 0; i < cnt; ++i) {
                 float t, u, v; uint32_t g;
                 if (STATS) cn.tris++;
                 if (!triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, g)) continue;
-                if (MODE == 2) { done = true; break; }                     // occluded: nothing to add
+                if (MODE == 2 && !literal) { occluded = true; break; }                // any hit blocks: nothing to add
                 if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; btri = start + i; bgid = g; tmax = t; }
             }
-            if (!done) {
-                if (sp > 0) cur = stk[(--sp) * KZ_BLOCK];
-                else {
-                    done = true;
-                    if (MODE == 0) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
-                    if (MODE == 1 && found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(btri));
-                    if (MODE == 2) { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; }
-                }
-            }
-            if (done) active = false;
+            if (occluded) active = false;
+            else if (sp > 0) cur = pop(sp);
+            else finish();
         }
     }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
