@@ -402,7 +402,15 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
                     found = false; bt = KZ_INF; bu = bv = 0.f; btri = 0; bgid = 0; literal = false;
                     if (STATS) cn.rays++;
                     if ((root != 0xFFFFFFFFu) && rayIsFinite(o, d)) {
-                        rx = 1.0f / d.x; ry = 1.0f / d.y; rz = 1.0f / d.z; cur = root; sp = 0; active = true;
+                        if (WIDE) {
+                            // The FMA slab form q*(s*rcp) + (p-o)*rcp turns into inf - inf = NaN for a zero direction component,
+                            // which would switch that axis off (a huge slab of the tree gets walked). A tiny signed stand-in keeps
+                            // every product finite; the sign of (box - origin) * 1e20 still decides the slab exactly as 1/0 would.
+                            rx = 1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
+                            ry = 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
+                            rz = 1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
+                        } else { rx = 1.0f / d.x; ry = 1.0f / d.y; rz = 1.0f / d.z; }
+                        cur = root; sp = 0; active = true;
                         if (MODE == 2) {
                             literal = !P.shadowFast;
                             if (!literal && P.nIlTris > 0) {
