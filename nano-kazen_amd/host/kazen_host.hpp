@@ -1,0 +1,369 @@
+// kazen_host.hpp — host-side mirror of nano-kazen's plugin surface for the path_mis hot path, above the C ABI
+// (include/kazen_mi355x.h). Header-only C++17, no dependencies.
+//
+// Same class names, registry strings, property names and defaults as the reference:
+//   ObjectFactory::createInstance(name, PropertyList)        include/kazen/object.h:133-138, KAZEN_REGISTER_CLASS :144-152
+//   Object::addChild / activate / getClassType               include/kazen/object.h:40-75
+//   Scene, Mesh, PerspectiveCamera("perspective"), Independent("independent"), PMJ02BN("pmj02bn"),
+//   PathMisIntegrator("path_mis"), Diffuse("diffuse"), KazenStandardSurface("kazenstandard"), AreaLight("area"),
+//   ConstantTexture("constanttexture"), BackgroundTexture("background"), GaussianFilter("gaussian"),
+//   MitchellNetravaliFilter("mitchell"), TentFilter("tent"), BoxFilter("box")
+//   renderer::render(Scene*, ...)                              include/kazen/renderer.h:10, src/kazen/renderer.cpp:72-153
+// The objects are DESCRIPTIONS: Scene::activate() flattens them into a KzSceneDesc (enum tags instead of vtables)
+// and renderer::render() hands that to the library, which does what renderer.cpp:85-133 did with TBB + Embree.
+// Error behaviour follows the reference: kazen::Exception (std::runtime_error) from createInstance/addChild/activate
+// (scene.cpp:33-35, parser.cpp:295-298); a plugin name that exists in the reference but is outside the hot path throws
+// "... is not on the MI355X hot path" — never a silent fallback.
+#pragma once
+#include "../../include/kazen_mi355x.h"
+
+#include <array>
+#include <cmath>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+
+namespace kazen {
+
+class Exception : public std::runtime_error {       // include/kazen/common.h:124-129
+public:
+    explicit Exception(const std::string &m) : std::runtime_error(m) {}
+};
+
+struct Color3f { float r = 0, g = 0, b = 0; Color3f() {} Color3f(float v) : r(v), g(v), b(v) {} Color3f(float r_, float g_, float b_) : r(r_), g(g_), b(b_) {} };
+struct Transform {                                   // include/kazen/transform.h:16-78 (row-major here)
+    std::array<float, 16> m{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    /// <lookat origin target up> as parser.cpp:268-287 builds it: columns = left, newUp, dir, origin
+    static Transform lookAt(const std::array<float, 3> &o, const std::array<float, 3> &t, const std::array<float, 3> &up) {
+        auto sub = [](auto a, auto b) { return std::array<float, 3>{a[0] - b[0], a[1] - b[1], a[2] - b[2]}; };
+        auto cross = [](auto a, auto b) { return std::array<float, 3>{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}; };
+        auto norm = [](auto a) { float l = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); return std::array<float, 3>{a[0] / l, a[1] / l, a[2] / l}; };
+        auto d = norm(sub(t, o)); auto left = norm(cross(up, d)); auto nu = cross(d, left);
+        Transform r;
+        r.m = {left[0], nu[0], d[0], o[0], left[1], nu[1], d[1], o[1], left[2], nu[2], d[2], o[2], 0, 0, 0, 1};
+        return r;
+    }
+};
+
+/// Typed property bag with defaults (include/kazen/proplist.h, src/kazen/proplist.cpp:5-32)
+class PropertyList {
+public:
+    using Value = std::variant<bool, int, float, std::string, Color3f, Transform>;
+    void setBoolean(const std::string &n, bool v) { m_[n] = v; }
+    void setInteger(const std::string &n, int v) { m_[n] = v; }
+    void setFloat(const std::string &n, float v) { m_[n] = v; }
+    void setString(const std::string &n, const std::string &v) { m_[n] = v; }
+    void setColor(const std::string &n, const Color3f &v) { m_[n] = v; }
+    void setTransform(const std::string &n, const Transform &v) { m_[n] = v; }
+    bool getBoolean(const std::string &n, bool d) const { return get<bool>(n, d); }
+    int getInteger(const std::string &n, int d) const { return get<int>(n, d); }
+    float getFloat(const std::string &n, float d) const { return get<float>(n, d); }
+    std::string getString(const std::string &n, const std::string &d) const { return get<std::string>(n, d); }
+    Color3f getColor(const std::string &n, const Color3f &d) const { return get<Color3f>(n, d); }
+    Transform getTransform(const std::string &n, const Transform &d) const { return get<Transform>(n, d); }
+private:
+    template <class T> T get(const std::string &n, const T &d) const {
+        auto it = m_.find(n);
+        if (it == m_.end()) return d;
+        if (!std::holds_alternative<T>(it->second)) throw Exception("Property '" + n + "' has the wrong type!");
+        return std::get<T>(it->second);
+    }
+    std::map<std::string, Value> m_;
+};
+
+class Object {                                       // include/kazen/object.h:17-100
+public:
+    enum EClassType { EScene = 0, EMesh, EBSDF, ELight, EMedium, ECamera, EIntegrator, ESampler, EReconstructionFilter, ETexture, EClassTypeCount };
+    virtual ~Object() {}
+    virtual EClassType getClassType() const = 0;
+    virtual void addChild(Object *) { throw Exception("Object::addChild() is not implemented for objects of type '" + classTypeName(getClassType()) + "'!"); }
+    virtual void setParent(Object *) {}
+    virtual void activate() {}
+    virtual std::string toString() const = 0;
+    void setId(const std::string &id) { m_id = id; }
+    const std::string &getId() const { return m_id; }
+    static std::string classTypeName(EClassType t) {
+        static const char *n[] = {"scene", "mesh", "bsdf", "light", "medium", "camera", "integrator", "sampler", "rfilter", "texture"};
+        return t < EClassTypeCount ? n[t] : "<unknown>";
+    }
+protected:
+    std::string m_id;
+};
+
+class ObjectFactory {                                // include/kazen/object.h:108-141
+public:
+    using Constructor = std::function<Object *(const PropertyList &)>;
+    static void registerClass(const std::string &name, const Constructor &c) { table()[name] = c; }
+    static Object *createInstance(const std::string &name, const PropertyList &props) {
+        auto &t = table();
+        auto it = t.find(name);
+        if (it != t.end()) return it->second(props);
+        static const char *offPath[] = {"normals", "ao", "whitted", "path_mats", "stratified", "correlated", "thinlens", "dielectric", "mirror",
+                                        "lambertian", "normalmap", "ggx", "roughconductor", "roughplastic", "roughdielectric", "imagetexture",
+                                        "colorramp", "blend", "nonscatter"};
+        for (const char *o : offPath)
+            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis + diffuse/kazenstandard + independent/pmj02bn + perspective)");
+        throw Exception("A constructor for class \"" + name + "\" could not be found!");
+    }
+private:
+    static std::map<std::string, Constructor> &table() { static std::map<std::string, Constructor> t; return t; }
+};
+#define KAZEN_MI355X_REGISTER(cls, name) \
+    inline bool cls##_registered = (::kazen::ObjectFactory::registerClass(name, [](const ::kazen::PropertyList &p) -> ::kazen::Object * { return new cls(p); }), true)
+
+// ---- textures (src/kazen/texture.cpp:104-145, :240-270): constants only -------------------------------------------
+class ConstantTexture : public Object {
+public:
+    explicit ConstantTexture(const PropertyList &p) { m_color = p.getColor("color", Color3f(0.f)); }
+    EClassType getClassType() const override { return ETexture; }
+    std::string toString() const override { return "ConstantTexture[]"; }
+    Color3f m_color;
+};
+class BackgroundTexture : public Object {
+public:
+    explicit BackgroundTexture(const PropertyList &p) { m_intensity = p.getFloat("intensity", 1.0f); }
+    ~BackgroundTexture() override { delete m_nested; }
+    void addChild(Object *o) override {
+        if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than nested Texture");
+        auto *c = dynamic_cast<ConstantTexture *>(o);
+        if (!c) throw Exception("background: only a nested constanttexture is on the MI355X hot path");
+        m_nested = c;
+    }
+    EClassType getClassType() const override { return ETexture; }
+    std::string toString() const override { return "Background[]"; }
+    float m_intensity; ConstantTexture *m_nested = nullptr;
+};
+
+// ---- BSDFs ----------------------------------------------------------------------------------------------------------
+class BSDF : public Object {
+public:
+    EClassType getClassType() const override { return EBSDF; }
+    virtual KzBSDF row() const = 0;
+};
+class Diffuse : public BSDF {                        // src/kazen/bsdf.cpp:20-92
+public:
+    explicit Diffuse(const PropertyList &p) { m_albedo = p.getColor("albedo", Color3f(0.5f)); }
+    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_DIFFUSE; b.albedo[0] = m_albedo.r; b.albedo[1] = m_albedo.g; b.albedo[2] = m_albedo.b; return b; }
+    std::string toString() const override { return "Diffuse[]"; }
+    Color3f m_albedo;
+};
+class KazenStandardSurface : public BSDF {           // src/kazen/bsdf.cpp:1157-1418
+public:
+    explicit KazenStandardSurface(const PropertyList &p) {
+        m_anisotropy = p.getFloat("anisotropy", 0.0f); m_specular = p.getFloat("specular", 0.5f); m_specularTint = p.getFloat("specularTint", 0.5f);
+        m_clearcoat = p.getFloat("clearcoat", 0.0f); m_clearcoatRoughness = p.getFloat("clearcoatRoughness", 0.5f);
+        m_sheen = p.getFloat("sheen", 0.0f); m_sheenTint = p.getFloat("sheenTint", 0.5f);
+    }
+    ~KazenStandardSurface() override { delete m_baseColor; delete m_roughness; delete m_metallic; }
+    void addChild(Object *o) override {              // bsdf.cpp:1373-1395: textures by id
+        if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than baseColor maps");
+        auto *c = dynamic_cast<ConstantTexture *>(o);
+        if (!c) throw Exception("kazenstandard: only constanttexture children are on the MI355X hot path");
+        auto set = [&](ConstantTexture *&slot, const char *what) { if (slot) throw Exception(std::string("There is already an ") + what + " defined!"); slot = c; };
+        if (o->getId() == "baseColor") set(m_baseColor, "baseColor");
+        else if (o->getId() == "metallic") set(m_metallic, "metallic");
+        else if (o->getId() == "roughness") set(m_roughness, "roughness");
+        else throw Exception("kazenstandard: texture id must be baseColor, metallic or roughness");
+    }
+    void activate() override { if (!m_baseColor || !m_roughness || !m_metallic) throw Exception("kazenstandard needs baseColor, roughness and metallic textures"); }
+    KzBSDF row() const override {
+        KzBSDF b{}; b.type = KZ_BSDF_KAZENSTANDARD;
+        b.baseColor[0] = m_baseColor->m_color.r; b.baseColor[1] = m_baseColor->m_color.g; b.baseColor[2] = m_baseColor->m_color.b;
+        b.roughness = m_roughness->m_color.r; b.metallic = m_metallic->m_color.r;       // .r() of the colour, bsdf.cpp:1227,1231
+        b.anisotropy = m_anisotropy; b.specular = m_specular; b.specularTint = m_specularTint; b.clearcoat = m_clearcoat;
+        b.clearcoatRoughness = m_clearcoatRoughness; b.sheen = m_sheen; b.sheenTint = m_sheenTint;
+        return b;
+    }
+    std::string toString() const override { return "KazenStandardSurface"; }
+    ConstantTexture *m_baseColor = nullptr, *m_roughness = nullptr, *m_metallic = nullptr;
+    float m_anisotropy, m_specular, m_specularTint, m_clearcoat, m_clearcoatRoughness, m_sheen, m_sheenTint;
+};
+
+// ---- light / filter / sampler / integrator / camera -------------------------------------------------------------------
+class AreaLight : public Object {                    // src/kazen/light.cpp:7-70
+public:
+    explicit AreaLight(const PropertyList &p) { m_color = p.getColor("color", Color3f(1.f)); m_intensity = p.getFloat("intensity", 1.f); m_vis = p.getBoolean("lightPrimaryVisibility", false); }
+    EClassType getClassType() const override { return ELight; }
+    bool getPrimaryVisibility() const { return m_vis; }
+    KzLight row() const { KzLight l{}; l.color[0] = m_color.r; l.color[1] = m_color.g; l.color[2] = m_color.b; l.intensity = m_intensity; l.primaryVisibility = m_vis ? 1 : 0; return l; }
+    std::string toString() const override { return "AreaLight[]"; }
+    Color3f m_color; float m_intensity; bool m_vis;
+};
+class ReconstructionFilter : public Object {         // include/kazen/rfilter.h:22-37, src/kazen/rfilter.cpp
+public:
+    EClassType getClassType() const override { return EReconstructionFilter; }
+    float getRadius() const { return m_f.radius; }
+    KzFilter m_f{};
+};
+class GaussianFilter : public ReconstructionFilter { public: explicit GaussianFilter(const PropertyList &p) { m_f.type = KZ_FILTER_GAUSSIAN; m_f.radius = p.getFloat("radius", 2.0f); m_f.stddev = p.getFloat("stddev", 0.5f); } std::string toString() const override { return "GaussianFilter[]"; } };
+class MitchellNetravaliFilter : public ReconstructionFilter { public: explicit MitchellNetravaliFilter(const PropertyList &p) { m_f.type = KZ_FILTER_MITCHELL; m_f.radius = p.getFloat("radius", 2.0f); m_f.B = p.getFloat("B", 1.0f / 3.0f); m_f.C = p.getFloat("C", 1.0f / 3.0f); } std::string toString() const override { return "MitchellNetravaliFilter[]"; } };
+class TentFilter : public ReconstructionFilter { public: explicit TentFilter(const PropertyList &) { m_f.type = KZ_FILTER_TENT; m_f.radius = 1.0f; } std::string toString() const override { return "TentFilter[]"; } };
+class BoxFilter : public ReconstructionFilter { public: explicit BoxFilter(const PropertyList &) { m_f.type = KZ_FILTER_BOX; m_f.radius = 0.5f; } std::string toString() const override { return "BoxFilter[]"; } };
+
+class Sampler : public Object {                      // include/kazen/sampler.h:44-107
+public:
+    EClassType getClassType() const override { return ESampler; }
+    uint32_t getSampleCount() const { return m_s.sampleCount; }
+    KzSampler m_s{};
+};
+class Independent : public Sampler {                 // src/kazen/sampler.cpp:18-71 (seed: the reference leaves it uninitialised; 0 here, H2)
+public:
+    explicit Independent(const PropertyList &p) { m_s.type = KZ_SAMPLER_INDEPENDENT; m_s.sampleCount = (uint32_t)p.getInteger("sampleCount", 1); m_s.seed = (uint64_t)p.getInteger("seed", 0); }
+    std::string toString() const override { return "Independent[sampleCount=" + std::to_string(m_s.sampleCount) + "]"; }
+};
+class PMJ02BN : public Sampler {                     // src/kazen/sampler.cpp:273-390; tables = the arrays of pmj02table.cpp / bluenoise.cpp
+public:
+    explicit PMJ02BN(const PropertyList &p) { m_s.type = KZ_SAMPLER_PMJ02BN; m_s.seed = (uint64_t)p.getInteger("seed", 1); m_s.sampleCount = (uint32_t)p.getInteger("sampleCount", 16); }
+    void setTables(const uint32_t *pmj02bnSamples, const uint16_t *blueNoiseTextures) { m_s.pmj02bnSamples = pmj02bnSamples; m_s.blueNoise = blueNoiseTextures; }
+    std::string toString() const override { return "PMJ02BN"; }
+};
+class Integrator : public Object { public: EClassType getClassType() const override { return EIntegrator; } virtual void preprocess(const class Scene *) {} KzIntegrator m_i{}; };
+class PathMisIntegrator : public Integrator {        // src/kazen/integrator.cpp:185-355
+public:
+    explicit PathMisIntegrator(const PropertyList &p) {
+        m_i.type = KZ_INTEGRATOR_PATH_MIS; m_i.maxDepth = std::min(512, p.getInteger("maxDepth", 5)); m_i.traceBias = p.getFloat("traceBias", 0.001f);
+        m_i.regularization = p.getBoolean("regularization", false) ? 1 : 0; m_i.accumulatedRoughness = p.getFloat("accumulatedRoughness", 0.5f);
+    }
+    std::string toString() const override { return "PathMisIntegrator[]"; }
+};
+class Camera : public Object { public: EClassType getClassType() const override { return ECamera; } KzCamera m_c{}; ReconstructionFilter *m_rfilter = nullptr; ~Camera() override { delete m_rfilter; } };
+class PerspectiveCamera : public Camera {            // src/kazen/camera.cpp:14-131
+public:
+    explicit PerspectiveCamera(const PropertyList &p) {
+        m_c.type = KZ_CAMERA_PERSPECTIVE; m_c.width = p.getInteger("width", 1280); m_c.height = p.getInteger("height", 720);
+        Transform t = p.getTransform("toWorld", Transform());
+        for (int i = 0; i < 16; ++i) m_c.toWorld[i] = t.m[i];
+        m_c.fov = p.getFloat("fov", 30.0f); m_c.nearClip = p.getFloat("nearClip", 1e-4f); m_c.farClip = p.getFloat("farClip", 1e4f);
+    }
+    void addChild(Object *o) override {
+        if (o->getClassType() != EReconstructionFilter) throw Exception("Camera::addChild(<" + classTypeName(o->getClassType()) + ">) is not supported!");
+        if (m_rfilter) throw Exception("Camera: tried to register multiple reconstruction filters!");
+        m_rfilter = static_cast<ReconstructionFilter *>(o);
+    }
+    void activate() override { if (!m_rfilter) m_rfilter = static_cast<ReconstructionFilter *>(ObjectFactory::createInstance("gaussian", PropertyList())); m_c.rfilter = m_rfilter->m_f; }
+    std::string toString() const override { return "PerspectiveCamera[]"; }
+};
+
+// ---- mesh: buffers in the layout of kazen::Mesh (mesh.h:176-179); the OBJ loader itself is host scene I/O, out of scope ----
+class Mesh : public Object {
+public:
+    Mesh() {}
+    explicit Mesh(const PropertyList &) {}
+    ~Mesh() override { delete m_bsdf; delete m_light; }
+    void setBuffers(std::vector<float> V, std::vector<uint32_t> F, std::vector<float> N = {}, std::vector<float> UV = {}) { m_V = std::move(V); m_F = std::move(F); m_N = std::move(N); m_UV = std::move(UV); }
+    void addChild(Object *o) override {              // mesh.cpp:135-165
+        switch (o->getClassType()) {
+        case EBSDF: if (m_bsdf) throw Exception("Mesh: tried to register multiple BSDF instances!"); m_bsdf = static_cast<BSDF *>(o); break;
+        case ELight: if (m_light) throw Exception("Mesh: tried to register multiple light instances!"); m_light = static_cast<AreaLight *>(o); break;
+        default: throw Exception("Mesh::addChild(<" + classTypeName(o->getClassType()) + ">) is not supported!");
+        }
+    }
+    bool isLight() const { return m_light != nullptr; }
+    EClassType getClassType() const override { return EMesh; }
+    std::string toString() const override { return "Mesh[]"; }
+    std::vector<float> m_V, m_N, m_UV; std::vector<uint32_t> m_F; BSDF *m_bsdf = nullptr; AreaLight *m_light = nullptr;
+};
+
+// ---- scene ---------------------------------------------------------------------------------------------------------------
+class Scene : public Object {                        // src/kazen/scene.cpp, include/kazen/scene.h
+public:
+    explicit Scene(const PropertyList & = PropertyList()) {}
+    ~Scene() override { if (m_handle) kz_scene_destroy(m_handle); for (auto *m : m_meshes) delete m; delete m_sampler; delete m_camera; delete m_integrator; delete m_background; }
+    void addChild(Object *o) override {              // scene.cpp:81-130
+        switch (o->getClassType()) {
+        case EMesh: m_meshes.push_back(static_cast<Mesh *>(o)); break;
+        case ESampler: if (m_sampler) throw Exception("There can only be one sampler per scene!"); m_sampler = static_cast<Sampler *>(o); break;
+        case ECamera: if (m_camera) throw Exception("There can only be one camera per scene!"); m_camera = static_cast<Camera *>(o); break;
+        case EIntegrator: if (m_integrator) throw Exception("There can only be one integrator per scene!"); m_integrator = static_cast<Integrator *>(o); break;
+        case ETexture: {
+            auto *b = dynamic_cast<BackgroundTexture *>(o);
+            if (!b) throw Exception("Scene::addChild(<texture>): only \"background\" is supported");
+            m_background = b; break;
+        }
+        default: throw Exception("Scene::addChild(<" + classTypeName(o->getClassType()) + ">) is not supported!");
+        }
+    }
+    /// scene.cpp:29-52 + the flattening: builds the KzSceneDesc and the library scene (host BVH build included)
+    void activate() override {
+        if (!m_integrator) throw Exception("No integrator was specified!");
+        if (!m_camera) throw Exception("No camera was specified!");
+        if (!m_sampler) m_sampler = static_cast<Sampler *>(ObjectFactory::createInstance("independent", PropertyList()));
+        m_bsdfRows.clear(); m_lightRows.clear(); m_meshRows.clear();
+        for (Mesh *m : m_meshes) {
+            KzMesh k{}; k.V = m->m_V.data(); k.F = m->m_F.data(); k.N = m->m_N.empty() ? nullptr : m->m_N.data(); k.UV = m->m_UV.empty() ? nullptr : m->m_UV.data();
+            k.nV = (uint32_t)(m->m_V.size() / 3); k.nF = (uint32_t)(m->m_F.size() / 3);
+            k.bsdf = -1; k.light = -1;
+            if (m->m_bsdf) { m->m_bsdf->activate(); k.bsdf = (int32_t)m_bsdfRows.size(); m_bsdfRows.push_back(m->m_bsdf->row()); }   // no bsdf: default diffuse (mesh.cpp:25-28)
+            if (m->m_light) { k.light = (int32_t)m_lightRows.size(); m_lightRows.push_back(m->m_light->row()); }
+            m_meshRows.push_back(k);
+        }
+        m_camera->activate();
+        KzSceneDesc d{};
+        d.abiVersion = KZ_ABI_VERSION;
+        d.meshes = m_meshRows.data(); d.nMeshes = (uint32_t)m_meshRows.size();
+        d.bsdfs = m_bsdfRows.data(); d.nBsdfs = (uint32_t)m_bsdfRows.size();
+        d.lights = m_lightRows.data(); d.nLights = (uint32_t)m_lightRows.size();
+        d.camera = m_camera->m_c; d.sampler = m_sampler->m_s; d.integrator = m_integrator->m_i;
+        if (m_background && m_background->m_nested) {
+            d.background.present = 1; d.background.intensity = m_background->m_intensity;
+            d.background.color[0] = m_background->m_nested->m_color.r; d.background.color[1] = m_background->m_nested->m_color.g; d.background.color[2] = m_background->m_nested->m_color.b;
+        }
+        m_desc = d;
+        if (m_handle) { kz_scene_destroy(m_handle); m_handle = nullptr; }
+        int rc = kz_scene_create(&m_desc, &m_handle);
+        if (rc != KZ_OK) throw Exception(std::string("kz_scene_create: ") + kz_last_error());
+    }
+    const std::vector<Mesh *> &getMeshes() const { return m_meshes; }
+    const Camera *getCamera() const { return m_camera; }
+    const Sampler *getSampler() const { return m_sampler; }
+    const Integrator *getIntegrator() const { return m_integrator; }
+    size_t getNumLights() const { return m_lightRows.size(); }
+    const KzSceneDesc &desc() const { return m_desc; }
+    KzScene *handle() const { return m_handle; }
+    EClassType getClassType() const override { return EScene; }
+    std::string toString() const override { return "Scene[]"; }
+private:
+    std::vector<Mesh *> m_meshes; Sampler *m_sampler = nullptr; Camera *m_camera = nullptr; Integrator *m_integrator = nullptr; BackgroundTexture *m_background = nullptr;
+    std::vector<KzMesh> m_meshRows; std::vector<KzBSDF> m_bsdfRows; std::vector<KzLight> m_lightRows;
+    KzSceneDesc m_desc{}; KzScene *m_handle = nullptr;
+};
+
+KAZEN_MI355X_REGISTER(Scene, "scene");
+KAZEN_MI355X_REGISTER(Mesh, "obj");
+KAZEN_MI355X_REGISTER(AreaLight, "area");
+KAZEN_MI355X_REGISTER(Diffuse, "diffuse");
+KAZEN_MI355X_REGISTER(KazenStandardSurface, "kazenstandard");
+KAZEN_MI355X_REGISTER(ConstantTexture, "constanttexture");
+KAZEN_MI355X_REGISTER(BackgroundTexture, "background");
+KAZEN_MI355X_REGISTER(PerspectiveCamera, "perspective");
+KAZEN_MI355X_REGISTER(GaussianFilter, "gaussian");
+KAZEN_MI355X_REGISTER(MitchellNetravaliFilter, "mitchell");
+KAZEN_MI355X_REGISTER(TentFilter, "tent");
+KAZEN_MI355X_REGISTER(BoxFilter, "box");
+KAZEN_MI355X_REGISTER(Independent, "independent");
+KAZEN_MI355X_REGISTER(PMJ02BN, "pmj02bn");
+KAZEN_MI355X_REGISTER(PathMisIntegrator, "path_mis");
+
+namespace renderer {
+/// The drop-in for kazen::renderer::render (renderer.cpp:72-153): render every sample of every pixel on `device` and
+/// return the normalised bitmap (h x w x rgb, linear) — what result.toBitmap() holds before savePNG. File output (PNG/EXR
+/// through OpenImageIO in the reference) stays with the caller: it is host I/O, outside the hot path.
+inline std::vector<float> render(Scene *scene, int device = 0) {
+    KzScene *h = scene->handle();
+    if (!h) throw Exception("renderer::render: scene was not activated");
+    if (kz_scene_upload(h, device) != KZ_OK) throw Exception(std::string("kz_scene_upload: ") + kz_last_error());
+    KzRenderOpts o{};
+    if (kz_render(h, &o) != KZ_OK) throw Exception(std::string("kz_render: ") + kz_last_error());
+    int32_t w, hh, b;
+    kz_film_dims(h, &w, &hh, &b);
+    std::vector<float> film((size_t)(w + 2 * b) * (hh + 2 * b) * 4), rgb((size_t)w * hh * 3);
+    if (kz_film_download(h, film.data(), film.size()) != KZ_OK) throw Exception(std::string("kz_film_download: ") + kz_last_error());
+    kz_film_to_rgb(film.data(), w, hh, b, rgb.data());
+    return rgb;
+}
+} // namespace renderer
+} // namespace kazen

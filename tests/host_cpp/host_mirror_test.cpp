@@ -1,0 +1,87 @@
+// Drives the C++ host mirror (nano-kazen_amd/host/kazen_host.hpp) the way nano-kazen's parser drives its object
+// model (parser.cpp:116-301: children first, createInstance, addChild, activate), then either dumps the flattened
+// description as JSON (no GPU needed) or renders on GPU 0 and writes the linear rgb bitmap to a file.
+#include "../../nano-kazen_amd/host/kazen_host.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+using namespace kazen;
+
+static Mesh *quadMesh(const float p[4][3], const float n[3]) {
+    auto *m = static_cast<Mesh *>(ObjectFactory::createInstance("obj", PropertyList()));
+    std::vector<float> V, N, UV = {0, 0, 1, 0, 1, 1, 0, 1};
+    for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) { V.push_back(p[i][a]); N.push_back(n[a]); }
+    m->setBuffers(V, {0, 1, 2, 0, 2, 3}, N, UV);
+    return m;
+}
+static Object *constTex(const char *id, float r, float g, float b) {
+    PropertyList p; p.setColor("color", Color3f(r, g, b));
+    Object *t = ObjectFactory::createInstance("constanttexture", p); t->setId(id); return t;
+}
+
+static Scene *buildScene() {
+    auto *scene = static_cast<Scene *>(ObjectFactory::createInstance("scene", PropertyList()));
+    { PropertyList p; p.setInteger("maxDepth", 4); scene->addChild(ObjectFactory::createInstance("path_mis", p)); }
+    { PropertyList p; p.setInteger("sampleCount", 8); p.setInteger("seed", 0); scene->addChild(ObjectFactory::createInstance("independent", p)); }
+    { PropertyList p; p.setInteger("width", 64); p.setInteger("height", 48); p.setFloat("fov", 40.f); p.setFloat("nearClip", 0.1f); p.setFloat("farClip", 100.f);
+      p.setTransform("toWorld", Transform::lookAt({0, 0.5f, 3.f}, {0, 0, 0}, {0, 1, 0}));
+      Object *cam = ObjectFactory::createInstance("perspective", p);
+      PropertyList f; f.setFloat("radius", 2.0f); f.setFloat("stddev", 0.5f);
+      cam->addChild(ObjectFactory::createInstance("gaussian", f));
+      scene->addChild(cam); }
+    const float up[3] = {0, 1, 0}, down[3] = {0, -1, 0}, front[3] = {0, 0, 1};
+    const float floorP[4][3] = {{-2, -1, -2}, {2, -1, -2}, {2, -1, 2}, {-2, -1, 2}};
+    const float wallP[4][3] = {{-2, -1, -2}, {-2, 2, -2}, {2, 2, -2}, {2, -1, -2}};
+    const float lightP[4][3] = {{-0.5f, 1.5f, -0.5f}, {-0.5f, 1.5f, 0.5f}, {0.5f, 1.5f, 0.5f}, {0.5f, 1.5f, -0.5f}};
+    const float panelP[4][3] = {{-0.8f, -0.6f, 0}, {0.8f, -0.6f, 0}, {0.8f, 0.6f, -0.6f}, {-0.8f, 0.6f, -0.6f}};
+    const float panelN[3] = {0, 0.70710678f, 0.70710678f};
+    scene->addChild(quadMesh(floorP, up));                                    // no bsdf child: default diffuse 0.5
+    { Mesh *m = quadMesh(wallP, front); PropertyList p; p.setColor("albedo", Color3f(0.7f, 0.3f, 0.3f)); m->addChild(ObjectFactory::createInstance("diffuse", p)); scene->addChild(m); }
+    { Mesh *m = quadMesh(panelP, panelN); PropertyList p; p.setFloat("clearcoat", 1.0f); p.setFloat("sheen", 0.5f);
+      Object *b = ObjectFactory::createInstance("kazenstandard", p);
+      b->addChild(constTex("baseColor", 0.8f, 0.6f, 0.2f)); b->addChild(constTex("roughness", 0.4f, 0.4f, 0.4f)); b->addChild(constTex("metallic", 0.f, 0.f, 0.f));
+      m->addChild(b); scene->addChild(m); }
+    { Mesh *m = quadMesh(lightP, down); PropertyList p; p.setFloat("intensity", 12.f); p.setColor("color", Color3f(1.f, 0.9f, 0.8f)); m->addChild(ObjectFactory::createInstance("area", p)); scene->addChild(m); }
+    { PropertyList p; p.setFloat("intensity", 0.25f); Object *bg = ObjectFactory::createInstance("background", p); bg->addChild(constTex("", 0.5f, 0.6f, 1.0f)); scene->addChild(bg); }
+    scene->activate();
+    return scene;
+}
+
+template <class F> static std::string thrown(F f) { try { f(); } catch (const Exception &e) { return e.what(); } return ""; }
+
+int main(int argc, char **argv) {
+    if (argc >= 3 && !std::strcmp(argv[1], "--render")) {
+        std::unique_ptr<Scene> scene(buildScene());
+        std::vector<float> rgb = renderer::render(scene.get(), 0);
+        std::ofstream(argv[2], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
+        double s = 0; for (float v : rgb) s += v;
+        std::printf("{\"pixels\": %zu, \"mean\": %.6f}\n", rgb.size() / 3, s / rgb.size());
+        return 0;
+    }
+    std::unique_ptr<Scene> scene(buildScene());
+    const KzSceneDesc &d = scene->desc();
+    KzBvhInfo info; kz_scene_bvh_info(scene->handle(), &info);
+    std::string e1 = thrown([] { ObjectFactory::createInstance("whitted", PropertyList()); });
+    std::string e2 = thrown([] { ObjectFactory::createInstance("nosuchclass", PropertyList()); });
+    std::string e3 = thrown([] { Scene s; s.addChild(ObjectFactory::createInstance("path_mis", PropertyList())); s.activate(); });
+    std::string e4 = thrown([] { Scene s; s.addChild(ObjectFactory::createInstance("independent", PropertyList())); s.addChild(ObjectFactory::createInstance("independent", PropertyList())); });
+    std::string e5 = thrown([] { std::unique_ptr<Object> c(ObjectFactory::createInstance("perspective", PropertyList())); c->addChild(ObjectFactory::createInstance("diffuse", PropertyList())); });
+    auto esc = [](std::string s) { for (auto &c : s) if (c == '"') c = '\''; return s; };
+    std::printf("{\"nMeshes\": %u, \"nBsdfs\": %u, \"nLights\": %u, \"meshBsdf\": [%d, %d, %d, %d], \"meshLight\": [%d, %d, %d, %d],\n",
+                d.nMeshes, d.nBsdfs, d.nLights, d.meshes[0].bsdf, d.meshes[1].bsdf, d.meshes[2].bsdf, d.meshes[3].bsdf,
+                d.meshes[0].light, d.meshes[1].light, d.meshes[2].light, d.meshes[3].light);
+    std::printf(" \"kiss\": [%d, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g], \"light\": [%g, %g, %g, %g, %d],\n", d.bsdfs[1].type, d.bsdfs[1].baseColor[0],
+                d.bsdfs[1].baseColor[1], d.bsdfs[1].baseColor[2], d.bsdfs[1].roughness, d.bsdfs[1].metallic, d.bsdfs[1].anisotropy, d.bsdfs[1].specular, d.bsdfs[1].specularTint,
+                d.bsdfs[1].clearcoat, d.bsdfs[1].clearcoatRoughness, d.bsdfs[1].sheen, d.bsdfs[1].sheenTint, d.lights[0].color[0], d.lights[0].color[1], d.lights[0].color[2],
+                d.lights[0].intensity, d.lights[0].primaryVisibility);
+    std::printf(" \"camera\": [%d, %d, %g, %g, %g, %d, %g, %g], \"sampler\": [%d, %u, %llu], \"integrator\": [%d, %d, %g, %d, %g], \"background\": [%d, %g, %g, %g, %g],\n",
+                d.camera.width, d.camera.height, d.camera.fov, d.camera.nearClip, d.camera.farClip, d.camera.rfilter.type, d.camera.rfilter.radius, d.camera.rfilter.stddev,
+                d.sampler.type, d.sampler.sampleCount, (unsigned long long)d.sampler.seed, d.integrator.type, d.integrator.maxDepth, d.integrator.traceBias,
+                d.integrator.regularization, d.integrator.accumulatedRoughness, d.background.present, d.background.color[0], d.background.color[1], d.background.color[2], d.background.intensity);
+    std::printf(" \"toWorld\": [");
+    for (int i = 0; i < 16; ++i) std::printf("%s%.9g", i ? ", " : "", d.camera.toWorld[i]);
+    std::printf("],\n \"bvhTris\": %u, \"errors\": [\"%s\", \"%s\", \"%s\", \"%s\", \"%s\"]}\n", info.nTris, esc(e1).c_str(), esc(e2).c_str(), esc(e3).c_str(), esc(e4).c_str(), esc(e5).c_str());
+    return 0;
+}

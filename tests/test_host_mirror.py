@@ -1,0 +1,69 @@
+"""The C++ host mirror (nano-kazen_amd/host/kazen_host.hpp) keeps the reference's plugin surface: registry strings,
+PropertyList names, defaults, addChild/activate order and exception behaviour. The test program is
+driven like the reference's parser drives its object model; Python builds the same scene through its own path."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host_cpp", "host_mirror_test.cpp")
+LIBDIR = os.path.join(ROOT, "nano-kazen_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory, kz):
+    kz.abi.load_library()
+    out = str(tmp_path_factory.mktemp("host") / "host_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", out, SRC, "-L" + LIBDIR, "-lkazen_mi355x", "-Wl,-rpath," + LIBDIR])
+    return out
+
+
+def python_twin(kz):
+    S = kz.scenes
+    s = S.SceneDescription()
+
+    def q(p, n):
+        P = np.array(p, np.float32)
+        return P, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), np.tile(np.array(n, np.float32), (4, 1)), np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    s.add_mesh(*q([(-2, -1, -2), (2, -1, -2), (2, -1, 2), (-2, -1, 2)], (0, 1, 0)))
+    s.add_mesh(*q([(-2, -1, -2), (-2, 2, -2), (2, 2, -2), (2, -1, -2)], (0, 0, 1)), bsdf=S.diffuse((0.7, 0.3, 0.3)))
+    s.add_mesh(*q([(-0.8, -0.6, 0), (0.8, -0.6, 0), (0.8, 0.6, -0.6), (-0.8, 0.6, -0.6)], (0, 0.70710678, 0.70710678)),
+               bsdf=S.kazenstandard((0.8, 0.6, 0.2), roughness=0.4, metallic=0.0, clearcoat=1.0, sheen=0.5))
+    s.add_mesh(*q([(-0.5, 1.5, -0.5), (-0.5, 1.5, 0.5), (0.5, 1.5, 0.5), (0.5, 1.5, -0.5)], (0, -1, 0)), light=S.area((1.0, 0.9, 0.8), 12.0, False))
+    s.background = {"color": (0.5, 0.6, 1.0), "intensity": 0.25}
+    s.camera.update(width=64, height=48, fov=40.0, nearClip=0.1, farClip=100.0, toWorld=S.look_at((0, 0.5, 3.0), (0, 0, 0), (0, 1, 0)))
+    s.sampler = {"type": "independent", "sampleCount": 8, "seed": 0}
+    s.integrator["maxDepth"] = 4
+    return s
+
+
+def test_flattened_description_and_errors(exe, kz):
+    d = json.loads(subprocess.check_output([exe]).decode())
+    assert (d["nMeshes"], d["nBsdfs"], d["nLights"], d["bvhTris"]) == (4, 2, 1, 8)
+    assert d["meshBsdf"] == [-1, 0, 1, -1] and d["meshLight"] == [-1, -1, -1, 0]          # no bsdf child -> default diffuse
+    assert np.allclose(d["kiss"], [1, 0.8, 0.6, 0.2, 0.4, 0, 0, 0.5, 0.5, 1, 0.5, 0.5, 0.5])     # reference defaults (bsdf.cpp:1160-1167)
+    assert np.allclose(d["light"], [1, 0.9, 0.8, 12, 0])                                      # lightPrimaryVisibility defaults to false
+    assert np.allclose(d["camera"], [64, 48, 40, 0.1, 100, 0, 2, 0.5]) and d["sampler"] == [0, 8, 0]
+    assert np.allclose(d["integrator"], [0, 4, 0.001, 0, 0.5]) and np.allclose(d["background"], [1, 0.5, 0.6, 1.0, 0.25])
+    assert np.allclose(d["toWorld"], kz.scenes.look_at((0, 0.5, 3.0), (0, 0, 0), (0, 1, 0)).reshape(-1), atol=1e-6)
+    e = d["errors"]
+    assert "not on the MI355X hot path" in e[0] and "could not be found" in e[1]
+    assert e[2] == "No camera was specified!" and e[3] == "There can only be one sampler per scene!" and "is not supported" in e[4]
+
+
+@pytest.mark.gpu
+def test_cpp_render_equals_python_render(exe, kz, O, gpu_lib, tmp_path):
+    out = str(tmp_path / "rgb.bin")
+    info = json.loads(subprocess.check_output([exe, "--render", out]).decode())
+    rgb = np.fromfile(out, np.float32).reshape(48, 64, 3)
+    assert info["pixels"] == 64 * 48 and rgb.mean() > 0.01
+    twin = python_twin(kz)
+    sc = kz.Scene(twin, device=0)
+    sc.render()
+    assert np.array_equal(sc.rgb(), rgb)                       # same description -> same film, bit for bit
+    ora = O.OracleScene(twin)
+    cpu = ora.rgb(ora.render(threads=0))
+    assert float(np.sqrt(np.mean((rgb - cpu) ** 2))) < 1e-3
