@@ -60,9 +60,13 @@ def main():
         log("warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # rehearsal on a 1-GPU box: KZ_BENCH_BACKEND=gloo KZ_BENCH_DEVICE=0 runs every rank on GPU 0 with CPU collectives
+    backend = os.environ.get("KZ_BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("KZ_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device_index)
+    cdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     kz = importlib.import_module("nano-kazen_amd")
     t0 = time.time()
@@ -70,7 +74,7 @@ def main():
     t1 = time.time()
     scene = kz.Scene(desc)
     bvh = scene.bvh_info()
-    scene.upload(local_rank)
+    scene.upload(device_index)
     t2 = time.time()
     if rank == 0:
         log("scene: %d tris, synth %.1fs, BVH %d nodes depth %d SAH %.1f built in %.2fs, upload+build %.1fs"
@@ -104,14 +108,14 @@ def main():
     kernel_ms_last = scene.last_kernel_ms()      # HIP events on the launch stream, around the path kernel (last step)
     # film merge: once per render, outside the per-step loop but reported (not a data-path collective)
     t_m = time.perf_counter()
-    film = torch.from_numpy(scene.film()).cuda()
+    film = torch.from_numpy(scene.film()).to(cdev)
     if world > 1:
         dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
     merge_s = time.perf_counter() - t_m
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    px = torch.tensor([my_pixels], dtype=torch.float64, device="cuda")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    px = torch.tensor([my_pixels], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(px, op=dist.ReduceOp.SUM)
