@@ -45,8 +45,11 @@ enum {
 enum { KZ_BSDF_DIFFUSE = 0        /* "diffuse"       src/kazen/bsdf.cpp:20-92     */,
        KZ_BSDF_KAZENSTANDARD = 1  /* "kazenstandard" src/kazen/bsdf.cpp:1157-1418 */ };
 enum { KZ_SAMPLER_INDEPENDENT = 0 /* "independent"   src/kazen/sampler.cpp:18-71   */,
-       KZ_SAMPLER_PMJ02BN = 1     /* "pmj02bn"       src/kazen/sampler.cpp:273-390 */ };
-enum { KZ_CAMERA_PERSPECTIVE = 0  /* "perspective"   src/kazen/camera.cpp:14-131   */ };
+       KZ_SAMPLER_PMJ02BN = 1     /* "pmj02bn"       src/kazen/sampler.cpp:273-390 */,
+       KZ_SAMPLER_STRATIFIED = 2  /* "stratified"    src/kazen/sampler.cpp:81-156  */,
+       KZ_SAMPLER_CORRELATED = 3  /* "correlated"    src/kazen/sampler.cpp:176-269 */ };
+enum { KZ_CAMERA_PERSPECTIVE = 0  /* "perspective"   src/kazen/camera.cpp:14-131   */,
+       KZ_CAMERA_THINLENS = 1     /* "thinlens"      src/kazen/camera.cpp:133-270  */ };
 enum { KZ_INTEGRATOR_PATH_MIS = 0 /* "path_mis"      src/kazen/integrator.cpp:185-355 */ };
 enum { KZ_FILTER_GAUSSIAN = 0     /* "gaussian"      src/kazen/rfilter.cpp:10-31   */,
        KZ_FILTER_MITCHELL = 1     /* "mitchell"      src/kazen/rfilter.cpp:39-70   */,
@@ -115,6 +118,8 @@ typedef struct KzCamera {
     float toWorld[16];          /* row-major 4x4 camera-to-world ("toWorld")           */
     float fov;                  /* horizontal, degrees, default 30                     */
     float nearClip, farClip;    /* defaults 1e-4, 1e4                                  */
+    float apertureRadius;       /* thinlens: "apertureRadius", default 1                */
+    float focusDistance;        /* thinlens: "focusDistance", default 0                 */
     const float *sampleToCamera;/* optional row-major 4x4 override (an adapter inside a kazen tree may hand over
                                    Eigen's own inverse, camera.cpp:60-62); NULL = computed by the library */
     KzFilter rfilter;
@@ -125,7 +130,9 @@ typedef struct KzCamera {
  * kazen::pmj02bnSamples and kazen::BlueNoiseTextures verbatim. */
 typedef struct KzSampler {
     int32_t type;               /* KZ_SAMPLER_*                                        */
-    uint32_t sampleCount;       /* "sampleCount"                                       */
+    uint32_t sampleCount;       /* "sampleCount" (stratified/correlated round it up: kz_scene_sample_count tells) */
+    int32_t resolution;         /* stratified: "resolution", default 4 (sampler.cpp:86) */
+    int32_t pad_;
     uint64_t seed;              /* "seed" (independent: the reference never initialises it; we define 0) */
     const uint32_t *pmj02bnSamples; /* [5][65536][2] fixed-point 2^-32, pmj02bn only   */
     const uint16_t *blueNoise;      /* [48][128][128], indexed [tex][x][y], pmj02bn only */
@@ -208,6 +215,8 @@ void kz_scene_destroy(KzScene *scene);
 /* Host BVH statistics (node count, leaf count, max depth, SAH cost) for reports. */
 typedef struct KzBvhInfo { uint32_t nNodes, nLeaves, nTris, maxDepth, maxLeafSize; float sahCost; double buildSeconds; } KzBvhInfo;
 int kz_scene_bvh_info(const KzScene *scene, KzBvhInfo *out);
+/* Sampler::getSampleCount() after the constructor's rounding (sampler.cpp:87-92, :181-187, :284-287). */
+int kz_scene_sample_count(const KzScene *scene, uint32_t *out);
 
 /* Upload node/triangle/attribute/material/light/sampler tables to the HBM of `device`
  * and allocate the device film. Fails with KZ_ERR_NO_DEVICE when no GPU is usable. */

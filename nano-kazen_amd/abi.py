@@ -11,8 +11,8 @@ KZ_ABI_VERSION = 1
 
 KZ_OK, KZ_ERR_INVALID_ARG, KZ_ERR_UNSUPPORTED, KZ_ERR_NO_DEVICE, KZ_ERR_HIP, KZ_ERR_STATE, KZ_ERR_OOM = range(7)
 KZ_BSDF_DIFFUSE, KZ_BSDF_KAZENSTANDARD = 0, 1
-KZ_SAMPLER_INDEPENDENT, KZ_SAMPLER_PMJ02BN = 0, 1
-KZ_CAMERA_PERSPECTIVE = 0
+KZ_SAMPLER_INDEPENDENT, KZ_SAMPLER_PMJ02BN, KZ_SAMPLER_STRATIFIED, KZ_SAMPLER_CORRELATED = 0, 1, 2, 3
+KZ_CAMERA_PERSPECTIVE, KZ_CAMERA_THINLENS = 0, 1
 KZ_INTEGRATOR_PATH_MIS = 0
 KZ_FILTER_GAUSSIAN, KZ_FILTER_MITCHELL, KZ_FILTER_TENT, KZ_FILTER_BOX = 0, 1, 2, 3
 KZ_FILTER_RESOLUTION = 32
@@ -47,11 +47,12 @@ class KzFilter(C.Structure):
 class KzCamera(C.Structure):
     _fields_ = [("type", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("toWorld", C.c_float * 16),
                 ("fov", C.c_float), ("nearClip", C.c_float), ("farClip", C.c_float),
+                ("apertureRadius", C.c_float), ("focusDistance", C.c_float),
                 ("sampleToCamera", f32p), ("rfilter", KzFilter)]
 
 
 class KzSampler(C.Structure):
-    _fields_ = [("type", C.c_int32), ("sampleCount", C.c_uint32), ("seed", C.c_uint64),
+    _fields_ = [("type", C.c_int32), ("sampleCount", C.c_uint32), ("resolution", C.c_int32), ("pad_", C.c_int32), ("seed", C.c_uint64),
                 ("pmj02bnSamples", u32p), ("blueNoise", u16p)]
 
 
@@ -105,7 +106,7 @@ class KzBvhInfo(C.Structure):
 EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
            "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
-           "kz_device_count", "kz_render_samples", "kz_bsdf_query"]
+           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
@@ -132,6 +133,7 @@ def load_library():
     lib.kz_scene_destroy.argtypes = [C.c_void_p]
     lib.kz_scene_destroy.restype = None
     lib.kz_scene_bvh_info.argtypes = [C.c_void_p, C.POINTER(KzBvhInfo)]
+    lib.kz_scene_sample_count.argtypes = [C.c_void_p, u32p]
     lib.kz_scene_upload.argtypes = [C.c_void_p, C.c_int]
     lib.kz_render.argtypes = [C.c_void_p, C.POINTER(KzRenderOpts)]
     lib.kz_film_download.argtypes = [C.c_void_p, f32p, C.c_size_t]

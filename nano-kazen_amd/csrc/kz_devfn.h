@@ -95,7 +95,8 @@ struct Sampler {
     __device__ __forceinline__ float nextFloat() { return __uint_as_float((nextUInt() >> 9) | 0x3f800000u) - 1.0f; }
     __device__ void generateSample(const KzParams &P, const KzDevTables &T, int x, int y, uint32_t sampleIndex) {
         px = x; py = y; idx = sampleIndex;
-        if (type == KZ_SAMPLER_INDEPENDENT) {
+        if (type != KZ_SAMPLER_PMJ02BN) {                 // independent, stratified, correlated: same pcg32 seeding
+            dim = 0;
             uint64_t h = hashPixelSeed(x, y, P.seed);
             // pcg32::seed(initseq) = seed(MixBits(initseq), initseq)
             inc = (h << 1u) | 1u;
@@ -116,6 +117,20 @@ struct Sampler {
     }
     __device__ float next1D(const KzParams &P, const KzDevTables &T) {
         if (type == KZ_SAMPLER_INDEPENDENT) return nextFloat();
+        if (type == KZ_SAMPLER_STRATIFIED) {                                       // sampler.cpp:119-127
+            const uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
+            const int stratum = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h);
+            ++dim;
+            const float delta = nextFloat();
+            return ((float)stratum + delta) / (float)P.sampleCount;
+        }
+        if (type == KZ_SAMPLER_CORRELATED) {                                       // sampler.cpp:215-227
+            const uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
+            const int p = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h * 0x45fbe943u);
+            const float j = nextFloat();
+            ++dim;
+            return ((float)p + j) / (float)P.sampleCount;
+        }
         uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
         int index = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h);
         float delta = blueNoise(T, dim);
@@ -124,6 +139,29 @@ struct Sampler {
     }
     __device__ void next2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
         if (type == KZ_SAMPLER_INDEPENDENT) { y = nextFloat(); x = nextFloat(); return; }
+        if (type == KZ_SAMPLER_STRATIFIED) {                                       // sampler.cpp:129-139
+            const uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
+            const int stratum = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h);
+            dim += 2;
+            const int sx = stratum % P.resX, sy = stratum / P.resX;
+            const float dx = nextFloat();
+            const float dy = nextFloat();
+            x = ((float)sx + dx) / (float)P.resX; y = ((float)sy + dy) / (float)P.resX;
+            return;
+        }
+        if (type == KZ_SAMPLER_CORRELATED) {                                       // sampler.cpp:229-251
+            const uint32_t h = (uint32_t)hashPixelDimSeed(px, py, dim, P.seed);    // permute() takes the low 32 bits of hash * const
+            const uint32_t s = permuteIdx(idx, P.sampleCount, h * 0x51633e2du);
+            const uint32_t cy = s / (uint32_t)P.resX, cx = s % (uint32_t)P.resX;
+            const uint32_t sx = permuteIdx(cx, (uint32_t)P.resX, h * 0x68bc21ebu);
+            const uint32_t sy = permuteIdx(cy, (uint32_t)P.resY, h * 0x02e5be93u);
+            const float jx = nextFloat();
+            const float jy = nextFloat();
+            dim += 2;
+            x = ((float)cx + ((float)sy + jx) / (float)P.resY) / (float)P.resX;
+            y = ((float)cy + ((float)sx + jy) / (float)P.resX) / (float)P.resY;
+            return;
+        }
         uint32_t index = idx;
         uint32_t inst = dim / 2;
         if (inst >= KZ_PMJ02BN_SETS) {
@@ -140,7 +178,7 @@ struct Sampler {
         x = fminf(ux, KZ_ONE_MINUS_EPS); y = fminf(uy, KZ_ONE_MINUS_EPS);
     }
     __device__ void nextPixel2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
-        if (type == KZ_SAMPLER_INDEPENDENT) { next2D(P, T, x, y); return; }
+        if (type != KZ_SAMPLER_PMJ02BN) { next2D(P, T, x, y); return; }
         int tile = P.pixelTileSize;
         int tx = px % tile, ty = py % tile;
         size_t off = (size_t)(tx + ty * tile) * P.sampleCount + idx;
@@ -654,18 +692,31 @@ __device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, floa
 __device__ __forceinline__ float powerHeuristic(float a, float b) { a *= a; b *= b; return a > 0.f ? a / (a + b) : 0.f; }   // integrator.cpp:340-344
 
 // a3 PerspectiveCamera::sampleRay (camera.cpp:70-91, transform.h:49-62)
-__device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy, V3 &o, V3 &d, float &mint, float &maxt) {
+__device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy, float ax, float ay, V3 &o, V3 &d, float &mint, float &maxt) {
     const float *m = P.s2c;
     float x = sx * P.invW, y = sy * P.invH;
     float rx = m[0] * x + m[1] * y + m[2] * 0.0f + m[3];
     float ry = m[4] * x + m[5] * y + m[6] * 0.0f + m[7];
     float rz = m[8] * x + m[9] * y + m[10] * 0.0f + m[11];
     float rw = m[12] * x + m[13] * y + m[14] * 0.0f + m[15];
-    V3 dl = normalized(mk(rx / rw, ry / rw, rz / rw));
-    float invZ = 1.0f / dl.z;
+    const V3 nearP = mk(rx / rw, ry / rw, rz / rw);
     const float *w = P.c2w;
-    float ow = w[15];
-    o = mk(w[3] / ow, w[7] / ow, w[11] / ow);
+    V3 dl;
+    if (P.cameraType == KZ_CAMERA_THINLENS) {                                      // camera.cpp:191-223, warp.cpp:41-50
+        const float r = sqrtf(ax);
+        const float ang = 2.0f * KZ_PI_F * ay;
+        const float tx = cosf(ang) * r * P.apertureRadius, ty = sinf(ang) * r * P.apertureRadius;
+        const V3 focusP = nearP * (P.focusDistance / nearP.z);
+        dl = normalized(focusP - mk(tx, ty, 0.0f));
+        const float pw = w[12] * tx + w[13] * ty + w[14] * 0.0f + w[15];
+        o = mk((w[0] * tx + w[1] * ty + w[2] * 0.0f + w[3]) / pw, (w[4] * tx + w[5] * ty + w[6] * 0.0f + w[7]) / pw,
+               (w[8] * tx + w[9] * ty + w[10] * 0.0f + w[11]) / pw);
+    } else {
+        dl = normalized(nearP);
+        const float ow = w[15];
+        o = mk(w[3] / ow, w[7] / ow, w[11] / ow);
+    }
+    float invZ = 1.0f / dl.z;
     d = mk(w[0] * dl.x + w[1] * dl.y + w[2] * dl.z, w[4] * dl.x + w[5] * dl.y + w[6] * dl.z, w[8] * dl.x + w[9] * dl.y + w[10] * dl.z);
     mint = P.nearClip * invZ; maxt = P.farClip * invZ;
 }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDev
         const float sx = (float)px + jx, sy = (float)py + jy;
         float ax, ay; smp.next2D(P, T, ax, ay);                  // aperture sample, always consumed (renderer.cpp:28)
         V3 ro, rd; float mint, maxt;
-        cameraRay(P, sx, sy, ro, rd, mint, maxt);
+        cameraRay(P, sx, sy, ax, ay, ro, rd, mint, maxt);
         V3 L = pathLi<STATS>(P, T, smp, ro, rd, mint, maxt, s_stack + threadIdx.x, cn);
         outJx[item] = jx; outJy[item] = jy; outR[item] = L.x; outG[item] = L.y; outB[item] = L.z;
         if (STATS) {

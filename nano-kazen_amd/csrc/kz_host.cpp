@@ -90,10 +90,12 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     *out = nullptr;
     if (d->abiVersion != KZ_ABI_VERSION) return kz_fail(KZ_ERR_INVALID_ARG, "ABI version %u, library is %u", d->abiVersion, KZ_ABI_VERSION);
     // plugin types outside the hot path are an error, never a silent fallback
-    if (d->camera.type != KZ_CAMERA_PERSPECTIVE) return kz_fail(KZ_ERR_UNSUPPORTED, "camera type %d is not on the hot path (only \"perspective\")", d->camera.type);
+    if (d->camera.type != KZ_CAMERA_PERSPECTIVE && d->camera.type != KZ_CAMERA_THINLENS) return kz_fail(KZ_ERR_UNSUPPORTED, "camera type %d is not supported (\"perspective\", \"thinlens\")", d->camera.type);
     if (d->integrator.type != KZ_INTEGRATOR_PATH_MIS) return kz_fail(KZ_ERR_UNSUPPORTED, "integrator type %d is not on the hot path (only \"path_mis\")", d->integrator.type);
-    if (d->sampler.type != KZ_SAMPLER_INDEPENDENT && d->sampler.type != KZ_SAMPLER_PMJ02BN)
-        return kz_fail(KZ_ERR_UNSUPPORTED, "sampler type %d is not on the hot path (\"independent\", \"pmj02bn\")", d->sampler.type);
+    if (d->sampler.type < KZ_SAMPLER_INDEPENDENT || d->sampler.type > KZ_SAMPLER_CORRELATED)
+        return kz_fail(KZ_ERR_UNSUPPORTED, "sampler type %d is not supported (\"independent\", \"pmj02bn\", \"stratified\", \"correlated\")", d->sampler.type);
+    if (d->sampler.type == KZ_SAMPLER_STRATIFIED && (d->sampler.resolution < 1 || d->sampler.resolution > 256)) return kz_fail(KZ_ERR_INVALID_ARG, "stratified resolution %d", d->sampler.resolution);
+    if (d->sampler.sampleCount > 65536) return kz_fail(KZ_ERR_UNSUPPORTED, "sampleCount %u (limit 65536)", d->sampler.sampleCount);
     if (d->camera.rfilter.type < KZ_FILTER_GAUSSIAN || d->camera.rfilter.type > KZ_FILTER_BOX) return kz_fail(KZ_ERR_UNSUPPORTED, "rfilter type %d", d->camera.rfilter.type);
     if (d->camera.width <= 0 || d->camera.height <= 0 || d->camera.width > 65535 || d->camera.height > 65535) return kz_fail(KZ_ERR_INVALID_ARG, "image size %dx%d", d->camera.width, d->camera.height);
     if (d->sampler.sampleCount == 0) return kz_fail(KZ_ERR_INVALID_ARG, "sampleCount is 0");
@@ -254,6 +256,18 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     p.samplerType = d->sampler.type;
     p.seed = d->sampler.seed;
     p.sampleCount = d->sampler.sampleCount;
+    p.resX = p.resY = 1;
+    p.cameraType = d->camera.type; p.apertureRadius = d->camera.apertureRadius; p.focusDistance = d->camera.focusDistance;
+    if (d->sampler.type == KZ_SAMPLER_STRATIFIED) {                       // Stratified ctor, sampler.cpp:84-92
+        int res = d->sampler.resolution;
+        while ((uint32_t)(res * res) < p.sampleCount) res++;
+        p.resX = p.resY = res; p.sampleCount = (uint32_t)(res * res);
+    }
+    if (d->sampler.type == KZ_SAMPLER_CORRELATED) {                       // Correlated ctor, sampler.cpp:179-187
+        int r1 = (int)std::sqrt((double)p.sampleCount);
+        int r0 = (int)((p.sampleCount + r1 - 1) / r1);
+        p.resX = r0; p.resY = r1; p.sampleCount = (uint32_t)(r0 * r1);
+    }
     if (d->sampler.type == KZ_SAMPLER_PMJ02BN) {
         if (!d->sampler.pmj02bnSamples || !d->sampler.blueNoise) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "pmj02bn sampler without its tables"); }
         if (p.sampleCount > KZ_PMJ02BN_SAMPLES) p.sampleCount = KZ_PMJ02BN_SAMPLES;               // sampler.cpp:284-287
@@ -305,6 +319,12 @@ void kz_scene_destroy(KzScene *scene) {
 int kz_scene_bvh_info(const KzScene *scene, KzBvhInfo *out) {
     if (!scene || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
     *out = scene->bvh;
+    return KZ_OK;
+}
+
+int kz_scene_sample_count(const KzScene *scene, uint32_t *out) {
+    if (!scene || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
+    *out = scene->prm.sampleCount;
     return KZ_OK;
 }
 

@@ -73,6 +73,8 @@ struct KzParams {
     int32_t maxDepth; float traceBias; int32_t regularization; float accumulatedRoughness;
     // sampler
     int32_t samplerType; uint32_t sampleCount; uint64_t seed; int32_t pixelTileSize;
+    int32_t resX, resY;                  // stratified resolution / correlated m_resolution
+    int32_t cameraType; float apertureRadius, focusDistance;
     // lights / background
     uint32_t nLights; float lightPickPdf;
     int32_t bgPresent; float bgRadiance[3];

@@ -29,7 +29,7 @@ struct KzWf {
     float4 *hit;                   // t u v tri(bits); t = +inf: miss
     float4 *thr;                   // throughput.xyz eta
     float4 *misc;                  // bsdfPdf accumulatedRoughness - -
-    uint4 *smp;                    // independent: pcg32 state/inc; pmj02bn: dimension in .x
+    uint4 *smp;                    // pcg32 state (.x,.y) + dimension index (.z); the pcg32 stream id is recomputed from the pixel
     float4 *shA, *shB, *shL;       // shadow (or walk-through) ray o.xyz tmax | d.xyz tmin | pending radiance
     uint32_t *queue[3];            // two ping-pong path queues + the shadow queue
     uint32_t *counts;              // [stage][4] zeroed per pass
@@ -76,12 +76,13 @@ __device__ __forceinline__ void wfStatsFlush(unsigned long long *stats, const Co
 __device__ __forceinline__ void wfLoadSampler(const KzParams &P, const KzWf &W, uint32_t slot, int px, int py, uint32_t sampleIndex, Sampler &s) {
     const uint4 v = W.smp[slot];
     s.type = P.samplerType; s.px = px; s.py = py; s.idx = sampleIndex;
-    s.state = (uint64_t)v.x | ((uint64_t)v.y << 32); s.inc = (uint64_t)v.z | ((uint64_t)v.w << 32); s.dim = v.x;
+    s.state = (uint64_t)v.x | ((uint64_t)v.y << 32); s.dim = v.z;
+    s.inc = (P.samplerType == KZ_SAMPLER_PMJ02BN) ? 0ull : ((hashPixelSeed(px, py, P.seed) << 1u) | 1u);      // pcg32 stream id: a function of the pixel
 }
 __device__ __forceinline__ void wfStoreSampler(const KzParams &P, const KzWf &W, uint32_t slot, const Sampler &s) {
     uint4 v;
-    if (P.samplerType == KZ_SAMPLER_INDEPENDENT) { v.x = (uint32_t)s.state; v.y = (uint32_t)(s.state >> 32); v.z = (uint32_t)s.inc; v.w = (uint32_t)(s.inc >> 32); }
-    else { v.x = s.dim; v.y = v.z = v.w = 0; }
+    v.x = (uint32_t)s.state; v.y = (uint32_t)(s.state >> 32); v.z = s.dim; v.w = 0;
+    (void)P;
     W.smp[slot] = v;
 }
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_generate(KzParams P, KzDevTabl
     const float sx = (float)px + jx, sy = (float)py + jy;
     float ax, ay; smp.next2D(P, T, ax, ay);
     V3 ro, rd; float mint, maxt;
-    cameraRay(P, sx, sy, ro, rd, mint, maxt);
+    cameraRay(P, sx, sy, ax, ay, ro, rd, mint, maxt);
     W.rayA[item] = make_float4(ro.x, ro.y, ro.z, mint);
     W.rayB[item] = make_float4(rd.x, rd.y, rd.z, maxt);
     W.thr[item] = make_float4(1.f, 1.f, 1.f, 1.f);

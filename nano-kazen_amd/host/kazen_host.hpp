@@ -102,11 +102,11 @@ public:
         auto &t = table();
         auto it = t.find(name);
         if (it != t.end()) return it->second(props);
-        static const char *offPath[] = {"normals", "ao", "whitted", "path_mats", "stratified", "correlated", "thinlens", "dielectric", "mirror",
+        static const char *offPath[] = {"normals", "ao", "whitted", "path_mats", "dielectric", "mirror",
                                         "lambertian", "normalmap", "ggx", "roughconductor", "roughplastic", "roughdielectric", "imagetexture",
                                         "colorramp", "blend", "nonscatter"};
         for (const char *o : offPath)
-            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis + diffuse/kazenstandard + independent/pmj02bn + perspective)");
+            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis; diffuse/kazenstandard; independent/pmj02bn/stratified/correlated; perspective/thinlens)");
         throw Exception("A constructor for class \"" + name + "\" could not be found!");
     }
 private:
@@ -221,6 +221,16 @@ public:
     void setTables(const uint32_t *pmj02bnSamples, const uint16_t *blueNoiseTextures) { m_s.pmj02bnSamples = pmj02bnSamples; m_s.blueNoise = blueNoiseTextures; }
     std::string toString() const override { return "PMJ02BN"; }
 };
+class Stratified : public Sampler {                  // src/kazen/sampler.cpp:81-156 (the library applies the constructor's rounding)
+public:
+    explicit Stratified(const PropertyList &p) { m_s.type = KZ_SAMPLER_STRATIFIED; m_s.seed = (uint64_t)p.getInteger("seed", 1); m_s.sampleCount = (uint32_t)p.getInteger("sampleCount", 16); m_s.resolution = p.getInteger("resolution", 4); }
+    std::string toString() const override { return "Stratified"; }
+};
+class Correlated : public Sampler {                  // src/kazen/sampler.cpp:176-269
+public:
+    explicit Correlated(const PropertyList &p) { m_s.type = KZ_SAMPLER_CORRELATED; m_s.seed = (uint64_t)p.getInteger("seed", 1); m_s.sampleCount = (uint32_t)p.getInteger("sampleCount", 16); m_s.resolution = 4; }
+    std::string toString() const override { return "Correlated"; }
+};
 class Integrator : public Object { public: EClassType getClassType() const override { return EIntegrator; } virtual void preprocess(const class Scene *) {} KzIntegrator m_i{}; };
 class PathMisIntegrator : public Integrator {        // src/kazen/integrator.cpp:185-355
 public:
@@ -246,6 +256,12 @@ public:
     }
     void activate() override { if (!m_rfilter) m_rfilter = static_cast<ReconstructionFilter *>(ObjectFactory::createInstance("gaussian", PropertyList())); m_c.rfilter = m_rfilter->m_f; }
     std::string toString() const override { return "PerspectiveCamera[]"; }
+};
+
+class ThinlensCamera : public PerspectiveCamera {    // src/kazen/camera.cpp:133-270
+public:
+    explicit ThinlensCamera(const PropertyList &p) : PerspectiveCamera(p) { m_c.type = KZ_CAMERA_THINLENS; m_c.apertureRadius = p.getFloat("apertureRadius", 1.0f); m_c.focusDistance = p.getFloat("focusDistance", 0.0f); }
+    std::string toString() const override { return "ThinlensCamera[]"; }
 };
 
 // ---- mesh: buffers in the layout of kazen::Mesh (mesh.h:176-179); the OBJ loader itself is host scene I/O, out of scope ----
@@ -345,6 +361,9 @@ KAZEN_MI355X_REGISTER(MitchellNetravaliFilter, "mitchell");
 KAZEN_MI355X_REGISTER(TentFilter, "tent");
 KAZEN_MI355X_REGISTER(BoxFilter, "box");
 KAZEN_MI355X_REGISTER(Independent, "independent");
+KAZEN_MI355X_REGISTER(Stratified, "stratified");
+KAZEN_MI355X_REGISTER(Correlated, "correlated");
+KAZEN_MI355X_REGISTER(ThinlensCamera, "thinlens");
 KAZEN_MI355X_REGISTER(PMJ02BN, "pmj02bn");
 KAZEN_MI355X_REGISTER(PathMisIntegrator, "path_mis");
 

@@ -20,6 +20,9 @@ class Scene:
         w, hh, b = C.c_int32(), C.c_int32(), C.c_int32()
         abi.check(self.lib, self.lib.kz_film_dims(self.h, C.byref(w), C.byref(hh), C.byref(b)))
         self.width, self.height, self.border = w.value, hh.value, b.value
+        n = C.c_uint32()
+        abi.check(self.lib, self.lib.kz_scene_sample_count(self.h, C.byref(n)))
+        self.sample_count = n.value
         if device is not None:
             self.upload(device)
 

@@ -156,7 +156,9 @@ class SceneDescription:
         d.bsdfs, d.nBsdfs = cb, len(bsdfs)
         d.lights, d.nLights = cl, len(lights)
         cam = self.camera
-        d.camera.type = abi.KZ_CAMERA_PERSPECTIVE if cam["type"] == "perspective" else 99
+        d.camera.type = {"perspective": abi.KZ_CAMERA_PERSPECTIVE, "thinlens": abi.KZ_CAMERA_THINLENS}.get(cam["type"], 99)
+        d.camera.apertureRadius = cam.get("apertureRadius", 1.0)
+        d.camera.focusDistance = cam.get("focusDistance", 0.0)
         d.camera.width, d.camera.height = cam["width"], cam["height"]
         tw = np.ascontiguousarray(cam["toWorld"], np.float32).reshape(16)
         d.camera.toWorld[:] = tw.tolist()
@@ -169,7 +171,8 @@ class SceneDescription:
         d.camera.rfilter.stddev = rf.get("stddev", 0.5)
         d.camera.rfilter.B, d.camera.rfilter.C = rf.get("B", 1 / 3.0), rf.get("C", 1 / 3.0)
         s = self.sampler
-        d.sampler.type = {"independent": 0, "pmj02bn": 1}.get(s["type"], 99)
+        d.sampler.type = {"independent": 0, "pmj02bn": 1, "stratified": 2, "correlated": 3}.get(s["type"], 99)
+        d.sampler.resolution = s.get("resolution", 4)
         d.sampler.sampleCount = s["sampleCount"]
         d.sampler.seed = s.get("seed", 0 if s["type"] == "independent" else 1)
         if s["type"] == "pmj02bn":

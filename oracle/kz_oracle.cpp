@@ -281,6 +281,7 @@ struct Scene {
     // pmj02bn pixel samples (sampler.cpp:291-309)
     int pixelTileSize = 0; std::vector<float> pixelSamples;
     uint32_t sampleCount = 1;
+    int resX = 1, resY = 1;       // stratified: resolution; correlated: m_resolution (sampler.cpp:181-187)
     // geometry
     std::vector<Tri> tris;        // leaf order
     std::vector<BNode> nodes;
@@ -778,12 +779,10 @@ struct Sampler {
     int32_t px = 0, py = 0; uint32_t sampleIndex = 0, dim = 0;
     void generateSample(int32_t x, int32_t y, uint32_t idx) {
         px = x; py = y; sampleIndex = idx;
-        if (type == KZ_SAMPLER_INDEPENDENT) {                            // sampler.cpp:43-46
-            rng.seed(HashPixelSeed(x, y, sc->smp.seed));
-            rng.advance((int64_t)(idx * 65536ull + 0));
-        } else {
-            dim = 2;                                                     // sampler.cpp:333-337 max(2, 0)
-        }
+        if (type == KZ_SAMPLER_PMJ02BN) { dim = 2; return; }             // sampler.cpp:333-337 max(2, 0)
+        rng.seed(HashPixelSeed(x, y, sc->smp.seed));                     // sampler.cpp:43-46, :111-117, :207-213
+        rng.advance((int64_t)(idx * 65536ull + 0));
+        dim = 0;
     }
     float bluenoise(uint32_t texIndex) const {                           // bluenoise.h:16-23
         int t = (int)texIndex % KZ_BLUENOISE_TEXTURES;
@@ -797,6 +796,20 @@ struct Sampler {
     }
     float next1D() {
         if (type == KZ_SAMPLER_INDEPENDENT) return rng.nextFloat();      // sampler.cpp:48-50
+        if (type == KZ_SAMPLER_STRATIFIED) {                             // sampler.cpp:119-127
+            uint64_t hash = HashPixelDimSeed(px, py, dim, sc->smp.seed);
+            int stratum = (int)permute(sampleIndex, sc->sampleCount, (uint32_t)hash);
+            ++dim;
+            float delta = rng.nextFloat();
+            return (stratum + delta) / sc->sampleCount;
+        }
+        if (type == KZ_SAMPLER_CORRELATED) {                             // sampler.cpp:215-227
+            uint64_t hash = HashPixelDimSeed(px, py, dim, sc->smp.seed);
+            int p = (int)permute(sampleIndex, sc->sampleCount, (uint32_t)(hash * 0x45fbe943));
+            float j = rng.nextFloat();
+            ++dim;
+            return (p + j) / sc->sampleCount;
+        }
         uint64_t hash = HashPixelDimSeed(px, py, dim, sc->smp.seed);     // sampler.cpp:339-347
         int index = (int)permute(sampleIndex, sc->sampleCount, (uint32_t)hash);
         float delta = bluenoise(dim);
@@ -807,6 +820,31 @@ struct Sampler {
         if (type == KZ_SAMPLER_INDEPENDENT) {                            // sampler.cpp:52-57, H1
             y = rng.nextFloat();
             x = rng.nextFloat();
+            return;
+        }
+        if (type == KZ_SAMPLER_STRATIFIED) {                             // sampler.cpp:129-139 (dx, dy are sequenced statements)
+            uint64_t hash = HashPixelDimSeed(px, py, dim, sc->smp.seed);
+            int stratum = (int)permute(sampleIndex, sc->sampleCount, (uint32_t)hash);
+            dim += 2;
+            int res = sc->resX;
+            int sx = stratum % res, sy = stratum / res;
+            float dx = rng.nextFloat();
+            float dy = rng.nextFloat();
+            x = (sx + dx) / res; y = (sy + dy) / res;
+            return;
+        }
+        if (type == KZ_SAMPLER_CORRELATED) {                             // sampler.cpp:229-251 (Kensler CMJ)
+            uint64_t hash = HashPixelDimSeed(px, py, dim, sc->smp.seed);
+            int s = (int)permute(sampleIndex, sc->sampleCount, (uint32_t)(hash * 0x51633e2d));
+            uint32_t cy = (uint32_t)s / (uint32_t)sc->resX;
+            uint32_t cx = (uint32_t)s % (uint32_t)sc->resX;
+            uint32_t sx = permute(cx, (uint32_t)sc->resX, (uint32_t)(hash * 0x68bc21eb));
+            uint32_t sy = permute(cy, (uint32_t)sc->resY, (uint32_t)(hash * 0x02e5be93));
+            float jx = rng.nextFloat();
+            float jy = rng.nextFloat();
+            dim += 2;
+            x = (cx + (sy + jx) / sc->resY) / sc->resX;
+            y = (cy + (sx + jy) / sc->resX) / sc->resY;
             return;
         }
         int index = (int)sampleIndex;                                    // sampler.cpp:349-371
@@ -823,7 +861,7 @@ struct Sampler {
         x = std::min(ux, OneMinusEpsilon); y = std::min(uy, OneMinusEpsilon);
     }
     void nextPixel2D(float &x, float &y) {
-        if (type == KZ_SAMPLER_INDEPENDENT) { next2D(x, y); return; }    // sampler.cpp:59-61
+        if (type != KZ_SAMPLER_PMJ02BN) { next2D(x, y); return; }        // sampler.cpp:59-61, :141-143, :253-255
         int tile = sc->pixelTileSize;                                    // sampler.cpp:373-377
         int tx = px % tile, ty = py % tile;
         size_t offset = (size_t)(tx + ty * tile) * sc->sampleCount + sampleIndex;
@@ -898,7 +936,7 @@ static int prepareCamera(Scene &sc) {
     for (int i = 0; i < 16; ++i) sc.s2c[i] = (float)Mi[i];
     return KZ_OK;
 }
-static void cameraSampleRay(const Scene &sc, float sx, float sy, Ray &ray) {
+static void cameraSampleRay(const Scene &sc, float sx, float sy, float ax, float ay, Ray &ray) {
     const float *m = sc.s2c;
     float x = sx * sc.invW, y = sy * sc.invH;
     float rx = m[0] * x + m[1] * y + m[2] * 0.0f + m[3];                         // transform.h:59-62
@@ -906,11 +944,23 @@ static void cameraSampleRay(const Scene &sc, float sx, float sy, Ray &ray) {
     float rz = m[8] * x + m[9] * y + m[10] * 0.0f + m[11];
     float rw = m[12] * x + m[13] * y + m[14] * 0.0f + m[15];
     V3 nearP(rx / rw, ry / rw, rz / rw);
-    V3 d = normalized(nearP);
-    float invZ = 1.0f / d.z;
     const float *w = sc.cam.toWorld;
-    float ow = w[15];
-    ray.o = V3(w[3] / ow, w[7] / ow, w[11] / ow);                                // toWorld * Point3f(0,0,0)
+    V3 d;
+    if (sc.cam.type == KZ_CAMERA_THINLENS) {                                     // camera.cpp:191-223
+        float tx, ty; squareToUniformDisk(ax, ay, tx, ty);
+        tx *= sc.cam.apertureRadius; ty *= sc.cam.apertureRadius;
+        V3 apertureP(tx, ty, 0.0f);
+        V3 focusP = nearP * (sc.cam.focusDistance / nearP.z);
+        d = normalized(focusP - apertureP);
+        float pw = w[12] * tx + w[13] * ty + w[14] * 0.0f + w[15];
+        ray.o = V3((w[0] * tx + w[1] * ty + w[2] * 0.0f + w[3]) / pw, (w[4] * tx + w[5] * ty + w[6] * 0.0f + w[7]) / pw,
+                   (w[8] * tx + w[9] * ty + w[10] * 0.0f + w[11]) / pw);
+    } else {
+        d = normalized(nearP);
+        float ow = w[15];
+        ray.o = V3(w[3] / ow, w[7] / ow, w[11] / ow);                            // toWorld * Point3f(0,0,0)
+    }
+    float invZ = 1.0f / d.z;
     ray.d = V3(w[0] * d.x + w[1] * d.y + w[2] * d.z, w[4] * d.x + w[5] * d.y + w[6] * d.z,
                w[8] * d.x + w[9] * d.y + w[10] * d.z);                           // transform.h:49-51
     ray.mint = sc.cam.nearClip * invZ; ray.maxt = sc.cam.farClip * invZ;
@@ -1149,7 +1199,7 @@ static V3 renderSample(const Scene &sc, Sampler &sampler, int px, int py, uint32
     float jx, jy; sampler.nextPixel2D(jx, jy);
     sx = (float)px + jx; sy = (float)py + jy;
     float ax, ay; sampler.next2D(ax, ay);      // aperture sample: always drawn (renderer.cpp:28)
-    Ray ray; cameraSampleRay(sc, sx, sy, ray);
+    Ray ray; cameraSampleRay(sc, sx, sy, ax, ay, ray);
     ls.samples++;
     return Li(sc, sampler, ray, ls);           // camera weight is Color3f(1) (camera.cpp:90)
 }
@@ -1177,9 +1227,9 @@ const char *kzo_last_error() { return g_err; }
 int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) {
     if (!d || !out) return fail(KZ_ERR_INVALID_ARG, "null argument");
     if (d->abiVersion != KZ_ABI_VERSION) return fail(KZ_ERR_INVALID_ARG, "abi version mismatch");
-    if (d->camera.type != KZ_CAMERA_PERSPECTIVE) return fail(KZ_ERR_UNSUPPORTED, "camera type");
+    if (d->camera.type != KZ_CAMERA_PERSPECTIVE && d->camera.type != KZ_CAMERA_THINLENS) return fail(KZ_ERR_UNSUPPORTED, "camera type");
     if (d->integrator.type != KZ_INTEGRATOR_PATH_MIS) return fail(KZ_ERR_UNSUPPORTED, "integrator type");
-    if (d->sampler.type != KZ_SAMPLER_INDEPENDENT && d->sampler.type != KZ_SAMPLER_PMJ02BN) return fail(KZ_ERR_UNSUPPORTED, "sampler type");
+    if (d->sampler.type < KZ_SAMPLER_INDEPENDENT || d->sampler.type > KZ_SAMPLER_CORRELATED) return fail(KZ_ERR_UNSUPPORTED, "sampler type");
     Scene *sc = new Scene();
     sc->cam = d->camera; sc->smp = d->sampler; sc->integ = d->integrator; sc->bg = d->background;
     sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->nBsdfs);
@@ -1199,6 +1249,16 @@ int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) {
         if (md.light >= 0) { prepareLightMesh(md); sc->lightMeshes.push_back((int)m); }
     }
     sc->sampleCount = d->sampler.sampleCount;
+    if (d->sampler.type == KZ_SAMPLER_STRATIFIED) {                                       // sampler.cpp:84-92
+        int res = d->sampler.resolution;
+        while ((uint32_t)(res * res) < sc->sampleCount) res++;
+        sc->resX = sc->resY = res; sc->sampleCount = (uint32_t)(res * res);
+    }
+    if (d->sampler.type == KZ_SAMPLER_CORRELATED) {                                       // sampler.cpp:179-187
+        int r1 = (int)std::sqrt((double)sc->sampleCount);
+        int r0 = (int)((sc->sampleCount + r1 - 1) / r1);
+        sc->resX = r0; sc->resY = r1; sc->sampleCount = (uint32_t)(r0 * r1);
+    }
     if (d->sampler.type == KZ_SAMPLER_PMJ02BN) {
         if (!d->sampler.pmj02bnSamples || !d->sampler.blueNoise) { delete sc; return fail(KZ_ERR_INVALID_ARG, "pmj02bn tables missing"); }
         sc->pmjTable.assign(d->sampler.pmj02bnSamples, d->sampler.pmj02bnSamples + (size_t)KZ_PMJ02BN_SETS * KZ_PMJ02BN_SAMPLES * 2);
@@ -1219,6 +1279,7 @@ int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) {
 void kzo_scene_destroy(void *s) { delete (Scene *)s; }
 void kzo_set_brute(void *s, int brute) { ((Scene *)s)->useBrute = brute != 0; }
 
+unsigned kzo_sample_count(void *s) { return ((Scene *)s)->sampleCount; }
 int kzo_film_dims(void *s, int *w, int *h, int *b) { Scene *sc = (Scene *)s; *w = sc->cam.width; *h = sc->cam.height; *b = sc->border; return 0; }
 
 int kzo_bvh_info(void *s, KzBvhInfo *o) {
@@ -1360,7 +1421,7 @@ void kzo_sampler_stream(void *s, int32_t px, int32_t py, uint32_t idx, int n1, f
     for (int i = 0; i < n1; ++i) out[4 + i] = sm.next1D();
 }
 void kzo_camera_ray(void *s, float sx, float sy, float *o6, float *mint, float *maxt) {
-    Scene &sc = *(Scene *)s; Ray r; cameraSampleRay(sc, sx, sy, r);
+    Scene &sc = *(Scene *)s; Ray r; cameraSampleRay(sc, sx, sy, 0.5f, 0.5f, r);
     o6[0] = r.o.x; o6[1] = r.o.y; o6[2] = r.o.z; o6[3] = r.d.x; o6[4] = r.d.y; o6[5] = r.d.z; *mint = r.mint; *maxt = r.maxt;
 }
 void kzo_filter_table(void *s, float *tab33, float *radius, int *border) {

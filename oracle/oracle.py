@@ -38,6 +38,8 @@ def lib():
         L.kzo_set_brute.argtypes = [C.c_void_p, C.c_int]
         L.kzo_set_brute.restype = None
         L.kzo_film_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        L.kzo_sample_count.argtypes = [C.c_void_p]
+        L.kzo_sample_count.restype = C.c_uint
         L.kzo_bvh_info.argtypes = [C.c_void_p, C.POINTER(abi.KzBvhInfo)]
         L.kzo_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.KzTile), C.c_uint32, C.c_int, abi.f32p]
         L.kzo_film_to_rgb.argtypes = [abi.f32p, C.c_int, C.c_int, C.c_int, abi.f32p]
@@ -100,6 +102,7 @@ class OracleScene:
         w, hh, b = C.c_int(), C.c_int(), C.c_int()
         self.L.kzo_film_dims(self.h, C.byref(w), C.byref(hh), C.byref(b))
         self.width, self.height, self.border = w.value, hh.value, b.value
+        self.sample_count = int(self.L.kzo_sample_count(self.h))
 
     def close(self):
         if getattr(self, "h", None):

@@ -63,9 +63,10 @@ def test_no_device_is_a_loud_error(kz):
 
 
 @pytest.mark.parametrize("mutate,code", [
-    (lambda s: s.sampler.update(type="stratified"), 2),
+    (lambda s: s.sampler.update(type="halton"), 2),
     (lambda s: s.integrator.update(type="whitted"), 2),
-    (lambda s: s.camera.update(type="thinlens"), 2),
+    (lambda s: s.camera.update(type="orthographic"), 2),
+    (lambda s: s.sampler.update(type="stratified", resolution=0), 1),
     (lambda s: s.meshes[0].update(bsdf={"type": "mirror"}), 2),
     (lambda s: s.sampler.update(sampleCount=0), 1),
     (lambda s: s.camera.update(width=0), 1),

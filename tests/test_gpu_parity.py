@@ -137,6 +137,20 @@ def test_per_sample_radiance_matches_goldens(gpu_lib, kz, gold, tag, sampler, se
     assert np.allclose(out[:, 2:], g[:, 2:], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("kind", ["stratified", "correlated", "independent", "pmj02bn"])
+def test_sampler_streams_are_bit_exact(gpu_lib, kz, O, kind):
+    """The pixel-sample positions are pure sampler output (hash, permute, pcg32, tables): identical bits on CPU and GPU."""
+    d = kz.scenes.cornell_box(40, 24, 9, sampler=kind, seed=2)
+    sc, ora = kz.Scene(d, device=0), O.OracleScene(d)
+    assert sc.sample_count == ora.sample_count
+    rng = np.random.default_rng(4)
+    pxy = np.stack([rng.integers(0, 40, 300), rng.integers(0, 24, 300)], 1).astype(np.int32)
+    idx = rng.integers(0, sc.sample_count, 300).astype(np.uint32)
+    g, c = sc.render_samples(pxy, idx), ora.render_samples(pxy, idx)
+    assert np.array_equal(g[:, :2], c[:, :2])
+    assert np.allclose(g[:, 2:], c[:, 2:], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("tag,sampler,seed", [("ind", "independent", 0), ("pmj", "pmj02bn", 1)])
 def test_golden_film(gpu_lib, kz, gold, tag, sampler, seed):
     sc = kz.Scene(kz.scenes.cornell_box(32, 32, 4, sampler=sampler, seed=seed), device=0)
@@ -156,7 +170,17 @@ CASES = {
     "c3_hero": lambda S: S.hero_scene(320, 180, 16, detail=0.5),                            # configs[2] geometry, reduced size
     "c4_soup_pmj": lambda S: S.random_triangles(200000, 240, 136, 16),                      # configs[3] at reduced size
     "ragged_size": lambda S: S.cornell_box(77, 45, 5),                                      # not a multiple of anything
+    "stratified": lambda S: S.cornell_box(96, 80, 10, sampler="stratified", seed=1),        # rounds to 16 spp
+    "correlated": lambda S: S.cornell_box(96, 80, 12, sampler="correlated", seed=3),
+    "thinlens": lambda S: _thinlens(S),
 }
+
+
+def _thinlens(S):
+    d = S.hero_scene(200, 112, 8, detail=0.3)
+    d.camera.update(type="thinlens", apertureRadius=0.15, focusDistance=8.0)
+    d.sampler = {"type": "correlated", "sampleCount": 9, "seed": 5}
+    return d
 
 
 @pytest.mark.parametrize("name", list(CASES))

@@ -248,7 +248,44 @@ def test_pmj02bn_pixel_samples_are_stratified(O, kz):
 
 def test_unsupported_plugins_are_errors(O, kz):
     s = kz.scenes.cornell_box(16, 16, 1)
-    s.sampler["type"] = "stratified"
+    s.sampler["type"] = "halton"
     with pytest.raises(kz.abi.KzError) as e:
         O.OracleScene(s)
     assert e.value.code == kz.abi.KZ_ERR_UNSUPPORTED
+
+
+# ---- "next" rows of SURVEY 8f: stratified / correlated samplers, thin-lens camera -------------------------------------
+@pytest.mark.parametrize("kind,spp,expect", [("stratified", 16, 16), ("stratified", 5, 16), ("stratified", 20, 25), ("correlated", 16, 16), ("correlated", 12, 12), ("correlated", 7, 8)])
+def test_sample_count_rounding_follows_the_constructors(O, kz, kind, spp, expect):
+    """Stratified: resolution starts at 4 and grows until res^2 >= sampleCount (sampler.cpp:86-92); Correlated: ry = floor(sqrt(n)),
+    rx = ceil(n / ry) (sampler.cpp:181-187). The library and the oracle report the same rounded count."""
+    d = kz.scenes.cornell_box(16, 16, spp, sampler=kind, seed=1)
+    assert O.OracleScene(d).sample_count == expect
+    assert kz.Scene(d).sample_count == expect
+
+
+@pytest.mark.parametrize("kind", ["stratified", "correlated"])
+def test_jittered_samplers_are_stratified(O, kz, kind):
+    """The 16 pixel samples of one pixel: one per cell of the 4x4 grid; correlated multi-jitter also has one per 1/16 column and row."""
+    o = O.OracleScene(kz.scenes.cornell_box(16, 16, 16, sampler=kind, seed=1))
+    for px, py in ((0, 0), (7, 3), (15, 15)):
+        j = np.array([o.sampler_stream(px, py, i, 2)[:2] for i in range(16)])
+        assert (j >= 0).all() and (j < 1).all()
+        assert len(set((int(x * 4), int(y * 4)) for x, y in j)) == 16
+        if kind == "correlated":
+            assert len(set(int(x * 16) for x, _ in j)) == 16 and len(set(int(y * 16) for _, y in j)) == 16
+        # 1-D draws of the same dimension over the 16 samples: one per 1/16 stratum
+        u = np.array([o.sampler_stream(px, py, i, 2)[4] for i in range(16)])
+        assert sorted((u * 16).astype(int).tolist()) == list(range(16))
+
+
+def test_thinlens_reduces_to_pinhole_at_zero_aperture(O, kz):
+    a = kz.scenes.cornell_box(24, 24, 2)
+    b = kz.scenes.cornell_box(24, 24, 2)
+    b.camera.update(type="thinlens", apertureRadius=0.0, focusDistance=3.0)
+    fa, fb = O.OracleScene(a).render(threads=1), O.OracleScene(b).render(threads=1)
+    assert np.allclose(fa, fb, rtol=1e-4, atol=1e-5)
+    c = kz.scenes.cornell_box(24, 24, 2)
+    c.camera.update(type="thinlens", apertureRadius=0.3, focusDistance=3.6)
+    fc = O.OracleScene(c).render(threads=1)
+    assert np.isfinite(fc).all() and not np.allclose(fa, fc, rtol=1e-2, atol=1e-3)
