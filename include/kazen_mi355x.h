@@ -43,7 +43,9 @@ enum {
 
 /* ---- plugin type tags (reference registry names in comments) ------------ */
 enum { KZ_BSDF_DIFFUSE = 0        /* "diffuse"       src/kazen/bsdf.cpp:20-92     */,
-       KZ_BSDF_KAZENSTANDARD = 1  /* "kazenstandard" src/kazen/bsdf.cpp:1157-1418 */ };
+       KZ_BSDF_KAZENSTANDARD = 1  /* "kazenstandard" src/kazen/bsdf.cpp:1157-1418 */,
+       KZ_BSDF_MIRROR = 2         /* "mirror"        src/kazen/bsdf.cpp:161-196   */,
+       KZ_BSDF_DIELECTRIC = 3     /* "dielectric"    src/kazen/bsdf.cpp:98-155    */ };
 enum { KZ_SAMPLER_INDEPENDENT = 0 /* "independent"   src/kazen/sampler.cpp:18-71   */,
        KZ_SAMPLER_PMJ02BN = 1     /* "pmj02bn"       src/kazen/sampler.cpp:273-390 */,
        KZ_SAMPLER_STRATIFIED = 2  /* "stratified"    src/kazen/sampler.cpp:81-156  */,
@@ -80,6 +82,9 @@ typedef struct KzBSDF {
     float clearcoatRoughness;   /* default 0.5                                        */
     float sheen;                /* default 0                                          */
     float sheenTint;            /* default 0.5                                        */
+    float intIOR;               /* dielectric: "intIOR", default 1.5046               */
+    float extIOR;               /* dielectric: "extIOR", default 1.000277             */
+    float pad_[2];
 } KzBSDF;
 
 /* "area" light (src/kazen/light.cpp:7-66). radiance = intensity * color. */

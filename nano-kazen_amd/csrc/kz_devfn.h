@@ -633,11 +633,43 @@ __device__ float kissPdf(const KzBSDF &m, V3 wi, V3 wo, float accRough) {       
     float coatPdf = ggxVNDF(wi, H, roughnessToAlpha(lerpf(m.clearcoatRoughness, .01f, .3f), 0.f)) / jacobian;
     return diffuse * KZ_INV_PI * wo.z + (1.f - diffuse) * (GTR2 * specPdf + (1.f - GTR2) * coatPdf);
 }
-// returns the sample weight; wo is the sampled direction; alive=false when the path contributes nothing further
-__device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive) {
-    wo = mk(0.f, 0.f, 1.f);
-    if (wi.z <= 0) { alive = false; return mk(0.f); }                              // bsdf.cpp:60-61, :1302-1303
+// fresnel (common.cpp:447-475) and refract (common.cpp:526-534)
+__device__ __forceinline__ float fresnelIOR(float cosThetaI, float extIOR, float intIOR) {
+    float etaI = extIOR, etaT = intIOR;
+    if (extIOR == intIOR) return 0.0f;
+    if (cosThetaI < 0.0f) { float t = etaI; etaI = etaT; etaT = t; cosThetaI = -cosThetaI; }
+    float eta = etaI / etaT, sinThetaTSqr = eta * eta * (1 - cosThetaI * cosThetaI);
+    if (sinThetaTSqr > 1.0f) return 1.0f;
+    float cosThetaT = sqrtf(1.0f - sinThetaTSqr);
+    float Rs = (etaI * cosThetaI - etaT * cosThetaT) / (etaI * cosThetaI + etaT * cosThetaT);
+    float Rp = (etaT * cosThetaI - etaI * cosThetaT) / (etaT * cosThetaI + etaI * cosThetaT);
+    return (Rs * Rs + Rp * Rp) / 2.0f;
+}
+__device__ __forceinline__ V3 refractV(V3 wi, V3 n, float eta) {
+    float cosThetaI = dot(wi, n);
+    if (cosThetaI < 0) eta = 1.0f / eta;
+    float cosThetaT2 = 1 - (1 - cosThetaI * cosThetaI) * (eta * eta);
+    if (cosThetaT2 <= 0.0f) return mk(0.0f);
+    float sign = cosThetaI >= 0.0f ? 1.0f : -1.0f;
+    return n * (-cosThetaI * eta + sign * sqrtf(cosThetaT2)) + wi * eta;
+}
+// returns the sample weight; wo is the sampled direction; alive=false when the path contributes nothing further;
+// discrete = bRec.measure == EDiscrete; etaScale = bRec.eta
+__device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive, bool &discrete, float &etaScale) {
+    wo = mk(0.f, 0.f, 1.f); discrete = false; etaScale = 1.0f;
+    if (m.type == KZ_BSDF_DIELECTRIC) {                                            // bsdf.cpp:119-143 (no back-side test)
+        alive = true; discrete = true;
+        if (s1 < fresnelIOR(wi.z, m.extIOR, m.intIOR)) { wo = mk(-wi.x, -wi.y, wi.z); return mk(1.0f); }
+        V3 n = mk(0.0f, 0.0f, 1.0f);
+        float factor = m.intIOR / m.extIOR;
+        if (wi.z < 0.f) { factor = m.extIOR / m.intIOR; n.z = -1.0f; }
+        wo = refractV(-wi, n, factor);
+        etaScale = m.intIOR / m.extIOR;
+        return mk(1.0f);
+    }
+    if (wi.z <= 0) { alive = false; return mk(0.f); }                              // bsdf.cpp:60-61, :176-177, :1302-1303
     alive = true;
+    if (m.type == KZ_BSDF_MIRROR) { wo = mk(-wi.x, -wi.y, wi.z); discrete = true; return mk(1.0f); }   // bsdf.cpp:175-191
     if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:59-75
         wo = squareToCosineHemisphere(s2x, s2y);
         return mk(m.albedo[0], m.albedo[1], m.albedo[2]);
@@ -662,10 +694,12 @@ __device__ __forceinline__ V3 bsdfEval(const KzBSDF &m, V3 wi, V3 wo, float accR
         if (wi.z <= 0 || wo.z <= 0) return mk(0.f);
         return mk(m.albedo[0], m.albedo[1], m.albedo[2]) * KZ_INV_PI * wo.z;
     }
+    if (m.type != KZ_BSDF_KAZENSTANDARD) return mk(0.f);                           // discrete BRDFs evaluate to zero
     return kissEval(m, wi, wo, accRough);
 }
 __device__ __forceinline__ float bsdfPdf(const KzBSDF &m, V3 wi, V3 wo, float accRough) {
     if (m.type == KZ_BSDF_DIFFUSE) { if (wi.z <= 0 || wo.z <= 0) return 0.f; return KZ_INV_PI * wo.z; }   // bsdf.cpp:40-56
+    if (m.type != KZ_BSDF_KAZENSTANDARD) return 0.f;
     return kissPdf(m, wi, wo, accRough);
 }
 
@@ -800,9 +834,10 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
         // ---- BSDF sampling (integrator.cpp:304-309): next2D BEFORE next1D (H1)
         float s2x, s2y; smp.next2D(P, T, s2x, s2y);
         float s1 = smp.next1D(P, T);
-        V3 woLocal; bool alive;
-        V3 weight = bsdfSample(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, alive);
+        V3 woLocal; bool alive, discrete; float etaScale;
+        V3 weight = bsdfSample(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, alive, discrete, etaScale);
         throughput = throughput * weight;
+        eta *= etaScale;
         // zero weight: the reference keeps looping with throughput 0 (contributes exactly 0); terminate instead
         if (!alive || (weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) break;
         float bpdf = bsdfPdf(bsdf, wiLocal, woLocal, accRough);
@@ -819,6 +854,7 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             float lpdf = lightPdfSolidAngle(T.lights[nl].normalization, its.sh.n, wi, its.p, ro);
             bsdfWeight = powerHeuristic(bpdf, lpdf);
         }
+        if (discrete) bsdfWeight = 1.f;                                                       // integrator.cpp:329-331
         depth++;
     }
     return L;

@@ -102,8 +102,8 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     if (!(d->camera.rfilter.radius > 0.f) || d->camera.rfilter.radius > 4.0f) return kz_fail(KZ_ERR_UNSUPPORTED, "filter radius %g (supported: (0, 4])", d->camera.rfilter.radius);
     if ((d->nMeshes && !d->meshes) || (d->nBsdfs && !d->bsdfs) || (d->nLights && !d->lights)) return kz_fail(KZ_ERR_INVALID_ARG, "null table with non-zero count");
     for (uint32_t i = 0; i < d->nBsdfs; ++i)
-        if (d->bsdfs[i].type != KZ_BSDF_DIFFUSE && d->bsdfs[i].type != KZ_BSDF_KAZENSTANDARD)
-            return kz_fail(KZ_ERR_UNSUPPORTED, "bsdf %u has type %d (only \"diffuse\" and \"kazenstandard\" are on the hot path)", i, d->bsdfs[i].type);
+        if (d->bsdfs[i].type < KZ_BSDF_DIFFUSE || d->bsdfs[i].type > KZ_BSDF_DIELECTRIC)
+            return kz_fail(KZ_ERR_UNSUPPORTED, "bsdf %u has type %d (supported: \"diffuse\", \"kazenstandard\", \"mirror\", \"dielectric\")", i, d->bsdfs[i].type);
 
     KzScene *sc = new KzScene();
     std::memset(&sc->prm, 0, sizeof sc->prm);

@@ -28,7 +28,7 @@ struct KzWf {
     float4 *rayA, *rayB;           // o.xyz tmin | d.xyz tmax
     float4 *hit;                   // t u v tri(bits); t = +inf: miss
     float4 *thr;                   // throughput.xyz eta
-    float4 *misc;                  // bsdfPdf accumulatedRoughness - -
+    float4 *misc;                  // bsdfPdf accumulatedRoughness discrete(EDiscrete) -
     uint4 *smp;                    // pcg32 state (.x,.y) + dimension index (.z); the pcg32 stream id is recomputed from the pixel
     float4 *shA, *shB, *shL;       // shadow (or walk-through) ray o.xyz tmax | d.xyz tmin | pending radiance
     uint32_t *queue[3];            // two ping-pong path queues + the shadow queue
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shade(KzParams P, KzDevTables 
                     const KzLightRow &lr = T.lights[mrow.light];
                     const V3 wi = normalized(its.p - ro);
                     float bsdfWeight = 1.f;
-                    if (iter > 0) bsdfWeight = powerHeuristic(mi.x, lightPdfSolidAngle(lr.normalization, its.sh.n, wi, its.p, ro));
+                    if (iter > 0 && mi.z == 0.f) bsdfWeight = powerHeuristic(mi.x, lightPdfSolidAngle(lr.normalization, its.sh.n, wi, its.p, ro));   // mi.z: EDiscrete (integrator.cpp:329-331)
                     if (dot(its.sh.n, -wi) > 0.f) {
                         const V3 c = (bsdfWeight * throughput) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
                         W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
@@ -270,9 +270,10 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shade(KzParams P, KzDevTables 
                         if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
                         float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
                         const float s1 = smp.next1D(P, T);
-                        V3 woLocal; bool ok;
-                        const V3 weight = bsdfSample(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, ok);
+                        V3 woLocal; bool ok, discrete; float etaScale;
+                        const V3 weight = bsdfSample(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale);
                         throughput = throughput * weight;
+                        const float etaNext = eta * etaScale;
                         if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
                             const float bpdf = bsdfPdf(bsdf, wiLocal, woLocal, accRough);
                             const V3 nd = toWorld(its.sh, woLocal);                           // H9
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shade(KzParams P, KzDevTables 
                             if (iter + 1 < P.maxDepth || P.bgPresent) {
                                 W.rayA[slot] = make_float4(its.p.x, its.p.y, its.p.z, eps);
                                 W.rayB[slot] = make_float4(nd.x, nd.y, nd.z, KZ_INF);
-                                W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, eta);
-                                W.misc[slot] = make_float4(bpdf, accRough, 0.f, 0.f);
+                                W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, etaNext);
+                                W.misc[slot] = make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f);
                                 wfStoreSampler(P, W, slot, smp);
                                 pushNext = true;
                             }

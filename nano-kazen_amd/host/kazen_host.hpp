@@ -102,11 +102,11 @@ public:
         auto &t = table();
         auto it = t.find(name);
         if (it != t.end()) return it->second(props);
-        static const char *offPath[] = {"normals", "ao", "whitted", "path_mats", "dielectric", "mirror",
+        static const char *offPath[] = {"normals", "ao", "whitted", "path_mats",
                                         "lambertian", "normalmap", "ggx", "roughconductor", "roughplastic", "roughdielectric", "imagetexture",
                                         "colorramp", "blend", "nonscatter"};
         for (const char *o : offPath)
-            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis; diffuse/kazenstandard; independent/pmj02bn/stratified/correlated; perspective/thinlens)");
+            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis; diffuse/kazenstandard/mirror/dielectric; independent/pmj02bn/stratified/correlated; perspective/thinlens)");
         throw Exception("A constructor for class \"" + name + "\" could not be found!");
     }
 private:
@@ -181,6 +181,20 @@ public:
     std::string toString() const override { return "KazenStandardSurface"; }
     ConstantTexture *m_baseColor = nullptr, *m_roughness = nullptr, *m_metallic = nullptr;
     float m_anisotropy, m_specular, m_specularTint, m_clearcoat, m_clearcoatRoughness, m_sheen, m_sheenTint;
+};
+
+class Mirror : public BSDF {                         // src/kazen/bsdf.cpp:161-196
+public:
+    explicit Mirror(const PropertyList &) {}
+    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_MIRROR; return b; }
+    std::string toString() const override { return "Mirror[]"; }
+};
+class Dielectric : public BSDF {                     // src/kazen/bsdf.cpp:98-155
+public:
+    explicit Dielectric(const PropertyList &p) { m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); }
+    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_DIELECTRIC; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
+    std::string toString() const override { return "Dielectric[]"; }
+    float m_intIOR, m_extIOR;
 };
 
 // ---- light / filter / sampler / integrator / camera -------------------------------------------------------------------
@@ -353,6 +367,8 @@ KAZEN_MI355X_REGISTER(Mesh, "obj");
 KAZEN_MI355X_REGISTER(AreaLight, "area");
 KAZEN_MI355X_REGISTER(Diffuse, "diffuse");
 KAZEN_MI355X_REGISTER(KazenStandardSurface, "kazenstandard");
+KAZEN_MI355X_REGISTER(Mirror, "mirror");
+KAZEN_MI355X_REGISTER(Dielectric, "dielectric");
 KAZEN_MI355X_REGISTER(ConstantTexture, "constanttexture");
 KAZEN_MI355X_REGISTER(BackgroundTexture, "background");
 KAZEN_MI355X_REGISTER(PerspectiveCamera, "perspective");

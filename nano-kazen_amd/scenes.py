@@ -65,6 +65,14 @@ def kazenstandard(baseColor=(0.5, 0.5, 0.5), roughness=0.5, metallic=0.0, anisot
             "clearcoatRoughness": clearcoatRoughness, "sheen": sheen, "sheenTint": sheenTint}
 
 
+def mirror():
+    return {"type": "mirror"}
+
+
+def dielectric(intIOR=1.5046, extIOR=1.000277):
+    return {"type": "dielectric", "intIOR": intIOR, "extIOR": extIOR}
+
+
 def area(color=(1.0, 1.0, 1.0), intensity=1.0, lightPrimaryVisibility=False):
     return {"type": "area", "color": tuple(color), "intensity": intensity,
             "lightPrimaryVisibility": bool(lightPrimaryVisibility)}
@@ -143,6 +151,11 @@ class SceneDescription:
                 for f in ("roughness", "metallic", "anisotropy", "specular", "specularTint", "clearcoat",
                           "clearcoatRoughness", "sheen", "sheenTint"):
                     setattr(k, f, b[f])
+            elif b["type"] == "mirror":
+                k.type = abi.KZ_BSDF_MIRROR
+            elif b["type"] == "dielectric":
+                k.type = abi.KZ_BSDF_DIELECTRIC
+                k.intIOR, k.extIOR = b["intIOR"], b["extIOR"]
             else:
                 k.type = 99      # unsupported plugin: the library must answer KZ_ERR_UNSUPPORTED
         cl = (abi.KzLight * max(1, len(lights)))()
@@ -393,6 +406,16 @@ def cornell_box(width=256, height=256, spp=16, sampler="independent", seed=0, ma
                     toWorld=look_at((0, 0, 3.6), (0, 0, 0), (0, 1, 0)))
     s.sampler = {"type": sampler, "sampleCount": spp, "seed": seed}
     s.integrator["maxDepth"] = maxDepth
+    return s
+
+
+def glass_scene(width=128, height=128, spp=16, sampler="independent", seed=0, maxDepth=8):
+    """Cornell-style box with a mirror block and a glass (dielectric) sphere: the EDiscrete / eta branches of Li."""
+    s = cornell_box(width, height, spp, sampler, seed, maxDepth)
+    s.meshes[5]["bsdf"] = mirror()
+    del s.meshes[6]
+    s.add_mesh(*_vfnuv(uv_sphere((0.4, -0.6, 0.35), 0.4, 24, 25)), bsdf=dielectric())
+    s.meshes.append(s.meshes.pop(6))          # keep the light last is not required; order only fixes ids
     return s
 
 

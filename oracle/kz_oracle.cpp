@@ -755,15 +755,67 @@ static V3 kissSample(const KzBSDF &m, BRec &b, float sample1, float s2x, float s
     return kissEval(m, b) / pdf;
 }
 
+// fresnel (src/kazen/common.cpp:447-475) and refract (:526-534)
+static float fresnelIOR(float cosThetaI, float extIOR, float intIOR) {
+    float etaI = extIOR, etaT = intIOR;
+    if (extIOR == intIOR) return 0.0f;
+    if (cosThetaI < 0.0f) { std::swap(etaI, etaT); cosThetaI = -cosThetaI; }
+    float eta = etaI / etaT, sinThetaTSqr = eta * eta * (1 - cosThetaI * cosThetaI);
+    if (sinThetaTSqr > 1.0f) return 1.0f;
+    float cosThetaT = std::sqrt(1.0f - sinThetaTSqr);
+    float Rs = (etaI * cosThetaI - etaT * cosThetaT) / (etaI * cosThetaI + etaT * cosThetaT);
+    float Rp = (etaT * cosThetaI - etaI * cosThetaT) / (etaT * cosThetaI + etaI * cosThetaT);
+    return (Rs * Rs + Rp * Rp) / 2.0f;
+}
+static V3 refractV(V3 wi, V3 n, float eta) {
+    float cosThetaI = dot(wi, n);
+    if (cosThetaI < 0) eta = 1.0f / eta;
+    float cosThetaT2 = 1 - (1 - cosThetaI * cosThetaI) * (eta * eta);
+    if (cosThetaT2 <= 0.0f) return V3(0.0f);
+    float sign = cosThetaI >= 0.0f ? 1.0f : -1.0f;
+    return n * (-cosThetaI * eta + sign * std::sqrt(cosThetaT2)) + wi * eta;
+}
+// Mirror (bsdf.cpp:161-196) and Dielectric (bsdf.cpp:98-155): discrete lobes, eval = pdf = 0
+static V3 mirrorSample(BRec &b, bool &ok) {
+    if (b.wi.z <= 0) { ok = false; return V3(0.f); }
+    ok = true;
+    b.wo = V3(-b.wi.x, -b.wi.y, b.wi.z); b.measure = EDiscrete; b.eta = 1.0f;
+    return V3(1.0f);
+}
+static V3 dielectricSample(const KzBSDF &m, BRec &b, float sample1, bool &ok) {
+    ok = true;
+    b.measure = EDiscrete;
+    float cosThetaI = b.wi.z;
+    float fresnelTerm = fresnelIOR(cosThetaI, m.extIOR, m.intIOR);
+    if (sample1 < fresnelTerm) { b.wo = V3(-b.wi.x, -b.wi.y, b.wi.z); b.eta = 1.f; return V3(1.0f); }
+    V3 n(0.0f, 0.0f, 1.0f);
+    float factor = m.intIOR / m.extIOR;
+    if (b.wi.z < 0.f) { factor = m.extIOR / m.intIOR; n.z = -1.0f; }
+    b.wo = refractV(-b.wi, n, factor);
+    b.eta = m.intIOR / m.extIOR;
+    return V3(1.0f);
+}
+
 static const KzBSDF &meshBsdf(const Scene &sc, int mesh) {
-    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f};
+    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f, 1.5046f, 1.000277f, {0, 0}};
     int b = sc.meshes[mesh].bsdf;
     return b < 0 ? dflt : sc.bsdfs[b];
 }
-static V3 bsdfEval(const KzBSDF &m, const BRec &b) { return m.type == KZ_BSDF_DIFFUSE ? diffuseEval(m, b) : kissEval(m, b); }
-static float bsdfPdf(const KzBSDF &m, const BRec &b) { return m.type == KZ_BSDF_DIFFUSE ? diffusePdf(m, b) : kissPdf(m, b); }
+static V3 bsdfEval(const KzBSDF &m, const BRec &b) {
+    if (m.type == KZ_BSDF_DIFFUSE) return diffuseEval(m, b);
+    if (m.type == KZ_BSDF_KAZENSTANDARD) return kissEval(m, b);
+    return V3(0.f);                                                     // discrete BRDFs evaluate to zero (bsdf.cpp:109-112,165-168)
+}
+static float bsdfPdf(const KzBSDF &m, const BRec &b) {
+    if (m.type == KZ_BSDF_DIFFUSE) return diffusePdf(m, b);
+    if (m.type == KZ_BSDF_KAZENSTANDARD) return kissPdf(m, b);
+    return 0.f;
+}
 static V3 bsdfSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {
-    return m.type == KZ_BSDF_DIFFUSE ? diffuseSample(m, b, s1, s2x, s2y, ok) : kissSample(m, b, s1, s2x, s2y, ok);
+    if (m.type == KZ_BSDF_DIFFUSE) return diffuseSample(m, b, s1, s2x, s2y, ok);
+    if (m.type == KZ_BSDF_KAZENSTANDARD) return kissSample(m, b, s1, s2x, s2y, ok);
+    if (m.type == KZ_BSDF_MIRROR) return mirrorSample(b, ok);
+    return dielectricSample(m, b, s1, ok);
 }
 static float bsdfRegularize(const KzBSDF &m) { return m.type == KZ_BSDF_KAZENSTANDARD ? m.roughness : 0.f; }   // bsdf.cpp:1397-1399, bsdf.h:125
 
@@ -1234,7 +1286,7 @@ int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) {
     sc->cam = d->camera; sc->smp = d->sampler; sc->integ = d->integrator; sc->bg = d->background;
     sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->nBsdfs);
     sc->lights.assign(d->lights, d->lights + d->nLights);
-    for (auto &b : sc->bsdfs) if (b.type != KZ_BSDF_DIFFUSE && b.type != KZ_BSDF_KAZENSTANDARD) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "bsdf type"); }
+    for (auto &b : sc->bsdfs) if (b.type < KZ_BSDF_DIFFUSE || b.type > KZ_BSDF_DIELECTRIC) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "bsdf type"); }
     sc->meshes.resize(d->nMeshes);
     for (uint32_t m = 0; m < d->nMeshes; ++m) {
         const KzMesh &km = d->meshes[m]; MeshData &md = sc->meshes[m];

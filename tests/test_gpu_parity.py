@@ -173,6 +173,7 @@ CASES = {
     "stratified": lambda S: S.cornell_box(96, 80, 10, sampler="stratified", seed=1),        # rounds to 16 spp
     "correlated": lambda S: S.cornell_box(96, 80, 12, sampler="correlated", seed=3),
     "thinlens": lambda S: _thinlens(S),
+    "mirror_glass": lambda S: S.glass_scene(96, 96, 16),                                     # EDiscrete + eta branches
 }
 
 

@@ -289,3 +289,27 @@ def test_thinlens_reduces_to_pinhole_at_zero_aperture(O, kz):
     c.camera.update(type="thinlens", apertureRadius=0.3, focusDistance=3.6)
     fc = O.OracleScene(c).render(threads=1)
     assert np.isfinite(fc).all() and not np.allclose(fa, fc, rtol=1e-2, atol=1e-3)
+
+
+def test_discrete_bsdfs(O, kz):
+    """mirror / dielectric (bsdf.cpp:98-196): eval = pdf = 0, sample is a delta lobe; energy conserving weights of 1."""
+    S = kz.scenes
+    wi = np.array([0.3, -0.2, 0.93], np.float32)
+    wi /= np.linalg.norm(wi)
+    assert (O.bsdf(S.mirror(), "eval", wi, (0, 0, 1)) == 0).all() and O.bsdf(S.mirror(), "pdf", wi, (0, 0, 1)) == 0
+    w, wo, ok = O.bsdf(S.mirror(), "sample", wi, None, 0, 0.3, (0.1, 0.2))
+    assert ok and np.allclose(w, 1) and np.allclose(wo, (-wi[0], -wi[1], wi[2]))
+    w, wo, ok = O.bsdf(S.mirror(), "sample", -wi, None, 0, 0.3, (0.1, 0.2))
+    assert not ok and np.allclose(w, 0)
+    g = S.dielectric()
+    w, wo, ok = O.bsdf(g, "sample", wi, None, 0, 0.999, (0.1, 0.2))            # transmit
+    assert ok and np.allclose(w, 1) and wo[2] < 0 and abs(np.linalg.norm(wo) - 1) < 1e-5
+    # Snell: sin(t) = sin(i) * ext/int
+    assert abs(np.hypot(wo[0], wo[1]) - np.hypot(wi[0], wi[1]) * 1.000277 / 1.5046) < 1e-5
+    w, wo2, ok = O.bsdf(g, "sample", wi, None, 0, 0.0, (0.1, 0.2))             # reflect (fresnel > 0)
+    assert np.allclose(wo2, (-wi[0], -wi[1], wi[2]))
+    graz = np.array([0.9999, 0, -0.0141], np.float32)                          # from inside at grazing angle: total internal reflection
+    w, wo3, ok = O.bsdf(g, "sample", graz, None, 0, 0.9999, (0.1, 0.2))
+    assert np.allclose(wo3, (-graz[0], -graz[1], graz[2]))
+    film = O.OracleScene(S.glass_scene(32, 32, 4)).render(threads=2)
+    assert np.isfinite(film).all() and film[..., :3].sum() > 0
