@@ -244,20 +244,21 @@ __device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t no
     const float ax = __uint_as_float((q0.w & 0xffu) << 23) * rx, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * ry,
                 az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * rz;
     const float bx = (__uint_as_float(q0.x) - o.x) * rx, by = (__uint_as_float(q0.y) - o.y) * ry, bz = (__uint_as_float(q0.z) - o.z) * rz;
+    // The sign of the direction says which plane of a slab is entered first: pick the packed near / far words for all four
+    // children at once (rcp is finite and non-zero here, see the caller), so each child needs only 6 cvt + 6 fma + max3 + min3.
+    // An empty slot (qlo = 255, qhi = 0) comes out with near > far on every axis for either sign: never hit.
+    const uint32_t nX = rx >= 0.f ? q1.x : q1.w, fX = rx >= 0.f ? q1.w : q1.x;
+    const uint32_t nY = ry >= 0.f ? q1.y : q2.x, fY = ry >= 0.f ? q2.x : q1.y;
+    const uint32_t nZ = rz >= 0.f ? q1.z : q2.y, fZ = rz >= 0.f ? q2.y : q1.z;
     uint32_t key[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float lx = (float)((q1.x >> (8 * i)) & 0xffu), ly = (float)((q1.y >> (8 * i)) & 0xffu), lz = (float)((q1.z >> (8 * i)) & 0xffu);
-        const float hx = (float)((q1.w >> (8 * i)) & 0xffu), hy = (float)((q2.x >> (8 * i)) & 0xffu), hz = (float)((q2.y >> (8 * i)) & 0xffu);
-        const bool empty = lx > hx;                       // unused slot: qlo = 255, qhi = 0
-        float t0 = fmaf(lx, ax, bx), t1 = fmaf(hx, ax, bx);
-        float n = fminf(t0, t1), f = fmaxf(t0, t1);
-        t0 = fmaf(ly, ay, by); t1 = fmaf(hy, ay, by); n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
-        t0 = fmaf(lz, az, bz); t1 = fmaf(hz, az, bz); n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
-        f *= 1.0000004f;
-        n = fmaxf(n, tmin);
-        const bool hit = !empty && (n <= fminf(f, tmax));
-        key[i] = hit ? ((__float_as_uint(n) & ~3u) | (uint32_t)i) : 0xFFFFFFFFu;
+        const float tnx = fmaf((float)((nX >> (8 * i)) & 0xffu), ax, bx), tfx = fmaf((float)((fX >> (8 * i)) & 0xffu), ax, bx);
+        const float tny = fmaf((float)((nY >> (8 * i)) & 0xffu), ay, by), tfy = fmaf((float)((fY >> (8 * i)) & 0xffu), ay, by);
+        const float tnz = fmaf((float)((nZ >> (8 * i)) & 0xffu), az, bz), tfz = fmaf((float)((fZ >> (8 * i)) & 0xffu), az, bz);
+        const float n = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);
+        const float f = fminf(fminf(fminf(tfx, tfy), tfz) * 1.0000004f, tmax);
+        key[i] = (n <= f) ? ((__float_as_uint(n) & ~3u) | (uint32_t)i) : 0xFFFFFFFFu;
     }
     // 5-comparator sorting network on unsigned keys
     uint32_t a = min(key[0], key[1]), b = max(key[0], key[1]), c = min(key[2], key[3]), d = max(key[2], key[3]);
