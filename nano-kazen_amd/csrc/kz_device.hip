@@ -368,7 +368,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     const dim3 blk(KZ_BLOCK);
     auto envInt = [](const char *n, int dflt) { const char *e = std::getenv(n); return e ? std::atoi(e) : dflt; };
     KzTune tune = {envInt("KZ_TUNE_REFILL", 40), envInt("KZ_TUNE_POSTPONE", 20), envInt("KZ_TUNE_BATCH", 128), envInt("KZ_TUNE_TRAV_BLOCKS", 8), envInt("KZ_TUNE_SHADE_BLOCKS", 6),
-                   envInt("KZ_TUNE_LDS_STACK", 12), envInt("KZ_TUNE_WIDE", 1), nullptr, 0};
+                   envInt("KZ_TUNE_LDS_STACK", 16), envInt("KZ_TUNE_WIDE", 1), nullptr, 0};
     const dim3 gTrav((unsigned)(ds->numCU * tune.travBlocksPerCU)), gShade((unsigned)(ds->numCU * tune.shadeBlocksPerCU));
     // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
@@ -390,11 +390,12 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, ds->pixList, items, Sp, sBegin);
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
     static const int traceKernel = [] { const char *e = std::getenv("KZ_TRACE_KERNEL"); return e ? std::atoi(e) : 1; }();
-#define KZ_TRACE(MODE, q, cptr, cimm, headp) do { \
-        if (tune.wide) { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune); \
-                         else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune); } \
-        else { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune); \
-               else hipLaunchKernelGGL((kz_wf_trace<MODE, false, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune); } } while (0)
+#define KZ_TRACE2(MODE, q, cptr, cimm, headp, qb, cb) do { \
+        if (tune.wide) { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
+                         else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } \
+        else { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
+               else hipLaunchKernelGGL((kz_wf_trace<MODE, false, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } } while (0)
+#define KZ_TRACE(MODE, q, cptr, cimm, headp) KZ_TRACE2(MODE, q, cptr, cimm, headp, (const uint32_t *)nullptr, (const uint32_t *)nullptr)
 #define KZ_EXTEND(KEEP, q, cptr, cimm, headp) do { if (traceKernel) KZ_TRACE((KEEP ? 1 : 0), q, cptr, cimm, headp); \
                                             else if (st) hipLaunchKernelGGL((kz_wf_extend<true, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); \
                                             else hipLaunchKernelGGL((kz_wf_extend<false, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); } while (0)
@@ -408,6 +409,15 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
         uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
         if (st) hipLaunchKernelGGL(kz_wf_shade<true>, gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount);
         else hipLaunchKernelGGL(kz_wf_shade<false>, gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount);
+        const bool lastIter = iter == maxDepth - 1;
+        const bool needExtend = !lastIter || P.bgPresent;
+        static const int mixed = [] { const char *e = std::getenv("KZ_TUNE_MIXED"); return e ? std::atoi(e) : 0; }();   // measured: no gain on C4 (43.16 vs 43.06 ms), kept as an option
+        if (traceKernel && mixed && P.nLights > 0 && needExtend) {
+            // one launch for the shadow rays of this bounce and the closest-hit rays of the next
+            KZ_TRACE2(3, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, (const uint32_t *)shQ, (const uint32_t *)shCount);
+            cur = nextQ; curCount = nextCount;
+            continue;
+        }
         if (P.nLights > 0) {
             if (traceKernel) KZ_TRACE(2, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3);
             else if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
@@ -419,6 +429,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     }
 #undef KZ_EXTEND
 #undef KZ_TRACE
+#undef KZ_TRACE2
     if (P.bgPresent) hipLaunchKernelGGL(kz_wf_final, gShade, blk, 0, stream, P, W, cur, curCount);
     if (st) hipLaunchKernelGGL(kz_wf_count, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, W, items);
     HIP_TRY(hipGetLastError());

@@ -330,17 +330,22 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // WIDE selects the quantised BVH4 (KzNode4) instead of the BVH2. The per-lane stack keeps tune.ldsStack entries in LDS
 // ([entry][lane] columns, conflict free) and spills deeper entries to a global overflow area sized from the builder's
 // worst-case bound, so LDS no longer caps occupancy.
-// MODE 0: closest hit -> W.hit; 1: same on the shA/shB ray, previous hit kept on a miss (H6); 2: shadow test -> adds W.shL.
+// MODE 0: closest hit -> W.hit; 1: same on the shA/shB ray, previous hit kept on a miss (H6); 2: shadow test -> adds W.shL;
+// 3: mixed launch — entries [0, countA) of queue are closest-hit rays (the next bounce), entries of queueB are the shadow rays of
+// the bounce before: both only depend on the same shade stage, and one launch has one tail instead of two.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment; such
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
 struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide; uint32_t *ovf; uint32_t ovfStride; };
 
 template <int MODE, bool STATS, bool WIDE>
 __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
-                                                        const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune) {
+                                                        const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune,
+                                                        const uint32_t *__restrict__ queueB, const uint32_t *__restrict__ countPtrB) {
     extern __shared__ uint32_t s_stack[];
     uint32_t *stk = s_stack + threadIdx.x;
-    const uint32_t count = countPtr ? *countPtr : countImm;
+    const uint32_t countA = countPtr ? *countPtr : countImm;
+    const uint32_t count = countA + ((MODE == 3) ? *countPtrB : 0u);
+    int kind = (MODE == 3) ? 0 : MODE;              // per-lane ray kind; a compile-time constant unless the launch is mixed
     const int lane = threadIdx.x & 63;
     const int LS = tune.ldsStack;
     uint32_t *ovf = tune.ovf + (size_t)blockIdx.x * KZ_BLOCK + threadIdx.x;
@@ -363,9 +368,9 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
     // the lane's stack ran empty: publish the result (or, for a literal shadow lane, decide / walk through the light)
     auto finish = [&]() {
         active = false;
-        if (MODE == 0) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
-        if (MODE == 1) { if (found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(btri)); }
-        if (MODE == 2) {
+        if (kind == 0) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+        if (kind == 1) { if (found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(btri)); }
+        if (kind == 2) {
             if (!literal || !found) addPending();                                    // nothing on the segment
             else {
                 const uint32_t om = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + btri)[2].y);
@@ -396,9 +401,10 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
                 const uint32_t rank = (uint32_t)__popcll(~act & ltMask);
                 if (!active && rank < take) {
                     const uint32_t qi = poolNext + rank;
-                    slot = queue ? queue[qi] : qi;
+                    if (MODE == 3) { kind = qi < countA ? 0 : 2; slot = qi < countA ? queue[qi] : queueB[qi - countA]; }
+                    else slot = queue ? queue[qi] : qi;
                     float4 a, b;
-                    if (MODE == 0) { a = W.rayA[slot]; b = W.rayB[slot]; }
+                    if (kind == 0) { a = W.rayA[slot]; b = W.rayB[slot]; }
                     else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w); }
                     o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); tmin = a.w; tmax = b.w; segMax = b.w;
                     found = false; bt = KZ_INF; bu = bv = 0.f; btri = 0; bgid = 0; literal = false;
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
                             rz = 1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
                         } else { rx = 1.0f / d.x; ry = 1.0f / d.y; rz = 1.0f / d.z; }
                         cur = root; sp = 0; active = true;
-                        if (MODE == 2) {
+                        if (kind == 2) {
                             literal = !P.shadowFast;
                             if (!literal && P.nIlTris > 0) {
                                 float t0 = (P.ilLo[0] - o.x) * rx, t1 = (P.ilHi[0] - o.x) * rx;
@@ -430,8 +436,8 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
                         }
                     } else {
                         // a ray that cannot hit anything (empty scene, non-finite origin/direction)
-                        if (MODE == 0) W.hit[slot] = make_float4(KZ_INF, 0.f, 0.f, 0.f);
-                        if (MODE == 2) addPending();
+                        if (kind == 0) W.hit[slot] = make_float4(KZ_INF, 0.f, 0.f, 0.f);
+                        if (kind == 2) addPending();
                     }
                 }
                 poolNext += take;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
                 float t, u, v; uint32_t g;
                 if (STATS) cn.tris++;
                 if (!triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, g)) continue;
-                if (MODE == 2 && !literal) { occluded = true; break; }                // any hit blocks: nothing to add
+                if (kind == 2 && !literal) { occluded = true; break; }                // any hit blocks: nothing to add
                 if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; btri = start + i; bgid = g; tmax = t; }
             }
             if (occluded) active = false;

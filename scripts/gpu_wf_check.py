@@ -23,10 +23,14 @@ for name, desc in cases:
 d = S.random_triangles(1000000, 1920, 1080, 1024)
 sc = kz.Scene(d, device=0)
 import os
-for wide, ls in ((0,12),(0,24),(1,8),(1,12),(1,16),(1,24)):
+for wide, ls in ((1,12),(1,16)):
     os.environ["KZ_TUNE_WIDE"]=str(wide); os.environ["KZ_TUNE_LDS_STACK"]=str(ls)
     sc.render(32, 48, pipeline=2); sc.sync(); sc.render(32, 48, pipeline=2); sc.sync()
     print("C4 wavefront wide", wide, "ldsStack", ls, "pass ms %.1f" % sc.last_kernel_ms(), flush=True)
+for mixed in (0, 1):
+    os.environ["KZ_TUNE_MIXED"]=str(mixed)
+    sc.render(32, 48, pipeline=2); sc.sync(); sc.render(32, 48, pipeline=2); sc.sync()
+    print("C4 mixed", mixed, "pass ms %.2f" % sc.last_kernel_ms(), flush=True)
 os.environ["KZ_TUNE_WIDE"]="1"; os.environ["KZ_TUNE_LDS_STACK"]="12"
 sc.render(32,48,pipeline=1); a = sc.film(); sc.render(32,48,pipeline=2); b = sc.film()
 print("C4 identical", np.array_equal(a,b), np.abs(a-b).max())
