@@ -45,7 +45,11 @@ enum {
 enum { KZ_BSDF_DIFFUSE = 0        /* "diffuse"       src/kazen/bsdf.cpp:20-92     */,
        KZ_BSDF_KAZENSTANDARD = 1  /* "kazenstandard" src/kazen/bsdf.cpp:1157-1418 */,
        KZ_BSDF_MIRROR = 2         /* "mirror"        src/kazen/bsdf.cpp:161-196   */,
-       KZ_BSDF_DIELECTRIC = 3     /* "dielectric"    src/kazen/bsdf.cpp:98-155    */ };
+       KZ_BSDF_DIELECTRIC = 3     /* "dielectric"    src/kazen/bsdf.cpp:98-155    */,
+       KZ_BSDF_GGX = 4            /* "ggx"           src/kazen/bsdf.cpp:629-689 (constanttexture albedo) */,
+       KZ_BSDF_ROUGHCONDUCTOR = 5 /* "roughconductor" src/kazen/bsdf.cpp:692-811  */,
+       KZ_BSDF_ROUGHPLASTIC = 6   /* "roughplastic"  src/kazen/bsdf.cpp:814-943   */,
+       KZ_BSDF_ROUGHDIELECTRIC = 7/* "roughdielectric" src/kazen/bsdf.cpp:947-1145 */ };
 enum { KZ_SAMPLER_INDEPENDENT = 0 /* "independent"   src/kazen/sampler.cpp:18-71   */,
        KZ_SAMPLER_PMJ02BN = 1     /* "pmj02bn"       src/kazen/sampler.cpp:273-390 */,
        KZ_SAMPLER_STRATIFIED = 2  /* "stratified"    src/kazen/sampler.cpp:81-156  */,
@@ -84,8 +88,13 @@ typedef struct KzBSDF {
     float sheenTint;            /* default 0.5                                        */
     float intIOR;               /* dielectric: "intIOR", default 1.5046               */
     float extIOR;               /* dielectric: "extIOR", default 1.000277             */
-    float pad_[2];
+    float alpha;                /* roughconductor/roughplastic: "alpha" (default 0.1), roughdielectric: "roughness" (0.1), ggx: "roughness" (0.5);
+                                   the raw property: the library applies max(0.001, x^2) where the constructor does */
+    float condEta[3];           /* roughconductor: eta of "material" (Au default / Cu / Cr, bsdf.cpp:795-806) */
+    float condK[3];             /* roughconductor: k                                    */
+    float pad_[3];
 } KzBSDF;
+/* albedo doubles as: "kd" of roughplastic (default 0.5), the constanttexture albedo of ggx. */
 
 /* "area" light (src/kazen/light.cpp:7-66). radiance = intensity * color. */
 typedef struct KzLight {

@@ -11,6 +11,7 @@ KZ_ABI_VERSION = 1
 
 KZ_OK, KZ_ERR_INVALID_ARG, KZ_ERR_UNSUPPORTED, KZ_ERR_NO_DEVICE, KZ_ERR_HIP, KZ_ERR_STATE, KZ_ERR_OOM = range(7)
 KZ_BSDF_DIFFUSE, KZ_BSDF_KAZENSTANDARD, KZ_BSDF_MIRROR, KZ_BSDF_DIELECTRIC = 0, 1, 2, 3
+KZ_BSDF_GGX, KZ_BSDF_ROUGHCONDUCTOR, KZ_BSDF_ROUGHPLASTIC, KZ_BSDF_ROUGHDIELECTRIC = 4, 5, 6, 7
 KZ_SAMPLER_INDEPENDENT, KZ_SAMPLER_PMJ02BN, KZ_SAMPLER_STRATIFIED, KZ_SAMPLER_CORRELATED = 0, 1, 2, 3
 KZ_CAMERA_PERSPECTIVE, KZ_CAMERA_THINLENS = 0, 1
 KZ_INTEGRATOR_PATH_MIS = 0
@@ -29,7 +30,8 @@ class KzBSDF(C.Structure):
                 ("roughness", C.c_float), ("metallic", C.c_float), ("anisotropy", C.c_float),
                 ("specular", C.c_float), ("specularTint", C.c_float), ("clearcoat", C.c_float),
                 ("clearcoatRoughness", C.c_float), ("sheen", C.c_float), ("sheenTint", C.c_float),
-                ("intIOR", C.c_float), ("extIOR", C.c_float), ("pad_", C.c_float * 2)]
+                ("intIOR", C.c_float), ("extIOR", C.c_float), ("alpha", C.c_float), ("condEta", C.c_float * 3),
+                ("condK", C.c_float * 3), ("pad_", C.c_float * 3)]
 
 
 class KzLight(C.Structure):

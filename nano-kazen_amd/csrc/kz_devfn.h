@@ -654,11 +654,161 @@ __device__ __forceinline__ V3 refractV(V3 wi, V3 n, float eta) {
     float sign = cosThetaI >= 0.0f ? 1.0f : -1.0f;
     return n * (-cosThetaI * eta + sign * sqrtf(cosThetaT2)) + wi * eta;
 }
+// ---- Beckmann helpers of roughconductor / roughplastic / roughdielectric (bsdf.cpp:721-750, warp.cpp:120-129, frame.h:63-68)
+__device__ __forceinline__ float tanThetaV(V3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return sqrtf(temp) / v.z; }
+__device__ __forceinline__ float alphaOf(float x) { return fmaxf(0.001f, sqr(x)); }
+__device__ __forceinline__ float evalBeckmann(V3 m, float alpha) {
+    float temp = tanThetaV(m) / alpha, ct = m.z, ct2 = ct * ct;
+    return expf(-temp * temp) / (KZ_PI_F * alpha * alpha * ct2 * ct2);
+}
+__device__ __forceinline__ float smithBeckmannG1(V3 v, V3 m, float alpha) {
+    if (dot(v, m) * v.z <= 0.0f) return 0.0f;
+    float tt = fabsf(tanThetaV(v));
+    if (tt == 0.0f) return 1.0f;
+    float a = 1.0f / (alpha * tt);
+    if (a >= 1.6f) return 1.0f;
+    float aSqr = a * a;
+    return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+}
+__device__ __forceinline__ V3 squareToBeckmann(float sx, float sy, float alpha) {
+    float phi = 2 * KZ_PI_F * sx;
+    float theta = atanf(alpha * sqrtf(logf(1 / (1 - sy))));
+    return mk(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
+}
+__device__ __forceinline__ float squareToBeckmannPdf(V3 m, float alpha) {
+    float theta = acosf(m.z / norm(m));
+    float ok = (fabsf(norm(m) - 1) < KZ_EPSILON && m.z >= 0) ? 1.f : 0.f;
+    return ok * expf(-powf(tanf(theta), 2.f) / (alpha * alpha)) / (KZ_PI_F * alpha * alpha * powf(cosf(theta), 3.f));
+}
+__device__ __forceinline__ float fresnelDielectricT(float cosThetaI_, float eta, float &cosThetaT_) {        // common.cpp:492-518
+    float scale = (cosThetaI_ > 0.f) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    float cosThetaI = fabsf(cosThetaI_), cosThetaT = sqrtf(cosThetaTSqr);
+    float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+__device__ __forceinline__ V3 fresnelCond(float c, V3 eta, V3 k) {                                           // bsdf.cpp:709-717
+    V3 tmp_f = eta * eta + k * k;
+    V3 tmp = tmp_f * (c * c);
+    V3 twoEtaC = 2.f * eta * c;
+    V3 a = tmp - twoEtaC + mk(1.f), bq = tmp + twoEtaC + mk(1.f);
+    V3 Rparl2 = mk(a.x / bq.x, a.y / bq.y, a.z / bq.z);
+    V3 c2 = mk(c * c);
+    V3 e = tmp_f - twoEtaC + c2, f = tmp_f + twoEtaC + c2;
+    V3 Rperp2 = mk(e.x / f.x, e.y / f.y, e.z / f.z);
+    return (Rparl2 + Rperp2) / 2.0f;
+}
+__device__ __forceinline__ float signf1(float v) { return (v > 0.f) ? 1.f : -1.f; }
+// "ggx" (bsdf.cpp:629-689), "roughconductor" (:692-811), "roughplastic" (:814-943), "roughdielectric" (:947-1145)
+__device__ V3 roughEval(const KzBSDF &m, V3 wi, V3 wo) {
+    if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {
+        if (wi.z == 0) return mk(0.f);
+        const float alpha = alphaOf(m.alpha), mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
+        const bool refl = wi.z * wo.z > 0.f;
+        const float eta = wi.z > 0.f ? mEta : mInvEta;
+        V3 wm = refl ? normalized(wi + wo) : normalized(wi + wo * eta);
+        wm = wm * signf1(wm.z);
+        float ct; const float F = fresnelDielectricT(dot(wi, wm), mEta, ct);
+        const float D = evalBeckmann(wm, alpha);
+        const float G = smithBeckmannG1(wo, wm, alpha) * smithBeckmannG1(wi, wm, alpha);
+        if (refl) return mk((F * G * D) / (4.f * fabsf(wi.z)));
+        const float denom = dot(wi, wm) + eta * dot(wo, wm);
+        const float value = ((1 - F) * D * G * eta * eta * dot(wi, wm) * dot(wo, wm)) / (wi.z * sqr(denom));
+        return mk(fabsf(value));
+    }
+    if (wi.z <= 0 || wo.z <= 0) return mk(0.f);
+    if (m.type == KZ_BSDF_GGX) return evalGGXSmithBRDF(wi, wo, mk(m.albedo[0], m.albedo[1], m.albedo[2]), m.alpha, m.anisotropy) * wo.z;
+    const float alpha = alphaOf(m.alpha);
+    const V3 wh = normalized(wi + wo);
+    const float D = evalBeckmann(wh, alpha);
+    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) {
+        const V3 F = fresnelCond(dot(wh, wo), mk(m.condEta[0], m.condEta[1], m.condEta[2]), mk(m.condK[0], m.condK[1], m.condK[2]));
+        const float G = smithBeckmannG1(wi, wh, alpha) * smithBeckmannG1(wo, wh, alpha);
+        return D * F * G / (4.f * wi.z);
+    }
+    const V3 kd = mk(m.albedo[0], m.albedo[1], m.albedo[2]);                                                 // roughplastic
+    const float ks = 1 - maxCoeff(kd);
+    const float F = fresnelIOR(dot(wh, wo), m.extIOR, m.intIOR);
+    const float G = smithBeckmannG1(wo, wh, alpha) * smithBeckmannG1(wi, wh, alpha);
+    return kd * KZ_INV_PI * wo.z + mk(ks * (D * F * G) / (4.f * wi.z));
+}
+__device__ float roughPdf(const KzBSDF &m, V3 wi, V3 wo) {
+    if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {
+        const float mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
+        const bool refl = wi.z * wo.z > 0.f;
+        const float eta = wi.z > 0.f ? mEta : mInvEta;
+        V3 wm; float dwm_dwo;
+        if (refl) { wm = normalized(wi + wo); dwm_dwo = 1.0f / (4.0f * dot(wo, wm)); }
+        else { wm = normalized(wi + wo * eta); const float sd = dot(wi, wm) + eta * dot(wo, wm); dwm_dwo = (eta * eta * dot(wo, wm)) / (sd * sd); }
+        wm = wm * signf1(wm.z);
+        float ct; const float F = fresnelDielectricT(dot(wi, wm), mEta, ct);
+        float prob = evalBeckmann(wm, alphaOf(m.alpha)) * wm.z;
+        prob *= refl ? F : (1 - F);
+        return fabsf(prob * dwm_dwo);
+    }
+    if (wi.z <= 0 || wo.z <= 0) return 0.f;
+    const V3 wh = normalized(wi + wo);
+    if (m.type == KZ_BSDF_GGX) return ggxVNDF(wi, wh, roughnessToAlpha(m.alpha, m.anisotropy)) / (4.0f * dot(wi, wh));
+    const float D = evalBeckmann(wh, alphaOf(m.alpha));
+    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) return D * wh.z * (1.f / (4.f * dot(wh, wo)));
+    const float ks = 1 - fmaxf(m.albedo[0], fmaxf(m.albedo[1], m.albedo[2]));
+    return ks * D * wh.z * (1.f / (4.f * fabsf(dot(wh, wo)))) + (1 - ks) * wo.z * KZ_INV_PI;
+}
+__device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y, V3 &wo, bool &alive, float &etaScale) {
+    alive = true;
+    if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {
+        const float mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
+        const float alpha = alphaOf(m.alpha) * (1.2f - 0.2f * sqrtf(fabsf(wi.z)));
+        const V3 wm = squareToBeckmann(s2x, s2y, alpha);
+        const float pdf = squareToBeckmannPdf(wm, alpha);
+        if (pdf == 0.f) return mk(0.f);
+        float cosThetaT; const float F = fresnelDielectricT(dot(wi, wm), mEta, cosThetaT);
+        if (!(s1 > F)) {
+            wo = reflectV(wi, wm);
+            if (wi.z * wo.z <= 0) return mk(0.f);
+        } else {
+            if (cosThetaT == 0) return mk(0.f);
+            float e = mEta; if (cosThetaT < 0) e = 1.f / e;
+            wo = wm * (dot(wi, wm) * e + cosThetaT) - wi * e;
+            etaScale = cosThetaT < 0.f ? mEta : mInvEta;
+            if (wi.z * wo.z >= 0) return mk(0.f);
+        }
+        const float D = evalBeckmann(wm, alpha);
+        const float G = smithBeckmannG1(wo, wm, alpha) * smithBeckmannG1(wi, wm, alpha);
+        return mk(fabsf(D * G * dot(wi, wm) / (pdf * wi.z)));
+    }
+    if (wi.z <= 0) { alive = false; return mk(0.f); }
+    if (m.type == KZ_BSDF_GGX) {
+        const A2 alpha = roughnessToAlpha(m.alpha, m.anisotropy);
+        const V3 H = sampleGGXVNDF(wi, alpha, s2x, s2y);
+        wo = reflectV(wi, H);                                                                                 // not normalised (ggx_brdf.h:189)
+        const float pdf = ggxVNDF(wi, H, alpha) / (4.0f * dot(wi, H));
+        const V3 color = evalGGXSmithBRDF(wi, wo, mk(m.albedo[0], m.albedo[1], m.albedo[2]), m.alpha, m.anisotropy);
+        if (wo.z <= 0) return mk(0.f);
+        return color * wo.z / pdf;
+    }
+    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) {
+        const V3 wh = squareToBeckmann(s2x, s2y, alphaOf(m.alpha));
+        wo = normalized(reflectV(wi, wh));
+    } else {
+        const float ks = 1 - fmaxf(m.albedo[0], fmaxf(m.albedo[1], m.albedo[2]));
+        if (s1 < ks) { const V3 wh = squareToBeckmann(s2x, s2y, alphaOf(m.alpha)); wo = normalized((2.f * dot(wh, wi) * wh) - wi); }
+        else wo = squareToCosineHemisphere(s2x, s2y);
+    }
+    if (wo.z <= 0) return mk(0.f);
+    return roughEval(m, wi, wo) / roughPdf(m, wi, wo);
+}
+
 // returns the sample weight; wo is the sampled direction; alive=false when the path contributes nothing further;
 // discrete = bRec.measure == EDiscrete; etaScale = bRec.eta
+// EXT = false compiles only diffuse + kazenstandard (the BASELINE configs): the scene-level switch keeps the shade kernel at
+// ~70 VGPRs instead of ~160 when no mirror / dielectric / ggx / rough* row is present.
+template <bool EXT>
 __device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive, bool &discrete, float &etaScale) {
     wo = mk(0.f, 0.f, 1.f); discrete = false; etaScale = 1.0f;
-    if (m.type == KZ_BSDF_DIELECTRIC) {                                            // bsdf.cpp:119-143 (no back-side test)
+    if (EXT && m.type == KZ_BSDF_DIELECTRIC) {                                            // bsdf.cpp:119-143 (no back-side test)
         alive = true; discrete = true;
         if (s1 < fresnelIOR(wi.z, m.extIOR, m.intIOR)) { wo = mk(-wi.x, -wi.y, wi.z); return mk(1.0f); }
         V3 n = mk(0.0f, 0.0f, 1.0f);
@@ -668,9 +818,10 @@ __device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float
         etaScale = m.intIOR / m.extIOR;
         return mk(1.0f);
     }
+    if (EXT && m.type >= KZ_BSDF_GGX) return roughSample(m, wi, s1, s2x, s2y, wo, alive, etaScale);
     if (wi.z <= 0) { alive = false; return mk(0.f); }                              // bsdf.cpp:60-61, :176-177, :1302-1303
     alive = true;
-    if (m.type == KZ_BSDF_MIRROR) { wo = mk(-wi.x, -wi.y, wi.z); discrete = true; return mk(1.0f); }   // bsdf.cpp:175-191
+    if (EXT && m.type == KZ_BSDF_MIRROR) { wo = mk(-wi.x, -wi.y, wi.z); discrete = true; return mk(1.0f); }   // bsdf.cpp:175-191
     if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:59-75
         wo = squareToCosineHemisphere(s2x, s2y);
         return mk(m.albedo[0], m.albedo[1], m.albedo[2]);
@@ -690,17 +841,21 @@ __device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float
     if (wo.z <= 0 || pdf <= KZ_EPSILON || invalid) return mk(0.f);
     return kissEval(m, wi, wo, accRough) / pdf;
 }
+template <bool EXT>
 __device__ __forceinline__ V3 bsdfEval(const KzBSDF &m, V3 wi, V3 wo, float accRough) {
     if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:27-37 (measure is ESolidAngle at every call site)
         if (wi.z <= 0 || wo.z <= 0) return mk(0.f);
         return mk(m.albedo[0], m.albedo[1], m.albedo[2]) * KZ_INV_PI * wo.z;
     }
-    if (m.type != KZ_BSDF_KAZENSTANDARD) return mk(0.f);                           // discrete BRDFs evaluate to zero
+    if (EXT && m.type >= KZ_BSDF_GGX) return roughEval(m, wi, wo);
+    if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) return mk(0.f);                           // discrete BRDFs evaluate to zero
     return kissEval(m, wi, wo, accRough);
 }
+template <bool EXT>
 __device__ __forceinline__ float bsdfPdf(const KzBSDF &m, V3 wi, V3 wo, float accRough) {
     if (m.type == KZ_BSDF_DIFFUSE) { if (wi.z <= 0 || wo.z <= 0) return 0.f; return KZ_INV_PI * wo.z; }   // bsdf.cpp:40-56
-    if (m.type != KZ_BSDF_KAZENSTANDARD) return 0.f;
+    if (EXT && m.type >= KZ_BSDF_GGX) return roughPdf(m, wi, wo);
+    if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) return 0.f;
     return kissPdf(m, wi, wo, accRough);
 }
 
@@ -759,7 +914,7 @@ __device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy,
 // ============================================================================================
 // a10 PathMisIntegrator::Li (integrator.cpp:195-338) — megakernel form, one lane per path
 // ============================================================================================
-template <bool STATS>
+template <bool STATS, bool EXT>
 __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 ro, V3 rd, float rmint, float rmaxt,
                      uint32_t *stk, Counters &cn) {
     const float eps = P.traceBias;
@@ -825,8 +980,8 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             const bool occluded = shadowOccluded<STATS>(P, T, its.p, lwi, eps, dist - eps, stk, cn);
             if (!occluded) {
                 V3 woLocal = toLocal(its.sh, lwi);
-                V3 f = bsdfEval(bsdf, wiLocal, woLocal, accRough);
-                float bpdf = bsdfPdf(bsdf, wiLocal, woLocal, accRough);
+                V3 f = bsdfEval<EXT>(bsdf, wiLocal, woLocal, accRough);
+                float bpdf = bsdfPdf<EXT>(bsdf, wiLocal, woLocal, accRough);
                 float lightWeight = powerHeuristic(lpdf, bpdf);
                 L = L + throughput * Ls * f * lightWeight;
             }
@@ -836,12 +991,12 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
         float s2x, s2y; smp.next2D(P, T, s2x, s2y);
         float s1 = smp.next1D(P, T);
         V3 woLocal; bool alive, discrete; float etaScale;
-        V3 weight = bsdfSample(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, alive, discrete, etaScale);
+        V3 weight = bsdfSample<EXT>(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, alive, discrete, etaScale);
         throughput = throughput * weight;
         eta *= etaScale;
         // zero weight: the reference keeps looping with throughput 0 (contributes exactly 0); terminate instead
         if (!alive || (weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) break;
-        float bpdf = bsdfPdf(bsdf, wiLocal, woLocal, accRough);
+        float bpdf = bsdfPdf<EXT>(bsdf, wiLocal, woLocal, accRough);
         ro = its.p; rd = toWorld(its.sh, woLocal);                                            // H9: not re-normalised
         if (!closestHit<STATS>(T, P.rootRef, ro, rd, eps, KZ_INF, rh, stk, cn)) {
             if (P.bgPresent && !(isnan(rd.x) || isnan(rd.y) || isnan(rd.z)))                  // scene.cpp:54-79

@@ -22,7 +22,7 @@
 
 
 // a1/a2 renderBlock + renderSample (renderer.cpp:20-69): item = pixLinear * S + sampleOffset
-template <bool STATS>
+template <bool STATS, bool EXT>
 __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDevTables T, const uint32_t *__restrict__ pixList,
                                                                uint32_t nItems, uint32_t S, uint32_t sampleBegin, const uint32_t *__restrict__ itemSample,
                                                                float *__restrict__ outJx, float *__restrict__ outJy, float *__restrict__ outR,
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDev
         float ax, ay; smp.next2D(P, T, ax, ay);                  // aperture sample, always consumed (renderer.cpp:28)
         V3 ro, rd; float mint, maxt;
         cameraRay(P, sx, sy, ax, ay, ro, rd, mint, maxt);
-        V3 L = pathLi<STATS>(P, T, smp, ro, rd, mint, maxt, s_stack + threadIdx.x, cn);
+        V3 L = pathLi<STATS, EXT>(P, T, smp, ro, rd, mint, maxt, s_stack + threadIdx.x, cn);
         outJx[item] = jx; outJy[item] = jy; outR[item] = L.x; outG[item] = L.y; outB[item] = L.z;
         if (STATS) {
             bool valid = L.x >= 0 && L.y >= 0 && L.z >= 0 && isfinite(L.x) && isfinite(L.y) && isfinite(L.z);
@@ -183,11 +183,11 @@ __global__ void kz_bsdf_kernel(KzDevTables T, uint32_t n, const int32_t *__restr
     if (i >= n) return;
     const KzBSDF m = T.bsdfs[bsdf[i]];
     const V3 a = mk(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), b = mk(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
-    V3 e = bsdfEval(m, a, b, acc[i]);
+    V3 e = bsdfEval<true>(m, a, b, acc[i]);
     evalOut[3 * i] = e.x; evalOut[3 * i + 1] = e.y; evalOut[3 * i + 2] = e.z;
-    pdfOut[i] = bsdfPdf(m, a, b, acc[i]);
+    pdfOut[i] = bsdfPdf<true>(m, a, b, acc[i]);
     V3 d; bool alive, discrete; float etaScale;
-    V3 w = bsdfSample(m, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive, discrete, etaScale);
+    V3 w = bsdfSample<true>(m, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive, discrete, etaScale);
     float *o = sampleOut + 7 * i;
     o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = d.x; o[4] = d.y; o[5] = d.z; o[6] = alive ? 1.f : 0.f;
 }
@@ -407,8 +407,10 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     const uint32_t *cur = nullptr, *curCount = nullptr;
     for (int iter = 0; iter < maxDepth; ++iter) {
         uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
-        if (st) hipLaunchKernelGGL(kz_wf_shade<true>, gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount);
-        else hipLaunchKernelGGL(kz_wf_shade<false>, gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount);
+#define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
+        if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
+        else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
+#undef KZ_SHADE
         const bool lastIter = iter == maxDepth - 1;
         const bool needExtend = !lastIter || P.bgPresent;
         static const int mixed = [] { const char *e = std::getenv("KZ_TUNE_MIXED"); return e ? std::atoi(e) : 0; }();   // measured: no gain on C4 (43.16 vs 43.06 ms), kept as an option
@@ -477,12 +479,13 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
         const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
         HIP_TRY(hipEventRecord(ep.a, stream));
         if (pipeline == 2) { if ((rc = wfPass(scene, ds, stream, s, Sp, (uint32_t)items))) return rc; }
-        else if (ds->statsOn)
-            hipLaunchKernelGGL(kz_path_megakernel<true>, grid, dim3(KZ_BLOCK), 0, stream, P, ds->T, ds->pixList, (uint32_t)items, Sp, s, (const uint32_t *)nullptr,
-                               ds->sJx, ds->sJy, ds->sR, ds->sG, ds->sB, ds->stats);
-        else
-            hipLaunchKernelGGL(kz_path_megakernel<false>, grid, dim3(KZ_BLOCK), 0, stream, P, ds->T, ds->pixList, (uint32_t)items, Sp, s, (const uint32_t *)nullptr,
-                               ds->sJx, ds->sJy, ds->sR, ds->sG, ds->sB, ds->stats);
+        else {
+#define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, stream, P, ds->T, ds->pixList, (uint32_t)items, Sp, s, \
+                                           (const uint32_t *)nullptr, ds->sJx, ds->sJy, ds->sR, ds->sG, ds->sB, ds->stats)
+            if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, true); else KZ_MEGA(true, false); }
+            else { if (P.bsdfExt) KZ_MEGA(false, true); else KZ_MEGA(false, false); }
+#undef KZ_MEGA
+        }
         HIP_TRY(hipEventRecord(ep.b, stream));
         HIP_TRY(hipGetLastError());
         const dim3 fgrid((cols + KZ_FILM_TILE - 1) / KZ_FILM_TILE, (rows + KZ_FILM_TILE - 1) / KZ_FILM_TILE);
@@ -583,7 +586,7 @@ int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint
     uint32_t *dP = nullptr, *dI = nullptr; float *dO = nullptr;
     HIP_TRY(hipMalloc((void **)&dP, (size_t)n * 4)); HIP_TRY(hipMalloc((void **)&dI, (size_t)n * 4)); HIP_TRY(hipMalloc((void **)&dO, (size_t)n * 20));
     HIP_TRY(hipMemcpy(dP, pl.data(), (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dI, idx, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kz_path_megakernel<false>, dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, P, ds->T, dP, n, 1u, 0u, dI,
+    hipLaunchKernelGGL((kz_path_megakernel<false, true>), dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, P, ds->T, dP, n, 1u, 0u, dI,
                        dO, dO + n, dO + 2 * (size_t)n, dO + 3 * (size_t)n, dO + 4 * (size_t)n, ds->stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

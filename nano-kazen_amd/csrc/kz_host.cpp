@@ -102,8 +102,8 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     if (!(d->camera.rfilter.radius > 0.f) || d->camera.rfilter.radius > 4.0f) return kz_fail(KZ_ERR_UNSUPPORTED, "filter radius %g (supported: (0, 4])", d->camera.rfilter.radius);
     if ((d->nMeshes && !d->meshes) || (d->nBsdfs && !d->bsdfs) || (d->nLights && !d->lights)) return kz_fail(KZ_ERR_INVALID_ARG, "null table with non-zero count");
     for (uint32_t i = 0; i < d->nBsdfs; ++i)
-        if (d->bsdfs[i].type < KZ_BSDF_DIFFUSE || d->bsdfs[i].type > KZ_BSDF_DIELECTRIC)
-            return kz_fail(KZ_ERR_UNSUPPORTED, "bsdf %u has type %d (supported: \"diffuse\", \"kazenstandard\", \"mirror\", \"dielectric\")", i, d->bsdfs[i].type);
+        if (d->bsdfs[i].type < KZ_BSDF_DIFFUSE || d->bsdfs[i].type > KZ_BSDF_ROUGHDIELECTRIC)
+            return kz_fail(KZ_ERR_UNSUPPORTED, "bsdf %u has type %d (supported: diffuse, kazenstandard, mirror, dielectric, ggx, roughconductor, roughplastic, roughdielectric)", i, d->bsdfs[i].type);
 
     KzScene *sc = new KzScene();
     std::memset(&sc->prm, 0, sizeof sc->prm);
@@ -188,6 +188,8 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
       if (rc != KZ_OK) { delete sc; return kz_fail(rc, "BVH4 collapse failed"); }
       p.rootRef4 = r4; p.stackBound4 = sb; }
     p.stackDepth = (int32_t)std::max<uint32_t>(2u, sc->bvh.maxDepth + 1);
+    p.bsdfExt = 0;
+    for (const KzBSDF &b : sc->bsdfs) if (b.type > KZ_BSDF_KAZENSTANDARD) p.bsdfExt = 1;
     // invisible-light triangles for the exact any-hit shadow test
     p.shadowFast = 1; p.nIlTris = 0; p.anyInvisibleLight = 0;
     for (int a = 0; a < 3; ++a) { p.ilLo[a] = INFINITY; p.ilHi[a] = -INFINITY; }

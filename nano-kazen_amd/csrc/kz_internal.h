@@ -86,6 +86,7 @@ struct KzParams {
     // any-hit form of the shadow test exact (kz_devfn.h shadowOccluded)
     int32_t shadowFast; uint32_t nIlTris; float ilLo[3], ilHi[3];
     int32_t anyInvisibleLight; int32_t stackDepth;
+    int32_t bsdfExt;                     // any BSDF row beyond diffuse / kazenstandard (selects the larger kernel variants)
 };
 
 // Device pointers (all HBM-resident after kz_scene_upload).

@@ -167,8 +167,11 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
 }
 
 // ---- shade(iter): everything between two ray queries of Li ---------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
+#ifndef KZ_SHADE_WAVES
+#define KZ_SHADE_WAVES 3
+#endif
+template <bool STATS, bool EXT>
+__global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
                                                         uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm,
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
@@ -256,8 +259,8 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shade(KzParams P, KzDevTables 
                             }
                             Ls = Ls / P.lightPickPdf;
                             const V3 woL = toLocal(its.sh, lwi);
-                            const V3 f = bsdfEval(bsdf, wiLocal, woL, accRough);
-                            const float bpdfL = bsdfPdf(bsdf, wiLocal, woL, accRough);
+                            const V3 f = bsdfEval<EXT>(bsdf, wiLocal, woL, accRough);
+                            const float bpdfL = bsdfPdf<EXT>(bsdf, wiLocal, woL, accRough);
                             const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
                             // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
                             if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
@@ -271,11 +274,11 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shade(KzParams P, KzDevTables 
                         float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
                         const float s1 = smp.next1D(P, T);
                         V3 woLocal; bool ok, discrete; float etaScale;
-                        const V3 weight = bsdfSample(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale);
+                        const V3 weight = bsdfSample<EXT>(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale);
                         throughput = throughput * weight;
                         const float etaNext = eta * etaScale;
                         if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
-                            const float bpdf = bsdfPdf(bsdf, wiLocal, woLocal, accRough);
+                            const float bpdf = bsdfPdf<EXT>(bsdf, wiLocal, woLocal, accRough);
                             const V3 nd = toWorld(its.sh, woLocal);                           // H9
                             // the ray after the LAST bounce only matters for the background term
                             if (iter + 1 < P.maxDepth || P.bgPresent) {

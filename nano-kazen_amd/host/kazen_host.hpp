@@ -103,10 +103,10 @@ public:
         auto it = t.find(name);
         if (it != t.end()) return it->second(props);
         static const char *offPath[] = {"normals", "ao", "whitted", "path_mats",
-                                        "lambertian", "normalmap", "ggx", "roughconductor", "roughplastic", "roughdielectric", "imagetexture",
+                                        "lambertian", "normalmap", "imagetexture",
                                         "colorramp", "blend", "nonscatter"};
         for (const char *o : offPath)
-            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis; diffuse/kazenstandard/mirror/dielectric; independent/pmj02bn/stratified/correlated; perspective/thinlens)");
+            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis; diffuse/kazenstandard/mirror/dielectric/ggx/roughconductor/roughplastic/roughdielectric; independent/pmj02bn/stratified/correlated; perspective/thinlens)");
         throw Exception("A constructor for class \"" + name + "\" could not be found!");
     }
 private:
@@ -195,6 +195,51 @@ public:
     KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_DIELECTRIC; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
     std::string toString() const override { return "Dielectric[]"; }
     float m_intIOR, m_extIOR;
+};
+
+class GGX : public BSDF {                            // src/kazen/bsdf.cpp:629-689 (albedo: a constanttexture child)
+public:
+    explicit GGX(const PropertyList &p) { m_roughness = p.getFloat("roughness", 0.5f); m_anisotropy = p.getFloat("anisotropy", 0.f); }
+    ~GGX() override { delete m_albedo; }
+    void addChild(Object *o) override {
+        auto *c = dynamic_cast<ConstantTexture *>(o);
+        if (o->getClassType() != ETexture || !c) throw Exception("addChild is not supported other than (constant) albedo maps");
+        m_albedo = c;
+    }
+    void activate() override { if (!m_albedo) throw Exception("ggx needs an albedo texture"); }
+    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_GGX; b.albedo[0] = m_albedo->m_color.r; b.albedo[1] = m_albedo->m_color.g; b.albedo[2] = m_albedo->m_color.b; b.alpha = m_roughness; b.anisotropy = m_anisotropy; return b; }
+    std::string toString() const override { return "GGX[]"; }
+    ConstantTexture *m_albedo = nullptr; float m_roughness, m_anisotropy;
+};
+class RoughConductor : public BSDF {                 // src/kazen/bsdf.cpp:692-811
+public:
+    explicit RoughConductor(const PropertyList &p) {
+        m_alpha = p.getFloat("alpha", 0.1f);
+        const std::string mat = p.getString("material", "Au");
+        static const float T[3][6] = {{0.1431189557f, 0.3749570432f, 1.4424785571f, 3.9831604247f, 2.3857207478f, 1.6032152899f},
+                                      {0.2004376970f, 0.9240334304f, 1.1022119527f, 3.9129485033f, 2.4528477015f, 2.1421879552f},
+                                      {4.3696828663f, 2.9167024892f, 1.6547005413f, 5.2064337956f, 4.2313645277f, 3.7549467933f}};
+        int i = mat == "Au" ? 0 : mat == "Cu" ? 1 : mat == "Cr" ? 2 : -1;
+        if (i < 0) throw Exception("roughconductor: unknown material \"" + mat + "\" (the reference leaves eta/k uninitialised here)");
+        for (int a = 0; a < 3; ++a) { m_eta[a] = T[i][a]; m_k[a] = T[i][3 + a]; }
+    }
+    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHCONDUCTOR; b.alpha = m_alpha; for (int a = 0; a < 3; ++a) { b.condEta[a] = m_eta[a]; b.condK[a] = m_k[a]; } return b; }
+    std::string toString() const override { return "RoughConductor[]"; }
+    float m_alpha, m_eta[3], m_k[3];
+};
+class RoughPlastic : public BSDF {                   // src/kazen/bsdf.cpp:814-943
+public:
+    explicit RoughPlastic(const PropertyList &p) { m_alpha = p.getFloat("alpha", 0.1f); m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); m_kd = p.getColor("kd", Color3f(0.5f)); }
+    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHPLASTIC; b.alpha = m_alpha; b.intIOR = m_intIOR; b.extIOR = m_extIOR; b.albedo[0] = m_kd.r; b.albedo[1] = m_kd.g; b.albedo[2] = m_kd.b; return b; }
+    std::string toString() const override { return "RoughPlastic[]"; }
+    float m_alpha, m_intIOR, m_extIOR; Color3f m_kd;
+};
+class RoughDielectric : public BSDF {                // src/kazen/bsdf.cpp:947-1145
+public:
+    explicit RoughDielectric(const PropertyList &p) { m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); m_roughness = p.getFloat("roughness", 0.1f); }
+    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHDIELECTRIC; b.alpha = m_roughness; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
+    std::string toString() const override { return "RoughDielectric"; }
+    float m_intIOR, m_extIOR, m_roughness;
 };
 
 // ---- light / filter / sampler / integrator / camera -------------------------------------------------------------------
@@ -369,6 +414,10 @@ KAZEN_MI355X_REGISTER(Diffuse, "diffuse");
 KAZEN_MI355X_REGISTER(KazenStandardSurface, "kazenstandard");
 KAZEN_MI355X_REGISTER(Mirror, "mirror");
 KAZEN_MI355X_REGISTER(Dielectric, "dielectric");
+KAZEN_MI355X_REGISTER(GGX, "ggx");
+KAZEN_MI355X_REGISTER(RoughConductor, "roughconductor");
+KAZEN_MI355X_REGISTER(RoughPlastic, "roughplastic");
+KAZEN_MI355X_REGISTER(RoughDielectric, "roughdielectric");
 KAZEN_MI355X_REGISTER(ConstantTexture, "constanttexture");
 KAZEN_MI355X_REGISTER(BackgroundTexture, "background");
 KAZEN_MI355X_REGISTER(PerspectiveCamera, "perspective");

@@ -73,6 +73,27 @@ def dielectric(intIOR=1.5046, extIOR=1.000277):
     return {"type": "dielectric", "intIOR": intIOR, "extIOR": extIOR}
 
 
+CONDUCTORS = {"Au": ((0.1431189557, 0.3749570432, 1.4424785571), (3.9831604247, 2.3857207478, 1.6032152899)),
+              "Cu": ((0.2004376970, 0.9240334304, 1.1022119527), (3.9129485033, 2.4528477015, 2.1421879552)),
+              "Cr": ((4.3696828663, 2.9167024892, 1.6547005413), (5.2064337956, 4.2313645277, 3.7549467933))}      # bsdf.cpp:795-806
+
+
+def ggx(albedo=(0.5, 0.5, 0.5), roughness=0.5, anisotropy=0.0):
+    return {"type": "ggx", "albedo": tuple(albedo), "roughness": roughness, "anisotropy": anisotropy}
+
+
+def roughconductor(alpha=0.1, material="Au"):
+    return {"type": "roughconductor", "alpha": alpha, "material": material}
+
+
+def roughplastic(alpha=0.1, intIOR=1.5046, extIOR=1.000277, kd=(0.5, 0.5, 0.5)):
+    return {"type": "roughplastic", "alpha": alpha, "intIOR": intIOR, "extIOR": extIOR, "kd": tuple(kd)}
+
+
+def roughdielectric(roughness=0.1, intIOR=1.5046, extIOR=1.000277):
+    return {"type": "roughdielectric", "roughness": roughness, "intIOR": intIOR, "extIOR": extIOR}
+
+
 def area(color=(1.0, 1.0, 1.0), intensity=1.0, lightPrimaryVisibility=False):
     return {"type": "area", "color": tuple(color), "intensity": intensity,
             "lightPrimaryVisibility": bool(lightPrimaryVisibility)}
@@ -156,6 +177,21 @@ class SceneDescription:
             elif b["type"] == "dielectric":
                 k.type = abi.KZ_BSDF_DIELECTRIC
                 k.intIOR, k.extIOR = b["intIOR"], b["extIOR"]
+            elif b["type"] == "ggx":
+                k.type = abi.KZ_BSDF_GGX
+                k.albedo[:] = b["albedo"]
+                k.alpha, k.anisotropy = b["roughness"], b["anisotropy"]
+            elif b["type"] == "roughconductor":
+                k.type = abi.KZ_BSDF_ROUGHCONDUCTOR
+                k.alpha = b["alpha"]
+                k.condEta[:], k.condK[:] = CONDUCTORS[b["material"]]
+            elif b["type"] == "roughplastic":
+                k.type = abi.KZ_BSDF_ROUGHPLASTIC
+                k.alpha, k.intIOR, k.extIOR = b["alpha"], b["intIOR"], b["extIOR"]
+                k.albedo[:] = b["kd"]
+            elif b["type"] == "roughdielectric":
+                k.type = abi.KZ_BSDF_ROUGHDIELECTRIC
+                k.alpha, k.intIOR, k.extIOR = b["roughness"], b["intIOR"], b["extIOR"]
             else:
                 k.type = 99      # unsupported plugin: the library must answer KZ_ERR_UNSUPPORTED
         cl = (abi.KzLight * max(1, len(lights)))()
@@ -416,6 +452,27 @@ def glass_scene(width=128, height=128, spp=16, sampler="independent", seed=0, ma
     del s.meshes[6]
     s.add_mesh(*_vfnuv(uv_sphere((0.4, -0.6, 0.35), 0.4, 24, 25)), bsdf=dielectric())
     s.meshes.append(s.meshes.pop(6))          # keep the light last is not required; order only fixes ids
+    return s
+
+
+def materials_scene(width=160, height=96, spp=16, sampler="independent", seed=0, maxDepth=6):
+    """Studio backdrop + one sphere per BSDF plugin (ggx, roughconductor x3, roughplastic, roughdielectric, dielectric, mirror,
+    kazenstandard, diffuse) + two area lights: every BSDF::eval/pdf/sample on the path in one frame."""
+    s = SceneDescription()
+    s.add_mesh(*_vfnuv(quad((-8, 0, -4), (8, 0, -4), (8, 0, 6), (-8, 0, 6), flip=True)), bsdf=diffuse((0.7, 0.7, 0.7)))
+    s.add_mesh(*_vfnuv(quad((-8, 0, -4), (-8, 6, -4), (8, 6, -4), (8, 0, -4), flip=True)), bsdf=diffuse((0.6, 0.65, 0.7)))
+    rows = [ggx((0.9, 0.6, 0.3), 0.3), roughconductor(0.3, "Au"), roughconductor(0.5, "Cu"), roughconductor(0.2, "Cr"), roughplastic(0.3, kd=(0.2, 0.4, 0.7)),
+            roughdielectric(0.4), dielectric(), mirror(), kazenstandard((0.7, 0.2, 0.2), 0.4, clearcoat=1.0), diffuse((0.3, 0.7, 0.3))]
+    for i, r in enumerate(rows):
+        x = -4.5 + (i % 5) * 2.25
+        z = 0.0 if i < 5 else 2.4
+        s.add_mesh(*_vfnuv(uv_sphere((x, 0.8, z), 0.8, 20, 21)), bsdf=r)
+    for (cx, cz, inten) in ((-3.0, 1.5, 14.0), (3.0, 2.5, 10.0)):
+        q = quad((cx - 1, 5.0, cz - 1), (cx - 1, 5.0, cz + 1), (cx + 1, 5.0, cz + 1), (cx + 1, 5.0, cz - 1), flip=True)
+        s.add_mesh(*_vfnuv(q), bsdf=diffuse((0, 0, 0)), light=area((1, 1, 1), inten, False))
+    s.camera.update(width=width, height=height, fov=42.0, nearClip=0.1, farClip=100.0, toWorld=look_at((0, 3.2, 9.5), (0, 0.9, 1.0), (0, 1, 0)))
+    s.sampler = {"type": sampler, "sampleCount": spp, "seed": seed}
+    s.integrator["maxDepth"] = maxDepth
     return s
 
 

@@ -796,25 +796,218 @@ static V3 dielectricSample(const KzBSDF &m, BRec &b, float sample1, bool &ok) {
     return V3(1.0f);
 }
 
+// ---- Beckmann helpers shared by roughconductor / roughplastic / roughdielectric --------------------------------------
+static inline float tanTheta(V3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return std::sqrt(temp) / v.z; }   // frame.h:63-68
+static inline float alphaOf(float x) { return std::max(0.001f, sqr(x)); }                                                         // bsdf.cpp:699-701, :820-823, :958-960
+static float evalBeckmann(V3 m, float alpha) {                                                                                    // bsdf.cpp:721-727
+    float temp = tanTheta(m) / alpha, ct = m.z, ct2 = ct * ct;
+    return (float)(std::exp(-temp * temp) / (M_PI * alpha * alpha * ct2 * ct2));
+}
+static float smithBeckmannG1(V3 v, V3 m, float alpha) {                                                                           // bsdf.cpp:730-750
+    if (dot(v, m) * v.z <= 0.0f) return 0.0f;
+    float tt = std::fabs(tanTheta(v));
+    if (tt == 0.0f) return 1.0f;
+    float a = 1.0f / (alpha * tt);
+    if (a >= 1.6f) return 1.0f;
+    float aSqr = a * a;
+    return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+}
+static V3 squareToBeckmann(float sx, float sy, float alpha) {                                                                     // warp.cpp:120-124
+    float phi = (float)(2 * M_PI * sx);
+    float theta = std::atan(alpha * std::sqrt(std::log(1 / (1 - sy))));
+    return V3(std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta));
+}
+static float squareToBeckmannPdf(V3 m, float alpha) {                                                                             // warp.cpp:126-129
+    float theta = std::acos(m.z / norm(m));
+    float ok = (std::fabs(norm(m) - 1) < Epsilon && m.z >= 0) ? 1.f : 0.f;
+    return (float)(ok * std::exp(-std::pow(std::tan(theta), 2.f) / (alpha * alpha)) / (M_PI * alpha * alpha * std::pow(std::cos(theta), 3.f)));
+}
+static float fresnelDielectricT(float cosThetaI_, float eta, float &cosThetaT_) {                                                 // common.cpp:492-518
+    float scale = (cosThetaI_ > 0.f) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    float cosThetaI = std::fabs(cosThetaI_), cosThetaT = std::sqrt(cosThetaTSqr);
+    float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+// GGX ("ggx", bsdf.cpp:629-689) with a constant albedo; alpha field = "roughness"
+static V3 ggxEval(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z <= 0 || b.wo.z <= 0) return V3(0.f);
+    return evaluateGGXSmithBRDF(b.wi, b.wo, V3(m.albedo[0], m.albedo[1], m.albedo[2]), m.alpha, m.anisotropy) * b.wo.z;
+}
+static float ggxPdf(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z <= 0 || b.wo.z <= 0) return 0.f;
+    V3 H = normalized(b.wi + b.wo);
+    return ggxSmithVNDF(b.wi, H, roughnessToAlpha(m.alpha, m.anisotropy)) / (4.0f * dot(b.wi, H));
+}
+static V3 ggxSample(const KzBSDF &m, BRec &b, float s2x, float s2y, bool &ok) {                                                    // bsdf.cpp:658-669 + ggx_brdf.h:175-203
+    if (b.wi.z <= 0) { ok = false; return V3(0.f); }
+    ok = true;
+    A2 alpha = roughnessToAlpha(m.alpha, m.anisotropy);
+    V3 H = sampleGGXSmithVNDF(b.wi, alpha, s2x, s2y);            // wi.z > 0: no flip
+    b.wo = reflect(b.wi, H);                                     // NOT normalised here (ggx_brdf.h:189)
+    float pdf = ggxSmithVNDF(b.wi, H, alpha) / (4.0f * dot(b.wi, H));
+    V3 color = evaluateGGXSmithBRDF(b.wi, b.wo, V3(m.albedo[0], m.albedo[1], m.albedo[2]), m.alpha, m.anisotropy);
+    if (b.wo.z <= 0) return V3(0.f);
+    return color * b.wo.z / pdf;                                 // measure stays EUnknownMeasure, eta stays 1
+}
+// RoughConductor (bsdf.cpp:692-811)
+static V3 fresnelCond(float c, V3 eta, V3 k) {                                                                                    // bsdf.cpp:709-717
+    V3 tmp_f = eta * eta + k * k;
+    V3 tmp = tmp_f * (c * c);
+    V3 twoEtaC = 2.f * eta * c;
+    V3 a = tmp - twoEtaC + V3(1.f), bq = tmp + twoEtaC + V3(1.f);
+    V3 Rparl2(a.x / bq.x, a.y / bq.y, a.z / bq.z);
+    V3 c2(c * c);
+    V3 e = tmp_f - twoEtaC + c2, f = tmp_f + twoEtaC + c2;
+    V3 Rperp2(e.x / f.x, e.y / f.y, e.z / f.z);
+    return (Rparl2 + Rperp2) / 2.0f;
+}
+static V3 rcondEval(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z <= 0 || b.wo.z <= 0) return V3(0.f);
+    float alpha = alphaOf(m.alpha);
+    V3 wh = normalized(b.wi + b.wo);
+    V3 F = fresnelCond(dot(wh, b.wo), V3(m.condEta[0], m.condEta[1], m.condEta[2]), V3(m.condK[0], m.condK[1], m.condK[2]));
+    float D = evalBeckmann(wh, alpha);
+    float G = smithBeckmannG1(b.wi, wh, alpha) * smithBeckmannG1(b.wo, wh, alpha);
+    return D * F * G / (4.f * b.wi.z);
+}
+static float rcondPdf(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z <= 0 || b.wo.z <= 0) return 0.f;
+    V3 wh = normalized(b.wi + b.wo);
+    float D = evalBeckmann(wh, alphaOf(m.alpha));
+    float Jh = 1.f / (4.f * dot(wh, b.wo));
+    return D * wh.z * Jh;
+}
+static V3 rcondSample(const KzBSDF &m, BRec &b, float s2x, float s2y, bool &ok) {
+    if (b.wi.z <= 0) { ok = false; return V3(0.f); }
+    ok = true;
+    V3 wh = squareToBeckmann(s2x, s2y, alphaOf(m.alpha));
+    b.wo = normalized(reflect(b.wi, wh));
+    if (b.wo.z <= 0) return V3(0.f);
+    return rcondEval(m, b) / rcondPdf(m, b);
+}
+// RoughPlastic (bsdf.cpp:814-943): ks = 1 - max(kd)
+static V3 rplasEval(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z <= 0 || b.wo.z <= 0) return V3(0.f);
+    float alpha = alphaOf(m.alpha);
+    V3 kd(m.albedo[0], m.albedo[1], m.albedo[2]);
+    float ks = 1 - maxCoeff(kd);
+    V3 wh = normalized(b.wi + b.wo);
+    float D = evalBeckmann(wh, alpha);
+    float F = fresnelIOR(dot(wh, b.wo), m.extIOR, m.intIOR);
+    float G = smithBeckmannG1(b.wo, wh, alpha) * smithBeckmannG1(b.wi, wh, alpha);
+    return kd * INV_PI * b.wo.z + V3(ks * (D * F * G) / (4.f * b.wi.z));
+}
+static float rplasPdf(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z <= 0 || b.wo.z <= 0) return 0.f;
+    V3 kd(m.albedo[0], m.albedo[1], m.albedo[2]);
+    float ks = 1 - maxCoeff(kd);
+    V3 wh = normalized(b.wi + b.wo);
+    float D = evalBeckmann(wh, alphaOf(m.alpha));
+    float Jh = 1.f / (4.f * std::fabs(dot(wh, b.wo)));           // H3: float abs
+    return ks * D * wh.z * Jh + (1 - ks) * b.wo.z * INV_PI;
+}
+static V3 rplasSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {
+    if (b.wi.z <= 0) { ok = false; return V3(0.f); }
+    ok = true;
+    float ks = 1 - std::max(m.albedo[0], std::max(m.albedo[1], m.albedo[2]));
+    if (s1 < ks) {
+        V3 wh = squareToBeckmann(s2x, s2y, alphaOf(m.alpha));
+        b.wo = normalized((2.f * dot(wh, b.wi) * wh) - b.wi);
+    } else b.wo = squareToCosineHemisphere(s2x, s2y);
+    if (b.wo.z <= 0) return V3(0.f);
+    return rplasEval(m, b) / rplasPdf(m, b);
+}
+// RoughDielectric (bsdf.cpp:947-1145)
+static inline float signf(float v) { return (v > 0.f) ? 1.f : -1.f; }                                                             // common.h:266-268
+static V3 rdielEval(const KzBSDF &m, const BRec &b) {
+    if (b.wi.z == 0) return V3(0.f);
+    float alpha = alphaOf(m.alpha), mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
+    float cosThetaI = b.wi.z, cosThetaO = b.wo.z;
+    bool reflectI = cosThetaI * cosThetaO > 0.f;
+    float eta = cosThetaI > 0.f ? mEta : mInvEta;
+    V3 wm = reflectI ? normalized(b.wi + b.wo) : normalized(b.wi + b.wo * eta);
+    wm = wm * signf(wm.z);
+    float ct; float F = fresnelDielectricT(dot(b.wi, wm), mEta, ct);
+    float D = evalBeckmann(wm, alpha);
+    float G = smithBeckmannG1(b.wo, wm, alpha) * smithBeckmannG1(b.wi, wm, alpha);
+    if (reflectI) return V3((F * G * D) / (4.f * std::fabs(cosThetaI)));
+    float denom = dot(b.wi, wm) + eta * dot(b.wo, wm);
+    float value = ((1 - F) * D * G * eta * eta * dot(b.wi, wm) * dot(b.wo, wm)) / (cosThetaI * sqr(denom));
+    return V3(std::fabs(value));
+}
+static float rdielPdf(const KzBSDF &m, const BRec &b) {
+    float mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
+    float cosThetaI = b.wi.z, cosThetaO = b.wo.z;
+    bool reflectI = cosThetaI * cosThetaO > 0.f;
+    float eta = cosThetaI > 0.f ? mEta : mInvEta;
+    V3 wm; float dwm_dwo;
+    if (reflectI) { wm = normalized(b.wi + b.wo); dwm_dwo = 1.0f / (4.0f * dot(b.wo, wm)); }
+    else { wm = normalized(b.wi + b.wo * eta); float sd = dot(b.wi, wm) + eta * dot(b.wo, wm); dwm_dwo = (eta * eta * dot(b.wo, wm)) / (sd * sd); }
+    wm = wm * signf(wm.z);
+    float ct; float F = fresnelDielectricT(dot(b.wi, wm), mEta, ct);
+    float D = evalBeckmann(wm, alphaOf(m.alpha));
+    float prob = D * wm.z;
+    prob *= reflectI ? F : (1 - F);
+    return std::fabs(prob * dwm_dwo);
+}
+static V3 rdielSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {
+    ok = true;
+    float mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
+    float alpha = alphaOf(m.alpha) * (1.2f - 0.2f * std::sqrt(std::fabs(b.wi.z)));
+    V3 wm = squareToBeckmann(s2x, s2y, alpha);
+    float pdf = squareToBeckmannPdf(wm, alpha);
+    if (pdf == 0.f) return V3(0.f);
+    float cosThetaT; float F = fresnelDielectricT(dot(b.wi, wm), mEta, cosThetaT);
+    bool sampleReflection = !(s1 > F);
+    if (sampleReflection) {
+        b.wo = reflect(b.wi, wm); b.eta = 1.0f;
+        if (b.wi.z * b.wo.z <= 0) return V3(0.f);
+    } else {
+        if (cosThetaT == 0) return V3(0.f);
+        float e = mEta; if (cosThetaT < 0) e = 1.f / e;                           // RoughDielectric::refract, bsdf.cpp:1127-1132
+        b.wo = wm * (dot(b.wi, wm) * e + cosThetaT) - b.wi * e;
+        b.eta = cosThetaT < 0.f ? mEta : mInvEta;
+        if (b.wi.z * b.wo.z >= 0) return V3(0.f);
+    }
+    float D = evalBeckmann(wm, alpha);
+    float G = smithBeckmannG1(b.wo, wm, alpha) * smithBeckmannG1(b.wi, wm, alpha);
+    return V3(std::fabs(D * G * dot(b.wi, wm) / (pdf * b.wi.z)));
+}
+
 static const KzBSDF &meshBsdf(const Scene &sc, int mesh) {
-    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f, 1.5046f, 1.000277f, {0, 0}};
+    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f, 1.5046f, 1.000277f, 0.1f, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     int b = sc.meshes[mesh].bsdf;
     return b < 0 ? dflt : sc.bsdfs[b];
 }
 static V3 bsdfEval(const KzBSDF &m, const BRec &b) {
     if (m.type == KZ_BSDF_DIFFUSE) return diffuseEval(m, b);
     if (m.type == KZ_BSDF_KAZENSTANDARD) return kissEval(m, b);
+    if (m.type == KZ_BSDF_GGX) return ggxEval(m, b);
+    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) return rcondEval(m, b);
+    if (m.type == KZ_BSDF_ROUGHPLASTIC) return rplasEval(m, b);
+    if (m.type == KZ_BSDF_ROUGHDIELECTRIC) return rdielEval(m, b);
     return V3(0.f);                                                     // discrete BRDFs evaluate to zero (bsdf.cpp:109-112,165-168)
 }
 static float bsdfPdf(const KzBSDF &m, const BRec &b) {
     if (m.type == KZ_BSDF_DIFFUSE) return diffusePdf(m, b);
     if (m.type == KZ_BSDF_KAZENSTANDARD) return kissPdf(m, b);
+    if (m.type == KZ_BSDF_GGX) return ggxPdf(m, b);
+    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) return rcondPdf(m, b);
+    if (m.type == KZ_BSDF_ROUGHPLASTIC) return rplasPdf(m, b);
+    if (m.type == KZ_BSDF_ROUGHDIELECTRIC) return rdielPdf(m, b);
     return 0.f;
 }
 static V3 bsdfSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {
     if (m.type == KZ_BSDF_DIFFUSE) return diffuseSample(m, b, s1, s2x, s2y, ok);
     if (m.type == KZ_BSDF_KAZENSTANDARD) return kissSample(m, b, s1, s2x, s2y, ok);
     if (m.type == KZ_BSDF_MIRROR) return mirrorSample(b, ok);
+    if (m.type == KZ_BSDF_GGX) return ggxSample(m, b, s2x, s2y, ok);
+    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) return rcondSample(m, b, s2x, s2y, ok);
+    if (m.type == KZ_BSDF_ROUGHPLASTIC) return rplasSample(m, b, s1, s2x, s2y, ok);
+    if (m.type == KZ_BSDF_ROUGHDIELECTRIC) return rdielSample(m, b, s1, s2x, s2y, ok);
     return dielectricSample(m, b, s1, ok);
 }
 static float bsdfRegularize(const KzBSDF &m) { return m.type == KZ_BSDF_KAZENSTANDARD ? m.roughness : 0.f; }   // bsdf.cpp:1397-1399, bsdf.h:125
@@ -1286,7 +1479,7 @@ int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) {
     sc->cam = d->camera; sc->smp = d->sampler; sc->integ = d->integrator; sc->bg = d->background;
     sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->nBsdfs);
     sc->lights.assign(d->lights, d->lights + d->nLights);
-    for (auto &b : sc->bsdfs) if (b.type < KZ_BSDF_DIFFUSE || b.type > KZ_BSDF_DIELECTRIC) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "bsdf type"); }
+    for (auto &b : sc->bsdfs) if (b.type < KZ_BSDF_DIFFUSE || b.type > KZ_BSDF_ROUGHDIELECTRIC) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "bsdf type"); }
     sc->meshes.resize(d->nMeshes);
     for (uint32_t m = 0; m < d->nMeshes; ++m) {
         const KzMesh &km = d->meshes[m]; MeshData &md = sc->meshes[m];

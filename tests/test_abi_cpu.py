@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(kz):
 
 def test_struct_sizes_match_the_header(kz):
     a = kz.abi
-    assert C.sizeof(a.KzBSDF) == 80 and C.sizeof(a.KzLight) == 20 and C.sizeof(a.KzTile) == 16
+    assert C.sizeof(a.KzBSDF) == 112 and C.sizeof(a.KzLight) == 20 and C.sizeof(a.KzTile) == 16
     assert C.sizeof(a.KzHit) == 88 and C.sizeof(a.KzStats) == 56 and C.sizeof(a.KzMesh) == 48
 
 
@@ -67,7 +67,7 @@ def test_no_device_is_a_loud_error(kz):
     (lambda s: s.integrator.update(type="whitted"), 2),
     (lambda s: s.camera.update(type="orthographic"), 2),
     (lambda s: s.sampler.update(type="stratified", resolution=0), 1),
-    (lambda s: s.meshes[0].update(bsdf={"type": "roughplastic"}), 2),
+    (lambda s: s.meshes[0].update(bsdf={"type": "normalmap"}), 2),
     (lambda s: s.sampler.update(sampleCount=0), 1),
     (lambda s: s.camera.update(width=0), 1),
     (lambda s: s.meshes[0]["F"].__setitem__((0, 0), 999), 1),

@@ -126,6 +126,40 @@ def test_bsdf_tables_match_goldens(gpu_lib, kz, O, gold):
                 assert np.allclose(sm[k, :3], e / np.float32(p), rtol=3e-5, atol=1e-7), (r, k)
 
 
+def test_extended_bsdf_tables_match_oracle(gpu_lib, kz, O):
+    """BSDF::eval / pdf / sample of every plugin row beyond diffuse/kiss, on both sides of the surface, GPU vs oracle."""
+    S = kz.scenes
+    rows = [S.ggx((0.9, 0.6, 0.3), 0.3, 0.2), S.roughconductor(0.3, "Au"), S.roughconductor(0.05, "Cr"), S.roughplastic(0.3, kd=(0.2, 0.4, 0.7)),
+            S.roughdielectric(0.4), S.roughdielectric(0.1, 1.33, 1.0), S.dielectric(), S.mirror()]
+    s = S.SceneDescription()
+    for r in rows:
+        s.add_mesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 2]], np.uint32), bsdf=r)
+    s.camera.update(width=32, height=32)
+    sc = kz.Scene(s, device=0)
+    rng = np.random.default_rng(9)
+    m = 128
+    wi = rng.normal(size=(m, 3)).astype(np.float32)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    wo = rng.normal(size=(m, 3)).astype(np.float32)
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    wi[:96, 2] = np.abs(wi[:96, 2]) + 0.02            # mostly front side; the last 32 come from below (transmission / back-face)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    s3 = rng.random((m, 3)).astype(np.float32)
+    acc = np.zeros(m, np.float32)
+    for r, row in enumerate(rows):
+        ev, pd, sm = sc.bsdf_query(np.full(m, r, np.int32), wi, wo, acc, s3)
+        for k in range(m):
+            e = O.bsdf(row, "eval", wi[k], wo[k])
+            p = O.bsdf(row, "pdf", wi[k], wo[k])
+            assert np.allclose(ev[k], e, rtol=3e-4, atol=1e-6), (r, k, ev[k], e)
+            assert np.isclose(pd[k], p, rtol=3e-4, atol=1e-6), (r, k, pd[k], p)
+            w, d, ok = O.bsdf(row, "sample", wi[k], None, 0.0, float(s3[k, 0]), (float(s3[k, 1]), float(s3[k, 2])))
+            assert bool(sm[k, 6]) == ok, (r, k)
+            if ok and np.any(w != 0):
+                assert np.allclose(sm[k, 3:6], d, rtol=0, atol=5e-6), (r, k)
+                assert np.allclose(sm[k, :3], w, rtol=5e-3, atol=1e-5), (r, k, sm[k, :3], w)
+
+
 @pytest.mark.parametrize("tag,sampler,seed", [("ind", "independent", 0), ("pmj", "pmj02bn", 1)])
 def test_per_sample_radiance_matches_goldens(gpu_lib, kz, gold, tag, sampler, seed):
     """renderSample for explicit (pixel, sample) pairs against the committed oracle vectors: the pixel sample
@@ -174,6 +208,7 @@ CASES = {
     "correlated": lambda S: S.cornell_box(96, 80, 12, sampler="correlated", seed=3),
     "thinlens": lambda S: _thinlens(S),
     "mirror_glass": lambda S: S.glass_scene(96, 96, 16),                                     # EDiscrete + eta branches
+    "all_bsdfs": lambda S: S.materials_scene(160, 96, 16),                                   # ggx + rough* 
 }
 
 

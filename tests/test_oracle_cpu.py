@@ -313,3 +313,37 @@ def test_discrete_bsdfs(O, kz):
     assert np.allclose(wo3, (-graz[0], -graz[1], graz[2]))
     film = O.OracleScene(S.glass_scene(32, 32, 4)).render(threads=2)
     assert np.isfinite(film).all() and film[..., :3].sum() > 0
+
+
+def test_rough_bsdfs_are_sane(O, kz):
+    """ggx / roughconductor / roughplastic / roughdielectric (bsdf.cpp:629-1145): reciprocity-free sanity — finite, non-negative,
+    sample() == eval/pdf for the reflection models, pdf integrates to <= 1, glass transmits to the other side."""
+    S = kz.scenes
+    rng = np.random.default_rng(5)
+    wi = np.array([0.35, 0.1, 0.93], np.float32)
+    wi /= np.linalg.norm(wi)
+    for row in (S.ggx((0.8, 0.8, 0.8), 0.4), S.roughconductor(0.3, "Cu"), S.roughplastic(0.3)):
+        for _ in range(40):
+            s = rng.random(3)
+            w, wo, ok = O.bsdf(row, "sample", wi, None, 0.0, float(s[0]), (float(s[1]), float(s[2])))
+            assert ok and np.isfinite(w).all() and (w >= 0).all()
+            if np.any(w > 0) and row["type"] != "ggx":
+                e, p = O.bsdf(row, "eval", wi, wo), O.bsdf(row, "pdf", wi, wo)
+                assert np.allclose(w, e / p, rtol=1e-5)
+        n = 3000
+        z = rng.random(n)
+        ph = 2 * np.pi * rng.random(n)
+        r = np.sqrt(1 - z * z)
+        dirs = np.stack([r * np.cos(ph), r * np.sin(ph), z], 1).astype(np.float32)
+        est = np.mean([O.bsdf(row, "pdf", wi, d) for d in dirs]) * 2 * np.pi
+        assert 0.6 < est < 1.15, (row["type"], est)
+    glass = S.roughdielectric(0.3)
+    below = 0
+    for _ in range(200):
+        s = rng.random(3)
+        w, wo, ok = O.bsdf(glass, "sample", wi, None, 0.0, float(s[0]), (float(s[1]), float(s[2])))
+        assert np.isfinite(w).all()
+        below += int(np.any(w > 0) and wo[2] < 0)
+    assert below > 100                                   # mostly transmission at near-normal incidence
+    film = O.OracleScene(S.materials_scene(48, 32, 4)).render(threads=4)
+    assert np.isfinite(film).all() and film[..., :3].sum() > 0
