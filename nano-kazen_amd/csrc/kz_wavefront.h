@@ -230,6 +230,15 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                     if (alive) {
                         const KzBSDF bsdf = T.bsdfs[mrow.bsdf];
                         const V3 wiLocal = toLocal(its.sh, -rd);
+                        // A one-sided BSDF seen from below evaluates to 0 for every light sample (no shadow ray, nothing added) and its
+                        // sample() returns 0 (the path ends): nothing after this point can be observed. Only the two-sided
+                        // transmissive models go on. (The light sample is still counted so the counters match the reference's work.)
+                        const bool twoSided = EXT && (bsdf.type == KZ_BSDF_DIELECTRIC || bsdf.type == KZ_BSDF_ROUGHDIELECTRIC);
+                        if (!(wiLocal.z > 0.f) && !twoSided && !isnan(wiLocal.z)) { if (STATS && P.nLights > 0) cn.lsamples++; alive = false; }
+                    }
+                    if (alive) {
+                        const KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+                        const V3 wiLocal = toLocal(its.sh, -rd);
                         const float pick = smp.next1D(P, T);                                  // drawn even without lights
                         if (P.nLights > 0) {                                                  // integrator.cpp:247-295
                             const uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
