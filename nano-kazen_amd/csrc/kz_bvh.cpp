@@ -69,7 +69,24 @@ static void build(Ctx &cx, uint32_t node, uint32_t b, uint32_t e, uint32_t depth
     bool forceMedian = (int)depth + ceilLog2(n) >= DEPTH_CAP;
     int bestAxis = -1, bestSplit = 0;
     float bestCost = kInf;
-    if (!forceMedian || n <= cx.maxLeaf) {
+    int sweepAxis = -1; uint32_t sweepMid = 0;
+    if ((!forceMedian || n <= cx.maxLeaf) && n <= 64) {
+        // exact SAH sweep for small ranges: every split position along every axis (binning is too coarse down here)
+        std::vector<Ref> tmp(cx.refs.begin() + b, cx.refs.begin() + e), bestOrder;
+        std::vector<float> rArea(n);
+        for (int a = 0; a < 3; ++a) {
+            std::sort(tmp.begin(), tmp.end(), [a](const Ref &x, const Ref &y) { return x.c[a] < y.c[a]; });
+            Box acc; acc.reset();
+            for (uint32_t i = n; i-- > 1;) { acc.grow(tmp[i].b); rArea[i] = acc.area(); }
+            acc.reset();
+            for (uint32_t i = 0; i + 1 < n; ++i) {
+                acc.grow(tmp[i].b);
+                float cost = acc.area() * (float)(i + 1) + rArea[i + 1] * (float)(n - i - 1);
+                if (cost < bestCost) { bestCost = cost; sweepAxis = a; sweepMid = i + 1; bestOrder = tmp; }
+            }
+        }
+        if (sweepAxis >= 0) { std::copy(bestOrder.begin(), bestOrder.end(), cx.refs.begin() + b); bestAxis = sweepAxis; }
+    } else if (!forceMedian || n <= cx.maxLeaf) {
         for (int a = 0; a < 3; ++a) {
             float ext = cb.hi[a] - cb.lo[a];
             if (!(ext > 0.f)) continue;
@@ -99,7 +116,8 @@ static void build(Ctx &cx, uint32_t node, uint32_t b, uint32_t e, uint32_t depth
         const float A = t.b.area();
         if (bestAxis < 0 || !(A > 0.f) || (float)n * A <= cx.nodeCost * A + bestCost) { makeLeaf(); return; }
     }
-    if (!forceMedian && bestAxis >= 0) {
+    if (!forceMedian && sweepAxis >= 0) mid = b + sweepMid;
+    else if (!forceMedian && bestAxis >= 0) {
         int a = bestAxis; float lo = cb.lo[a], scale = NBINS / (cb.hi[a] - cb.lo[a]);
         auto it = std::partition(cx.refs.begin() + b, cx.refs.begin() + e, [&](const Ref &r) {
             return std::min(NBINS - 1, (int)((r.c[a] - lo) * scale)) <= bestSplit;
