@@ -367,7 +367,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     const size_t stackBytes = (size_t)P.stackDepth * KZ_BLOCK * sizeof(uint32_t);
     const dim3 blk(KZ_BLOCK);
     auto envInt = [](const char *n, int dflt) { const char *e = std::getenv(n); return e ? std::atoi(e) : dflt; };
-    KzTune tune = {envInt("KZ_TUNE_REFILL", 40), envInt("KZ_TUNE_POSTPONE", 20), envInt("KZ_TUNE_BATCH", 128), envInt("KZ_TUNE_TRAV_BLOCKS", 8), envInt("KZ_TUNE_SHADE_BLOCKS", 6),
+    KzTune tune = {envInt("KZ_TUNE_REFILL", 40), envInt("KZ_TUNE_POSTPONE", 28), envInt("KZ_TUNE_BATCH", 128), envInt("KZ_TUNE_TRAV_BLOCKS", 8), envInt("KZ_TUNE_SHADE_BLOCKS", 6),
                    envInt("KZ_TUNE_LDS_STACK", 16), envInt("KZ_TUNE_WIDE", 1), nullptr, 0};
     const dim3 gTrav((unsigned)(ds->numCU * tune.travBlocksPerCU)), gShade((unsigned)(ds->numCU * tune.shadeBlocksPerCU));
     // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
