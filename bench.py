@@ -105,7 +105,8 @@ def main():
         step(args.warmup + k)
     barrier()
     elapsed = time.perf_counter() - t_start
-    kernel_ms_last = scene.last_kernel_ms()      # HIP events on the launch stream, around the path kernel (last step)
+    kernel_ms_last = scene.last_kernel_ms()      # HIP events on the launch stream, around the path kernels of the last step
+    stage_ms_last = scene.last_stage_ms()
     # film merge: once per render, outside the per-step loop but reported (not a data-path collective)
     t_m = time.perf_counter()
     film = torch.from_numpy(scene.film()).to(cdev)
@@ -160,7 +161,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel": "wavefront pass = kz_wf_generate + maxDepth x (kz_wf_trace<0> closest-hit + kz_wf_shade + "
                               "kz_wf_trace<2> shadow); hipEvent span on the launch stream",
-                    "kernel_ms": round(kernel_ms_last, 3),
+                    "kernel_ms": round(kernel_ms_last, 3), "stages_ms": stage_ms_last,
                     "bytes_per_sample": round(bps, 1), "bytes_per_sample_source": "cpu oracle counters" if cpu else "gpu megakernel counters",
                     "bytes_per_sample_gpu_reference_shaped": round(bps_gpu_ref, 1), "bytes_per_sample_executed": round(bps_exec, 1),
                     "samples_per_launch": launch_samples,

@@ -274,6 +274,9 @@ int kz_sync(KzScene *scene);
 /* Average device time of the dominant kernel(s) of the last kz_render, in ms,
  * from hipEvents recorded on the launch stream (0 if none). */
 int kz_last_kernel_ms(KzScene *scene, float *ms);
+/* Device time per stage of the last pass (wavefront pipeline): out5 = generate, closest-hit traversal, shade, shadow
+ * traversal, film gather — the per-kernel sums a rocprofv3 --kernel-trace of the same run shows. */
+int kz_last_stage_ms(KzScene *scene, float *out5);
 
 const char *kz_last_error(void);
 int kz_abi_version(void);

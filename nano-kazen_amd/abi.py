@@ -109,7 +109,7 @@ class KzBvhInfo(C.Structure):
 EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
            "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
-           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count"]
+           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
@@ -148,6 +148,7 @@ def load_library():
     lib.kz_get_stats.argtypes = [C.c_void_p, C.POINTER(KzStats), C.c_int]
     lib.kz_sync.argtypes = [C.c_void_p]
     lib.kz_last_kernel_ms.argtypes = [C.c_void_p, f32p]
+    lib.kz_last_stage_ms.argtypes = [C.c_void_p, f32p]
     lib.kz_render_samples.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), u32p, f32p]
     lib.kz_bsdf_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, f32p, f32p, f32p, f32p, f32p]
     _lib = lib

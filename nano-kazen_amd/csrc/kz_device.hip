@@ -207,6 +207,7 @@ struct KzDeviceState {
     std::vector<KzTile> curTiles; bool tilesValid = false;
     unsigned long long *stats = nullptr; bool statsOn = false;
     hipStream_t lastStream = nullptr;
+    std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;   // boundaries of the stages of the last pass
     KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0; int numCU = 256;
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
     std::vector<EventPair> events; size_t eventsUsed = 0;
@@ -238,6 +239,7 @@ void kz_device_release(KzScene *scene) {
                     (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->ovf})
         if (p) (void)hipFree(p);
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : ds->stageEv) (void)hipEventDestroy(e);
     delete ds;
     scene->dev = nullptr;
 }
@@ -342,6 +344,14 @@ static size_t passItemBudget() {
     return (size_t)1 << 25;      // 33.5 M (pixel,sample) items per pass: 640 MB of sample records
 }
 
+
+static int stageMark(KzDeviceState *ds, hipStream_t stream, int kind) {
+    if (ds->stageUsed == ds->stageEv.size()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ds->stageEv.push_back(e); ds->stageKind.push_back(0); }
+    ds->stageKind[ds->stageUsed] = kind;
+    HIP_TRY(hipEventRecord(ds->stageEv[ds->stageUsed++], stream));
+    return KZ_OK;
+}
+
 // ---- wavefront pass: allocate the SoA path state for `need` slots, then queue the stages of one pass on `stream` ----
 static int wfEnsure(KzScene *scene, KzDeviceState *ds, size_t need, hipStream_t stream) {
     if (need <= ds->wfCap && !ds->wfAllocs.empty()) return KZ_OK;
@@ -386,8 +396,11 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
         tune.ovf = ds->ovf; tune.ovfStride = (uint32_t)stride;
     }
     const int maxDepth = P.maxDepth;
+    ds->stageUsed = 0;
     HIP_TRY(hipMemsetAsync(W.counts, 0, 4 * 520 * sizeof(uint32_t), stream));
+    { int rc_ = stageMark(ds, stream, -1); if (rc_) return rc_; }
     hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, ds->pixList, items, Sp, sBegin);
+    { int rc_ = stageMark(ds, stream, 0); if (rc_) return rc_; }
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
     static const int traceKernel = [] { const char *e = std::getenv("KZ_TRACE_KERNEL"); return e ? std::atoi(e) : 1; }();
 #define KZ_TRACE2(MODE, q, cptr, cimm, headp, qb, cb) do { \
@@ -404,6 +417,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
         hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);
         KZ_EXTEND(true, (const uint32_t *)W.queue[2], (const uint32_t *)(W.counts + 0), 0u, W.counts + 3);
     }
+    { int rc_ = stageMark(ds, stream, 1); if (rc_) return rc_; }
     const uint32_t *cur = nullptr, *curCount = nullptr;
     for (int iter = 0; iter < maxDepth; ++iter) {
         uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
@@ -411,6 +425,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
         if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
         else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
 #undef KZ_SHADE
+        { int rc_ = stageMark(ds, stream, 2); if (rc_) return rc_; }
         const bool lastIter = iter == maxDepth - 1;
         const bool needExtend = !lastIter || P.bgPresent;
         static const int mixed = [] { const char *e = std::getenv("KZ_TUNE_MIXED"); return e ? std::atoi(e) : 0; }();   // measured: no gain on C4 (43.16 vs 43.06 ms), kept as an option
@@ -418,6 +433,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
             // one launch for the shadow rays of this bounce and the closest-hit rays of the next
             KZ_TRACE2(3, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, (const uint32_t *)shQ, (const uint32_t *)shCount);
             cur = nextQ; curCount = nextCount;
+            { int rc_ = stageMark(ds, stream, 1); if (rc_) return rc_; }
             continue;
         }
         if (P.nLights > 0) {
@@ -425,8 +441,9 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
             else if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
             else hipLaunchKernelGGL(kz_wf_shadow<false>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
         }
+        { int rc_ = stageMark(ds, stream, 3); if (rc_) return rc_; }
         const bool last = iter == maxDepth - 1;
-        if (!last || P.bgPresent) KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2);
+        if (!last || P.bgPresent) { KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2); int rc_ = stageMark(ds, stream, 1); if (rc_) return rc_; }
         cur = nextQ; curCount = nextCount;
     }
 #undef KZ_EXTEND
@@ -494,6 +511,23 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
         hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, stream, P, ds->T.filter, ds->pixIndex, Sp, ds->sJx, ds->sJy, ds->sR, ds->sG,
                            ds->sB, ds->film);
         HIP_TRY(hipGetLastError());
+        if (pipeline == 2) { int rc_ = stageMark(ds, stream, 4); if (rc_) return rc_; }
+    }
+    return KZ_OK;
+}
+
+// Device time of the stages of the LAST pass of the last kz_render (wavefront pipeline), from hipEvents on the launch stream:
+// out[0] generate, [1] closest-hit traversal (all kz_wf_trace<0>/<1> launches + primary fix), [2] shade, [3] shadow traversal, [4] film.
+int kz_last_stage_ms(KzScene *scene, float *out5) {
+    KzDeviceState *ds; int rc;
+    if ((rc = requireDevice(scene, &ds))) return rc;
+    if (!out5) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
+    for (int i = 0; i < 5; ++i) out5[i] = 0.f;
+    HIP_TRY(hipStreamSynchronize(ds->lastStream));
+    for (size_t i = 1; i < ds->stageUsed; ++i) {
+        float t = 0; HIP_TRY(hipEventElapsedTime(&t, ds->stageEv[i - 1], ds->stageEv[i]));
+        const int k = ds->stageKind[i];
+        if (k >= 0 && k < 5) out5[k] += t;
     }
     return KZ_OK;
 }

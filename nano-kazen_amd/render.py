@@ -116,6 +116,11 @@ class Scene:
         abi.check(self.lib, self.lib.kz_get_stats(self.h, C.byref(s), 1 if reset else 0))
         return s.as_dict()
 
+    def last_stage_ms(self):
+        out = np.zeros(5, np.float32)
+        abi.check(self.lib, self.lib.kz_last_stage_ms(self.h, out.ctypes.data_as(abi.f32p)))
+        return dict(zip(("generate", "trace_closest", "shade", "trace_shadow", "film"), [round(float(x), 3) for x in out]))
+
     def last_kernel_ms(self):
         ms = C.c_float()
         abi.check(self.lib, self.lib.kz_last_kernel_ms(self.h, C.byref(ms)))

@@ -409,7 +409,7 @@ def grid_sheet(fn, nu, nv):
     P = np.array([[fn(u, v) for u in us] for v in vs], np.float64)       # (nv+1, nu+1, 3)
     du = np.gradient(P, axis=1)
     dv = np.gradient(P, axis=0)
-    n = np.cross(dv, du)
+    n = np.cross(du, dv)
     n /= np.linalg.norm(n, axis=2, keepdims=True)
     UV = np.array([[(u, v) for u in us] for v in vs], np.float32)
     F = []
