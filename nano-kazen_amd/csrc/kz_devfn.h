@@ -806,8 +806,11 @@ __device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y
 // EXT = false compiles only diffuse + kazenstandard (the BASELINE configs): the scene-level switch keeps the shade kernel at
 // ~70 VGPRs instead of ~160 when no mirror / dielectric / ggx / rough* row is present.
 template <bool EXT>
-__device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive, bool &discrete, float &etaScale) {
-    wo = mk(0.f, 0.f, 1.f); discrete = false; etaScale = 1.0f;
+// pdfOut: BSDF::pdf at the sampled direction when the model computes it on the way (diffuse, kiss) — the integrator's own
+// pdf(bRec) call right after sample() (integrator.cpp:314) is the same function of the same arguments, so it is reused, not
+// recomputed; pdfOut < 0 means "not provided".
+__device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive, bool &discrete, float &etaScale, float &pdfOut) {
+    wo = mk(0.f, 0.f, 1.f); discrete = false; etaScale = 1.0f; pdfOut = -1.f;
     if (EXT && m.type == KZ_BSDF_DIELECTRIC) {                                            // bsdf.cpp:119-143 (no back-side test)
         alive = true; discrete = true;
         if (s1 < fresnelIOR(wi.z, m.extIOR, m.intIOR)) { wo = mk(-wi.x, -wi.y, wi.z); return mk(1.0f); }
@@ -818,12 +821,13 @@ __device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float
         etaScale = m.intIOR / m.extIOR;
         return mk(1.0f);
     }
-    if (EXT && m.type >= KZ_BSDF_GGX) return roughSample(m, wi, s1, s2x, s2y, wo, alive, etaScale);
+    if (EXT && m.type >= KZ_BSDF_GGX) return roughSample(m, wi, s1, s2x, s2y, wo, alive, etaScale);      // pdfOut stays -1: the caller evaluates pdf()
     if (wi.z <= 0) { alive = false; return mk(0.f); }                              // bsdf.cpp:60-61, :176-177, :1302-1303
     alive = true;
     if (EXT && m.type == KZ_BSDF_MIRROR) { wo = mk(-wi.x, -wi.y, wi.z); discrete = true; return mk(1.0f); }   // bsdf.cpp:175-191
     if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:59-75
         wo = squareToCosineHemisphere(s2x, s2y);
+        pdfOut = wo.z <= 0 ? 0.f : KZ_INV_PI * wo.z;                              // Diffuse::pdf (bsdf.cpp:40-56), wi.z > 0 here
         return mk(m.albedo[0], m.albedo[1], m.albedo[2]);
     }
     float diffuse = (1.f - m.metallic) * 0.5f;                                     // bsdf.cpp:1301-1371
@@ -839,6 +843,7 @@ __device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float
     bool invalid = isnan(wo.x) || isnan(wo.y) || isnan(wo.z);
     float pdf = kissPdf(m, wi, wo, accRough);
     if (wo.z <= 0 || pdf <= KZ_EPSILON || invalid) return mk(0.f);
+    pdfOut = pdf;
     return kissEval(m, wi, wo, accRough) / pdf;
 }
 template <bool EXT>
@@ -990,8 +995,8 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
         // ---- BSDF sampling (integrator.cpp:304-309): next2D BEFORE next1D (H1)
         float s2x, s2y; smp.next2D(P, T, s2x, s2y);
         float s1 = smp.next1D(P, T);
-        V3 woLocal; bool alive, discrete; float etaScale;
-        V3 weight = bsdfSample<EXT>(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, alive, discrete, etaScale);
+        V3 woLocal; bool alive, discrete; float etaScale, pdfUnused;
+        V3 weight = bsdfSample<EXT>(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, alive, discrete, etaScale, pdfUnused);
         throughput = throughput * weight;
         eta *= etaScale;
         // zero weight: the reference keeps looping with throughput 0 (contributes exactly 0); terminate instead

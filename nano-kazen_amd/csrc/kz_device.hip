@@ -186,8 +186,8 @@ __global__ void kz_bsdf_kernel(KzDevTables T, uint32_t n, const int32_t *__restr
     V3 e = bsdfEval<true>(m, a, b, acc[i]);
     evalOut[3 * i] = e.x; evalOut[3 * i + 1] = e.y; evalOut[3 * i + 2] = e.z;
     pdfOut[i] = bsdfPdf<true>(m, a, b, acc[i]);
-    V3 d; bool alive, discrete; float etaScale;
-    V3 w = bsdfSample<true>(m, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive, discrete, etaScale);
+    V3 d; bool alive, discrete; float etaScale, pdfS;
+    V3 w = bsdfSample<true>(m, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive, discrete, etaScale, pdfS);
     float *o = sampleOut + 7 * i;
     o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = d.x; o[4] = d.y; o[5] = d.z; o[6] = alive ? 1.f : 0.f;
 }

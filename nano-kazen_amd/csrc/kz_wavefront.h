@@ -282,12 +282,12 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                         if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
                         float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
                         const float s1 = smp.next1D(P, T);
-                        V3 woLocal; bool ok, discrete; float etaScale;
-                        const V3 weight = bsdfSample<EXT>(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale);
+                        V3 woLocal; bool ok, discrete; float etaScale, pdfS;
+                        const V3 weight = bsdfSample<EXT>(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale, pdfS);
                         throughput = throughput * weight;
                         const float etaNext = eta * etaScale;
                         if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
-                            const float bpdf = bsdfPdf<EXT>(bsdf, wiLocal, woLocal, accRough);
+                            const float bpdf = pdfS >= 0.f ? pdfS : bsdfPdf<EXT>(bsdf, wiLocal, woLocal, accRough);
                             const V3 nd = toWorld(its.sh, woLocal);                           // H9
                             // the ray after the LAST bounce only matters for the background term
                             if (iter + 1 < P.maxDepth || P.bgPresent) {
