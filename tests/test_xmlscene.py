@@ -79,3 +79,17 @@ def test_reference_scene_files_match_their_published_pngs(kz, O, name):
     ref = np.asarray(Image.open("/root/reference/doc/2022_q1/img/param/%s.png" % name).convert("RGB").resize((16, 9), Image.BOX), np.float32) / 255
     mine = srgb.reshape(9, 10, 16, 10, 3).mean(axis=(1, 3))
     assert np.abs(mine - ref).max() < 0.07 and abs(mine.mean() - ref.mean()) < 0.025
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout is only present in the build container")
+def test_every_reference_scene_file_loads(kz):
+    """All checked-in scene XMLs of the reference (scene/2022_q1/**) stay inside the hot path's plugin set: they load through
+    xmlscene.load_xml unchanged and pass kz_scene_create's validation on the host (no GPU needed)."""
+    import glob
+    files = sorted(glob.glob("/root/reference/scene/2022_q1/**/*.xml", recursive=True))
+    assert len(files) >= 23
+    for f in files:
+        d = kz.xmlscene.load_xml(f, {"camera": {"width": 32, "height": 18}, "sampler": {"sampleCount": 1}})
+        assert d.n_tris() > 0 and any(m["light"] for m in d.meshes), f
+    sc = kz.Scene(d, device=None)                                                   # host-side build of the last one
+    assert sc.bvh_info()["nTris"] == d.n_tris()
