@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 1
+#define KZ_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -49,7 +49,15 @@ enum { KZ_BSDF_DIFFUSE = 0        /* "diffuse"       src/kazen/bsdf.cpp:20-92   
        KZ_BSDF_GGX = 4            /* "ggx"           src/kazen/bsdf.cpp:629-689 (constanttexture albedo) */,
        KZ_BSDF_ROUGHCONDUCTOR = 5 /* "roughconductor" src/kazen/bsdf.cpp:692-811  */,
        KZ_BSDF_ROUGHPLASTIC = 6   /* "roughplastic"  src/kazen/bsdf.cpp:814-943   */,
-       KZ_BSDF_ROUGHDIELECTRIC = 7/* "roughdielectric" src/kazen/bsdf.cpp:947-1145 */ };
+       KZ_BSDF_ROUGHDIELECTRIC = 7/* "roughdielectric" src/kazen/bsdf.cpp:947-1145 */,
+       KZ_BSDF_NORMALMAP = 8      /* "normalmap"     src/kazen/bsdf.cpp:281-417 (wraps row `nested`, texture `normalTex`) */ };
+enum { KZ_TEX_CONSTANT = 0        /* "constanttexture" src/kazen/texture.cpp:10-32   */,
+       KZ_TEX_IMAGE = 1           /* "imagetexture"    src/kazen/texture.cpp:36-98   */,
+       KZ_TEX_COLORRAMP = 2       /* "colorramp"       src/kazen/texture.cpp:149-195 */,
+       KZ_TEX_BLEND = 3           /* "blend"           src/kazen/texture.cpp:199-270 */ };
+enum { KZ_BLEND_MIX = 0, KZ_BLEND_MULTIPLY = 1, KZ_BLEND_NONE = 2 /* any other "blendmode" string: evaluates to 0, texture.cpp:236 */ };
+enum { KZ_PIXEL_U8 = 0            /* value/255, what OpenImageIO hands out for 8-bit files */, KZ_PIXEL_F32 = 1 };
+#define KZ_TEX_MAX_DEPTH 8               /* operand-stack depth of a flattened texture tree */
 enum { KZ_SAMPLER_INDEPENDENT = 0 /* "independent"   src/kazen/sampler.cpp:18-71   */,
        KZ_SAMPLER_PMJ02BN = 1     /* "pmj02bn"       src/kazen/sampler.cpp:273-390 */,
        KZ_SAMPLER_STRATIFIED = 2  /* "stratified"    src/kazen/sampler.cpp:81-156  */,
@@ -70,9 +78,36 @@ enum { KZ_FILTER_GAUSSIAN = 0     /* "gaussian"      src/kazen/rfilter.cpp:10-31
 
 /* ---- scene description -------------------------------------------------- */
 
-/* BSDF row. Replaces BSDF subclasses Diffuse / KazenStandardSurface with their
- * constant-texture parameters folded (texture.cpp "constanttexture" only).
- * Defaults are the reference's PropertyList defaults (bsdf.cpp:23, :1160-1167). */
+/* A decoded raster (what OpenImageIO's ImageInput would deliver): row 0 = top scan line, `channels` interleaved.
+ * Files with fewer than 3 channels fill the missing ones with 0 (TextureOpt::fill), more than 3 are truncated. */
+typedef struct KzImage {
+    const void *pixels;         /* height*width*channels values of `format`            */
+    int32_t width, height, channels;
+    int32_t format;             /* KZ_PIXEL_*                                          */
+} KzImage;
+
+/* Texture<Color3f> node (texture.h; texture.cpp). Children are indices into KzSceneDesc.textures, -1 = not attached:
+ *   COLORRAMP: child[0] = nested (absent: evaluates to 0, texture.cpp:170)
+ *   BLEND:     child[0] = "mask" (absent: 0.5), child[1] = "input1" (absent: 0), child[2] = "input2" (absent: 1)
+ * IMAGE: texture.cpp:46-64 calls OpenImageIO's TextureSystem::texture(s = u*scale, t = (1-v)*scale, zero derivatives,
+ * periodic wrap). OpenImageIO is not part of the reference checkout; this library defines the lookup as BILINEAR over the
+ * full-resolution level, texel centres at (i+0.5)/width, then Color3f::toLinearRGB when srgb != 0. */
+typedef struct KzTexture {
+    int32_t type;               /* KZ_TEX_*                                            */
+    float color[3];             /* CONSTANT: "color" (default 0.5)                     */
+    int32_t image;              /* IMAGE: index into KzSceneDesc.images                */
+    float scale;                /* IMAGE: "scale" (default 1)                          */
+    int32_t srgb;               /* IMAGE: "colorspace" == "srgb" (the default)         */
+    float rampMin, rampMax;     /* COLORRAMP: "min" (0), "max" (1)                     */
+    int32_t blendMode;          /* BLEND: KZ_BLEND_* ("blendmode", default "mix")      */
+    int32_t child[3];
+    int32_t pad_[3];
+} KzTexture;
+
+/* BSDF row. Replaces the BSDF subclasses; parameters that the reference reads through a Texture<Color3f> child
+ * (diffuse/lambertian/ggx "albedo", kiss "baseColor" / "roughness" / "metallic") are either folded constants
+ * (texture id 0) or a 1-based index into KzSceneDesc.textures (id k > 0 -> textures[k-1]); zero-initialised rows
+ * therefore mean "constants only". Defaults are the reference's PropertyList defaults (bsdf.cpp:23, :1160-1167). */
 typedef struct KzBSDF {
     int32_t type;               /* KZ_BSDF_*                                          */
     float albedo[3];            /* diffuse: "albedo"       (default 0.5)              */
@@ -92,8 +127,13 @@ typedef struct KzBSDF {
                                    the raw property: the library applies max(0.001, x^2) where the constructor does */
     float condEta[3];           /* roughconductor: eta of "material" (Au default / Cu / Cr, bsdf.cpp:795-806) */
     float condK[3];             /* roughconductor: k                                    */
-    float pad_[3];
-} KzBSDF;
+    int32_t albedoTex;          /* diffuse ("lambertian", bsdf.cpp:202-276) / ggx albedo, kiss baseColor: texture id or 0   */
+    int32_t roughnessTex;       /* kiss roughness (.r()): texture id or 0              */
+    int32_t metallicTex;        /* kiss metallic  (.r()): texture id or 0              */
+    int32_t normalTex;          /* normalmap: texture id (required)                    */
+    int32_t nested;             /* normalmap: index of the wrapped BSDF row (not itself a normalmap) */
+    int32_t pad_[2];
+} KzBSDF;                       /* 128 bytes */
 /* albedo doubles as: "kd" of roughplastic (default 0.5), the constanttexture albedo of ggx. */
 
 /* "area" light (src/kazen/light.cpp:7-66). radiance = intensity * color. */
@@ -177,6 +217,8 @@ typedef struct KzSceneDesc {
     KzSampler sampler;
     KzIntegrator integrator;
     KzBackground background;
+    const KzTexture *textures; uint32_t nTextures;
+    const KzImage *images;     uint32_t nImages;
 } KzSceneDesc;
 
 /* ---- rendering ---------------------------------------------------------- */
@@ -259,10 +301,13 @@ int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d,
  * the block.put; pxy = n x (x,y), out = n x (pixelSample.x, pixelSample.y, r, g, b).
  * kz_bsdf_query: BSDF::eval / pdf / sample (bsdf.h:80-108) of row bsdf[i] for local directions wi/wo (n x 3), with
  * its.accumulatedRoughness accRough[i] and the (sample1, sample2.x, sample2.y) triple s3; evalOut n x 3,
- * pdfOut n, sampleOut n x 7 = (weight rgb, sampled wo xyz, alive). */
+ * pdfOut n, sampleOut n x 7 = (weight rgb, sampled wo xyz, alive). uv (n x 2, may be NULL = 0) feeds the texture-backed
+ * parameters; the intersection record is the identity frame with dpdu = +x (what a normalmap row perturbs). */
 int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint32_t *idx, float *out);
 int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *wi, const float *wo, const float *accRough,
-                  const float *s3, float *evalOut, float *pdfOut, float *sampleOut);
+                  const float *s3, const float *uv, float *evalOut, float *pdfOut, float *sampleOut);
+/* Texture<Color3f>::eval(uv) (texture.h) of textures[tex[i]] at uv (n x 2); out n x 3. */
+int kz_texture_query(KzScene *scene, uint32_t n, const int32_t *tex, const float *uv, float *out);
 
 /* Statistics: enable=1 switches to the counting kernel variant (slower). */
 int kz_set_stats(KzScene *scene, int enable);

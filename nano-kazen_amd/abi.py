@@ -7,11 +7,15 @@ is missing: there is no CPU fallback in the product path.
 import ctypes as C
 import os
 
-KZ_ABI_VERSION = 1
+KZ_ABI_VERSION = 2
 
 KZ_OK, KZ_ERR_INVALID_ARG, KZ_ERR_UNSUPPORTED, KZ_ERR_NO_DEVICE, KZ_ERR_HIP, KZ_ERR_STATE, KZ_ERR_OOM = range(7)
 KZ_BSDF_DIFFUSE, KZ_BSDF_KAZENSTANDARD, KZ_BSDF_MIRROR, KZ_BSDF_DIELECTRIC = 0, 1, 2, 3
-KZ_BSDF_GGX, KZ_BSDF_ROUGHCONDUCTOR, KZ_BSDF_ROUGHPLASTIC, KZ_BSDF_ROUGHDIELECTRIC = 4, 5, 6, 7
+KZ_BSDF_GGX, KZ_BSDF_ROUGHCONDUCTOR, KZ_BSDF_ROUGHPLASTIC, KZ_BSDF_ROUGHDIELECTRIC, KZ_BSDF_NORMALMAP = 4, 5, 6, 7, 8
+KZ_TEX_CONSTANT, KZ_TEX_IMAGE, KZ_TEX_COLORRAMP, KZ_TEX_BLEND = 0, 1, 2, 3
+KZ_BLEND_MIX, KZ_BLEND_MULTIPLY, KZ_BLEND_NONE = 0, 1, 2
+KZ_PIXEL_U8, KZ_PIXEL_F32 = 0, 1
+KZ_TEX_MAX_DEPTH = 8
 KZ_SAMPLER_INDEPENDENT, KZ_SAMPLER_PMJ02BN, KZ_SAMPLER_STRATIFIED, KZ_SAMPLER_CORRELATED = 0, 1, 2, 3
 KZ_CAMERA_PERSPECTIVE, KZ_CAMERA_THINLENS = 0, 1
 KZ_INTEGRATOR_PATH_MIS = 0
@@ -31,7 +35,17 @@ class KzBSDF(C.Structure):
                 ("specular", C.c_float), ("specularTint", C.c_float), ("clearcoat", C.c_float),
                 ("clearcoatRoughness", C.c_float), ("sheen", C.c_float), ("sheenTint", C.c_float),
                 ("intIOR", C.c_float), ("extIOR", C.c_float), ("alpha", C.c_float), ("condEta", C.c_float * 3),
-                ("condK", C.c_float * 3), ("pad_", C.c_float * 3)]
+                ("condK", C.c_float * 3), ("albedoTex", C.c_int32), ("roughnessTex", C.c_int32), ("metallicTex", C.c_int32),
+                ("normalTex", C.c_int32), ("nested", C.c_int32), ("pad_", C.c_int32 * 2)]
+
+
+class KzImage(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("format", C.c_int32)]
+
+
+class KzTexture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("image", C.c_int32), ("scale", C.c_float), ("srgb", C.c_int32),
+                ("rampMin", C.c_float), ("rampMax", C.c_float), ("blendMode", C.c_int32), ("child", C.c_int32 * 3), ("pad_", C.c_int32 * 3)]
 
 
 class KzLight(C.Structure):
@@ -74,7 +88,9 @@ class KzSceneDesc(C.Structure):
                 ("bsdfs", C.POINTER(KzBSDF)), ("nBsdfs", C.c_uint32),
                 ("lights", C.POINTER(KzLight)), ("nLights", C.c_uint32),
                 ("camera", KzCamera), ("sampler", KzSampler), ("integrator", KzIntegrator),
-                ("background", KzBackground)]
+                ("background", KzBackground),
+                ("textures", C.POINTER(KzTexture)), ("nTextures", C.c_uint32),
+                ("images", C.POINTER(KzImage)), ("nImages", C.c_uint32)]
 
 
 class KzTile(C.Structure):
@@ -109,7 +125,7 @@ class KzBvhInfo(C.Structure):
 EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
            "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
-           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms"]
+           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
@@ -150,7 +166,8 @@ def load_library():
     lib.kz_last_kernel_ms.argtypes = [C.c_void_p, f32p]
     lib.kz_last_stage_ms.argtypes = [C.c_void_p, f32p]
     lib.kz_render_samples.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), u32p, f32p]
-    lib.kz_bsdf_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, f32p, f32p, f32p, f32p, f32p]
+    lib.kz_bsdf_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p]
+    lib.kz_texture_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p]
     _lib = lib
     return lib
 

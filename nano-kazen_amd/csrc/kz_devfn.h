@@ -480,6 +480,7 @@ __device__ __forceinline__ V3 toWorld(const Frame3 &f, V3 v) { return f.s * v.x 
 
 struct Its {
     V3 p; float t; float uvx, uvy; Frame3 sh; V3 geoN; uint32_t mesh; uint32_t prim; float bu, bv;
+    V3 dpdu;        // accel.cpp:185,209 — only NormalMap::getFrame reads it (dead code in the kernels without normal maps)
 };
 
 template <bool GEO>
@@ -510,9 +511,9 @@ __device__ __forceinline__ void postIntersect(const KzDevTables &T, const RawHit
     its.geoN = geoN;
     its.uvx = rh.u; its.uvy = rh.v;
     if (hasUV) { its.uvx = bx * uv0x + by * uv1x + bz * uv2x; its.uvy = bx * uv0y + by * uv1y + bz * uv2y; }   // accel.cpp:161-164
+    bool tangent = false;
     if (hasN) {
         const V3 shN = bx * n0 + by * n1 + bz * n2;
-        bool tangent = false;
         if (hasUV) {                                                          // accel.cpp:166-217
             const float duv0x = uv1x - uv0x, duv0y = uv1y - uv0y, duv1x = uv2x - uv0x, duv1y = uv2y - uv0y;
             const float length = norm(gx);
@@ -523,11 +524,15 @@ __device__ __forceinline__ void postIntersect(const KzDevTables &T, const RawHit
                 its.sh.n = normalized(shN);
                 its.sh.s = normalized(dpdu - shN * dot(shN, dpdu));
                 its.sh.t = normalized(cross(its.sh.n, its.sh.s));
+                its.dpdu = dpdu;
                 tangent = true;
             }
         }
         if (!tangent) its.sh = frameFromNormal(normalized(shN));              // accel.cpp:203-229
     } else its.sh = frameFromNormal(geoN);                                    // accel.cpp:231-233
+    // H12: outside the tangent branch the reference leaves its.dpdu stale / uninitialised except in the degenerate-uv
+    // branch, which sets it to shFrame.s (accel.cpp:209); that value is used for every non-tangent branch here.
+    if (!tangent) its.dpdu = its.sh.s;
 }
 
 // ============================================================================================
@@ -864,6 +869,137 @@ __device__ __forceinline__ float bsdfPdf(const KzBSDF &m, V3 wi, V3 wo, float ac
     return kissPdf(m, wi, wo, accRough);
 }
 
+
+// ============================================================================================
+// Texture<Color3f> trees (texture.cpp:10-270) and the NormalMap wrapper (bsdf.cpp:281-417).
+// Only reachable from the EXT kernel variants (KzParams::bsdfExt).
+// ============================================================================================
+__device__ __forceinline__ float texelAt(const KzImageRow &im, const uint8_t *base, int x, int y, int c) {
+    if (c >= im.channels) return 0.0f;                                             // missing channels: TextureOpt::fill = 0
+    const size_t i = ((size_t)y * (size_t)im.width + (size_t)x) * (size_t)im.channels + (size_t)c;
+    return im.format == KZ_PIXEL_F32 ? reinterpret_cast<const float *>(base)[i] : (float)base[i] * (1.0f / 255.0f);
+}
+__device__ __forceinline__ int wrapPeriodic(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+__device__ __forceinline__ float srgbToLinear(float v) {                           // Color3f::toLinearRGB, common.cpp:368-382
+    return v <= 0.04045f ? v * (1.0f / 12.92f) : powf((v + 0.055f) * (1.0f / 1.055f), 2.4f);
+}
+// ImageTexture::eval (texture.cpp:46-64): s = u*scale, t = (1-v)*scale, periodic wrap; bilinear as declared in kazen_mi355x.h
+__device__ V3 imageLookup(const KzDevTables &T, uint32_t image, float scale, uint32_t srgb, float u, float v) {
+    const KzImageRow im = T.images[image];
+    const uint8_t *base = T.texels + im.offset;
+    const float s = u * scale, t = (1.0f - v) * scale;
+    const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
+    if (!(fabsf(x) < 1.0e9f) || !(fabsf(y) < 1.0e9f)) return mk(0.f);             // non-finite uv: defined as black
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float fx = x - fx0, fy = y - fy0;
+    const int x0 = wrapPeriodic((int)fx0, im.width), x1 = wrapPeriodic((int)fx0 + 1, im.width);
+    const int y0 = wrapPeriodic((int)fy0, im.height), y1 = wrapPeriodic((int)fy0 + 1, im.height);
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float top = (1.0f - fx) * texelAt(im, base, x0, y0, c) + fx * texelAt(im, base, x1, y0, c);
+        const float bot = (1.0f - fx) * texelAt(im, base, x0, y1, c) + fx * texelAt(im, base, x1, y1, c);
+        r[c] = (1.0f - fy) * top + fy * bot;
+        if (srgb) r[c] = srgbToLinear(r[c]);
+    }
+    return mk(r[0], r[1], r[2]);
+}
+__device__ __forceinline__ float clampRef(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   // common.h:237-243
+// texId is 1-based (KzBSDF::*Tex); the postfix program was flattened by kz_scene_create
+__device__ V3 texEval(const KzDevTables &T, int32_t texId, float u, float v) {
+    const KzTexProg pr = T.texProgs[texId - 1];
+    V3 st[KZ_TEX_MAX_DEPTH];
+    int sp = 0;
+    for (uint32_t i = 0; i < pr.count; ++i) {
+        const KzTexOp op = T.texOps[pr.start + i];
+        if (op.op == KZ_TOP_CONST) st[sp++] = mk(op.f0, op.f1, op.f2);
+        else if (op.op == KZ_TOP_IMAGE) st[sp++] = imageLookup(T, op.a, op.f0, op.b, u, v);
+        else if (op.op == KZ_TOP_RAMP) {                                           // texture.cpp:162-172
+            const V3 c = st[sp - 1];
+            st[sp - 1] = mk(op.f0 + (op.f1 - op.f0) * clampRef(c.x, 0.0f, 1.0f), op.f0 + (op.f1 - op.f0) * clampRef(c.y, 0.0f, 1.0f),
+                            op.f0 + (op.f1 - op.f0) * clampRef(c.z, 0.0f, 1.0f));
+        } else {                                                                   // texture.cpp:211-237
+            const V3 in2 = st[sp - 1], in1 = st[sp - 2], mask = st[sp - 3];
+            sp -= 3;
+            V3 r = mk(0.f);
+            if (op.a == KZ_BLEND_MIX) r = mk(lerpf(mask.x, in1.x, in2.x), lerpf(mask.x, in1.y, in2.y), lerpf(mask.x, in1.z, in2.z));
+            else if (op.a == KZ_BLEND_MULTIPLY) r = in1 * in2;
+            st[sp++] = r;
+        }
+    }
+    return st[0];
+}
+// fold the texture-backed parameters of a (local copy of a) BSDF row at this hit's uv: bRec.uv is its.uv at every call
+// site of the integrator (integrator.cpp:285,305), so eval / pdf / sample / regularize of one hit all see these values
+__device__ __forceinline__ void resolveTextures(const KzDevTables &T, KzBSDF &b, float u, float v) {
+    if (b.albedoTex) {
+        const V3 c = texEval(T, b.albedoTex, u, v);
+        if (b.type == KZ_BSDF_KAZENSTANDARD) { b.baseColor[0] = c.x; b.baseColor[1] = c.y; b.baseColor[2] = c.z; }
+        else { b.albedo[0] = c.x; b.albedo[1] = c.y; b.albedo[2] = c.z; }
+    }
+    if (b.roughnessTex) b.roughness = texEval(T, b.roughnessTex, u, v).x;
+    if (b.metallicTex) b.metallic = texEval(T, b.metallicTex, u, v).x;
+}
+
+// NormalMap (bsdf.cpp:281-417). n = 2*rgb-1 in the local shading frame (not normalised for the dot(n, wi) tests);
+// pf = getFrame(its, n.normalized(), wi) (bsdf.cpp:365-374).
+struct NMap { bool on; V3 n; Frame3 pf; };
+__device__ __forceinline__ void nmapSetup(const KzDevTables &T, const KzBSDF &outer, const Its &its, NMap &nm) {
+    const V3 rgb = texEval(T, outer.normalTex, its.uvx, its.uvy);
+    nm.on = true;
+    nm.n = mk(2 * rgb.x - 1, 2 * rgb.y - 1, 2 * rgb.z - 1);
+    nm.pf.n = normalized(toWorld(its.sh, normalized(nm.n)));
+    nm.pf.s = normalized(its.dpdu - nm.pf.n * dot(nm.pf.n, its.dpdu));
+    nm.pf.t = normalized(cross(nm.pf.n, nm.pf.s));
+}
+// One hit's BSDF: the row (normalmap unwrapped to its nested row, textures folded) + the perturbed frame
+template <bool EXT>
+__device__ __forceinline__ void surfaceSetup(const KzDevTables &T, const Its &its, KzBSDF &b, NMap &nm) {
+    nm.on = false;
+    if (EXT) {
+        if (b.type == KZ_BSDF_NORMALMAP) { nmapSetup(T, b, its, nm); b = T.bsdfs[b.nested]; }
+        resolveTextures(T, b, its.uvx, its.uvy);
+    }
+}
+// solid: bRec.measure == ESolidAngle. Only Diffuse checks it (bsdf.cpp:30,43,213,225); it is lost when NormalMap::sample goes
+// through the perturbed record, whose measure is never copied back (bsdf.cpp:348-362).
+template <bool EXT>
+__device__ __forceinline__ V3 surfEval(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, V3 wo, float accRough) {
+    if (!EXT || !nm.on) return bsdfEval<EXT>(b, wi, wo, accRough);
+    if (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0) return bsdfEval<EXT>(b, wi, wo, accRough);          // bsdf.cpp:295-296
+    const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi)), woP = toLocal(nm.pf, toWorld(its.sh, wo));
+    if (wo.z * woP.z <= 0) return mk(0.f);
+    return bsdfEval<EXT>(b, wiP, woP, 0.0f);            // the perturbed record carries a fresh Intersection: accumulatedRoughness 0
+}
+template <bool EXT>
+__device__ __forceinline__ float surfPdf(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, V3 wo, float accRough, bool solid) {
+    if (!EXT || !nm.on) return bsdfPdf<EXT>(b, wi, wo, accRough);
+    if (!solid && b.type == KZ_BSDF_DIFFUSE) return 0.0f;
+    if (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0) return bsdfPdf<EXT>(b, wi, wo, accRough);
+    const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi)), woP = toLocal(nm.pf, toWorld(its.sh, wo));
+    if (wo.z * woP.z <= 0) return 0.0f;
+    return bsdfPdf<EXT>(b, wiP, woP, 0.0f);
+}
+template <bool EXT>
+__device__ __forceinline__ V3 surfSample(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, float accRough, float s1, float s2x, float s2y,
+                                         V3 &wo, bool &alive, bool &discrete, float &etaScale, float &pdfOut, bool &solid) {
+    solid = true;
+    if (!EXT || !nm.on) return bsdfSample<EXT>(b, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
+    if (wi.z > 0 && dot(nm.n, wi) <= 0) {                                                                // bsdf.cpp:342-345
+        const V3 w = bsdfSample<EXT>(b, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
+        pdfOut = -1.f;                                   // NormalMap::pdf may take the other branch: let the caller evaluate it
+        return w;
+    }
+    const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi));
+    V3 woP; bool discN; float pdfN;
+    const V3 w = bsdfSample<EXT>(b, wiP, 0.0f, s1, s2x, s2y, woP, alive, discN, etaScale, pdfN);
+    discrete = false; solid = false; pdfOut = -1.f;      // measure stays EUnknownMeasure in the caller's record
+    if (!alive || (w.x == 0.f && w.y == 0.f && w.z == 0.f)) { wo = mk(0.f, 0.f, 1.f); return mk(0.f); }
+    wo = toLocal(its.sh, toWorld(nm.pf, woP));
+    if (wo.z * woP.z <= 0) return mk(0.f);
+    return w;
+}
+
 // ============================================================================================
 // a18/a19 lights (light.cpp:16-51, mesh.cpp:108-133, dpdf.h:99-104)
 // ============================================================================================
@@ -949,7 +1085,8 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             if (probability <= smp.next1D(P, T)) break;
             throughput = throughput / probability;
         }
-        const KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+        KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+        NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
         const V3 wiLocal = toLocal(its.sh, -rd);
         // ---- light sampling (integrator.cpp:247-295); the pick is drawn even when there are no lights
         float pick = smp.next1D(P, T);
@@ -985,8 +1122,8 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             const bool occluded = shadowOccluded<STATS>(P, T, its.p, lwi, eps, dist - eps, stk, cn);
             if (!occluded) {
                 V3 woLocal = toLocal(its.sh, lwi);
-                V3 f = bsdfEval<EXT>(bsdf, wiLocal, woLocal, accRough);
-                float bpdf = bsdfPdf<EXT>(bsdf, wiLocal, woLocal, accRough);
+                V3 f = surfEval<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough);
+                float bpdf = surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, true);
                 float lightWeight = powerHeuristic(lpdf, bpdf);
                 L = L + throughput * Ls * f * lightWeight;
             }
@@ -995,13 +1132,13 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
         // ---- BSDF sampling (integrator.cpp:304-309): next2D BEFORE next1D (H1)
         float s2x, s2y; smp.next2D(P, T, s2x, s2y);
         float s1 = smp.next1D(P, T);
-        V3 woLocal; bool alive, discrete; float etaScale, pdfUnused;
-        V3 weight = bsdfSample<EXT>(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, alive, discrete, etaScale, pdfUnused);
+        V3 woLocal; bool alive, discrete, solid; float etaScale, pdfUnused;
+        V3 weight = surfSample<EXT>(bsdf, nm, its, wiLocal, accRough, s1, s2x, s2y, woLocal, alive, discrete, etaScale, pdfUnused, solid);
         throughput = throughput * weight;
         eta *= etaScale;
         // zero weight: the reference keeps looping with throughput 0 (contributes exactly 0); terminate instead
         if (!alive || (weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) break;
-        float bpdf = bsdfPdf<EXT>(bsdf, wiLocal, woLocal, accRough);
+        float bpdf = surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, solid);
         ro = its.p; rd = toWorld(its.sh, woLocal);                                            // H9: not re-normalised
         if (!closestHit<STATS>(T, P.rootRef, ro, rd, eps, KZ_INF, rh, stk, cn)) {
             if (P.bgPresent && !(isnan(rd.x) || isnan(rd.y) || isnan(rd.z)))                  // scene.cpp:54-79

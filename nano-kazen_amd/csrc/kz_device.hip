@@ -175,21 +175,35 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_trace_kernel(KzParams P, KzDevTab
 }
 
 
-// Function-level query kernel for the BSDF tables (parity tests of a20/a21/a22/a23 on the device)
+// Function-level query kernels for the BSDF / texture tables (parity tests of a20/a21/a22/a23 and the 8f rows on the device).
+// The intersection record is the identity frame (s, t, n = x, y, z; dpdu = x) at the given uv.
 __global__ void kz_bsdf_kernel(KzDevTables T, uint32_t n, const int32_t *__restrict__ bsdf, const float *__restrict__ wi, const float *__restrict__ wo,
-                               const float *__restrict__ acc, const float *__restrict__ s3, float *__restrict__ evalOut, float *__restrict__ pdfOut,
-                               float *__restrict__ sampleOut) {
+                               const float *__restrict__ acc, const float *__restrict__ s3, const float *__restrict__ uv, float *__restrict__ evalOut,
+                               float *__restrict__ pdfOut, float *__restrict__ sampleOut) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const KzBSDF m = T.bsdfs[bsdf[i]];
+    KzBSDF m = T.bsdfs[bsdf[i]];
+    Its its;
+    its.p = mk(0.f); its.t = 0.f; its.uvx = uv ? uv[2 * i] : 0.f; its.uvy = uv ? uv[2 * i + 1] : 0.f;
+    its.sh.s = mk(1.f, 0.f, 0.f); its.sh.t = mk(0.f, 1.f, 0.f); its.sh.n = mk(0.f, 0.f, 1.f); its.geoN = its.sh.n; its.dpdu = its.sh.s;
+    its.mesh = 0; its.prim = 0; its.bu = its.bv = 0.f;
+    NMap nm; surfaceSetup<true>(T, its, m, nm);
     const V3 a = mk(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), b = mk(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
-    V3 e = bsdfEval<true>(m, a, b, acc[i]);
+    V3 e = surfEval<true>(m, nm, its, a, b, acc[i]);
     evalOut[3 * i] = e.x; evalOut[3 * i + 1] = e.y; evalOut[3 * i + 2] = e.z;
-    pdfOut[i] = bsdfPdf<true>(m, a, b, acc[i]);
-    V3 d; bool alive, discrete; float etaScale, pdfS;
-    V3 w = bsdfSample<true>(m, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive, discrete, etaScale, pdfS);
-    float *o = sampleOut + 7 * i;
+    pdfOut[i] = surfPdf<true>(m, nm, its, a, b, acc[i], true);
+    V3 d; bool alive, discrete, solid; float etaScale, pdfS;
+    V3 w = surfSample<true>(m, nm, its, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive, discrete, etaScale, pdfS, solid);
+    const bool zero = w.x == 0.f && w.y == 0.f && w.z == 0.f;
+    float *o = sampleOut + 8 * i;
     o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = d.x; o[4] = d.y; o[5] = d.z; o[6] = alive ? 1.f : 0.f;
+    o[7] = (!alive || zero) ? 0.f : (pdfS >= 0.f ? pdfS : surfPdf<true>(m, nm, its, a, d, acc[i], solid));      // integrator.cpp:314
+}
+__global__ void kz_texture_kernel(KzDevTables T, uint32_t n, const int32_t *__restrict__ tex, const float *__restrict__ uv, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 c = texEval(T, tex[i] + 1, uv[2 * i], uv[2 * i + 1]);
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
 }
 
 // ============================================================================================
@@ -278,6 +292,10 @@ int kz_scene_upload(KzScene *scene, int device) {
     std::vector<float> ft(scene->filter, scene->filter + KZ_FILTER_RESOLUTION + 1);
     if ((rc = uploadVec(ds, ft, &ds->T.filter))) return rc;
     if ((rc = uploadVec(ds, scene->ilTris, &ds->T.ilTris))) return rc;
+    if ((rc = uploadVec(ds, scene->texProgs, &ds->T.texProgs))) return rc;
+    if ((rc = uploadVec(ds, scene->texOps, &ds->T.texOps))) return rc;
+    if ((rc = uploadVec(ds, scene->images, &ds->T.images))) return rc;
+    if ((rc = uploadVec(ds, scene->texels, &ds->T.texels))) return rc;
     const KzParams &P = scene->prm;
     ds->filmPixels = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border);
     HIP_TRY(hipMalloc((void **)&ds->film, ds->filmPixels * sizeof(float4)));
@@ -634,27 +652,48 @@ int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint
     return KZ_OK;
 }
 
-// BSDF::eval / pdf / sample of bsdf rows on the device: evalOut 3n, pdfOut n, sampleOut 7n (weight, wo, alive).
+// BSDF::eval / pdf / sample of bsdf rows on the device: evalOut 3n, pdfOut n, sampleOut 8n (weight, wo, alive, pdf after sample).
 int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *wi, const float *wo, const float *accRough, const float *s3,
-                  float *evalOut, float *pdfOut, float *sampleOut) {
+                  const float *uv, float *evalOut, float *pdfOut, float *sampleOut) {
     KzDeviceState *ds; int rc;
     if ((rc = requireDevice(scene, &ds))) return rc;
     if (n == 0) return KZ_OK;
     if (!bsdf || !wi || !wo || !accRough || !s3 || !evalOut || !pdfOut || !sampleOut) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
     for (uint32_t i = 0; i < n; ++i) if (bsdf[i] < 0 || (size_t)bsdf[i] >= scene->bsdfs.size()) return kz_fail(KZ_ERR_INVALID_ARG, "bsdf index %d", bsdf[i]);
     float *d = nullptr; int32_t *dB = nullptr;
-    const size_t fl = (size_t)n * (3 + 3 + 1 + 3 + 3 + 1 + 7);
+    const size_t fl = (size_t)n * (3 + 3 + 1 + 3 + 3 + 1 + 8 + 2);
     HIP_TRY(hipMalloc((void **)&d, fl * 4)); HIP_TRY(hipMalloc((void **)&dB, (size_t)n * 4));
-    float *dWi = d, *dWo = d + 3 * (size_t)n, *dAcc = d + 6 * (size_t)n, *dS = d + 7 * (size_t)n, *dE = d + 10 * (size_t)n, *dP = d + 13 * (size_t)n, *dSm = d + 14 * (size_t)n;
+    float *dWi = d, *dWo = d + 3 * (size_t)n, *dAcc = d + 6 * (size_t)n, *dS = d + 7 * (size_t)n, *dE = d + 10 * (size_t)n, *dP = d + 13 * (size_t)n,
+          *dSm = d + 14 * (size_t)n, *dUv = d + 22 * (size_t)n;
     HIP_TRY(hipMemcpy(dB, bsdf, (size_t)n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dWi, wi, (size_t)n * 12, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dWo, wo, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dAcc, accRough, (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dS, s3, (size_t)n * 12, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kz_bsdf_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, ds->T, n, dB, dWi, dWo, dAcc, dS, dE, dP, dSm);
+    if (uv) HIP_TRY(hipMemcpy(dUv, uv, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_bsdf_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, ds->T, n, dB, dWi, dWo, dAcc, dS, uv ? dUv : (const float *)nullptr, dE, dP, dSm);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(evalOut, dE, (size_t)n * 12, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(pdfOut, dP, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(sampleOut, dSm, (size_t)n * 28, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sampleOut, dSm, (size_t)n * 32, hipMemcpyDeviceToHost));
     (void)hipFree(d); (void)hipFree(dB);
+    return KZ_OK;
+}
+
+// Texture<Color3f>::eval(uv) of texture rows on the device: out 3n.
+int kz_texture_query(KzScene *scene, uint32_t n, const int32_t *tex, const float *uv, float *out) {
+    KzDeviceState *ds; int rc;
+    if ((rc = requireDevice(scene, &ds))) return rc;
+    if (n == 0) return KZ_OK;
+    if (!tex || !uv || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
+    for (uint32_t i = 0; i < n; ++i) if (tex[i] < 0 || (size_t)tex[i] >= scene->texProgs.size()) return kz_fail(KZ_ERR_INVALID_ARG, "texture index %d", tex[i]);
+    float *d = nullptr; int32_t *dT = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)n * 5 * 4)); HIP_TRY(hipMalloc((void **)&dT, (size_t)n * 4));
+    float *dUv = d, *dO = d + 2 * (size_t)n;
+    HIP_TRY(hipMemcpy(dT, tex, (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dUv, uv, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_texture_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, ds->T, n, dT, dUv, dO);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dO, (size_t)n * 12, hipMemcpyDeviceToHost));
+    (void)hipFree(d); (void)hipFree(dT);
     return KZ_OK;
 }
 

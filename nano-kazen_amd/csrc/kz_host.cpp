@@ -78,6 +78,71 @@ float filterEval(const KzFilter &f, float x) {
 
 const uint64_t PCG32_MULT = 0x5851f42d4c957f2dULL;
 
+// ---- textures (texture.cpp): copy the rasters into one blob, flatten every KzTexture tree into a postfix program ----------
+static int emitTexture(const KzSceneDesc *d, KzScene *sc, int32_t t, int depthBudget, int &stackNow, int &stackMax) {
+    if (depthBudget <= 0) return kz_fail(KZ_ERR_UNSUPPORTED, "texture graph is cyclic or deeper than 32 levels");
+    if (sc->texOps.size() > (1u << 16)) return kz_fail(KZ_ERR_UNSUPPORTED, "texture graphs flatten to more than 65536 operations");
+    const KzTexture &k = d->textures[t];
+    KzTexOp op; std::memset(&op, 0, sizeof op);
+    auto pushConst = [&](float v) { KzTexOp c; std::memset(&c, 0, sizeof c); c.op = KZ_TOP_CONST; c.f0 = c.f1 = c.f2 = v; sc->texOps.push_back(c); stackNow++; stackMax = std::max(stackMax, stackNow); };
+    auto child = [&](int i, float dflt) -> int {
+        const int32_t c = k.child[i];
+        if (c < 0) { pushConst(dflt); return KZ_OK; }
+        if (c >= (int32_t)d->nTextures) return kz_fail(KZ_ERR_INVALID_ARG, "texture %d: child %d out of range", t, c);
+        return emitTexture(d, sc, c, depthBudget - 1, stackNow, stackMax);
+    };
+    switch (k.type) {
+    case KZ_TEX_CONSTANT:
+        op.op = KZ_TOP_CONST; op.f0 = k.color[0]; op.f1 = k.color[1]; op.f2 = k.color[2];
+        sc->texOps.push_back(op); stackNow++; stackMax = std::max(stackMax, stackNow);
+        return KZ_OK;
+    case KZ_TEX_IMAGE:
+        if (k.image < 0 || k.image >= (int32_t)d->nImages) return kz_fail(KZ_ERR_INVALID_ARG, "texture %d: image index %d out of range", t, k.image);
+        op.op = KZ_TOP_IMAGE; op.a = (uint32_t)k.image; op.f0 = k.scale; op.b = k.srgb ? 1u : 0u;
+        sc->texOps.push_back(op); stackNow++; stackMax = std::max(stackMax, stackNow);
+        return KZ_OK;
+    case KZ_TEX_COLORRAMP: {
+        if (k.child[0] < 0) { pushConst(0.f); return KZ_OK; }                      // texture.cpp:170: no nested texture -> 0 (not ramped)
+        int rc = child(0, 0.f); if (rc != KZ_OK) return rc;
+        op.op = KZ_TOP_RAMP; op.f0 = k.rampMin; op.f1 = k.rampMax;
+        sc->texOps.push_back(op);
+        return KZ_OK; }
+    case KZ_TEX_BLEND: {
+        if (k.blendMode < KZ_BLEND_MIX || k.blendMode > KZ_BLEND_NONE) return kz_fail(KZ_ERR_INVALID_ARG, "texture %d: blend mode %d", t, k.blendMode);
+        int rc = child(0, 0.5f); if (rc != KZ_OK) return rc;                       // mask, input1, input2 defaults: texture.cpp:213-215
+        rc = child(1, 0.f); if (rc != KZ_OK) return rc;
+        rc = child(2, 1.f); if (rc != KZ_OK) return rc;
+        op.op = KZ_TOP_BLEND; op.a = (uint32_t)k.blendMode;
+        sc->texOps.push_back(op); stackNow -= 2;
+        return KZ_OK; }
+    default:
+        return kz_fail(KZ_ERR_UNSUPPORTED, "texture %d has type %d (supported: constanttexture, imagetexture, colorramp, blend)", t, k.type);
+    }
+}
+static int flattenTextures(const KzSceneDesc *d, KzScene *sc) {
+    for (uint32_t i = 0; i < d->nImages; ++i) {
+        const KzImage &im = d->images[i];
+        if (!im.pixels || im.width <= 0 || im.height <= 0 || im.channels <= 0 || im.channels > 16 || im.width > 65536 || im.height > 65536 ||
+            (im.format != KZ_PIXEL_U8 && im.format != KZ_PIXEL_F32))
+            return kz_fail(KZ_ERR_INVALID_ARG, "image %u: %dx%dx%d format %d", i, im.width, im.height, im.channels, im.format);
+        const size_t bytes = (size_t)im.width * im.height * im.channels * (im.format == KZ_PIXEL_F32 ? 4 : 1);
+        KzImageRow row; row.offset = (sc->texels.size() + 15) & ~(size_t)15; row.width = im.width; row.height = im.height; row.channels = im.channels; row.format = im.format;
+        sc->texels.resize(row.offset + bytes);
+        std::memcpy(sc->texels.data() + row.offset, im.pixels, bytes);
+        sc->images.push_back(row);
+    }
+    for (uint32_t t = 0; t < d->nTextures; ++t) {
+        KzTexProg pr; pr.start = (uint32_t)sc->texOps.size();
+        int now = 0, mx = 0;
+        int rc = emitTexture(d, sc, (int32_t)t, 32, now, mx);
+        if (rc != KZ_OK) return rc;
+        if (mx > KZ_TEX_MAX_DEPTH) return kz_fail(KZ_ERR_UNSUPPORTED, "texture %u needs an operand stack of %d (limit %d)", t, mx, KZ_TEX_MAX_DEPTH);
+        pr.count = (uint32_t)sc->texOps.size() - pr.start;
+        sc->texProgs.push_back(pr);
+    }
+    return KZ_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -101,13 +166,28 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     if (d->sampler.sampleCount == 0) return kz_fail(KZ_ERR_INVALID_ARG, "sampleCount is 0");
     if (!(d->camera.rfilter.radius > 0.f) || d->camera.rfilter.radius > 4.0f) return kz_fail(KZ_ERR_UNSUPPORTED, "filter radius %g (supported: (0, 4])", d->camera.rfilter.radius);
     if ((d->nMeshes && !d->meshes) || (d->nBsdfs && !d->bsdfs) || (d->nLights && !d->lights)) return kz_fail(KZ_ERR_INVALID_ARG, "null table with non-zero count");
-    for (uint32_t i = 0; i < d->nBsdfs; ++i)
-        if (d->bsdfs[i].type < KZ_BSDF_DIFFUSE || d->bsdfs[i].type > KZ_BSDF_ROUGHDIELECTRIC)
-            return kz_fail(KZ_ERR_UNSUPPORTED, "bsdf %u has type %d (supported: diffuse, kazenstandard, mirror, dielectric, ggx, roughconductor, roughplastic, roughdielectric)", i, d->bsdfs[i].type);
+    if ((d->nTextures && !d->textures) || (d->nImages && !d->images)) return kz_fail(KZ_ERR_INVALID_ARG, "null texture/image table with non-zero count");
+    for (uint32_t i = 0; i < d->nBsdfs; ++i) {
+        const KzBSDF &b = d->bsdfs[i];
+        if (b.type < KZ_BSDF_DIFFUSE || b.type > KZ_BSDF_NORMALMAP)
+            return kz_fail(KZ_ERR_UNSUPPORTED, "bsdf %u has type %d (supported: diffuse, kazenstandard, mirror, dielectric, ggx, roughconductor, roughplastic, roughdielectric, normalmap)", i, b.type);
+        const int32_t ids[4] = {b.albedoTex, b.roughnessTex, b.metallicTex, b.normalTex};
+        for (int32_t id : ids) if (id < 0 || id > (int32_t)d->nTextures) return kz_fail(KZ_ERR_INVALID_ARG, "bsdf %u: texture id %d out of range (0 = constant, 1..%u)", i, id, d->nTextures);
+        // which rows read a Texture child: diffuse/lambertian + ggx "albedo" (bsdf.cpp:259-262, :672-675), kiss (bsdf.cpp:1375-1390)
+        const bool takesAlbedo = b.type == KZ_BSDF_DIFFUSE || b.type == KZ_BSDF_GGX || b.type == KZ_BSDF_KAZENSTANDARD;
+        if ((b.albedoTex && !takesAlbedo) || ((b.roughnessTex || b.metallicTex) && b.type != KZ_BSDF_KAZENSTANDARD) || (b.normalTex && b.type != KZ_BSDF_NORMALMAP))
+            return kz_fail(KZ_ERR_INVALID_ARG, "bsdf %u (type %d): a texture id is set on a parameter this model does not read through a texture", i, b.type);
+        if (b.type == KZ_BSDF_NORMALMAP) {                  // bsdf.cpp:391-404: one texture child + one nested BSDF
+            if (b.normalTex == 0) return kz_fail(KZ_ERR_INVALID_ARG, "bsdf %u: normalmap without a normal texture", i);
+            if (b.nested < 0 || b.nested >= (int32_t)d->nBsdfs || d->bsdfs[b.nested].type == KZ_BSDF_NORMALMAP)
+                return kz_fail(KZ_ERR_INVALID_ARG, "bsdf %u: normalmap needs a nested BSDF row that is not itself a normalmap (got %d)", i, b.nested);
+        }
+    }
 
     KzScene *sc = new KzScene();
     std::memset(&sc->prm, 0, sizeof sc->prm);
     sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->nBsdfs);
+    { int trc = flattenTextures(d, sc); if (trc != KZ_OK) { delete sc; return trc; } }
     int defaultBsdf = -1;
 
     // ---- geometry: (mesh, face) order = Embree geomID / primID order (accel.cpp:40-55)
@@ -189,7 +269,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
       p.rootRef4 = r4; p.stackBound4 = sb; }
     p.stackDepth = (int32_t)std::max<uint32_t>(2u, sc->bvh.maxDepth + 1);
     p.bsdfExt = 0;
-    for (const KzBSDF &b : sc->bsdfs) if (b.type > KZ_BSDF_KAZENSTANDARD) p.bsdfExt = 1;
+    for (const KzBSDF &b : sc->bsdfs) if (b.type > KZ_BSDF_KAZENSTANDARD || b.albedoTex || b.roughnessTex || b.metallicTex) p.bsdfExt = 1;
     // invisible-light triangles for the exact any-hit shadow test
     p.shadowFast = 1; p.nIlTris = 0; p.anyInvisibleLight = 0;
     for (int a = 0; a < 3; ++a) { p.ilLo[a] = INFINITY; p.ilHi[a] = -INFINITY; }

@@ -58,6 +58,21 @@ struct KzLightRow {
     float normalization;   // DiscretePDF::m_normalization = Mesh::pdf() (mesh.h:165-168)
     uint32_t pad[3];
 };
+// Flattened texture trees (texture.cpp): every KzTexture root becomes a postfix program over a small operand stack,
+// so the device needs no recursion. 32 B per op.
+enum { KZ_TOP_CONST = 0, KZ_TOP_IMAGE = 1, KZ_TOP_RAMP = 2, KZ_TOP_BLEND = 3 };
+struct KzTexOp {
+    uint32_t op;           // KZ_TOP_*
+    uint32_t a;            // IMAGE: image row; BLEND: KZ_BLEND_*
+    float f0, f1, f2;      // CONST: colour; IMAGE: f0 = scale; RAMP: f0 = min, f1 = max
+    uint32_t b;            // IMAGE: srgb flag
+    uint32_t pad[2];
+};
+static_assert(sizeof(KzTexOp) == 32, "texture op must be 32 B");
+struct KzTexProg { uint32_t start, count; };
+struct KzImageRow { uint64_t offset; int32_t width, height, channels, format; };   // offset in bytes into the texel blob, 16-B aligned
+static_assert(sizeof(KzBSDF) == 128, "BSDF row must be 128 B");
+
 // pcg32 jump-ahead pair for advance(sampleIndex * 65536): state' = mult*state + inc*plus (pcg32.h:145-166 is
 // linear in `inc`, so the pair is pixel independent and tabulated once per sample index).
 struct KzPcgJump { uint64_t mult, plus; };
@@ -86,7 +101,8 @@ struct KzParams {
     // any-hit form of the shadow test exact (kz_devfn.h shadowOccluded)
     int32_t shadowFast; uint32_t nIlTris; float ilLo[3], ilHi[3];
     int32_t anyInvisibleLight; int32_t stackDepth;
-    int32_t bsdfExt;                     // any BSDF row beyond diffuse / kazenstandard (selects the larger kernel variants)
+    int32_t bsdfExt;                     // any BSDF row beyond constant diffuse / kazenstandard: other models, texture-backed
+                                         // parameters, normal maps (selects the larger kernel variants)
 };
 
 // Device pointers (all HBM-resident after kz_scene_upload).
@@ -105,6 +121,10 @@ struct KzDevTables {
     const KzPcgJump *jump;      // [sampleCount]
     const float *filter;        // [33]
     const KzTri *ilTris;        // invisible-light triangles (<= 64) for the exact any-hit shadow test
+    const KzTexProg *texProgs;  // [nTextures]
+    const KzTexOp *texOps;
+    const KzImageRow *images;
+    const uint8_t *texels;
 };
 
 struct KzScene {
@@ -122,6 +142,10 @@ struct KzScene {
     std::vector<float> pixelSamples;
     std::vector<KzPcgJump> jump;
     std::vector<KzTri> ilTris;
+    std::vector<KzTexProg> texProgs;
+    std::vector<KzTexOp> texOps;
+    std::vector<KzImageRow> images;
+    std::vector<uint8_t> texels;
     float filter[KZ_FILTER_RESOLUTION + 1];
     KzParams prm;
     KzBvhInfo bvh;

@@ -233,11 +233,13 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                         // A one-sided BSDF seen from below evaluates to 0 for every light sample (no shadow ray, nothing added) and its
                         // sample() returns 0 (the path ends): nothing after this point can be observed. Only the two-sided
                         // transmissive models go on. (The light sample is still counted so the counters match the reference's work.)
-                        const bool twoSided = EXT && (bsdf.type == KZ_BSDF_DIELECTRIC || bsdf.type == KZ_BSDF_ROUGHDIELECTRIC);
+                        // A normal map can turn a below-the-horizon wi into an above-the-horizon one in the perturbed frame.
+                        const bool twoSided = EXT && (bsdf.type == KZ_BSDF_DIELECTRIC || bsdf.type == KZ_BSDF_ROUGHDIELECTRIC || bsdf.type == KZ_BSDF_NORMALMAP);
                         if (!(wiLocal.z > 0.f) && !twoSided && !isnan(wiLocal.z)) { if (STATS && P.nLights > 0) cn.lsamples++; alive = false; }
                     }
                     if (alive) {
-                        const KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+                        KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+                        NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
                         const V3 wiLocal = toLocal(its.sh, -rd);
                         const float pick = smp.next1D(P, T);                                  // drawn even without lights
                         if (P.nLights > 0) {                                                  // integrator.cpp:247-295
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                             }
                             Ls = Ls / P.lightPickPdf;
                             const V3 woL = toLocal(its.sh, lwi);
-                            const V3 f = bsdfEval<EXT>(bsdf, wiLocal, woL, accRough);
-                            const float bpdfL = bsdfPdf<EXT>(bsdf, wiLocal, woL, accRough);
+                            const V3 f = surfEval<EXT>(bsdf, nm, its, wiLocal, woL, accRough);
+                            const float bpdfL = surfPdf<EXT>(bsdf, nm, its, wiLocal, woL, accRough, true);
                             const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
                             // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
                             if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
@@ -282,12 +284,12 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                         if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
                         float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
                         const float s1 = smp.next1D(P, T);
-                        V3 woLocal; bool ok, discrete; float etaScale, pdfS;
-                        const V3 weight = bsdfSample<EXT>(bsdf, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale, pdfS);
+                        V3 woLocal; bool ok, discrete, solid; float etaScale, pdfS;
+                        const V3 weight = surfSample<EXT>(bsdf, nm, its, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale, pdfS, solid);
                         throughput = throughput * weight;
                         const float etaNext = eta * etaScale;
                         if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
-                            const float bpdf = pdfS >= 0.f ? pdfS : bsdfPdf<EXT>(bsdf, wiLocal, woLocal, accRough);
+                            const float bpdf = pdfS >= 0.f ? pdfS : surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, solid);
                             const V3 nd = toWorld(its.sh, woLocal);                           // H9
                             // the ray after the LAST bounce only matters for the background term
                             if (iter + 1 < P.maxDepth || P.bgPresent) {

@@ -18,7 +18,11 @@
 #include "../../include/kazen_mi355x.h"
 
 #include <array>
+#include <cctype>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
@@ -102,11 +106,9 @@ public:
         auto &t = table();
         auto it = t.find(name);
         if (it != t.end()) return it->second(props);
-        static const char *offPath[] = {"normals", "ao", "whitted", "path_mats",
-                                        "lambertian", "normalmap", "imagetexture",
-                                        "colorramp", "blend", "nonscatter"};
+        static const char *offPath[] = {"normals", "ao", "whitted", "path_mats", "nonscatter"};
         for (const char *o : offPath)
-            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis; diffuse/kazenstandard/mirror/dielectric/ggx/roughconductor/roughplastic/roughdielectric; independent/pmj02bn/stratified/correlated; perspective/thinlens)");
+            if (name == o) throw Exception("Class \"" + name + "\" exists in nano-kazen but is not on the MI355X hot path (path_mis; diffuse/lambertian/kazenstandard/mirror/dielectric/ggx/roughconductor/roughplastic/roughdielectric/normalmap; constanttexture/imagetexture/colorramp/blend; independent/pmj02bn/stratified/correlated; perspective/thinlens)");
         throw Exception("A constructor for class \"" + name + "\" could not be found!");
     }
 private:
@@ -115,13 +117,121 @@ private:
 #define KAZEN_MI355X_REGISTER(cls, name) \
     inline bool cls##_registered = (::kazen::ObjectFactory::registerClass(name, [](const ::kazen::PropertyList &p) -> ::kazen::Object * { return new cls(p); }), true)
 
-// ---- textures (src/kazen/texture.cpp:104-145, :240-270): constants only -------------------------------------------
-class ConstantTexture : public Object {
+// ---- textures (src/kazen/texture.cpp) -------------------------------------------------------------------------------
+// Rows of one scene flattening: textures / images / the BSDF rows that normalmaps wrap (placed behind the per-mesh rows).
+class Texture;
+class BSDF;
+struct RowBuilder {
+    std::vector<KzTexture> textures; std::vector<KzImage> images;
+    std::map<const Texture *, int> seen;
+    int nestedBase = 0; std::vector<const BSDF *> nested;
+    int tex(const Texture *t);                       // 1-based texture id (0 for a null pointer)
+    int nestedRow(const BSDF *b) { nested.push_back(b); return nestedBase + (int)nested.size() - 1; }
+};
+class Texture : public Object {
 public:
-    explicit ConstantTexture(const PropertyList &p) { m_color = p.getColor("color", Color3f(0.f)); }
     EClassType getClassType() const override { return ETexture; }
+    virtual KzTexture row(RowBuilder &rb) const = 0;
+    virtual bool isConstant() const { return false; }
+};
+inline int RowBuilder::tex(const Texture *t) {
+    if (!t) return 0;
+    auto it = seen.find(t);
+    if (it != seen.end()) return it->second;
+    KzTexture k = t->row(*this);                     // children first
+    textures.push_back(k);
+    return seen[t] = (int)textures.size();
+}
+class ConstantTexture : public Texture {             // texture.cpp:10-32
+public:
+    explicit ConstantTexture(const PropertyList &p) { m_color = p.getColor("color", Color3f(0.5f)); }
+    KzTexture row(RowBuilder &) const override { KzTexture k{}; k.type = KZ_TEX_CONSTANT; k.color[0] = m_color.r; k.color[1] = m_color.g; k.color[2] = m_color.b; k.child[0] = k.child[1] = k.child[2] = -1; return k; }
+    bool isConstant() const override { return true; }
     std::string toString() const override { return "ConstantTexture[]"; }
     Color3f m_color;
+};
+/// "imagetexture" (texture.cpp:36-98). The reference decodes the file through OpenImageIO; this dependency-free mirror reads
+/// binary PGM / PPM (P5 / P6, 8 or 16 bit) and PFM, and takes any other format as an already decoded raster (setRaster).
+class ImageTexture : public Texture {
+public:
+    explicit ImageTexture(const PropertyList &p) {
+        m_filename = p.getString("filename", ""); m_colorspace = p.getString("colorspace", "srgb"); m_scale = p.getFloat("scale", 1.0f);
+        if (!m_filename.empty()) load(m_filename);
+    }
+    void setRaster(int width, int height, int channels, int format, const void *pixels) {
+        m_w = width; m_h = height; m_c = channels; m_fmt = format;
+        size_t bytes = (size_t)width * height * channels * (format == KZ_PIXEL_F32 ? 4 : 1);
+        m_px.assign((const uint8_t *)pixels, (const uint8_t *)pixels + bytes);
+    }
+    KzTexture row(RowBuilder &rb) const override {
+        if (m_px.empty()) throw Exception("imagetexture \"" + m_filename + "\": no raster (decode the file in the host application and call setRaster)");
+        KzImage im{}; im.pixels = m_px.data(); im.width = m_w; im.height = m_h; im.channels = m_c; im.format = m_fmt;
+        rb.images.push_back(im);
+        KzTexture k{}; k.type = KZ_TEX_IMAGE; k.image = (int32_t)rb.images.size() - 1; k.scale = m_scale; k.srgb = m_colorspace == "srgb" ? 1 : 0;
+        k.child[0] = k.child[1] = k.child[2] = -1;
+        return k;
+    }
+    std::string toString() const override { return "ImageTexture[]"; }
+private:
+    void load(const std::string &fn) {
+        FILE *f = std::fopen(fn.c_str(), "rb");
+        if (!f) throw Exception("imagetexture: cannot open \"" + fn + "\"");
+        char magic[3] = {0, 0, 0};
+        auto token = [&](std::string &out) { out.clear(); int ch; while ((ch = std::fgetc(f)) != EOF) { if (ch == '#') { while ((ch = std::fgetc(f)) != EOF && ch != '\n') {} continue; } if (std::isspace(ch)) { if (!out.empty()) break; continue; } out.push_back((char)ch); } };
+        if (std::fread(magic, 1, 2, f) != 2) { std::fclose(f); throw Exception("imagetexture: \"" + fn + "\" is empty"); }
+        const std::string m(magic);
+        std::string a, b, c;
+        if (m == "P5" || m == "P6") {
+            token(a); token(b); token(c);
+            const int w = std::atoi(a.c_str()), h = std::atoi(b.c_str()), maxv = std::atoi(c.c_str()), ch = m == "P6" ? 3 : 1;
+            if (w <= 0 || h <= 0 || maxv <= 0 || maxv > 65535) { std::fclose(f); throw Exception("imagetexture: bad PNM header in \"" + fn + "\""); }
+            const size_t n = (size_t)w * h * ch;
+            if (maxv < 256) { std::vector<uint8_t> px(n); if (std::fread(px.data(), 1, n, f) != n) { std::fclose(f); throw Exception("imagetexture: truncated \"" + fn + "\""); }
+                if (maxv != 255) { std::vector<float> fl(n); for (size_t i = 0; i < n; ++i) fl[i] = (float)px[i] / (float)maxv; setRaster(w, h, ch, KZ_PIXEL_F32, fl.data()); } else setRaster(w, h, ch, KZ_PIXEL_U8, px.data()); }
+            else { std::vector<uint8_t> px(2 * n); if (std::fread(px.data(), 1, 2 * n, f) != 2 * n) { std::fclose(f); throw Exception("imagetexture: truncated \"" + fn + "\""); }
+                std::vector<float> fl(n); for (size_t i = 0; i < n; ++i) fl[i] = (float)((px[2 * i] << 8) | px[2 * i + 1]) / (float)maxv; setRaster(w, h, ch, KZ_PIXEL_F32, fl.data()); }
+        } else if (m == "PF" || m == "Pf") {
+            token(a); token(b); token(c);
+            const int w = std::atoi(a.c_str()), h = std::atoi(b.c_str()), ch = m == "PF" ? 3 : 1; const double sc = std::atof(c.c_str());
+            if (w <= 0 || h <= 0 || sc == 0.0) { std::fclose(f); throw Exception("imagetexture: bad PFM header in \"" + fn + "\""); }
+            const size_t n = (size_t)w * h * ch; std::vector<float> fl(n), out(n);
+            if (std::fread(fl.data(), 4, n, f) != n) { std::fclose(f); throw Exception("imagetexture: truncated \"" + fn + "\""); }
+            if (sc > 0) for (size_t i = 0; i < n; ++i) { uint32_t u; std::memcpy(&u, &fl[i], 4); u = (u >> 24) | ((u >> 8) & 0xff00u) | ((u << 8) & 0xff0000u) | (u << 24); std::memcpy(&fl[i], &u, 4); }   // big endian file
+            for (int y = 0; y < h; ++y) std::memcpy(&out[(size_t)y * w * ch], &fl[(size_t)(h - 1 - y) * w * ch], (size_t)w * ch * 4);   // PFM rows are bottom-up
+            setRaster(w, h, ch, KZ_PIXEL_F32, out.data());
+        } else { std::fclose(f); m_px.clear(); return; }     // another container (PNG, EXR, ...): the raster must come through setRaster
+        std::fclose(f);
+    }
+    std::string m_filename, m_colorspace; float m_scale; int m_w = 0, m_h = 0, m_c = 0, m_fmt = KZ_PIXEL_U8; std::vector<uint8_t> m_px;
+};
+class ColorRampTexture : public Texture {            // texture.cpp:149-195
+public:
+    explicit ColorRampTexture(const PropertyList &p) { m_min = p.getFloat("min", 0.0f); m_max = p.getFloat("max", 1.0f); }
+    ~ColorRampTexture() override { delete m_nested; }
+    void addChild(Object *o) override { if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than nested Texture"); m_nested = static_cast<Texture *>(o); }
+    KzTexture row(RowBuilder &rb) const override { KzTexture k{}; k.type = KZ_TEX_COLORRAMP; k.rampMin = m_min; k.rampMax = m_max; k.child[0] = rb.tex(m_nested) - 1; k.child[1] = k.child[2] = -1; return k; }
+    std::string toString() const override { return "ColorRampTexture[]"; }
+    float m_min, m_max; Texture *m_nested = nullptr;
+};
+class BlendTexture : public Texture {                // texture.cpp:199-270
+public:
+    explicit BlendTexture(const PropertyList &p) { m_blendmode = p.getString("blendmode", "mix"); }
+    ~BlendTexture() override { delete m_mask; delete m_input1; delete m_input2; }
+    void addChild(Object *o) override {
+        if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than nested Texture");
+        auto set = [&](Texture *&slot, const char *what) { if (slot) throw Exception(std::string("There is already an ") + what + " defined!"); slot = static_cast<Texture *>(o); };
+        if (o->getId() == "mask") set(m_mask, "mask");
+        else if (o->getId() == "input1") set(m_input1, "input1");
+        else if (o->getId() == "input2") set(m_input2, "input2");
+        else throw Exception("The name of this texture does not match any field!");
+    }
+    KzTexture row(RowBuilder &rb) const override {
+        KzTexture k{}; k.type = KZ_TEX_BLEND; k.blendMode = m_blendmode == "mix" ? KZ_BLEND_MIX : m_blendmode == "multiply" ? KZ_BLEND_MULTIPLY : KZ_BLEND_NONE;
+        k.child[0] = rb.tex(m_mask) - 1; k.child[1] = rb.tex(m_input1) - 1; k.child[2] = rb.tex(m_input2) - 1;
+        return k;
+    }
+    std::string toString() const override { return "BlendTexture[]"; }
+    std::string m_blendmode; Texture *m_mask = nullptr, *m_input1 = nullptr, *m_input2 = nullptr;
 };
 class BackgroundTexture : public Object {
 public:
@@ -139,17 +249,57 @@ public:
 };
 
 // ---- BSDFs ----------------------------------------------------------------------------------------------------------
+// A texture child that is a constanttexture is folded into the row (texture id 0); any other texture goes through the table.
 class BSDF : public Object {
 public:
     EClassType getClassType() const override { return EBSDF; }
-    virtual KzBSDF row() const = 0;
+    virtual KzBSDF row(RowBuilder &rb) const = 0;
+protected:
+    static void bind3(RowBuilder &rb, const Texture *t, float *dst, int32_t &id) {
+        if (t->isConstant()) { const Color3f &c = static_cast<const ConstantTexture *>(t)->m_color; dst[0] = c.r; dst[1] = c.g; dst[2] = c.b; id = 0; }
+        else id = rb.tex(t);
+    }
+    static void bind1(RowBuilder &rb, const Texture *t, float &dst, int32_t &id) {       // .r() of the colour (bsdf.cpp:1227,1231)
+        if (t->isConstant()) { dst = static_cast<const ConstantTexture *>(t)->m_color.r; id = 0; }
+        else id = rb.tex(t);
+    }
 };
 class Diffuse : public BSDF {                        // src/kazen/bsdf.cpp:20-92
 public:
     explicit Diffuse(const PropertyList &p) { m_albedo = p.getColor("albedo", Color3f(0.5f)); }
-    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_DIFFUSE; b.albedo[0] = m_albedo.r; b.albedo[1] = m_albedo.g; b.albedo[2] = m_albedo.b; return b; }
+    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_DIFFUSE; b.albedo[0] = m_albedo.r; b.albedo[1] = m_albedo.g; b.albedo[2] = m_albedo.b; return b; }
     std::string toString() const override { return "Diffuse[]"; }
     Color3f m_albedo;
+};
+class Lambertian : public BSDF {                     // src/kazen/bsdf.cpp:202-276: the diffuse model, albedo through a texture child
+public:
+    explicit Lambertian(const PropertyList &) {}
+    ~Lambertian() override { delete m_albedo; }
+    void addChild(Object *o) override { if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than albedi maps"); m_albedo = static_cast<Texture *>(o); }
+    void activate() override { if (!m_albedo) throw Exception("lambertian needs an albedo texture"); }
+    KzBSDF row(RowBuilder &rb) const override { KzBSDF b{}; b.type = KZ_BSDF_DIFFUSE; bind3(rb, m_albedo, b.albedo, b.albedoTex); return b; }
+    std::string toString() const override { return "Lambertian[]"; }
+    Texture *m_albedo = nullptr;
+};
+class NormalMap : public BSDF {                      // src/kazen/bsdf.cpp:281-417
+public:
+    explicit NormalMap(const PropertyList &) {}
+    ~NormalMap() override { delete m_normalMap; delete m_nested; }
+    void addChild(Object *o) override {
+        switch (o->getClassType()) {
+        case ETexture: m_normalMap = static_cast<Texture *>(o); break;
+        case EBSDF: m_nested = static_cast<BSDF *>(o); break;
+        default: throw Exception("addChild is not supported other than normal maps and nested BSDF");
+        }
+    }
+    void activate() override {
+        if (!m_normalMap || !m_nested) throw Exception("normalmap needs a normal texture and a nested BSDF");
+        if (dynamic_cast<NormalMap *>(m_nested)) throw Exception("a normalmap nested in a normalmap is not on the MI355X hot path");
+        m_nested->activate();
+    }
+    KzBSDF row(RowBuilder &rb) const override { KzBSDF b{}; b.type = KZ_BSDF_NORMALMAP; b.normalTex = rb.tex(m_normalMap); b.nested = rb.nestedRow(m_nested); return b; }
+    std::string toString() const override { return "NormalMap[]"; }
+    Texture *m_normalMap = nullptr; BSDF *m_nested = nullptr;
 };
 class KazenStandardSurface : public BSDF {           // src/kazen/bsdf.cpp:1157-1418
 public:
@@ -161,55 +311,52 @@ public:
     ~KazenStandardSurface() override { delete m_baseColor; delete m_roughness; delete m_metallic; }
     void addChild(Object *o) override {              // bsdf.cpp:1373-1395: textures by id
         if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than baseColor maps");
-        auto *c = dynamic_cast<ConstantTexture *>(o);
-        if (!c) throw Exception("kazenstandard: only constanttexture children are on the MI355X hot path");
-        auto set = [&](ConstantTexture *&slot, const char *what) { if (slot) throw Exception(std::string("There is already an ") + what + " defined!"); slot = c; };
+        auto *c = static_cast<Texture *>(o);
+        auto set = [&](Texture *&slot, const char *what) { if (slot) throw Exception(std::string("There is already an ") + what + " defined!"); slot = c; };
         if (o->getId() == "baseColor") set(m_baseColor, "baseColor");
         else if (o->getId() == "metallic") set(m_metallic, "metallic");
         else if (o->getId() == "roughness") set(m_roughness, "roughness");
         else throw Exception("kazenstandard: texture id must be baseColor, metallic or roughness");
     }
     void activate() override { if (!m_baseColor || !m_roughness || !m_metallic) throw Exception("kazenstandard needs baseColor, roughness and metallic textures"); }
-    KzBSDF row() const override {
+    KzBSDF row(RowBuilder &rb) const override {
         KzBSDF b{}; b.type = KZ_BSDF_KAZENSTANDARD;
-        b.baseColor[0] = m_baseColor->m_color.r; b.baseColor[1] = m_baseColor->m_color.g; b.baseColor[2] = m_baseColor->m_color.b;
-        b.roughness = m_roughness->m_color.r; b.metallic = m_metallic->m_color.r;       // .r() of the colour, bsdf.cpp:1227,1231
+        bind3(rb, m_baseColor, b.baseColor, b.albedoTex); bind1(rb, m_roughness, b.roughness, b.roughnessTex); bind1(rb, m_metallic, b.metallic, b.metallicTex);
         b.anisotropy = m_anisotropy; b.specular = m_specular; b.specularTint = m_specularTint; b.clearcoat = m_clearcoat;
         b.clearcoatRoughness = m_clearcoatRoughness; b.sheen = m_sheen; b.sheenTint = m_sheenTint;
         return b;
     }
     std::string toString() const override { return "KazenStandardSurface"; }
-    ConstantTexture *m_baseColor = nullptr, *m_roughness = nullptr, *m_metallic = nullptr;
+    Texture *m_baseColor = nullptr, *m_roughness = nullptr, *m_metallic = nullptr;
     float m_anisotropy, m_specular, m_specularTint, m_clearcoat, m_clearcoatRoughness, m_sheen, m_sheenTint;
 };
 
 class Mirror : public BSDF {                         // src/kazen/bsdf.cpp:161-196
 public:
     explicit Mirror(const PropertyList &) {}
-    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_MIRROR; return b; }
+    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_MIRROR; return b; }
     std::string toString() const override { return "Mirror[]"; }
 };
 class Dielectric : public BSDF {                     // src/kazen/bsdf.cpp:98-155
 public:
     explicit Dielectric(const PropertyList &p) { m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); }
-    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_DIELECTRIC; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
+    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_DIELECTRIC; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
     std::string toString() const override { return "Dielectric[]"; }
     float m_intIOR, m_extIOR;
 };
 
-class GGX : public BSDF {                            // src/kazen/bsdf.cpp:629-689 (albedo: a constanttexture child)
+class GGX : public BSDF {                            // src/kazen/bsdf.cpp:629-689 (albedo: a texture child)
 public:
     explicit GGX(const PropertyList &p) { m_roughness = p.getFloat("roughness", 0.5f); m_anisotropy = p.getFloat("anisotropy", 0.f); }
     ~GGX() override { delete m_albedo; }
     void addChild(Object *o) override {
-        auto *c = dynamic_cast<ConstantTexture *>(o);
-        if (o->getClassType() != ETexture || !c) throw Exception("addChild is not supported other than (constant) albedo maps");
-        m_albedo = c;
+        if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than albedi maps");
+        m_albedo = static_cast<Texture *>(o);
     }
     void activate() override { if (!m_albedo) throw Exception("ggx needs an albedo texture"); }
-    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_GGX; b.albedo[0] = m_albedo->m_color.r; b.albedo[1] = m_albedo->m_color.g; b.albedo[2] = m_albedo->m_color.b; b.alpha = m_roughness; b.anisotropy = m_anisotropy; return b; }
+    KzBSDF row(RowBuilder &rb) const override { KzBSDF b{}; b.type = KZ_BSDF_GGX; bind3(rb, m_albedo, b.albedo, b.albedoTex); b.alpha = m_roughness; b.anisotropy = m_anisotropy; return b; }
     std::string toString() const override { return "GGX[]"; }
-    ConstantTexture *m_albedo = nullptr; float m_roughness, m_anisotropy;
+    Texture *m_albedo = nullptr; float m_roughness, m_anisotropy;
 };
 class RoughConductor : public BSDF {                 // src/kazen/bsdf.cpp:692-811
 public:
@@ -223,21 +370,21 @@ public:
         if (i < 0) throw Exception("roughconductor: unknown material \"" + mat + "\" (the reference leaves eta/k uninitialised here)");
         for (int a = 0; a < 3; ++a) { m_eta[a] = T[i][a]; m_k[a] = T[i][3 + a]; }
     }
-    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHCONDUCTOR; b.alpha = m_alpha; for (int a = 0; a < 3; ++a) { b.condEta[a] = m_eta[a]; b.condK[a] = m_k[a]; } return b; }
+    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHCONDUCTOR; b.alpha = m_alpha; for (int a = 0; a < 3; ++a) { b.condEta[a] = m_eta[a]; b.condK[a] = m_k[a]; } return b; }
     std::string toString() const override { return "RoughConductor[]"; }
     float m_alpha, m_eta[3], m_k[3];
 };
 class RoughPlastic : public BSDF {                   // src/kazen/bsdf.cpp:814-943
 public:
     explicit RoughPlastic(const PropertyList &p) { m_alpha = p.getFloat("alpha", 0.1f); m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); m_kd = p.getColor("kd", Color3f(0.5f)); }
-    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHPLASTIC; b.alpha = m_alpha; b.intIOR = m_intIOR; b.extIOR = m_extIOR; b.albedo[0] = m_kd.r; b.albedo[1] = m_kd.g; b.albedo[2] = m_kd.b; return b; }
+    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHPLASTIC; b.alpha = m_alpha; b.intIOR = m_intIOR; b.extIOR = m_extIOR; b.albedo[0] = m_kd.r; b.albedo[1] = m_kd.g; b.albedo[2] = m_kd.b; return b; }
     std::string toString() const override { return "RoughPlastic[]"; }
     float m_alpha, m_intIOR, m_extIOR; Color3f m_kd;
 };
 class RoughDielectric : public BSDF {                // src/kazen/bsdf.cpp:947-1145
 public:
     explicit RoughDielectric(const PropertyList &p) { m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); m_roughness = p.getFloat("roughness", 0.1f); }
-    KzBSDF row() const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHDIELECTRIC; b.alpha = m_roughness; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
+    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHDIELECTRIC; b.alpha = m_roughness; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
     std::string toString() const override { return "RoughDielectric"; }
     float m_intIOR, m_extIOR, m_roughness;
 };
@@ -368,20 +515,25 @@ public:
         if (!m_camera) throw Exception("No camera was specified!");
         if (!m_sampler) m_sampler = static_cast<Sampler *>(ObjectFactory::createInstance("independent", PropertyList()));
         m_bsdfRows.clear(); m_lightRows.clear(); m_meshRows.clear();
+        m_rb = RowBuilder();
+        for (Mesh *m : m_meshes) if (m->m_bsdf) m_rb.nestedBase++;                     // rows wrapped by normalmaps go behind the per-mesh rows
         for (Mesh *m : m_meshes) {
             KzMesh k{}; k.V = m->m_V.data(); k.F = m->m_F.data(); k.N = m->m_N.empty() ? nullptr : m->m_N.data(); k.UV = m->m_UV.empty() ? nullptr : m->m_UV.data();
             k.nV = (uint32_t)(m->m_V.size() / 3); k.nF = (uint32_t)(m->m_F.size() / 3);
             k.bsdf = -1; k.light = -1;
-            if (m->m_bsdf) { m->m_bsdf->activate(); k.bsdf = (int32_t)m_bsdfRows.size(); m_bsdfRows.push_back(m->m_bsdf->row()); }   // no bsdf: default diffuse (mesh.cpp:25-28)
+            if (m->m_bsdf) { m->m_bsdf->activate(); k.bsdf = (int32_t)m_bsdfRows.size(); m_bsdfRows.push_back(m->m_bsdf->row(m_rb)); }   // no bsdf: default diffuse (mesh.cpp:25-28)
             if (m->m_light) { k.light = (int32_t)m_lightRows.size(); m_lightRows.push_back(m->m_light->row()); }
             m_meshRows.push_back(k);
         }
+        for (size_t i = 0; i < m_rb.nested.size(); ++i) m_bsdfRows.push_back(m_rb.nested[i]->row(m_rb));
         m_camera->activate();
         KzSceneDesc d{};
         d.abiVersion = KZ_ABI_VERSION;
         d.meshes = m_meshRows.data(); d.nMeshes = (uint32_t)m_meshRows.size();
         d.bsdfs = m_bsdfRows.data(); d.nBsdfs = (uint32_t)m_bsdfRows.size();
         d.lights = m_lightRows.data(); d.nLights = (uint32_t)m_lightRows.size();
+        d.textures = m_rb.textures.data(); d.nTextures = (uint32_t)m_rb.textures.size();
+        d.images = m_rb.images.data(); d.nImages = (uint32_t)m_rb.images.size();
         d.camera = m_camera->m_c; d.sampler = m_sampler->m_s; d.integrator = m_integrator->m_i;
         if (m_background && m_background->m_nested) {
             d.background.present = 1; d.background.intensity = m_background->m_intensity;
@@ -403,7 +555,7 @@ public:
     std::string toString() const override { return "Scene[]"; }
 private:
     std::vector<Mesh *> m_meshes; Sampler *m_sampler = nullptr; Camera *m_camera = nullptr; Integrator *m_integrator = nullptr; BackgroundTexture *m_background = nullptr;
-    std::vector<KzMesh> m_meshRows; std::vector<KzBSDF> m_bsdfRows; std::vector<KzLight> m_lightRows;
+    std::vector<KzMesh> m_meshRows; std::vector<KzBSDF> m_bsdfRows; std::vector<KzLight> m_lightRows; RowBuilder m_rb;
     KzSceneDesc m_desc{}; KzScene *m_handle = nullptr;
 };
 
@@ -418,7 +570,12 @@ KAZEN_MI355X_REGISTER(GGX, "ggx");
 KAZEN_MI355X_REGISTER(RoughConductor, "roughconductor");
 KAZEN_MI355X_REGISTER(RoughPlastic, "roughplastic");
 KAZEN_MI355X_REGISTER(RoughDielectric, "roughdielectric");
+KAZEN_MI355X_REGISTER(Lambertian, "lambertian");
+KAZEN_MI355X_REGISTER(NormalMap, "normalmap");
 KAZEN_MI355X_REGISTER(ConstantTexture, "constanttexture");
+KAZEN_MI355X_REGISTER(ImageTexture, "imagetexture");
+KAZEN_MI355X_REGISTER(ColorRampTexture, "colorramp");
+KAZEN_MI355X_REGISTER(BlendTexture, "blend");
 KAZEN_MI355X_REGISTER(BackgroundTexture, "background");
 KAZEN_MI355X_REGISTER(PerspectiveCamera, "perspective");
 KAZEN_MI355X_REGISTER(GaussianFilter, "gaussian");

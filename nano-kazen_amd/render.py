@@ -97,16 +97,26 @@ class Scene:
                                                        idx.ctypes.data_as(abi.u32p), out.ctypes.data_as(abi.f32p)))
         return out
 
-    def bsdf_query(self, bsdf, wi, wo, acc, s3):
+    def bsdf_query(self, bsdf, wi, wo, acc, s3, uv=None):
+        """eval (n,3), pdf (n,), sample (n,8) = weight rgb, wo xyz, alive, pdf(bRec) after sample()."""
         bsdf = np.ascontiguousarray(bsdf, np.int32)
         n = bsdf.shape[0]
         wi, wo, s3 = (np.ascontiguousarray(a, np.float32) for a in (wi, wo, s3))
         acc = np.ascontiguousarray(acc, np.float32)
-        ev, pd, sm = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 7), np.float32)
+        uv = None if uv is None else np.ascontiguousarray(uv, np.float32)
+        ev, pd, sm = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 8), np.float32)
         f = lambda a: a.ctypes.data_as(abi.f32p)
         abi.check(self.lib, self.lib.kz_bsdf_query(self.h, n, bsdf.ctypes.data_as(C.POINTER(C.c_int32)), f(wi), f(wo), f(acc), f(s3),
-                                                   f(ev), f(pd), f(sm)))
+                                                   None if uv is None else f(uv), f(ev), f(pd), f(sm)))
         return ev, pd, sm
+
+    def texture_query(self, tex, uv):
+        tex = np.ascontiguousarray(tex, np.int32)
+        uv = np.ascontiguousarray(uv, np.float32)
+        out = np.zeros((tex.shape[0], 3), np.float32)
+        abi.check(self.lib, self.lib.kz_texture_query(self.h, tex.shape[0], tex.ctypes.data_as(C.POINTER(C.c_int32)), uv.ctypes.data_as(abi.f32p),
+                                                      out.ctypes.data_as(abi.f32p)))
+        return out
 
     def set_stats(self, enable=True):
         abi.check(self.lib, self.lib.kz_set_stats(self.h, 1 if enable else 0))

@@ -54,13 +54,17 @@ def pcg32_floats(initseq, n):
 
 
 # ----------------------------------------------------------------------------- description
+def _c3(v):
+    return v if isinstance(v, dict) else tuple(v)
+
+
 def diffuse(albedo=(0.5, 0.5, 0.5)):
-    return {"type": "diffuse", "albedo": tuple(albedo)}
+    return {"type": "diffuse", "albedo": _c3(albedo)}
 
 
 def kazenstandard(baseColor=(0.5, 0.5, 0.5), roughness=0.5, metallic=0.0, anisotropy=0.0, specular=0.5,
                   specularTint=0.5, clearcoat=0.0, clearcoatRoughness=0.5, sheen=0.0, sheenTint=0.5):
-    return {"type": "kazenstandard", "baseColor": tuple(baseColor), "roughness": roughness, "metallic": metallic,
+    return {"type": "kazenstandard", "baseColor": _c3(baseColor), "roughness": roughness, "metallic": metallic,
             "anisotropy": anisotropy, "specular": specular, "specularTint": specularTint, "clearcoat": clearcoat,
             "clearcoatRoughness": clearcoatRoughness, "sheen": sheen, "sheenTint": sheenTint}
 
@@ -79,7 +83,7 @@ CONDUCTORS = {"Au": ((0.1431189557, 0.3749570432, 1.4424785571), (3.9831604247, 
 
 
 def ggx(albedo=(0.5, 0.5, 0.5), roughness=0.5, anisotropy=0.0):
-    return {"type": "ggx", "albedo": tuple(albedo), "roughness": roughness, "anisotropy": anisotropy}
+    return {"type": "ggx", "albedo": _c3(albedo), "roughness": roughness, "anisotropy": anisotropy}
 
 
 def roughconductor(alpha=0.1, material="Au"):
@@ -92,6 +96,39 @@ def roughplastic(alpha=0.1, intIOR=1.5046, extIOR=1.000277, kd=(0.5, 0.5, 0.5)):
 
 def roughdielectric(roughness=0.1, intIOR=1.5046, extIOR=1.000277):
     return {"type": "roughdielectric", "roughness": roughness, "intIOR": intIOR, "extIOR": extIOR}
+
+
+# Texture<Color3f> nodes (texture.cpp). Wherever the reference reads a parameter through a texture child (diffuse/lambertian/ggx
+# "albedo", kiss "baseColor" / "roughness" / "metallic") the BSDF dicts above accept one of these instead of a constant.
+def constanttexture(color=(0.5, 0.5, 0.5)):
+    return {"type": "constanttexture", "color": tuple(color)}
+
+
+def imagetexture(image, scale=1.0, colorspace="srgb"):
+    """image: (H, W, C) uint8 or float32 raster, row 0 = top scan line (what OpenImageIO decodes from the file)."""
+    a = np.asarray(image)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    a = np.ascontiguousarray(a, np.uint8 if a.dtype == np.uint8 else np.float32)
+    return {"type": "imagetexture", "image": a, "scale": float(scale), "colorspace": colorspace}
+
+
+def colorramp(nested=None, min=0.0, max=1.0):
+    return {"type": "colorramp", "min": float(min), "max": float(max), "nested": nested}
+
+
+def blend(mask=None, input1=None, input2=None, blendmode="mix"):
+    return {"type": "blend", "blendmode": blendmode, "mask": mask, "input1": input1, "input2": input2}
+
+
+def lambertian(albedo):
+    """"lambertian" (bsdf.cpp:202-276) = the diffuse model with its albedo read through a texture."""
+    return {"type": "diffuse", "albedo": albedo}
+
+
+def normalmap(normal, nested):
+    """"normalmap" (bsdf.cpp:281-417): `normal` is a texture dict, `nested` a BSDF dict (not itself a normalmap)."""
+    return {"type": "normalmap", "normal": normal, "nested": nested}
 
 
 def area(color=(1.0, 1.0, 1.0), intensity=1.0, lightPrimaryVisibility=False):
@@ -159,17 +196,53 @@ class SceneDescription:
             else:
                 k.light = len(lights)
                 lights.append(m["light"])
+        # normalmap rows reference their nested BSDF by row index: nested rows go behind the per-mesh rows
+        i = 0
+        while i < len(bsdfs):
+            if bsdfs[i]["type"] == "normalmap":
+                bsdfs.append(bsdfs[i]["nested"])
+                bsdfs[i] = dict(bsdfs[i], _nested=len(bsdfs) - 1)
+            i += 1
+        textures, images, tex_ids = [], [], {}
+
+        def tex_id(t):
+            """1-based texture id of a texture dict (children first), 0 for None."""
+            if t is None:
+                return 0
+            if id(t) in tex_ids:
+                return tex_ids[id(t)]
+            kids = {"colorramp": ("nested",), "blend": ("mask", "input1", "input2")}.get(t["type"], ())
+            child = [tex_id(t.get(c)) - 1 for c in kids] + [-1] * (3 - len(kids))
+            row = {"t": t, "child": child, "image": -1}
+            if t["type"] == "imagetexture":
+                row["image"] = len(images)
+                images.append(t["image"])
+            textures.append(row)
+            tex_ids[id(t)] = len(textures)
+            return len(textures)
+
+        def param(k, b, name, field, texfield):
+            v = b[name]
+            if isinstance(v, dict):
+                setattr(k, texfield, tex_id(v))
+            elif isinstance(field, str) and field in ("roughness", "metallic"):
+                setattr(k, field, v)
+            else:
+                getattr(k, field)[:] = v
+
         cb = (abi.KzBSDF * max(1, len(bsdfs)))()
         for i, b in enumerate(bsdfs):
             k = cb[i]
             if b["type"] == "diffuse":
                 k.type = abi.KZ_BSDF_DIFFUSE
-                k.albedo[:] = b["albedo"]
+                param(k, b, "albedo", "albedo", "albedoTex")
                 k.specular, k.specularTint, k.clearcoatRoughness, k.sheenTint = 0.5, 0.5, 0.5, 0.5
             elif b["type"] == "kazenstandard":
                 k.type = abi.KZ_BSDF_KAZENSTANDARD
-                k.baseColor[:] = b["baseColor"]
-                for f in ("roughness", "metallic", "anisotropy", "specular", "specularTint", "clearcoat",
+                param(k, b, "baseColor", "baseColor", "albedoTex")
+                param(k, b, "roughness", "roughness", "roughnessTex")
+                param(k, b, "metallic", "metallic", "metallicTex")
+                for f in ("anisotropy", "specular", "specularTint", "clearcoat",
                           "clearcoatRoughness", "sheen", "sheenTint"):
                     setattr(k, f, b[f])
             elif b["type"] == "mirror":
@@ -179,7 +252,7 @@ class SceneDescription:
                 k.intIOR, k.extIOR = b["intIOR"], b["extIOR"]
             elif b["type"] == "ggx":
                 k.type = abi.KZ_BSDF_GGX
-                k.albedo[:] = b["albedo"]
+                param(k, b, "albedo", "albedo", "albedoTex")
                 k.alpha, k.anisotropy = b["roughness"], b["anisotropy"]
             elif b["type"] == "roughconductor":
                 k.type = abi.KZ_BSDF_ROUGHCONDUCTOR
@@ -192,8 +265,28 @@ class SceneDescription:
             elif b["type"] == "roughdielectric":
                 k.type = abi.KZ_BSDF_ROUGHDIELECTRIC
                 k.alpha, k.intIOR, k.extIOR = b["roughness"], b["intIOR"], b["extIOR"]
+            elif b["type"] == "normalmap":
+                k.type = abi.KZ_BSDF_NORMALMAP
+                k.normalTex = tex_id(b["normal"])
+                k.nested = b["_nested"]
             else:
                 k.type = 99      # unsupported plugin: the library must answer KZ_ERR_UNSUPPORTED
+        ct = (abi.KzTexture * max(1, len(textures)))()
+        for i, row in enumerate(textures):
+            t, k = row["t"], ct[i]
+            k.type = {"constanttexture": abi.KZ_TEX_CONSTANT, "imagetexture": abi.KZ_TEX_IMAGE, "colorramp": abi.KZ_TEX_COLORRAMP,
+                      "blend": abi.KZ_TEX_BLEND}.get(t["type"], 99)
+            k.color[:] = t.get("color", (0.5, 0.5, 0.5))
+            k.image, k.scale, k.srgb = row["image"], t.get("scale", 1.0), 1 if t.get("colorspace", "srgb") == "srgb" else 0
+            k.rampMin, k.rampMax = t.get("min", 0.0), t.get("max", 1.0)
+            k.blendMode = {"mix": abi.KZ_BLEND_MIX, "multiply": abi.KZ_BLEND_MULTIPLY}.get(t.get("blendmode", "mix"), abi.KZ_BLEND_NONE)
+            k.child[:] = row["child"]
+        ci = (abi.KzImage * max(1, len(images)))()
+        for i, a in enumerate(images):
+            ci[i].pixels = a.ctypes.data
+            ci[i].height, ci[i].width, ci[i].channels = a.shape
+            ci[i].format = abi.KZ_PIXEL_U8 if a.dtype == np.uint8 else abi.KZ_PIXEL_F32
+        self.n_bsdf_rows, self.n_textures = len(bsdfs), len(textures)
         cl = (abi.KzLight * max(1, len(lights)))()
         for i, l in enumerate(lights):
             cl[i].color[:] = l["color"]
@@ -204,6 +297,8 @@ class SceneDescription:
         d.meshes, d.nMeshes = cm, len(self.meshes)
         d.bsdfs, d.nBsdfs = cb, len(bsdfs)
         d.lights, d.nLights = cl, len(lights)
+        d.textures, d.nTextures = ct, len(textures)
+        d.images, d.nImages = ci, len(images)
         cam = self.camera
         d.camera.type = {"perspective": abi.KZ_CAMERA_PERSPECTIVE, "thinlens": abi.KZ_CAMERA_THINLENS}.get(cam["type"], 99)
         d.camera.apertureRadius = cam.get("apertureRadius", 1.0)
@@ -241,7 +336,7 @@ class SceneDescription:
             d.background.present = 1
             d.background.color[:] = self.background["color"]
             d.background.intensity = self.background.get("intensity", 1.0)
-        keep += [cm, cb, cl]
+        keep += [cm, cb, cl, ct, ci, images]
         self._keep = keep
         return d
 
@@ -473,6 +568,58 @@ def materials_scene(width=160, height=96, spp=16, sampler="independent", seed=0,
     s.camera.update(width=width, height=height, fov=42.0, nearClip=0.1, farClip=100.0, toWorld=look_at((0, 3.2, 9.5), (0, 0.9, 1.0), (0, 1, 0)))
     s.sampler = {"type": sampler, "sampleCount": spp, "seed": seed}
     s.integrator["maxDepth"] = maxDepth
+    return s
+
+
+def _test_images(seed=7):
+    """Small procedural rasters: an 8x8 sRGB checker, a 32x32 colour noise (u8), a 16x16 one-channel float map, and a 32x32
+    tangent-space normal map of a bump field (linear, u8)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:8, 0:8]
+    chk = np.where(((xx + yy) & 1)[:, :, None] == 0, np.array([230, 225, 210], np.uint8), np.array([40, 60, 120], np.uint8)).astype(np.uint8)
+    noise = rng.integers(30, 255, (32, 32, 3), dtype=np.uint8)
+    gray = rng.random((16, 16, 1), dtype=np.float32)
+    y, x = np.mgrid[0:32, 0:32] / 32.0
+    hgt = 0.06 * (np.sin(2 * np.pi * 3 * x) * np.cos(2 * np.pi * 2 * y))
+    dx = np.roll(hgt, -1, 1) - np.roll(hgt, 1, 1)
+    dy = np.roll(hgt, -1, 0) - np.roll(hgt, 1, 0)
+    n = np.stack([-dx * 16, -dy * 16, np.ones_like(hgt)], -1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    nrm = np.clip(np.rint((n * 0.5 + 0.5) * 255), 0, 255).astype(np.uint8)
+    return chk, noise, gray, nrm
+
+
+def textured_scene(width=160, height=96, spp=16, sampler="independent", seed=0, maxDepth=6, regularization=True):
+    """SURVEY 8f rank 4 in one frame: image / colorramp / blend textures behind diffuse ("lambertian"), ggx and kazenstandard
+    parameters, and normalmap rows over kazenstandard, diffuse, roughconductor and dielectric."""
+    chk, noise, gray, nrm = _test_images()
+    t_chk = imagetexture(chk, scale=6.0, colorspace="srgb")
+    t_noise = imagetexture(noise, scale=2.0, colorspace="srgb")
+    t_gray = imagetexture(gray, scale=3.0, colorspace="linear")
+    t_nrm = imagetexture(nrm, scale=2.0, colorspace="linear")
+    s = SceneDescription()
+    s.add_mesh(*_vfnuv(quad((-8, 0, -4), (8, 0, -4), (8, 0, 6), (-8, 0, 6), flip=True)), bsdf=lambertian(t_chk))
+    wall = blend(mask=t_gray, input1=constanttexture((0.8, 0.25, 0.2)), input2=t_noise, blendmode="mix")
+    s.add_mesh(*_vfnuv(quad((-8, 0, -4), (-8, 6, -4), (8, 6, -4), (8, 0, -4), flip=True)), bsdf=lambertian(wall))
+    rows = [kazenstandard(t_noise, colorramp(t_gray, 0.1, 0.8), t_gray, clearcoat=0.5),
+            normalmap(t_nrm, kazenstandard((0.8, 0.5, 0.2), colorramp(t_gray, 0.2, 0.6), 0.0, specular=0.8)),
+            normalmap(t_nrm, diffuse((0.3, 0.7, 0.4))),
+            ggx(blend(None, t_chk, t_noise, "multiply"), 0.35),
+            normalmap(t_nrm, roughconductor(0.25, "Cu")),
+            normalmap(t_nrm, dielectric()),
+            normalmap(t_nrm, lambertian(t_chk)),
+            kazenstandard((0.6, 0.6, 0.65), t_gray, 1.0)]
+    for i, r in enumerate(rows):
+        x = -3.0 + (i % 4) * 2.0
+        z = 0.0 if i < 4 else 2.4
+        s.add_mesh(*_vfnuv(uv_sphere((x, 0.8, z), 0.8, 20, 21)), bsdf=r)
+    for (cx, cz, inten) in ((-3.0, 1.5, 14.0), (3.0, 2.5, 10.0)):
+        q = quad((cx - 1, 5.0, cz - 1), (cx - 1, 5.0, cz + 1), (cx + 1, 5.0, cz + 1), (cx + 1, 5.0, cz - 1), flip=True)
+        s.add_mesh(*_vfnuv(q), bsdf=diffuse((0, 0, 0)), light=area((1, 1, 1), inten, False))
+    s.camera.update(width=width, height=height, fov=42.0, nearClip=0.1, farClip=100.0, toWorld=look_at((0, 3.2, 9.5), (0, 0.9, 1.0), (0, 1, 0)))
+    s.sampler = {"type": sampler, "sampleCount": spp, "seed": seed}
+    s.integrator["maxDepth"] = maxDepth
+    s.integrator["regularization"] = regularization
     return s
 
 

@@ -6,7 +6,8 @@ Follows the reference's loader so that the unchanged scene files drive the MI355
   * value parsing                       string::toVector3f / tokenize on ", " (common.cpp), toBool "true"/"false"
   * OBJ loading                         src/kazen/mesh.cpp:200-343: v transformed by toWorld, vn by the inverse transpose and
                                         normalised, (p,uv,n) triples deduplicated in encounter order, quads split (0,1,2),(3,0,2)
-Plugins outside the supported set raise ValueError (never a silent fallback); image textures are not supported.
+Plugins outside the supported set raise ValueError (never a silent fallback). Image files of <texture type="imagetexture"> are
+decoded with PIL (8-bit PNG/JPEG -> u8 raster, 16-bit -> float), which is what OpenImageIO's reader hands the texture system.
 Host-side I/O only: nothing here is on the per-sample path.
 """
 import math
@@ -115,21 +116,83 @@ def _children(node, tag):
 
 def _const_texture(node):
     if node.get("type") != "constanttexture":
-        raise ValueError("texture type \"%s\" is not supported (only constanttexture)" % node.get("type"))
-    return tuple(_props(node).get("color", (0.0, 0.0, 0.0)))
+        raise ValueError("texture type \"%s\" is not supported here (only constanttexture)" % node.get("type"))
+    return tuple(_props(node).get("color", (0.5, 0.5, 0.5)))              # texture.cpp:13
 
 
-def _bsdf(node):
+def _load_image(path):
+    from PIL import Image
+    if not os.path.exists(path):
+        raise ValueError("imagetexture: file \"%s\" does not exist" % path)
+    try:
+        im = Image.open(path)
+        im.load()
+    except Exception as e:                                                 # e.g. OpenEXR: no decoder in this environment
+        raise ValueError("imagetexture: cannot decode \"%s\" (%s)" % (path, e))
+    if im.mode in ("I;16", "I;16B", "I"):
+        return (np.asarray(im, np.float32) / np.float32(65535.0))[:, :, None]
+    if im.mode == "F":
+        return np.asarray(im, np.float32)[:, :, None]
+    if im.mode not in ("L", "RGB", "RGBA"):
+        im = im.convert("RGBA" if "A" in im.getbands() else "RGB")
+    a = np.asarray(im, np.uint8)
+    return a[:, :, None] if a.ndim == 2 else a
+
+
+def _texture(node, base, folded=False):
+    """<texture> -> texture dict (texture.cpp). folded=True returns a constanttexture as its colour tuple (the folded form)."""
     t = node.get("type")
     p = _props(node)
-    tex = {c.get("id", ""): _const_texture(c) for c in _children(node, "texture")}
+    kids = _children(node, "texture")
+    if t == "constanttexture":
+        c = tuple(p.get("color", (0.5, 0.5, 0.5)))
+        return c if folded else S.constanttexture(c)
+    if t == "imagetexture":
+        if "filename" not in p:
+            raise ValueError("imagetexture needs a \"filename\"")
+        fn = p["filename"] if os.path.isabs(p["filename"]) else os.path.join(base, p["filename"])     # the resolver appends the scene's directory (main.cpp)
+        return S.imagetexture(_load_image(fn), p.get("scale", 1.0), p.get("colorspace", "srgb"))
+    if t == "colorramp":
+        if len(kids) > 1:
+            raise ValueError("colorramp takes one nested texture")
+        return S.colorramp(_texture(kids[0], base) if kids else None, p.get("min", 0.0), p.get("max", 1.0))
+    if t == "blend":
+        slot = {}
+        for k in kids:                                                      # texture.cpp:241-262: children are matched by id
+            cid = k.get("id", "")
+            if cid not in ("mask", "input1", "input2"):
+                raise ValueError("The name of this texture does not match any field!")
+            if cid in slot:
+                raise ValueError("There is already an %s defined!" % cid)
+            slot[cid] = _texture(k, base)
+        return S.blend(slot.get("mask"), slot.get("input1"), slot.get("input2"), p.get("blendmode", "mix"))
+    raise ValueError("texture type \"%s\" is not supported by the MI355X core" % t)
+
+
+def _bsdf(node, base="."):
+    t = node.get("type")
+    p = _props(node)
+    tkids = _children(node, "texture")
+    tex = {c.get("id", ""): _texture(c, base, folded=True) for c in tkids}
     if t == "diffuse":
         return S.diffuse(p.get("albedo", (0.5, 0.5, 0.5)))
+    if t == "lambertian":                                                   # bsdf.cpp:259-262: any texture child is the albedo
+        if not tex:
+            raise ValueError("lambertian needs an albedo texture child")
+        return S.lambertian(_texture(tkids[-1], base))
+    if t == "normalmap":                                                    # bsdf.cpp:391-404
+        nested = _children(node, "bsdf")
+        if not tkids or len(nested) != 1:
+            raise ValueError("normalmap needs a normal texture child and one nested bsdf")
+        if nested[0].get("type") == "normalmap":
+            raise ValueError("a normalmap nested in a normalmap is not supported by the MI355X core")
+        return S.normalmap(_texture(tkids[-1], base), _bsdf(nested[0], base))
     if t == "kazenstandard":
         for k in ("baseColor", "roughness", "metallic"):
             if k not in tex:
-                raise ValueError("kazenstandard needs a constanttexture child with id=\"%s\"" % k)
-        return S.kazenstandard(tex["baseColor"], tex["roughness"][0], tex["metallic"][0], p.get("anisotropy", 0.0), p.get("specular", 0.5),
+                raise ValueError("kazenstandard needs a texture child with id=\"%s\"" % k)
+        rough, metal = (v if isinstance(v, dict) else v[0] for v in (tex["roughness"], tex["metallic"]))
+        return S.kazenstandard(tex["baseColor"], rough, metal, p.get("anisotropy", 0.0), p.get("specular", 0.5),
                                p.get("specularTint", 0.5), p.get("clearcoat", 0.0), p.get("clearcoatRoughness", 0.5), p.get("sheen", 0.0), p.get("sheenTint", 0.5))
     if t == "mirror":
         return S.mirror()
@@ -137,8 +200,8 @@ def _bsdf(node):
         return S.dielectric(p.get("intIOR", 1.5046), p.get("extIOR", 1.000277))
     if t == "ggx":
         if not tex:
-            raise ValueError("ggx needs an albedo constanttexture child")
-        return S.ggx(next(iter(tex.values())), p.get("roughness", 0.5), p.get("anisotropy", 0.0))
+            raise ValueError("ggx needs an albedo texture child")
+        return S.ggx(list(tex.values())[-1], p.get("roughness", 0.5), p.get("anisotropy", 0.0))
     if t == "roughconductor":
         mat = p.get("material", "Au")
         if mat not in S.CONDUCTORS:
@@ -263,7 +326,7 @@ def load_xml(path, overrides=None):
                     raise ValueError("light \"%s\" is not supported" % ls[0].get("type"))
                 lp = _props(ls[0])
                 light = S.area(lp.get("color", (1.0, 1.0, 1.0)), lp.get("intensity", 1.0), lp.get("lightPrimaryVisibility", False))
-            s.add_mesh(V, F, N, UV, bsdf=_bsdf(bs[0]) if bs else None, light=light)
+            s.add_mesh(V, F, N, UV, bsdf=_bsdf(bs[0], base) if bs else None, light=light)
         elif node.tag in OBJECT_TAGS:
             raise ValueError("Scene::addChild(<%s>) is not supported!" % node.tag)
         else:

@@ -241,6 +241,7 @@ struct Intersection {
     Frame shFrame, geoFrame;
     int mesh = -1;
     float accumulatedRoughness = 0.f;   // mesh.h:40
+    V3 dpdu;                            // mesh.h:33 (H12: defined as shFrame.s wherever accel.cpp leaves it unset)
     // extra (not in the reference record): prim ids for ray-level tests
     int prim = -1;
     float bu = 0, bv = 0;
@@ -266,6 +267,9 @@ struct Scene {
     std::vector<MeshData> meshes;
     std::vector<KzBSDF> bsdfs;
     std::vector<KzLight> lights;
+    std::vector<KzTexture> textures;         // Texture<Color3f> nodes (texture.cpp)
+    struct Image { int w, h, c, fmt; std::vector<uint8_t> px; };
+    std::vector<Image> images;
     std::vector<int> lightMeshes;            // Scene::m_lights (scene.cpp:42-46), mesh order
     KzCamera cam;
     KzSampler smp;
@@ -541,6 +545,7 @@ static bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its, boo
     V3 dp0 = p1 - p0, dp1 = p2 - p0;
     its.geoFrame = Frame(normalized(cross(dp0, dp1)));                           // accel.cpp:156-158
     float uv0x = 0, uv0y = 0, uv1x = 0, uv1y = 0, uv2x = 0, uv2y = 0;
+    bool tangent = false;
     if (hasUV) {                                                                 // accel.cpp:161-164
         uv0x = md.UV[2 * idx0]; uv0y = md.UV[2 * idx0 + 1];
         uv1x = md.UV[2 * idx1]; uv1y = md.UV[2 * idx1 + 1];
@@ -561,8 +566,9 @@ static bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its, boo
                 its.shFrame.n = normalized(shNormal);
                 its.shFrame.s = normalized(dpdu - shNormal * dot(shNormal, dpdu));
                 its.shFrame.t = normalized(cross(its.shFrame.n, its.shFrame.s));
+                its.dpdu = dpdu; tangent = true;
             } else {
-                its.shFrame = Frame(normalized(shNormal));
+                its.shFrame = Frame(normalized(shNormal));                       // accel.cpp:203-212 sets dpdu = shFrame.s here
             }
         } else {
             its.shFrame = Frame(normalized(shNormal));
@@ -573,6 +579,10 @@ static bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its, boo
     } else {
         its.shFrame = its.geoFrame;                                              // accel.cpp:231-233
     }
+    // H12: in the branches that never assign its.dpdu the reference reads whatever the record held before (the previous
+    // bounce's value, or uninitialised memory). Only NormalMap::getFrame reads it; defined here as shFrame.s, the value
+    // the degenerate-uv branch assigns.
+    if (!tangent) its.dpdu = its.shFrame.s;
     return true;
 }
 
@@ -665,7 +675,14 @@ static V3 evaluateGGXSmithBRDF(V3 V, V3 L, V3 f0, float roughness, float anisotr
 // BSDFs. BSDFQueryRecord: wi, wo local; measure; eta (bsdf.h:20-53).
 // ---------------------------------------------------------------------------------
 enum { EUnknownMeasure = 0, ESolidAngle = 1, EDiscrete = 2 };
-struct BRec { V3 wi, wo; float eta = 1.f; int measure = EUnknownMeasure; float accumulatedRoughness = 0.f; };
+// bRec.its (bsdf.h:22) is a COPY of the integrator's record (integrator.cpp:284,306) and default-constructed in the
+// records NormalMap builds (accumulatedRoughness 0, bsdf.cpp:301,325,350); uv is set beside it.
+struct BRec {
+    V3 wi, wo; float eta = 1.f; int measure = EUnknownMeasure; float accumulatedRoughness = 0.f;
+    float uvx = 0.f, uvy = 0.f;
+    const Scene *sc = nullptr;          // where the Texture children live
+    const Intersection *its = nullptr;  // bRec.its: shFrame, dpdu, uv (NormalMap only)
+};
 
 static inline float lerpf(float t, float v1, float v2) { return (1.f - t) * v1 + t * v2; }   // common.h:255-257
 static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -677,10 +694,73 @@ static inline float schlickWeight(float x) {                               // bs
 static inline V3 lerp3(V3 c1, V3 c2, float t) { return (1.f - t) * c1 + t * c2; }   // bsdf.cpp:1181-1183
 static inline float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }   // common.cpp:393-395
 
-// a20 Diffuse (bsdf.cpp:27-75)
+
+// ---------------------------------------------------------------------------------
+// textures (src/kazen/texture.cpp). ImageTexture::eval hands (u*scale, (1-v)*scale) with zero
+// derivatives and periodic wrap to OpenImageIO's TextureSystem::texture (texture.cpp:46-64). OpenImageIO (pinned only
+// as "find_package(OpenImageIO)" by the reference, no version, not vendored) is absent from the checkout, so its
+// filter cannot be restated from source: the lookup is DECLARED as bilinear over the full-resolution level with
+// texel centres at (i+0.5)/res, as SURVEY 8f row 4 specifies. Parity of this one function is unpinned.
+// ---------------------------------------------------------------------------------
+static inline float texelAt(const Scene::Image &im, int x, int y, int c) {
+    if (c >= im.c) return 0.0f;                                                  // missing channels: TextureOpt::fill = 0
+    size_t i = ((size_t)y * (size_t)im.w + (size_t)x) * (size_t)im.c + (size_t)c;
+    if (im.fmt == KZ_PIXEL_F32) { float v; std::memcpy(&v, im.px.data() + 4 * i, 4); return v; }
+    return (float)im.px[i] * (1.0f / 255.0f);
+}
+static inline int wrapPeriodic(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+static inline float srgbToLinear(float v) {                                      // Color3f::toLinearRGB, common.cpp:368-382
+    return v <= 0.04045f ? v * (1.0f / 12.92f) : std::pow((v + 0.055f) * (1.0f / 1.055f), 2.4f);
+}
+static V3 imageLookup(const Scene &sc, const KzTexture &k, float u, float v) {
+    const Scene::Image &im = sc.images[k.image];
+    float s = u * k.scale, t = (1.0f - v) * k.scale;                             // texture.cpp:55
+    float x = s * (float)im.w - 0.5f, y = t * (float)im.h - 0.5f;
+    if (!(std::fabs(x) < 1.0e9f) || !(std::fabs(y) < 1.0e9f)) return V3(0.f);
+    float fx0 = std::floor(x), fy0 = std::floor(y);
+    float fx = x - fx0, fy = y - fy0;
+    int x0 = wrapPeriodic((int)fx0, im.w), x1 = wrapPeriodic((int)fx0 + 1, im.w);
+    int y0 = wrapPeriodic((int)fy0, im.h), y1 = wrapPeriodic((int)fy0 + 1, im.h);
+    float r[3];
+    for (int c = 0; c < 3; ++c) {
+        float top = (1.0f - fx) * texelAt(im, x0, y0, c) + fx * texelAt(im, x1, y0, c);
+        float bot = (1.0f - fx) * texelAt(im, x0, y1, c) + fx * texelAt(im, x1, y1, c);
+        r[c] = (1.0f - fy) * top + fy * bot;
+        if (k.srgb) r[c] = srgbToLinear(r[c]);                                   // texture.cpp:60-61
+    }
+    return V3(r[0], r[1], r[2]);
+}
+// Texture<Color3f>::eval(uv) by recursion over the node table, like the virtual calls of texture.cpp
+static V3 textureEval(const Scene &sc, int t, float u, float v) {
+    const KzTexture &k = sc.textures[t];
+    switch (k.type) {
+    case KZ_TEX_CONSTANT: return V3(k.color[0], k.color[1], k.color[2]);        // texture.cpp:16-18
+    case KZ_TEX_IMAGE: return imageLookup(sc, k, u, v);
+    case KZ_TEX_COLORRAMP: {                                                     // texture.cpp:162-172
+        if (k.child[0] < 0) return V3(0.f);
+        V3 c = textureEval(sc, k.child[0], u, v);
+        auto ramp = [&](float in) { in = clampf(in, 0.0f, 1.0f); return k.rampMin + (k.rampMax - k.rampMin) * in; };
+        return V3(ramp(c.x), ramp(c.y), ramp(c.z)); }
+    default: {                                                                   // blend, texture.cpp:211-237
+        V3 mask(0.5f), input1(0.f), input2(1.f);
+        if (k.child[0] >= 0) mask = textureEval(sc, k.child[0], u, v);
+        if (k.child[1] >= 0) input1 = textureEval(sc, k.child[1], u, v);
+        if (k.child[2] >= 0) input2 = textureEval(sc, k.child[2], u, v);
+        if (k.blendMode == KZ_BLEND_MIX) return V3(lerpf(mask.x, input1.x, input2.x), lerpf(mask.x, input1.y, input2.y), lerpf(mask.x, input1.z, input2.z));
+        if (k.blendMode == KZ_BLEND_MULTIPLY) return V3(input1.x * input2.x, input1.y * input2.y, input1.z * input2.z);
+        return V3(0.f); }
+    }
+}
+// m_albedo->eval(bRec.uv) etc.: a texture id of 0 is the folded constanttexture
+static inline V3 albedoAt(const KzBSDF &m, const BRec &b) { return m.albedoTex ? textureEval(*b.sc, m.albedoTex - 1, b.uvx, b.uvy) : V3(m.albedo[0], m.albedo[1], m.albedo[2]); }
+static inline V3 baseColorAt(const KzBSDF &m, const BRec &b) { return m.albedoTex ? textureEval(*b.sc, m.albedoTex - 1, b.uvx, b.uvy) : V3(m.baseColor[0], m.baseColor[1], m.baseColor[2]); }
+static inline float roughnessAt(const KzBSDF &m, const BRec &b) { return m.roughnessTex ? textureEval(*b.sc, m.roughnessTex - 1, b.uvx, b.uvy).x : m.roughness; }
+static inline float metallicAt(const KzBSDF &m, const BRec &b) { return m.metallicTex ? textureEval(*b.sc, m.metallicTex - 1, b.uvx, b.uvy).x : m.metallic; }
+
+// a20 Diffuse (bsdf.cpp:27-75); with a texture child: Lambertian (bsdf.cpp:202-276)
 static V3 diffuseEval(const KzBSDF &m, const BRec &b) {
     if (b.measure != ESolidAngle || b.wi.z <= 0 || b.wo.z <= 0) return V3(0.f);
-    return V3(m.albedo[0], m.albedo[1], m.albedo[2]) * INV_PI * b.wo.z;
+    return albedoAt(m, b) * INV_PI * b.wo.z;
 }
 static float diffusePdf(const KzBSDF &, const BRec &b) {
     if (b.measure != ESolidAngle || b.wi.z <= 0 || b.wo.z <= 0) return 0.f;
@@ -692,16 +772,16 @@ static V3 diffuseSample(const KzBSDF &m, BRec &b, float, float s2x, float s2y, b
     b.measure = ESolidAngle;
     b.wo = squareToCosineHemisphere(s2x, s2y);
     b.eta = 1.0f;
-    return V3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    return albedoAt(m, b);
 }
 
 // a21 KazenStandardSurface (bsdf.cpp:1215-1267 eval, :1269-1299 pdf, :1301-1371 sample)
 static V3 kissEval(const KzBSDF &m, const BRec &b) {
     if (b.wi.z <= 0 || b.wo.z <= 0) return V3(0.f);
     V3 V = b.wi, L = b.wo, H = normalized(V + L);
-    V3 Cdlin(m.baseColor[0], m.baseColor[1], m.baseColor[2]);
-    float metallic = m.metallic;
-    float roughness = std::min(1.f, m.roughness + b.accumulatedRoughness);
+    V3 Cdlin = baseColorAt(m, b);
+    float metallic = metallicAt(m, b);
+    float roughness = std::min(1.f, roughnessAt(m, b) + b.accumulatedRoughness);
     float Cdlum = luminance(Cdlin);
     V3 Ctint = Cdlum > 0.f ? Cdlin / Cdlum : V3(1.f);
     V3 Ctintmix = 0.08f * m.specular * lerp3(V3(1.f), Ctint, m.specularTint);
@@ -720,11 +800,11 @@ static V3 kissEval(const KzBSDF &m, const BRec &b) {
 }
 static float kissPdf(const KzBSDF &m, const BRec &b) {
     if (b.wi.z <= 0 || b.wo.z <= 0) return 0.f;
-    float diffuse = (1.f - m.metallic) * 0.5f;
+    float diffuse = (1.f - metallicAt(m, b)) * 0.5f;
     float GTR2 = 1.f / (1.f + m.clearcoat);
     V3 H = normalized(b.wi + b.wo);
     float jacobian = 4.0f * dot(b.wi, H);
-    float roughness = std::min(1.f, m.roughness + b.accumulatedRoughness);
+    float roughness = std::min(1.f, roughnessAt(m, b) + b.accumulatedRoughness);
     A2 alpha = roughnessToAlpha(roughness, m.anisotropy);
     float specPdf = ggxSmithVNDF(b.wi, H, alpha) / jacobian;
     A2 coatalpha = roughnessToAlpha(lerpf(m.clearcoatRoughness, .01f, .3f), 0.f);
@@ -736,14 +816,14 @@ static V3 kissSample(const KzBSDF &m, BRec &b, float sample1, float s2x, float s
     if (b.wi.z <= 0) { ok = false; return V3(0.f); }
     ok = true;
     b.measure = ESolidAngle; b.eta = 1.0f;
-    float diffuse = (1.f - m.metallic) * 0.5f;
+    float diffuse = (1.f - metallicAt(m, b)) * 0.5f;
     if (sample1 < diffuse) {
         b.wo = squareToCosineHemisphere(s2x, s2y);
     } else {
         float sample = (sample1 - diffuse) / (1.f - diffuse);
         float GTR2 = 1.f / (1.f + m.clearcoat);
         V3 H; bool flip = b.wi.z <= 0.f;
-        A2 alpha = (sample < GTR2) ? roughnessToAlpha(m.roughness, m.anisotropy)             // H7: no accumulatedRoughness
+        A2 alpha = (sample < GTR2) ? roughnessToAlpha(roughnessAt(m, b), m.anisotropy)       // H7: no accumulatedRoughness
                                    : roughnessToAlpha(lerpf(m.clearcoatRoughness, 0.01f, .3f), 0.f);
         H = sampleGGXSmithVNDF(flip ? -b.wi : b.wi, alpha, s2x, s2y);
         H = flip ? -H : H;
@@ -834,7 +914,7 @@ static float fresnelDielectricT(float cosThetaI_, float eta, float &cosThetaT_) 
 // GGX ("ggx", bsdf.cpp:629-689) with a constant albedo; alpha field = "roughness"
 static V3 ggxEval(const KzBSDF &m, const BRec &b) {
     if (b.wi.z <= 0 || b.wo.z <= 0) return V3(0.f);
-    return evaluateGGXSmithBRDF(b.wi, b.wo, V3(m.albedo[0], m.albedo[1], m.albedo[2]), m.alpha, m.anisotropy) * b.wo.z;
+    return evaluateGGXSmithBRDF(b.wi, b.wo, albedoAt(m, b), m.alpha, m.anisotropy) * b.wo.z;
 }
 static float ggxPdf(const KzBSDF &m, const BRec &b) {
     if (b.wi.z <= 0 || b.wo.z <= 0) return 0.f;
@@ -848,7 +928,7 @@ static V3 ggxSample(const KzBSDF &m, BRec &b, float s2x, float s2y, bool &ok) { 
     V3 H = sampleGGXSmithVNDF(b.wi, alpha, s2x, s2y);            // wi.z > 0: no flip
     b.wo = reflect(b.wi, H);                                     // NOT normalised here (ggx_brdf.h:189)
     float pdf = ggxSmithVNDF(b.wi, H, alpha) / (4.0f * dot(b.wi, H));
-    V3 color = evaluateGGXSmithBRDF(b.wi, b.wo, V3(m.albedo[0], m.albedo[1], m.albedo[2]), m.alpha, m.anisotropy);
+    V3 color = evaluateGGXSmithBRDF(b.wi, b.wo, albedoAt(m, b), m.alpha, m.anisotropy);
     if (b.wo.z <= 0) return V3(0.f);
     return color * b.wo.z / pdf;                                 // measure stays EUnknownMeasure, eta stays 1
 }
@@ -978,11 +1058,11 @@ static V3 rdielSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, 
 }
 
 static const KzBSDF &meshBsdf(const Scene &sc, int mesh) {
-    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f, 1.5046f, 1.000277f, 0.1f, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f, 1.5046f, 1.000277f, 0.1f, {0, 0, 0}, {0, 0, 0}, 0, 0, 0, 0, 0, {0, 0}};
     int b = sc.meshes[mesh].bsdf;
     return b < 0 ? dflt : sc.bsdfs[b];
 }
-static V3 bsdfEval(const KzBSDF &m, const BRec &b) {
+static V3 nestedEval(const KzBSDF &m, const BRec &b) {
     if (m.type == KZ_BSDF_DIFFUSE) return diffuseEval(m, b);
     if (m.type == KZ_BSDF_KAZENSTANDARD) return kissEval(m, b);
     if (m.type == KZ_BSDF_GGX) return ggxEval(m, b);
@@ -991,7 +1071,7 @@ static V3 bsdfEval(const KzBSDF &m, const BRec &b) {
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) return rdielEval(m, b);
     return V3(0.f);                                                     // discrete BRDFs evaluate to zero (bsdf.cpp:109-112,165-168)
 }
-static float bsdfPdf(const KzBSDF &m, const BRec &b) {
+static float nestedPdf(const KzBSDF &m, const BRec &b) {
     if (m.type == KZ_BSDF_DIFFUSE) return diffusePdf(m, b);
     if (m.type == KZ_BSDF_KAZENSTANDARD) return kissPdf(m, b);
     if (m.type == KZ_BSDF_GGX) return ggxPdf(m, b);
@@ -1000,7 +1080,7 @@ static float bsdfPdf(const KzBSDF &m, const BRec &b) {
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) return rdielPdf(m, b);
     return 0.f;
 }
-static V3 bsdfSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {
+static V3 nestedSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {
     if (m.type == KZ_BSDF_DIFFUSE) return diffuseSample(m, b, s1, s2x, s2y, ok);
     if (m.type == KZ_BSDF_KAZENSTANDARD) return kissSample(m, b, s1, s2x, s2y, ok);
     if (m.type == KZ_BSDF_MIRROR) return mirrorSample(b, ok);
@@ -1010,7 +1090,70 @@ static V3 bsdfSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, b
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) return rdielSample(m, b, s1, s2x, s2y, ok);
     return dielectricSample(m, b, s1, ok);
 }
-static float bsdfRegularize(const KzBSDF &m) { return m.type == KZ_BSDF_KAZENSTANDARD ? m.roughness : 0.f; }   // bsdf.cpp:1397-1399, bsdf.h:125
+
+// NormalMap (bsdf.cpp:281-417): a BSDF wrapping a nested BSDF behind a frame perturbed by an RGB normal texture.
+static Frame normalMapFrame(const Intersection &its, V3 n) {             // getFrame, "naive implementation" (bsdf.cpp:365-374)
+    Frame result;
+    result.n = normalized(its.shFrame.toWorld(n));
+    result.s = normalized(its.dpdu - result.n * dot(result.n, its.dpdu));
+    result.t = normalized(cross(result.n, result.s));
+    return result;
+}
+static inline V3 normalMapN(const KzBSDF &m, const BRec &b) {            // bsdf.cpp:292-293: its.uv
+    V3 rgb = textureEval(*b.sc, m.normalTex - 1, b.its->uvx, b.its->uvy);
+    return V3(2 * rgb.x - 1, 2 * rgb.y - 1, 2 * rgb.z - 1);
+}
+static V3 normalMapEval(const Scene &sc, const KzBSDF &m, const BRec &b) {          // bsdf.cpp:290-312
+    const KzBSDF &nested = sc.bsdfs[m.nested];
+    const Intersection &its = *b.its;
+    V3 n = normalMapN(m, b);
+    if (b.wi.z > 0 && b.wo.z > 0 && dot(n, b.wi) <= 0) return nestedEval(nested, b);
+    Frame pf = normalMapFrame(its, normalized(n));
+    BRec q; q.wi = pf.toLocal(its.shFrame.toWorld(b.wi)); q.wo = pf.toLocal(its.shFrame.toWorld(b.wo)); q.measure = b.measure;
+    if (b.wo.z * q.wo.z <= 0) return V3(0.0f);
+    q.uvx = b.uvx; q.uvy = b.uvy; q.eta = b.eta; q.sc = b.sc;          // q.its stays default: accumulatedRoughness 0
+    return nestedEval(nested, q);
+}
+static float normalMapPdf(const Scene &sc, const KzBSDF &m, const BRec &b) {        // bsdf.cpp:314-336
+    const KzBSDF &nested = sc.bsdfs[m.nested];
+    const Intersection &its = *b.its;
+    V3 n = normalMapN(m, b);
+    if (b.wi.z > 0 && b.wo.z > 0 && dot(n, b.wi) <= 0) return nestedPdf(nested, b);
+    Frame pf = normalMapFrame(its, normalized(n));
+    BRec q; q.wi = pf.toLocal(its.shFrame.toWorld(b.wi)); q.wo = pf.toLocal(its.shFrame.toWorld(b.wo)); q.measure = b.measure;
+    if (b.wo.z * q.wo.z <= 0) return 0.0f;
+    q.uvx = b.uvx; q.uvy = b.uvy; q.eta = b.eta; q.sc = b.sc;
+    return nestedPdf(nested, q);
+}
+static V3 normalMapSample(const Scene &sc, const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {   // bsdf.cpp:338-363
+    const KzBSDF &nested = sc.bsdfs[m.nested];
+    const Intersection &its = *b.its;
+    V3 n = normalMapN(m, b);
+    if (b.wi.z > 0 && dot(n, b.wi) <= 0) { b.eta = 1.0f; return nestedSample(nested, b, s1, s2x, s2y, ok); }
+    Frame pf = normalMapFrame(its, normalized(n));
+    BRec q; q.wi = pf.toLocal(its.shFrame.toWorld(b.wi));
+    q.uvx = its.uvx; q.uvy = its.uvy; q.measure = b.measure; q.eta = b.eta; q.sc = b.sc;
+    V3 result = nestedSample(nested, q, s1, s2x, s2y, ok);
+    if (ok && !(result.x == 0.f && result.y == 0.f && result.z == 0.f)) {
+        b.wo = its.shFrame.toLocal(pf.toWorld(q.wo));
+        b.eta = q.eta;                                                   // measure is NOT copied back: it stays EUnknownMeasure
+        if (b.wo.z * q.wo.z <= 0) return V3(0.0f);
+    }
+    return result;
+}
+
+static V3 bsdfEval(const KzBSDF &m, const BRec &b) { return m.type == KZ_BSDF_NORMALMAP ? normalMapEval(*b.sc, m, b) : nestedEval(m, b); }
+static float bsdfPdf(const KzBSDF &m, const BRec &b) { return m.type == KZ_BSDF_NORMALMAP ? normalMapPdf(*b.sc, m, b) : nestedPdf(m, b); }
+static V3 bsdfSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, bool &ok) {
+    return m.type == KZ_BSDF_NORMALMAP ? normalMapSample(*b.sc, m, b, s1, s2x, s2y, ok) : nestedSample(m, b, s1, s2x, s2y, ok);
+}
+// BSDF::regularize(uv): kiss returns m_roughness->eval(uv).r() (bsdf.cpp:1397-1399), NormalMap forwards to its nested BSDF
+// (bsdf.cpp:411), every other model inherits 0 (bsdf.h:125)
+static float bsdfRegularize(const Scene &sc, const KzBSDF &m_, float u, float v) {
+    const KzBSDF &m = m_.type == KZ_BSDF_NORMALMAP ? sc.bsdfs[m_.nested] : m_;
+    if (m.type != KZ_BSDF_KAZENSTANDARD) return 0.f;
+    return m.roughnessTex ? textureEval(sc, m.roughnessTex - 1, u, v).x : m.roughness;
+}
 
 // ---------------------------------------------------------------------------------
 // a4/a5/a9 samplers (src/kazen/sampler.cpp). H1: GCC evaluates call arguments right to
@@ -1398,7 +1541,7 @@ static V3 Li(const Scene &sc, Sampler &sampler, const Ray &ray_, LocalStats &ls)
             }
             if (!occluded) {
                 BRec b; b.wi = its.shFrame.toLocal(-ray.d); b.wo = its.shFrame.toLocal(lr.wi); b.measure = ESolidAngle;
-                b.accumulatedRoughness = its.accumulatedRoughness;
+                b.accumulatedRoughness = its.accumulatedRoughness; b.its = &its; b.uvx = its.uvx; b.uvy = its.uvy; b.sc = &sc;   // integrator.cpp:284-285
                 V3 f = bsdfEval(bsdf, b);
                 float bpdf = bsdfPdf(bsdf, b);
                 float lightWeight = powerHeuristic(lpdf, bpdf);
@@ -1406,9 +1549,10 @@ static V3 Li(const Scene &sc, Sampler &sampler, const Ray &ray_, LocalStats &ls)
             }
         }
         if (sc.integ.regularization)                                               // integrator.cpp:298-301
-            its.accumulatedRoughness += bsdfRegularize(bsdf) * sc.integ.accumulatedRoughness;
+            its.accumulatedRoughness += bsdfRegularize(sc, bsdf, its.uvx, its.uvy) * sc.integ.accumulatedRoughness;
         // ---- BSDF sampling (integrator.cpp:304-309). H1: next2D is drawn before next1D.
         BRec b; b.wi = its.shFrame.toLocal(-ray.d); b.accumulatedRoughness = its.accumulatedRoughness;
+        b.its = &its; b.uvx = its.uvx; b.uvy = its.uvy; b.sc = &sc;                  // integrator.cpp:305-306
         float s2x, s2y; sampler.next2D(s2x, s2y);
         float s1 = sampler.next1D();
         bool ok;
@@ -1479,7 +1623,26 @@ int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) {
     sc->cam = d->camera; sc->smp = d->sampler; sc->integ = d->integrator; sc->bg = d->background;
     sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->nBsdfs);
     sc->lights.assign(d->lights, d->lights + d->nLights);
-    for (auto &b : sc->bsdfs) if (b.type < KZ_BSDF_DIFFUSE || b.type > KZ_BSDF_ROUGHDIELECTRIC) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "bsdf type"); }
+    if (d->nTextures) sc->textures.assign(d->textures, d->textures + d->nTextures);
+    for (uint32_t i = 0; i < d->nImages; ++i) {
+        const KzImage &im = d->images[i];
+        if (!im.pixels || im.width <= 0 || im.height <= 0 || im.channels <= 0 || (im.format != KZ_PIXEL_U8 && im.format != KZ_PIXEL_F32)) { delete sc; return fail(KZ_ERR_INVALID_ARG, "image"); }
+        Scene::Image o; o.w = im.width; o.h = im.height; o.c = im.channels; o.fmt = im.format;
+        size_t bytes = (size_t)im.width * im.height * im.channels * (im.format == KZ_PIXEL_F32 ? 4 : 1);
+        o.px.assign((const uint8_t *)im.pixels, (const uint8_t *)im.pixels + bytes);
+        sc->images.push_back(std::move(o));
+    }
+    for (auto &t : sc->textures) {
+        if (t.type < KZ_TEX_CONSTANT || t.type > KZ_TEX_BLEND) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "texture type"); }
+        if (t.type == KZ_TEX_IMAGE && (t.image < 0 || t.image >= (int)d->nImages)) { delete sc; return fail(KZ_ERR_INVALID_ARG, "texture image index"); }
+        for (int c = 0; c < 3; ++c) if (t.child[c] >= (int)d->nTextures) { delete sc; return fail(KZ_ERR_INVALID_ARG, "texture child index"); }
+    }
+    for (auto &b : sc->bsdfs) {
+        if (b.type < KZ_BSDF_DIFFUSE || b.type > KZ_BSDF_NORMALMAP) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "bsdf type"); }
+        const int ids[4] = {b.albedoTex, b.roughnessTex, b.metallicTex, b.normalTex};
+        for (int id : ids) if (id < 0 || id > (int)d->nTextures) { delete sc; return fail(KZ_ERR_INVALID_ARG, "bsdf texture id"); }
+        if (b.type == KZ_BSDF_NORMALMAP && (b.normalTex == 0 || b.nested < 0 || b.nested >= (int)d->nBsdfs || d->bsdfs[b.nested].type == KZ_BSDF_NORMALMAP)) { delete sc; return fail(KZ_ERR_INVALID_ARG, "normalmap row"); }
+    }
     sc->meshes.resize(d->nMeshes);
     for (uint32_t m = 0; m < d->nMeshes; ++m) {
         const KzMesh &km = d->meshes[m]; MeshData &md = sc->meshes[m];
@@ -1686,6 +1849,28 @@ void kzo_bsdf(const KzBSDF *m, int which, const float *wi, const float *wo, floa
     b.wo = V3(wo[0], wo[1], wo[2]); b.measure = ESolidAngle;
     if (which == 0) { V3 f = bsdfEval(*m, b); out[0] = f.x; out[1] = f.y; out[2] = f.z; }
     else out[0] = bsdfPdf(*m, b);
+}
+// Scene-aware form (texture children, normalmap rows): the intersection record is the identity frame with dpdu = +x at uv.
+// which = 2 returns 8 floats: weight 3, wo 3, ok, and pdf(bRec) right after sample() (integrator.cpp:314; 0 when the path ends).
+void kzo_scene_bsdf(void *s, int bsdfIdx, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float u, float v, float *out) {
+    Scene &sc = *(Scene *)s; const KzBSDF &m = sc.bsdfs[bsdfIdx];
+    Intersection its; its.uvx = u; its.uvy = v; its.accumulatedRoughness = accRough;
+    its.shFrame.s = V3(1, 0, 0); its.shFrame.t = V3(0, 1, 0); its.shFrame.n = V3(0, 0, 1); its.geoFrame = its.shFrame; its.dpdu = V3(1, 0, 0);
+    BRec b; b.wi = V3(wi[0], wi[1], wi[2]); b.accumulatedRoughness = accRough; b.its = &its; b.uvx = u; b.uvy = v; b.sc = &sc;
+    if (which == 2) {
+        bool ok; V3 w = bsdfSample(m, b, s1, s2x, s2y, ok);
+        bool zero = w.x == 0.f && w.y == 0.f && w.z == 0.f;
+        if (!ok || zero) b.wo = (ok ? b.wo : V3(0, 0, 1));
+        out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = b.wo.x; out[4] = b.wo.y; out[5] = b.wo.z; out[6] = ok ? 1.f : 0.f;
+        out[7] = (!ok || zero) ? 0.f : bsdfPdf(m, b);
+        return;
+    }
+    b.wo = V3(wo[0], wo[1], wo[2]); b.measure = ESolidAngle;
+    if (which == 0) { V3 f = bsdfEval(m, b); out[0] = f.x; out[1] = f.y; out[2] = f.z; }
+    else out[0] = bsdfPdf(m, b);
+}
+void kzo_texture(void *s, int tex, float u, float v, float *out) {
+    V3 c = textureEval(*(Scene *)s, tex, u, v); out[0] = c.x; out[1] = c.y; out[2] = c.z;
 }
 void kzo_ggx_sample_vndf(const float *V, float ax, float ay, float rx, float ry, float *H) {
     V3 h = sampleGGXSmithVNDF(V3(V[0], V[1], V[2]), A2{ax, ay}, rx, ry); H[0] = h.x; H[1] = h.y; H[2] = h.z;

@@ -75,6 +75,10 @@ def lib():
         L.kzo_frame.restype = None
         L.kzo_bsdf.argtypes = [C.POINTER(abi.KzBSDF), C.c_int, abi.f32p, abi.f32p, C.c_float, C.c_float, C.c_float, C.c_float, abi.f32p]
         L.kzo_bsdf.restype = None
+        L.kzo_scene_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_int, abi.f32p, abi.f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, abi.f32p]
+        L.kzo_scene_bsdf.restype = None
+        L.kzo_texture.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, abi.f32p]
+        L.kzo_texture.restype = None
         L.kzo_ggx_sample_vndf.argtypes = [abi.f32p, C.c_float, C.c_float, C.c_float, C.c_float, abi.f32p]
         L.kzo_ggx_sample_vndf.restype = None
         L.kzo_light_sample.argtypes = [C.c_void_p, C.c_int, abi.f32p, C.c_float, C.c_float, C.c_float, abi.f32p]
@@ -176,6 +180,25 @@ class OracleScene:
         out = np.zeros(14, np.float32)
         ref = np.ascontiguousarray(ref, np.float32)
         self.L.kzo_light_sample(self.h, light_idx, _fp(ref), u0, u1, u2, _fp(out))
+        return out
+
+    def bsdf(self, row, which, wi, wo=None, acc_rough=0.0, s1=0.0, s2=(0.0, 0.0), uv=(0.0, 0.0)):
+        """BSDF row `row` of this scene (texture children and normalmap rows included) on the identity frame at uv.
+        'eval' -> rgb, 'pdf' -> float, 'sample' -> 8 floats (weight rgb, wo xyz, ok, pdf(bRec) after sample())."""
+        wi = np.ascontiguousarray(wi, np.float32)
+        wo_ = np.ascontiguousarray(wo if wo is not None else (0, 0, 1), np.float32)
+        out = np.zeros(8, np.float32)
+        self.L.kzo_scene_bsdf(self.h, row, {"eval": 0, "pdf": 1, "sample": 2}[which], _fp(wi), _fp(wo_), acc_rough, s1, s2[0], s2[1], uv[0], uv[1], _fp(out))
+        return out[:3].copy() if which == "eval" else (float(out[0]) if which == "pdf" else out.copy())
+
+    def texture(self, tex, uv):
+        """Texture<Color3f>::eval of texture row `tex` at each uv (n, 2) -> (n, 3)."""
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((uv.shape[0], 3), np.float32)
+        tmp = np.zeros(3, np.float32)
+        for i in range(uv.shape[0]):
+            self.L.kzo_texture(self.h, tex, float(uv[i, 0]), float(uv[i, 1]), _fp(tmp))
+            out[i] = tmp
         return out
 
     def render_samples(self, pxy, idx):

@@ -49,6 +49,46 @@ static Scene *buildScene() {
     return scene;
 }
 
+// SURVEY 8f rank 4 through the plugin surface: lambertian + imagetexture (a PPM file), a normalmap (raster handed over with
+// setRaster) over a kazenstandard whose roughness is a colorramp of a blend.
+static Scene *buildTexturedScene(const char *ppm) {
+    auto *scene = static_cast<Scene *>(ObjectFactory::createInstance("scene", PropertyList()));
+    { PropertyList p; p.setInteger("maxDepth", 4); p.setBoolean("regularization", true); scene->addChild(ObjectFactory::createInstance("path_mis", p)); }
+    { PropertyList p; p.setInteger("sampleCount", 8); p.setInteger("seed", 0); scene->addChild(ObjectFactory::createInstance("independent", p)); }
+    { PropertyList p; p.setInteger("width", 64); p.setInteger("height", 48); p.setFloat("fov", 40.f); p.setFloat("nearClip", 0.1f); p.setFloat("farClip", 100.f);
+      p.setTransform("toWorld", Transform::lookAt({0, 0.5f, 3.f}, {0, 0, 0}, {0, 1, 0}));
+      scene->addChild(ObjectFactory::createInstance("perspective", p)); }
+    const float up[3] = {0, 1, 0}, down[3] = {0, -1, 0};
+    const float floorP[4][3] = {{-2, -1, -2}, {2, -1, -2}, {2, -1, 2}, {-2, -1, 2}};
+    const float lightP[4][3] = {{-0.5f, 1.5f, -0.5f}, {-0.5f, 1.5f, 0.5f}, {0.5f, 1.5f, 0.5f}, {0.5f, 1.5f, -0.5f}};
+    const float panelP[4][3] = {{-0.8f, -0.6f, 0}, {0.8f, -0.6f, 0}, {0.8f, 0.6f, -0.6f}, {-0.8f, 0.6f, -0.6f}};
+    const float panelN[3] = {0, 0.70710678f, 0.70710678f};
+    auto image = [&](const char *id, float scale, const char *colorspace) {
+        PropertyList p; p.setString("filename", ppm); p.setFloat("scale", scale); p.setString("colorspace", colorspace);
+        Object *t = ObjectFactory::createInstance("imagetexture", p); t->setId(id); return t;
+    };
+    { Mesh *m = quadMesh(floorP, up); Object *b = ObjectFactory::createInstance("lambertian", PropertyList()); b->addChild(image("", 3.0f, "srgb")); m->addChild(b); scene->addChild(m); }
+    { Mesh *m = quadMesh(panelP, panelN);
+      Object *nm = ObjectFactory::createInstance("normalmap", PropertyList());
+      { PropertyList p; p.setString("colorspace", "linear");
+        auto *t = static_cast<ImageTexture *>(ObjectFactory::createInstance("imagetexture", p));
+        const uint8_t px[2 * 2 * 3] = {128, 128, 255, 160, 128, 240, 128, 160, 240, 100, 110, 235};
+        t->setRaster(2, 2, 3, KZ_PIXEL_U8, px);
+        nm->addChild(t); }
+      PropertyList p; p.setFloat("clearcoat", 1.0f);
+      Object *kiss = ObjectFactory::createInstance("kazenstandard", p);
+      kiss->addChild(image("baseColor", 1.0f, "srgb"));
+      { PropertyList r; r.setFloat("min", 0.2f); r.setFloat("max", 0.7f); Object *ramp = ObjectFactory::createInstance("colorramp", r); ramp->setId("roughness");
+        PropertyList bp; bp.setString("blendmode", "multiply"); Object *bl = ObjectFactory::createInstance("blend", bp);
+        bl->addChild(image("input1", 2.0f, "linear")); { Object *c = constTex("input2", 0.9f, 0.9f, 0.9f); bl->addChild(c); }
+        ramp->addChild(bl); kiss->addChild(ramp); }
+      kiss->addChild(constTex("metallic", 0.f, 0.f, 0.f));
+      nm->addChild(kiss); m->addChild(nm); scene->addChild(m); }
+    { Mesh *m = quadMesh(lightP, down); PropertyList p; p.setFloat("intensity", 12.f); m->addChild(ObjectFactory::createInstance("area", p)); scene->addChild(m); }
+    scene->activate();
+    return scene;
+}
+
 template <class F> static std::string thrown(F f) { try { f(); } catch (const Exception &e) { return e.what(); } return ""; }
 
 int main(int argc, char **argv) {
@@ -58,6 +98,29 @@ int main(int argc, char **argv) {
         std::ofstream(argv[2], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
         double s = 0; for (float v : rgb) s += v;
         std::printf("{\"pixels\": %zu, \"mean\": %.6f}\n", rgb.size() / 3, s / rgb.size());
+        return 0;
+    }
+    if (argc >= 3 && !std::strcmp(argv[1], "--textured")) {
+        std::unique_ptr<Scene> scene(buildTexturedScene(argv[2]));
+        const KzSceneDesc &d = scene->desc();
+        if (argc >= 4) {
+            std::vector<float> rgb = renderer::render(scene.get(), 0);
+            std::ofstream(argv[3], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
+        }
+        std::printf("{\"nBsdfs\": %u, \"nTextures\": %u, \"nImages\": %u, \"bsdfs\": [", d.nBsdfs, d.nTextures, d.nImages);
+        for (uint32_t i = 0; i < d.nBsdfs; ++i)
+            std::printf("%s[%d, %d, %d, %d, %d, %d, %g]", i ? ", " : "", d.bsdfs[i].type, d.bsdfs[i].albedoTex, d.bsdfs[i].roughnessTex, d.bsdfs[i].metallicTex, d.bsdfs[i].normalTex,
+                        d.bsdfs[i].nested, d.bsdfs[i].metallic);
+        std::printf("], \"textures\": [");
+        for (uint32_t i = 0; i < d.nTextures; ++i)
+            std::printf("%s[%d, %d, %g, %d, %g, %g, %d, %d, %d, %d]", i ? ", " : "", d.textures[i].type, d.textures[i].image, d.textures[i].scale, d.textures[i].srgb, d.textures[i].rampMin,
+                        d.textures[i].rampMax, d.textures[i].blendMode, d.textures[i].child[0], d.textures[i].child[1], d.textures[i].child[2]);
+        std::printf("], \"images\": [");
+        for (uint32_t i = 0; i < d.nImages; ++i) std::printf("%s[%d, %d, %d, %d]", i ? ", " : "", d.images[i].width, d.images[i].height, d.images[i].channels, d.images[i].format);
+        std::string e1 = thrown([] { std::unique_ptr<Object> t(ObjectFactory::createInstance("blend", PropertyList())); t->addChild(constTex("nosuchslot", 0, 0, 0)); });
+        std::string e2 = thrown([] { PropertyList p; p.setString("filename", "/nonexistent/file.ppm"); ObjectFactory::createInstance("imagetexture", p); });
+        for (std::string *e : {&e1, &e2}) for (auto &c : *e) if (c == '"') c = '\'';
+        std::printf("], \"errors\": [\"%s\", \"%s\"]}\n", e1.c_str(), e2.c_str());
         return 0;
     }
     std::unique_ptr<Scene> scene(buildScene());

@@ -20,10 +20,21 @@ def test_library_exports_every_declared_symbol(kz):
     assert lib.kz_abi_version() == kz.abi.KZ_ABI_VERSION
 
 
-def test_struct_sizes_match_the_header(kz):
+def test_struct_sizes_match_the_header(kz, tmp_path):
+    """sizeof of every structure as gcc sees the C header == sizeof of its ctypes mirror."""
+    import subprocess
     a = kz.abi
-    assert C.sizeof(a.KzBSDF) == 112 and C.sizeof(a.KzLight) == 20 and C.sizeof(a.KzTile) == 16
-    assert C.sizeof(a.KzHit) == 88 and C.sizeof(a.KzStats) == 56 and C.sizeof(a.KzMesh) == 48
+    names = ["KzBSDF", "KzImage", "KzTexture", "KzLight", "KzMesh", "KzFilter", "KzCamera", "KzSampler", "KzIntegrator", "KzBackground",
+             "KzSceneDesc", "KzTile", "KzRenderOpts", "KzStats", "KzHit", "KzBvhInfo"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "kazen_mi355x.h"\nint main(void){' +
+                   "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n in names:
+        assert C.sizeof(getattr(a, n)) == int(sizes[n]), n
+    assert C.sizeof(a.KzBSDF) == 128 and C.sizeof(a.KzTexture) == 64
 
 
 def test_scene_create_and_bvh_on_host(kz):
@@ -67,7 +78,7 @@ def test_no_device_is_a_loud_error(kz):
     (lambda s: s.integrator.update(type="whitted"), 2),
     (lambda s: s.camera.update(type="orthographic"), 2),
     (lambda s: s.sampler.update(type="stratified", resolution=0), 1),
-    (lambda s: s.meshes[0].update(bsdf={"type": "normalmap"}), 2),
+    (lambda s: s.meshes[0].update(bsdf={"type": "principled"}), 2),
     (lambda s: s.sampler.update(sampleCount=0), 1),
     (lambda s: s.camera.update(width=0), 1),
     (lambda s: s.meshes[0]["F"].__setitem__((0, 0), 999), 1),

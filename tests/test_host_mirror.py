@@ -68,3 +68,64 @@ def test_cpp_render_equals_python_render(exe, kz, O, gpu_lib, tmp_path):
     ora = O.OracleScene(twin)
     cpu = ora.rgb(ora.render(threads=0))
     assert float(np.sqrt(np.mean((rgb - cpu) ** 2))) < 1e-3
+
+
+# ---------------------------------------------------------------- SURVEY 8f rank 4 through the plugin surface
+def _write_ppm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P6\n# checker\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(img.tobytes())
+
+
+def textured_twin(kz):
+    S = kz.scenes
+    chk = S._test_images()[0]
+    s = S.SceneDescription()
+
+    def q(p, n):
+        P = np.array(p, np.float32)
+        return P, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), np.tile(np.array(n, np.float32), (4, 1)), np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    s.add_mesh(*q([(-2, -1, -2), (2, -1, -2), (2, -1, 2), (-2, -1, 2)], (0, 1, 0)), bsdf=S.lambertian(S.imagetexture(chk, 3.0, "srgb")))
+    nrm = np.array([[[128, 128, 255], [160, 128, 240]], [[128, 160, 240], [100, 110, 235]]], np.uint8)
+    kiss = S.kazenstandard(S.imagetexture(chk, 1.0, "srgb"), S.colorramp(S.blend(None, S.imagetexture(chk, 2.0, "linear"), S.constanttexture((0.9, 0.9, 0.9)), "multiply"), 0.2, 0.7),
+                           0.0, clearcoat=1.0)
+    s.add_mesh(*q([(-0.8, -0.6, 0), (0.8, -0.6, 0), (0.8, 0.6, -0.6), (-0.8, 0.6, -0.6)], (0, 0.70710678, 0.70710678)), bsdf=S.normalmap(S.imagetexture(nrm, 1.0, "linear"), kiss))
+    s.add_mesh(*q([(-0.5, 1.5, -0.5), (-0.5, 1.5, 0.5), (0.5, 1.5, 0.5), (0.5, 1.5, -0.5)], (0, -1, 0)), light=S.area((1.0, 1.0, 1.0), 12.0, False))
+    s.camera.update(width=64, height=48, fov=40.0, nearClip=0.1, farClip=100.0, toWorld=S.look_at((0, 0.5, 3.0), (0, 0, 0), (0, 1, 0)))
+    s.sampler = {"type": "independent", "sampleCount": 8, "seed": 0}
+    s.integrator.update(maxDepth=4, regularization=True)
+    return s
+
+
+def test_texture_plugins_flatten_like_the_python_path(exe, kz, tmp_path):
+    a = kz.abi
+    ppm = str(tmp_path / "checker.ppm")
+    _write_ppm(ppm, kz.scenes._test_images()[0])
+    d = json.loads(subprocess.check_output([exe, "--textured", ppm]).decode())
+    assert (d["nBsdfs"], d["nImages"]) == (3, 4)
+    lam, nm, kiss = d["bsdfs"]
+    assert lam[0] == a.KZ_BSDF_DIFFUSE and lam[1] > 0
+    assert nm[0] == a.KZ_BSDF_NORMALMAP and nm[4] > 0 and nm[5] == 2                         # the wrapped row sits behind the per-mesh rows
+    assert kiss[0] == a.KZ_BSDF_KAZENSTANDARD and kiss[1] > 0 and kiss[2] > 0 and kiss[3] == 0 and kiss[6] == 0.0     # metallic: a folded constanttexture
+    T = d["textures"]
+    ramp = T[kiss[2] - 1]
+    assert ramp[0] == a.KZ_TEX_COLORRAMP and np.allclose(ramp[4:6], [0.2, 0.7])
+    bl = T[ramp[7]]
+    assert bl[0] == a.KZ_TEX_BLEND and bl[6] == a.KZ_BLEND_MULTIPLY and bl[7] == -1 and T[bl[8]][0] == a.KZ_TEX_IMAGE and T[bl[9]][0] == a.KZ_TEX_CONSTANT
+    assert T[lam[1] - 1][:4] == [a.KZ_TEX_IMAGE, T[lam[1] - 1][1], 3.0, 1] and T[nm[4] - 1][3] == 0                   # srgb default / "linear"
+    assert [8, 8, 3, a.KZ_PIXEL_U8] in d["images"] and [2, 2, 3, a.KZ_PIXEL_U8] in d["images"]
+    assert "does not match any field" in d["errors"][0] and "cannot open" in d["errors"][1]
+
+
+@pytest.mark.gpu
+def test_cpp_textured_render_equals_python_render(exe, kz, O, gpu_lib, tmp_path):
+    ppm, out = str(tmp_path / "checker.ppm"), str(tmp_path / "rgb.bin")
+    _write_ppm(ppm, kz.scenes._test_images()[0])
+    subprocess.check_output([exe, "--textured", ppm, out])
+    rgb = np.fromfile(out, np.float32).reshape(48, 64, 3)
+    twin = textured_twin(kz)
+    sc = kz.Scene(twin, device=0)
+    sc.render()
+    assert float(np.sqrt(np.mean((sc.rgb() - rgb) ** 2))) < 1e-4
+    ora = O.OracleScene(twin)
+    assert float(np.sqrt(np.mean((rgb - ora.rgb(ora.render(threads=0))) ** 2))) < 1e-3

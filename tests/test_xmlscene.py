@@ -34,7 +34,8 @@ def test_mini_scene_parses_like_the_reference_loader(kz):
 def test_unsupported_content_raises(kz, tmp_path):
     txt = open(MINI).read()
     for old, new, msg in (('type="path_mis"', 'type="whitted"', "hot path"), ('type="correlated"', 'type="sobol"', "not supported"),
-                          ('<bsdf type="diffuse">', '<bsdf type="normalmap">', "not supported"), ('<camera type="perspective">', '<camera type="fisheye">', "not supported")):
+                          ('<bsdf type="diffuse">', '<bsdf type="principled">', "not supported"), ('<bsdf type="diffuse">', '<bsdf type="normalmap">', "needs a normal texture"),
+                          ('type="constanttexture" id="baseColor"', 'type="checkerboard" id="baseColor"', "not supported"), ('<camera type="perspective">', '<camera type="fisheye">', "not supported")):
         p = tmp_path / "bad.xml"
         p.write_text(txt.replace(old, new).replace('value="floor.obj"', 'value="%s"' % os.path.join(HERE, "golden", "xml", "floor.obj"))
                      .replace('value="cube.obj"', 'value="%s"' % os.path.join(HERE, "golden", "xml", "cube.obj"))
@@ -42,6 +43,46 @@ def test_unsupported_content_raises(kz, tmp_path):
         with pytest.raises(ValueError) as e:
             kz.xmlscene.load_xml(str(p))
         assert msg in str(e.value)
+
+
+TEXTURED = os.path.join(HERE, "golden", "xml", "textured.xml")
+
+
+def test_textured_scene_parses_like_the_reference_loader(kz):
+    """imagetexture / colorramp / blend children (matched by id, texture.cpp:241-262), lambertian and normalmap rows."""
+    d = kz.xmlscene.load_xml(TEXTURED)
+    floor, cube, light = d.meshes
+    assert floor["bsdf"]["type"] == "diffuse" and floor["bsdf"]["albedo"]["type"] == "imagetexture"
+    img = floor["bsdf"]["albedo"]
+    assert img["image"].shape == (8, 8, 3) and img["image"].dtype == np.uint8 and img["scale"] == 4.0 and img["colorspace"] == "srgb"
+    nm = cube["bsdf"]
+    assert nm["type"] == "normalmap" and nm["normal"]["colorspace"] == "linear" and nm["normal"]["image"].shape == (32, 32, 3)
+    kiss = nm["nested"]
+    assert kiss["type"] == "kazenstandard" and kiss["metallic"] == 0.0
+    bl = kiss["baseColor"]
+    assert bl["type"] == "blend" and bl["blendmode"] == "mix" and bl["mask"]["image"].shape == (16, 16, 1) and bl["input1"]["color"] == (0.8, 0.3, 0.2)
+    assert bl["input2"]["type"] == "imagetexture"
+    r = kiss["roughness"]
+    assert r["type"] == "colorramp" and (r["min"], r["max"]) == (0.2, 0.7) and r["nested"]["scale"] == 2.0
+    cd = d.to_c()
+    assert (cd.nBsdfs, cd.nTextures, cd.nImages) == (3, 8, 5) and cd.bsdfs[1].nested == 2 and cd.bsdfs[2].type == kz.abi.KZ_BSDF_KAZENSTANDARD
+    assert d.integrator["regularization"] is True
+    kz.Scene(d)                                                   # passes the product library's validation
+
+
+def test_textured_scene_oracle_render(kz, O):
+    o = O.OracleScene(kz.xmlscene.load_xml(TEXTURED))
+    rgb = o.rgb(o.render(threads=2))
+    assert np.isfinite(rgb).all() and rgb.mean() > 0.01
+
+
+@pytest.mark.gpu
+def test_textured_scene_gpu_matches_oracle(kz, O, gpu_lib):
+    d = kz.xmlscene.load_xml(TEXTURED)
+    sc = kz.Scene(d, device=0)
+    sc.render()
+    o = O.OracleScene(d)
+    assert float(np.sqrt(np.mean((sc.rgb() - o.rgb(o.render(threads=0))) ** 2))) < 1e-3
 
 
 def test_mini_scene_oracle_render(kz, O):
