@@ -291,6 +291,11 @@ int kz_film_dims(const KzScene *scene, int32_t *width, int32_t *height, int32_t 
 /* ImageBlock::toBitmap (block.cpp:39-45): rgb = film.rgb / film.w (0 when w == 0). */
 int kz_film_to_rgb(const float *film, int32_t width, int32_t height, int32_t border, float *rgb);
 
+/* ImageBlock::toBitmap followed by the tone map of Bitmap::savePNG (bitmap.cpp:45-52: Color3f::toSRGB, clamp(255*v, 0, 255),
+ * truncation to uint8), evaluated on the device: rgb8 = height*width*3 bytes, row 0 = top scan line — the buffer the
+ * reference hands to its PNG writer. */
+int kz_film_to_srgb8(KzScene *scene, uint8_t *rgb8, size_t nBytes);
+
 /* Ray-level entry mirroring Accel::rayIntersect(ray, its, shadowRay=false) for n rays
  * (host arrays; o,d = n x 3 floats). For parity tests of traversal + post-intersection. */
 int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d,

@@ -4,5 +4,5 @@ Python here is harness plumbing around the C ABI in include/kazen_mi355x.h (ctyp
 product is csrc/ (hand-written HIP for gfx950 + host BVH builder + the C-ABI shim).
 Import with importlib.import_module("nano-kazen_amd") (the directory name has a hyphen).
 """
-from . import abi, scenes, shard, xmlscene     # noqa: F401
+from . import abi, output, scenes, shard, xmlscene     # noqa: F401
 from .render import Scene            # noqa: F401

@@ -125,7 +125,7 @@ class KzBvhInfo(C.Structure):
 EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
            "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
-           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query"]
+           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
@@ -167,6 +167,7 @@ def load_library():
     lib.kz_last_stage_ms.argtypes = [C.c_void_p, f32p]
     lib.kz_render_samples.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), u32p, f32p]
     lib.kz_bsdf_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p]
+    lib.kz_film_to_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
     lib.kz_texture_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p]
     _lib = lib
     return lib

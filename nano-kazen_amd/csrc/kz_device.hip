@@ -175,6 +175,24 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_trace_kernel(KzParams P, KzDevTab
 }
 
 
+// Film -> 8-bit sRGB raster: Color4f::divideByFilterWeight (color.h:94-99), Color3f::toSRGB (common.cpp:351-366) and the
+// clamp + truncation of Bitmap::savePNG (bitmap.cpp:45-52). One pixel per lane, coalesced float4 reads.
+__global__ void kz_film_srgb8(const float4 *__restrict__ film, int width, int height, int border, uint8_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)(width * height)) return;
+    const int y = (int)(i / (uint32_t)width), x = (int)(i - (uint32_t)y * (uint32_t)width);
+    const float4 px = film[(size_t)(y + border) * (size_t)(width + 2 * border) + (size_t)(x + border)];
+    float c[3] = {0.f, 0.f, 0.f};
+    if (px.w != 0.f) { c[0] = px.x / px.w; c[1] = px.y / px.w; c[2] = px.z / px.w; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = c[k];
+        const float t = v <= 0.0031308f ? 12.92f * v : (1.0f + 0.055f) * powf(v, 1.0f / 2.4f) - 0.055f;
+        const float s = 255.f * t;
+        out[3 * (size_t)i + k] = (uint8_t)(s < 0.f ? 0.f : (s > 255.f ? 255.f : s));
+    }
+}
+
 // Function-level query kernels for the BSDF / texture tables (parity tests of a20/a21/a22/a23 and the 8f rows on the device).
 // The intersection record is the identity frame (s, t, n = x, y, z; dpdu = x) at the given uv.
 __global__ void kz_bsdf_kernel(KzDevTables T, uint32_t n, const int32_t *__restrict__ bsdf, const float *__restrict__ wi, const float *__restrict__ wo,
@@ -581,6 +599,26 @@ int kz_film_download(KzScene *scene, float *film, size_t nFloats) {
     if (!film || nFloats != ds->filmPixels * 4) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold %zu floats", ds->filmPixels * 4);
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
     HIP_TRY(hipMemcpy(film, ds->film, nFloats * sizeof(float), hipMemcpyDeviceToHost));
+    return KZ_OK;
+}
+
+// ImageBlock::toBitmap (block.cpp:39-45) + Bitmap::savePNG's tone map (bitmap.cpp:45-52): the film is resolved to the 8-bit
+// sRGB raster on the device, so the host link carries 3 bytes per pixel instead of the 16-byte film texel.
+int kz_film_to_srgb8(KzScene *scene, uint8_t *rgb8, size_t nBytes) {
+    KzDeviceState *ds; int rc;
+    if ((rc = requireDevice(scene, &ds))) return rc;
+    const KzParams &P = scene->prm;
+    const size_t need = (size_t)P.width * (size_t)P.height * 3;
+    if (!rgb8 || nBytes != need) return kz_fail(KZ_ERR_INVALID_ARG, "rgb8 buffer must hold %zu bytes", need);
+    uint8_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, need));
+    const uint32_t n = (uint32_t)(P.width * P.height);
+    hipLaunchKernelGGL(kz_film_srgb8, dim3((n + 255) / 256), dim3(256), 0, ds->lastStream, ds->film, P.width, P.height, P.border, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ds->lastStream);
+    if (e == hipSuccess) e = hipMemcpy(rgb8, d, need, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return kz_fail(KZ_ERR_HIP, "kz_film_to_srgb8: %s", hipGetErrorString(e));
     return KZ_OK;
 }
 

@@ -17,6 +17,7 @@
 #pragma once
 #include "../../include/kazen_mi355x.h"
 
+#include <algorithm>
 #include <array>
 #include <cctype>
 #include <cmath>
@@ -589,10 +590,92 @@ KAZEN_MI355X_REGISTER(ThinlensCamera, "thinlens");
 KAZEN_MI355X_REGISTER(PMJ02BN, "pmj02bn");
 KAZEN_MI355X_REGISTER(PathMisIntegrator, "path_mis");
 
+// ---- Bitmap (include/kazen/bitmap.h, src/kazen/bitmap.cpp:23-64): the renderer's output files ----------------------------
+// The reference writes through OpenImageIO; these writers are self-contained: an 8-bit RGB PNG (stored deflate blocks) and the
+// uncompressed scan-line form of OpenEXR with FLOAT channels B, G, R.
+class Bitmap {
+public:
+    Bitmap(int width, int height) : m_w(width), m_h(height), m_rgb((size_t)width * height * 3, 0.f) {}
+    Bitmap(int width, int height, std::vector<float> rgb) : m_w(width), m_h(height), m_rgb(std::move(rgb)) {}
+    int cols() const { return m_w; } int rows() const { return m_h; }
+    float *data() { return m_rgb.data(); } const float *data() const { return m_rgb.data(); }
+    void setSRGB8(std::vector<uint8_t> px) { m_rgb8 = std::move(px); }             // the device-side tone map (kz_film_to_srgb8)
+    /// bitmap.cpp:39-62: Color3f::toSRGB, clamp(255 v, 0, 255), truncate; ".png" is appended like the reference does
+    void savePNG(const std::string &filename) const {
+        std::vector<uint8_t> px = m_rgb8;
+        if (px.empty()) {
+            px.resize(m_rgb.size());
+            for (size_t i = 0; i < m_rgb.size(); ++i) {
+                const float v = m_rgb[i], t = v <= 0.0031308f ? 12.92f * v : (1.0f + 0.055f) * std::pow(v, 1.0f / 2.4f) - 0.055f, s = 255.f * t;
+                px[i] = (uint8_t)(s < 0.f ? 0.f : (s > 255.f ? 255.f : s));
+            }
+        }
+        std::vector<uint8_t> raw; raw.reserve((size_t)m_h * (3 * m_w + 1));
+        for (int y = 0; y < m_h; ++y) { raw.push_back(0); raw.insert(raw.end(), px.begin() + (size_t)y * 3 * m_w, px.begin() + (size_t)(y + 1) * 3 * m_w); }
+        std::vector<uint8_t> z = {0x78, 0x01};
+        for (size_t o = 0; o < raw.size() || o == 0; o += 65535) {
+            const size_t n = std::min<size_t>(65535, raw.size() - o);
+            z.push_back(o + n >= raw.size() ? 1 : 0); z.push_back(n & 0xff); z.push_back(n >> 8); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+            z.insert(z.end(), raw.begin() + o, raw.begin() + o + n);
+            if (raw.empty()) break;
+        }
+        uint32_t a = 1, b = 0; for (uint8_t c : raw) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+        for (int s = 24; s >= 0; s -= 8) z.push_back((((b << 16) | a) >> s) & 0xff);
+        std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+        auto be32 = [](std::vector<uint8_t> &v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((x >> s) & 0xff); };
+        auto chunk = [&](const char *tag, const std::vector<uint8_t> &d) {
+            be32(out, (uint32_t)d.size());
+            std::vector<uint8_t> td(tag, tag + 4); td.insert(td.end(), d.begin(), d.end());
+            uint32_t crc = 0xffffffffu;
+            for (uint8_t c : td) { crc ^= c; for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xedb88320u & (0u - (crc & 1u))); }
+            out.insert(out.end(), td.begin(), td.end()); be32(out, ~crc);
+        };
+        std::vector<uint8_t> ihdr; be32(ihdr, (uint32_t)m_w); be32(ihdr, (uint32_t)m_h); for (uint8_t c : {8, 2, 0, 0, 0}) ihdr.push_back(c);
+        chunk("IHDR", ihdr); chunk("IDAT", z); chunk("IEND", {});
+        writeFile(filename + ".png", out);
+    }
+    /// bitmap.cpp:23-37: three FLOAT channels
+    void saveEXR(const std::string &filename) const {
+        std::vector<uint8_t> o;
+        auto raw = [&](const void *p, size_t n) { o.insert(o.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+        auto i32 = [&](int32_t v) { raw(&v, 4); };
+        auto f32 = [&](float v) { raw(&v, 4); };
+        auto str = [&](const char *s) { raw(s, std::strlen(s) + 1); };
+        auto attr = [&](const char *name, const char *type, int32_t size) { str(name); str(type); i32(size); };
+        i32(20000630); i32(2);
+        attr("channels", "chlist", 3 * 18 + 1);
+        for (const char *c : {"B", "G", "R"}) { str(c); i32(2); const uint8_t lin[4] = {0, 0, 0, 0}; raw(lin, 4); i32(1); i32(1); }
+        o.push_back(0);
+        attr("compression", "compression", 1); o.push_back(0);
+        attr("dataWindow", "box2i", 16); i32(0); i32(0); i32(m_w - 1); i32(m_h - 1);
+        attr("displayWindow", "box2i", 16); i32(0); i32(0); i32(m_w - 1); i32(m_h - 1);
+        attr("lineOrder", "lineOrder", 1); o.push_back(0);
+        attr("pixelAspectRatio", "float", 4); f32(1.0f);
+        attr("screenWindowCenter", "v2f", 8); f32(0.f); f32(0.f);
+        attr("screenWindowWidth", "float", 4); f32(1.0f);
+        o.push_back(0);
+        const uint64_t line = 8 + 12 * (uint64_t)m_w, first = o.size() + 8 * (uint64_t)m_h;
+        for (int y = 0; y < m_h; ++y) { const uint64_t off = first + (uint64_t)y * line; raw(&off, 8); }
+        for (int y = 0; y < m_h; ++y) {
+            i32(y); i32(12 * m_w);
+            for (int c = 2; c >= 0; --c) for (int x = 0; x < m_w; ++x) f32(m_rgb[((size_t)y * m_w + x) * 3 + c]);
+        }
+        writeFile(filename + ".exr", o);
+    }
+private:
+    static void writeFile(const std::string &path, const std::vector<uint8_t> &bytes) {
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) throw Exception("Bitmap: cannot write \"" + path + "\"");
+        const size_t n = std::fwrite(bytes.data(), 1, bytes.size(), f);
+        std::fclose(f);
+        if (n != bytes.size()) throw Exception("Bitmap: short write to \"" + path + "\"");
+    }
+    int m_w, m_h; std::vector<float> m_rgb; std::vector<uint8_t> m_rgb8;
+};
+
 namespace renderer {
 /// The drop-in for kazen::renderer::render (renderer.cpp:72-153): render every sample of every pixel on `device` and
-/// return the normalised bitmap (h x w x rgb, linear) — what result.toBitmap() holds before savePNG. File output (PNG/EXR
-/// through OpenImageIO in the reference) stays with the caller: it is host I/O, outside the hot path.
+/// return the normalised bitmap (h x w x rgb, linear) — what result.toBitmap() holds before savePNG.
 inline std::vector<float> render(Scene *scene, int device = 0) {
     KzScene *h = scene->handle();
     if (!h) throw Exception("renderer::render: scene was not activated");
@@ -605,6 +688,18 @@ inline std::vector<float> render(Scene *scene, int device = 0) {
     if (kz_film_download(h, film.data(), film.size()) != KZ_OK) throw Exception(std::string("kz_film_download: ") + kz_last_error());
     kz_film_to_rgb(film.data(), w, hh, b, rgb.data());
     return rgb;
+}
+/// renderer.cpp:72-153 including the file: renders and writes `<stem of filename>.png` (renderer.cpp:143-152), tone-mapped on the device
+inline void render(Scene *scene, const std::string &filename, int device = 0) {
+    std::vector<float> rgb = render(scene, device);
+    int32_t w, hh, b;
+    kz_film_dims(scene->handle(), &w, &hh, &b);
+    Bitmap bitmap(w, hh, std::move(rgb));
+    std::vector<uint8_t> px((size_t)w * hh * 3);
+    if (kz_film_to_srgb8(scene->handle(), px.data(), px.size()) != KZ_OK) throw Exception(std::string("kz_film_to_srgb8: ") + kz_last_error());
+    bitmap.setSRGB8(std::move(px));
+    const size_t lastdot = filename.find_last_of(".");
+    bitmap.savePNG(lastdot == std::string::npos ? filename : filename.substr(0, lastdot));
 }
 } // namespace renderer
 } // namespace kazen

@@ -118,6 +118,12 @@ class Scene:
                                                       out.ctypes.data_as(abi.f32p)))
         return out
 
+    def srgb8(self):
+        """(h, w, 3) uint8: the raster Bitmap::savePNG writes (bitmap.cpp:39-62), resolved on the device."""
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        abi.check(self.lib, self.lib.kz_film_to_srgb8(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
+        return out
+
     def set_stats(self, enable=True):
         abi.check(self.lib, self.lib.kz_set_stats(self.h, 1 if enable else 0))
 

@@ -1777,6 +1777,16 @@ int kzo_film_to_rgb(const float *film, int w, int h, int b, float *rgb) {
     return 0;
 }
 
+// Bitmap::savePNG's raster (bitmap.cpp:45-52) from a normalised bitmap: Color3f::toSRGB (common.cpp:351-366), clamp, truncate
+int kzo_rgb_to_srgb8(const float *rgb, int w, int h, uint8_t *out) {
+    for (size_t i = 0; i < (size_t)w * h * 3; ++i) {
+        float value = rgb[i];
+        float t = value <= 0.0031308f ? 12.92f * value : (1.0f + 0.055f) * std::pow(value, 1.0f / 2.4f) - 0.055f;
+        out[i] = (uint8_t)clampf(255.f * t, 0.f, 255.f);
+    }
+    return 0;
+}
+
 int kzo_get_stats(void *s, KzStats *o, int reset) {
     Scene *sc = (Scene *)s;
     o->samples = sc->stats.samples; o->rays = sc->stats.rays; o->nodeVisits = sc->stats.nodeVisits; o->triTests = sc->stats.triTests;

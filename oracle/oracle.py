@@ -77,6 +77,7 @@ def lib():
         L.kzo_bsdf.restype = None
         L.kzo_scene_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_int, abi.f32p, abi.f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, abi.f32p]
         L.kzo_scene_bsdf.restype = None
+        L.kzo_rgb_to_srgb8.argtypes = [abi.f32p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
         L.kzo_texture.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, abi.f32p]
         L.kzo_texture.restype = None
         L.kzo_ggx_sample_vndf.argtypes = [abi.f32p, C.c_float, C.c_float, C.c_float, C.c_float, abi.f32p]
@@ -137,6 +138,12 @@ class OracleScene:
     def rgb(self, film):
         out = np.empty((self.height, self.width, 3), np.float32)
         self.L.kzo_film_to_rgb(_fp(np.ascontiguousarray(film, np.float32)), self.width, self.height, self.border, _fp(out))
+        return out
+
+    def srgb8(self, film):
+        rgb = self.rgb(film)
+        out = np.zeros(rgb.shape, np.uint8)
+        self.L.kzo_rgb_to_srgb8(_fp(rgb), rgb.shape[1], rgb.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint8)))
         return out
 
     def stats(self, reset=False):

@@ -100,6 +100,19 @@ int main(int argc, char **argv) {
         std::printf("{\"pixels\": %zu, \"mean\": %.6f}\n", rgb.size() / 3, s / rgb.size());
         return 0;
     }
+    if (argc >= 3 && !std::strcmp(argv[1], "--bitmap")) {            // Bitmap::savePNG / saveEXR of a deterministic 37 x 5 gradient (no GPU)
+        const int w = 37, h = 5;
+        Bitmap bm(w, h);
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) for (int c = 0; c < 3; ++c)
+            bm.data()[((size_t)y * w + x) * 3 + c] = (float)(x + 1) / (float)w * (c == 0 ? 1.2f : c == 1 ? 0.5f : 0.01f) + (float)y * 0.003f - (c == 2 && x == 0 ? 0.5f : 0.f);
+        bm.savePNG(argv[2]); bm.saveEXR(argv[2]);
+        return 0;
+    }
+    if (argc >= 3 && !std::strcmp(argv[1], "--render-png")) {        // renderer::render(scene, filename) (renderer.cpp:72-153)
+        std::unique_ptr<Scene> scene(buildScene());
+        renderer::render(scene.get(), std::string(argv[2]), 0);
+        return 0;
+    }
     if (argc >= 3 && !std::strcmp(argv[1], "--textured")) {
         std::unique_ptr<Scene> scene(buildTexturedScene(argv[2]));
         const KzSceneDesc &d = scene->desc();
