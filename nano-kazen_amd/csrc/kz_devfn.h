@@ -237,6 +237,7 @@ __device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin
 // Returns the four children as sortable keys: (bits of max(tnear, tmin) with the two low bits replaced by the child slot),
 // 0xFFFFFFFF for a miss, sorted ascending, so key[0] is the nearest hit child.
 struct Node4Test { uint32_t k0, k1, k2, k3; uint4 refs; };
+typedef float kz_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax) {
     const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + node);
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
@@ -245,19 +246,22 @@ __device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t no
                 az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * rz;
     const float bx = (__uint_as_float(q0.x) - o.x) * rx, by = (__uint_as_float(q0.y) - o.y) * ry, bz = (__uint_as_float(q0.z) - o.z) * rz;
     // The sign of the direction says which plane of a slab is entered first: pick the packed near / far words for all four
-    // children at once (rcp is finite and non-zero here, see the caller), so each child needs only 6 cvt + 6 fma + max3 + min3.
+    // children at once (rcp is finite and non-zero here, see the caller), so each child needs only 6 cvt + 3 packed fma (the
+    // near and the far plane of an axis share scale and offset: one v_pk_fma_f32) + max3 + min3.
     // An empty slot (qlo = 255, qhi = 0) comes out with near > far on every axis for either sign: never hit.
     const uint32_t nX = rx >= 0.f ? q1.x : q1.w, fX = rx >= 0.f ? q1.w : q1.x;
     const uint32_t nY = ry >= 0.f ? q1.y : q2.x, fY = ry >= 0.f ? q2.x : q1.y;
     const uint32_t nZ = rz >= 0.f ? q1.z : q2.y, fZ = rz >= 0.f ? q2.y : q1.z;
+    const kz_f2 AX = {ax, ax}, AY = {ay, ay}, AZ = {az, az}, BX = {bx, bx}, BY = {by, by}, BZ = {bz, bz};
     uint32_t key[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float tnx = fmaf((float)((nX >> (8 * i)) & 0xffu), ax, bx), tfx = fmaf((float)((fX >> (8 * i)) & 0xffu), ax, bx);
-        const float tny = fmaf((float)((nY >> (8 * i)) & 0xffu), ay, by), tfy = fmaf((float)((fY >> (8 * i)) & 0xffu), ay, by);
-        const float tnz = fmaf((float)((nZ >> (8 * i)) & 0xffu), az, bz), tfz = fmaf((float)((fZ >> (8 * i)) & 0xffu), az, bz);
-        const float n = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);
-        const float f = fminf(fminf(fminf(tfx, tfy), tfz) * 1.0000004f, tmax);
+        const kz_f2 qx = {(float)((nX >> (8 * i)) & 0xffu), (float)((fX >> (8 * i)) & 0xffu)};
+        const kz_f2 qy = {(float)((nY >> (8 * i)) & 0xffu), (float)((fY >> (8 * i)) & 0xffu)};
+        const kz_f2 qz = {(float)((nZ >> (8 * i)) & 0xffu), (float)((fZ >> (8 * i)) & 0xffu)};
+        const kz_f2 tx = __builtin_elementwise_fma(qx, AX, BX), ty = __builtin_elementwise_fma(qy, AY, BY), tz = __builtin_elementwise_fma(qz, AZ, BZ);
+        const float n = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), tmin);
+        const float f = fminf(fminf(fminf(tx.y, ty.y), tz.y) * 1.0000004f, tmax);
         key[i] = (n <= f) ? ((__float_as_uint(n) & ~3u) | (uint32_t)i) : 0xFFFFFFFFu;
     }
     // 5-comparator sorting network on unsigned keys
@@ -265,6 +269,13 @@ __device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t no
     uint32_t lo = min(a, c), m1 = max(a, c), m2 = min(b, d), hi = max(b, d);
     r.k0 = lo; r.k1 = min(m1, m2); r.k2 = max(m1, m2); r.k3 = hi;
     return r;
+}
+// branch-free slot select (two bit tests + three v_cndmask; an `i == 0 ? .. : i == 1 ? ..` chain is lowered to a switch with
+// divergent branches by the compiler)
+__device__ __forceinline__ uint32_t pick4b(const uint4 &v, uint32_t i) {
+    const bool b0 = i & 1u, b1 = i & 2u;
+    const uint32_t lo = b0 ? v.y : v.x, hi = b0 ? v.w : v.z;
+    return b1 ? hi : lo;
 }
 __device__ __forceinline__ uint32_t pick4(const uint4 &v, uint32_t i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 

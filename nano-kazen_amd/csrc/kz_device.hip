@@ -419,7 +419,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
     tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
-    const size_t traceLds = (size_t)tune.ldsStack * KZ_BLOCK * sizeof(uint32_t);
+    const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);      // + one scratch slot per lane (branch-free pushes)
     {
         const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack);
         if (needOvf > ds->ovfCap) {

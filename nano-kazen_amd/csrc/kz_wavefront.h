@@ -352,7 +352,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide; uint32_t *ovf; uint32_t ovfStride; };
 
 template <int MODE, bool STATS, bool WIDE>
-__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune,
                                                         const uint32_t *__restrict__ queueB, const uint32_t *__restrict__ countPtrB) {
     extern __shared__ uint32_t s_stack[];
@@ -469,12 +469,23 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace(KzParams P, KzDevTables 
                 if (STATS) cn.nodes++;
                 if (WIDE) {
                     const Node4Test nt = node4Test(T, cur, o, rx, ry, rz, tmin, tmax);
-                    if (nt.k0 != 0xFFFFFFFFu) {
-                        if (nt.k3 != 0xFFFFFFFFu) push(sp, pick4(nt.refs, nt.k3 & 3u));
-                        if (nt.k2 != 0xFFFFFFFFu) push(sp, pick4(nt.refs, nt.k2 & 3u));
-                        if (nt.k1 != 0xFFFFFFFFu) push(sp, pick4(nt.refs, nt.k1 & 3u));
-                        cur = pick4(nt.refs, nt.k0 & 3u);
-                    } else empty = true;
+                    // sorted keys: misses (0xFFFFFFFF) come last, so the hit children are k0 .. k(h-1). The nearest becomes
+                    // `cur`; the others go on the stack far-to-near WITHOUT branches: child j (1..3) lands on slot
+                    // sp + np - j when it was hit and on the lane's scratch slot otherwise (np = number of pushes).
+                    const uint32_t c0 = pick4b(nt.refs, nt.k0), c1 = pick4b(nt.refs, nt.k1), c2 = pick4b(nt.refs, nt.k2), c3 = pick4b(nt.refs, nt.k3);
+                    const int h1 = nt.k1 != 0xFFFFFFFFu, h2 = nt.k2 != 0xFFFFFFFFu, h3 = nt.k3 != 0xFFFFFFFFu;
+                    const int np = h1 + h2 + h3;
+                    if (sp + 3 <= LS) {                                              // common case: everything stays in LDS
+                        stk[(h1 ? sp + np - 1 : LS) * KZ_BLOCK] = c1;
+                        stk[(h2 ? sp + np - 2 : LS) * KZ_BLOCK] = c2;
+                        stk[(h3 ? sp : LS) * KZ_BLOCK] = c3;
+                        sp += np;
+                    } else {
+                        if (h3) push(sp, c3);
+                        if (h2) push(sp, c2);
+                        if (h1) push(sp, c1);
+                    }
+                    if (nt.k0 != 0xFFFFFFFFu) cur = c0; else empty = true;
                 } else {
                     const NodeTest nt = nodeTest(T, cur, o, rx, ry, rz, tmin, tmax);
                     if (nt.h0 && nt.h1) {
