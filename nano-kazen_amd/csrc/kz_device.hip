@@ -69,15 +69,19 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDev
 // are bit-identical to ImageBlock::put; only the order of the float additions differs (H10).
 // ============================================================================================
 #define KZ_FILM_TILE 16
-#define KZ_FILM_CHUNK 8
 #define KZ_FILM_RMAX (KZ_FILM_TILE + KZ_MAX_FILTER_TAPS - 1)
+// The filter weight of a sample is separable and, per axis, depends only on the sample and on WHICH of its `taps` neighbour
+// columns (rows) the film pixel is: the staging pass evaluates validity (Color3f::isValid), the bounds test and the table
+// look-up of block.cpp:64-80 once per (sample, tap) — 2*taps evaluations per sample instead of 2*taps^2 — and the gather pass
+// is left with five LDS reads and the multiply-adds of block.cpp:84. A sample that is invalid, absent or out of bounds carries
+// weight 0 and adds an exact zero, so the sums are the ones the reference forms.
 __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *__restrict__ filter, const int32_t *__restrict__ pixIndex,
-                                                      uint32_t S, const float *__restrict__ inJx, const float *__restrict__ inJy,
+                                                      uint32_t S, int chunk, const float *__restrict__ inJx, const float *__restrict__ inJy,
                                                       const float *__restrict__ inR, const float *__restrict__ inG, const float *__restrict__ inB,
                                                       float4 *__restrict__ film) {
     __shared__ float s_filter[KZ_FILTER_RESOLUTION + 1];
     __shared__ int32_t s_pl[KZ_FILM_RMAX * KZ_FILM_RMAX];
-    extern __shared__ float s_samp[];              // [5][KZ_FILM_CHUNK][R*R]
+    extern __shared__ float s_samp[];              // [3 + 2*taps][chunk][R*R]: r g b | wx[taps] | wy[taps]
     const int tid = threadIdx.x;
     if (tid <= KZ_FILTER_RESOLUTION) s_filter[tid] = filter[tid];
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border;
@@ -100,42 +104,43 @@ __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *_
     const bool inFilm = fx < cols && fy < rows;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float r = P.filterRadius, lf = P.lookupFactor;
-    const int plane = KZ_FILM_CHUNK * RR;
-    for (uint32_t sBase = 0; sBase < S; sBase += KZ_FILM_CHUNK) {
-        const int ch = (int)min((uint32_t)KZ_FILM_CHUNK, S - sBase);
+    const int plane = chunk * RR;
+    float *s_wx = s_samp + 3 * plane, *s_wy = s_samp + (3 + taps) * plane;
+    for (uint32_t sBase = 0; sBase < S; sBase += (uint32_t)chunk) {
+        const int ch = (int)min((uint32_t)chunk, S - sBase);
         __syncthreads();
-        for (int i = tid; i < RR * KZ_FILM_CHUNK; i += 256) {
-            const int q = i / KZ_FILM_CHUNK, s = i - q * KZ_FILM_CHUNK;
+        for (int i = tid; i < RR * ch; i += 256) {
+            const int q = i / ch, s = i - q * ch;
             const int pl = s_pl[q];
-            float jx = 0.f, jy = 0.f, cr = -1.f, cg = 0.f, cb = 0.f;     // r = -1: "no sample" (fails Color3f::isValid)
-            if (pl >= 0 && s < ch) {
-                const size_t gi = (size_t)pl * S + sBase + s;
-                jx = inJx[gi]; jy = inJy[gi]; cr = inR[gi]; cg = inG[gi]; cb = inB[gi];
-            }
+            if (pl < 0) continue;                                            // the gather pass skips these source pixels
+            const size_t gi = (size_t)pl * S + sBase + s;
+            const float jx = inJx[gi], jy = inJy[gi], cr = inR[gi], cg = inG[gi], cb = inB[gi];
+            const bool valid = cr >= 0.f && cg >= 0.f && cb >= 0.f && isfinite(cr) && isfinite(cg) && isfinite(cb);   // Color3f::isValid
             const int o = s * RR + q;
-            s_samp[o] = jx; s_samp[plane + o] = jy; s_samp[2 * plane + o] = cr; s_samp[3 * plane + o] = cg; s_samp[4 * plane + o] = cb;
+            s_samp[o] = valid ? cr : 0.f; s_samp[plane + o] = valid ? cg : 0.f; s_samp[2 * plane + o] = valid ? cb : 0.f;
+            const int px = sx0 + q % R, py = sy0 + q / R;
+            const int bx0 = px & ~31, by0 = py & ~31;                        // the reference block this sample is rendered in
+            const float posx = ((float)px + jx) - 0.5f - (float)(bx0 - P.border), posy = ((float)py + jy) - 0.5f - (float)(by0 - P.border);   // block.cpp:64-67
+            const float lox = ceilf(posx - r), hix = floorf(posx + r), loy = ceilf(posy - r), hiy = floorf(posy + r);                     // block.cpp:70-73
+            for (int t = 0; t < taps; ++t) {
+                // the film pixel that sees this source pixel through tap t: f = p + border - tapLo - t
+                const float xb = (float)(px + P.border - P.tapLo - t - bx0), yb = (float)(py + P.border - P.tapLo - t - by0);
+                float wx = 0.f, wy = 0.f;
+                if (valid && !(xb < lox || xb > hix)) wx = s_filter[(int)(fabsf(xb - posx) * lf)];                                       // block.cpp:77-80
+                if (valid && !(yb < loy || yb > hiy)) wy = s_filter[(int)(fabsf(yb - posy) * lf)];
+                s_wx[t * plane + o] = wx; s_wy[t * plane + o] = wy;
+            }
         }
         __syncthreads();
         if (!inFilm) continue;
         for (int dy = 0; dy < taps; ++dy) {
-            const int py = fy - P.border + P.tapLo + dy;
-            const int by0 = py & ~31;
-            const float yb = (float)(fy - by0), offy = (float)(by0 - P.border);
             for (int dx = 0; dx < taps; ++dx) {
                 const int q = (ly + dy) * R + (lx + dx);
                 if (s_pl[q] < 0) continue;
-                const int px = fx - P.border + P.tapLo + dx;
-                const int bx0 = px & ~31;                                    // the reference block this sample is rendered in
-                const float xb = (float)(fx - bx0), offx = (float)(bx0 - P.border);
                 for (int s = 0; s < ch; ++s) {
                     const int o = s * RR + q;
-                    const float cr = s_samp[2 * plane + o], cg = s_samp[3 * plane + o], cb = s_samp[4 * plane + o];
-                    if (!(cr >= 0.f && cg >= 0.f && cb >= 0.f && isfinite(cr) && isfinite(cg) && isfinite(cb))) continue;   // Color3f::isValid
-                    const float sx = (float)px + s_samp[o], sy = (float)py + s_samp[plane + o];
-                    const float posx = sx - 0.5f - offx, posy = sy - 0.5f - offy;            // block.cpp:64-67
-                    if (xb < ceilf(posx - r) || xb > floorf(posx + r) || yb < ceilf(posy - r) || yb > floorf(posy + r)) continue;   // block.cpp:70-73
-                    const float wx = s_filter[(int)(fabsf(xb - posx) * lf)];                // block.cpp:77-80
-                    const float wy = s_filter[(int)(fabsf(yb - posy) * lf)];
+                    const float cr = s_samp[o], cg = s_samp[plane + o], cb = s_samp[2 * plane + o];
+                    const float wx = s_wx[dx * plane + o], wy = s_wy[dy * plane + o];
                     acc.x += cr * wx * wy; acc.y += cg * wx * wy; acc.z += cb * wx * wy; acc.w += 1.0f * wx * wy;   // block.cpp:84
                 }
             }
@@ -542,9 +547,11 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
         HIP_TRY(hipEventRecord(ep.b, stream));
         HIP_TRY(hipGetLastError());
         const dim3 fgrid((cols + KZ_FILM_TILE - 1) / KZ_FILM_TILE, (rows + KZ_FILM_TILE - 1) / KZ_FILM_TILE);
-        const int fr = KZ_FILM_TILE + (P.tapHi - P.tapLo);
-        const size_t fshm = (size_t)5 * KZ_FILM_CHUNK * fr * fr * sizeof(float);
-        hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, stream, P, ds->T.filter, ds->pixIndex, Sp, ds->sJx, ds->sJy, ds->sR, ds->sG,
+        const int ftaps = P.tapHi - P.tapLo + 1, fr = KZ_FILM_TILE + ftaps - 1;
+        const size_t perSample = (size_t)(3 + 2 * ftaps) * fr * fr * sizeof(float);
+        const int fchunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)Sp, (size_t)8, (size_t)(64 * 1024) / perSample}));
+        const size_t fshm = perSample * fchunk;
+        hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, stream, P, ds->T.filter, ds->pixIndex, Sp, fchunk, ds->sJx, ds->sJy, ds->sR, ds->sG,
                            ds->sB, ds->film);
         HIP_TRY(hipGetLastError());
         if (pipeline == 2) { int rc_ = stageMark(ds, stream, 4); if (rc_) return rc_; }

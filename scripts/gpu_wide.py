@@ -11,4 +11,4 @@ for w in (1, 1):
     sc.render(32, 48); sc.sync(); sc.render(48, 64); sc.sync()
     print(w, sc.last_kernel_ms(), sc.last_stage_ms(), flush=True)
     films[w] = sc.film()
-np.save("gpurun_out/film_coop.npy", films[1][::8, ::8])
+np.save("gpurun_out/film_new.npy", films[1][::8, ::8])
