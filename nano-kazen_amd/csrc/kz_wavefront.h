@@ -22,7 +22,7 @@
 #pragma once
 #include "kz_devfn.h"
 
-#define KZ_WF_QCAP 2048            // LDS staging entries per output queue per workgroup
+#define KZ_WF_QCAP 1024            // LDS staging entries per output queue per workgroup
 
 struct KzWf {
     float4 *rayA, *rayB;           // o.xyz tmin | d.xyz tmax
@@ -170,145 +170,205 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
 #ifndef KZ_SHADE_WAVES
 #define KZ_SHADE_WAVES 3
 #endif
+// Two passes per round of 256 queue entries, because on many scenes about half of the hits end the path before any shading
+// happens (a one-sided BSDF seen from behind, an emitter, a miss): pass A rebuilds the intersection record and classifies;
+// the entries that still need the light sample and the BSDF sample are compacted through LDS (record = slot + frame + uv),
+// and pass B — which carries ~85 % of the kernel's instructions — only ever runs on full waves.
+#define KZ_SV_CAP (2 * KZ_BLOCK)
 template <bool STATS, bool EXT>
 __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
                                                         uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm,
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
                                                         uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
+    constexpr int SVW = EXT ? 20 : 16;                       // words per survivor: slot, p, s, t, n, uv, mesh (+ dpdu)
     __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
-    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; }
+    __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svN;
+    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svN = 0; }
     __syncthreads();
     WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
     const uint32_t count = countPtr ? *countPtr : countImm;
     const float eps = P.traceBias;
+    const int lane = threadIdx.x & 63;
     Counters cn = {0, 0, 0, 0, 0, 0};
-    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
-        const uint32_t qi = base + threadIdx.x;
-        bool pushNext = false, pushShadow = false;
+    for (uint32_t base = blockIdx.x * KZ_BLOCK;; base += gridDim.x * KZ_BLOCK) {
+        const bool more = base < count;                                               // uniform over the workgroup
+        // ================= pass A: hit record -> intersection, miss / emitter / back-face end here =================
+        bool survivor = false;
         uint32_t slot = 0;
-        if (qi < count) {
+        Its its;
+        if (more && base + threadIdx.x < count) {
+            const uint32_t qi = base + threadIdx.x;
             slot = queue ? queue[qi] : qi;
             const float4 h = W.hit[slot];
-            const float4 ra = W.rayA[slot], rb = W.rayB[slot];
-            const V3 ro = mk(ra.x, ra.y, ra.z), rd = mk(rb.x, rb.y, rb.z);
-            float4 th = W.thr[slot];
-            V3 throughput = mk(th.x, th.y, th.z);
-            const float eta = th.w;
+            const float4 rb = W.rayB[slot];
+            const V3 rd = mk(rb.x, rb.y, rb.z);
             if (!(h.x < KZ_INF)) {
                 // miss: black for the primary ray (H5), background after a bounce (integrator.cpp:315-318)
                 if (iter > 0 && P.bgPresent && !(isnan(rd.x) || isnan(rd.y) || isnan(rd.z))) {
-                    const V3 c = throughput * mk(P.bgRadiance[0], P.bgRadiance[1], P.bgRadiance[2]);
+                    const float4 th = W.thr[slot];
+                    const V3 c = mk(th.x, th.y, th.z) * mk(P.bgRadiance[0], P.bgRadiance[1], P.bgRadiance[2]);
                     W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
                 }
             } else {
                 RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = __float_as_uint(h.w);
                 rh.gid = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + rh.tri)[2].w);
-                Its its; postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
+                postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
                 const KzMeshRow mrow = T.meshes[its.mesh];
-                const float4 mi = W.misc[slot];
-                float accRough = mi.y;
                 if (mrow.light >= 0) {                                                        // integrator.cpp:226-231, 322-327
                     const KzLightRow &lr = T.lights[mrow.light];
+                    const float4 ra = W.rayA[slot], th = W.thr[slot], mi = W.misc[slot];
+                    const V3 ro = mk(ra.x, ra.y, ra.z);
                     const V3 wi = normalized(its.p - ro);
                     float bsdfWeight = 1.f;
                     if (iter > 0 && mi.z == 0.f) bsdfWeight = powerHeuristic(mi.x, lightPdfSolidAngle(lr.normalization, its.sh.n, wi, its.p, ro));   // mi.z: EDiscrete (integrator.cpp:329-331)
                     if (dot(its.sh.n, -wi) > 0.f) {
-                        const V3 c = (bsdfWeight * throughput) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
+                        const V3 c = (bsdfWeight * mk(th.x, th.y, th.z)) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
                         W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
                     }
                 } else {
-                    const uint32_t pl = slot / S;
-                    const uint32_t pxy = pixList[pl];
-                    Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
-                    bool alive = true;
-                    if (iter >= 3) {                                                          // integrator.cpp:237-244
-                        const float probability = fminf(maxCoeff(throughput) * eta * eta, 0.95f);
-                        if (probability <= smp.next1D(P, T)) alive = false;
-                        else throughput = throughput / probability;
-                    }
-                    if (alive) {
-                        const KzBSDF bsdf = T.bsdfs[mrow.bsdf];
-                        const V3 wiLocal = toLocal(its.sh, -rd);
-                        // A one-sided BSDF seen from below evaluates to 0 for every light sample (no shadow ray, nothing added) and its
-                        // sample() returns 0 (the path ends): nothing after this point can be observed. Only the two-sided
-                        // transmissive models go on. (The light sample is still counted so the counters match the reference's work.)
-                        // A normal map can turn a below-the-horizon wi into an above-the-horizon one in the perturbed frame.
-                        const bool twoSided = EXT && (bsdf.type == KZ_BSDF_DIELECTRIC || bsdf.type == KZ_BSDF_ROUGHDIELECTRIC || bsdf.type == KZ_BSDF_NORMALMAP);
-                        if (!(wiLocal.z > 0.f) && !twoSided && !isnan(wiLocal.z)) { if (STATS && P.nLights > 0) cn.lsamples++; alive = false; }
-                    }
-                    if (alive) {
-                        KzBSDF bsdf = T.bsdfs[mrow.bsdf];
-                        NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
-                        const V3 wiLocal = toLocal(its.sh, -rd);
-                        const float pick = smp.next1D(P, T);                                  // drawn even without lights
-                        if (P.nLights > 0) {                                                  // integrator.cpp:247-295
-                            const uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
-                            const KzLightRow lrow = T.lights[li];
-                            if (STATS) cn.lsamples++;
-                            const uint32_t tri = cdfSample(T.cdf + lrow.cdfOffset, lrow.nF, smp.next1D(P, T));
-                            const float su0 = sqrtf(smp.next1D(P, T));
-                            const float u = 1 - su0;
-                            const float v = smp.next1D(P, T) * su0;
-                            const float4 *sp = reinterpret_cast<const float4 *>(T.shade + lrow.triOffset + tri);
-                            const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-                            const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
-                            const V3 lp = p0 + u * (p1 - p0) + v * (p2 - p0);
-                            V3 ln;
-                            if (T.meshes[lrow.mesh].flags & 1u) {
-                                const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
-                                ln = n0 + u * (n1 - n0) + v * (n2 - n0);                      // H8
-                            } else ln = normalized(cross(p1 - p0, p2 - p0));
-                            const V3 toL = lp - its.p;
-                            const V3 lwi = normalized(toL);
-                            const float dist = norm(toL);
-                            const float lpdf = lightPdfSolidAngle(lrow.normalization, ln, lwi, lp, its.p);
-                            V3 Ls = mk(0.f);
-                            if (lpdf > 0.f && !isnan(lpdf) && !isinf(lpdf)) {
-                                const V3 ev = dot(ln, -lwi) > 0.f ? mk(lrow.radiance[0], lrow.radiance[1], lrow.radiance[2]) : mk(0.f);
-                                Ls = ev / lpdf;
-                            }
-                            Ls = Ls / P.lightPickPdf;
-                            const V3 woL = toLocal(its.sh, lwi);
-                            const V3 f = surfEval<EXT>(bsdf, nm, its, wiLocal, woL, accRough);
-                            const float bpdfL = surfPdf<EXT>(bsdf, nm, its, wiLocal, woL, accRough, true);
-                            const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
-                            // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
-                            if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
-                                W.shA[slot] = make_float4(its.p.x, its.p.y, its.p.z, dist - eps);
-                                W.shB[slot] = make_float4(lwi.x, lwi.y, lwi.z, eps);
-                                W.shL[slot] = make_float4(pend.x, pend.y, pend.z, 0.f);
-                                pushShadow = true;
-                            }
+                    // A one-sided BSDF seen from below evaluates to 0 for every light sample (no shadow ray, nothing added) and its
+                    // sample() returns 0 (the path ends): nothing after this point can be observed. Only the two-sided
+                    // transmissive models go on; a normal map can turn a below-the-horizon wi into an above-the-horizon one.
+                    const float wz = dot(-rd, its.sh.n);                                       // toLocal(its.sh, -rd).z
+                    bool twoSided = false;
+                    if (EXT) { const int bt = T.bsdfs[mrow.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
+                    survivor = (wz > 0.f) || twoSided || isnan(wz);
+                    if (STATS && !survivor && P.nLights > 0) {
+                        // counters only: the reference draws the roulette sample before it takes the light sample (integrator.cpp:237-247)
+                        bool alive = true;
+                        if (iter >= 3) {
+                            const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
+                            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
+                            const float4 th = W.thr[slot];
+                            if (fminf(maxCoeff(mk(th.x, th.y, th.z)) * th.w * th.w, 0.95f) <= smp.next1D(P, T)) alive = false;
                         }
-                        if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
-                        float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
-                        const float s1 = smp.next1D(P, T);
-                        V3 woLocal; bool ok, discrete, solid; float etaScale, pdfS;
-                        const V3 weight = surfSample<EXT>(bsdf, nm, its, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale, pdfS, solid);
-                        throughput = throughput * weight;
-                        const float etaNext = eta * etaScale;
-                        if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
-                            const float bpdf = pdfS >= 0.f ? pdfS : surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, solid);
-                            const V3 nd = toWorld(its.sh, woLocal);                           // H9
-                            // the ray after the LAST bounce only matters for the background term
-                            if (iter + 1 < P.maxDepth || P.bgPresent) {
-                                W.rayA[slot] = make_float4(its.p.x, its.p.y, its.p.z, eps);
-                                W.rayB[slot] = make_float4(nd.x, nd.y, nd.z, KZ_INF);
-                                W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, etaNext);
-                                W.misc[slot] = make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f);
-                                wfStoreSampler(P, W, slot, smp);
-                                pushNext = true;
-                            }
-                        }
+                        if (alive) cn.lsamples++;
                     }
                 }
             }
         }
+        {   // compaction of the survivors into the LDS record table
+            const unsigned long long m = __ballot(survivor);
+            uint32_t b = 0;
+            if (lane == 0 && m) b = atomicAdd(&s_svN, (uint32_t)__popcll(m));
+            b = __shfl(b, 0, 64);
+            if (survivor) {
+                uint32_t *r = s_sv + b + __popcll(m & ((1ull << lane) - 1ull));
+                r[0] = slot; r[KZ_SV_CAP] = __float_as_uint(its.p.x); r[2 * KZ_SV_CAP] = __float_as_uint(its.p.y); r[3 * KZ_SV_CAP] = __float_as_uint(its.p.z);
+                r[4 * KZ_SV_CAP] = __float_as_uint(its.sh.s.x); r[5 * KZ_SV_CAP] = __float_as_uint(its.sh.s.y); r[6 * KZ_SV_CAP] = __float_as_uint(its.sh.s.z);
+                r[7 * KZ_SV_CAP] = __float_as_uint(its.sh.t.x); r[8 * KZ_SV_CAP] = __float_as_uint(its.sh.t.y); r[9 * KZ_SV_CAP] = __float_as_uint(its.sh.t.z);
+                r[10 * KZ_SV_CAP] = __float_as_uint(its.sh.n.x); r[11 * KZ_SV_CAP] = __float_as_uint(its.sh.n.y); r[12 * KZ_SV_CAP] = __float_as_uint(its.sh.n.z);
+                r[13 * KZ_SV_CAP] = __float_as_uint(its.uvx); r[14 * KZ_SV_CAP] = __float_as_uint(its.uvy); r[15 * KZ_SV_CAP] = its.mesh;
+                if (EXT) { r[16 * KZ_SV_CAP] = __float_as_uint(its.dpdu.x); r[17 * KZ_SV_CAP] = __float_as_uint(its.dpdu.y); r[18 * KZ_SV_CAP] = __float_as_uint(its.dpdu.z); }
+            }
+        }
+        __syncthreads();
+        // ================= pass B: one survivor per thread once a full workgroup of them is waiting (or at the end) =================
+        const uint32_t nsv = s_svN;
+        bool pushNext = false, pushShadow = false;
+        uint32_t take = 0;
+        if (nsv >= KZ_BLOCK || (!more && nsv > 0)) take = min(nsv, (uint32_t)KZ_BLOCK);
+        if (threadIdx.x < take) {
+            const uint32_t *r = s_sv + (nsv - take) + threadIdx.x;
+            slot = r[0];
+            its.p = mk(__uint_as_float(r[KZ_SV_CAP]), __uint_as_float(r[2 * KZ_SV_CAP]), __uint_as_float(r[3 * KZ_SV_CAP]));
+            its.sh.s = mk(__uint_as_float(r[4 * KZ_SV_CAP]), __uint_as_float(r[5 * KZ_SV_CAP]), __uint_as_float(r[6 * KZ_SV_CAP]));
+            its.sh.t = mk(__uint_as_float(r[7 * KZ_SV_CAP]), __uint_as_float(r[8 * KZ_SV_CAP]), __uint_as_float(r[9 * KZ_SV_CAP]));
+            its.sh.n = mk(__uint_as_float(r[10 * KZ_SV_CAP]), __uint_as_float(r[11 * KZ_SV_CAP]), __uint_as_float(r[12 * KZ_SV_CAP]));
+            its.uvx = __uint_as_float(r[13 * KZ_SV_CAP]); its.uvy = __uint_as_float(r[14 * KZ_SV_CAP]); its.mesh = r[15 * KZ_SV_CAP];
+            if (EXT) its.dpdu = mk(__uint_as_float(r[16 * KZ_SV_CAP]), __uint_as_float(r[17 * KZ_SV_CAP]), __uint_as_float(r[18 * KZ_SV_CAP]));
+            const KzMeshRow mrow = T.meshes[its.mesh];
+            const float4 rb = W.rayB[slot];
+            const V3 rd = mk(rb.x, rb.y, rb.z);
+            float4 th = W.thr[slot];
+            V3 throughput = mk(th.x, th.y, th.z);
+            const float eta = th.w;
+            const float4 mi = W.misc[slot];
+            float accRough = mi.y;
+            const uint32_t pl = slot / S;
+            const uint32_t pxy = pixList[pl];
+            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
+            bool alive = true;
+            if (iter >= 3) {                                                          // integrator.cpp:237-244
+                const float probability = fminf(maxCoeff(throughput) * eta * eta, 0.95f);
+                if (probability <= smp.next1D(P, T)) alive = false;
+                else throughput = throughput / probability;
+            }
+            if (alive) {
+                KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+                NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
+                const V3 wiLocal = toLocal(its.sh, -rd);
+                const float pick = smp.next1D(P, T);                                  // drawn even without lights
+                if (P.nLights > 0) {                                                  // integrator.cpp:247-295
+                    const uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
+                    const KzLightRow lrow = T.lights[li];
+                    if (STATS) cn.lsamples++;
+                    const uint32_t tri = cdfSample(T.cdf + lrow.cdfOffset, lrow.nF, smp.next1D(P, T));
+                    const float su0 = sqrtf(smp.next1D(P, T));
+                    const float u = 1 - su0;
+                    const float v = smp.next1D(P, T) * su0;
+                    const float4 *sp = reinterpret_cast<const float4 *>(T.shade + lrow.triOffset + tri);
+                    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+                    const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
+                    const V3 lp = p0 + u * (p1 - p0) + v * (p2 - p0);
+                    V3 ln;
+                    if (T.meshes[lrow.mesh].flags & 1u) {
+                        const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
+                        ln = n0 + u * (n1 - n0) + v * (n2 - n0);                      // H8
+                    } else ln = normalized(cross(p1 - p0, p2 - p0));
+                    const V3 toL = lp - its.p;
+                    const V3 lwi = normalized(toL);
+                    const float dist = norm(toL);
+                    const float lpdf = lightPdfSolidAngle(lrow.normalization, ln, lwi, lp, its.p);
+                    V3 Ls = mk(0.f);
+                    if (lpdf > 0.f && !isnan(lpdf) && !isinf(lpdf)) {
+                        const V3 ev = dot(ln, -lwi) > 0.f ? mk(lrow.radiance[0], lrow.radiance[1], lrow.radiance[2]) : mk(0.f);
+                        Ls = ev / lpdf;
+                    }
+                    Ls = Ls / P.lightPickPdf;
+                    const V3 woL = toLocal(its.sh, lwi);
+                    const V3 f = surfEval<EXT>(bsdf, nm, its, wiLocal, woL, accRough);
+                    const float bpdfL = surfPdf<EXT>(bsdf, nm, its, wiLocal, woL, accRough, true);
+                    const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
+                    // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
+                    if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
+                        W.shA[slot] = make_float4(its.p.x, its.p.y, its.p.z, dist - eps);
+                        W.shB[slot] = make_float4(lwi.x, lwi.y, lwi.z, eps);
+                        W.shL[slot] = make_float4(pend.x, pend.y, pend.z, 0.f);
+                        pushShadow = true;
+                    }
+                }
+                if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
+                float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
+                const float s1 = smp.next1D(P, T);
+                V3 woLocal; bool ok, discrete, solid; float etaScale, pdfS;
+                const V3 weight = surfSample<EXT>(bsdf, nm, its, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale, pdfS, solid);
+                throughput = throughput * weight;
+                const float etaNext = eta * etaScale;
+                if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
+                    const float bpdf = pdfS >= 0.f ? pdfS : surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, solid);
+                    const V3 nd = toWorld(its.sh, woLocal);                           // H9
+                    // the ray after the LAST bounce only matters for the background term
+                    if (iter + 1 < P.maxDepth || P.bgPresent) {
+                        W.rayA[slot] = make_float4(its.p.x, its.p.y, its.p.z, eps);
+                        W.rayB[slot] = make_float4(nd.x, nd.y, nd.z, KZ_INF);
+                        W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, etaNext);
+                        W.misc[slot] = make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f);
+                        wfStoreSampler(P, W, slot, smp);
+                        pushNext = true;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // every record of this batch has been read
+        if (threadIdx.x == 0 && take) s_svN = nsv - take;
         apN.push(pushNext, slot);
         apS.push(pushShadow, slot);
-        apN.maybeFlush(false);
+        apN.maybeFlush(false);                             // (syncs: the new s_svN is visible before the next pass A)
         apS.maybeFlush(false);
+        if (!more && nsv - take == 0) break;
+        if (!more) base -= gridDim.x * KZ_BLOCK;           // stay past the end while the table drains
     }
     apN.maybeFlush(true);
     apS.maybeFlush(true);
