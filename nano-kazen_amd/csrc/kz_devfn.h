@@ -238,10 +238,12 @@ __device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin
 // 0xFFFFFFFF for a miss, sorted ascending, so key[0] is the nearest hit child.
 struct Node4Test { uint32_t k0, k1, k2, k3; uint4 refs; };
 typedef float kz_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax) {
+// keys in slot order: (bits of max(tnear, tmin) with the two low bits replaced by the child slot), 0xFFFFFFFF for a miss
+__device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax,
+                                          uint32_t (&key)[4], uint4 &refs) {
     const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + node);
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
-    Node4Test r; r.refs = np[3];
+    refs = np[3];
     const float ax = __uint_as_float((q0.w & 0xffu) << 23) * rx, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * ry,
                 az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * rz;
     const float bx = (__uint_as_float(q0.x) - o.x) * rx, by = (__uint_as_float(q0.y) - o.y) * ry, bz = (__uint_as_float(q0.z) - o.z) * rz;
@@ -253,7 +255,6 @@ __device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t no
     const uint32_t nY = ry >= 0.f ? q1.y : q2.x, fY = ry >= 0.f ? q2.x : q1.y;
     const uint32_t nZ = rz >= 0.f ? q1.z : q2.y, fZ = rz >= 0.f ? q2.y : q1.z;
     const kz_f2 AX = {ax, ax}, AY = {ay, ay}, AZ = {az, az}, BX = {bx, bx}, BY = {by, by}, BZ = {bz, bz};
-    uint32_t key[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const kz_f2 qx = {(float)((nX >> (8 * i)) & 0xffu), (float)((fX >> (8 * i)) & 0xffu)};
@@ -264,6 +265,10 @@ __device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t no
         const float f = fminf(fminf(fminf(tx.y, ty.y), tz.y) * 1.0000004f, tmax);
         key[i] = (n <= f) ? ((__float_as_uint(n) & ~3u) | (uint32_t)i) : 0xFFFFFFFFu;
     }
+}
+__device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax) {
+    Node4Test r; uint32_t key[4];
+    node4Keys(T, node, o, rx, ry, rz, tmin, tmax, key, r.refs);
     // 5-comparator sorting network on unsigned keys
     uint32_t a = min(key[0], key[1]), b = max(key[0], key[1]), c = min(key[2], key[3]), d = max(key[2], key[3]);
     uint32_t lo = min(a, c), m1 = max(a, c), m2 = min(b, d), hi = max(b, d);

@@ -527,7 +527,48 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
             if (inner) {
                 bool empty = false;
                 if (STATS) cn.nodes++;
-                if (WIDE) {
+#ifndef KZ_TRAV_ORDER
+#define KZ_TRAV_ORDER 1
+#endif
+#ifndef KZ_SHADOW_SLOT_ORDER
+#define KZ_SHADOW_SLOT_ORDER 1
+#endif
+                if (WIDE && KZ_TRAV_ORDER) {
+                    // Child order. Closest-hit rays descend into the NEAREST hit child and leave the other hit children on the
+                    // stack in slot order (a full sort of the siblings buys 6 % fewer node visits and costs 12 % more
+                    // instructions per visit); any-hit shadow rays take the hit children in slot order altogether. Pushes
+                    // are branch-free: a hit child lands on the next free slot, a missed one on the lane's scratch slot.
+                    uint32_t key[4]; uint4 refs;
+                    node4Keys(T, cur, o, rx, ry, rz, tmin, tmax, key, refs);
+                    bool p0, p1, p2, p3;                                          // child i goes on the stack
+                    uint32_t nxt; bool any;
+                    if (MODE == 2 && KZ_SHADOW_SLOT_ORDER) {
+                        const bool h0 = key[0] != 0xFFFFFFFFu, h1 = key[1] != 0xFFFFFFFFu, h2 = key[2] != 0xFFFFFFFFu, h3 = key[3] != 0xFFFFFFFFu;
+                        any = h0 || h1 || h2 || h3;
+                        nxt = h0 ? refs.x : (h1 ? refs.y : (h2 ? refs.z : refs.w));
+                        p0 = false; p1 = h1 && h0; p2 = h2 && (h0 || h1); p3 = h3 && (h0 || h1 || h2);
+                    } else {
+                        const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+                        any = kmin != 0xFFFFFFFFu;
+                        nxt = pick4b(refs, kmin);
+                        p0 = key[0] != 0xFFFFFFFFu && key[0] != kmin; p1 = key[1] != 0xFFFFFFFFu && key[1] != kmin;
+                        p2 = key[2] != 0xFFFFFFFFu && key[2] != kmin; p3 = key[3] != 0xFFFFFFFFu && key[3] != kmin;
+                    }
+                    const int c1 = (int)p0, c2 = c1 + (int)p1, c3 = c2 + (int)p2, np = c3 + (int)p3;
+                    if (sp + 3 <= LS) {                                              // common case: everything stays in LDS
+                        if (!(MODE == 2 && KZ_SHADOW_SLOT_ORDER)) stk[(p0 ? sp : LS) * KZ_BLOCK] = refs.x;
+                        stk[(p1 ? sp + c1 : LS) * KZ_BLOCK] = refs.y;
+                        stk[(p2 ? sp + c2 : LS) * KZ_BLOCK] = refs.z;
+                        stk[(p3 ? sp + c3 : LS) * KZ_BLOCK] = refs.w;
+                        sp += np;
+                    } else {
+                        if (p0) push(sp, refs.x);
+                        if (p1) push(sp, refs.y);
+                        if (p2) push(sp, refs.z);
+                        if (p3) push(sp, refs.w);
+                    }
+                    if (any) cur = nxt; else empty = true;
+                } else if (WIDE) {
                     const Node4Test nt = node4Test(T, cur, o, rx, ry, rz, tmin, tmax);
                     // sorted keys: misses (0xFFFFFFFF) come last, so the hit children are k0 .. k(h-1). The nearest becomes
                     // `cur`; the others go on the stack far-to-near WITHOUT branches: child j (1..3) lands on slot
