@@ -425,7 +425,8 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     uint32_t *ovf = tune.ovf + (size_t)blockIdx.x * KZ_BLOCK + threadIdx.x;
     const size_t ovfStride = tune.ovfStride;
     auto push = [&](int &sp_, uint32_t v) { if (sp_ < LS) stk[sp_ * KZ_BLOCK] = v; else ovf[(size_t)(sp_ - LS) * ovfStride] = v; ++sp_; };
-    auto pop = [&](int &sp_) -> uint32_t { --sp_; return sp_ < LS ? stk[sp_ * KZ_BLOCK] : ovf[(size_t)(sp_ - LS) * ovfStride]; };
+    // (an LDS read of the entry or of the scratch slot, replaced by the global entry in the rare deep case: no generic-pointer load)
+    auto pop = [&](int &sp_) -> uint32_t { --sp_; uint32_t v = stk[min(sp_, LS) * KZ_BLOCK]; if (sp_ >= LS) v = ovf[(size_t)(sp_ - LS) * ovfStride]; return v; };
     const uint32_t root = WIDE ? P.rootRef4 : P.rootRef;
     const float eps = P.traceBias;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
