@@ -157,8 +157,29 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the datasheet peak beside a measured device-to-device stream copy (read + write bytes / time)
+        copy_gbs = None
+        if True:
+            a = torch.empty(1 << 28, dtype=torch.float32, device="cuda:%d" % device_index)      # 1 GiB
+            b = torch.empty_like(a)
+            b.copy_(a); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                b.copy_(a)
+            e1.record(); torch.cuda.synchronize()
+            copy_gbs = round(8 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del a, b
+        pmc_note = None
+        ppath = os.path.join(ROOT, "profiles", "bound_latest.json")
+        if os.path.exists(ppath):
+            try:
+                pmc_note = json.load(open(ppath))
+            except Exception:
+                pmc_note = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "peak_copy_measured": copy_gbs,
+                    "limiter_from_pmc": pmc_note,
                     "kernel": "wavefront pass = kz_wf_generate + maxDepth x (kz_wf_trace<0> closest-hit + kz_wf_shade + "
                               "kz_wf_trace<2> shadow); hipEvent span on the launch stream",
                     "kernel_ms": round(kernel_ms_last, 3), "stages_ms": stage_ms_last,

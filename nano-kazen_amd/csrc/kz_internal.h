@@ -20,7 +20,8 @@ static_assert(sizeof(KzNode) == 64, "node packet must be 64 B");
 
 // BVH4 node with 8-bit quantised child boxes, 64 B (the wavefront traversal kernels use this tree; the megakernel and
 // kz_trace_rays keep the BVH2): one packet fetch tests FOUR children, which halves both the number of per-lane 16-B
-// gathers (the L1 tag rate is what bounds incoherent traversal on CDNA4) and the length of the dependent-load chain.
+// gathers and the length of the dependent-load chain (and, per ray, the instructions spent on loop control and stack traffic:
+// the traversal is VALU-issue-bound on MI355X).
 //   q0 = p.x p.y p.z | ex,ey,ez (biased float exponents, one byte each)   child box = p + q * 2^(e-127)
 //   q1 = qlo.x[4] qlo.y[4] qlo.z[4] qhi.x[4]   (4 x u8 per word, child i in byte i)
 //   q2 = qhi.y[4] qhi.z[4] - -

@@ -48,4 +48,12 @@ for k in wf:
         lanes = v.get("SQ_THREAD_CYCLES_VALU", 0) / max(v["SQ_ACTIVE_INST_VALU"], 1)
         print("%-34s launches %2d  ms %6.2f  VALU busy %4.0f%%  active lanes/instr %4.1f  VALU insts %6.0fM" %
               (k, v["launches"], v["GRBM_GUI_ACTIVE"] / 8 / 2.4e6, 100 * busy, lanes, v.get("SQ_INSTS_VALU", 0) / 1e6))
+bound = {"profile": "profiles/" + name, "note": "VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU"}
+for k in wf:
+    v = out[k]
+    if v.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_ACTIVE_INST_VALU" in v:
+        bound[k] = {"valu_busy": round(v["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v["GRBM_GUI_ACTIVE"] / 8), 3),
+                    "active_lanes_per_valu_inst": round(v.get("SQ_THREAD_CYCLES_VALU", 0) / max(v["SQ_ACTIVE_INST_VALU"], 1), 1),
+                    "l2_hit": round(v.get("TCC_HIT_sum", 0) / max(1.0, v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)), 3)}
+json.dump(bound, open(os.path.join(root, "profiles", "bound_latest.json"), "w"), indent=1)
 print(json.dumps(traffic)[:200])
