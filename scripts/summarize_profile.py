@@ -11,6 +11,17 @@ dst = os.path.join(root, "profiles", name)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench.json"))
 shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
+# With two passes in flight the kernel durations of the trace overlap; the per-pass figure comparable with bench.py's
+# roofline.kernel_ms is the steady-state distance between the ends of consecutive film kernels (one per pass).
+tr = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+if tr:
+    ends = sorted(int(r["End_Timestamp"]) for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith("kz_film_gather"))
+    gaps = sorted((b - a) / 1e6 for a, b in zip(ends, ends[1:]))
+    if gaps:
+        json.dump({"film_kernels": len(ends), "median_ms_between_pass_ends": round(gaps[len(gaps) // 2], 3), "min_ms": round(gaps[0], 3),
+                   "note": "rocprofv3 --kernel-trace of bench.py --steps 4 --warmup 1: time from the end of one pass (its kz_film_gather) to the end of the next"},
+                  open(os.path.join(dst, "pass_span_from_trace.json"), "w"), indent=1)
+        print("pass ends: n %d median gap %.3f ms" % (len(ends), gaps[len(gaps) // 2]))
 acc = defaultdict(lambda: defaultdict(float))
 launches = defaultdict(int)
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
