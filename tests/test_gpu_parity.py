@@ -361,6 +361,13 @@ def _fuzz_scene(S, seed):
               lambda: S.mirror(), lambda: S.dielectric(float(rng.uniform(1.2, 1.8)), 1.0), lambda: S.ggx(tuple(rng.uniform(0.2, 0.9, 3)), float(rng.uniform(0.05, 0.9)), float(rng.uniform(0, 0.5))),
               lambda: S.roughconductor(float(rng.uniform(0.05, 0.6)), str(rng.choice(["Au", "Cu", "Cr"]))), lambda: S.roughplastic(float(rng.uniform(0.05, 0.6)), kd=tuple(rng.uniform(0.1, 0.6, 3))),
               lambda: S.roughdielectric(float(rng.uniform(0.05, 0.6)))]
+    if seed % 3 == 0:                                                            # every third scene: texture trees and normal maps too (8f rank 4)
+        chk, noise, gray, nrm = S._test_images()
+        t_noise, t_gray = S.imagetexture(noise, float(rng.uniform(0.5, 4)), "srgb"), S.imagetexture(gray, float(rng.uniform(0.5, 4)), "linear")
+        t_nrm = S.imagetexture(nrm, float(rng.uniform(0.5, 3)), "linear")
+        makers += [lambda: S.lambertian(S.blend(t_gray, S.constanttexture(tuple(rng.uniform(0, 1, 3))), t_noise)),
+                   lambda: S.kazenstandard(t_noise, S.colorramp(t_gray, 0.1, 0.9), t_gray, clearcoat=float(rng.uniform(0, 1))),
+                   lambda: S.normalmap(t_nrm, makers[int(rng.integers(0, 8))]()), lambda: S.ggx(S.imagetexture(chk, 3.0, "srgb"), float(rng.uniform(0.1, 0.8)))]
     for m in d.meshes:
         if m["light"]:
             m["light"]["lightPrimaryVisibility"] = bool(rng.integers(0, 2))
@@ -386,7 +393,7 @@ def _fuzz_scene(S, seed):
     return d
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(15)))
 def test_randomized_scenes_match_oracle(gpu_lib, kz, O, seed):
     desc = _fuzz_scene(kz.scenes, 1000 + seed)
     sc = kz.Scene(desc, device=0)
