@@ -24,11 +24,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <sstream>
 #include <string>
+#include <unordered_map>
 #include <variant>
 #include <vector>
 
@@ -52,18 +55,63 @@ struct Transform {                                   // include/kazen/transform.
         r.m = {left[0], nu[0], d[0], o[0], left[1], nu[1], d[1], o[1], left[2], nu[2], d[2], o[2], 0, 0, 0, 1};
         return r;
     }
+    /// this * rhs (parser.cpp:243-290 left-multiplies every transform operation onto the running transform)
+    Transform operator*(const Transform &b) const {
+        Transform r;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s = 0.f; for (int k = 0; k < 4; ++k) s += m[4 * i + k] * b.m[4 * k + j]; r.m[4 * i + j] = s; }
+        return r;
+    }
+    /// Transform * Point3f: homogeneous multiply and divide (transform.h:59-62)
+    std::array<float, 3> point(const std::array<float, 3> &p) const {
+        float q[4];
+        for (int i = 0; i < 4; ++i) q[i] = m[4 * i] * p[0] + m[4 * i + 1] * p[1] + m[4 * i + 2] * p[2] + m[4 * i + 3];
+        return {q[0] / q[3], q[1] / q[3], q[2] / q[3]};
+    }
+    /// Transform * Normal3f: inverse transpose of the upper 3x3 (transform.h:54-56); the 4x4 inverse is formed in double
+    std::array<float, 3> normal(const std::array<float, 3> &n) const {
+        double a[16], inv[16]; for (int i = 0; i < 16; ++i) a[i] = m[i];
+        inv[0] = a[5]*a[10]*a[15]-a[5]*a[11]*a[14]-a[9]*a[6]*a[15]+a[9]*a[7]*a[14]+a[13]*a[6]*a[11]-a[13]*a[7]*a[10];
+        inv[4] = -a[4]*a[10]*a[15]+a[4]*a[11]*a[14]+a[8]*a[6]*a[15]-a[8]*a[7]*a[14]-a[12]*a[6]*a[11]+a[12]*a[7]*a[10];
+        inv[8] = a[4]*a[9]*a[15]-a[4]*a[11]*a[13]-a[8]*a[5]*a[15]+a[8]*a[7]*a[13]+a[12]*a[5]*a[11]-a[12]*a[7]*a[9];
+        inv[12] = -a[4]*a[9]*a[14]+a[4]*a[10]*a[13]+a[8]*a[5]*a[14]-a[8]*a[6]*a[13]-a[12]*a[5]*a[10]+a[12]*a[6]*a[9];
+        inv[1] = -a[1]*a[10]*a[15]+a[1]*a[11]*a[14]+a[9]*a[2]*a[15]-a[9]*a[3]*a[14]-a[13]*a[2]*a[11]+a[13]*a[3]*a[10];
+        inv[5] = a[0]*a[10]*a[15]-a[0]*a[11]*a[14]-a[8]*a[2]*a[15]+a[8]*a[3]*a[14]+a[12]*a[2]*a[11]-a[12]*a[3]*a[10];
+        inv[9] = -a[0]*a[9]*a[15]+a[0]*a[11]*a[13]+a[8]*a[1]*a[15]-a[8]*a[3]*a[13]-a[12]*a[1]*a[11]+a[12]*a[3]*a[9];
+        inv[2] = a[1]*a[6]*a[15]-a[1]*a[7]*a[14]-a[5]*a[2]*a[15]+a[5]*a[3]*a[14]+a[13]*a[2]*a[7]-a[13]*a[3]*a[6];
+        inv[6] = -a[0]*a[6]*a[15]+a[0]*a[7]*a[14]+a[4]*a[2]*a[15]-a[4]*a[3]*a[14]-a[12]*a[2]*a[7]+a[12]*a[3]*a[6];
+        inv[10] = a[0]*a[5]*a[15]-a[0]*a[7]*a[13]-a[4]*a[1]*a[15]+a[4]*a[3]*a[13]+a[12]*a[1]*a[7]-a[12]*a[3]*a[5];
+        const double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+        if (det == 0.0) return n;
+        // (M^-1)^T n: row i of the transposed inverse = column i of the inverse (rows/cols 0..2)
+        const double r0 = (inv[0] * n[0] + inv[4] * n[1] + inv[8] * n[2]) / det, r1 = (inv[1] * n[0] + inv[5] * n[1] + inv[9] * n[2]) / det,
+                     r2 = (inv[2] * n[0] + inv[6] * n[1] + inv[10] * n[2]) / det;
+        return {(float)r0, (float)r1, (float)r2};
+    }
 };
+using Vector3 = std::array<float, 3>;
+/// File resolver (filesystem/resolver.h as main.cpp uses it: the scene file's directory is prepended before parsing)
+inline std::vector<std::string> &fileResolverPaths() { static std::vector<std::string> p; return p; }
+inline std::string resolveFile(const std::string &name) {
+    if (name.empty() || name[0] == '/') return name;
+    for (const std::string &dir : fileResolverPaths()) { const std::string c = dir + "/" + name; if (std::ifstream(c).good()) return c; }
+    return name;
+}
 
 /// Typed property bag with defaults (include/kazen/proplist.h, src/kazen/proplist.cpp:5-32)
 class PropertyList {
 public:
-    using Value = std::variant<bool, int, float, std::string, Color3f, Transform>;
+    using Value = std::variant<bool, int, float, std::string, Color3f, Transform, Vector3>;
     void setBoolean(const std::string &n, bool v) { m_[n] = v; }
     void setInteger(const std::string &n, int v) { m_[n] = v; }
     void setFloat(const std::string &n, float v) { m_[n] = v; }
     void setString(const std::string &n, const std::string &v) { m_[n] = v; }
     void setColor(const std::string &n, const Color3f &v) { m_[n] = v; }
     void setTransform(const std::string &n, const Transform &v) { m_[n] = v; }
+    void setPoint(const std::string &n, const Vector3 &v) { m_[n] = v; }
+    void setVector(const std::string &n, const Vector3 &v) { m_[n] = v; }
+    Vector3 getPoint(const std::string &n, const Vector3 &d) const { return get<Vector3>(n, d); }
+    Vector3 getVector(const std::string &n, const Vector3 &d) const { return get<Vector3>(n, d); }
+    bool has(const std::string &n) const { return m_.count(n) != 0; }
     bool getBoolean(const std::string &n, bool d) const { return get<bool>(n, d); }
     int getInteger(const std::string &n, int d) const { return get<int>(n, d); }
     float getFloat(const std::string &n, float d) const { return get<float>(n, d); }
@@ -475,7 +523,56 @@ public:
 class Mesh : public Object {
 public:
     Mesh() {}
-    explicit Mesh(const PropertyList &) {}
+    /// "obj" (WavefrontOBJ, mesh.cpp:200-343): with a "filename" property the file is loaded exactly as the reference does —
+    /// v transformed by toWorld, vn by its inverse transpose and normalised, (p, uv, n) triples de-duplicated in encounter
+    /// order, quads split into (0,1,2) and (3,0,2); without one the buffers are handed over through setBuffers.
+    explicit Mesh(const PropertyList &props) {
+        if (!props.has("filename")) return;
+        const std::string filename = resolveFile(props.getString("filename", ""));
+        std::ifstream is(filename);
+        if (is.fail()) throw Exception("Unable to open OBJ file \"" + filename + "\"!");
+        const Transform trafo = props.getTransform("toWorld", Transform());
+        struct Key { uint32_t p = (uint32_t)-1, n = (uint32_t)-1, uv = (uint32_t)-1; bool operator==(const Key &o) const { return p == o.p && n == o.n && uv == o.uv; } };
+        struct KeyHash { size_t operator()(const Key &k) const { size_t h = std::hash<uint32_t>()(k.p); h = h * 37 + std::hash<uint32_t>()(k.uv); h = h * 37 + std::hash<uint32_t>()(k.n); return h; } };
+        auto toUInt = [](const std::string &t) { char *e = nullptr; unsigned long v = std::strtoul(t.c_str(), &e, 10); if (*e != '\0') throw Exception("Could not parse integer value \"" + t + "\""); return (uint32_t)v; };
+        auto parseKey = [&](const std::string &str) {
+            std::vector<std::string> tok; size_t last = 0;
+            for (;;) { size_t pos = str.find('/', last); tok.push_back(str.substr(last, pos == std::string::npos ? pos : pos - last)); if (pos == std::string::npos) break; last = pos + 1; }
+            if (tok.size() < 1 || tok.size() > 3) throw Exception("Invalid vertex data: \"" + str + "\"");
+            Key k; k.p = toUInt(tok[0]);
+            if (tok.size() >= 2 && !tok[1].empty()) k.uv = toUInt(tok[1]);
+            if (tok.size() >= 3 && !tok[2].empty()) k.n = toUInt(tok[2]);
+            return k;
+        };
+        std::vector<Vector3> positions, normals; std::vector<std::array<float, 2>> texcoords;
+        std::vector<Key> vertices; std::unordered_map<Key, uint32_t, KeyHash> vertexMap;
+        std::string lineStr;
+        while (std::getline(is, lineStr)) {
+            std::istringstream line(lineStr);
+            std::string prefix; line >> prefix;
+            if (prefix == "v") { Vector3 p{0, 0, 0}; line >> p[0] >> p[1] >> p[2]; positions.push_back(trafo.point(p)); }
+            else if (prefix == "vt") { std::array<float, 2> tc{0, 0}; line >> tc[0] >> tc[1]; texcoords.push_back(tc); }
+            else if (prefix == "vn") {
+                Vector3 n{0, 0, 0}; line >> n[0] >> n[1] >> n[2]; n = trafo.normal(n);
+                const float l2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                if (l2 > 0.f) { const float l = std::sqrt(l2); n = {n[0] / l, n[1] / l, n[2] / l}; }
+                normals.push_back(n);
+            } else if (prefix == "f") {
+                std::string v[4]; line >> v[0] >> v[1] >> v[2] >> v[3];
+                Key verts[6]; int nVertices = 3;
+                for (int i = 0; i < 3; ++i) verts[i] = parseKey(v[i]);
+                if (!v[3].empty()) { verts[3] = parseKey(v[3]); verts[4] = verts[0]; verts[5] = verts[2]; nVertices = 6; }
+                for (int i = 0; i < nVertices; ++i) {
+                    auto it = vertexMap.find(verts[i]);
+                    if (it == vertexMap.end()) { vertexMap[verts[i]] = (uint32_t)vertices.size(); m_F.push_back((uint32_t)vertices.size()); vertices.push_back(verts[i]); }
+                    else m_F.push_back(it->second);
+                }
+            }
+        }
+        for (const Key &k : vertices) { const Vector3 &p = positions.at(k.p - 1); m_V.insert(m_V.end(), p.begin(), p.end()); }
+        if (!normals.empty()) for (const Key &k : vertices) { const Vector3 &n = normals.at(k.n - 1); m_N.insert(m_N.end(), n.begin(), n.end()); }
+        if (!texcoords.empty()) for (const Key &k : vertices) { const auto &t = texcoords.at(k.uv - 1); m_UV.insert(m_UV.end(), t.begin(), t.end()); }
+    }
     ~Mesh() override { delete m_bsdf; delete m_light; }
     void setBuffers(std::vector<float> V, std::vector<uint32_t> F, std::vector<float> N = {}, std::vector<float> UV = {}) { m_V = std::move(V); m_F = std::move(F); m_N = std::move(N); m_UV = std::move(UV); }
     void addChild(Object *o) override {              // mesh.cpp:135-165

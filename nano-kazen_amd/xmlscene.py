@@ -28,10 +28,8 @@ def _floats(s):
 
 def _vec3(s):
     v = _floats(s)
-    if len(v) == 1:
-        v = v * 3
     if len(v) != 3:
-        raise ValueError("Cannot parse 3-vector '%s'" % s)
+        raise ValueError("Expected 3 values")                                  # string::toVector3f, common.cpp:271-279
     return v
 
 

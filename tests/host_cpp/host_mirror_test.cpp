@@ -2,6 +2,7 @@
 // model (parser.cpp:116-301: children first, createInstance, addChild, activate), then either dumps the flattened
 // description as JSON (no GPU needed) or renders on GPU 0 and writes the linear rgb bitmap to a file.
 #include "../../nano-kazen_amd/host/kazen_host.hpp"
+#include "../../nano-kazen_amd/host/kazen_sceneio.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -98,6 +99,38 @@ int main(int argc, char **argv) {
         std::ofstream(argv[2], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
         double s = 0; for (float v : rgb) s += v;
         std::printf("{\"pixels\": %zu, \"mean\": %.6f}\n", rgb.size() / 3, s / rgb.size());
+        return 0;
+    }
+    if (argc >= 3 && !std::strcmp(argv[1], "--xml")) {               // loadFromXML (parser.cpp:10-305) + the OBJ loader (mesh.cpp:200-343)
+        std::string err;
+        std::unique_ptr<Object> root;
+        try { root.reset(loadFromXML(argv[2])); } catch (const Exception &e) { err = e.what(); }
+        if (!root) { for (auto &c : err) if (c == '"') c = '\''; std::printf("{\"error\": \"%s\"}\n", err.c_str()); return 0; }
+        Scene *scene = static_cast<Scene *>(root.get());
+        const KzSceneDesc &d = scene->desc();
+        if (argc >= 4) {
+            std::vector<float> rgb = renderer::render(scene, 0);
+            std::ofstream(argv[3], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
+        }
+        std::printf("{\"nMeshes\": %u, \"nBsdfs\": %u, \"nLights\": %u, \"nTextures\": %u, \"nImages\": %u, \"meshes\": [", d.nMeshes, d.nBsdfs, d.nLights, d.nTextures, d.nImages);
+        for (uint32_t i = 0; i < d.nMeshes; ++i) {
+            const KzMesh &m = d.meshes[i];
+            double sv = 0, sn = 0, su = 0; unsigned long long sf = 0;
+            for (uint32_t k = 0; k < 3 * m.nV; ++k) { sv += m.V[k]; if (m.N) sn += m.N[k]; }
+            if (m.UV) for (uint32_t k = 0; k < 2 * m.nV; ++k) su += m.UV[k];
+            for (uint32_t k = 0; k < 3 * m.nF; ++k) sf += (unsigned long long)m.F[k] * (k % 7 + 1);
+            std::printf("%s[%u, %u, %d, %d, %d, %d, %.9g, %.9g, %.9g, %llu]", i ? ", " : "", m.nV, m.nF, m.N ? 1 : 0, m.UV ? 1 : 0, m.bsdf, m.light, sv, sn, su, sf);
+        }
+        std::printf("], \"bsdfTypes\": [");
+        for (uint32_t i = 0; i < d.nBsdfs; ++i) std::printf("%s%d", i ? ", " : "", d.bsdfs[i].type);
+        std::printf("], \"camera\": [%d, %d, %d, %.9g, %.9g, %.9g, %d, %.9g], \"toWorld\": [", d.camera.type, d.camera.width, d.camera.height, d.camera.fov, d.camera.nearClip,
+                    d.camera.farClip, d.camera.rfilter.type, d.camera.rfilter.radius);
+        for (int i = 0; i < 16; ++i) std::printf("%s%.9g", i ? ", " : "", d.camera.toWorld[i]);
+        std::printf("], \"sampler\": [%d, %u, %llu], \"integrator\": [%d, %.9g, %d, %.9g], \"background\": [%d, %.9g, %.9g, %.9g, %.9g], \"lights\": [", d.sampler.type,
+                    d.sampler.sampleCount, (unsigned long long)d.sampler.seed, d.integrator.maxDepth, d.integrator.traceBias, d.integrator.regularization,
+                    d.integrator.accumulatedRoughness, d.background.present, d.background.color[0], d.background.color[1], d.background.color[2], d.background.intensity);
+        for (uint32_t i = 0; i < d.nLights; ++i) std::printf("%s[%.9g, %.9g, %.9g, %.9g, %d]", i ? ", " : "", d.lights[i].color[0], d.lights[i].color[1], d.lights[i].color[2], d.lights[i].intensity, d.lights[i].primaryVisibility);
+        std::printf("]}\n");
         return 0;
     }
     if (argc >= 3 && !std::strcmp(argv[1], "--bitmap")) {            // Bitmap::savePNG / saveEXR of a deterministic 37 x 5 gradient (no GPU)

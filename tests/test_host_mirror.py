@@ -129,3 +129,74 @@ def test_cpp_textured_render_equals_python_render(exe, kz, O, gpu_lib, tmp_path)
     assert float(np.sqrt(np.mean((sc.rgb() - rgb) ** 2))) < 1e-4
     ora = O.OracleScene(twin)
     assert float(np.sqrt(np.mean((rgb - ora.rgb(ora.render(threads=0))) ** 2))) < 1e-3
+
+
+# ---------------------------------------------------------------- scene files through the C++ loader
+MINI = os.path.join(ROOT, "tests", "golden", "xml", "mini.xml")
+
+
+def _mesh_digest(m):
+    V, F = m["V"], m["F"].reshape(-1).astype(np.uint64)
+    w = (np.arange(F.size, dtype=np.uint64) % np.uint64(7)) + np.uint64(1)
+    return [V.shape[0], m["F"].shape[0], int(m["N"] is not None), int(m["UV"] is not None), float(V.astype(np.float64).sum()),
+            float(m["N"].astype(np.float64).sum()) if m["N"] is not None else 0.0, float(m["UV"].astype(np.float64).sum()) if m["UV"] is not None else 0.0,
+            int((F * w).sum())]
+
+
+def test_cpp_xml_loader_equals_the_python_one(exe, kz):
+    d = json.loads(subprocess.check_output([exe, "--xml", MINI]).decode())
+    assert "error" not in d, d
+    py = kz.xmlscene.load_xml(MINI)
+    assert d["nMeshes"] == len(py.meshes) and d["nLights"] == 1
+    for cm, pm in zip(d["meshes"], py.meshes):
+        g = _mesh_digest(pm)
+        assert cm[:4] == g[:4] and cm[9] == g[7]                                   # counts, presence of N / UV, the index buffer
+        assert np.allclose(cm[6:9], g[4:7], rtol=1e-5, atol=1e-4)                      # vertex / normal / uv sums (transform applied in float)
+    a = kz.abi
+    assert d["bsdfTypes"] == [a.KZ_BSDF_DIFFUSE, a.KZ_BSDF_KAZENSTANDARD]
+    assert d["camera"][:3] == [a.KZ_CAMERA_PERSPECTIVE, 48, 32] and np.allclose(d["camera"][3:6], [45, 0.1, 50]) and d["camera"][6] == a.KZ_FILTER_MITCHELL
+    assert np.allclose(d["toWorld"], np.asarray(py.camera["toWorld"]).reshape(-1), atol=1e-6)
+    assert d["sampler"] == [a.KZ_SAMPLER_CORRELATED, 9, 7] and d["integrator"][0] == 4 and np.isclose(d["integrator"][1], 0.002)
+    lp = [m["light"] for m in py.meshes if m["light"]][0]
+    assert np.allclose(d["background"], [1, *py.background["color"], py.background["intensity"]])
+    assert np.allclose(d["lights"][0], [*lp["color"], lp["intensity"], int(lp["lightPrimaryVisibility"])])
+
+
+def test_cpp_xml_loader_errors(exe, tmp_path):
+    txt = open(MINI).read()
+    here = os.path.join(ROOT, "tests", "golden", "xml")
+    for old, new, msg in (('type="path_mis"', 'type="whitted"', "not on the MI355X hot path"), ('<float name="fov" value="45"/>', '<float name="fov" value="wide"/>', "Could not parse floating point"),
+                          ('<lookat origin="0, 1.5, 5"', '<lookat origin="0, 1.5"', "Expected 3 values"), ('<sampler type="correlated">', '<sampler type="correlated"><lookat origin="0 0 0" target="0 0 1" up="0 1 0"/>', "transform nodes can only contain"),
+                          ('</scene>', '', "missing </scene>"), ('<integer name="maxDepth" value="4"/>', '<integer name="maxDepth"/>', "missing attribute"),
+                          ('value="floor.obj"', 'value="nosuchfile.obj"', "Unable to open OBJ file")):
+        p = tmp_path / "bad.xml"
+        p.write_text(txt.replace(old, new, 1).replace('value="cube.obj"', 'value="%s"' % os.path.join(here, "cube.obj")).replace('value="light.obj"', 'value="%s"' % os.path.join(here, "light.obj"))
+                     .replace('value="floor.obj"', 'value="%s"' % os.path.join(here, "floor.obj")))
+        d = json.loads(subprocess.check_output([exe, "--xml", str(p)]).decode())
+        assert msg in d.get("error", ""), (msg, d)
+
+
+@pytest.mark.gpu
+def test_cpp_xml_render_equals_python_render(exe, kz, gpu_lib, tmp_path):
+    out = str(tmp_path / "rgb.bin")
+    subprocess.check_output([exe, "--xml", MINI, out])
+    rgb = np.fromfile(out, np.float32).reshape(32, 48, 3)
+    sc = kz.Scene(kz.xmlscene.load_xml(MINI), device=0)
+    sc.render()
+    assert float(np.sqrt(np.mean((sc.rgb() - rgb) ** 2))) < 1e-4
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scene/2022_q1"), reason="the reference checkout is only present in the build container")
+@pytest.mark.parametrize("rel", ["parameters/default_m0_r0.5.xml", "parameters/m1_r0.xml", "WarmStudio/WarmStudio.xml"])
+def test_cpp_xml_loader_on_reference_scene_files(exe, kz, rel):
+    path = os.path.join("/root/reference/scene/2022_q1", rel)
+    d = json.loads(subprocess.check_output([exe, "--xml", path]).decode())
+    assert "error" not in d, d
+    py = kz.xmlscene.load_xml(path)
+    assert d["nMeshes"] == len(py.meshes) and d["nLights"] == sum(1 for m in py.meshes if m["light"])
+    for cm, pm in zip(d["meshes"], py.meshes):
+        g = _mesh_digest(pm)
+        assert cm[:4] == g[:4] and cm[9] == g[7]
+        assert np.allclose(cm[6:9], g[4:7], rtol=1e-5, atol=1e-2)
+    assert d["camera"][1:3] == [py.camera["width"], py.camera["height"]] and np.allclose(d["toWorld"], np.asarray(py.camera["toWorld"]).reshape(-1), atol=1e-6)
+    assert d["sampler"][1] == py.sampler["sampleCount"]
