@@ -200,3 +200,15 @@ def test_cpp_xml_loader_on_reference_scene_files(exe, kz, rel):
         assert np.allclose(cm[6:9], g[4:7], rtol=1e-5, atol=1e-2)
     assert d["camera"][1:3] == [py.camera["width"], py.camera["height"]] and np.allclose(d["toWorld"], np.asarray(py.camera["toWorld"]).reshape(-1), atol=1e-6)
     assert d["sampler"][1] == py.sampler["sampleCount"]
+
+
+def test_example_main_builds_and_fails_loudly_without_a_gpu(kz, tmp_path):
+    """nano-kazen_amd/host/example_main.cpp: main.cpp's shape on top of the library."""
+    out = str(tmp_path / "kazen_mi355x")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "nano-kazen_amd", "host", "example_main.cpp"), "-L" + LIBDIR, "-lkazen_mi355x",
+                           "-Wl,-rpath," + LIBDIR, "-o", out])
+    r = subprocess.run([out, "/nonexistent/scene.xml"], capture_output=True, text=True)
+    assert r.returncode != 0 and "file not found" in r.stderr
+    if kz.abi.load_library().kz_device_count() == 0:
+        r = subprocess.run([out, MINI], capture_output=True, text=True)
+        assert r.returncode != 0 and "no HIP device" in r.stderr          # the product path has no CPU fallback
