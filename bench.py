@@ -5,11 +5,11 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (BASELINE.json configs[3], "C4"): 1 M random triangles + 8 mesh lights in a closed diffuse room,
-1920x1080, pmj02bn sampler (1024 spp), path_mis maxDepth 5. A "step" is one kz_render call over one batch: a 32-spp
-slice (sample indices [32k, 32k+32)) of every pixel a GPU owns = 66.4 M (pixel, sample) paths per GPU per step, which
-the library runs as two 33.2 M-path passes kept in flight together on two internal streams. With N GPUs the image tiles
+1920x1080, pmj02bn sampler (1024 spp), path_mis maxDepth 5. A "step" is one kz_render call over one batch: a 128-spp
+slice (sample indices [128k, 128k+128)) of every pixel a GPU owns = 265 M (pixel, sample) paths per GPU per step, which
+the library runs as two 133 M-path passes (its default pass size, 2^27 items) kept in flight together on two internal streams. With N GPUs the image tiles
 (128x128) are dealt round-robin over the ranks and each rank
-renders 32*N spp of ITS tiles per step, so per-GPU work is fixed (weak scaling); there is no data-path
+renders 128*N spp of ITS tiles per step, so per-GPU work is fixed (weak scaling); there is no data-path
 collective — the per-rank films are summed once at the end (ImageBlock::put(ImageBlock&), block.cpp:87-96).
 Scene tables, BVH and sampler tables are resident in HBM before the timed region starts.
 
@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); 6.29 TB/s measured copy
-SPP_PER_STEP = 32             # two passes of PASS_SPP per call
-PASS_SPP = 16
+SPP_PER_STEP = 128            # two passes of PASS_SPP per call
+PASS_SPP = 64                 # 2^27 (pixel, sample) items per pass (the library's default pass size) / 1920x1080 pixels
 W, H, NTRIS, SPP = 1920, 1080, 1000000, 1024
 
 

@@ -400,10 +400,20 @@ static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, 
     return KZ_OK;
 }
 
+// (pixel, sample) items per pass. Measured on C4 with two passes in flight: 2^25 -> 981, 2^26 -> 1031, 2^27 -> 1061-1066, 2^28 -> 1071
+// Msamples/s (fewer launches and shorter relative tails per sample). 2^27 items = 23.6 GB of path state + sample records per pass
+// in flight, two in flight = 47 GB of the 288 GB; never more than half of what is free.
 static size_t passItemBudget() {
     const char *e = std::getenv("KZ_PASS_ITEMS");
     if (e) { long long v = std::atoll(e); if (v >= 1024) return (size_t)v; }
-    return (size_t)1 << 25;      // 33.5 M (pixel,sample) items per pass: 640 MB of sample records
+    size_t budget = (size_t)1 << 27;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) {
+        const size_t perItem = 2 * 176;                                  // both contexts: 8 float4 + uint4 + 3 queue words + 5 sample floats
+        const size_t fit = (totalB / 2) / perItem;                       // of the device total: what is already allocated for this scene counts as ours
+        budget = std::max<size_t>((size_t)1 << 22, std::min(budget, fit));
+    }
+    return budget;
 }
 
 

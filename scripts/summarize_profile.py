@@ -53,7 +53,7 @@ json.dump({k: out[k] for k in wf}, open(os.path.join(dst, "pmc_sum_over_one_pass
 fetch = sum(out[k].get("FETCH_SIZE", 0) for k in wf)
 write = sum(out[k].get("WRITE_SIZE", 0) for k in wf)
 traffic = {"hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "fetch_size_kib_raw": fetch, "write_size_kib": write,
-           "note": "sum over the wavefront path kernels of ONE pass (33.2 M samples), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; "
+           "note": "sum over the wavefront path kernels of ONE pass (bench.json roofline.samples_per_launch samples), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; "
                    "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md (our 16-B per-lane gathers are uncalibrated: raw figure kept)",
            "profile": "profiles/" + name}
 json.dump(traffic, open(os.path.join(root, "profiles", "traffic_latest.json"), "w"), indent=1)
