@@ -7,7 +7,7 @@ out = {}
 def run(name, desc, check=None):
     t0 = time.time(); sc = kz.Scene(desc); tb = time.time() - t0
     t0 = time.time(); sc.upload(0); tu = time.time() - t0
-    sc.render(0, min(4, sc.sample_count)); sc.sync()            # warm-up (allocations)
+    sc.render(); sc.sync()                                      # warm-up: the path-state buffers are sized by the first full call
     t0 = time.time(); sc.render(); sc.sync(); dt = time.time() - t0
     n = sc.width * sc.height * sc.sample_count
     rgb = sc.rgb()
