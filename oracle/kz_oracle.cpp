@@ -40,6 +40,15 @@ namespace kzo {
 // ---------------------------------------------------------------------------------
 // constants (include/kazen/common.h:27-40)
 // ---------------------------------------------------------------------------------
+// H11: the reference runs with flush-to-zero and denormals-are-zero set in MXCSR (main.cpp:22-23; the render threads inherit
+// the floating-point environment of the thread that creates them). Every entry point that does fp32 work holds one of these.
+struct FtzScope {
+#if defined(__SSE2__)
+    unsigned saved;
+    FtzScope() : saved(__builtin_ia32_stmxcsr()) { __builtin_ia32_ldmxcsr(saved | 0x8040u); }      // FTZ (bit 15) | DAZ (bit 6)
+    ~FtzScope() { __builtin_ia32_ldmxcsr(saved); }
+#endif
+};
 static const float Epsilon = 1e-5f;
 static const float OneMinusEpsilon = float(0x1.fffffep-1);
 static const float INV_PI = 0.31830988618379067154f;
@@ -1613,7 +1622,7 @@ extern "C" {
 
 const char *kzo_last_error() { return g_err; }
 
-int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) {
+int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) { FtzScope ftz_;
     if (!d || !out) return fail(KZ_ERR_INVALID_ARG, "null argument");
     if (d->abiVersion != KZ_ABI_VERSION) return fail(KZ_ERR_INVALID_ARG, "abi version mismatch");
     if (d->camera.type != KZ_CAMERA_PERSPECTIVE && d->camera.type != KZ_CAMERA_THINLENS) return fail(KZ_ERR_UNSUPPORTED, "camera type");
@@ -1747,6 +1756,7 @@ int kzo_render(void *s, uint32_t s0, uint32_t s1, const KzTile *tiles, uint32_t 
         }
         mergeStats(sc, ls);
     };
+    FtzScope ftz;                                                           // worker threads inherit it
     std::vector<std::thread> pool;
     for (int t = 1; t < threads; ++t) pool.emplace_back(work);
     work();
@@ -1766,7 +1776,7 @@ int kzo_render(void *s, uint32_t s0, uint32_t s1, const KzTile *tiles, uint32_t 
 }
 
 // ImageBlock::toBitmap (block.cpp:39-45) + Color4f::divideByFilterWeight (color.h:94-99)
-int kzo_film_to_rgb(const float *film, int w, int h, int b, float *rgb) {
+int kzo_film_to_rgb(const float *film, int w, int h, int b, float *rgb) { FtzScope ftz_;
     int cols = w + 2 * b;
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
         const float *p = &film[((size_t)(y + b) * cols + (x + b)) * 4];
@@ -1778,7 +1788,7 @@ int kzo_film_to_rgb(const float *film, int w, int h, int b, float *rgb) {
 }
 
 // Bitmap::savePNG's raster (bitmap.cpp:45-52) from a normalised bitmap: Color3f::toSRGB (common.cpp:351-366), clamp, truncate
-int kzo_rgb_to_srgb8(const float *rgb, int w, int h, uint8_t *out) {
+int kzo_rgb_to_srgb8(const float *rgb, int w, int h, uint8_t *out) { FtzScope ftz_;
     for (size_t i = 0; i < (size_t)w * h * 3; ++i) {
         float value = rgb[i];
         float t = value <= 0.0031308f ? 12.92f * value : (1.0f + 0.055f) * std::pow(value, 1.0f / 2.4f) - 0.055f;
@@ -1796,7 +1806,7 @@ int kzo_get_stats(void *s, KzStats *o, int reset) {
 }
 
 // Accel::rayIntersect(ray, its, false) for n rays.
-int kzo_trace_rays(void *s, uint32_t n, const float *o, const float *d, const float *tmin, const float *tmax, KzHit *hits) {
+int kzo_trace_rays(void *s, uint32_t n, const float *o, const float *d, const float *tmin, const float *tmax, KzHit *hits) { FtzScope ftz_;
     Scene &sc = *(Scene *)s; LocalStats ls;
     for (uint32_t i = 0; i < n; ++i) {
         Ray r(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin[i], tmax[i]);
@@ -1832,24 +1842,24 @@ void kzo_pcg32_seed2(uint64_t initstate, uint64_t initseq, int n, uint32_t *u) {
     for (int i = 0; i < n; ++i) u[i] = a.nextUInt();
 }
 // sampler stream of one (pixel, sample): nextPixel2D, next2D, then n1 x next1D
-void kzo_sampler_stream(void *s, int32_t px, int32_t py, uint32_t idx, int n1, float *out) {
+void kzo_sampler_stream(void *s, int32_t px, int32_t py, uint32_t idx, int n1, float *out) { FtzScope ftz_;
     Scene &sc = *(Scene *)s; Sampler sm; sm.sc = &sc; sm.type = sc.smp.type;
     sm.generateSample(px, py, idx);
     sm.nextPixel2D(out[0], out[1]); sm.next2D(out[2], out[3]);
     for (int i = 0; i < n1; ++i) out[4 + i] = sm.next1D();
 }
-void kzo_camera_ray(void *s, float sx, float sy, float *o6, float *mint, float *maxt) {
+void kzo_camera_ray(void *s, float sx, float sy, float *o6, float *mint, float *maxt) { FtzScope ftz_;
     Scene &sc = *(Scene *)s; Ray r; cameraSampleRay(sc, sx, sy, 0.5f, 0.5f, r);
     o6[0] = r.o.x; o6[1] = r.o.y; o6[2] = r.o.z; o6[3] = r.d.x; o6[4] = r.d.y; o6[5] = r.d.z; *mint = r.mint; *maxt = r.maxt;
 }
 void kzo_filter_table(void *s, float *tab33, float *radius, int *border) {
     Scene &sc = *(Scene *)s; std::memcpy(tab33, sc.filter, sizeof sc.filter); *radius = sc.filterRadius; *border = sc.border;
 }
-void kzo_cosine_hemisphere(float sx, float sy, float *o3) { V3 v = squareToCosineHemisphere(sx, sy); o3[0] = v.x; o3[1] = v.y; o3[2] = v.z; }
-void kzo_uniform_disk(float sx, float sy, float *o2) { squareToUniformDisk(sx, sy, o2[0], o2[1]); }
-void kzo_frame(const float *n, float *s3, float *t3) { Frame f(V3(n[0], n[1], n[2])); s3[0] = f.s.x; s3[1] = f.s.y; s3[2] = f.s.z; t3[0] = f.t.x; t3[1] = f.t.y; t3[2] = f.t.z; }
+void kzo_cosine_hemisphere(float sx, float sy, float *o3) { FtzScope ftz_; V3 v = squareToCosineHemisphere(sx, sy); o3[0] = v.x; o3[1] = v.y; o3[2] = v.z; }
+void kzo_uniform_disk(float sx, float sy, float *o2) { FtzScope ftz_; squareToUniformDisk(sx, sy, o2[0], o2[1]); }
+void kzo_frame(const float *n, float *s3, float *t3) { FtzScope ftz_; Frame f(V3(n[0], n[1], n[2])); s3[0] = f.s.x; s3[1] = f.s.y; s3[2] = f.s.z; t3[0] = f.t.x; t3[1] = f.t.y; t3[2] = f.t.z; }
 // BSDF: which = 0 eval (3 floats), 1 pdf (1 float), 2 sample (weight 3 + wo 3 + ok 1)
-void kzo_bsdf(const KzBSDF *m, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float *out) {
+void kzo_bsdf(const KzBSDF *m, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float *out) { FtzScope ftz_;
     BRec b; b.wi = V3(wi[0], wi[1], wi[2]); b.accumulatedRoughness = accRough;
     if (which == 2) {
         bool ok; V3 w = bsdfSample(*m, b, s1, s2x, s2y, ok);
@@ -1862,7 +1872,7 @@ void kzo_bsdf(const KzBSDF *m, int which, const float *wi, const float *wo, floa
 }
 // Scene-aware form (texture children, normalmap rows): the intersection record is the identity frame with dpdu = +x at uv.
 // which = 2 returns 8 floats: weight 3, wo 3, ok, and pdf(bRec) right after sample() (integrator.cpp:314; 0 when the path ends).
-void kzo_scene_bsdf(void *s, int bsdfIdx, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float u, float v, float *out) {
+void kzo_scene_bsdf(void *s, int bsdfIdx, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float u, float v, float *out) { FtzScope ftz_;
     Scene &sc = *(Scene *)s; const KzBSDF &m = sc.bsdfs[bsdfIdx];
     Intersection its; its.uvx = u; its.uvy = v; its.accumulatedRoughness = accRough;
     its.shFrame.s = V3(1, 0, 0); its.shFrame.t = V3(0, 1, 0); its.shFrame.n = V3(0, 0, 1); its.geoFrame = its.shFrame; its.dpdu = V3(1, 0, 0);
@@ -1879,15 +1889,15 @@ void kzo_scene_bsdf(void *s, int bsdfIdx, int which, const float *wi, const floa
     if (which == 0) { V3 f = bsdfEval(m, b); out[0] = f.x; out[1] = f.y; out[2] = f.z; }
     else out[0] = bsdfPdf(m, b);
 }
-void kzo_texture(void *s, int tex, float u, float v, float *out) {
+void kzo_texture(void *s, int tex, float u, float v, float *out) { FtzScope ftz_;
     V3 c = textureEval(*(Scene *)s, tex, u, v); out[0] = c.x; out[1] = c.y; out[2] = c.z;
 }
-void kzo_ggx_sample_vndf(const float *V, float ax, float ay, float rx, float ry, float *H) {
+void kzo_ggx_sample_vndf(const float *V, float ax, float ay, float rx, float ry, float *H) { FtzScope ftz_;
     V3 h = sampleGGXSmithVNDF(V3(V[0], V[1], V[2]), A2{ax, ay}, rx, ry); H[0] = h.x; H[1] = h.y; H[2] = h.z;
 }
 // light: sample the light mesh `lightIdx` (index into Scene::m_lights order) from `ref` with the
 // three Mesh::sample draws given explicitly: out = p(3) n(3) wi(3) pdf(1) Ls(3) (Ls = eval/pdf)
-void kzo_light_sample(void *s, int lightIdx, const float *ref, float u0, float u1, float u2, float *out) {
+void kzo_light_sample(void *s, int lightIdx, const float *ref, float u0, float u1, float u2, float *out) { FtzScope ftz_;
     Scene &sc = *(Scene *)s; const MeshData &md = sc.meshes[sc.lightMeshes[lightIdx]]; const KzLight &l = sc.lights[md.light];
     LRec r; r.ref = V3(ref[0], ref[1], ref[2]);
     size_t index = dpdfSample(md, u0);
@@ -1905,7 +1915,7 @@ void kzo_light_sample(void *s, int lightIdx, const float *ref, float u0, float u
     out[13] = (float)index;
 }
 // Radiance of single samples (no film): out = n x (sx, sy, r, g, b)
-void kzo_render_samples(void *s, uint32_t n, const int32_t *pxy, const uint32_t *idx, float *out) {
+void kzo_render_samples(void *s, uint32_t n, const int32_t *pxy, const uint32_t *idx, float *out) { FtzScope ftz_;
     Scene &sc = *(Scene *)s; Sampler sm; sm.sc = &sc; sm.type = sc.smp.type; LocalStats ls;
     _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON); _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
     for (uint32_t i = 0; i < n; ++i) {
