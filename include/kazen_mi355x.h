@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 2
+#define KZ_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -227,6 +227,21 @@ typedef struct KzSceneDesc {
  * reference's 32x32 KAZEN_BLOCK_SIZE, include/kazen/block.h:8, are natural). */
 typedef struct KzTile { int32_t x0, y0, w, h; } KzTile;
 
+/* Knobs of the persistent kernels. Zero = the library default, which is what the measured numbers use;
+ * they are part of the ABI so that nothing behind it depends on process-global state (the KZ_* environment variables of
+ * ABI v2 survive only as a debug override that is read ONCE, when the library is first used). */
+typedef struct KzTuning {
+    int32_t refill;             /* a wave refills idle lanes once fewer than this many are busy (default 40)       */
+    int32_t postpone;           /* node phase goes on while at least this many lanes hold inner nodes (default 28)  */
+    int32_t batch;              /* queue entries a wave reserves per global atomic (default 128)                     */
+    int32_t traceBlocksPerCU;   /* 256-thread workgroups per CU of the traversal kernels (default 8)                 */
+    int32_t shadeBlocksPerCU;   /* same for the shade kernel (default 6)                                             */
+    int32_t ldsStack;           /* per-lane traversal stack entries kept in LDS before the global overflow (default 16) */
+    int32_t bvh2;               /* 1 = traverse the BVH2 instead of the quantised BVH4 (default 0)                    */
+    int32_t packetPrimary;      /* primary rays: 0 = default (shared-stack packet traversal), 1 = per-lane, 2 = packet */
+    int32_t reserved[8];
+} KzTuning;
+
 typedef struct KzRenderOpts {
     uint32_t sampleBegin;       /* render sample indices [sampleBegin, sampleEnd) of every pixel;       */
     uint32_t sampleEnd;         /* 0,0 = all of sampler.sampleCount                                      */
@@ -235,6 +250,13 @@ typedef struct KzRenderOpts {
     int32_t pipeline;           /* 0 = library default, 1 = megakernel, 2 = wavefront                    */
     int32_t accumulate;         /* 0 = clear the device film first, 1 = add to what is there             */
     void *stream;               /* hipStream_t to launch on (NULL = the null stream)                     */
+    /* ---- ABI v3 (all zero = defaults) ---- */
+    int32_t device;             /* the replica to render on: a HIP device index kz_scene_upload was called with */
+    int32_t passesInFlight;     /* 0 = default (2: two passes kept in flight on two internal streams), 1 = one   */
+    uint64_t passItems;         /* (pixel, sample) items per pass; 0 = default 2^27, lowered to fit maxStateBytes */
+    uint64_t maxStateBytes;     /* cap on this replica's path state + sample records; 0 = min(half of the device's
+                                   memory, what is free + what the replica already holds for this purpose)       */
+    KzTuning tune;
 } KzRenderOpts;
 
 /* Counters the kernels keep (all optional; zero unless requested with kz_set_stats). */
@@ -274,18 +296,51 @@ int kz_scene_bvh_info(const KzScene *scene, KzBvhInfo *out);
 /* Sampler::getSampleCount() after the constructor's rounding (sampler.cpp:87-92, :181-187, :284-287). */
 int kz_scene_sample_count(const KzScene *scene, uint32_t *out);
 
-/* Upload node/triangle/attribute/material/light/sampler tables to the HBM of `device`
- * and allocate the device film. Fails with KZ_ERR_NO_DEVICE when no GPU is usable. */
+/* Upload node/triangle/attribute/material/light/sampler tables to the HBM of `device` and allocate that device's film.
+ * One KzScene (one host BVH build) can be resident on any number of devices: every call ADDS a replica (a second call for
+ * the same device is a no-op). Calls that take no device argument address the PRIMARY replica, the one uploaded first.
+ * Fails with KZ_ERR_NO_DEVICE when no GPU is usable. Thread-safe per (scene, device). */
 int kz_scene_upload(KzScene *scene, int device);
+/* Release the replica on `device` (-1: every replica). */
+int kz_scene_evict(KzScene *scene, int device);
+/* The devices the scene is resident on, primary first. */
+int kz_scene_devices(const KzScene *scene, int32_t *devices, uint32_t cap, uint32_t *count);
 
-/* The replacement for renderer.cpp:85-133: accumulate samples into the DEVICE film
+/* The replacement for renderer.cpp:85-133: accumulate samples into the DEVICE film of replica opts->device
  * ((h+2b) x (w+2b) float4 = rgb*w, w; ImageBlock convention, block.cpp:30,56-85).
- * Asynchronous on opts->stream. */
+ * Asynchronous on opts->stream. Re-entrant per (scene, device): one host thread per GPU may call it concurrently. */
 int kz_render(KzScene *scene, const KzRenderOpts *opts);
+
+/* SURVEY 8b tile variant, the unit of multi-GPU sharding: render `tiles` on `device` (overriding opts->tiles / opts->device),
+ * wait for the device, and, when film != NULL, copy that replica's film ((h+2b)*(w+2b)*4 floats) to the host.
+ * Blocking; re-entrant per (scene, device). opts may be NULL (all samples, defaults). */
+int kz_render_tiles(KzScene *scene, const KzRenderOpts *opts, const KzTile *tiles, uint32_t nTiles, int device,
+                    float *film, size_t nFloats);
+
+/* The analogue of the reference's driver (renderer.cpp:94-127: tbb::parallel_for over blocks, then ImageBlock::put(ImageBlock&)
+ * under a mutex, block.cpp:87-96) one level up: the image is cut into tileSize x tileSize tiles (a multiple of the 32-px
+ * block; 0 = 64) that are dealt over `devices` by area (kz_deal_tiles), ONE HOST THREAD PER DEVICE renders its share with
+ * kz_render_tiles, and the per-device films are summed on the host in the order of `devices` (deterministic, H10) into
+ * `film`. No collective, no peer access. Replicas are uploaded on demand. deviceMs (may be NULL) receives each device's
+ * wall time of render + download in ms. opts->tiles / opts->device / opts->stream are ignored. */
+int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *devices, uint32_t nDevices, int32_t tileSize,
+                    float *film, size_t nFloats, float *deviceMs);
+
+/* The tile dealing used by kz_render_multi, exported so that a multi-process launcher (one rank per GPU) deals identically:
+ * tiles in row-major order go, largest first, to the part with the least area so far (ties: the lower part), which for the
+ * interior tiles is a round-robin and spreads the smaller edge tiles evenly. Writes part `part` of `nParts` to out (up to cap
+ * entries) and its size to *count; returns KZ_ERR_INVALID_ARG if cap is too small (count is still set). */
+int kz_deal_tiles(int32_t width, int32_t height, int32_t tileSize, uint32_t nParts, uint32_t part, KzTile *out, uint32_t cap, uint32_t *count);
+
+/* ImageBlock::put(ImageBlock&) on the host (block.cpp:87-96): dst += src, element by element, in index order. */
+int kz_film_merge(float *dst, const float *src, size_t nFloats);
 
 /* Blocking copy of the device film to the host: film = (h+2b)*(w+2b)*4 floats. */
 int kz_film_download(KzScene *scene, float *film, size_t nFloats);
 int kz_film_clear(KzScene *scene, void *stream);
+/* The same for the replica on `device`. */
+int kz_film_download_on(KzScene *scene, int device, float *film, size_t nFloats);
+int kz_film_clear_on(KzScene *scene, int device, void *stream);
 /* Film geometry: border = ceil(radius-0.5) (block.cpp:14). */
 int kz_film_dims(const KzScene *scene, int32_t *width, int32_t *height, int32_t *border);
 /* ImageBlock::toBitmap (block.cpp:39-45): rgb = film.rgb / film.w (0 when w == 0). */
@@ -318,8 +373,9 @@ int kz_texture_query(KzScene *scene, uint32_t n, const int32_t *tex, const float
 int kz_set_stats(KzScene *scene, int enable);
 int kz_get_stats(KzScene *scene, KzStats *out, int reset);
 
-/* Wait for everything queued on the scene's stream. */
+/* Wait for everything queued on the primary replica's / that replica's launch stream. */
 int kz_sync(KzScene *scene);
+int kz_sync_on(KzScene *scene, int device);
 
 /* Average device time of the dominant kernel(s) of the last kz_render, in ms,
  * from hipEvents recorded on the launch stream (0 if none). */
@@ -327,6 +383,14 @@ int kz_last_kernel_ms(KzScene *scene, float *ms);
 /* Device time per stage of the last pass (wavefront pipeline): out5 = generate, closest-hit traversal, shade, shadow
  * traversal, film gather — the per-kernel sums a rocprofv3 --kernel-trace of the same run shows. */
 int kz_last_stage_ms(KzScene *scene, float *out5);
+
+/* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass, passes in flight. */
+typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes; } KzPassInfo;
+int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
+
+/* Test hook: the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off). Used by
+ * the error-path tests to show that a failure in the middle of a call releases what the call had allocated. */
+void kz_debug_fail_alloc(int nth);
 
 const char *kz_last_error(void);
 int kz_abi_version(void);

@@ -7,7 +7,7 @@ is missing: there is no CPU fallback in the product path.
 import ctypes as C
 import os
 
-KZ_ABI_VERSION = 2
+KZ_ABI_VERSION = 3
 
 KZ_OK, KZ_ERR_INVALID_ARG, KZ_ERR_UNSUPPORTED, KZ_ERR_NO_DEVICE, KZ_ERR_HIP, KZ_ERR_STATE, KZ_ERR_OOM = range(7)
 KZ_BSDF_DIFFUSE, KZ_BSDF_KAZENSTANDARD, KZ_BSDF_MIRROR, KZ_BSDF_DIELECTRIC = 0, 1, 2, 3
@@ -97,9 +97,25 @@ class KzTile(C.Structure):
     _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
 
 
+class KzTuning(C.Structure):
+    _fields_ = [("refill", C.c_int32), ("postpone", C.c_int32), ("batch", C.c_int32), ("traceBlocksPerCU", C.c_int32),
+                ("shadeBlocksPerCU", C.c_int32), ("ldsStack", C.c_int32), ("bvh2", C.c_int32), ("packetPrimary", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
+
+
 class KzRenderOpts(C.Structure):
     _fields_ = [("sampleBegin", C.c_uint32), ("sampleEnd", C.c_uint32), ("tiles", C.POINTER(KzTile)),
-                ("nTiles", C.c_uint32), ("pipeline", C.c_int32), ("accumulate", C.c_int32), ("stream", C.c_void_p)]
+                ("nTiles", C.c_uint32), ("pipeline", C.c_int32), ("accumulate", C.c_int32), ("stream", C.c_void_p),
+                ("device", C.c_int32), ("passesInFlight", C.c_int32), ("passItems", C.c_uint64), ("maxStateBytes", C.c_uint64),
+                ("tune", KzTuning)]
+
+
+class KzPassInfo(C.Structure):
+    _fields_ = [("passes", C.c_uint32), ("passesInFlight", C.c_uint32), ("itemsPerPass", C.c_uint64), ("sppPerPass", C.c_uint32),
+                ("pixels", C.c_uint32), ("stateBytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 class KzStats(C.Structure):
@@ -125,7 +141,9 @@ class KzBvhInfo(C.Structure):
 EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
            "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
-           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8"]
+           "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8",
+           "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
+           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
@@ -169,6 +187,18 @@ def load_library():
     lib.kz_bsdf_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p]
     lib.kz_film_to_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
     lib.kz_texture_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p]
+    lib.kz_scene_evict.argtypes = [C.c_void_p, C.c_int]
+    lib.kz_scene_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, u32p]
+    lib.kz_render_tiles.argtypes = [C.c_void_p, C.POINTER(KzRenderOpts), C.POINTER(KzTile), C.c_uint32, C.c_int, f32p, C.c_size_t]
+    lib.kz_render_multi.argtypes = [C.c_void_p, C.POINTER(KzRenderOpts), C.POINTER(C.c_int32), C.c_uint32, C.c_int32, f32p, C.c_size_t, f32p]
+    lib.kz_deal_tiles.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(KzTile), C.c_uint32, u32p]
+    lib.kz_film_merge.argtypes = [f32p, f32p, C.c_size_t]
+    lib.kz_film_download_on.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t]
+    lib.kz_film_clear_on.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.kz_sync_on.argtypes = [C.c_void_p, C.c_int]
+    lib.kz_last_pass_info.argtypes = [C.c_void_p, C.POINTER(KzPassInfo)]
+    lib.kz_debug_fail_alloc.argtypes = [C.c_int]
+    lib.kz_debug_fail_alloc.restype = None
     _lib = lib
     return lib
 

@@ -303,24 +303,9 @@ __device__ __forceinline__ bool closestHit(const KzDevTables &T, uint32_t rootRe
         if (cur & 0x80000000u) {
             uint32_t start = (cur & 0x7fffffffu) >> 3, count = (cur & 7u) + 1;
             for (uint32_t i = 0; i < count; ++i) {
-                const float4 *tp = reinterpret_cast<const float4 *>(T.tris + start + i);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, u, v; uint32_t gid;
                 if (STATS) cn.tris++;
-                const V3 p0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
-                // Mesh::rayIntersect, operation for operation
-                V3 pvec = cross(d, e2);
-                float det = dot(e1, pvec);
-                if (det > -1e-8f && det < 1e-8f) continue;
-                float inv_det = 1.0f / det;
-                V3 tvec = o - p0;
-                float u = dot(tvec, pvec) * inv_det;
-                if (u < 0.0f || u > 1.0f) continue;
-                V3 qvec = cross(tvec, e1);
-                float v = dot(d, qvec) * inv_det;
-                if (v < 0.0f || u + v > 1.0f) continue;
-                float t = dot(e2, qvec) * inv_det;
-                if (!(t >= tmin && t <= tmax)) continue;
-                uint32_t gid = __float_as_uint(c.w);
+                if (!triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, gid)) continue;
                 // ties on t go to the lower global triangle id: order independent (Embree's tie rule is unspecified)
                 if (!found || t < best.t || (t == best.t && gid < best.gid)) {
                     found = true; best.t = t; best.u = u; best.v = v; best.tri = start + i; best.gid = gid; tmax = t;
@@ -330,29 +315,14 @@ __device__ __forceinline__ bool closestHit(const KzDevTables &T, uint32_t rootRe
             cur = stk[(--sp) * KZ_BLOCK];
             continue;
         }
-        const float4 *np = reinterpret_cast<const float4 *>(T.nodes + cur);
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-        const uint4 q3 = *reinterpret_cast<const uint4 *>(np + 3);
         if (STATS) cn.nodes++;
-        // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
-        float t0, t1, n0, f0, n1, f1;
-        t0 = (q0.x - o.x) * rx; t1 = (q0.w - o.x) * rx; n0 = fminf(t0, t1); f0 = fmaxf(t0, t1);
-        t0 = (q0.y - o.y) * ry; t1 = (q1.x - o.y) * ry; n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
-        t0 = (q0.z - o.z) * rz; t1 = (q1.y - o.z) * rz; n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
-        t0 = (q1.z - o.x) * rx; t1 = (q2.y - o.x) * rx; n1 = fminf(t0, t1); f1 = fmaxf(t0, t1);
-        t0 = (q1.w - o.y) * ry; t1 = (q2.z - o.y) * ry; n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
-        t0 = (q2.x - o.z) * rz; t1 = (q2.w - o.z) * rz; n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
-        // fminf/fmaxf drop NaNs (0 * inf on a degenerate axis): the slab then does not constrain, which is conservative.
-        f0 *= 1.0000004f; f1 *= 1.0000004f;
-        const bool h0 = (fmaxf(n0, tmin) <= fminf(f0, tmax));
-        const bool h1 = (fmaxf(n1, tmin) <= fminf(f1, tmax));
-        if (h0 && h1) {
-            const bool swap = n1 < n0;
-            const uint32_t nearC = swap ? q3.y : q3.x, farC = swap ? q3.x : q3.y;
-            stk[(sp++) * KZ_BLOCK] = farC;
-            cur = nearC;
-        } else if (h0) cur = q3.x;
-        else if (h1) cur = q3.y;
+        const NodeTest nt = nodeTest(T, cur, o, rx, ry, rz, tmin, tmax);
+        if (nt.h0 && nt.h1) {
+            const bool swap = nt.n1 < nt.n0;
+            stk[(sp++) * KZ_BLOCK] = swap ? nt.c0 : nt.c1;
+            cur = swap ? nt.c1 : nt.c0;
+        } else if (nt.h0) cur = nt.c0;
+        else if (nt.h1) cur = nt.c1;
         else {
             if (sp == 0) break;
             cur = stk[(--sp) * KZ_BLOCK];
@@ -374,47 +344,22 @@ __device__ __forceinline__ bool anyHit(const KzDevTables &T, uint32_t rootRef, V
         if (cur & 0x80000000u) {
             uint32_t start = (cur & 0x7fffffffu) >> 3, count = (cur & 7u) + 1;
             for (uint32_t i = 0; i < count; ++i) {
-                const float4 *tp = reinterpret_cast<const float4 *>(T.tris + start + i);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, u, v; uint32_t gid;
                 if (STATS) cn.tris++;
-                const V3 p0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
-                V3 pvec = cross(d, e2);
-                float det = dot(e1, pvec);
-                if (det > -1e-8f && det < 1e-8f) continue;
-                float inv_det = 1.0f / det;
-                V3 tvec = o - p0;
-                float u = dot(tvec, pvec) * inv_det;
-                if (u < 0.0f || u > 1.0f) continue;
-                V3 qvec = cross(tvec, e1);
-                float v = dot(d, qvec) * inv_det;
-                if (v < 0.0f || u + v > 1.0f) continue;
-                float t = dot(e2, qvec) * inv_det;
-                if (t >= tmin && t <= tmax) return true;
+                if (triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, gid)) return true;
             }
             if (sp == 0) break;
             cur = stk[(--sp) * KZ_BLOCK];
             continue;
         }
-        const float4 *np = reinterpret_cast<const float4 *>(T.nodes + cur);
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-        const uint4 q3 = *reinterpret_cast<const uint4 *>(np + 3);
         if (STATS) cn.nodes++;
-        float t0, t1, n0, f0, n1, f1;
-        t0 = (q0.x - o.x) * rx; t1 = (q0.w - o.x) * rx; n0 = fminf(t0, t1); f0 = fmaxf(t0, t1);
-        t0 = (q0.y - o.y) * ry; t1 = (q1.x - o.y) * ry; n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
-        t0 = (q0.z - o.z) * rz; t1 = (q1.y - o.z) * rz; n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
-        t0 = (q1.z - o.x) * rx; t1 = (q2.y - o.x) * rx; n1 = fminf(t0, t1); f1 = fmaxf(t0, t1);
-        t0 = (q1.w - o.y) * ry; t1 = (q2.z - o.y) * ry; n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
-        t0 = (q2.x - o.z) * rz; t1 = (q2.w - o.z) * rz; n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
-        f0 *= 1.0000004f; f1 *= 1.0000004f;
-        const bool h0 = (fmaxf(n0, tmin) <= fminf(f0, tmax));
-        const bool h1 = (fmaxf(n1, tmin) <= fminf(f1, tmax));
-        if (h0 && h1) {
-            const bool swap = n1 < n0;
-            stk[(sp++) * KZ_BLOCK] = swap ? q3.x : q3.y;
-            cur = swap ? q3.y : q3.x;
-        } else if (h0) cur = q3.x;
-        else if (h1) cur = q3.y;
+        const NodeTest nt = nodeTest(T, cur, o, rx, ry, rz, tmin, tmax);
+        if (nt.h0 && nt.h1) {
+            const bool swap = nt.n1 < nt.n0;
+            stk[(sp++) * KZ_BLOCK] = swap ? nt.c0 : nt.c1;
+            cur = swap ? nt.c1 : nt.c0;
+        } else if (nt.h0) cur = nt.c0;
+        else if (nt.h1) cur = nt.c1;
         else {
             if (sp == 0) break;
             cur = stk[(--sp) * KZ_BLOCK];
@@ -439,43 +384,31 @@ __device__ __forceinline__ bool shadowOccludedLiteral(const KzParams &P, const K
     }
 }
 
+// Is a triangle of a light with lightPrimaryVisibility == false hit on the segment? The few such triangles (<= 64, P.nIlTris)
+// are tested by brute force behind their common bounding box (a conservative prefilter: rx, ry, rz only have to be finite
+// or the IEEE reciprocals of the direction).
+__device__ __forceinline__ bool invisibleLightOnSegment(const KzParams &P, const KzDevTables &T, V3 o, V3 d, float rx, float ry, float rz, float tmin, float tmax) {
+    if (P.nIlTris == 0) return false;
+    float t0 = (P.ilLo[0] - o.x) * rx, t1 = (P.ilHi[0] - o.x) * rx;
+    float n = fminf(t0, t1), f = fmaxf(t0, t1);
+    t0 = (P.ilLo[1] - o.y) * ry; t1 = (P.ilHi[1] - o.y) * ry; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
+    t0 = (P.ilLo[2] - o.z) * rz; t1 = (P.ilHi[2] - o.z) * rz; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
+    f *= 1.0000004f;
+    if (!(fmaxf(n, tmin) <= fminf(f, tmax))) return false;
+    for (uint32_t i = 0; i < P.nIlTris; ++i) {
+        float t, u, v; uint32_t g;
+        if (triTest(T.ilTris + i, o, d, tmin, tmax, t, u, v, g)) return true;
+    }
+    return false;
+}
+
 // Exact fast form of the same test. If no invisible-light triangle is hit on the segment, the reference's loop is a
-// single closest-hit query and "occluded" == "any triangle hit in [tmin,tmax]". The few invisible-light triangles
-// are tested by brute force behind their bounding box; only if one is hit (rare) the literal loop runs.
+// single closest-hit query and "occluded" == "any triangle hit in [tmin,tmax]"; only if one is hit (rare) the literal loop runs.
 template <bool STATS>
 __device__ __forceinline__ bool shadowOccluded(const KzParams &P, const KzDevTables &T, V3 so, V3 dir, float smin, float smax,
                                                uint32_t *stk, Counters &cn) {
-    if (P.shadowFast) {
-        bool lightOnSegment = false;
-        if (P.nIlTris > 0) {
-            const float rx = 1.0f / dir.x, ry = 1.0f / dir.y, rz = 1.0f / dir.z;
-            float t0 = (P.ilLo[0] - so.x) * rx, t1 = (P.ilHi[0] - so.x) * rx;
-            float n = fminf(t0, t1), f = fmaxf(t0, t1);
-            t0 = (P.ilLo[1] - so.y) * ry; t1 = (P.ilHi[1] - so.y) * ry; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
-            t0 = (P.ilLo[2] - so.z) * rz; t1 = (P.ilHi[2] - so.z) * rz; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
-            f *= 1.0000004f;
-            if (fmaxf(n, smin) <= fminf(f, smax)) {
-                for (uint32_t i = 0; i < P.nIlTris && !lightOnSegment; ++i) {
-                    const float4 *tp = reinterpret_cast<const float4 *>(T.ilTris + i);
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
-                    const V3 p0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
-                    V3 pvec = cross(dir, e2);
-                    float det = dot(e1, pvec);
-                    if (det > -1e-8f && det < 1e-8f) continue;
-                    float inv_det = 1.0f / det;
-                    V3 tvec = so - p0;
-                    float u = dot(tvec, pvec) * inv_det;
-                    if (u < 0.0f || u > 1.0f) continue;
-                    V3 qvec = cross(tvec, e1);
-                    float v = dot(dir, qvec) * inv_det;
-                    if (v < 0.0f || u + v > 1.0f) continue;
-                    float t = dot(e2, qvec) * inv_det;
-                    if (t >= smin && t <= smax) lightOnSegment = true;
-                }
-            }
-        }
-        if (!lightOnSegment) return anyHit<STATS>(T, P.rootRef, so, dir, smin, smax, stk, cn);
-    }
+    if (P.shadowFast && !invisibleLightOnSegment(P, T, so, dir, 1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z, smin, smax))
+        return anyHit<STATS>(T, P.rootRef, so, dir, smin, smax, stk, cn);
     return shadowOccludedLiteral<STATS>(P, T, so, dir, smin, smax, stk, cn);
 }
 

@@ -15,9 +15,13 @@
 #include "kz_wavefront.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 
@@ -230,96 +234,149 @@ __global__ void kz_texture_kernel(KzDevTables T, uint32_t n, const int32_t *__re
 }
 
 // ============================================================================================
-// host side: device state, upload, passes
+// host side: replicas (one device state per GPU the scene is resident on), upload, passes, the multi-device driver
 // ============================================================================================
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return kz_fail(KZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// Every device allocation of the library goes through here (kz_debug_fail_alloc can make the nth one fail).
+static thread_local int g_failAlloc = 0;
+static hipError_t kzMalloc(void **p, size_t bytes) {
+    *p = nullptr;
+    if (g_failAlloc > 0 && --g_failAlloc == 0) return hipErrorOutOfMemory;
+    return hipMalloc(p, bytes);
+}
+#define KZ_ALLOC(pp, bytes) do { hipError_t e_ = kzMalloc((void **)(pp), (bytes)); if (e_ != hipSuccess) \
+    return kz_fail(e_ == hipErrorOutOfMemory ? KZ_ERR_OOM : KZ_ERR_HIP, "device allocation of %zu bytes failed: %s", (size_t)(bytes), hipGetErrorString(e_)); } while (0)
+// A device buffer that is released on every way out of the call that made it.
+struct DevMem {
+    void *p = nullptr;
+    DevMem() = default;
+    DevMem(const DevMem &) = delete; DevMem &operator=(const DevMem &) = delete;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    template <class Tp> Tp *as() const { return (Tp *)p; }
+};
+
 struct EventPair { hipEvent_t a, b; };
+// path state + sample records + stage events of one pass in flight
+struct PassCtx {
+    KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0;
+    float *samp = nullptr; size_t sampCap = 0;                   // five SoA planes: jx | jy | r | g | b
+    uint32_t *ovf = nullptr; size_t ovfCap = 0;
+    std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
+    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t); }
+    void release() {
+        for (void *p : wfAllocs) (void)hipFree(p);
+        wfAllocs.clear(); wfCap = 0; wf = KzWf{};
+        if (samp) (void)hipFree(samp); samp = nullptr; sampCap = 0;
+        if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
+    }
+};
 struct KzDeviceState {
     int device = -1;
     KzDevTables T{};
     std::vector<void *> allocs;
     float4 *film = nullptr; size_t filmPixels = 0;
-    // per-pass sample buffers (SoA) and the pixel list / map of the current tile set
-    float *sJx = nullptr, *sJy = nullptr, *sR = nullptr, *sG = nullptr, *sB = nullptr; size_t sampCap = 0;
+    uint8_t *srgb = nullptr;                                     // staging raster of kz_film_to_srgb8 (allocated on first use)
     uint32_t *pixList = nullptr; int32_t *pixIndex = nullptr; size_t pixCap = 0; uint32_t nPix = 0;
     std::vector<KzTile> curTiles; bool tilesValid = false;
     unsigned long long *stats = nullptr; bool statsOn = false;
     hipStream_t lastStream = nullptr;
-    std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;   // boundaries of the stages of the last pass
-    KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0; int numCU = 256;
-    uint32_t *ovf = nullptr; size_t ovfCap = 0;
+    int numCU = 256; size_t totalMem = 0;
+    PassCtx ctx[2];
     std::vector<EventPair> events; size_t eventsUsed = 0;
-    // Two passes in flight: the path state / sample records / stage events above are "context 0"; `alt` holds context 1 and is
-    // swapped in while a pass of that context is being queued (kz_render). Each context has its own internal stream.
-    struct PassCtx {
-        KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0;
-        float *sJx = nullptr, *sJy = nullptr, *sR = nullptr, *sG = nullptr, *sB = nullptr; size_t sampCap = 0;
-        uint32_t *ovf = nullptr; size_t ovfCap = 0;
-        std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
-    } alt;
     hipStream_t passStream[2] = {nullptr, nullptr}; hipEvent_t evFork = nullptr, evFilm[2] = {nullptr, nullptr}, evCallA = nullptr, evCallB = nullptr;
-    int lastCtx = 0; uint32_t lastPasses = 0; bool lastDual = false;
-    void swapCtx() {
-        std::swap(wf, alt.wf); std::swap(wfAllocs, alt.wfAllocs); std::swap(wfCap, alt.wfCap);
-        std::swap(sJx, alt.sJx); std::swap(sJy, alt.sJy); std::swap(sR, alt.sR); std::swap(sG, alt.sG); std::swap(sB, alt.sB); std::swap(sampCap, alt.sampCap);
-        std::swap(ovf, alt.ovf); std::swap(ovfCap, alt.ovfCap);
-        std::swap(stageEv, alt.stageEv); std::swap(stageKind, alt.stageKind); std::swap(stageUsed, alt.stageUsed);
-    }
+    int lastCtx = 0; bool lastDual = false;
+    KzPassInfo lastInfo{};
 };
+struct KzReplicaSet { std::mutex m; std::vector<KzDeviceState *> v; };
 
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return kz_fail(KZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+static KzReplicaSet *replicaSet(const KzScene *scene) { return (KzReplicaSet *)scene->dev; }
 
 template <class Tp> static int uploadVec(KzDeviceState *ds, const std::vector<Tp> &v, const Tp **out) {
     *out = nullptr;
-    if (v.empty()) {          // keep a valid (dummy) pointer so kernels never see null
-        void *p = nullptr; HIP_TRY(hipMalloc(&p, 256)); HIP_TRY(hipMemset(p, 0, 256)); ds->allocs.push_back(p); *out = (const Tp *)p; return KZ_OK;
-    }
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, v.size() * sizeof(Tp)));
+    const size_t bytes = v.empty() ? 256 : v.size() * sizeof(Tp);    // keep a valid (dummy) pointer so kernels never see null
+    KZ_ALLOC(&p, bytes);
     ds->allocs.push_back(p);
-    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    if (v.empty()) HIP_TRY(hipMemset(p, 0, bytes));
+    else HIP_TRY(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
     *out = (const Tp *)p;
     return KZ_OK;
 }
 
-void kz_device_release(KzScene *scene) {
-    KzDeviceState *ds = (KzDeviceState *)scene->dev;
-    if (!ds) return;
+static void releaseReplica(KzDeviceState *ds) {
     (void)hipSetDevice(ds->device);
     (void)hipDeviceSynchronize();
     for (void *p : ds->allocs) (void)hipFree(p);
-    for (void *p : ds->wfAllocs) (void)hipFree(p);
-    for (void *p : {(void *)ds->film, (void *)ds->sJx, (void *)ds->sJy, (void *)ds->sR, (void *)ds->sG, (void *)ds->sB,
-                    (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->ovf})
-        if (p) (void)hipFree(p);
+    for (void *p : {(void *)ds->film, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats}) if (p) (void)hipFree(p);
+    for (auto &c : ds->ctx) { c.release(); for (auto &e : c.stageEv) (void)hipEventDestroy(e); }
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    for (auto &e : ds->stageEv) (void)hipEventDestroy(e);
-    for (void *p : ds->alt.wfAllocs) (void)hipFree(p);
-    for (void *p : {(void *)ds->alt.sJx, (void *)ds->alt.sJy, (void *)ds->alt.sR, (void *)ds->alt.sG, (void *)ds->alt.sB, (void *)ds->alt.ovf}) if (p) (void)hipFree(p);
-    for (auto &e : ds->alt.stageEv) (void)hipEventDestroy(e);
     for (hipStream_t st : ds->passStream) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : {ds->evFork, ds->evFilm[0], ds->evFilm[1], ds->evCallA, ds->evCallB}) if (e) (void)hipEventDestroy(e);
     delete ds;
+}
+
+void kz_device_init(KzScene *scene) { scene->dev = new KzReplicaSet(); }
+
+void kz_device_release(KzScene *scene) {
+    KzReplicaSet *rs = replicaSet(scene);
+    if (!rs) return;
+    for (KzDeviceState *ds : rs->v) releaseReplica(ds);
+    delete rs;
     scene->dev = nullptr;
 }
 
-extern "C" {
-
-int kz_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
+// The KZ_* environment variables of ABI v2, kept as a debug override: read once per process, applied only where the caller's
+// KzRenderOpts leaves a field at 0.
+struct EnvOverride { KzTuning tune{}; uint64_t passItems = 0; int passesInFlight = 0, pipeline = 0, traceKernel = 1, mixed = 0; };
+static const EnvOverride &envOverride() {
+    static const EnvOverride eo = [] {
+        EnvOverride o;
+        auto I = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
+        o.tune.refill = I("KZ_TUNE_REFILL", 0); o.tune.postpone = I("KZ_TUNE_POSTPONE", 0); o.tune.batch = I("KZ_TUNE_BATCH", 0);
+        o.tune.traceBlocksPerCU = I("KZ_TUNE_TRAV_BLOCKS", 0); o.tune.shadeBlocksPerCU = I("KZ_TUNE_SHADE_BLOCKS", 0);
+        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0);
+        if (const char *e = std::getenv("KZ_PASS_ITEMS")) { long long v = std::atoll(e); if (v >= 1024) o.passItems = (uint64_t)v; }
+        if (const char *e = std::getenv("KZ_DUAL_STREAM")) o.passesInFlight = std::atoi(e) ? 2 : 1;
+        o.pipeline = I("KZ_PIPELINE", 0); o.traceKernel = I("KZ_TRACE_KERNEL", 1); o.mixed = I("KZ_TUNE_MIXED", 0);
+        return o;
+    }();
+    return eo;
+}
+static KzTune resolveTune(const KzTuning &t) {
+    const KzTuning &e = envOverride().tune;
+    auto pick = [](int a, int b, int d) { return a > 0 ? a : (b > 0 ? b : d); };
+    KzTune r{};
+    r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
+    r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 6));
+    r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
+    r.packet = pick(t.packetPrimary, e.packetPrimary, 0);
+    r.ovf = nullptr; r.ovfStride = 0;
+    return r;
 }
 
-int kz_scene_upload(KzScene *scene, int device) {
+static int findReplica(const KzScene *scene, int device, KzDeviceState **out) {
     if (!scene) return kz_fail(KZ_ERR_INVALID_ARG, "null scene");
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return kz_fail(KZ_ERR_NO_DEVICE, "no HIP device visible (the product path has no CPU fallback)");
-    if (device < 0 || device >= n) return kz_fail(KZ_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, n);
-    if (scene->dev) kz_device_release(scene);
-    HIP_TRY(hipSetDevice(device));
-    KzDeviceState *ds = new KzDeviceState();
-    ds->device = device;
-    scene->dev = ds;
+    KzReplicaSet *rs = replicaSet(scene);
+    KzDeviceState *ds = nullptr;
+    if (rs) {
+        std::lock_guard<std::mutex> g(rs->m);
+        if (device < 0) ds = rs->v.empty() ? nullptr : rs->v.front();
+        else for (KzDeviceState *d : rs->v) if (d->device == device) { ds = d; break; }
+    }
+    if (!ds) {
+        if (device < 0 || !rs || rs->v.empty()) return kz_fail(KZ_ERR_STATE, "scene is not on a device: call kz_scene_upload first");
+        return kz_fail(KZ_ERR_STATE, "scene is not resident on device %d: call kz_scene_upload(scene, %d) first", device, device);
+    }
+    hipError_t e = hipSetDevice(ds->device);
+    if (e != hipSuccess) return kz_fail(KZ_ERR_HIP, "hipSetDevice(%d): %s", ds->device, hipGetErrorString(e));
+    *out = ds;
+    return KZ_OK;
+}
+// the primary replica (calls without a device argument)
+static int requireDevice(KzScene *scene, KzDeviceState **out) { return findReplica(scene, -1, out); }
+
+static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     int rc;
     if ((rc = uploadVec(ds, scene->nodes, &ds->T.nodes))) return rc;
     if ((rc = uploadVec(ds, scene->nodes4, &ds->T.nodes4))) return rc;
@@ -342,24 +399,72 @@ int kz_scene_upload(KzScene *scene, int device) {
     if ((rc = uploadVec(ds, scene->texels, &ds->T.texels))) return rc;
     const KzParams &P = scene->prm;
     ds->filmPixels = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border);
-    HIP_TRY(hipMalloc((void **)&ds->film, ds->filmPixels * sizeof(float4)));
+    KZ_ALLOC(&ds->film, ds->filmPixels * sizeof(float4));
     HIP_TRY(hipMemset(ds->film, 0, ds->filmPixels * sizeof(float4)));
-    HIP_TRY(hipMalloc((void **)&ds->stats, 8 * sizeof(unsigned long long)));
+    KZ_ALLOC(&ds->stats, 8 * sizeof(unsigned long long));
     HIP_TRY(hipMemset(ds->stats, 0, 8 * sizeof(unsigned long long)));
-    { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device)); ds->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+    { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, ds->device)); ds->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; ds->totalMem = prop.totalGlobalMem; }
     HIP_TRY(hipFuncSetAttribute((const void *)kz_film_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIP_TRY(hipDeviceSynchronize());
     return KZ_OK;
 }
 
-static int requireDevice(KzScene *scene, KzDeviceState **out) {
+extern "C" {
+
+void kz_debug_fail_alloc(int nth) { g_failAlloc = nth > 0 ? nth : 0; }
+
+int kz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int kz_scene_upload(KzScene *scene, int device) {
     if (!scene) return kz_fail(KZ_ERR_INVALID_ARG, "null scene");
-    if (!scene->dev) return kz_fail(KZ_ERR_STATE, "scene is not on a device: call kz_scene_upload first");
-    *out = (KzDeviceState *)scene->dev;
-    hipError_t e = hipSetDevice((*out)->device);
-    if (e != hipSuccess) return kz_fail(KZ_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return kz_fail(KZ_ERR_NO_DEVICE, "no HIP device visible (the product path has no CPU fallback)");
+    if (device < 0 || device >= n) return kz_fail(KZ_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, n);
+    KzReplicaSet *rs = replicaSet(scene);
+    {
+        std::lock_guard<std::mutex> g(rs->m);
+        for (KzDeviceState *d : rs->v) if (d->device == device) return KZ_OK;       // already resident
+    }
+    HIP_TRY(hipSetDevice(device));
+    KzDeviceState *ds = new KzDeviceState();
+    ds->device = device;
+    const int rc = uploadReplica(scene, ds);
+    if (rc) { releaseReplica(ds); return rc; }
+    std::lock_guard<std::mutex> g(rs->m);
+    for (KzDeviceState *d : rs->v) if (d->device == device) { releaseReplica(ds); return KZ_OK; }     // lost a race for the same device
+    rs->v.push_back(ds);
     return KZ_OK;
 }
+
+int kz_scene_evict(KzScene *scene, int device) {
+    if (!scene) return kz_fail(KZ_ERR_INVALID_ARG, "null scene");
+    KzReplicaSet *rs = replicaSet(scene);
+    std::vector<KzDeviceState *> gone;
+    {
+        std::lock_guard<std::mutex> g(rs->m);
+        for (size_t i = 0; i < rs->v.size();) {
+            if (device < 0 || rs->v[i]->device == device) { gone.push_back(rs->v[i]); rs->v.erase(rs->v.begin() + i); } else ++i;
+        }
+    }
+    if (gone.empty() && device >= 0) return kz_fail(KZ_ERR_STATE, "scene is not resident on device %d", device);
+    for (KzDeviceState *d : gone) releaseReplica(d);
+    return KZ_OK;
+}
+
+int kz_scene_devices(const KzScene *scene, int32_t *devices, uint32_t cap, uint32_t *count) {
+    if (!scene || !count) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
+    KzReplicaSet *rs = replicaSet(scene);
+    std::lock_guard<std::mutex> g(rs->m);
+    *count = (uint32_t)rs->v.size();
+    for (uint32_t i = 0; i < *count && i < cap && devices; ++i) devices[i] = rs->v[i]->device;
+    return KZ_OK;
+}
+
+} // extern "C"
 
 // pixel list (8x8 blocks row-major inside each tile, row-major inside a block) + image-sized index map
 static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, uint32_t nTiles, hipStream_t stream) {
@@ -385,11 +490,13 @@ static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, 
                     }
     }
     HIP_TRY(hipStreamSynchronize(stream));
-    if (!ds->pixIndex) HIP_TRY(hipMalloc((void **)&ds->pixIndex, index.size() * sizeof(int32_t)));
+    for (hipStream_t st : ds->passStream) if (st) HIP_TRY(hipStreamSynchronize(st));
+    ds->tilesValid = false;
+    if (!ds->pixIndex) KZ_ALLOC(&ds->pixIndex, index.size() * sizeof(int32_t));
     if (list.size() > ds->pixCap) {
-        if (ds->pixList) HIP_TRY(hipFree(ds->pixList));
-        ds->pixList = nullptr;
-        HIP_TRY(hipMalloc((void **)&ds->pixList, list.size() * sizeof(uint32_t)));
+        if (ds->pixList) (void)hipFree(ds->pixList);
+        ds->pixList = nullptr; ds->pixCap = 0;
+        KZ_ALLOC(&ds->pixList, list.size() * sizeof(uint32_t));
         ds->pixCap = list.size();
     }
     HIP_TRY(hipMemcpy(ds->pixList, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -400,57 +507,50 @@ static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, 
     return KZ_OK;
 }
 
-// (pixel, sample) items per pass. Measured on C4 with two passes in flight: 2^25 -> 981, 2^26 -> 1031, 2^27 -> 1061-1066, 2^28 -> 1071
-// Msamples/s (fewer launches and shorter relative tails per sample). 2^27 items = 23.6 GB of path state + sample records per pass
-// in flight, two in flight = 47 GB of the 288 GB; never more than half of what is free.
-static size_t passItemBudget() {
-    const char *e = std::getenv("KZ_PASS_ITEMS");
-    if (e) { long long v = std::atoll(e); if (v >= 1024) return (size_t)v; }
-    size_t budget = (size_t)1 << 27;
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) {
-        const size_t perItem = 2 * 176;                                  // both contexts: 8 float4 + uint4 + 3 queue words + 5 sample floats
-        const size_t fit = (totalB / 2) / perItem;                       // of the device total: what is already allocated for this scene counts as ours
-        budget = std::max<size_t>((size_t)1 << 22, std::min(budget, fit));
+static int stageMark(PassCtx &c, hipStream_t stream, int kind) {
+    if (c.stageUsed == c.stageEv.size()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c.stageEv.push_back(e); c.stageKind.push_back(0); }
+    c.stageKind[c.stageUsed] = kind;
+    HIP_TRY(hipEventRecord(c.stageEv[c.stageUsed++], stream));
+    return KZ_OK;
+}
+
+// Path state per (pixel, sample) item of a pass in flight: 8 float4 + uint4 + 3 queue words (wavefront) + 5 sample floats.
+static constexpr size_t KZ_STATE_BYTES_PER_ITEM = 8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t);
+static constexpr size_t KZ_SAMPLE_BYTES_PER_ITEM = 5 * sizeof(float);
+
+// ---- buffers of one pass context: sized for `need` items; nothing is left half-allocated on failure ----
+static int ctxEnsure(PassCtx &c, size_t need, bool wavefront, hipStream_t stream) {
+    if (need > c.sampCap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c.samp) (void)hipFree(c.samp);
+        c.samp = nullptr; c.sampCap = 0;
+        KZ_ALLOC(&c.samp, need * KZ_SAMPLE_BYTES_PER_ITEM);
+        c.sampCap = need;
     }
-    return budget;
-}
-
-
-static int stageMark(KzDeviceState *ds, hipStream_t stream, int kind) {
-    if (ds->stageUsed == ds->stageEv.size()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ds->stageEv.push_back(e); ds->stageKind.push_back(0); }
-    ds->stageKind[ds->stageUsed] = kind;
-    HIP_TRY(hipEventRecord(ds->stageEv[ds->stageUsed++], stream));
+    if (wavefront && (need > c.wfCap || c.wfAllocs.empty())) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (void *p : c.wfAllocs) (void)hipFree(p);
+        c.wfAllocs.clear(); c.wfCap = 0; c.wf = KzWf{};
+        KzWf W{};
+        auto alloc = [&](void **p, size_t bytes) -> int { KZ_ALLOC(p, bytes); c.wfAllocs.push_back(*p); return KZ_OK; };
+        int rc = KZ_OK;
+        for (float4 **p : {&W.rayA, &W.rayB, &W.hit, &W.thr, &W.misc, &W.shA, &W.shB, &W.shL}) if (!rc) rc = alloc((void **)p, need * sizeof(float4));
+        if (!rc) rc = alloc((void **)&W.smp, need * sizeof(uint4));
+        for (int q = 0; q < 3; ++q) if (!rc) rc = alloc((void **)&W.queue[q], need * sizeof(uint32_t));
+        if (!rc) rc = alloc((void **)&W.counts, 4 * 520 * sizeof(uint32_t));
+        if (rc) { for (void *p : c.wfAllocs) (void)hipFree(p); c.wfAllocs.clear(); return rc; }
+        c.wf = W; c.wfCap = need;
+    }
     return KZ_OK;
 }
 
-// ---- wavefront pass: allocate the SoA path state for `need` slots, then queue the stages of one pass on `stream` ----
-static int wfEnsure(KzScene *scene, KzDeviceState *ds, size_t need, hipStream_t stream) {
-    if (need <= ds->wfCap && !ds->wfAllocs.empty()) return KZ_OK;
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (void *p : ds->wfAllocs) (void)hipFree(p);
-    ds->wfAllocs.clear(); ds->wfCap = 0;
-    auto alloc = [&](void **p, size_t bytes) -> int { HIP_TRY(hipMalloc(p, bytes)); ds->wfAllocs.push_back(*p); return KZ_OK; };
-    KzWf &W = ds->wf; int rc;
-    for (float4 **p : {&W.rayA, &W.rayB, &W.hit, &W.thr, &W.misc, &W.shA, &W.shB, &W.shL}) if ((rc = alloc((void **)p, need * sizeof(float4)))) return rc;
-    if ((rc = alloc((void **)&W.smp, need * sizeof(uint4)))) return rc;
-    for (int q = 0; q < 3; ++q) if ((rc = alloc((void **)&W.queue[q], need * sizeof(uint32_t)))) return rc;
-    if ((rc = alloc((void **)&W.counts, 4 * 520 * sizeof(uint32_t)))) return rc;
-    ds->wfCap = need;
-    (void)scene;
-    return KZ_OK;
-}
-
-static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_t sBegin, uint32_t Sp, uint32_t items) {
+static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune) {
     const KzParams &P = scene->prm;
-    KzWf W = ds->wf;
-    W.outJx = ds->sJx; W.outJy = ds->sJy; W.outR = ds->sR; W.outG = ds->sG; W.outB = ds->sB; W.stats = ds->stats;
+    KzWf W = c.wf;
+    W.outJx = c.samp; W.outJy = c.samp + c.sampCap; W.outR = c.samp + 2 * c.sampCap; W.outG = c.samp + 3 * c.sampCap; W.outB = c.samp + 4 * c.sampCap; W.stats = ds->stats;
     const bool st = ds->statsOn;
     const size_t stackBytes = (size_t)P.stackDepth * KZ_BLOCK * sizeof(uint32_t);
     const dim3 blk(KZ_BLOCK);
-    auto envInt = [](const char *n, int dflt) { const char *e = std::getenv(n); return e ? std::atoi(e) : dflt; };
-    KzTune tune = {envInt("KZ_TUNE_REFILL", 40), envInt("KZ_TUNE_POSTPONE", 28), envInt("KZ_TUNE_BATCH", 128), envInt("KZ_TUNE_TRAV_BLOCKS", 8), envInt("KZ_TUNE_SHADE_BLOCKS", 6),
-                   envInt("KZ_TUNE_LDS_STACK", 16), envInt("KZ_TUNE_WIDE", 1), nullptr, 0};
     const dim3 gTrav((unsigned)(ds->numCU * tune.travBlocksPerCU)), gShade((unsigned)(ds->numCU * tune.shadeBlocksPerCU));
     // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
@@ -458,23 +558,23 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);      // + one scratch slot per lane (branch-free pushes)
     {
         const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack);
-        if (needOvf > ds->ovfCap) {
+        if (needOvf > c.ovfCap) {
             HIP_TRY(hipStreamSynchronize(stream));
-            if (ds->ovf) HIP_TRY(hipFree(ds->ovf));
-            ds->ovf = nullptr;
-            HIP_TRY(hipMalloc((void **)&ds->ovf, needOvf * sizeof(uint32_t)));
-            ds->ovfCap = needOvf;
+            if (c.ovf) (void)hipFree(c.ovf);
+            c.ovf = nullptr; c.ovfCap = 0;
+            KZ_ALLOC(&c.ovf, needOvf * sizeof(uint32_t));
+            c.ovfCap = needOvf;
         }
-        tune.ovf = ds->ovf; tune.ovfStride = (uint32_t)stride;
+        tune.ovf = c.ovf; tune.ovfStride = (uint32_t)stride;
     }
     const int maxDepth = P.maxDepth;
-    ds->stageUsed = 0;
+    c.stageUsed = 0;
     HIP_TRY(hipMemsetAsync(W.counts, 0, 4 * 520 * sizeof(uint32_t), stream));
-    { int rc_ = stageMark(ds, stream, -1); if (rc_) return rc_; }
+    { int rc_ = stageMark(c, stream, -1); if (rc_) return rc_; }
     hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, ds->pixList, items, Sp, sBegin);
-    { int rc_ = stageMark(ds, stream, 0); if (rc_) return rc_; }
+    { int rc_ = stageMark(c, stream, 0); if (rc_) return rc_; }
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
-    static const int traceKernel = [] { const char *e = std::getenv("KZ_TRACE_KERNEL"); return e ? std::atoi(e) : 1; }();
+    const int traceKernel = envOverride().traceKernel, mixed = envOverride().mixed;
 #define KZ_TRACE2(MODE, q, cptr, cimm, headp, qb, cb) do { \
         if (tune.wide) { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
                          else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } \
@@ -489,7 +589,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
         hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);
         KZ_EXTEND(true, (const uint32_t *)W.queue[2], (const uint32_t *)(W.counts + 0), 0u, W.counts + 3);
     }
-    { int rc_ = stageMark(ds, stream, 1); if (rc_) return rc_; }
+    { int rc_ = stageMark(c, stream, 1); if (rc_) return rc_; }
     const uint32_t *cur = nullptr, *curCount = nullptr;
     for (int iter = 0; iter < maxDepth; ++iter) {
         uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
@@ -497,15 +597,14 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
         if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
         else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
 #undef KZ_SHADE
-        { int rc_ = stageMark(ds, stream, 2); if (rc_) return rc_; }
+        { int rc_ = stageMark(c, stream, 2); if (rc_) return rc_; }
         const bool lastIter = iter == maxDepth - 1;
         const bool needExtend = !lastIter || P.bgPresent;
-        static const int mixed = [] { const char *e = std::getenv("KZ_TUNE_MIXED"); return e ? std::atoi(e) : 0; }();   // measured: no gain on C4 (43.16 vs 43.06 ms), kept as an option
         if (traceKernel && mixed && P.nLights > 0 && needExtend) {
-            // one launch for the shadow rays of this bounce and the closest-hit rays of the next
+            // one launch for the shadow rays of this bounce and the closest-hit rays of the next (measured: no gain on C4, kept as an option)
             KZ_TRACE2(3, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, (const uint32_t *)shQ, (const uint32_t *)shCount);
             cur = nextQ; curCount = nextCount;
-            { int rc_ = stageMark(ds, stream, 1); if (rc_) return rc_; }
+            { int rc_ = stageMark(c, stream, 1); if (rc_) return rc_; }
             continue;
         }
         if (P.nLights > 0) {
@@ -513,9 +612,8 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
             else if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
             else hipLaunchKernelGGL(kz_wf_shadow<false>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
         }
-        { int rc_ = stageMark(ds, stream, 3); if (rc_) return rc_; }
-        const bool last = iter == maxDepth - 1;
-        if (!last || P.bgPresent) { KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2); int rc_ = stageMark(ds, stream, 1); if (rc_) return rc_; }
+        { int rc_ = stageMark(c, stream, 3); if (rc_) return rc_; }
+        if (needExtend) { KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2); int rc_ = stageMark(c, stream, 1); if (rc_) return rc_; }
         cur = nextQ; curCount = nextCount;
     }
 #undef KZ_EXTEND
@@ -527,14 +625,13 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_
     return KZ_OK;
 }
 
-int kz_render(KzScene *scene, const KzRenderOpts *opts) {
-    KzDeviceState *ds; int rc;
-    if ((rc = requireDevice(scene, &ds))) return rc;
-    if (!opts) return kz_fail(KZ_ERR_INVALID_ARG, "null opts");
+static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts) {
+    int rc;
     const KzParams &P = scene->prm;
+    const EnvOverride &eo = envOverride();
     if (opts->pipeline < 0 || opts->pipeline > 2) return kz_fail(KZ_ERR_INVALID_ARG, "pipeline %d (0 = default, 1 = megakernel, 2 = wavefront)", opts->pipeline);
-    int pipeline = opts->pipeline;
-    if (pipeline == 0) { const char *e = std::getenv("KZ_PIPELINE"); pipeline = (e && std::atoi(e) == 1) ? 1 : 2; }
+    if (opts->passesInFlight < 0 || opts->passesInFlight > 2) return kz_fail(KZ_ERR_INVALID_ARG, "passesInFlight %d (0 = default, 1, 2)", opts->passesInFlight);
+    int pipeline = opts->pipeline ? opts->pipeline : (eo.pipeline == 1 ? 1 : 2);
     uint32_t s0 = opts->sampleBegin, s1 = opts->sampleEnd;
     if (s0 == 0 && s1 == 0) s1 = P.sampleCount;
     if (s0 >= s1 || s1 > P.sampleCount) return kz_fail(KZ_ERR_INVALID_ARG, "sample range [%u,%u) outside [0,%u)", s0, s1, P.sampleCount);
@@ -542,15 +639,39 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
     ds->lastStream = stream;
     if ((rc = prepareTiles(scene, ds, opts->tiles, opts->nTiles, stream))) return rc;
     if (!opts->accumulate) HIP_TRY(hipMemsetAsync(ds->film, 0, ds->filmPixels * sizeof(float4), stream));
-    const size_t budget = passItemBudget();
-    uint32_t S = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / std::max<uint32_t>(1, ds->nPix), s1 - s0));
+    const KzTune tune = resolveTune(opts->tune);
+    // ---- pass size. Measured on C4 with two passes in flight: 2^25 -> 981, 2^26 -> 1031, 2^27 -> 1061-1066, 2^28 -> 1071 Msamples/s
+    // (fewer launches and shorter relative tails per sample): default 2^27 items = 23.6 GB of path state + sample records per pass in flight.
+    // The state never takes more than the caller's limit; without one, not more than half of the device and not more than what
+    // is free now plus what this replica already holds for the purpose (another process or replica may own the rest).
+    int nCtx = pipeline == 2 ? (opts->passesInFlight ? opts->passesInFlight : (eo.passesInFlight ? eo.passesInFlight : 2)) : 1;
+    const size_t perItem = (pipeline == 2 ? KZ_STATE_BYTES_PER_ITEM : 0) + KZ_SAMPLE_BYTES_PER_ITEM;
+    size_t limit = opts->maxStateBytes;
+    if (!limit) {
+        size_t freeB = 0, totalB = 0;
+        const size_t held = ds->ctx[0].bytes() + ds->ctx[1].bytes();
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) limit = std::min(totalB / 2, freeB + held - std::min(freeB + held, (size_t)256 << 20));
+        else limit = (size_t)32 << 30;
+    }
+    size_t wantItems = opts->passItems ? (size_t)opts->passItems : (eo.passItems ? (size_t)eo.passItems : (size_t)1 << 27);
+    wantItems = std::max<size_t>(wantItems, ds->nPix);                   // at least one sample of every pixel per pass
+    uint32_t S = (uint32_t)std::min<size_t>(wantItems / std::max<uint32_t>(1, ds->nPix), s1 - s0);
+    uint32_t nPasses = (s1 - s0 + S - 1) / S;
+    if (nPasses < 2) nCtx = 1;
+    while ((size_t)ds->nPix * S * perItem * nCtx > limit) {
+        if (S > 1) S = std::max<uint32_t>(1, std::min<uint32_t>(S - 1, (uint32_t)(limit / ((size_t)ds->nPix * perItem * nCtx))));
+        else if (nCtx > 1) nCtx = 1;
+        else return kz_fail(KZ_ERR_OOM, "one sample of the %u pixels of this tile set needs %zu bytes of path state, the limit is %zu: render fewer tiles per call",
+                            ds->nPix, (size_t)ds->nPix * perItem, limit);
+        nPasses = (s1 - s0 + S - 1) / S;
+    }
     const size_t need = (size_t)ds->nPix * S;
-    const uint32_t nPasses = (s1 - s0 + S - 1) / S;
+    if (need >= (1ull << 32)) return kz_fail(KZ_ERR_UNSUPPORTED, "pass of %zu items (limit 2^32)", need);
     // Two passes in flight on two internal streams when the call has at least two: the persistent traversal kernels of one pass
     // drain (fewer and fewer busy waves) while the other pass keeps the machine full (C4: 36.9 -> 33.5 ms per pass). The passes
     // are independent except for the film, whose read-modify-write kernels are chained with events in pass order.
-    const int dualEnv = [] { const char *e = std::getenv("KZ_DUAL_STREAM"); return e ? std::atoi(e) : 1; }();
-    const bool dual = pipeline == 2 && nPasses >= 2 && dualEnv != 0;
+    const bool dual = pipeline == 2 && nPasses >= 2 && nCtx == 2;
+    if (!dual && ds->ctx[1].bytes() && (size_t)ds->nPix * S * perItem + ds->ctx[1].bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[1].release(); }
     if (!ds->evCallA) { HIP_TRY(hipEventCreate(&ds->evCallA)); HIP_TRY(hipEventCreate(&ds->evCallB)); }
     if (dual && !ds->passStream[0]) {
         // Different priorities put the two streams on different hardware queues whatever other streams the process has created
@@ -563,17 +684,6 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
         }
         HIP_TRY(hipEventCreateWithFlags(&ds->evFork, hipEventDisableTiming));
     }
-    auto ensureSamples = [&](hipStream_t st) -> int {
-        if (need <= ds->sampCap) return KZ_OK;
-        HIP_TRY(hipStreamSynchronize(st));
-        for (float **p : {&ds->sJx, &ds->sJy, &ds->sR, &ds->sG, &ds->sB}) {
-            if (*p) HIP_TRY(hipFree(*p));
-            *p = nullptr;
-            HIP_TRY(hipMalloc((void **)p, need * sizeof(float)));
-        }
-        ds->sampCap = need;
-        return KZ_OK;
-    };
     ds->eventsUsed = 0;
     HIP_TRY(hipEventRecord(ds->evCallA, stream));
     if (dual) {
@@ -585,48 +695,153 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
     for (uint32_t s = s0; s < s1; s += S, ++pass) {
         const uint32_t Sp = std::min(S, s1 - s);
         const size_t items = (size_t)ds->nPix * Sp;
-        if (items >= (1ull << 32)) return kz_fail(KZ_ERR_UNSUPPORTED, "pass too large");
-        const int c = dual ? (int)(pass & 1u) : 0;
-        hipStream_t pst = dual ? ds->passStream[c] : stream;
-        if (c == 1) ds->swapCtx();
-        struct SwapBack { KzDeviceState *d; bool on; ~SwapBack() { if (on) d->swapCtx(); } } swapBack{ds, c == 1};
-        if ((rc = ensureSamples(pst))) return rc;
-        if (pipeline == 2 && (rc = wfEnsure(scene, ds, need, pst))) return rc;
+        const int ci = dual ? (int)(pass & 1u) : 0;
+        PassCtx &c = ds->ctx[ci];
+        hipStream_t pst = dual ? ds->passStream[ci] : stream;
+        if ((rc = ctxEnsure(c, need, pipeline == 2, pst))) return rc;
         if (ds->eventsUsed == ds->events.size()) {
             EventPair ep; HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); ds->events.push_back(ep);
         }
         EventPair &ep = ds->events[ds->eventsUsed++];
         const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
+        float *sJx = c.samp, *sJy = c.samp + c.sampCap, *sR = c.samp + 2 * c.sampCap, *sG = c.samp + 3 * c.sampCap, *sB = c.samp + 4 * c.sampCap;
         HIP_TRY(hipEventRecord(ep.a, pst));
-        if (pipeline == 2) { if ((rc = wfPass(scene, ds, pst, s, Sp, (uint32_t)items))) return rc; }
+        if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, s, Sp, (uint32_t)items, tune))) return rc; }
         else {
 #define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, ds->pixList, (uint32_t)items, Sp, s, \
-                                           (const uint32_t *)nullptr, ds->sJx, ds->sJy, ds->sR, ds->sG, ds->sB, ds->stats)
+                                           (const uint32_t *)nullptr, sJx, sJy, sR, sG, sB, ds->stats)
             if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, true); else KZ_MEGA(true, false); }
             else { if (P.bsdfExt) KZ_MEGA(false, true); else KZ_MEGA(false, false); }
 #undef KZ_MEGA
         }
         HIP_TRY(hipEventRecord(ep.b, pst));
         HIP_TRY(hipGetLastError());
-        if (dual && pass > 0) HIP_TRY(hipStreamWaitEvent(pst, ds->evFilm[c ^ 1], 0));       // film of the previous pass is in
+        if (dual && pass > 0) HIP_TRY(hipStreamWaitEvent(pst, ds->evFilm[ci ^ 1], 0));       // film of the previous pass is in
         const dim3 fgrid((cols + KZ_FILM_TILE - 1) / KZ_FILM_TILE, (rows + KZ_FILM_TILE - 1) / KZ_FILM_TILE);
         const int ftaps = P.tapHi - P.tapLo + 1, fr = KZ_FILM_TILE + ftaps - 1;
         const size_t perSample = (size_t)(3 + 2 * ftaps) * fr * fr * sizeof(float);
         const int fchunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)Sp, (size_t)8, (size_t)(64 * 1024) / perSample}));
         const size_t fshm = perSample * fchunk;
-        hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, pst, P, ds->T.filter, ds->pixIndex, Sp, fchunk, ds->sJx, ds->sJy, ds->sR, ds->sG,
-                           ds->sB, ds->film);
+        hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, pst, P, ds->T.filter, ds->pixIndex, Sp, fchunk, sJx, sJy, sR, sG, sB, ds->film);
         HIP_TRY(hipGetLastError());
-        if (dual) HIP_TRY(hipEventRecord(ds->evFilm[c], pst));
-        if (pipeline == 2) { int rc_ = stageMark(ds, pst, 4); if (rc_) return rc_; }
-        ds->lastCtx = c;
+        if (dual) HIP_TRY(hipEventRecord(ds->evFilm[ci], pst));
+        if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
+        ds->lastCtx = ci;
     }
     if (dual) {                                                        // join: everything after this call on `stream` sees the film
         HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[0], 0));
         HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[1], 0));
     }
     HIP_TRY(hipEventRecord(ds->evCallB, stream));
-    ds->lastPasses = pass; ds->lastDual = dual;
+    ds->lastDual = dual;
+    ds->lastInfo.passes = pass; ds->lastInfo.passesInFlight = dual ? 2 : 1; ds->lastInfo.itemsPerPass = need; ds->lastInfo.sppPerPass = S;
+    ds->lastInfo.pixels = ds->nPix; ds->lastInfo.stateBytes = ds->ctx[0].bytes() + ds->ctx[1].bytes();
+    return KZ_OK;
+}
+
+extern "C" {
+
+int kz_render(KzScene *scene, const KzRenderOpts *opts) {
+    if (!opts) return kz_fail(KZ_ERR_INVALID_ARG, "null opts");
+    KzDeviceState *ds; int rc;
+    // opts->device addresses a replica by HIP device index; a scene resident on ONE device is addressed by any zero-initialised opts
+    if ((rc = findReplica(scene, opts->device, &ds))) {
+        KzReplicaSet *rs = scene ? replicaSet(scene) : nullptr;
+        bool single = false;
+        if (rs) { std::lock_guard<std::mutex> g(rs->m); single = rs->v.size() == 1 && opts->device == 0; }
+        if (!single || (rc = findReplica(scene, -1, &ds))) return rc;
+    }
+    return renderOn(scene, ds, opts);
+}
+
+int kz_render_tiles(KzScene *scene, const KzRenderOpts *opts, const KzTile *tiles, uint32_t nTiles, int device, float *film, size_t nFloats) {
+    KzDeviceState *ds; int rc;
+    if ((rc = findReplica(scene, device, &ds))) return rc;
+    if (film && nFloats != ds->filmPixels * 4) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold %zu floats", ds->filmPixels * 4);
+    KzRenderOpts o{};
+    if (opts) o = *opts;
+    o.tiles = tiles; o.nTiles = nTiles; o.device = device;
+    if ((rc = renderOn(scene, ds, &o))) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)o.stream));
+    if (film) HIP_TRY(hipMemcpy(film, ds->film, nFloats * sizeof(float), hipMemcpyDeviceToHost));
+    return KZ_OK;
+}
+
+int kz_deal_tiles(int32_t width, int32_t height, int32_t tileSize, uint32_t nParts, uint32_t part, KzTile *out, uint32_t cap, uint32_t *count) {
+    if (tileSize == 0) tileSize = 64;
+    if (width <= 0 || height <= 0 || tileSize < 32 || tileSize % 32 || nParts == 0 || part >= nParts || !count)
+        return kz_fail(KZ_ERR_INVALID_ARG, "kz_deal_tiles: bad argument (tile size must be a positive multiple of 32, part < nParts)");
+    std::vector<KzTile> tiles;
+    for (int y = 0; y < height; y += tileSize)
+        for (int x = 0; x < width; x += tileSize) tiles.push_back(KzTile{x, y, std::min(tileSize, width - x), std::min(tileSize, height - y)});
+    // largest first (stable: row-major order among equals), each to the part with the least area so far (ties: the lower part)
+    std::vector<uint32_t> order(tiles.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (int64_t)tiles[a].w * tiles[a].h > (int64_t)tiles[b].w * tiles[b].h; });
+    std::vector<int64_t> area(nParts, 0);
+    std::vector<uint32_t> mine;
+    for (uint32_t i : order) {
+        uint32_t best = 0;
+        for (uint32_t p = 1; p < nParts; ++p) if (area[p] < area[best]) best = p;
+        area[best] += (int64_t)tiles[i].w * tiles[i].h;
+        if (best == part) mine.push_back(i);
+    }
+    std::sort(mine.begin(), mine.end());                                // back to row-major order within the part
+    *count = (uint32_t)mine.size();
+    if (mine.size() > cap || (!out && !mine.empty())) return kz_fail(KZ_ERR_INVALID_ARG, "kz_deal_tiles: %zu tiles, room for %u", mine.size(), cap);
+    for (size_t i = 0; i < mine.size(); ++i) out[i] = tiles[mine[i]];
+    return KZ_OK;
+}
+
+int kz_film_merge(float *dst, const float *src, size_t nFloats) {
+    if (!dst || !src) return kz_fail(KZ_ERR_INVALID_ARG, "null film");
+    for (size_t i = 0; i < nFloats; ++i) dst[i] += src[i];
+    return KZ_OK;
+}
+
+int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *devices, uint32_t nDevices, int32_t tileSize, float *film, size_t nFloats,
+                    float *deviceMs) {
+    if (!scene || !devices || nDevices == 0 || !film) return kz_fail(KZ_ERR_INVALID_ARG, "kz_render_multi: null argument");
+    const KzParams &P = scene->prm;
+    const size_t filmFloats = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border) * 4;
+    if (nFloats != filmFloats) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold %zu floats", filmFloats);
+    for (uint32_t i = 0; i < nDevices; ++i) for (uint32_t j = 0; j < i; ++j) if (devices[i] == devices[j]) return kz_fail(KZ_ERR_INVALID_ARG, "device %d listed twice", devices[i]);
+    struct Job { std::vector<KzTile> tiles; std::vector<float> film; int rc = KZ_OK; std::string err; float ms = 0.f; };
+    std::vector<Job> jobs(nDevices);
+    for (uint32_t i = 0; i < nDevices; ++i) {
+        uint32_t n = 0;
+        (void)kz_deal_tiles(P.width, P.height, tileSize, nDevices, i, nullptr, 0, &n);
+        jobs[i].tiles.resize(n);
+        int rc = n ? kz_deal_tiles(P.width, P.height, tileSize, nDevices, i, jobs[i].tiles.data(), n, &n) : KZ_OK;
+        if (rc) return rc;
+    }
+    // one host thread per device (renderer.cpp:94-127 runs one TBB task per block; here a task is a GPU's whole tile share)
+    std::vector<std::thread> threads;
+    for (uint32_t i = 0; i < nDevices; ++i) {
+        threads.emplace_back([&, i]() {
+            Job &j = jobs[i];
+            const auto t0 = std::chrono::steady_clock::now();
+            if (j.tiles.empty()) return;
+            j.rc = kz_scene_upload(scene, devices[i]);
+            if (!j.rc) {
+                if (i > 0) j.film.resize(filmFloats);                    // device 0 of the list renders straight into the caller's buffer
+                KzRenderOpts o{};
+                if (opts) o = *opts;
+                o.stream = nullptr; o.accumulate = 0;
+                j.rc = kz_render_tiles(scene, &o, j.tiles.data(), (uint32_t)j.tiles.size(), devices[i], i > 0 ? j.film.data() : film, filmFloats);
+            }
+            if (j.rc) j.err = kz_last_error();                             // the message is thread-local: carry it to the caller's thread
+            j.ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (uint32_t i = 0; i < nDevices; ++i) {
+        if (deviceMs) deviceMs[i] = jobs[i].ms;
+        if (jobs[i].rc) return kz_fail(jobs[i].rc, "device %d: %s", devices[i], jobs[i].err.c_str());
+    }
+    // ImageBlock::put(ImageBlock&) (block.cpp:87-96) in the fixed order of `devices`
+    if (jobs[0].tiles.empty()) std::memset(film, 0, filmFloats * sizeof(float));
+    for (uint32_t i = 1; i < nDevices; ++i) if (!jobs[i].tiles.empty()) kz_film_merge(film, jobs[i].film.data(), filmFloats);
     return KZ_OK;
 }
 
@@ -638,32 +853,39 @@ int kz_last_stage_ms(KzScene *scene, float *out5) {
     if (!out5) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
     for (int i = 0; i < 5; ++i) out5[i] = 0.f;
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
-    const std::vector<hipEvent_t> &ev = ds->lastCtx ? ds->alt.stageEv : ds->stageEv;
-    const std::vector<int> &kind = ds->lastCtx ? ds->alt.stageKind : ds->stageKind;
-    const size_t used = ds->lastCtx ? ds->alt.stageUsed : ds->stageUsed;
-    for (size_t i = 1; i < used; ++i) {
-        float t = 0; HIP_TRY(hipEventElapsedTime(&t, ev[i - 1], ev[i]));
-        const int k = kind[i];
+    const PassCtx &c = ds->ctx[ds->lastCtx];
+    for (size_t i = 1; i < c.stageUsed; ++i) {
+        float t = 0; HIP_TRY(hipEventElapsedTime(&t, c.stageEv[i - 1], c.stageEv[i]));
+        const int k = c.stageKind[i];
         if (k >= 0 && k < 5) out5[k] += t;
     }
     return KZ_OK;
 }
 
-int kz_sync(KzScene *scene) {
+int kz_last_pass_info(KzScene *scene, KzPassInfo *out) {
     KzDeviceState *ds; int rc;
     if ((rc = requireDevice(scene, &ds))) return rc;
+    if (!out) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
+    *out = ds->lastInfo;
+    return KZ_OK;
+}
+
+int kz_sync_on(KzScene *scene, int device) {
+    KzDeviceState *ds; int rc;
+    if ((rc = findReplica(scene, device, &ds))) return rc;
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
     return KZ_OK;
 }
+int kz_sync(KzScene *scene) { return kz_sync_on(scene, -1); }
 
 int kz_last_kernel_ms(KzScene *scene, float *ms) {
     KzDeviceState *ds; int rc;
     if ((rc = requireDevice(scene, &ds))) return rc;
     if (!ms) return kz_fail(KZ_ERR_INVALID_ARG, "null ms");
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
-    if (ds->lastDual && ds->lastPasses) {          // passes overlap: the per-pass figure is the span of the call over its passes (film included)
+    if (ds->lastDual && ds->lastInfo.passes) {          // passes overlap: the per-pass figure is the span of the call over its passes (film included)
         float t = 0; HIP_TRY(hipEventElapsedTime(&t, ds->evCallA, ds->evCallB));
-        *ms = t / (float)ds->lastPasses;
+        *ms = t / (float)ds->lastInfo.passes;
         return KZ_OK;
     }
     double tot = 0;
@@ -672,21 +894,23 @@ int kz_last_kernel_ms(KzScene *scene, float *ms) {
     return KZ_OK;
 }
 
-int kz_film_clear(KzScene *scene, void *stream) {
+int kz_film_clear_on(KzScene *scene, int device, void *stream) {
     KzDeviceState *ds; int rc;
-    if ((rc = requireDevice(scene, &ds))) return rc;
+    if ((rc = findReplica(scene, device, &ds))) return rc;
     HIP_TRY(hipMemsetAsync(ds->film, 0, ds->filmPixels * sizeof(float4), (hipStream_t)stream));
     return KZ_OK;
 }
+int kz_film_clear(KzScene *scene, void *stream) { return kz_film_clear_on(scene, -1, stream); }
 
-int kz_film_download(KzScene *scene, float *film, size_t nFloats) {
+int kz_film_download_on(KzScene *scene, int device, float *film, size_t nFloats) {
     KzDeviceState *ds; int rc;
-    if ((rc = requireDevice(scene, &ds))) return rc;
+    if ((rc = findReplica(scene, device, &ds))) return rc;
     if (!film || nFloats != ds->filmPixels * 4) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold %zu floats", ds->filmPixels * 4);
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
     HIP_TRY(hipMemcpy(film, ds->film, nFloats * sizeof(float), hipMemcpyDeviceToHost));
     return KZ_OK;
 }
+int kz_film_download(KzScene *scene, float *film, size_t nFloats) { return kz_film_download_on(scene, -1, film, nFloats); }
 
 // ImageBlock::toBitmap (block.cpp:39-45) + Bitmap::savePNG's tone map (bitmap.cpp:45-52): the film is resolved to the 8-bit
 // sRGB raster on the device, so the host link carries 3 bytes per pixel instead of the 16-byte film texel.
@@ -696,15 +920,12 @@ int kz_film_to_srgb8(KzScene *scene, uint8_t *rgb8, size_t nBytes) {
     const KzParams &P = scene->prm;
     const size_t need = (size_t)P.width * (size_t)P.height * 3;
     if (!rgb8 || nBytes != need) return kz_fail(KZ_ERR_INVALID_ARG, "rgb8 buffer must hold %zu bytes", need);
-    uint8_t *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, need));
+    if (!ds->srgb) KZ_ALLOC(&ds->srgb, need);                          // staging raster kept with the replica
     const uint32_t n = (uint32_t)(P.width * P.height);
-    hipLaunchKernelGGL(kz_film_srgb8, dim3((n + 255) / 256), dim3(256), 0, ds->lastStream, ds->film, P.width, P.height, P.border, d);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ds->lastStream);
-    if (e == hipSuccess) e = hipMemcpy(rgb8, d, need, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    if (e != hipSuccess) return kz_fail(KZ_ERR_HIP, "kz_film_to_srgb8: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kz_film_srgb8, dim3((n + 255) / 256), dim3(256), 0, ds->lastStream, ds->film, P.width, P.height, P.border, ds->srgb);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ds->lastStream));
+    HIP_TRY(hipMemcpy(rgb8, ds->srgb, need, hipMemcpyDeviceToHost));
     return KZ_OK;
 }
 
@@ -732,17 +953,16 @@ int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d, co
     if ((rc = requireDevice(scene, &ds))) return rc;
     if (n == 0) return KZ_OK;
     if (!o || !d || !tmin || !tmax || !hits) return kz_fail(KZ_ERR_INVALID_ARG, "null ray buffer");
-    float *dO = nullptr, *dD = nullptr, *dA = nullptr, *dB = nullptr; KzHit *dH = nullptr;
-    HIP_TRY(hipMalloc((void **)&dO, (size_t)n * 12)); HIP_TRY(hipMalloc((void **)&dD, (size_t)n * 12));
-    HIP_TRY(hipMalloc((void **)&dA, (size_t)n * 4)); HIP_TRY(hipMalloc((void **)&dB, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&dH, (size_t)n * sizeof(KzHit)));
-    HIP_TRY(hipMemcpy(dO, o, (size_t)n * 12, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dD, d, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dA, tmin, (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dB, tmax, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kz_trace_kernel, dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, scene->prm, ds->T, n, dO, dD, dA, dB, dH);
+    DevMem dO, dD, dA, dB, dH;
+    KZ_ALLOC(&dO.p, (size_t)n * 12); KZ_ALLOC(&dD.p, (size_t)n * 12); KZ_ALLOC(&dA.p, (size_t)n * 4); KZ_ALLOC(&dB.p, (size_t)n * 4);
+    KZ_ALLOC(&dH.p, (size_t)n * sizeof(KzHit));
+    HIP_TRY(hipMemcpy(dO.p, o, (size_t)n * 12, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dD.p, d, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dA.p, tmin, (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dB.p, tmax, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_trace_kernel, dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, scene->prm, ds->T, n, dO.as<float>(), dD.as<float>(), dA.as<float>(),
+                       dB.as<float>(), dH.as<KzHit>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(hits, dH, (size_t)n * sizeof(KzHit), hipMemcpyDeviceToHost));
-    (void)hipFree(dO); (void)hipFree(dD); (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dH);
+    HIP_TRY(hipMemcpy(hits, dH.p, (size_t)n * sizeof(KzHit), hipMemcpyDeviceToHost));
     return KZ_OK;
 }
 
@@ -759,10 +979,11 @@ int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint
             return kz_fail(KZ_ERR_INVALID_ARG, "sample %u: pixel (%d,%d) index %u out of range", i, pxy[2 * i], pxy[2 * i + 1], idx[i]);
         pl[i] = (uint32_t)pxy[2 * i] | ((uint32_t)pxy[2 * i + 1] << 16);
     }
-    uint32_t *dP = nullptr, *dI = nullptr; float *dO = nullptr;
-    HIP_TRY(hipMalloc((void **)&dP, (size_t)n * 4)); HIP_TRY(hipMalloc((void **)&dI, (size_t)n * 4)); HIP_TRY(hipMalloc((void **)&dO, (size_t)n * 20));
-    HIP_TRY(hipMemcpy(dP, pl.data(), (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dI, idx, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL((kz_path_megakernel<false, true>), dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, P, ds->T, dP, n, 1u, 0u, dI,
+    DevMem dP, dI, dOut;
+    KZ_ALLOC(&dP.p, (size_t)n * 4); KZ_ALLOC(&dI.p, (size_t)n * 4); KZ_ALLOC(&dOut.p, (size_t)n * 20);
+    float *dO = dOut.as<float>();
+    HIP_TRY(hipMemcpy(dP.p, pl.data(), (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dI.p, idx, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((kz_path_megakernel<false, true>), dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, P, ds->T, dP.as<uint32_t>(), n, 1u, 0u, dI.as<uint32_t>(),
                        dO, dO + n, dO + 2 * (size_t)n, dO + 3 * (size_t)n, dO + 4 * (size_t)n, ds->stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -772,7 +993,6 @@ int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint
         out[5 * i] = (float)pxy[2 * i] + h[i]; out[5 * i + 1] = (float)pxy[2 * i + 1] + h[n + i];
         out[5 * i + 2] = h[2 * (size_t)n + i]; out[5 * i + 3] = h[3 * (size_t)n + i]; out[5 * i + 4] = h[4 * (size_t)n + i];
     }
-    (void)hipFree(dP); (void)hipFree(dI); (void)hipFree(dO);
     return KZ_OK;
 }
 
@@ -784,9 +1004,10 @@ int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *
     if (n == 0) return KZ_OK;
     if (!bsdf || !wi || !wo || !accRough || !s3 || !evalOut || !pdfOut || !sampleOut) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
     for (uint32_t i = 0; i < n; ++i) if (bsdf[i] < 0 || (size_t)bsdf[i] >= scene->bsdfs.size()) return kz_fail(KZ_ERR_INVALID_ARG, "bsdf index %d", bsdf[i]);
-    float *d = nullptr; int32_t *dB = nullptr;
+    DevMem dF, dBs;
     const size_t fl = (size_t)n * (3 + 3 + 1 + 3 + 3 + 1 + 8 + 2);
-    HIP_TRY(hipMalloc((void **)&d, fl * 4)); HIP_TRY(hipMalloc((void **)&dB, (size_t)n * 4));
+    KZ_ALLOC(&dF.p, fl * 4); KZ_ALLOC(&dBs.p, (size_t)n * 4);
+    float *d = dF.as<float>(); int32_t *dB = dBs.as<int32_t>();
     float *dWi = d, *dWo = d + 3 * (size_t)n, *dAcc = d + 6 * (size_t)n, *dS = d + 7 * (size_t)n, *dE = d + 10 * (size_t)n, *dP = d + 13 * (size_t)n,
           *dSm = d + 14 * (size_t)n, *dUv = d + 22 * (size_t)n;
     HIP_TRY(hipMemcpy(dB, bsdf, (size_t)n * 4, hipMemcpyHostToDevice));
@@ -798,7 +1019,6 @@ int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(evalOut, dE, (size_t)n * 12, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(pdfOut, dP, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(sampleOut, dSm, (size_t)n * 32, hipMemcpyDeviceToHost));
-    (void)hipFree(d); (void)hipFree(dB);
     return KZ_OK;
 }
 
@@ -809,15 +1029,15 @@ int kz_texture_query(KzScene *scene, uint32_t n, const int32_t *tex, const float
     if (n == 0) return KZ_OK;
     if (!tex || !uv || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
     for (uint32_t i = 0; i < n; ++i) if (tex[i] < 0 || (size_t)tex[i] >= scene->texProgs.size()) return kz_fail(KZ_ERR_INVALID_ARG, "texture index %d", tex[i]);
-    float *d = nullptr; int32_t *dT = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, (size_t)n * 5 * 4)); HIP_TRY(hipMalloc((void **)&dT, (size_t)n * 4));
+    DevMem dF, dTx;
+    KZ_ALLOC(&dF.p, (size_t)n * 5 * 4); KZ_ALLOC(&dTx.p, (size_t)n * 4);
+    float *d = dF.as<float>(); int32_t *dT = dTx.as<int32_t>();
     float *dUv = d, *dO = d + 2 * (size_t)n;
     HIP_TRY(hipMemcpy(dT, tex, (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dUv, uv, (size_t)n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(kz_texture_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, ds->T, n, dT, dUv, dO);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dO, (size_t)n * 12, hipMemcpyDeviceToHost));
-    (void)hipFree(d); (void)hipFree(dT);
     return KZ_OK;
 }
 

@@ -388,6 +388,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
             sc->jump[s].mult = acc_mult; sc->jump[s].plus = acc_plus;
         }
     }
+    kz_device_init(sc);
     *out = sc;
     return KZ_OK;
 }

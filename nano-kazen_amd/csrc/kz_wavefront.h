@@ -409,7 +409,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // the bounce before: both only depend on the same shade stage, and one launch has one tail instead of two.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment; such
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
-struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide; uint32_t *ovf; uint32_t ovfStride; };
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet; uint32_t *ovf; uint32_t ovfStride; };
 
 template <int MODE, bool STATS, bool WIDE>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
@@ -495,19 +495,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                         } else { rx = 1.0f / d.x; ry = 1.0f / d.y; rz = 1.0f / d.z; }
                         cur = root; sp = 0; active = true;
                         if (kind == 2) {
-                            literal = !P.shadowFast;
-                            if (!literal && P.nIlTris > 0) {
-                                float t0 = (P.ilLo[0] - o.x) * rx, t1 = (P.ilHi[0] - o.x) * rx;
-                                float n = fminf(t0, t1), f = fmaxf(t0, t1);
-                                t0 = (P.ilLo[1] - o.y) * ry; t1 = (P.ilHi[1] - o.y) * ry; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
-                                t0 = (P.ilLo[2] - o.z) * rz; t1 = (P.ilHi[2] - o.z) * rz; n = fmaxf(n, fminf(t0, t1)); f = fminf(f, fmaxf(t0, t1));
-                                f *= 1.0000004f;
-                                if (fmaxf(n, tmin) <= fminf(f, tmax))
-                                    for (uint32_t i = 0; i < P.nIlTris && !literal; ++i) {
-                                        float t, u, v; uint32_t g;
-                                        if (triTest(T.ilTris + i, o, d, tmin, tmax, t, u, v, g)) literal = true;
-                                    }
-                            }
+                            literal = !P.shadowFast || invisibleLightOnSegment(P, T, o, d, rx, ry, rz, tmin, tmax);
                         }
                     } else {
                         // a ray that cannot hit anything (empty scene, non-finite origin/direction)

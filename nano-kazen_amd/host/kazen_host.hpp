@@ -778,25 +778,50 @@ inline std::vector<float> render(Scene *scene, int device = 0) {
     if (!h) throw Exception("renderer::render: scene was not activated");
     if (kz_scene_upload(h, device) != KZ_OK) throw Exception(std::string("kz_scene_upload: ") + kz_last_error());
     KzRenderOpts o{};
+    o.device = device;
     if (kz_render(h, &o) != KZ_OK) throw Exception(std::string("kz_render: ") + kz_last_error());
     int32_t w, hh, b;
     kz_film_dims(h, &w, &hh, &b);
     std::vector<float> film((size_t)(w + 2 * b) * (hh + 2 * b) * 4), rgb((size_t)w * hh * 3);
-    if (kz_film_download(h, film.data(), film.size()) != KZ_OK) throw Exception(std::string("kz_film_download: ") + kz_last_error());
+    if (kz_film_download_on(h, device, film.data(), film.size()) != KZ_OK) throw Exception(std::string("kz_film_download: ") + kz_last_error());
     kz_film_to_rgb(film.data(), w, hh, b, rgb.data());
     return rgb;
 }
-/// renderer.cpp:72-153 including the file: renders and writes `<stem of filename>.png` (renderer.cpp:143-152), tone-mapped on the device
-inline void render(Scene *scene, const std::string &filename, int device = 0) {
-    std::vector<float> rgb = render(scene, device);
+/// The same over several GPUs of one node, the reference's own decomposition one level up (renderer.cpp:94-127 runs one
+/// task per 32x32 block and merges with ImageBlock::put(ImageBlock&) under a mutex, block.cpp:87-96): ONE scene (one host
+/// BVH) resident on every device of `devices`, one host thread per device rendering its share of 64x64 tiles
+/// (kz_deal_tiles: by area), per-device films summed on the host in the order of `devices`. No collective.
+/// An empty list means every visible device.
+inline std::vector<float> render(Scene *scene, std::vector<int> devices, std::vector<float> *deviceMs = nullptr) {
+    KzScene *h = scene->handle();
+    if (!h) throw Exception("renderer::render: scene was not activated");
+    if (devices.empty()) for (int d = 0; d < kz_device_count(); ++d) devices.push_back(d);
+    if (devices.empty()) throw Exception("renderer::render: no HIP device visible (the MI355X path has no CPU fallback)");
+    int32_t w, hh, b;
+    kz_film_dims(h, &w, &hh, &b);
+    std::vector<float> film((size_t)(w + 2 * b) * (hh + 2 * b) * 4), rgb((size_t)w * hh * 3), ms(devices.size());
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    if (kz_render_multi(h, nullptr, devs.data(), (uint32_t)devs.size(), 0, film.data(), film.size(), ms.data()) != KZ_OK)
+        throw Exception(std::string("kz_render_multi: ") + kz_last_error());
+    if (deviceMs) *deviceMs = ms;
+    kz_film_to_rgb(film.data(), w, hh, b, rgb.data());
+    return rgb;
+}
+inline void saveBitmap(Scene *scene, std::vector<float> rgb, const std::string &filename, bool deviceToneMap) {
     int32_t w, hh, b;
     kz_film_dims(scene->handle(), &w, &hh, &b);
     Bitmap bitmap(w, hh, std::move(rgb));
-    std::vector<uint8_t> px((size_t)w * hh * 3);
-    if (kz_film_to_srgb8(scene->handle(), px.data(), px.size()) != KZ_OK) throw Exception(std::string("kz_film_to_srgb8: ") + kz_last_error());
-    bitmap.setSRGB8(std::move(px));
+    if (deviceToneMap) {
+        std::vector<uint8_t> px((size_t)w * hh * 3);
+        if (kz_film_to_srgb8(scene->handle(), px.data(), px.size()) != KZ_OK) throw Exception(std::string("kz_film_to_srgb8: ") + kz_last_error());
+        bitmap.setSRGB8(std::move(px));
+    }
     const size_t lastdot = filename.find_last_of(".");
     bitmap.savePNG(lastdot == std::string::npos ? filename : filename.substr(0, lastdot));
 }
+/// renderer.cpp:72-153 including the file: renders and writes `<stem of filename>.png` (renderer.cpp:143-152), tone-mapped on the device
+inline void render(Scene *scene, const std::string &filename, int device = 0) { saveBitmap(scene, render(scene, device), filename, true); }
+/// multi-GPU form; the merged film lives on the host, so Bitmap::savePNG applies the reference's tone map there (bitmap.cpp:45-52)
+inline void render(Scene *scene, const std::string &filename, const std::vector<int> &devices) { saveBitmap(scene, render(scene, devices), filename, false); }
 } // namespace renderer
 } // namespace kazen

@@ -43,10 +43,24 @@ class Scene:
         return {k: getattr(info, k) for k, _ in info._fields_}
 
     def upload(self, device=0):
+        """Adds a replica on `device` (the first one uploaded is the primary, which the calls without a device address)."""
         abi.check(self.lib, self.lib.kz_scene_upload(self.h, int(device)))
-        self.device = int(device)
+        if self.device is None:
+            self.device = int(device)
 
-    def render(self, sample_begin=0, sample_end=0, tiles=None, accumulate=False, pipeline=0, stream=None):
+    def evict(self, device=-1):
+        abi.check(self.lib, self.lib.kz_scene_evict(self.h, int(device)))
+        if device < 0 or device == self.device:
+            self.device = None
+
+    def devices(self):
+        buf = (C.c_int32 * 64)()
+        n = C.c_uint32()
+        abi.check(self.lib, self.lib.kz_scene_devices(self.h, buf, 64, C.byref(n)))
+        return [int(buf[i]) for i in range(n.value)]
+
+    def _opts(self, sample_begin=0, sample_end=0, tiles=None, accumulate=False, pipeline=0, stream=None, device=None,
+              passes_in_flight=0, pass_items=0, max_state_bytes=0, tune=None):
         o = abi.KzRenderOpts()
         o.sampleBegin, o.sampleEnd = sample_begin, sample_end
         keep = None
@@ -56,7 +70,46 @@ class Scene:
         o.pipeline = pipeline
         o.accumulate = 1 if accumulate else 0
         o.stream = stream
+        o.device = (self.device or 0) if device is None else int(device)
+        o.passesInFlight, o.passItems, o.maxStateBytes = int(passes_in_flight), int(pass_items), int(max_state_bytes)
+        for k, v in (tune or {}).items():
+            setattr(o.tune, k, int(v))
+        return o, keep
+
+    def render(self, sample_begin=0, sample_end=0, tiles=None, accumulate=False, pipeline=0, stream=None, **kw):
+        """kz_render. Keywords: device, passes_in_flight, pass_items, max_state_bytes, tune={KzTuning field: value}."""
+        o, keep = self._opts(sample_begin, sample_end, tiles, accumulate, pipeline, stream, **kw)
         abi.check(self.lib, self.lib.kz_render(self.h, C.byref(o)))
+
+    def render_tiles(self, tiles, device=None, sample_begin=0, sample_end=0, download=True, **kw):
+        """kz_render_tiles: blocking render of `tiles` on `device`; returns that replica's film (or None)."""
+        o, _ = self._opts(sample_begin, sample_end, **kw)
+        arr = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
+        dev = (self.device or 0) if device is None else int(device)
+        n = (self.height + 2 * self.border) * (self.width + 2 * self.border) * 4
+        out = np.empty(n, np.float32) if download else None
+        abi.check(self.lib, self.lib.kz_render_tiles(self.h, C.byref(o), arr, len(tiles), dev,
+                                                      out.ctypes.data_as(abi.f32p) if download else None, n if download else 0))
+        return out.reshape(self.height + 2 * self.border, self.width + 2 * self.border, 4) if download else None
+
+    def render_multi(self, devices, tile_size=0, sample_begin=0, sample_end=0, **kw):
+        """kz_render_multi: one host thread per device, tiles dealt by area, films summed on the host in device order.
+        Returns (film, per-device ms)."""
+        o, _ = self._opts(sample_begin, sample_end, **kw)
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        n = (self.height + 2 * self.border) * (self.width + 2 * self.border) * 4
+        out = np.empty(n, np.float32)
+        ms = np.zeros(len(devices), np.float32)
+        abi.check(self.lib, self.lib.kz_render_multi(self.h, C.byref(o), devs, len(devices), int(tile_size), out.ctypes.data_as(abi.f32p), n,
+                                                      ms.ctypes.data_as(abi.f32p)))
+        if self.device is None:
+            self.device = int(devices[0])
+        return out.reshape(self.height + 2 * self.border, self.width + 2 * self.border, 4), ms
+
+    def last_pass_info(self):
+        info = abi.KzPassInfo()
+        abi.check(self.lib, self.lib.kz_last_pass_info(self.h, C.byref(info)))
+        return info.as_dict()
 
     def sync(self):
         abi.check(self.lib, self.lib.kz_sync(self.h))

@@ -23,6 +23,37 @@ def tiles_for_rank(tiles, rank, world):
     return [t for i, t in enumerate(tiles) if i % world == rank]
 
 
+def deal_tiles(width, height, parts, part, tile=64):
+    """kz_deal_tiles (the dealing kz_render_multi uses): tiles go, largest first, to the part with the least area so far;
+    row-major order inside a part. Every rank of a multi-process launch calls this with its own `part`."""
+    import ctypes as C
+    from . import abi
+    lib = abi.load_library()
+    n = C.c_uint32()
+    cap = ((width + tile - 1) // tile) * ((height + tile - 1) // tile)
+    buf = (abi.KzTile * cap)()
+    abi.check(lib, lib.kz_deal_tiles(width, height, tile, parts, part, buf, cap, C.byref(n)))
+    return [(buf[i].x0, buf[i].y0, buf[i].w, buf[i].h) for i in range(n.value)]
+
+
+def gather_films(film, rank, world):
+    """The host gather of a multi-process launch (one rank per GPU): every rank hands its host film to rank 0 over the CPU
+    process group (gloo) and rank 0 adds them in rank order - ImageBlock::put(ImageBlock&), block.cpp:87-96. No RCCL, no
+    device collective: the films are (h+2b) x (w+2b) x 4 floats, 33 MB at 1920x1080. Returns the merged film on rank 0, None elsewhere."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return film
+    t = torch.from_numpy(np.ascontiguousarray(film))
+    if rank == 0:
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.gather(t, bufs, dst=0)
+        return merge_films([b.numpy() for b in bufs])
+    dist.gather(t, None, dst=0)
+    return None
+
+
 def merge_films(films):
     """Sum per-rank films in rank order (deterministic, H10)."""
     out = films[0].copy()

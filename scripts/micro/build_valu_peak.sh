@@ -11,7 +11,7 @@ import glob, json, re, sys
 from collections import Counter
 s = open(glob.glob(sys.argv[1] + "/*gfx950*.s")[0]).read()
 out = {}
-for k in range(5):
+for k in range(5):  # the five loop variants (the single-opcode kernels are asm, counted by construction)
     m = re.search(r"^_Z9valu_loopILi%dE\w*:[^\n]*\n(.*?)^\.Lfunc_end" % k, s, re.S | re.M)
     parts = re.split(r"^(\.LBB\d+_\d+):.*$", m.group(1), flags=re.M)
     for i in range(1, len(parts) - 1, 2):

@@ -101,6 +101,48 @@ __global__ __launch_bounds__(256) void valu_loop(int iters, float seed, unsigned
     if (r == 1234.5678f) sink[0] = r;
 }
 
+// ---- single-opcode variants (32 independent instructions per iteration): what each VALU opcode of the traversal costs ----
+#define OP16(fmt) \
+    fmt(0) fmt(1) fmt(2) fmt(3) fmt(4) fmt(5) fmt(6) fmt(7) fmt(8) fmt(9) fmt(10) fmt(11) fmt(12) fmt(13) fmt(14) fmt(15)
+template <int V>
+__global__ __launch_bounds__(256) void op_loop(int iters, float seed, unsigned long long *__restrict__ cycles, float *__restrict__ sink) {
+    float a[16]; unsigned u[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a[i] = seed + threadIdx.x + i; u[i] = __float_as_uint(a[i]) * 2654435761u; }
+    const float m = 0.999f, c = 1e-3f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define OPS(TXT) asm volatile(TXT TXT : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), \
+                              "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) : "v"(m), "v"(c), "v"(u[0]), "v"(u[1]) : "vcc", "s20", "s21")
+#define R16(A, B) A "%0" B "\n" A "%1" B "\n" A "%2" B "\n" A "%3" B "\n" A "%4" B "\n" A "%5" B "\n" A "%6" B "\n" A "%7" B "\n" \
+                  A "%8" B "\n" A "%9" B "\n" A "%10" B "\n" A "%11" B "\n" A "%12" B "\n" A "%13" B "\n" A "%14" B "\n" A "%15" B "\n"
+        if (V == 0) OPS(R16("v_fma_f32 ", ", %16, %17, %17"));             // dst = m * c + c style: independent of dst (no chain at all)
+        else if (V == 1) OPS(R16("v_add_f32 ", ", %16, %17"));
+        else if (V == 2) OPS(R16("v_cvt_f32_ubyte1 ", ", %18"));
+        else if (V == 3) OPS(R16("v_max3_f32 ", ", %16, %17, %16"));
+        else if (V == 4) OPS(R16("v_max_f32 ", ", %16, %17"));
+        else if (V == 5) OPS(R16("v_cndmask_b32 ", ", %16, %17, vcc"));
+        else if (V == 6) OPS(R16("v_and_or_b32 ", ", %18, %19, %18"));
+        else if (V == 7) OPS(R16("v_mul_lo_u32 ", ", %18, %19"));
+        else if (V == 8) OPS(R16("v_cmp_le_f32 vcc, %16, ", ""));
+        else if (V == 9) OPS(R16("v_mov_b32 ", ", %16"));
+        else if (V == 10) OPS(R16("v_rcp_f32 ", ", %16"));
+        else if (V == 11) OPS(R16("v_perm_b32 ", ", %18, %19, %18"));
+        else if (V == 12) OPS(R16("v_mul_f32 ", ", %16, %17"));
+        else if (V == 13) OPS(R16("v_min3_f32 ", ", %16, %17, %16"));
+        else if (V == 14) OPS(R16("v_cndmask_b32_e64 ", ", %16, %17, s[20:21]"));           // select by an SGPR-pair mask
+        else if (V == 15) OPS(R16("v_cmp_le_f32 vcc, %16, %17\n v_cndmask_b32 ", ", %16, %17, vcc"));   // compare + select pairs (32 + 32)
+        else if (V == 16) OPS(R16("v_fma_f32 ", ", %16, s20, %17"));                         // VOP3 with one SGPR operand
+        else if (V == 17) OPS(R16("v_cvt_f32_ubyte0 ", ", s20"));                            // conversion of a wave-uniform byte
+        else if (V == 18) OPS(R16("v_lshrrev_b32 ", ", 8, %18"));
+        else OPS(R16("v_bfe_u32 ", ", %18, 8, 8"));
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0;
+    float r = 0; for (int i = 0; i < 16; ++i) r += a[i];
+    if (r == 1234.5678f) sink[0] = r;
+}
 
 int main(int argc, char **argv) {
     int only = argc > 1 ? atoi(argv[1]) : -1;
@@ -139,6 +181,27 @@ int main(int argc, char **argv) {
             printf("\n");
             first = false;
         }
+    }
+
+    static const char *opName[] = {"v_fma_f32", "v_add_f32", "v_cvt_f32_ubyte1", "v_max3_f32", "v_max_f32", "v_cndmask_b32", "v_and_or_b32", "v_mul_lo_u32",
+                                   "v_cmp_le_f32", "v_mov_b32", "v_rcp_f32", "v_perm_b32", "v_mul_f32", "v_min3_f32",
+                                   "v_cndmask_b32 (sgpr pair)", "v_cmp+v_cndmask pairs", "v_fma_f32 (sgpr operand)", "v_cvt_f32_ubyte0 (sgpr)", "v_lshrrev_b32", "v_bfe_u32"};
+    for (int v = 0; v < 20 && only < 0; ++v) {
+        const int wps = 8, blocks = cus * wps;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            switch (v) {
+#define LAUNCH(K) case K: hipLaunchKernelGGL(op_loop<K>, dim3(blocks), dim3(256), 0, 0, iters, 1.0f, dC, dS); break;
+                LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) LAUNCH(14) LAUNCH(15) LAUNCH(16) LAUNCH(17) LAUNCH(18) LAUNCH(19)
+            }
+            CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        }
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        // whole-kernel rate: 8 waves/SIMD x 32 instructions x iters per SIMD over the kernel's duration at the 2.4 GHz maximum clock
+        const double perSimdPerCycle = 8.0 * (v == 15 ? 64 : 32) * iters / (ms * 1e-3 * 2.4e9);
+        printf(", {\"op\": \"%s\", \"waves_per_simd\": 8, \"ms\": %.3f, \"asm_instr_per_iter\": 32, \"wave_instr_per_cycle_per_simd_at_2p4GHz\": %.4f, "
+               "\"cycles_per_instr_at_2p4GHz\": %.3f}\n", opName[v], ms, perSimdPerCycle, 1.0 / perSimdPerCycle);
     }
     printf("]}\n");
     return 0;

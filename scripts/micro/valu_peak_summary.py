@@ -8,7 +8,7 @@ def rows(d):
     return list(csv.DictReader(open(f[0]))) if f else []
 acc = {}
 for r in rows("pmc_sq") + rows("pmc_grbm"):
-    if "valu_loop" not in r["Kernel_Name"]:
+    if "valu_loop" not in r["Kernel_Name"] and "op_loop" not in r["Kernel_Name"]:
         continue
     acc.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 # dispatches come in the program's order: per (variant, wps) two launches (warm-up, timed); the two PMC runs number them alike

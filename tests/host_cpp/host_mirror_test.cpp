@@ -141,6 +141,16 @@ int main(int argc, char **argv) {
         bm.savePNG(argv[2]); bm.saveEXR(argv[2]);
         return 0;
     }
+    if (argc >= 4 && !std::strcmp(argv[1], "--render-multi")) {      // renderer::render(scene, devices): argv[3] = device list "0,1,.."
+        std::unique_ptr<Scene> scene(buildScene());
+        std::vector<int> devs;
+        for (const char *c = argv[3]; *c;) { devs.push_back(std::atoi(c)); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
+        std::vector<float> ms;
+        std::vector<float> rgb = renderer::render(scene.get(), devs, &ms);
+        std::ofstream(argv[2], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
+        std::printf("{\"pixels\": %zu, \"devices\": %zu}\n", rgb.size() / 3, ms.size());
+        return 0;
+    }
     if (argc >= 3 && !std::strcmp(argv[1], "--render-png")) {        // renderer::render(scene, filename) (renderer.cpp:72-153)
         std::unique_ptr<Scene> scene(buildScene());
         renderer::render(scene.get(), std::string(argv[2]), 0);

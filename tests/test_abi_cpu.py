@@ -25,7 +25,7 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
     import subprocess
     a = kz.abi
     names = ["KzBSDF", "KzImage", "KzTexture", "KzLight", "KzMesh", "KzFilter", "KzCamera", "KzSampler", "KzIntegrator", "KzBackground",
-             "KzSceneDesc", "KzTile", "KzRenderOpts", "KzStats", "KzHit", "KzBvhInfo"]
+             "KzSceneDesc", "KzTile", "KzTuning", "KzRenderOpts", "KzPassInfo", "KzStats", "KzHit", "KzBvhInfo"]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "kazen_mi355x.h"\nint main(void){' +
                    "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}\n")
@@ -35,6 +35,50 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
     for n in names:
         assert C.sizeof(getattr(a, n)) == int(sizes[n]), n
     assert C.sizeof(a.KzBSDF) == 128 and C.sizeof(a.KzTexture) == 64
+
+
+def test_render_opts_layout_v3(kz):
+    """ABI v3: the v2 prefix of KzRenderOpts keeps its offsets (a v2 caller's zero-extended struct means "defaults")."""
+    o = kz.abi.KzRenderOpts
+    assert (o.sampleBegin.offset, o.sampleEnd.offset, o.tiles.offset, o.nTiles.offset, o.pipeline.offset, o.accumulate.offset, o.stream.offset) == (0, 4, 8, 16, 20, 24, 32)
+    assert o.device.offset == 40 and o.passItems.offset == 48 and o.maxStateBytes.offset == 56 and o.tune.offset == 64
+    assert C.sizeof(kz.abi.KzTuning) == 64 and C.sizeof(o) == 128
+
+
+@pytest.mark.parametrize("w,h,tile,parts", [(1920, 1080, 64, 8), (3840, 2160, 64, 8), (1920, 1080, 128, 3), (100, 70, 32, 5), (64, 64, 64, 4)])
+def test_deal_tiles_partitions_the_image_by_area(kz, w, h, tile, parts):
+    """kz_deal_tiles: every pixel in exactly one part, tiles on the 32-px block grid, areas balanced to one tile."""
+    cover = np.zeros((h, w), np.int32)
+    areas = []
+    for p in range(parts):
+        tl = kz.shard.deal_tiles(w, h, parts, p, tile)
+        assert tl == sorted(tl, key=lambda t: (t[1], t[0]))              # row-major inside a part
+        for (x0, y0, tw, th) in tl:
+            assert x0 % 32 == 0 and y0 % 32 == 0 and 0 < tw <= tile and 0 < th <= tile
+            cover[y0:y0 + th, x0:x0 + tw] += 1
+        areas.append(sum(t[2] * t[3] for t in tl))
+    assert (cover == 1).all()
+    assert max(areas) - min(areas) <= tile * tile
+    # 8 GPUs on the C4 / C5 frames: the imbalance the old 128-px round-robin had (ranks of 16 or 17 tiles) is gone
+    if parts == 8:
+        assert (max(areas) - min(areas)) / (w * h / parts) < 0.02
+
+
+def test_deal_tiles_rejects_bad_arguments(kz):
+    lib = kz.abi.load_library()
+    n = C.c_uint32()
+    assert lib.kz_deal_tiles(64, 64, 48, 2, 0, None, 0, C.byref(n)) == kz.abi.KZ_ERR_INVALID_ARG       # not a multiple of 32
+    assert lib.kz_deal_tiles(64, 64, 32, 2, 2, None, 0, C.byref(n)) == kz.abi.KZ_ERR_INVALID_ARG       # part >= nParts
+    assert lib.kz_deal_tiles(64, 64, 32, 2, 0, None, 0, C.byref(n)) == kz.abi.KZ_ERR_INVALID_ARG and n.value == 2   # no room: count still set
+
+
+def test_film_merge_is_an_elementwise_sum(kz):
+    lib = kz.abi.load_library()
+    a = np.arange(40, dtype=np.float32)
+    b = np.full(40, 0.5, np.float32)
+    assert lib.kz_film_merge(a.ctypes.data_as(kz.abi.f32p), b.ctypes.data_as(kz.abi.f32p), 40) == 0
+    assert np.array_equal(a, np.arange(40, dtype=np.float32) + 0.5)
+    assert lib.kz_film_merge(None, b.ctypes.data_as(kz.abi.f32p), 40) == kz.abi.KZ_ERR_INVALID_ARG
 
 
 def test_scene_create_and_bvh_on_host(kz):
@@ -71,6 +115,10 @@ def test_no_device_is_a_loud_error(kz):
     with pytest.raises(kz.abi.KzError) as e:
         sc.render()
     assert e.value.code == kz.abi.KZ_ERR_STATE
+    assert sc.devices() == []
+    with pytest.raises(kz.abi.KzError) as e:                      # the multi-device driver fails the same way, from its worker thread
+        sc.render_multi([0])
+    assert e.value.code == kz.abi.KZ_ERR_NO_DEVICE and "device 0" in str(e.value)
 
 
 @pytest.mark.parametrize("mutate,code", [

@@ -1,0 +1,234 @@
+"""-m gpu: the BASELINE.json configs at their FULL sizes, and the multi-device entry points of ABI v3.
+
+* C2 (sphere + environment, 512x512) at its full 64 spp against the oracle;
+* C3 (hero scene, full detail = 508 k triangles, 1920x1080x256): properties + crop parity against the oracle;
+* C5 (the 1 M-triangle scene at 3840x2160, pmj02bn 4096): a 4-spp slice rendered as EIGHT tile shares through
+  kz_render_tiles (the unit of multi-GPU sharding), summed on the host, against the one-shot film and, on a crop, the oracle;
+* kz_render_multi (one host thread per device, host gather) on the devices this box has;
+* replicas, budget limits and error paths of ABI v3.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+L2_TOL = 1e-3
+
+
+def l2(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def _crop_rgb(film, x0, y0, w, h, b):
+    c = film[y0:y0 + h + 2 * b, x0:x0 + w + 2 * b]
+    return c[..., :3] / np.maximum(c[..., 3:], 1e-20), c[..., 3]
+
+
+def test_c2_full_spp_matches_oracle(gpu_lib, kz, O):
+    desc = kz.scenes.sphere_env(512, 512, 64)                       # BASELINE configs[1] as quoted: 512x512, 64 spp
+    sc = kz.Scene(desc, device=0)
+    sc.set_stats(True)
+    sc.render()
+    st = sc.stats()
+    ora = O.OracleScene(desc)
+    cpu = ora.rgb(ora.render(threads=0))
+    assert st["samples"] == 512 * 512 * 64 == ora.stats()["samples"] and st["droppedSamples"] == 0
+    assert l2(sc.rgb(), cpu) < L2_TOL
+
+
+def test_c3_full_size_properties_and_crop(gpu_lib, kz, O):
+    """configs[2]: hero scene at full detail, full kiss BSDF + 3 lights, 1920x1080, 256 spp, all of it rendered."""
+    desc = kz.scenes.hero_scene(1920, 1080, 256)
+    sc = kz.Scene(desc, device=0)
+    assert sc.bvh_info()["nTris"] > 500000
+    sc.set_stats(True)
+    sc.render()
+    film = sc.film()
+    st = sc.stats(reset=True)
+    assert st["samples"] == 1920 * 1080 * 256 and st["droppedSamples"] == 0 and np.isfinite(film).all()
+    # total filter mass per sample equals that of a small render with the same filter (interior samples: the full kernel sum)
+    small = kz.Scene(kz.scenes.cornell_box(64, 64, 16), device=0)
+    small.render()
+    mass, mass_small = film[..., 3].sum() / st["samples"], small.film()[..., 3].sum() / (64 * 64 * 16)
+    assert abs(mass - mass_small) < 2e-3 * mass_small
+    rgb = sc.rgb(film)
+    assert 0.01 < rgb.mean() < 10 and (rgb >= 0).all()
+    # the megakernel pipeline (reference-shaped) gives the same film bit for bit on a sample slice
+    sc.set_stats(False)
+    sc.render(0, 8)
+    a = sc.film()
+    sc.render(0, 8, pipeline=1)
+    assert np.array_equal(sc.film(), a)
+    # crop parity at the full 256 spp: two 48x48 windows (object + floor, backdrop) against the oracle
+    ora = O.OracleScene(desc)
+    b = sc.border
+    for (x0, y0) in ((936, 520), (300, 760)):
+        tile = [(x0, y0, 48, 48)]
+        film_c = ora.render(tiles=tile, threads=0)
+        sc.render(tiles=tile)
+        rg, wg = _crop_rgb(sc.film(), x0, y0, 48, 48, b)
+        rc, wc = _crop_rgb(film_c, x0, y0, 48, 48, b)
+        assert np.allclose(wg, wc, rtol=1e-5, atol=1e-5)
+        assert l2(rg, rc) < L2_TOL, (x0, y0)
+
+
+def test_c5_workload_as_eight_tile_shares(gpu_lib, kz, O):
+    """configs[4]: 3840x2160, 1 M triangles, pmj02bn 4096 spp; a 4-spp slice. Eight tile shares (what eight GPUs would get)
+    rendered one after the other on this GPU through kz_render_tiles and summed on the host in share order."""
+    Wd, Hd = 3840, 2160
+    desc = kz.scenes.random_triangles(1000000, Wd, Hd, 4096)
+    sc = kz.Scene(desc, device=0)
+    assert sc.sample_count == 4096 and sc.bvh_info()["nTris"] == 1000028
+    sc.render(100, 104)
+    whole = sc.film()
+    total, areas = None, []
+    for part in range(8):
+        tiles = kz.shard.deal_tiles(Wd, Hd, 8, part, 64)
+        areas.append(sum(t[2] * t[3] for t in tiles))
+        f = sc.render_tiles(tiles, device=0, sample_begin=100, sample_end=104)
+        if total is None:
+            total = f.copy()
+        else:
+            assert gpu_lib.kz_film_merge(total.ctypes.data_as(kz.abi.f32p), f.ctypes.data_as(kz.abi.f32p), f.size) == 0
+    assert sum(areas) == Wd * Hd and (max(areas) - min(areas)) / (Wd * Hd / 8) < 0.01
+    assert np.allclose(total, whole, rtol=1e-5, atol=1e-6)
+    # the in-process driver (one host thread per device, host gather) on the devices of this box
+    devs = list(range(min(gpu_lib.kz_device_count(), 8)))
+    merged, ms = sc.render_multi(devs, sample_begin=100, sample_end=104)
+    assert np.allclose(merged, whole, rtol=1e-5, atol=1e-6) and (ms > 0).all()
+    assert sc.devices()[0] == 0 and set(sc.devices()) == set(devs)
+    # a 64x64 crop of the same slice against the oracle
+    ora = O.OracleScene(desc)
+    x0, y0, b = 1888, 1048, sc.border
+    film_c = ora.render(100, 104, tiles=[(x0, y0, 64, 64)], threads=0)
+    sc.render(100, 104, tiles=[(x0, y0, 64, 64)])
+    rg, wg = _crop_rgb(sc.film(), x0, y0, 64, 64, b)
+    rc, wc = _crop_rgb(film_c, x0, y0, 64, 64, b)
+    assert np.allclose(wg, wc, rtol=1e-5, atol=1e-6)
+    assert l2(rg, rc) < L2_TOL
+
+
+def test_render_multi_equals_single_device(gpu_lib, kz, O):
+    desc = kz.scenes.cornell_box(200, 136, 8, sampler="pmj02bn")
+    sc = kz.Scene(desc)                                               # not uploaded: kz_render_multi brings the replicas up itself
+    devs = list(range(min(gpu_lib.kz_device_count(), 8)))
+    merged, ms = sc.render_multi(devs, tile_size=32)
+    assert sc.devices() == devs
+    sc.render(device=devs[0])
+    assert np.allclose(merged, sc.film(), rtol=1e-5, atol=1e-6)
+    ora = O.OracleScene(desc)
+    assert l2(sc.rgb(merged), ora.rgb(ora.render(threads=0))) < L2_TOL
+    merged2, _ = sc.render_multi(devs, tile_size=32)
+    assert np.array_equal(merged, merged2)                            # deterministic: fixed dealing, fixed merge order
+    with pytest.raises(kz.abi.KzError):
+        sc.render_multi([0, 0])
+
+
+def test_replicas_and_device_addressing(gpu_lib, kz):
+    sc = kz.Scene(kz.scenes.cornell_box(48, 48, 2))
+    with pytest.raises(kz.abi.KzError) as e:
+        sc.render(device=0)
+    assert e.value.code == kz.abi.KZ_ERR_STATE
+    sc.upload(0)
+    sc.upload(0)                                                      # adding the same replica twice is a no-op
+    assert sc.devices() == [0]
+    with pytest.raises(kz.abi.KzError) as e:
+        sc.render_tiles([(0, 0, 32, 32)], device=gpu_lib.kz_device_count())      # not resident there
+    assert e.value.code == kz.abi.KZ_ERR_STATE and "not resident" in str(e.value)
+    sc.render()
+    a = sc.film()
+    sc.evict(0)
+    assert sc.devices() == []
+    with pytest.raises(kz.abi.KzError):
+        sc.film()
+    sc.upload(0)
+    sc.render()
+    assert np.array_equal(sc.film(), a)
+
+
+def test_state_budget_and_pass_options(gpu_lib, kz, O):
+    """KzRenderOpts v3: pass size, passes in flight and the state cap are per-call options; every schedule gives the film of
+    pass-at-a-time up to the order of the film additions, and the cap is respected."""
+    desc = kz.scenes.cornell_box(96, 80, 24, sampler="pmj02bn")
+    sc = kz.Scene(desc, device=0)
+    npx = 96 * 80
+    sc.render(pass_items=npx * 4, passes_in_flight=1)                 # 6 passes of 4 spp, one at a time
+    one_at_a_time = sc.film()
+    info = sc.last_pass_info()
+    assert (info["passes"], info["passesInFlight"], info["sppPerPass"], info["pixels"]) == (6, 1, 4, npx)
+    for _ in range(3):                                                # two in flight, repeated: an ordering bug would show as run-to-run differences
+        sc.render(pass_items=npx * 4, passes_in_flight=2)
+        assert np.array_equal(sc.film(), one_at_a_time)
+    assert sc.last_pass_info()["passesInFlight"] == 2
+    per_item = 8 * 16 + 16 + 12 + 20
+    sc.render(max_state_bytes=npx * 3 * per_item * 2)                 # room for two contexts of 3 spp
+    info = sc.last_pass_info()
+    assert info["sppPerPass"] == 3 and info["passes"] == 8 and info["stateBytes"] <= npx * 3 * per_item * 2 + (1 << 22)
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    sc.render(max_state_bytes=npx * per_item)                         # one context of one sample
+    assert sc.last_pass_info()["sppPerPass"] == 1 and sc.last_pass_info()["passesInFlight"] == 1
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    with pytest.raises(kz.abi.KzError) as e:
+        sc.render(max_state_bytes=1000)
+    assert e.value.code == kz.abi.KZ_ERR_OOM
+    sc.render(tune={"refill": 56, "postpone": 16, "batch": 64, "traceBlocksPerCU": 4, "shadeBlocksPerCU": 3, "ldsStack": 4})
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)     # knobs change the schedule, never the paths
+    sc.render(tune={"bvh2": 1})
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    ora = O.OracleScene(desc)
+    assert l2(sc.rgb(one_at_a_time), ora.rgb(ora.render(threads=0))) < L2_TOL
+
+
+def test_failed_calls_release_their_device_memory(gpu_lib, kz):
+    """A failure in the middle of a call (kz_debug_fail_alloc makes the nth device allocation fail) returns KZ_ERR_OOM and
+    leaves no device memory behind: hipMemGetInfo before == after."""
+    import torch
+    desc = kz.scenes.cornell_box(64, 64, 4)
+    sc = kz.Scene(desc, device=0)
+    sc.render()
+    good = sc.film()
+    o = np.zeros((1000, 3), np.float32)
+    d = np.tile(np.array([[0, 0, -1]], np.float32), (1000, 1))
+    sc.trace_rays(o, d, 1e-3, np.inf)
+    uv = np.zeros((16, 2), np.float32)
+    z3 = np.tile(np.array([[0, 0, 1]], np.float32), (16, 1))
+
+    def free_now():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    calls = {
+        "kz_trace_rays": (5, lambda: sc.trace_rays(o, d, 1e-3, np.inf)),
+        "kz_render_samples": (3, lambda: sc.render_samples(np.zeros((8, 2), np.int32), np.zeros(8, np.uint32))),
+        "kz_bsdf_query": (2, lambda: sc.bsdf_query(np.zeros(16, np.int32), z3, z3, np.zeros(16, np.float32), np.zeros((16, 3), np.float32), uv)),
+    }
+    for name, (n_allocs, call) in calls.items():
+        for nth in range(1, n_allocs + 1):
+            before = free_now()
+            gpu_lib.kz_debug_fail_alloc(nth)
+            with pytest.raises(kz.abi.KzError) as e:
+                call()
+            gpu_lib.kz_debug_fail_alloc(0)
+            assert e.value.code == kz.abi.KZ_ERR_OOM, name
+            assert free_now() == before, (name, nth)
+        call()                                                        # and the call works again afterwards
+    # a render whose state buffers fail half way: nothing half-allocated is used afterwards
+    big = kz.Scene(kz.scenes.cornell_box(64, 64, 4), device=0)
+    before = free_now()
+    for nth in (1, 2, 5, 9, 13):
+        gpu_lib.kz_debug_fail_alloc(nth)
+        with pytest.raises(kz.abi.KzError):
+            big.render()
+        gpu_lib.kz_debug_fail_alloc(0)
+    assert free_now() <= before
+    big.render()
+    assert np.array_equal(big.film(), good)
+    # a failed upload leaves no replica and no memory behind
+    sc2 = kz.Scene(desc)
+    before = free_now()
+    gpu_lib.kz_debug_fail_alloc(7)
+    with pytest.raises(kz.abi.KzError):
+        sc2.upload(0)
+    gpu_lib.kz_debug_fail_alloc(0)
+    assert sc2.devices() == [] and free_now() == before

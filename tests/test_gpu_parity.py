@@ -415,27 +415,24 @@ def test_randomized_scenes_match_oracle(gpu_lib, kz, O, seed):
     assert np.array_equal(sc.film(), film)
 
 
-def test_two_passes_in_flight_equal_one_at_a_time(gpu_lib, kz, O, monkeypatch):
-    """kz_render splits a call into passes (KZ_PASS_ITEMS) and keeps two of them in flight on two internal streams; the film is
-    accumulated in pass order either way, so both schedules and a single big pass... give the same bits as pass-at-a-time, and
-    the oracle's film within the bar."""
+def test_two_passes_in_flight_equal_one_at_a_time(gpu_lib, kz, O):
+    """kz_render splits a call into passes (KzRenderOpts.passItems) and keeps two of them in flight on two internal streams; the
+    film is accumulated in pass order either way, so both schedules give the same bits as pass-at-a-time, and the oracle's film
+    within the bar."""
     desc = kz.scenes.cornell_box(96, 80, 24, sampler="pmj02bn")
     sc = kz.Scene(desc, device=0)
-    monkeypatch.setenv("KZ_PASS_ITEMS", str(96 * 80 * 4))          # 6 passes of 4 spp
-    monkeypatch.setenv("KZ_DUAL_STREAM", "0")
-    sc.render()
+    items = 96 * 80 * 4                                             # 6 passes of 4 spp
+    sc.render(pass_items=items, passes_in_flight=1)
     one_at_a_time = sc.film()
-    monkeypatch.setenv("KZ_DUAL_STREAM", "1")
     for _ in range(3):                                               # repeated: an ordering bug would show as run-to-run differences
-        sc.render()
+        sc.render(pass_items=items)
         assert np.array_equal(sc.film(), one_at_a_time)
-    sc.render(0, 10)                                                 # 3 passes, the last one short; then accumulate the rest in two calls
-    sc.render(10, 24, accumulate=True)
+    sc.render(0, 10, pass_items=items)                               # 3 passes, the last one short; then accumulate the rest in two calls
+    sc.render(10, 24, accumulate=True, pass_items=items)
     ms = sc.last_kernel_ms()
     split = sc.film()
     assert ms > 0 and np.allclose(split, one_at_a_time, rtol=2e-5, atol=1e-5)          # other pass boundaries: another order of additions (H10)
     ora = O.OracleScene(desc)
     assert l2(sc.rgb(one_at_a_time), ora.rgb(ora.render(threads=0))) < L2_TOL
-    monkeypatch.delenv("KZ_PASS_ITEMS")
     sc.render()                                                      # one pass
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)

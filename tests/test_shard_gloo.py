@@ -1,7 +1,10 @@
-"""world_size-2 gloo test of the N>1 path on CPU: tile partition + film merge. The product kernels need a GPU,
-so each rank renders ITS tiles with the CPU oracle (test infrastructure) — what is under test is the host
-logic bench.py uses: make_tiles / tiles_for_rank cover the image exactly once, and summing the per-rank films
-(ImageBlock::put(ImageBlock&), block.cpp:87-96) reproduces the single-process film."""
+"""world_size-2 tests of the N>1 path (one process per GPU, CPU process group): kz_deal_tiles + the host gather that
+bench.py uses (shard.gather_films: gloo gather to rank 0, films summed in rank order = ImageBlock::put(ImageBlock&),
+block.cpp:87-96) reproduce the single-process film.
+
+* not gpu: each rank renders ITS tiles with the CPU oracle (test infrastructure) - what is under test is the host logic;
+* gpu: the same two ranks render through the HIP path (kz_render_tiles on GPU 0) and the merged film is compared with the
+  one-shot HIP film and with the oracle."""
 import os
 import socket
 import sys
@@ -10,6 +13,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, SPP = 160, 96, 4
 
 
 def _free_port():
@@ -20,23 +24,25 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, use_gpu):
     import importlib
-    import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
     kz = importlib.import_module("nano-kazen_amd")
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    desc = kz.scenes.cornell_box(96, 64, 4)
-    tiles = kz.shard.tiles_for_rank(kz.shard.make_tiles(96, 64, 32), rank, world)
-    ora = O.OracleScene(desc)
-    film = torch.from_numpy(ora.render(tiles=tiles, threads=1))
+    desc = kz.scenes.cornell_box(W, H, SPP)
+    tiles = kz.shard.deal_tiles(W, H, world, rank, 32)
+    if use_gpu:
+        sc = kz.Scene(desc, device=0)
+        film = sc.render_tiles(tiles, device=0)
+    else:
+        import oracle as O
+        film = O.OracleScene(desc).render(tiles=tiles, threads=1)
     dist.barrier()
-    dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+    merged = kz.shard.gather_films(film, rank, world)
     if rank == 0:
-        np.save(out, film.numpy())
+        np.save(out, merged)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,11 +50,25 @@ def _worker(rank, world, port, out):
 def test_two_rank_tile_sharding_matches_single_process(kz, O, tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "film.npy")
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, False), nprocs=2, join=True)
     merged = np.load(out)
-    whole = O.OracleScene(kz.scenes.cornell_box(96, 64, 4)).render(threads=1)
+    whole = O.OracleScene(kz.scenes.cornell_box(W, H, SPP)).render(threads=1)
     assert np.allclose(merged, whole, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_two_rank_hip_sharding_matches_one_shot(gpu_lib, kz, O, tmp_path):
+    """The N > 1 HIP path itself: two processes, each with its own replica on GPU 0, tiles dealt by kz_deal_tiles, host gather."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "film.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    merged = np.load(out)
+    desc = kz.scenes.cornell_box(W, H, SPP)
+    sc = kz.Scene(desc, device=0)
+    sc.render()
+    assert np.allclose(merged, sc.film(), rtol=1e-5, atol=1e-6)
+    ora = O.OracleScene(desc)
+    assert float(np.sqrt(np.mean((sc.rgb(merged) - ora.rgb(ora.render(threads=0))) ** 2))) < 1e-3
 
 
 @pytest.mark.parametrize("w,h,tile,world", [(1920, 1080, 128, 8), (96, 64, 32, 2), (77, 45, 32, 3)])
