@@ -584,7 +584,12 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #define KZ_EXTEND(KEEP, q, cptr, cimm, headp) do { if (traceKernel) KZ_TRACE((KEEP ? 1 : 0), q, cptr, cimm, headp); \
                                             else if (st) hipLaunchKernelGGL((kz_wf_extend<true, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); \
                                             else hipLaunchKernelGGL((kz_wf_extend<false, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); } while (0)
-    KZ_EXTEND(false, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2);
+    // camera rays: the wave-level packet traversal (kz_wf_trace_packet) unless the caller asks for the per-lane kernel
+    const bool packet = traceKernel && tune.wide && tune.packet != 1 && P.stackBound4 <= 128;
+    if (packet) {
+        if (st) hipLaunchKernelGGL(kz_wf_trace_packet<true>, gTrav, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8);
+        else hipLaunchKernelGGL(kz_wf_trace_packet<false>, gTrav, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8);
+    } else KZ_EXTEND(false, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2);
     if (P.anyInvisibleLight) {
         hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);
         KZ_EXTEND(true, (const uint32_t *)W.queue[2], (const uint32_t *)(W.counts + 0), 0u, W.counts + 3);

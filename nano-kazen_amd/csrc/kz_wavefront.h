@@ -608,6 +608,111 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     if (STATS) wfStatsFlush(W.stats, cn, 0);
 }
 
+// ---- packet traversal for coherent rays (the camera rays of a pass) ------------------------------------------------------
+// The items of a pass are ordered pixel-major (item = pixel * S + sample, pixels in 8x8 blocks), so the 64 camera rays of a wave
+// belong to one pixel (S >= 64) or to a few neighbouring ones: they walk the same nodes. The per-lane kernel above spends ~45 % of
+// its node step on per-lane child sorting and stack traffic and keeps 43 of 64 lanes busy on these rays
+// (profiles/r01j_big_passes); here the WAVE walks the tree once with ONE stack:
+//   * `cur` and the stack are wave-uniform (SGPRs; the stack is a VGPR written and read with v_writelane / v_readlane, one entry
+//     per lane position: 128 entries in two registers, enough for the builder's worst case or the launch falls back to kz_wf_trace);
+//   * every lane tests the node's four boxes against ITS ray and tmax (node4Keys, unchanged); the v_cmp results are the
+//     wave's hit masks; a child is visited if ANY lane hit it, in the front-to-back order of the first lane that hit anything;
+//   * at a leaf every lane runs the same Moeller-Trumbore test (triTest) and keeps its own closest hit.
+// Every lane sees a superset of the nodes its own traversal would visit and the boxes are conservative, so each lane's closest
+// hit (t, u, v, triangle; ties to the lower triangle id) is the one kz_wf_trace finds: the films stay bit-identical.
+// v_writelane_b32: one lane of a VGPR takes a wave-uniform value (this clang has a builtin for v_readlane only). On gfx9 the
+// instruction may read one SGPR besides M0, so the lane select travels in M0 (saved and restored around it).
+__device__ __forceinline__ void kzWriteLane(uint32_t &reg, uint32_t value, int laneSel) {
+    uint32_t keep;                                   // M0 is reserved by the compiler: put it back
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(reg), "=&s"(keep) : "s"(value), "s"(laneSel));
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace_packet(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
+                                                        const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, int batchPackets) {
+    const uint32_t count = countPtr ? *countPtr : countImm;
+    const uint32_t nPackets = (count + 63u) / 64u;
+    const int lane = threadIdx.x & 63;
+    const uint32_t root = P.rootRef4;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    uint32_t pNext = 0, pEnd = 0;
+    for (;;) {
+        if (pNext >= pEnd) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(head, (uint32_t)batchPackets);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= nPackets) break;
+            pNext = b; pEnd = min(b + (uint32_t)batchPackets, nPackets);
+        }
+        const uint32_t qi = pNext * 64u + (uint32_t)lane;
+        ++pNext;
+        const bool have = qi < count;
+        const uint32_t slot = have ? (queue ? queue[qi] : qi) : 0u;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
+        if (have) { a = W.rayA[slot]; b = W.rayB[slot]; }
+        const V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
+        const float tmin = a.w;
+        // a lane without a ray, or with a ray that can hit nothing (non-finite, see kz_wf_trace), carries tmax = -inf: it fails every box and triangle test
+        const bool live = have && root != 0xFFFFFFFFu && rayIsFinite(o, d);
+        float tmax = live ? b.w : -KZ_INF;
+        const float rx = 1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
+        const float ry = 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
+        const float rz = 1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
+        bool found = false; float bt = KZ_INF, bu = 0.f, bv = 0.f; uint32_t btri = 0, bgid = 0;
+        if (STATS && have) cn.rays++;
+        if (__ballot(live) != 0ull) {
+            uint32_t cur = root;                       // wave-uniform
+            int sp = 0;                                // wave-uniform
+            uint32_t stk0 = 0, stk1 = 0;               // the shared stack: entry i lives in lane i of stk0 (i < 64) or lane i - 64 of stk1
+            for (;;) {
+                if (!(cur & 0x80000000u)) {
+                    uint32_t key[4]; uint4 refs;
+                    node4Keys(T, cur, o, rx, ry, rz, tmin, tmax, key, refs);
+                    if (STATS && live) cn.nodes++;
+                    const unsigned long long m0 = __ballot(key[0] != 0xFFFFFFFFu), m1 = __ballot(key[1] != 0xFFFFFFFFu),
+                                             m2 = __ballot(key[2] != 0xFFFFFFFFu), m3 = __ballot(key[3] != 0xFFFFFFFFu);
+                    const unsigned long long any = m0 | m1 | m2 | m3;
+                    bool descended = false;
+                    if (any != 0ull) {
+                        // order of the first lane that hit anything; a child only other lanes hit sorts behind that lane's own hits
+                        const int rep = __ffsll((long long)any) - 1;
+                        uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key[0], rep), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key[1], rep),
+                                 k2 = (uint32_t)__builtin_amdgcn_readlane((int)key[2], rep), k3 = (uint32_t)__builtin_amdgcn_readlane((int)key[3], rep);
+                        k0 = m0 ? min(k0, 0xFFFFFFF8u) : 0xFFFFFFFFu; k1 = m1 ? min(k1, 0xFFFFFFF9u) : 0xFFFFFFFFu;
+                        k2 = m2 ? min(k2, 0xFFFFFFFAu) : 0xFFFFFFFFu; k3 = m3 ? min(k3, 0xFFFFFFFBu) : 0xFFFFFFFFu;
+                        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)refs.x), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)refs.y),
+                                       r2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)refs.z), r3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)refs.w);
+                        // 5-comparator sorting network on (key, ref) pairs, all scalar
+                        uint32_t ka = k0, kb = k1, kc = k2, kd = k3, ra = r0, rb = r1, rc = r2, rd = r3;
+#define KZ_CSWAP(x, y, rx_, ry_) do { const bool s_ = y < x; const uint32_t tx_ = s_ ? y : x, ty_ = s_ ? x : y, tr_ = s_ ? ry_ : rx_, ts_ = s_ ? rx_ : ry_; x = tx_; y = ty_; rx_ = tr_; ry_ = ts_; } while (0)
+                        KZ_CSWAP(ka, kb, ra, rb); KZ_CSWAP(kc, kd, rc, rd); KZ_CSWAP(ka, kc, ra, rc); KZ_CSWAP(kb, kd, rb, rd); KZ_CSWAP(kb, kc, rb, rc);
+#undef KZ_CSWAP
+                        // push far to near, descend into the nearest
+                        if (kd != 0xFFFFFFFFu) { if (sp < 64) kzWriteLane(stk0, rd, sp); else kzWriteLane(stk1, rd, sp - 64); ++sp; }
+                        if (kc != 0xFFFFFFFFu) { if (sp < 64) kzWriteLane(stk0, rc, sp); else kzWriteLane(stk1, rc, sp - 64); ++sp; }
+                        if (kb != 0xFFFFFFFFu) { if (sp < 64) kzWriteLane(stk0, rb, sp); else kzWriteLane(stk1, rb, sp - 64); ++sp; }
+                        cur = ra; descended = true;
+                    }
+                    if (descended) continue;
+                } else {
+                    const uint32_t start = (cur & 0x7fffffffu) >> 3, cnt = (cur & 7u) + 1;
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        float t, u, v; uint32_t g;
+                        if (STATS && live) cn.tris++;
+                        if (!triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, g)) continue;
+                        if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; btri = start + i; bgid = g; tmax = t; }
+                    }
+                }
+                if (sp == 0) break;
+                --sp;
+                cur = (uint32_t)(sp < 64 ? __builtin_amdgcn_readlane((int)stk0, sp) : __builtin_amdgcn_readlane((int)stk1, sp - 64));
+            }
+        }
+        if (have) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+    }
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+}
+
 // ---- final: the ray after the last bounce contributes only the background on a miss (integrator.cpp:315-318) ------------
 __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_final(KzParams P, KzWf W, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ countPtr) {
     const uint32_t count = *countPtr;

@@ -39,7 +39,7 @@ def test_c2_full_spp_matches_oracle(gpu_lib, kz, O):
 
 def test_c3_full_size_properties_and_crop(gpu_lib, kz, O):
     """configs[2]: hero scene at full detail, full kiss BSDF + 3 lights, 1920x1080, 256 spp, all of it rendered."""
-    desc = kz.scenes.hero_scene(1920, 1080, 256)
+    desc = kz.scenes.hero_scene(1920, 1080, 256, detail=2.0)
     sc = kz.Scene(desc, device=0)
     assert sc.bvh_info()["nTris"] > 500000
     sc.set_stats(True)
@@ -176,6 +176,11 @@ def test_state_budget_and_pass_options(gpu_lib, kz, O):
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)     # knobs change the schedule, never the paths
     sc.render(tune={"bvh2": 1})
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    # camera rays: wave-level packet traversal (default) and the per-lane kernel find the same hits, bit for bit
+    sc.render(pass_items=npx * 4, tune={"packetPrimary": 1})
+    assert np.array_equal(sc.film(), one_at_a_time)
+    sc.render(pass_items=npx * 4, tune={"packetPrimary": 2})
+    assert np.array_equal(sc.film(), one_at_a_time)
     ora = O.OracleScene(desc)
     assert l2(sc.rgb(one_at_a_time), ora.rgb(ora.render(threads=0))) < L2_TOL
 
