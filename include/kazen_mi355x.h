@@ -395,6 +395,8 @@ void kz_debug_fail_alloc(int nth);
 const char *kz_last_error(void);
 int kz_abi_version(void);
 int kz_device_count(void);
+/* hipMemGetInfo of `device` (what the default state budget of kz_render is derived from). */
+int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes);
 
 #ifdef __cplusplus
 }

@@ -419,6 +419,17 @@ int kz_device_count(void) {
     return n;
 }
 
+int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes) {
+    int n = kz_device_count();
+    if (device < 0 || device >= n) return kz_fail(n ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (freeBytes) *freeBytes = f;
+    if (totalBytes) *totalBytes = t;
+    return KZ_OK;
+}
+
 int kz_scene_upload(KzScene *scene, int device) {
     if (!scene) return kz_fail(KZ_ERR_INVALID_ARG, "null scene");
     int n = 0;
@@ -660,16 +671,18 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     }
     size_t wantItems = opts->passItems ? (size_t)opts->passItems : (eo.passItems ? (size_t)eo.passItems : (size_t)1 << 27);
     wantItems = std::max<size_t>(wantItems, ds->nPix);                   // at least one sample of every pixel per pass
-    uint32_t S = (uint32_t)std::min<size_t>(wantItems / std::max<uint32_t>(1, ds->nPix), s1 - s0);
-    uint32_t nPasses = (s1 - s0 + S - 1) / S;
-    if (nPasses < 2) nCtx = 1;
-    while ((size_t)ds->nPix * S * perItem * nCtx > limit) {
-        if (S > 1) S = std::max<uint32_t>(1, std::min<uint32_t>(S - 1, (uint32_t)(limit / ((size_t)ds->nPix * perItem * nCtx))));
-        else if (nCtx > 1) nCtx = 1;
-        else return kz_fail(KZ_ERR_OOM, "one sample of the %u pixels of this tile set needs %zu bytes of path state, the limit is %zu: render fewer tiles per call",
-                            ds->nPix, (size_t)ds->nPix * perItem, limit);
-        nPasses = (s1 - s0 + S - 1) / S;
+    const uint32_t nSamples = s1 - s0;
+    uint32_t S = (uint32_t)std::min<size_t>(wantItems / std::max<uint32_t>(1, ds->nPix), nSamples);
+    auto fits = [&](int ctx) { return (uint32_t)std::min<size_t>(limit / ((size_t)ds->nPix * perItem * (size_t)ctx), 0xFFFFFFFFu); };   // largest S under the limit
+    if (S >= nSamples && fits(1) >= S) nCtx = 1;                          // the whole call is one pass
+    else if (nCtx == 2 && fits(2) >= 1) { S = std::min(S, fits(2)); if ((nSamples + S - 1) / S < 2) nCtx = 1; }
+    else {
+        nCtx = 1;
+        if (fits(1) < 1) return kz_fail(KZ_ERR_OOM, "one sample of the %u pixels of this tile set needs %zu bytes of path state, the limit is %zu: render fewer tiles per call",
+                                        ds->nPix, (size_t)ds->nPix * perItem, limit);
+        S = std::min(S, fits(1));
     }
+    const uint32_t nPasses = (nSamples + S - 1) / S;
     const size_t need = (size_t)ds->nPix * S;
     if (need >= (1ull << 32)) return kz_fail(KZ_ERR_UNSUPPORTED, "pass of %zu items (limit 2^32)", need);
     // Two passes in flight on two internal streams when the call has at least two: the persistent traversal kernels of one pass
