@@ -100,7 +100,7 @@ class KzTile(C.Structure):
 class KzTuning(C.Structure):
     _fields_ = [("refill", C.c_int32), ("postpone", C.c_int32), ("batch", C.c_int32), ("traceBlocksPerCU", C.c_int32),
                 ("shadeBlocksPerCU", C.c_int32), ("ldsStack", C.c_int32), ("bvh2", C.c_int32), ("packetPrimary", C.c_int32),
-                ("reserved", C.c_int32 * 8)]
+                ("keyStack", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class KzRenderOpts(C.Structure):
@@ -146,7 +146,8 @@ EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene
            "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
+# KZ_LIB_PATH: a development build of the library (scripts/build_variant.sh) instead of the in-tree one; probes only
+LIB_PATH = os.environ.get("KZ_LIB_PATH") or os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
 _lib = None
 
 

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -335,7 +336,7 @@ static const EnvOverride &envOverride() {
         auto I = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
         o.tune.refill = I("KZ_TUNE_REFILL", 0); o.tune.postpone = I("KZ_TUNE_POSTPONE", 0); o.tune.batch = I("KZ_TUNE_BATCH", 0);
         o.tune.traceBlocksPerCU = I("KZ_TUNE_TRAV_BLOCKS", 0); o.tune.shadeBlocksPerCU = I("KZ_TUNE_SHADE_BLOCKS", 0);
-        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0);
+        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0);
         if (const char *e = std::getenv("KZ_PASS_ITEMS")) { long long v = std::atoll(e); if (v >= 1024) o.passItems = (uint64_t)v; }
         if (const char *e = std::getenv("KZ_DUAL_STREAM")) o.passesInFlight = std::atoi(e) ? 2 : 1;
         o.pipeline = I("KZ_PIPELINE", 0); o.traceKernel = I("KZ_TRACE_KERNEL", 1); o.mixed = I("KZ_TUNE_MIXED", 0);
@@ -350,7 +351,7 @@ static KzTune resolveTune(const KzTuning &t) {
     r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
     r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 6));
     r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
-    r.packet = pick(t.packetPrimary, e.packetPrimary, 0);
+    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0);
     r.ovf = nullptr; r.ovfStride = 0;
     return r;
 }
@@ -401,8 +402,8 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     ds->filmPixels = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border);
     KZ_ALLOC(&ds->film, ds->filmPixels * sizeof(float4));
     HIP_TRY(hipMemset(ds->film, 0, ds->filmPixels * sizeof(float4)));
-    KZ_ALLOC(&ds->stats, 8 * sizeof(unsigned long long));
-    HIP_TRY(hipMemset(ds->stats, 0, 8 * sizeof(unsigned long long)));
+    KZ_ALLOC(&ds->stats, 24 * sizeof(unsigned long long));             // 8 counters of KzStats + 16 lane statistics of the -DKZ_LANESTAT development build
+    HIP_TRY(hipMemset(ds->stats, 0, 24 * sizeof(unsigned long long)));
     { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, ds->device)); ds->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; ds->totalMem = prop.totalGlobalMem; }
     HIP_TRY(hipFuncSetAttribute((const void *)kz_film_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIP_TRY(hipDeviceSynchronize());
@@ -566,9 +567,12 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
     tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
+    // closest-hit rays on the BVH4 carry the entry distance with every stack entry (second column block in LDS, odd rows of the overflow area)
+    const bool keys = tune.wide && tune.keyStack != 1;
     const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);      // + one scratch slot per lane (branch-free pushes)
+    const size_t traceLdsK = keys ? 2 * traceLds : traceLds;
     {
-        const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack);
+        const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack) * (keys ? 2 : 1);
         if (needOvf > c.ovfCap) {
             HIP_TRY(hipStreamSynchronize(stream));
             if (c.ovf) (void)hipFree(c.ovf);
@@ -587,7 +591,10 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
     const int traceKernel = envOverride().traceKernel, mixed = envOverride().mixed;
 #define KZ_TRACE2(MODE, q, cptr, cimm, headp, qb, cb) do { \
-        if (tune.wide) { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
+        if (tune.wide && keys && (MODE == 0 || MODE == 1)) { \
+                         if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true, true>), gTrav, blk, traceLdsK, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
+                         else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true, true>), gTrav, blk, traceLdsK, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } \
+        else if (tune.wide) { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
                          else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } \
         else { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
                else hipLaunchKernelGGL((kz_wf_trace<MODE, false, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } } while (0)
@@ -962,6 +969,19 @@ int kz_get_stats(KzScene *scene, KzStats *out, int reset) {
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, ds->stats, sizeof h, hipMemcpyDeviceToHost));
     out->samples = h[0]; out->rays = h[1]; out->nodeVisits = h[2]; out->triTests = h[3]; out->shadedHits = h[4]; out->lightSamples = h[5]; out->droppedSamples = h[6];
+#ifdef KZ_LANESTAT
+    {
+        unsigned long long ls[16];
+        HIP_TRY(hipMemcpy(ls, ds->stats + 8, sizeof ls, hipMemcpyDeviceToHost));
+        for (int m = 0; m < 2; ++m) {
+            const unsigned long long *a = ls + 8 * m;
+            std::fprintf(stderr, "lanestat %s: node iters %llu  active/iter %.2f  inner/iter %.2f | leaf phases %llu  lanes/phase %.2f  tri iters/phase %.2f | refills %llu  lanes/refill %.2f\n",
+                         m ? "shadow " : "closest", a[0], a[0] ? (double)a[1] / a[0] : 0.0, a[0] ? (double)a[2] / a[0] : 0.0, a[3], a[3] ? (double)a[4] / a[3] : 0.0,
+                         a[3] ? (double)a[7] / a[3] : 0.0, a[5], a[5] ? (double)a[6] / a[5] : 0.0);
+        }
+        if (reset) HIP_TRY(hipMemset(ds->stats + 8, 0, sizeof ls));
+    }
+#endif
     if (reset) HIP_TRY(hipMemset(ds->stats, 0, sizeof h));
     return KZ_OK;
 }

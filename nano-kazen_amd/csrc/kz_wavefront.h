@@ -409,9 +409,9 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // the bounce before: both only depend on the same shade stage, and one launch has one tail instead of two.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment; such
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
-struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet; uint32_t *ovf; uint32_t ovfStride; };
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack; uint32_t *ovf; uint32_t ovfStride; };
 
-template <int MODE, bool STATS, bool WIDE>
+template <int MODE, bool STATS, bool WIDE, bool KEYS = false>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune,
                                                         const uint32_t *__restrict__ queueB, const uint32_t *__restrict__ countPtrB) {
@@ -424,9 +424,16 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     const int LS = tune.ldsStack;
     uint32_t *ovf = tune.ovf + (size_t)blockIdx.x * KZ_BLOCK + threadIdx.x;
     const size_t ovfStride = tune.ovfStride;
-    auto push = [&](int &sp_, uint32_t v) { if (sp_ < LS) stk[sp_ * KZ_BLOCK] = v; else ovf[(size_t)(sp_ - LS) * ovfStride] = v; ++sp_; };
-    // (an LDS read of the entry or of the scratch slot, replaced by the global entry in the rare deep case: no generic-pointer load)
-    auto pop = [&](int &sp_) -> uint32_t { --sp_; uint32_t v = stk[min(sp_, LS) * KZ_BLOCK]; if (sp_ >= LS) v = ovf[(size_t)(sp_ - LS) * ovfStride]; return v; };
+    // KEYS (closest-hit rays on the BVH4): every stack entry carries the entry distance of its box (the sortable key of node4Keys), in a
+    // second LDS column block / in the odd rows of the overflow area. An entry whose box starts behind the closest hit found so far
+    // is dropped at pop time for the price of two LDS reads and a compare instead of a full node step on four boxes that all miss.
+    const int kOff = (LS + 1) * KZ_BLOCK;              // key column block behind the ref column block (KEYS only)
+    const size_t ovfW = KEYS ? 2 : 1;
+    auto push = [&](int &sp_, uint32_t v, uint32_t k) {
+        if (sp_ < LS) { stk[sp_ * KZ_BLOCK] = v; if (KEYS) stk[kOff + sp_ * KZ_BLOCK] = k; }
+        else { ovf[(size_t)(sp_ - LS) * ovfW * ovfStride] = v; if (KEYS) ovf[((size_t)(sp_ - LS) * 2 + 1) * ovfStride] = k; }
+        ++sp_;
+    };
     const uint32_t root = WIDE ? P.rootRef4 : P.rootRef;
     const float eps = P.traceBias;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
@@ -439,6 +446,23 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     uint32_t cur = 0, slot = 0; int sp = 0;
     bool found = false; float bt = 0.f, bu = 0.f, bv = 0.f; uint32_t btri = 0, bgid = 0;
 
+    // next stack entry that can still matter -> cur; false when the stack is empty
+    auto popNext = [&]() -> bool {
+        while (sp > 0) {
+            --sp;
+            // (LDS reads of the entry or of the scratch row, replaced by the global entry in the rare deep case: a select between an LDS and a
+            // global address would become a generic-pointer load)
+            const int row = min(sp, LS) * KZ_BLOCK;
+            uint32_t v = stk[row], k = KEYS ? stk[kOff + row] : 0u;
+            if (sp >= LS) { v = ovf[(size_t)(sp - LS) * ovfW * ovfStride]; if (KEYS) k = ovf[((size_t)(sp - LS) * 2 + 1) * ovfStride]; }
+            if (!KEYS || (k & ~3u) <= __float_as_uint(tmax)) { cur = v; return true; }      // key = bits of max(tnear, tmin), low two bits = slot
+        }
+        return false;
+    };
+#ifdef KZ_LANESTAT
+    // development build only (-DKZ_LANESTAT): where the lanes of the while-while loop are, summed per wave (wave-uniform counts)
+    unsigned long long lsNodeIters = 0, lsActiveAtNode = 0, lsInnerAtNode = 0, lsLeafPhases = 0, lsLeafLanes = 0, lsRefills = 0, lsRefillLanes = 0, lsTriIters = 0;
+#endif
     auto addPending = [&]() { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; };
     // the lane's stack ran empty: publish the result (or, for a literal shadow lane, decide / walk through the light)
     auto finish = [&]() {
@@ -473,6 +497,9 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
             }
             if (!exhausted) {
                 const uint32_t take = min((uint32_t)(64 - nAct), poolEnd - poolNext);
+#ifdef KZ_LANESTAT
+                lsRefills++; lsRefillLanes += take;
+#endif
                 const uint32_t rank = (uint32_t)__popcll(~act & ltMask);
                 if (!active && rank < take) {
                     const uint32_t qi = poolNext + rank;
@@ -513,6 +540,9 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
             const unsigned long long im = __ballot(inner);
             if (im == 0) break;
             if (__popcll(im) < tune.postpone && __ballot(active && (cur & 0x80000000u)) != 0) break;
+#ifdef KZ_LANESTAT
+            lsNodeIters++; lsInnerAtNode += __popcll(im); lsActiveAtNode += __popcll(__ballot(active));
+#endif
             if (inner) {
                 bool empty = false;
                 if (STATS) cn.nodes++;
@@ -545,16 +575,16 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                     }
                     const int c1 = (int)p0, c2 = c1 + (int)p1, c3 = c2 + (int)p2, np = c3 + (int)p3;
                     if (sp + 3 <= LS) {                                              // common case: everything stays in LDS
-                        if (!(MODE == 2 && KZ_SHADOW_SLOT_ORDER)) stk[(p0 ? sp : LS) * KZ_BLOCK] = refs.x;
-                        stk[(p1 ? sp + c1 : LS) * KZ_BLOCK] = refs.y;
-                        stk[(p2 ? sp + c2 : LS) * KZ_BLOCK] = refs.z;
-                        stk[(p3 ? sp + c3 : LS) * KZ_BLOCK] = refs.w;
+                        const int o0 = (p0 ? sp : LS) * KZ_BLOCK, o1 = (p1 ? sp + c1 : LS) * KZ_BLOCK, o2 = (p2 ? sp + c2 : LS) * KZ_BLOCK, o3 = (p3 ? sp + c3 : LS) * KZ_BLOCK;
+                        if (!(MODE == 2 && KZ_SHADOW_SLOT_ORDER)) { stk[o0] = refs.x; if (KEYS) stk[kOff + o0] = key[0]; }
+                        stk[o1] = refs.y; stk[o2] = refs.z; stk[o3] = refs.w;
+                        if (KEYS) { stk[kOff + o1] = key[1]; stk[kOff + o2] = key[2]; stk[kOff + o3] = key[3]; }
                         sp += np;
                     } else {
-                        if (p0) push(sp, refs.x);
-                        if (p1) push(sp, refs.y);
-                        if (p2) push(sp, refs.z);
-                        if (p3) push(sp, refs.w);
+                        if (p0) push(sp, refs.x, key[0]);
+                        if (p1) push(sp, refs.y, key[1]);
+                        if (p2) push(sp, refs.z, key[2]);
+                        if (p3) push(sp, refs.w, key[3]);
                     }
                     if (any) cur = nxt; else empty = true;
                 } else if (WIDE) {
@@ -566,30 +596,34 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                     const int h1 = nt.k1 != 0xFFFFFFFFu, h2 = nt.k2 != 0xFFFFFFFFu, h3 = nt.k3 != 0xFFFFFFFFu;
                     const int np = h1 + h2 + h3;
                     if (sp + 3 <= LS) {                                              // common case: everything stays in LDS
-                        stk[(h1 ? sp + np - 1 : LS) * KZ_BLOCK] = c1;
-                        stk[(h2 ? sp + np - 2 : LS) * KZ_BLOCK] = c2;
-                        stk[(h3 ? sp : LS) * KZ_BLOCK] = c3;
+                        const int o1 = (h1 ? sp + np - 1 : LS) * KZ_BLOCK, o2 = (h2 ? sp + np - 2 : LS) * KZ_BLOCK, o3 = (h3 ? sp : LS) * KZ_BLOCK;
+                        stk[o1] = c1; stk[o2] = c2; stk[o3] = c3;
+                        if (KEYS) { stk[kOff + o1] = nt.k1; stk[kOff + o2] = nt.k2; stk[kOff + o3] = nt.k3; }
                         sp += np;
                     } else {
-                        if (h3) push(sp, c3);
-                        if (h2) push(sp, c2);
-                        if (h1) push(sp, c1);
+                        if (h3) push(sp, c3, nt.k3);
+                        if (h2) push(sp, c2, nt.k2);
+                        if (h1) push(sp, c1, nt.k1);
                     }
                     if (nt.k0 != 0xFFFFFFFFu) cur = c0; else empty = true;
                 } else {
                     const NodeTest nt = nodeTest(T, cur, o, rx, ry, rz, tmin, tmax);
                     if (nt.h0 && nt.h1) {
                         const bool swap = nt.n1 < nt.n0;
-                        push(sp, swap ? nt.c0 : nt.c1);
+                        push(sp, swap ? nt.c0 : nt.c1, 0u);
                         cur = swap ? nt.c1 : nt.c0;
                     } else if (nt.h0) cur = nt.c0;
                     else if (nt.h1) cur = nt.c1;
                     else empty = true;
                 }
-                if (empty) { if (sp > 0) cur = pop(sp); else finish(); }
+                if (empty) { if (!popNext()) finish(); }
             }
         }
         // ---- leaf phase
+#ifdef KZ_LANESTAT
+        { const unsigned long long lm = __ballot(active && (cur & 0x80000000u)); if (lm) { lsLeafPhases++; lsLeafLanes += __popcll(lm);
+          uint32_t mc = (active && (cur & 0x80000000u)) ? (cur & 7u) + 1 : 0; for (int off = 32; off > 0; off >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, off, 64)); lsTriIters += mc; } }
+#endif
         if (active && (cur & 0x80000000u)) {
             const uint32_t start = (cur & 0x7fffffffu) >> 3, cnt = (cur & 7u) + 1;
             bool occluded = false;
@@ -601,11 +635,17 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; btri = start + i; bgid = g; tmax = t; }
             }
             if (occluded) active = false;
-            else if (sp > 0) cur = pop(sp);
-            else finish();
+            else if (!popNext()) finish();
         }
     }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
+#ifdef KZ_LANESTAT
+    if (lane == 0) {
+        unsigned long long *ls = W.stats + 8 + (MODE == 2 ? 8 : 0);
+        atomicAdd(ls + 0, lsNodeIters); atomicAdd(ls + 1, lsActiveAtNode); atomicAdd(ls + 2, lsInnerAtNode); atomicAdd(ls + 3, lsLeafPhases);
+        atomicAdd(ls + 4, lsLeafLanes); atomicAdd(ls + 5, lsRefills); atomicAdd(ls + 6, lsRefillLanes); atomicAdd(ls + 7, lsTriIters);
+    }
+#endif
 }
 
 // ---- packet traversal for coherent rays (the camera rays of a pass) ------------------------------------------------------

@@ -1,0 +1,94 @@
+"""Development probes for the GPU box (run through gpurun); not part of the product or of the test suite.
+
+    python scripts/probe.py configs [c5]                 full renders of the BASELINE.json configs (time, Msamples/s, L2 vs oracle for C1/C2)
+    python scripts/probe.py stages [--tune k=v,...] [--opts passes_in_flight=1,...] [--scene c4|c3|c1|c2] [--spp N]
+                                                         per-stage device times of one pass + Msamples/s of a full call
+    python scripts/probe.py sweep --knob refill --values 24,32,40,48,56 [--scene c4]
+                                                         the same for a list of values of one KzTuning field (or pass_items / passes_in_flight)
+    KZ_LIB_PATH=nano-kazen_amd/csrc/variants/lanestat/libkazen_mi355x.so python scripts/probe.py lanestat
+                                                         where the lanes of the traversal loop are (needs scripts/build_variant.sh lanestat -DKZ_LANESTAT)
+"""
+import argparse, importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+kz = importlib.import_module("nano-kazen_amd")
+S = kz.scenes
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def scene(name):
+    return {"c1": lambda: S.cornell_box(256, 256, 16), "c2": lambda: S.sphere_env(512, 512, 64), "c3": lambda: S.hero_scene(1920, 1080, 256, detail=2.0),
+            "c4": lambda: S.random_triangles(1000000, 1920, 1080, 1024), "c5": lambda: S.random_triangles(1000000, 3840, 2160, 4096)}[name]()
+
+
+def kv(s, cast=int):
+    return {k: cast(v) for k, v in (p.split("=") for p in s.split(",") if p)} if s else {}
+
+
+def timed(sc, s0, s1, **kw):
+    sc.render(s0, s1, **kw); sc.sync()
+    t0 = time.perf_counter(); sc.render(s0, s1, **kw); sc.sync()
+    return time.perf_counter() - t0
+
+
+def cmd_configs(a):
+    out = {}
+    for name in ["c1", "c2", "c3", "c4"] + (["c5"] if a.c5 else []):
+        desc = scene(name)
+        t0 = time.time(); sc = kz.Scene(desc); tb = time.time() - t0
+        sc.upload(0)
+        dt = timed(sc, 0, 0)
+        n = sc.width * sc.height * sc.sample_count
+        rgb = sc.rgb()
+        out[name] = {"width": sc.width, "height": sc.height, "spp": sc.sample_count, "tris": desc.n_tris(), "render_s": round(dt, 4), "Msamples_per_s": round(n / dt / 1e6, 1),
+                     "scene_build_s": round(tb, 2), "image_mean": round(float(rgb.mean()), 5), "passes": sc.last_pass_info()}
+        if name in ("c1", "c2"):
+            import oracle as O
+            o = O.OracleScene(desc); t0 = time.time(); c = o.rgb(o.render(threads=0)); tc = time.time() - t0
+            out[name].update(oracle_s=round(tc, 2), oracle_Msamples_per_s=round(n / tc / 1e6, 3), l2_vs_oracle=float(np.sqrt(np.mean((rgb - c) ** 2))))
+        print(name, out[name], flush=True)
+        sc.close()
+    json.dump(out, open(os.path.join(OUT, "configs.json"), "w"), indent=1)
+
+
+def one(sc, spp, tune, opts):
+    info = None
+    dt = timed(sc, 0, spp, tune=tune, **opts)
+    info = sc.last_pass_info()
+    sc.render(0, info["sppPerPass"], tune=tune, **dict(opts, passes_in_flight=1)); sc.sync()
+    st = sc.last_stage_ms()
+    return {"Msamples_per_s": round(sc.width * sc.height * spp / dt / 1e6, 1), "call_ms": round(dt * 1e3, 2), "stages_one_pass_alone": st, "passes": info["passes"], "spp_per_pass": info["sppPerPass"]}
+
+
+def cmd_stages(a):
+    sc = kz.Scene(scene(a.scene), device=0)
+    spp = a.spp or min(sc.sample_count, 128)
+    print(json.dumps({"scene": a.scene, "tune": kv(a.tune), "opts": kv(a.opts), **one(sc, spp, kv(a.tune), kv(a.opts))}), flush=True)
+
+
+def cmd_sweep(a):
+    sc = kz.Scene(scene(a.scene), device=0)
+    spp = a.spp or min(sc.sample_count, 128)
+    for v in a.values.split(","):
+        tune, opts = kv(a.tune), kv(a.opts)
+        (opts if a.knob in ("pass_items", "passes_in_flight", "max_state_bytes") else tune)[a.knob] = int(v)
+        print(json.dumps({"knob": a.knob, "value": int(v), **one(sc, spp, tune, opts)}), flush=True)
+
+
+def cmd_lanestat(a):
+    sc = kz.Scene(scene(a.scene), device=0)
+    sc.set_stats(True)
+    spp = a.spp or 16
+    sc.render(0, spp, passes_in_flight=1, tune=kv(a.tune)); sc.sync()
+    print(json.dumps(sc.stats(reset=True)), flush=True)          # the library prints the lane statistics on stderr
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat"])
+ap.add_argument("c5", nargs="?")
+ap.add_argument("--scene", default="c4"); ap.add_argument("--spp", type=int, default=0)
+ap.add_argument("--tune", default=""); ap.add_argument("--opts", default="")
+ap.add_argument("--knob", default="refill"); ap.add_argument("--values", default="")
+a = ap.parse_args()
+{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat}[a.cmd](a)
