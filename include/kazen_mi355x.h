@@ -239,7 +239,8 @@ typedef struct KzTuning {
     int32_t ldsStack;           /* per-lane traversal stack entries kept in LDS before the global overflow (default 16) */
     int32_t bvh2;               /* 1 = traverse the BVH2 instead of the quantised BVH4 (default 0)                    */
     int32_t packetPrimary;      /* primary rays: 0 = default (shared-stack packet traversal), 1 = per-lane, 2 = packet */
-    int32_t keyStack;           /* closest-hit stack entries carry their box entry distance and are culled at pop time: 0 = default (on), 1 = off, 2 = on */
+    int32_t keyStack;           /* stack entries carry their box entry distance and are culled at pop time: 0 = default (packet kernel only),
+                                   1 = off, 2 = also in the per-lane closest-hit kernel (measured slower on C4) */
     int32_t reserved[7];
 } KzTuning;
 

@@ -568,7 +568,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
     tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
     // closest-hit rays on the BVH4 carry the entry distance with every stack entry (second column block in LDS, odd rows of the overflow area)
-    const bool keys = tune.wide && tune.keyStack != 1;
+    const bool keys = tune.wide && tune.keyStack == 2;      // per-lane kernel: measured slower on C4 (r02c), on request only
     const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);      // + one scratch slot per lane (branch-free pushes)
     const size_t traceLdsK = keys ? 2 * traceLds : traceLds;
     {
@@ -605,8 +605,10 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     // camera rays: the wave-level packet traversal (kz_wf_trace_packet) unless the caller asks for the per-lane kernel
     const bool packet = traceKernel && tune.wide && tune.packet != 1 && P.stackBound4 <= 128;
     if (packet) {
-        if (st) hipLaunchKernelGGL(kz_wf_trace_packet<true>, gTrav, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8);
-        else hipLaunchKernelGGL(kz_wf_trace_packet<false>, gTrav, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8);
+#define KZ_PACKET(ST, KY) hipLaunchKernelGGL((kz_wf_trace_packet<ST, KY>), gTrav, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8)
+        if (tune.keyStack != 1) { if (st) KZ_PACKET(true, true); else KZ_PACKET(false, true); }
+        else { if (st) KZ_PACKET(true, false); else KZ_PACKET(false, false); }
+#undef KZ_PACKET
     } else KZ_EXTEND(false, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2);
     if (P.anyInvisibleLight) {
         hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);

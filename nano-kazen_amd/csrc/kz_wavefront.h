@@ -667,9 +667,15 @@ __device__ __forceinline__ void kzWriteLane(uint32_t &reg, uint32_t value, int l
     asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(reg), "=&s"(keep) : "s"(value), "s"(laneSel));
 }
 
-template <bool STATS>
+// KEYS: every lane also keeps, for the first KZ_PACKET_KEYS entries of the shared stack, ITS OWN entry distance of that box (LDS,
+// [entry][lane]); a popped entry that no lane can still reach (box behind the lane's closest hit, or never hit by the lane) is dropped
+// for one LDS read and a compare instead of a node step.
+#define KZ_PACKET_KEYS 16
+template <bool STATS, bool KEYS>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace_packet(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, int batchPackets) {
+    __shared__ uint32_t s_keys[KEYS ? KZ_PACKET_KEYS * KZ_BLOCK : 1];
+    uint32_t *kst = s_keys + (KEYS ? threadIdx.x : 0);
     const uint32_t count = countPtr ? *countPtr : countImm;
     const uint32_t nPackets = (count + 63u) / 64u;
     const int lane = threadIdx.x & 63;
@@ -727,10 +733,15 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 #define KZ_CSWAP(x, y, rx_, ry_) do { const bool s_ = y < x; const uint32_t tx_ = s_ ? y : x, ty_ = s_ ? x : y, tr_ = s_ ? ry_ : rx_, ts_ = s_ ? rx_ : ry_; x = tx_; y = ty_; rx_ = tr_; ry_ = ts_; } while (0)
                         KZ_CSWAP(ka, kb, ra, rb); KZ_CSWAP(kc, kd, rc, rd); KZ_CSWAP(ka, kc, ra, rc); KZ_CSWAP(kb, kd, rb, rd); KZ_CSWAP(kb, kc, rb, rc);
 #undef KZ_CSWAP
-                        // push far to near, descend into the nearest
-                        if (kd != 0xFFFFFFFFu) { if (sp < 64) kzWriteLane(stk0, rd, sp); else kzWriteLane(stk1, rd, sp - 64); ++sp; }
-                        if (kc != 0xFFFFFFFFu) { if (sp < 64) kzWriteLane(stk0, rc, sp); else kzWriteLane(stk1, rc, sp - 64); ++sp; }
-                        if (kb != 0xFFFFFFFFu) { if (sp < 64) kzWriteLane(stk0, rb, sp); else kzWriteLane(stk1, rb, sp - 64); ++sp; }
+                        // push far to near, descend into the nearest; a lane's own key of a pushed child is key[low two bits of the sorted key]
+                        auto pushEntry = [&](uint32_t ks, uint32_t ref) {
+                            if (KEYS && sp < KZ_PACKET_KEYS) { const uint32_t i = ks & 3u; kst[sp * KZ_BLOCK] = i == 0 ? key[0] : (i == 1 ? key[1] : (i == 2 ? key[2] : key[3])); }
+                            if (sp < 64) kzWriteLane(stk0, ref, sp); else kzWriteLane(stk1, ref, sp - 64);
+                            ++sp;
+                        };
+                        if (kd != 0xFFFFFFFFu) pushEntry(kd, rd);
+                        if (kc != 0xFFFFFFFFu) pushEntry(kc, rc);
+                        if (kb != 0xFFFFFFFFu) pushEntry(kb, rb);
                         cur = ra; descended = true;
                     }
                     if (descended) continue;
@@ -743,9 +754,18 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                         if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; btri = start + i; bgid = g; tmax = t; }
                     }
                 }
-                if (sp == 0) break;
-                --sp;
-                cur = (uint32_t)(sp < 64 ? __builtin_amdgcn_readlane((int)stk0, sp) : __builtin_amdgcn_readlane((int)stk1, sp - 64));
+                bool more = false;
+                while (sp > 0) {
+                    --sp;
+                    if (KEYS && sp < KZ_PACKET_KEYS) {                    // does any lane still need this entry?
+                        const uint32_t k = kst[sp * KZ_BLOCK];
+                        if (__ballot(k != 0xFFFFFFFFu && (k & ~3u) <= __float_as_uint(tmax)) == 0ull) continue;
+                    }
+                    cur = (uint32_t)(sp < 64 ? __builtin_amdgcn_readlane((int)stk0, sp) : __builtin_amdgcn_readlane((int)stk1, sp - 64));
+                    more = true;
+                    break;
+                }
+                if (!more) break;
             }
         }
         if (have) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);

@@ -5,6 +5,8 @@
                                                          per-stage device times of one pass + Msamples/s of a full call
     python scripts/probe.py sweep --knob refill --values 24,32,40,48,56 [--scene c4]
                                                          the same for a list of values of one KzTuning field (or pass_items / passes_in_flight)
+    python scripts/probe.py counters --values 'keyStack=1;keyStack=2'
+                                                         executed node visits / triangle tests / rays per sample for each tuning
     KZ_LIB_PATH=nano-kazen_amd/csrc/variants/lanestat/libkazen_mi355x.so python scripts/probe.py lanestat
                                                          where the lanes of the traversal loop are (needs scripts/build_variant.sh lanestat -DKZ_LANESTAT)
 """
@@ -76,6 +78,19 @@ def cmd_sweep(a):
         print(json.dumps({"knob": a.knob, "value": int(v), **one(sc, spp, tune, opts)}), flush=True)
 
 
+def cmd_counters(a):
+    """executed work per sample (node visits, triangle tests, rays) for a list of tunings: --values 'keyStack=1;keyStack=2'"""
+    sc = kz.Scene(scene(a.scene), device=0)
+    sc.set_stats(True)
+    spp = a.spp or 16
+    for t in (a.values.split(";") if a.values else [""]):
+        sc.stats(reset=True)
+        sc.render(0, spp, passes_in_flight=1, tune=kv(t)); sc.sync()
+        st = sc.stats(reset=True)
+        n = max(1, st["samples"])
+        print(json.dumps({"tune": t, **{k: round(v / n, 3) for k, v in st.items() if k != "samples"}}), flush=True)
+
+
 def cmd_lanestat(a):
     sc = kz.Scene(scene(a.scene), device=0)
     sc.set_stats(True)
@@ -85,10 +100,10 @@ def cmd_lanestat(a):
 
 
 ap = argparse.ArgumentParser()
-ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat"])
+ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters"])
 ap.add_argument("c5", nargs="?")
 ap.add_argument("--scene", default="c4"); ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--tune", default=""); ap.add_argument("--opts", default="")
 ap.add_argument("--knob", default="refill"); ap.add_argument("--values", default="")
 a = ap.parse_args()
-{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat}[a.cmd](a)
+{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters}[a.cmd](a)
