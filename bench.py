@@ -211,15 +211,17 @@ def main():
         roofline = {"bound": "valu", "unit": "G wave-instr/s", "peak": round(peak_rate, 1),
                     "peak_source": "scripts/micro/valu_peak.hip v_fma_f32, 8 waves/SIMD, measured (profiles/%s)" % peak["profile"],
                     "achieved": None, "frac": None, "traffic": None,
-                    "kernel": "kz_wf_trace<0> (closest-hit traversal: 1 primary + %d bounce launches per pass)" % (desc.integrator["maxDepth"] - 1),
+                    "kernel": "closest-hit traversal = kz_wf_trace_packet (camera rays) + %d launches of kz_wf_trace<0> (bounce rays) per pass" % (desc.integrator["maxDepth"] - 1),
                     "kernel_ms_one_pass_alone": stage_ms["trace_closest"], "pass_ms_in_flight": round(kernel_ms_last, 3),
                     "pass_ms_alone": round(alone_ms, 3), "stages_ms_one_pass_alone": stage_ms, "samples_per_launch": launch_samples,
                     "passes_per_step": info["passes"], "passes_in_flight": info["passesInFlight"]}
         if facts:
-            k = facts["kernels"]["kz_wf_trace<0>"]
-            ach = k["valu_wave_instr_per_sample"] * launch_samples / (stage_ms["trace_closest"] * 1e-3) / 1e9
+            ks = [facts["kernels"][n] for n in ("kz_wf_trace_packet", "kz_wf_trace<0>") if n in facts["kernels"]]     # camera rays + bounce rays
+            instr = sum(k["valu_wave_instr_per_sample"] for k in ks)
+            lanes = sum(k["valu_wave_instr_per_sample"] * k["lanes"] for k in ks) / instr
+            ach = instr * launch_samples / (stage_ms["trace_closest"] * 1e-3) / 1e9
             roofline.update({"achieved": round(ach, 1), "frac": round(ach / peak_rate, 4),
-                             "lanes_active_per_valu_instr": k["lanes"], "useful_frac": round(ach / peak_rate * k["lanes"] / 64.0, 4),
+                             "lanes_active_per_valu_instr": round(lanes, 1), "useful_frac": round(ach / peak_rate * lanes / 64.0, 4),
                              "mix_ceiling": peak.get("node_mix_wave_instr_per_s") and round(peak["node_mix_wave_instr_per_s"] / 1e9, 1),
                              "traffic": facts.get("hbm_bytes_per_sample") and int(facts["hbm_bytes_per_sample"] * launch_samples),
                              "counter_facts": {"profile": facts["profile"], "commit": facts["commit"], "per_kernel": facts["kernels"]}})

@@ -241,7 +241,9 @@ typedef struct KzTuning {
     int32_t packetPrimary;      /* primary rays: 0 = default (shared-stack packet traversal), 1 = per-lane, 2 = packet */
     int32_t keyStack;           /* stack entries carry their box entry distance and are culled at pop time: 0 = default (packet kernel only),
                                    1 = off, 2 = also in the per-lane closest-hit kernel (measured slower on C4) */
-    int32_t reserved[7];
+    int32_t ldsTop;             /* BVH4 packets of the top of the tree (breadth-first prefix) staged in LDS by the per-lane traversal
+                                   kernels: 0 = default (off: measured no gain on C4, profiles/r02c_lds_top), n = that many (<= 1536) */
+    int32_t reserved[6];
 } KzTuning;
 
 typedef struct KzRenderOpts {

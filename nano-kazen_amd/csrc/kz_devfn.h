@@ -239,11 +239,8 @@ __device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin
 struct Node4Test { uint32_t k0, k1, k2, k3; uint4 refs; };
 typedef float kz_f2 __attribute__((ext_vector_type(2)));
 // keys in slot order: (bits of max(tnear, tmin) with the two low bits replaced by the child slot), 0xFFFFFFFF for a miss
-__device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax,
-                                          uint32_t (&key)[4], uint4 &refs) {
-    const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + node);
-    const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
-    refs = np[3];
+__device__ __forceinline__ void node4KeysOf(const uint4 q0, const uint4 q1, const uint4 q2, V3 o, float rx, float ry, float rz, float tmin, float tmax,
+                                            uint32_t (&key)[4]) {
     const float ax = __uint_as_float((q0.w & 0xffu) << 23) * rx, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * ry,
                 az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * rz;
     const float bx = (__uint_as_float(q0.x) - o.x) * rx, by = (__uint_as_float(q0.y) - o.y) * ry, bz = (__uint_as_float(q0.z) - o.z) * rz;
@@ -265,6 +262,13 @@ __device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V
         const float f = fminf(fminf(fminf(tx.y, ty.y), tz.y) * 1.0000004f, tmax);
         key[i] = (n <= f) ? ((__float_as_uint(n) & ~3u) | (uint32_t)i) : 0xFFFFFFFFu;
     }
+}
+__device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax,
+                                          uint32_t (&key)[4], uint4 &refs) {
+    const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + node);
+    const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
+    refs = np[3];
+    node4KeysOf(q0, q1, q2, o, rx, ry, rz, tmin, tmax, key);
 }
 __device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax) {
     Node4Test r; uint32_t key[4];

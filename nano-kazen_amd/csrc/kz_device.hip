@@ -336,7 +336,7 @@ static const EnvOverride &envOverride() {
         auto I = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
         o.tune.refill = I("KZ_TUNE_REFILL", 0); o.tune.postpone = I("KZ_TUNE_POSTPONE", 0); o.tune.batch = I("KZ_TUNE_BATCH", 0);
         o.tune.traceBlocksPerCU = I("KZ_TUNE_TRAV_BLOCKS", 0); o.tune.shadeBlocksPerCU = I("KZ_TUNE_SHADE_BLOCKS", 0);
-        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0);
+        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0); o.tune.ldsTop = I("KZ_TUNE_LDS_TOP", 0);
         if (const char *e = std::getenv("KZ_PASS_ITEMS")) { long long v = std::atoll(e); if (v >= 1024) o.passItems = (uint64_t)v; }
         if (const char *e = std::getenv("KZ_DUAL_STREAM")) o.passesInFlight = std::atoi(e) ? 2 : 1;
         o.pipeline = I("KZ_PIPELINE", 0); o.traceKernel = I("KZ_TRACE_KERNEL", 1); o.mixed = I("KZ_TUNE_MIXED", 0);
@@ -351,7 +351,7 @@ static KzTune resolveTune(const KzTuning &t) {
     r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
     r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 6));
     r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
-    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0);
+    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0);
     r.ovf = nullptr; r.ovfStride = 0;
     return r;
 }
@@ -569,8 +569,14 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
     // closest-hit rays on the BVH4 carry the entry distance with every stack entry (second column block in LDS, odd rows of the overflow area)
     const bool keys = tune.wide && tune.keyStack == 2;      // per-lane kernel: measured slower on C4 (r02c), on request only
-    const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);      // + one scratch slot per lane (branch-free pushes)
-    const size_t traceLdsK = keys ? 2 * traceLds : traceLds;
+    tune.ldsTop = tune.wide ? (int)std::min<size_t>((size_t)std::max(0, tune.ldsTop), std::min<size_t>(scene->nodes4.size(), 1536)) : 0;
+    const size_t topBytes = (size_t)tune.ldsTop * sizeof(KzNode4);
+    const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t) + topBytes;      // + one scratch slot per lane (branch-free pushes)
+    const size_t traceLdsK = (keys ? 2 : 1) * (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t) + topBytes;
+    if (traceLdsK > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace<0, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace<2, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     {
         const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack) * (keys ? 2 : 1);
         if (needOvf > c.ovfCap) {

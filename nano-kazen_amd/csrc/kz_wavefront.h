@@ -409,7 +409,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // the bounce before: both only depend on the same shade stage, and one launch has one tail instead of two.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment; such
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
-struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack; uint32_t *ovf; uint32_t ovfStride; };
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop; uint32_t *ovf; uint32_t ovfStride; };
 
 template <int MODE, bool STATS, bool WIDE, bool KEYS = false>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
@@ -428,6 +428,16 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     // second LDS column block / in the odd rows of the overflow area. An entry whose box starts behind the closest hit found so far
     // is dropped at pop time for the price of two LDS reads and a compare instead of a full node step on four boxes that all miss.
     const int kOff = (LS + 1) * KZ_BLOCK;              // key column block behind the ref column block (KEYS only)
+    // tune.ldsTop > 0 (north_star: "LDS-staged BVH node packets"): the first ldsTop packets of the breadth-first BVH4 array = the top
+    // levels of the tree are copied into LDS behind the stacks by the whole workgroup and node steps on them read LDS instead of L1.
+    const uint32_t nTop = WIDE ? (uint32_t)tune.ldsTop : 0u;
+    const uint4 *s_top = reinterpret_cast<const uint4 *>(s_stack + (LS + 1) * KZ_BLOCK * (KEYS ? 2 : 1));
+    if (nTop) {
+        uint4 *w = reinterpret_cast<uint4 *>(s_stack + (LS + 1) * KZ_BLOCK * (KEYS ? 2 : 1));
+        const uint4 *src = reinterpret_cast<const uint4 *>(T.nodes4);
+        for (uint32_t i = threadIdx.x; i < nTop * 4u; i += KZ_BLOCK) w[i] = src[i];
+        __syncthreads();
+    }
     const size_t ovfW = KEYS ? 2 : 1;
     auto push = [&](int &sp_, uint32_t v, uint32_t k) {
         if (sp_ < LS) { stk[sp_ * KZ_BLOCK] = v; if (KEYS) stk[kOff + sp_ * KZ_BLOCK] = k; }
@@ -558,7 +568,12 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                     // instructions per visit); any-hit shadow rays take the hit children in slot order altogether. Pushes
                     // are branch-free: a hit child lands on the next free slot, a missed one on the lane's scratch slot.
                     uint32_t key[4]; uint4 refs;
-                    node4Keys(T, cur, o, rx, ry, rz, tmin, tmax, key, refs);
+                    if (nTop) {
+                        uint4 q0, q1, q2;
+                        if (cur < nTop) { const uint4 *lp = s_top + cur * 4u; q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; refs = lp[3]; }
+                        else { const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + cur); q0 = np[0]; q1 = np[1]; q2 = np[2]; refs = np[3]; }
+                        node4KeysOf(q0, q1, q2, o, rx, ry, rz, tmin, tmax, key);
+                    } else node4Keys(T, cur, o, rx, ry, rz, tmin, tmax, key, refs);
                     bool p0, p1, p2, p3;                                          // child i goes on the stack
                     uint32_t nxt; bool any;
                     if (MODE == 2 && KZ_SHADOW_SLOT_ORDER) {

@@ -84,7 +84,7 @@ def group(prefix):
     c = defaultdict(float)
     for k in ks:
         for n, v in out[k].items():
-            if isinstance(v, float) and n.isupper() or n in ("launches",):
+            if n == "launches" or (isinstance(v, float) and n.split("_")[0] in ("SQ", "TCC", "TCP", "GRBM", "FETCH", "WRITE")):
                 c[n] += v
     return c
 kernels = {}
