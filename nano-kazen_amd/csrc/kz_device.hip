@@ -572,10 +572,10 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     tune.ldsTop = tune.wide ? (int)std::min<size_t>((size_t)std::max(0, tune.ldsTop), std::min<size_t>(scene->nodes4.size(), 1536)) : 0;
     const size_t topBytes = (size_t)tune.ldsTop * sizeof(KzNode4);
     const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t) + topBytes;      // + one scratch slot per lane (branch-free pushes)
-    const size_t traceLdsK = (keys ? 2 : 1) * (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t) + topBytes;
-    if (traceLdsK > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace<0, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace<2, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t traceLdsK = 2 * (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);
+    if (traceLds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace<0, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace<2, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     {
         const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack) * (keys ? 2 : 1);
@@ -597,7 +597,9 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
     const int traceKernel = envOverride().traceKernel, mixed = envOverride().mixed;
 #define KZ_TRACE2(MODE, q, cptr, cimm, headp, qb, cb) do { \
-        if (tune.wide && keys && (MODE == 0 || MODE == 1)) { \
+        if (tune.wide && tune.ldsTop > 0 && !st && (MODE == 0 || MODE == 2)) \
+                         hipLaunchKernelGGL((kz_wf_trace<MODE, false, true, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
+        else if (tune.wide && keys && (MODE == 0 || MODE == 1)) { \
                          if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true, true>), gTrav, blk, traceLdsK, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
                          else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true, true>), gTrav, blk, traceLdsK, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } \
         else if (tune.wide) { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \

@@ -234,7 +234,22 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                     bool twoSided = false;
                     if (EXT) { const int bt = T.bsdfs[mrow.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
                     survivor = (wz > 0.f) || twoSided || isnan(wz);
-                    if (STATS && !survivor && P.nLights > 0) {
+                    if (survivor && iter >= 3) {
+                        // Russian roulette (integrator.cpp:237-244) here, in front of the compaction: a path it ends does not take a lane of
+                        // pass B (at depth 3 and 4 that was 2 of 3 lanes). The survivor's scaled throughput and advanced sampler go back to
+                        // the path state, where pass B reads them.
+                        const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
+                        Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
+                        const float4 th = W.thr[slot];
+                        V3 throughput = mk(th.x, th.y, th.z);
+                        const float probability = fminf(maxCoeff(throughput) * th.w * th.w, 0.95f);
+                        if (probability <= smp.next1D(P, T)) survivor = false;
+                        else {
+                            throughput = throughput / probability;
+                            W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, th.w);
+                            wfStoreSampler(P, W, slot, smp);
+                        }
+                    } else if (STATS && !survivor && P.nLights > 0) {
                         // counters only: the reference draws the roulette sample before it takes the light sample (integrator.cpp:237-247)
                         bool alive = true;
                         if (iter >= 3) {
@@ -289,13 +304,7 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
             const uint32_t pl = slot / S;
             const uint32_t pxy = pixList[pl];
             Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
-            bool alive = true;
-            if (iter >= 3) {                                                          // integrator.cpp:237-244
-                const float probability = fminf(maxCoeff(throughput) * eta * eta, 0.95f);
-                if (probability <= smp.next1D(P, T)) alive = false;
-                else throughput = throughput / probability;
-            }
-            if (alive) {
+            {                                                                         // (the roulette of integrator.cpp:237-244 was played in pass A)
                 KzBSDF bsdf = T.bsdfs[mrow.bsdf];
                 NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
                 const V3 wiLocal = toLocal(its.sh, -rd);
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
 struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop; uint32_t *ovf; uint32_t ovfStride; };
 
-template <int MODE, bool STATS, bool WIDE, bool KEYS = false>
+template <int MODE, bool STATS, bool WIDE, bool KEYS = false, bool TOP = false>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune,
                                                         const uint32_t *__restrict__ queueB, const uint32_t *__restrict__ countPtrB) {
@@ -428,9 +437,11 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     // second LDS column block / in the odd rows of the overflow area. An entry whose box starts behind the closest hit found so far
     // is dropped at pop time for the price of two LDS reads and a compare instead of a full node step on four boxes that all miss.
     const int kOff = (LS + 1) * KZ_BLOCK;              // key column block behind the ref column block (KEYS only)
-    // tune.ldsTop > 0 (north_star: "LDS-staged BVH node packets"): the first ldsTop packets of the breadth-first BVH4 array = the top
+    // TOP (tune.ldsTop > 0; north_star: "LDS-staged BVH node packets"): the first ldsTop packets of the breadth-first BVH4 array = the top
     // levels of the tree are copied into LDS behind the stacks by the whole workgroup and node steps on them read LDS instead of L1.
-    const uint32_t nTop = WIDE ? (uint32_t)tune.ldsTop : 0u;
+    // Measured on C4 (profiles/r02c_lds_top): 13 % fewer L1 accesses, 1-3 % less time, and the test in the node step costs the
+    // kernels that do not use it 5 % -> a separate instantiation, off by default.
+    const uint32_t nTop = (WIDE && TOP) ? (uint32_t)tune.ldsTop : 0u;
     const uint4 *s_top = reinterpret_cast<const uint4 *>(s_stack + (LS + 1) * KZ_BLOCK * (KEYS ? 2 : 1));
     if (nTop) {
         uint4 *w = reinterpret_cast<uint4 *>(s_stack + (LS + 1) * KZ_BLOCK * (KEYS ? 2 : 1));
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                     // instructions per visit); any-hit shadow rays take the hit children in slot order altogether. Pushes
                     // are branch-free: a hit child lands on the next free slot, a missed one on the lane's scratch slot.
                     uint32_t key[4]; uint4 refs;
-                    if (nTop) {
+                    if (TOP) {
                         uint4 q0, q1, q2;
                         if (cur < nTop) { const uint4 *lp = s_top + cur * 4u; q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; refs = lp[3]; }
                         else { const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + cur); q0 = np[0]; q1 = np[1]; q2 = np[2]; refs = np[3]; }

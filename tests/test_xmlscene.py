@@ -102,24 +102,38 @@ def test_mini_scene_gpu_matches_oracle(kz, O, gpu_lib):
     assert float(np.sqrt(np.mean((sc.rgb() - o.rgb(o.render(threads=0))) ** 2))) < 1e-3
 
 
+PIN_IMAGES = ["default_m0_r0.5", "m0.0_r0", "m0.0_r0.5", "m0.0_r1", "m0_r0_spec0", "m0_r0_spec0.5", "m0_r0_spec1", "m0_r0_spec1_st0.5", "m0_r0_spec1_st1",
+              "m1_r0", "m1_r0.5", "m1_r1", "r0.5_c0", "r0.5_c0.5", "r0.5_c1", "r0.5_c1_cr0.5", "r0.5_c1_cr1", "r0_s0", "r0_s0.5", "r0_s1", "r0_s1_st0.5", "r0_s1_st1"]
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout is only present in the build container")
-@pytest.mark.parametrize("name", ["default_m0_r0.5", "m0.0_r1", "m1_r0.5", "m1_r1", "r0.5_c1_cr0.5", "r0_s1_st1", "m0_r0_spec1_st1", "m0_r0_spec0"])
+@pytest.mark.parametrize("name", PIN_IMAGES)
 def test_reference_scene_files_match_their_published_pngs(kz, O, name):
-    """scene/2022_q1/parameters/*.xml (36 378 triangles, SURVEY 8d C1 geometry; a kiss parameter sweep over metallic, roughness,
-    specular, specularTint, clearcoat, sheen) loaded UNCHANGED and rendered by the oracle at 160x90x64: the tone-mapped result
-    agrees with the reference's own 4096-spp PNG (doc/2022_q1/img/param/) at low frequency. This is the only image-level pin the
-    reference offers ('usable only as a statistical sanity check'); all 22 files were checked by hand: max |d| 0.040-0.096
-    on a 16x9 grid, except m1_r0 (a perfect mirror whose HDR highlights need the full 1920x1080 resolution before tone mapping)."""
+    """ALL 22 scene/2022_q1/parameters/*.xml (36 378 triangles, SURVEY 8d C1 geometry; a kiss parameter sweep over metallic,
+    roughness, specular, specularTint, clearcoat, sheen) loaded UNCHANGED and rendered by the oracle at 240x135x64: the tone-mapped
+    result agrees with the reference's own 4096-spp PNG (doc/2022_q1/img/param/) at low frequency. This is the only image-level
+    pin the reference offers ('usable only as a statistical sanity check'). Blocks of the 16x9 grid in which the picture
+    is clipped (value 255: the mirror-like objects' highlights, whose HDR energy the 8-bit picture has lost) are left out.
+
+    What the bound encodes (scripts/pin_reference_pngs.py, profiles/pin/table.json: 480x270x256 per image): in LINEAR radiance the
+    oracle is 0.953 of the picture on average, with the SAME shape in all 22 images whatever the object's BSDF is - floor 0.943
+    (0.9426-0.9438), top rows 1.016 (1.0142-1.0174), sigma 0.039 - i.e. max |d| 0.042-0.048 sRGB on this grid and a mean of
+    -0.014...-0.018. A transport or BSDF bug in the restatement would break that uniformity; the bound is set just above the
+    measured worst case so that any new deviation shows."""
     from PIL import Image
-    d = kz.xmlscene.load_xml(os.path.join(REF, name + ".xml"), {"camera": {"width": 160, "height": 90}, "sampler": {"sampleCount": 64}})
+    d = kz.xmlscene.load_xml(os.path.join(REF, name + ".xml"), {"camera": {"width": 240, "height": 135}, "sampler": {"sampleCount": 64}})
     assert d.n_tris() == 36378
     o = O.OracleScene(d)
     rgb = o.rgb(o.render(threads=0))
     x = np.clip(rgb, 0, 1)
     srgb = np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1 / 2.4) - 0.055)            # common.cpp:352-366
-    ref = np.asarray(Image.open("/root/reference/doc/2022_q1/img/param/%s.png" % name).convert("RGB").resize((16, 9), Image.BOX), np.float32) / 255
-    mine = srgb.reshape(9, 10, 16, 10, 3).mean(axis=(1, 3))
-    assert np.abs(mine - ref).max() < 0.07 and abs(mine.mean() - ref.mean()) < 0.025
+    png = np.asarray(Image.open("/root/reference/doc/2022_q1/img/param/%s.png" % name).convert("RGB"), np.float32) / 255
+    clipped = (png >= 1.0).any(axis=2).reshape(9, 120, 16, 120).any(axis=(1, 3))
+    ref = png.reshape(9, 120, 16, 120, 3).mean(axis=(1, 3))
+    mine = srgb.reshape(9, 15, 16, 15, 3).mean(axis=(1, 3))
+    ok = ~clipped
+    assert ok.sum() >= 120
+    assert np.abs(mine - ref)[ok].max() < 0.055 and -0.022 < mine[ok].mean() - ref[ok].mean() < -0.010
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout is only present in the build container")
