@@ -459,7 +459,13 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     const float eps = P.traceBias;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     Counters cn = {0, 0, 0, 0, 0, 0};
-    uint32_t poolNext = 0, poolEnd = 0;
+    // Queue entries are claimed in batches. The FIRST batch of a wave is static (wave w owns entries [w*batch, (w+1)*batch)): a
+    // launch on a short queue then costs no atomics at all, where 8192 waves hitting one counter took ~95 us (one word serves ~88
+    // dequeues/us) - the whole duration of the late, nearly empty bounces of a small frame. Further batches come from the shared counter.
+    const uint32_t nWaves = gridDim.x * (KZ_BLOCK / 64), waveId = blockIdx.x * (KZ_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t batch = max(64u, min((uint32_t)tune.batch, ((count + nWaves - 1) / nWaves + 63u) & ~63u));   // short queues: spread over all waves
+    const bool staticOnly = (unsigned long long)nWaves * batch >= count;
+    uint32_t poolNext = min(waveId * batch, count), poolEnd = min(poolNext + batch, count);
     bool exhausted = false;
     bool active = false, literal = false;
     V3 o = mk(0.f), d = mk(0.f);
@@ -510,11 +516,14 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int nAct = __popcll(act);
         if (nAct < tune.refill && !exhausted) {
             if (poolNext >= poolEnd) {
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(head, (uint32_t)tune.batch);
-                b = __builtin_amdgcn_readfirstlane(b);
+                uint32_t b = count;
+                if (!staticOnly) {
+                    if (lane == 0) b = atomicAdd(head, batch);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    b = (b < 0xFFFFFFFFu - nWaves * batch) ? b + nWaves * batch : count;            // dynamic batches start behind the static ones
+                }
                 if (b >= count) { exhausted = true; poolNext = poolEnd = 0; }
-                else { poolNext = b; poolEnd = min(b + (uint32_t)tune.batch, count); }
+                else { poolNext = b; poolEnd = min(b + batch, count); }
             }
             if (!exhausted) {
                 const uint32_t take = min((uint32_t)(64 - nAct), poolEnd - poolNext);
@@ -707,14 +716,19 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     const int lane = threadIdx.x & 63;
     const uint32_t root = P.rootRef4;
     Counters cn = {0, 0, 0, 0, 0, 0};
-    uint32_t pNext = 0, pEnd = 0;
+    // first batch static (wave w owns packets [w*bp, (w+1)*bp)), further batches from the shared counter: see kz_wf_trace
+    const uint32_t nWaves = gridDim.x * (KZ_BLOCK / 64), waveId = blockIdx.x * (KZ_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t bp = max(1u, min((uint32_t)batchPackets, (nPackets + nWaves - 1) / nWaves));
+    const bool staticOnly = (unsigned long long)nWaves * bp >= nPackets;
+    uint32_t pNext = min(waveId * bp, nPackets), pEnd = min(pNext + bp, nPackets);
     for (;;) {
         if (pNext >= pEnd) {
+            if (staticOnly) break;
             uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(head, (uint32_t)batchPackets);
-            b = __builtin_amdgcn_readfirstlane(b);
+            if (lane == 0) b = atomicAdd(head, bp);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + nWaves * bp;
             if (b >= nPackets) break;
-            pNext = b; pEnd = min(b + (uint32_t)batchPackets, nPackets);
+            pNext = b; pEnd = min(b + bp, nPackets);
         }
         const uint32_t qi = pNext * 64u + (uint32_t)lane;
         ++pNext;
