@@ -60,6 +60,15 @@ __device__ __forceinline__ uint64_t hashPixelDimSeed(int px, int py, uint32_t di
     h *= MURMUR_M;
     return murmurFinish(h);
 }
+// The same hash with its first block - the only part that depends on the pixel - taken from `hp` = hashPixelBlock(px, py): a path
+// draws ~7 samples per bounce at consecutive dimensions of ONE pixel, so the samplers compute that block once per kernel invocation.
+__device__ __forceinline__ uint64_t hashPixelBlock(int px, int py) { return murmurBlock(20ull * MURMUR_M, (uint64_t)(uint32_t)px | ((uint64_t)(uint32_t)py << 32)); }
+__device__ __forceinline__ uint64_t hashDimSeed(uint64_t hp, uint32_t dim, uint64_t seed) {
+    uint64_t h = murmurBlock(hp, (uint64_t)dim | ((seed & 0xffffffffull) << 32));
+    h ^= (seed >> 32);            // the 4 tail bytes
+    h *= MURMUR_M;
+    return murmurFinish(h);
+}
 __device__ __forceinline__ uint64_t mixBits(uint64_t v) {
     v ^= (v >> 31); v *= 0x7fb5d329728ea185ull; v ^= (v >> 27); v *= 0x81dadef4bc2dd44dull; v ^= (v >> 33);
     return v;
@@ -84,6 +93,7 @@ struct Sampler {
     uint64_t state, inc;            // independent: pcg32
     int px, py; uint32_t idx, dim;  // pmj02bn
     int type;
+    uint64_t hp;                    // hashPixelBlock(px, py): the pixel's share of Hash(p, dim, seed) (every sampler but independent)
 
     __device__ __forceinline__ uint32_t nextUInt() {
         uint64_t old = state;
@@ -95,6 +105,7 @@ struct Sampler {
     __device__ __forceinline__ float nextFloat() { return __uint_as_float((nextUInt() >> 9) | 0x3f800000u) - 1.0f; }
     __device__ void generateSample(const KzParams &P, const KzDevTables &T, int x, int y, uint32_t sampleIndex) {
         px = x; py = y; idx = sampleIndex;
+        hp = type != KZ_SAMPLER_INDEPENDENT ? hashPixelBlock(x, y) : 0ull;
         if (type != KZ_SAMPLER_PMJ02BN) {                 // independent, stratified, correlated: same pcg32 seeding
             dim = 0;
             uint64_t h = hashPixelSeed(x, y, P.seed);
@@ -118,20 +129,20 @@ struct Sampler {
     __device__ float next1D(const KzParams &P, const KzDevTables &T) {
         if (type == KZ_SAMPLER_INDEPENDENT) return nextFloat();
         if (type == KZ_SAMPLER_STRATIFIED) {                                       // sampler.cpp:119-127
-            const uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
+            const uint64_t h = hashDimSeed(hp, dim, P.seed);
             const int stratum = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h);
             ++dim;
             const float delta = nextFloat();
             return ((float)stratum + delta) / (float)P.sampleCount;
         }
         if (type == KZ_SAMPLER_CORRELATED) {                                       // sampler.cpp:215-227
-            const uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
+            const uint64_t h = hashDimSeed(hp, dim, P.seed);
             const int p = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h * 0x45fbe943u);
             const float j = nextFloat();
             ++dim;
             return ((float)p + j) / (float)P.sampleCount;
         }
-        uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
+        uint64_t h = hashDimSeed(hp, dim, P.seed);
         int index = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h);
         float delta = blueNoise(T, dim);
         ++dim;
@@ -140,7 +151,7 @@ struct Sampler {
     __device__ void next2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
         if (type == KZ_SAMPLER_INDEPENDENT) { y = nextFloat(); x = nextFloat(); return; }
         if (type == KZ_SAMPLER_STRATIFIED) {                                       // sampler.cpp:129-139
-            const uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
+            const uint64_t h = hashDimSeed(hp, dim, P.seed);
             const int stratum = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h);
             dim += 2;
             const int sx = stratum % P.resX, sy = stratum / P.resX;
@@ -150,7 +161,7 @@ struct Sampler {
             return;
         }
         if (type == KZ_SAMPLER_CORRELATED) {                                       // sampler.cpp:229-251
-            const uint32_t h = (uint32_t)hashPixelDimSeed(px, py, dim, P.seed);    // permute() takes the low 32 bits of hash * const
+            const uint32_t h = (uint32_t)hashDimSeed(hp, dim, P.seed);    // permute() takes the low 32 bits of hash * const
             const uint32_t s = permuteIdx(idx, P.sampleCount, h * 0x51633e2du);
             const uint32_t cy = s / (uint32_t)P.resX, cx = s % (uint32_t)P.resX;
             const uint32_t sx = permuteIdx(cx, (uint32_t)P.resX, h * 0x68bc21ebu);
@@ -165,7 +176,7 @@ struct Sampler {
         uint32_t index = idx;
         uint32_t inst = dim / 2;
         if (inst >= KZ_PMJ02BN_SETS) {
-            uint64_t h = hashPixelDimSeed(px, py, dim, P.seed);
+            uint64_t h = hashDimSeed(hp, dim, P.seed);
             index = permuteIdx(idx, P.sampleCount, (uint32_t)h);
         }
         inst %= KZ_PMJ02BN_SETS; index %= KZ_PMJ02BN_SAMPLES;

@@ -78,6 +78,7 @@ __device__ __forceinline__ void wfLoadSampler(const KzParams &P, const KzWf &W, 
     s.type = P.samplerType; s.px = px; s.py = py; s.idx = sampleIndex;
     s.state = (uint64_t)v.x | ((uint64_t)v.y << 32); s.dim = v.z;
     s.inc = (P.samplerType == KZ_SAMPLER_PMJ02BN) ? 0ull : ((hashPixelSeed(px, py, P.seed) << 1u) | 1u);      // pcg32 stream id: a function of the pixel
+    s.hp = (P.samplerType != KZ_SAMPLER_INDEPENDENT) ? hashPixelBlock(px, py) : 0ull;
 }
 __device__ __forceinline__ void wfStoreSampler(const KzParams &P, const KzWf &W, uint32_t slot, const Sampler &s) {
     uint4 v;
@@ -431,8 +432,12 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     int kind = (MODE == 3) ? 0 : MODE;              // per-lane ray kind; a compile-time constant unless the launch is mixed
     const int lane = threadIdx.x & 63;
     const int LS = tune.ldsStack;
-    uint32_t *ovf = tune.ovf + (size_t)blockIdx.x * KZ_BLOCK + threadIdx.x;
+    // overflow rows live at tune.ovf[row * ovfStride + thread]: the (rare) deep case forms its address from the scalar base and a 32-bit
+    // thread index instead of keeping a 64-bit per-lane pointer alive through the loop
+    uint32_t *const ovfBase = tune.ovf;
+    const uint32_t ovfLane = blockIdx.x * KZ_BLOCK + threadIdx.x;
     const size_t ovfStride = tune.ovfStride;
+#define ovf(row) ovfBase[(size_t)(row) * ovfStride + ovfLane]
     // KEYS (closest-hit rays on the BVH4): every stack entry carries the entry distance of its box (the sortable key of node4Keys), in a
     // second LDS column block / in the odd rows of the overflow area. An entry whose box starts behind the closest hit found so far
     // is dropped at pop time for the price of two LDS reads and a compare instead of a full node step on four boxes that all miss.
@@ -452,12 +457,11 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     const size_t ovfW = KEYS ? 2 : 1;
     auto push = [&](int &sp_, uint32_t v, uint32_t k) {
         if (sp_ < LS) { stk[sp_ * KZ_BLOCK] = v; if (KEYS) stk[kOff + sp_ * KZ_BLOCK] = k; }
-        else { ovf[(size_t)(sp_ - LS) * ovfW * ovfStride] = v; if (KEYS) ovf[((size_t)(sp_ - LS) * 2 + 1) * ovfStride] = k; }
+        else { ovf((size_t)(sp_ - LS) * ovfW) = v; if (KEYS) ovf((size_t)(sp_ - LS) * 2 + 1) = k; }
         ++sp_;
     };
     const uint32_t root = WIDE ? P.rootRef4 : P.rootRef;
     const float eps = P.traceBias;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
     Counters cn = {0, 0, 0, 0, 0, 0};
     // Queue entries are claimed in batches. The FIRST batch of a wave is static (wave w owns entries [w*batch, (w+1)*batch)): a
     // launch on a short queue then costs no atomics at all, where 8192 waves hitting one counter took ~95 us (one word serves ~88
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
             // global address would become a generic-pointer load)
             const int row = min(sp, LS) * KZ_BLOCK;
             uint32_t v = stk[row], k = KEYS ? stk[kOff + row] : 0u;
-            if (sp >= LS) { v = ovf[(size_t)(sp - LS) * ovfW * ovfStride]; if (KEYS) k = ovf[((size_t)(sp - LS) * 2 + 1) * ovfStride]; }
+            if (sp >= LS) { v = ovf((size_t)(sp - LS) * ovfW); if (KEYS) k = ovf((size_t)(sp - LS) * 2 + 1); }
             if (!KEYS || (k & ~3u) <= __float_as_uint(tmax)) { cur = v; return true; }      // key = bits of max(tnear, tmin), low two bits = slot
         }
         return false;
@@ -530,7 +534,8 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 #ifdef KZ_LANESTAT
                 lsRefills++; lsRefillLanes += take;
 #endif
-                const uint32_t rank = (uint32_t)__popcll(~act & ltMask);
+                const unsigned long long idle = ~act;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));   // idle lanes below this one
                 if (!active && rank < take) {
                     const uint32_t qi = poolNext + rank;
                     if (MODE == 3) { kind = qi < countA ? 0 : 2; slot = qi < countA ? queue[qi] : queueB[qi - countA]; }
@@ -681,6 +686,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         atomicAdd(ls + 4, lsLeafLanes); atomicAdd(ls + 5, lsRefills); atomicAdd(ls + 6, lsRefillLanes); atomicAdd(ls + 7, lsTriIters);
     }
 #endif
+#undef ovf
 }
 
 // ---- packet traversal for coherent rays (the camera rays of a pass) ------------------------------------------------------
