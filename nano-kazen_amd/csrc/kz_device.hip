@@ -159,6 +159,97 @@ __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *_
     }
 }
 
+// ---- a25 in two kernels for filters of at most 4 taps per axis (every default of the reference: gaussian / mitchell radius 2, tent, box) ----
+// kz_film_gather stages the samples of a 20x20 pixel neighbourhood three at a time (LDS) and so reads 12-byte pieces of the 256-byte
+// sample rows: rocprofv3 shows 23.5 GB fetched per pass for 2.65 GB of records, an HBM-bound 6.2 ms (profiles/r02b_packet_primary).
+// Here every record is read exactly once, coalesced:
+//   kz_film_taps   one wave per SOURCE pixel, lanes = its samples: validity, the separable filter weights of block.cpp:64-80 per tap,
+//                  the 4x4 weighted products of block.cpp:84; the products of 64 samples go through LDS ([sample][value], padded rows)
+//                  and lane v adds up value v over the samples IN SAMPLE ORDER -> 16 (rgb*w, w) sums per pixel, 256 B, one coalesced store.
+//   kz_film_apply  one thread per FILM pixel: adds, in a fixed (row, column) tap order, the tap sums of the <= 16 source pixels that reach it.
+// Deterministic (fixed orders everywhere); the weights are the ones kz_film_gather forms (block-relative positions, same table look-ups).
+#define KZ_TAPS_MAX 4
+#define KZ_TAPS_ROW 68                       // floats per sample row in LDS: 64 values + 4 pad -> conflict-free b128 stores and b32 column reads
+__global__ __launch_bounds__(128) void kz_film_taps(KzParams P, const float *__restrict__ filter, const uint32_t *__restrict__ pixList, uint32_t nPix, uint32_t S,
+                                                    const float *__restrict__ inJx, const float *__restrict__ inJy, const float *__restrict__ inR,
+                                                    const float *__restrict__ inG, const float *__restrict__ inB, float *__restrict__ tapSums) {
+    __shared__ float s_filter[KZ_FILTER_RESOLUTION + 1];
+    __shared__ __attribute__((aligned(16))) float s_prod[2][64 * KZ_TAPS_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid <= KZ_FILTER_RESOLUTION) s_filter[tid] = filter[tid];
+    __syncthreads();
+    const uint32_t pl = blockIdx.x * 2 + wave;
+    const bool havePixel = pl < nPix;                                  // (no early return: both waves meet at the barriers)
+    const uint32_t pxy = havePixel ? pixList[pl] : 0u;
+    const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
+    const int bx0 = px & ~31, by0 = py & ~31;                          // the reference block this pixel is rendered in
+    const int taps = P.tapHi - P.tapLo + 1;
+    const float r = P.filterRadius, lf = P.lookupFactor;
+    float *row = s_prod[wave] + lane * KZ_TAPS_ROW;
+    float acc = 0.f;
+    for (uint32_t sBase = 0; sBase < S; sBase += 64u) {
+        const uint32_t sIdx = sBase + (uint32_t)lane;
+        float wx[KZ_TAPS_MAX] = {0.f, 0.f, 0.f, 0.f}, wy[KZ_TAPS_MAX] = {0.f, 0.f, 0.f, 0.f};
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+        if (havePixel && sIdx < S) {
+            const size_t gi = (size_t)pl * S + sIdx;
+            const float jx = inJx[gi], jy = inJy[gi];
+            cr = inR[gi]; cg = inG[gi]; cb = inB[gi];
+            const bool valid = cr >= 0.f && cg >= 0.f && cb >= 0.f && isfinite(cr) && isfinite(cg) && isfinite(cb);   // Color3f::isValid
+            if (!valid) { cr = 0.f; cg = 0.f; cb = 0.f; }
+            const float posx = ((float)px + jx) - 0.5f - (float)(bx0 - P.border), posy = ((float)py + jy) - 0.5f - (float)(by0 - P.border);   // block.cpp:64-67
+            const float lox = ceilf(posx - r), hix = floorf(posx + r), loy = ceilf(posy - r), hiy = floorf(posy + r);                     // block.cpp:70-73
+#pragma unroll
+            for (int t = 0; t < KZ_TAPS_MAX; ++t) {
+                if (t < taps) {
+                    const float xb = (float)(px + P.border - P.tapLo - t - bx0), yb = (float)(py + P.border - P.tapLo - t - by0);
+                    if (valid && !(xb < lox || xb > hix)) wx[t] = s_filter[(int)(fabsf(xb - posx) * lf)];                                 // block.cpp:77-80
+                    if (valid && !(yb < loy || yb > hiy)) wy[t] = s_filter[(int)(fabsf(yb - posy) * lf)];
+                }
+            }
+        }
+#pragma unroll
+        for (int ty = 0; ty < KZ_TAPS_MAX; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < KZ_TAPS_MAX; ++tx)
+                *reinterpret_cast<float4 *>(row + (ty * KZ_TAPS_MAX + tx) * 4) = make_float4(cr * wx[tx] * wy[ty], cg * wx[tx] * wy[ty], cb * wx[tx] * wy[ty], 1.0f * wx[tx] * wy[ty]);   // block.cpp:84
+        __syncthreads();
+        const uint32_t n = min(64u, S - sBase);
+        const float *col = s_prod[wave] + lane;
+        for (uint32_t k = 0; k < n; ++k) acc += col[k * KZ_TAPS_ROW];       // value `lane` of sample sBase + k, in sample order
+        __syncthreads();
+    }
+    if (havePixel) tapSums[(size_t)pl * 64 + lane] = acc;
+}
+
+__global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *__restrict__ pixIndex, const float4 *__restrict__ tapSums, float4 *__restrict__ film) {
+    const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border;
+    const int fx = blockIdx.x * 16 + (threadIdx.x & 15), fy = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (fx >= cols || fy >= rows) return;
+    const int taps = P.tapHi - P.tapLo + 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
+    for (int ty = 0; ty < taps; ++ty) {
+        const int y = fy - P.border + P.tapLo + ty;                    // the source pixel that reaches this film pixel through tap (tx, ty)
+        if (y < 0 || y >= P.height) continue;
+        for (int tx = 0; tx < taps; ++tx) {
+            const int x = fx - P.border + P.tapLo + tx;
+            if (x < 0 || x >= P.width) continue;
+            const int32_t pl = pixIndex[y * P.width + x];
+            if (pl < 0) continue;
+            const float4 t = tapSums[(size_t)pl * 16 + ty * KZ_TAPS_MAX + tx];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            any = true;
+        }
+    }
+    if (any) {
+        float4 *dst = film + (size_t)fy * cols + fx;
+        float4 o = *dst;
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+        *dst = o;
+    }
+}
+
 // Accel::rayIntersect(ray, its, false) for a batch of rays (ray-level parity tests)
 __global__ __launch_bounds__(KZ_BLOCK) void kz_trace_kernel(KzParams P, KzDevTables T, uint32_t n, const float *__restrict__ o,
                                                             const float *__restrict__ d, const float *__restrict__ tmin,
@@ -262,14 +353,16 @@ struct EventPair { hipEvent_t a, b; };
 struct PassCtx {
     KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0;
     float *samp = nullptr; size_t sampCap = 0;                   // five SoA planes: jx | jy | r | g | b
+    float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: 16 float4 per pixel of the tile set
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
-    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t); }
+    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 256; }
     void release() {
         for (void *p : wfAllocs) (void)hipFree(p);
         wfAllocs.clear(); wfCap = 0; wf = KzWf{};
         if (samp) (void)hipFree(samp); samp = nullptr; sampCap = 0;
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
+        if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
     }
 };
 struct KzDeviceState {
@@ -336,7 +429,7 @@ static const EnvOverride &envOverride() {
         auto I = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
         o.tune.refill = I("KZ_TUNE_REFILL", 0); o.tune.postpone = I("KZ_TUNE_POSTPONE", 0); o.tune.batch = I("KZ_TUNE_BATCH", 0);
         o.tune.traceBlocksPerCU = I("KZ_TUNE_TRAV_BLOCKS", 0); o.tune.shadeBlocksPerCU = I("KZ_TUNE_SHADE_BLOCKS", 0);
-        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0); o.tune.ldsTop = I("KZ_TUNE_LDS_TOP", 0);
+        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0); o.tune.ldsTop = I("KZ_TUNE_LDS_TOP", 0); o.tune.filmGather = I("KZ_TUNE_FILM_GATHER", 0);
         if (const char *e = std::getenv("KZ_PASS_ITEMS")) { long long v = std::atoll(e); if (v >= 1024) o.passItems = (uint64_t)v; }
         if (const char *e = std::getenv("KZ_DUAL_STREAM")) o.passesInFlight = std::atoi(e) ? 2 : 1;
         o.pipeline = I("KZ_PIPELINE", 0); o.traceKernel = I("KZ_TRACE_KERNEL", 1); o.mixed = I("KZ_TUNE_MIXED", 0);
@@ -351,7 +444,7 @@ static KzTune resolveTune(const KzTuning &t) {
     r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
     r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 6));
     r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
-    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0);
+    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0);
     r.ovf = nullptr; r.ovfStride = 0;
     return r;
 }
@@ -531,7 +624,14 @@ static constexpr size_t KZ_STATE_BYTES_PER_ITEM = 8 * sizeof(float4) + sizeof(ui
 static constexpr size_t KZ_SAMPLE_BYTES_PER_ITEM = 5 * sizeof(float);
 
 // ---- buffers of one pass context: sized for `need` items; nothing is left half-allocated on failure ----
-static int ctxEnsure(PassCtx &c, size_t need, bool wavefront, hipStream_t stream) {
+static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, hipStream_t stream) {
+    if (nPix > c.tapsCap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c.taps) (void)hipFree(c.taps);
+        c.taps = nullptr; c.tapsCap = 0;
+        KZ_ALLOC(&c.taps, nPix * 256);
+        c.tapsCap = nPix;
+    }
     if (need > c.sampCap) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.samp) (void)hipFree(c.samp);
@@ -733,7 +833,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         const int ci = dual ? (int)(pass & 1u) : 0;
         PassCtx &c = ds->ctx[ci];
         hipStream_t pst = dual ? ds->passStream[ci] : stream;
-        if ((rc = ctxEnsure(c, need, pipeline == 2, pst))) return rc;
+        if ((rc = ctxEnsure(c, need, ds->nPix, pipeline == 2, pst))) return rc;
         if (ds->eventsUsed == ds->events.size()) {
             EventPair ep; HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); ds->events.push_back(ep);
         }
@@ -753,11 +853,18 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         HIP_TRY(hipGetLastError());
         if (dual && pass > 0) HIP_TRY(hipStreamWaitEvent(pst, ds->evFilm[ci ^ 1], 0));       // film of the previous pass is in
         const dim3 fgrid((cols + KZ_FILM_TILE - 1) / KZ_FILM_TILE, (rows + KZ_FILM_TILE - 1) / KZ_FILM_TILE);
-        const int ftaps = P.tapHi - P.tapLo + 1, fr = KZ_FILM_TILE + ftaps - 1;
-        const size_t perSample = (size_t)(3 + 2 * ftaps) * fr * fr * sizeof(float);
-        const int fchunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)Sp, (size_t)8, (size_t)(64 * 1024) / perSample}));
-        const size_t fshm = perSample * fchunk;
-        hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, pst, P, ds->T.filter, ds->pixIndex, Sp, fchunk, sJx, sJy, sR, sG, sB, ds->film);
+        const int ftaps = P.tapHi - P.tapLo + 1;
+        if (ftaps <= KZ_TAPS_MAX && tune.filmGather != 1) {
+            // two kernels, every sample record read once (the tap sums do not depend on the film, so only kz_film_apply waits for the previous pass's film)
+            hipLaunchKernelGGL(kz_film_taps, dim3((ds->nPix + 1) / 2), dim3(128), 0, pst, P, ds->T.filter, ds->pixList, ds->nPix, Sp, sJx, sJy, sR, sG, sB, c.taps);
+            hipLaunchKernelGGL(kz_film_apply, fgrid, dim3(256), 0, pst, P, ds->pixIndex, (const float4 *)c.taps, ds->film);
+        } else {
+            const int fr = KZ_FILM_TILE + ftaps - 1;
+            const size_t perSample = (size_t)(3 + 2 * ftaps) * fr * fr * sizeof(float);
+            const int fchunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)Sp, (size_t)8, (size_t)(64 * 1024) / perSample}));
+            const size_t fshm = perSample * fchunk;
+            hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, pst, P, ds->T.filter, ds->pixIndex, Sp, fchunk, sJx, sJy, sR, sG, sB, ds->film);
+        }
         HIP_TRY(hipGetLastError());
         if (dual) HIP_TRY(hipEventRecord(ds->evFilm[ci], pst));
         if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }

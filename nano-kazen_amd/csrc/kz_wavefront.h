@@ -419,7 +419,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // the bounce before: both only depend on the same shade stage, and one launch has one tail instead of two.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment; such
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
-struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop; uint32_t *ovf; uint32_t ovfStride; };
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop, filmGather; uint32_t *ovf; uint32_t ovfStride; };
 
 template <int MODE, bool STATS, bool WIDE, bool KEYS = false, bool TOP = false>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,

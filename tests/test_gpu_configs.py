@@ -185,6 +185,9 @@ def test_state_budget_and_pass_options(gpu_lib, kz, O):
     for t in ({"keyStack": 1}, {"keyStack": 2, "ldsStack": 3}, {"ldsTop": 5}, {"ldsTop": 1000, "ldsStack": 6, "keyStack": 2}, {"keyStack": 1, "packetPrimary": 1}, {"keyStack": 2, "packetPrimary": 1, "ldsStack": 2}):
         sc.render(pass_items=npx * 4, tune=t)
         assert np.array_equal(sc.film(), one_at_a_time), t
+    # film reconstruction: per-pixel tap sums + apply (default) vs the staged gather of round 1: same weights, another summation order
+    sc.render(pass_items=npx * 4, tune={"filmGather": 1})
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
     ora = O.OracleScene(desc)
     assert l2(sc.rgb(one_at_a_time), ora.rgb(ora.render(threads=0))) < L2_TOL
 
