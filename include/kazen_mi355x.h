@@ -243,7 +243,7 @@ typedef struct KzTuning {
                                    1 = off, 2 = also in the per-lane closest-hit kernel (measured slower on C4) */
     int32_t ldsTop;             /* BVH4 packets of the top of the tree (breadth-first prefix) staged in LDS by the per-lane traversal
                                    kernels: 0 = default (off: measured no gain on C4, profiles/r02c_lds_top), n = that many (<= 1536) */
-    int32_t filmGather;         /* film reconstruction: 0 = default (per-pixel tap sums + apply for filters of <= 4 taps per axis, the staged
+    int32_t filmGather;         /* film reconstruction: 0 = default (per-pixel tap sums + apply for filters of <= 5 taps per axis, the staged
                                    gather otherwise), 1 = always the staged gather kernel of round 1 */
     int32_t reserved[5];
 } KzTuning;

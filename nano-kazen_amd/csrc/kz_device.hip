@@ -159,22 +159,24 @@ __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *_
     }
 }
 
-// ---- a25 in two kernels for filters of at most 4 taps per axis (every default of the reference: gaussian / mitchell radius 2, tent, box) ----
+// ---- a25 in two kernels for filters of at most 5 taps per axis (every default of the reference: gaussian / mitchell radius 2, tent, box) ----
 // kz_film_gather stages the samples of a 20x20 pixel neighbourhood three at a time (LDS) and so reads 12-byte pieces of the 256-byte
 // sample rows: rocprofv3 shows 23.5 GB fetched per pass for 2.65 GB of records, an HBM-bound 6.2 ms (profiles/r02b_packet_primary).
 // Here every record is read exactly once, coalesced:
 //   kz_film_taps   one wave per SOURCE pixel, lanes = its samples: validity, the separable filter weights of block.cpp:64-80 per tap,
-//                  the 4x4 weighted products of block.cpp:84; the products of 64 samples go through LDS ([sample][value], padded rows)
-//                  and lane v adds up value v over the samples IN SAMPLE ORDER -> 16 (rgb*w, w) sums per pixel, 256 B, one coalesced store.
-//   kz_film_apply  one thread per FILM pixel: adds, in a fixed (row, column) tap order, the tap sums of the <= 16 source pixels that reach it.
+//                  the taps x taps weighted products of block.cpp:84; the products of 64 samples go through LDS ([sample][value], padded rows)
+//                  and lane v adds up value v (and 64 + v) over the samples IN SAMPLE ORDER -> taps^2 (rgb*w, w) sums per pixel, coalesced stores.
+//   kz_film_apply  one thread per FILM pixel: adds, in a fixed (row, column) tap order, the tap sums of the <= taps^2 source pixels that reach it.
 // Deterministic (fixed orders everywhere); the weights are the ones kz_film_gather forms (block-relative positions, same table look-ups).
-#define KZ_TAPS_MAX 4
-#define KZ_TAPS_ROW 68                       // floats per sample row in LDS: 64 values + 4 pad -> conflict-free b128 stores and b32 column reads
+#define KZ_TAPS_MAX 5                        // gaussian / mitchell radius 2: taps -2..2
+template <int TAPS>
 __global__ __launch_bounds__(128) void kz_film_taps(KzParams P, const float *__restrict__ filter, const uint32_t *__restrict__ pixList, uint32_t nPix, uint32_t S,
                                                     const float *__restrict__ inJx, const float *__restrict__ inJy, const float *__restrict__ inR,
                                                     const float *__restrict__ inG, const float *__restrict__ inB, float *__restrict__ tapSums) {
+    constexpr int NV = TAPS * TAPS * 4;                 // values per sample: (rgb * w, w) per tap
+    constexpr int ROW = NV + ((NV % 32) == 4 ? 0 : (36 - (NV % 32)) % 32);     // floats per sample row: = 4 mod 32 -> conflict-free b128 stores, b32 column reads
     __shared__ float s_filter[KZ_FILTER_RESOLUTION + 1];
-    __shared__ __attribute__((aligned(16))) float s_prod[2][64 * KZ_TAPS_ROW];
+    __shared__ __attribute__((aligned(16))) float s_prod[2][64 * ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid <= KZ_FILTER_RESOLUTION) s_filter[tid] = filter[tid];
     __syncthreads();
@@ -183,13 +185,14 @@ __global__ __launch_bounds__(128) void kz_film_taps(KzParams P, const float *__r
     const uint32_t pxy = havePixel ? pixList[pl] : 0u;
     const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
     const int bx0 = px & ~31, by0 = py & ~31;                          // the reference block this pixel is rendered in
-    const int taps = P.tapHi - P.tapLo + 1;
     const float r = P.filterRadius, lf = P.lookupFactor;
-    float *row = s_prod[wave] + lane * KZ_TAPS_ROW;
-    float acc = 0.f;
+    float *row = s_prod[wave] + lane * ROW;
+    float acc0 = 0.f, acc1 = 0.f;                                      // lane v owns value v and, where NV > 64, value 64 + v
     for (uint32_t sBase = 0; sBase < S; sBase += 64u) {
         const uint32_t sIdx = sBase + (uint32_t)lane;
-        float wx[KZ_TAPS_MAX] = {0.f, 0.f, 0.f, 0.f}, wy[KZ_TAPS_MAX] = {0.f, 0.f, 0.f, 0.f};
+        float wx[TAPS], wy[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) { wx[t] = 0.f; wy[t] = 0.f; }
         float cr = 0.f, cg = 0.f, cb = 0.f;
         if (havePixel && sIdx < S) {
             const size_t gi = (size_t)pl * S + sIdx;
@@ -200,26 +203,28 @@ __global__ __launch_bounds__(128) void kz_film_taps(KzParams P, const float *__r
             const float posx = ((float)px + jx) - 0.5f - (float)(bx0 - P.border), posy = ((float)py + jy) - 0.5f - (float)(by0 - P.border);   // block.cpp:64-67
             const float lox = ceilf(posx - r), hix = floorf(posx + r), loy = ceilf(posy - r), hiy = floorf(posy + r);                     // block.cpp:70-73
 #pragma unroll
-            for (int t = 0; t < KZ_TAPS_MAX; ++t) {
-                if (t < taps) {
-                    const float xb = (float)(px + P.border - P.tapLo - t - bx0), yb = (float)(py + P.border - P.tapLo - t - by0);
-                    if (valid && !(xb < lox || xb > hix)) wx[t] = s_filter[(int)(fabsf(xb - posx) * lf)];                                 // block.cpp:77-80
-                    if (valid && !(yb < loy || yb > hiy)) wy[t] = s_filter[(int)(fabsf(yb - posy) * lf)];
-                }
+            for (int t = 0; t < TAPS; ++t) {
+                const float xb = (float)(px + P.border - P.tapLo - t - bx0), yb = (float)(py + P.border - P.tapLo - t - by0);
+                if (valid && !(xb < lox || xb > hix)) wx[t] = s_filter[(int)(fabsf(xb - posx) * lf)];                                     // block.cpp:77-80
+                if (valid && !(yb < loy || yb > hiy)) wy[t] = s_filter[(int)(fabsf(yb - posy) * lf)];
             }
         }
 #pragma unroll
-        for (int ty = 0; ty < KZ_TAPS_MAX; ++ty)
+        for (int ty = 0; ty < TAPS; ++ty)
 #pragma unroll
-            for (int tx = 0; tx < KZ_TAPS_MAX; ++tx)
-                *reinterpret_cast<float4 *>(row + (ty * KZ_TAPS_MAX + tx) * 4) = make_float4(cr * wx[tx] * wy[ty], cg * wx[tx] * wy[ty], cb * wx[tx] * wy[ty], 1.0f * wx[tx] * wy[ty]);   // block.cpp:84
+            for (int tx = 0; tx < TAPS; ++tx)
+                *reinterpret_cast<float4 *>(row + (ty * TAPS + tx) * 4) = make_float4(cr * wx[tx] * wy[ty], cg * wx[tx] * wy[ty], cb * wx[tx] * wy[ty], 1.0f * wx[tx] * wy[ty]);   // block.cpp:84
         __syncthreads();
         const uint32_t n = min(64u, S - sBase);
         const float *col = s_prod[wave] + lane;
-        for (uint32_t k = 0; k < n; ++k) acc += col[k * KZ_TAPS_ROW];       // value `lane` of sample sBase + k, in sample order
+        for (uint32_t k = 0; k < n; ++k) acc0 += col[k * ROW];             // value `lane` of sample sBase + k, in sample order
+        if (NV > 64 && lane < NV - 64) for (uint32_t k = 0; k < n; ++k) acc1 += col[k * ROW + 64];
         __syncthreads();
     }
-    if (havePixel) tapSums[(size_t)pl * 64 + lane] = acc;
+    if (havePixel) {
+        if (lane < NV) tapSums[(size_t)pl * NV + lane] = acc0;
+        if (NV > 64 && lane < NV - 64) tapSums[(size_t)pl * NV + 64 + lane] = acc1;
+    }
 }
 
 __global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *__restrict__ pixIndex, const float4 *__restrict__ tapSums, float4 *__restrict__ film) {
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *
             if (x < 0 || x >= P.width) continue;
             const int32_t pl = pixIndex[y * P.width + x];
             if (pl < 0) continue;
-            const float4 t = tapSums[(size_t)pl * 16 + ty * KZ_TAPS_MAX + tx];
+            const float4 t = tapSums[(size_t)pl * (taps * taps) + ty * taps + tx];
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             any = true;
         }
@@ -356,7 +361,7 @@ struct PassCtx {
     float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: 16 float4 per pixel of the tile set
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
-    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 256; }
+    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400; }
     void release() {
         for (void *p : wfAllocs) (void)hipFree(p);
         wfAllocs.clear(); wfCap = 0; wf = KzWf{};
@@ -629,7 +634,7 @@ static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, hipSt
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.taps) (void)hipFree(c.taps);
         c.taps = nullptr; c.tapsCap = 0;
-        KZ_ALLOC(&c.taps, nPix * 256);
+        KZ_ALLOC(&c.taps, nPix * (size_t)(KZ_TAPS_MAX * KZ_TAPS_MAX * 16));
         c.tapsCap = nPix;
     }
     if (need > c.sampCap) {
@@ -856,7 +861,9 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         const int ftaps = P.tapHi - P.tapLo + 1;
         if (ftaps <= KZ_TAPS_MAX && tune.filmGather != 1) {
             // two kernels, every sample record read once (the tap sums do not depend on the film, so only kz_film_apply waits for the previous pass's film)
-            hipLaunchKernelGGL(kz_film_taps, dim3((ds->nPix + 1) / 2), dim3(128), 0, pst, P, ds->T.filter, ds->pixList, ds->nPix, Sp, sJx, sJy, sR, sG, sB, c.taps);
+#define KZ_FILM_TAPS(N) hipLaunchKernelGGL(kz_film_taps<N>, dim3((ds->nPix + 1) / 2), dim3(128), 0, pst, P, ds->T.filter, ds->pixList, ds->nPix, Sp, sJx, sJy, sR, sG, sB, c.taps)
+            switch (ftaps) { case 1: KZ_FILM_TAPS(1); break; case 2: KZ_FILM_TAPS(2); break; case 3: KZ_FILM_TAPS(3); break; case 4: KZ_FILM_TAPS(4); break; default: KZ_FILM_TAPS(5); break; }
+#undef KZ_FILM_TAPS
             hipLaunchKernelGGL(kz_film_apply, fgrid, dim3(256), 0, pst, P, ds->pixIndex, (const float4 *)c.taps, ds->film);
         } else {
             const int fr = KZ_FILM_TILE + ftaps - 1;
