@@ -162,72 +162,82 @@ __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *_
 // ---- a25 in two kernels for filters of at most 5 taps per axis (every default of the reference: gaussian / mitchell radius 2, tent, box) ----
 // kz_film_gather stages the samples of a 20x20 pixel neighbourhood three at a time (LDS) and so reads 12-byte pieces of the 256-byte
 // sample rows: rocprofv3 shows 23.5 GB fetched per pass for 2.65 GB of records, an HBM-bound 6.2 ms (profiles/r02b_packet_primary).
-// Here every record is read exactly once, coalesced:
-//   kz_film_taps   one wave per SOURCE pixel, lanes = its samples: validity, the separable filter weights of block.cpp:64-80 per tap,
-//                  the taps x taps weighted products of block.cpp:84; the products of 64 samples go through LDS ([sample][value], padded rows)
-//                  and lane v adds up value v (and 64 + v) over the samples IN SAMPLE ORDER -> taps^2 (rgb*w, w) sums per pixel, coalesced stores.
+// Here every record is read exactly once:
+//   kz_film_taps   one THREAD per SOURCE pixel, one wave per 64 consecutive pixels of the pass's pixel list (an 8x8 block). The wave copies
+//                  16 samples of its 64 pixels at a time into LDS with coalesced 64-byte pieces, transposed to [sample][pixel]; each thread
+//                  then walks ITS pixel's samples in sample order - validity, the separable filter weights of block.cpp:64-80 per tap, the
+//                  taps x taps weighted products of block.cpp:84 - into taps^2 (rgb*w, w) accumulators that never leave its registers,
+//                  and stores them tap-major ([tap][pixel]: coalesced).
 //   kz_film_apply  one thread per FILM pixel: adds, in a fixed (row, column) tap order, the tap sums of the <= taps^2 source pixels that reach it.
-// Deterministic (fixed orders everywhere); the weights are the ones kz_film_gather forms (block-relative positions, same table look-ups).
+// Deterministic (per pixel the samples are added in index order, as the reference's put() loop does; fixed tap order in the second
+// kernel); the weights are the ones kz_film_gather forms (block-relative positions, same table look-ups).
 #define KZ_TAPS_MAX 5                        // gaussian / mitchell radius 2: taps -2..2
+#define KZ_TAPS_CHUNK 16                     // samples per staging round (64 B of every sample row)
 template <int TAPS>
-__global__ __launch_bounds__(128) void kz_film_taps(KzParams P, const float *__restrict__ filter, const uint32_t *__restrict__ pixList, uint32_t nPix, uint32_t S,
-                                                    const float *__restrict__ inJx, const float *__restrict__ inJy, const float *__restrict__ inR,
-                                                    const float *__restrict__ inG, const float *__restrict__ inB, float *__restrict__ tapSums) {
-    constexpr int NV = TAPS * TAPS * 4;                 // values per sample: (rgb * w, w) per tap
-    constexpr int ROW = NV + ((NV % 32) == 4 ? 0 : (36 - (NV % 32)) % 32);     // floats per sample row: = 4 mod 32 -> conflict-free b128 stores, b32 column reads
+__global__ __launch_bounds__(64) void kz_film_taps(KzParams P, const float *__restrict__ filter, const uint32_t *__restrict__ pixList, uint32_t nPix, uint32_t S,
+                                                   const float *__restrict__ inJx, const float *__restrict__ inJy, const float *__restrict__ inR,
+                                                   const float *__restrict__ inG, const float *__restrict__ inB, float4 *__restrict__ tapSums) {
     __shared__ float s_filter[KZ_FILTER_RESOLUTION + 1];
-    __shared__ __attribute__((aligned(16))) float s_prod[2][64 * ROW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid <= KZ_FILTER_RESOLUTION) s_filter[tid] = filter[tid];
-    __syncthreads();
-    const uint32_t pl = blockIdx.x * 2 + wave;
-    const bool havePixel = pl < nPix;                                  // (no early return: both waves meet at the barriers)
+    __shared__ float s_in[5][KZ_TAPS_CHUNK][65];                       // [array][sample][pixel], rows padded against bank conflicts of the transposing store
+    const int lane = threadIdx.x;
+    if (lane <= KZ_FILTER_RESOLUTION) s_filter[lane] = filter[lane];
+    const uint32_t pl0 = blockIdx.x * 64u, pl = pl0 + (uint32_t)lane;
+    const bool havePixel = pl < nPix;
     const uint32_t pxy = havePixel ? pixList[pl] : 0u;
     const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
     const int bx0 = px & ~31, by0 = py & ~31;                          // the reference block this pixel is rendered in
     const float r = P.filterRadius, lf = P.lookupFactor;
-    float *row = s_prod[wave] + lane * ROW;
-    float acc0 = 0.f, acc1 = 0.f;                                      // lane v owns value v and, where NV > 64, value 64 + v
-    for (uint32_t sBase = 0; sBase < S; sBase += 64u) {
-        const uint32_t sIdx = sBase + (uint32_t)lane;
-        float wx[TAPS], wy[TAPS];
+    float xb[TAPS], yb[TAPS];                                          // block-relative film coordinates this pixel reaches through tap t
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) { wx[t] = 0.f; wy[t] = 0.f; }
-        float cr = 0.f, cg = 0.f, cb = 0.f;
-        if (havePixel && sIdx < S) {
-            const size_t gi = (size_t)pl * S + sIdx;
-            const float jx = inJx[gi], jy = inJy[gi];
-            cr = inR[gi]; cg = inG[gi]; cb = inB[gi];
-            const bool valid = cr >= 0.f && cg >= 0.f && cb >= 0.f && isfinite(cr) && isfinite(cg) && isfinite(cb);   // Color3f::isValid
-            if (!valid) { cr = 0.f; cg = 0.f; cb = 0.f; }
-            const float posx = ((float)px + jx) - 0.5f - (float)(bx0 - P.border), posy = ((float)py + jy) - 0.5f - (float)(by0 - P.border);   // block.cpp:64-67
-            const float lox = ceilf(posx - r), hix = floorf(posx + r), loy = ceilf(posy - r), hiy = floorf(posy + r);                     // block.cpp:70-73
+    for (int t = 0; t < TAPS; ++t) { xb[t] = (float)(px + P.border - P.tapLo - t - bx0); yb[t] = (float)(py + P.border - P.tapLo - t - by0); }
+    float4 acc[TAPS * TAPS];
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const float xb = (float)(px + P.border - P.tapLo - t - bx0), yb = (float)(py + P.border - P.tapLo - t - by0);
-                if (valid && !(xb < lox || xb > hix)) wx[t] = s_filter[(int)(fabsf(xb - posx) * lf)];                                     // block.cpp:77-80
-                if (valid && !(yb < loy || yb > hiy)) wy[t] = s_filter[(int)(fabsf(yb - posy) * lf)];
+    for (int i = 0; i < TAPS * TAPS; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *const in[5] = {inJx, inJy, inR, inG, inB};
+    const uint32_t nRows = min(64u, nPix - min(nPix, pl0));            // pixels of this wave
+    for (uint32_t c0 = 0; c0 < S; c0 += KZ_TAPS_CHUNK) {
+        const uint32_t n = min((uint32_t)KZ_TAPS_CHUNK, S - c0);
+        __syncthreads();
+        for (uint32_t i = lane; i < nRows * KZ_TAPS_CHUNK; i += 64u) {  // consecutive lanes: consecutive samples of one pixel (64-B pieces), then the next pixel
+            const uint32_t p = i / KZ_TAPS_CHUNK, k = i % KZ_TAPS_CHUNK;
+            if (k < n) {
+                const size_t gi = (size_t)(pl0 + p) * S + c0 + k;
+#pragma unroll
+                for (int a = 0; a < 5; ++a) s_in[a][k][p] = in[a][gi];
             }
         }
-#pragma unroll
-        for (int ty = 0; ty < TAPS; ++ty)
-#pragma unroll
-            for (int tx = 0; tx < TAPS; ++tx)
-                *reinterpret_cast<float4 *>(row + (ty * TAPS + tx) * 4) = make_float4(cr * wx[tx] * wy[ty], cg * wx[tx] * wy[ty], cb * wx[tx] * wy[ty], 1.0f * wx[tx] * wy[ty]);   // block.cpp:84
         __syncthreads();
-        const uint32_t n = min(64u, S - sBase);
-        const float *col = s_prod[wave] + lane;
-        for (uint32_t k = 0; k < n; ++k) acc0 += col[k * ROW];             // value `lane` of sample sBase + k, in sample order
-        if (NV > 64 && lane < NV - 64) for (uint32_t k = 0; k < n; ++k) acc1 += col[k * ROW + 64];
-        __syncthreads();
+        if (havePixel) {
+            for (uint32_t k = 0; k < n; ++k) {
+                const float jx = s_in[0][k][lane], jy = s_in[1][k][lane];
+                float cr = s_in[2][k][lane], cg = s_in[3][k][lane], cb = s_in[4][k][lane];
+                const bool valid = cr >= 0.f && cg >= 0.f && cb >= 0.f && isfinite(cr) && isfinite(cg) && isfinite(cb);   // Color3f::isValid
+                if (!valid) continue;                                  // an invalid sample carries weight 0 everywhere: adds exact zeros
+                const float posx = ((float)px + jx) - 0.5f - (float)(bx0 - P.border), posy = ((float)py + jy) - 0.5f - (float)(by0 - P.border);   // block.cpp:64-67
+                const float lox = ceilf(posx - r), hix = floorf(posx + r), loy = ceilf(posy - r), hiy = floorf(posy + r);                     // block.cpp:70-73
+                float wx[TAPS], wy[TAPS];
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    wx[t] = !(xb[t] < lox || xb[t] > hix) ? s_filter[(int)(fabsf(xb[t] - posx) * lf)] : 0.f;                                 // block.cpp:77-80
+                    wy[t] = !(yb[t] < loy || yb[t] > hiy) ? s_filter[(int)(fabsf(yb[t] - posy) * lf)] : 0.f;
+                }
+#pragma unroll
+                for (int ty = 0; ty < TAPS; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < TAPS; ++tx) {
+                        float4 &a = acc[ty * TAPS + tx];
+                        a.x += cr * wx[tx] * wy[ty]; a.y += cg * wx[tx] * wy[ty]; a.z += cb * wx[tx] * wy[ty]; a.w += 1.0f * wx[tx] * wy[ty];     // block.cpp:84
+                    }
+            }
+        }
     }
     if (havePixel) {
-        if (lane < NV) tapSums[(size_t)pl * NV + lane] = acc0;
-        if (NV > 64 && lane < NV - 64) tapSums[(size_t)pl * NV + 64 + lane] = acc1;
+#pragma unroll
+        for (int i = 0; i < TAPS * TAPS; ++i) tapSums[(size_t)i * nPix + pl] = acc[i];
     }
 }
 
-__global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *__restrict__ pixIndex, const float4 *__restrict__ tapSums, float4 *__restrict__ film) {
+__global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *__restrict__ pixIndex, const float4 *__restrict__ tapSums, uint32_t nPix, float4 *__restrict__ film) {
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border;
     const int fx = blockIdx.x * 16 + (threadIdx.x & 15), fy = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (fx >= cols || fy >= rows) return;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *
             if (x < 0 || x >= P.width) continue;
             const int32_t pl = pixIndex[y * P.width + x];
             if (pl < 0) continue;
-            const float4 t = tapSums[(size_t)pl * (taps * taps) + ty * taps + tx];
+            const float4 t = tapSums[(size_t)(ty * taps + tx) * nPix + (size_t)pl];
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             any = true;
         }
@@ -861,10 +871,10 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         const int ftaps = P.tapHi - P.tapLo + 1;
         if (ftaps <= KZ_TAPS_MAX && tune.filmGather != 1) {
             // two kernels, every sample record read once (the tap sums do not depend on the film, so only kz_film_apply waits for the previous pass's film)
-#define KZ_FILM_TAPS(N) hipLaunchKernelGGL(kz_film_taps<N>, dim3((ds->nPix + 1) / 2), dim3(128), 0, pst, P, ds->T.filter, ds->pixList, ds->nPix, Sp, sJx, sJy, sR, sG, sB, c.taps)
+#define KZ_FILM_TAPS(N) hipLaunchKernelGGL(kz_film_taps<N>, dim3((ds->nPix + 63) / 64), dim3(64), 0, pst, P, ds->T.filter, ds->pixList, ds->nPix, Sp, sJx, sJy, sR, sG, sB, (float4 *)c.taps)
             switch (ftaps) { case 1: KZ_FILM_TAPS(1); break; case 2: KZ_FILM_TAPS(2); break; case 3: KZ_FILM_TAPS(3); break; case 4: KZ_FILM_TAPS(4); break; default: KZ_FILM_TAPS(5); break; }
 #undef KZ_FILM_TAPS
-            hipLaunchKernelGGL(kz_film_apply, fgrid, dim3(256), 0, pst, P, ds->pixIndex, (const float4 *)c.taps, ds->film);
+            hipLaunchKernelGGL(kz_film_apply, fgrid, dim3(256), 0, pst, P, ds->pixIndex, (const float4 *)c.taps, ds->nPix, ds->film);
         } else {
             const int fr = KZ_FILM_TILE + ftaps - 1;
             const size_t perSample = (size_t)(3 + 2 * ftaps) * fr * fr * sizeof(float);
