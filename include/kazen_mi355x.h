@@ -245,7 +245,9 @@ typedef struct KzTuning {
                                    kernels: 0 = default (off: measured no gain on C4, profiles/r02c_lds_top), n = that many (<= 1536) */
     int32_t filmGather;         /* film reconstruction: 0 = default (per-pixel tap sums + apply for filters of <= 5 taps per axis, the staged
                                    gather otherwise), 1 = always the staged gather kernel of round 1 */
-    int32_t reserved[5];
+    int32_t leafQueue;          /* bounce / shadow traversal with a decoupled leaf phase (kz_wf_trace_dq: per-wave job queue in LDS): 0 = default,
+                                   1 = off, 2 = on */
+    int32_t reserved[4];
 } KzTuning;
 
 typedef struct KzRenderOpts {

@@ -368,16 +368,18 @@ struct EventPair { hipEvent_t a, b; };
 struct PassCtx {
     KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0;
     float *samp = nullptr; size_t sampCap = 0;                   // five SoA planes: jx | jy | r | g | b
-    float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: 16 float4 per pixel of the tile set
+    float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: taps^2 float4 per pixel of the tile set
+    uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
-    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400; }
+    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4; }
     void release() {
         for (void *p : wfAllocs) (void)hipFree(p);
         wfAllocs.clear(); wfCap = 0; wf = KzWf{};
         if (samp) (void)hipFree(samp); samp = nullptr; sampCap = 0;
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
         if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
+        if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
     }
 };
 struct KzDeviceState {
@@ -444,7 +446,7 @@ static const EnvOverride &envOverride() {
         auto I = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
         o.tune.refill = I("KZ_TUNE_REFILL", 0); o.tune.postpone = I("KZ_TUNE_POSTPONE", 0); o.tune.batch = I("KZ_TUNE_BATCH", 0);
         o.tune.traceBlocksPerCU = I("KZ_TUNE_TRAV_BLOCKS", 0); o.tune.shadeBlocksPerCU = I("KZ_TUNE_SHADE_BLOCKS", 0);
-        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0); o.tune.ldsTop = I("KZ_TUNE_LDS_TOP", 0); o.tune.filmGather = I("KZ_TUNE_FILM_GATHER", 0);
+        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0); o.tune.ldsTop = I("KZ_TUNE_LDS_TOP", 0); o.tune.filmGather = I("KZ_TUNE_FILM_GATHER", 0); o.tune.leafQueue = I("KZ_TUNE_LEAF_QUEUE", 0);
         if (const char *e = std::getenv("KZ_PASS_ITEMS")) { long long v = std::atoll(e); if (v >= 1024) o.passItems = (uint64_t)v; }
         if (const char *e = std::getenv("KZ_DUAL_STREAM")) o.passesInFlight = std::atoi(e) ? 2 : 1;
         o.pipeline = I("KZ_PIPELINE", 0); o.traceKernel = I("KZ_TRACE_KERNEL", 1); o.mixed = I("KZ_TUNE_MIXED", 0);
@@ -459,7 +461,7 @@ static KzTune resolveTune(const KzTuning &t) {
     r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
     r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 6));
     r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
-    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0);
+    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0); r.leafQueue = pick(t.leafQueue, e.leafQueue, 0);
     r.ovf = nullptr; r.ovfStride = 0;
     return r;
 }
@@ -664,7 +666,7 @@ static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, hipSt
         for (float4 **p : {&W.rayA, &W.rayB, &W.hit, &W.thr, &W.misc, &W.shA, &W.shB, &W.shL}) if (!rc) rc = alloc((void **)p, need * sizeof(float4));
         if (!rc) rc = alloc((void **)&W.smp, need * sizeof(uint4));
         for (int q = 0; q < 3; ++q) if (!rc) rc = alloc((void **)&W.queue[q], need * sizeof(uint32_t));
-        if (!rc) rc = alloc((void **)&W.counts, 4 * 520 * sizeof(uint32_t));
+        if (!rc) rc = alloc((void **)&W.counts, 8 * 520 * sizeof(uint32_t));
         if (rc) { for (void *p : c.wfAllocs) (void)hipFree(p); c.wfAllocs.clear(); return rc; }
         c.wf = W; c.wfCap = need;
     }
@@ -703,9 +705,33 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
         }
         tune.ovf = c.ovf; tune.ovfStride = (uint32_t)stride;
     }
+    // decoupled leaf queue (kz_wf_trace_dq): bounce rays, and shadow rays when the exact any-hit form applies (shadowFast)
+    const bool dq = tune.wide && tune.leafQueue == 2 && !st;
+    const int dqLS = std::max(2, std::min(tune.ldsStack, std::min(stackBound, 9)));                 // 9 rows + queue + results = 19.4 KB per workgroup: 8 per CU
+    const size_t dqLds = (size_t)4 * ((size_t)(dqLS + 1) * 64 + 128 + 192 + 2 * KZ_DQ_JOBS) * sizeof(uint32_t);
+    KzTune tuneDq = tune; tuneDq.ldsStack = dqLS;
+    if (dq) {
+        const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - dqLS);
+        if (needOvf > c.ovfCap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (c.ovf) (void)hipFree(c.ovf);
+            c.ovf = nullptr; c.ovfCap = 0;
+            KZ_ALLOC(&c.ovf, needOvf * sizeof(uint32_t));
+            c.ovfCap = needOvf;
+            tune.ovf = c.ovf;
+        }
+        tuneDq.ovf = c.ovf; tuneDq.ovfStride = (uint32_t)stride;
+        if (items > c.litCap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (c.litQueue) (void)hipFree(c.litQueue);
+            c.litQueue = nullptr; c.litCap = 0;
+            KZ_ALLOC(&c.litQueue, (size_t)items * sizeof(uint32_t));
+            c.litCap = items;
+        }
+    }
     const int maxDepth = P.maxDepth;
     c.stageUsed = 0;
-    HIP_TRY(hipMemsetAsync(W.counts, 0, 4 * 520 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(W.counts, 0, 8 * 520 * sizeof(uint32_t), stream));
     { int rc_ = stageMark(c, stream, -1); if (rc_) return rc_; }
     hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, ds->pixList, items, Sp, sBegin);
     { int rc_ = stageMark(c, stream, 0); if (rc_) return rc_; }
@@ -756,12 +782,23 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
             continue;
         }
         if (P.nLights > 0) {
-            if (traceKernel) KZ_TRACE(2, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3);
+            if (dq && P.shadowFast) {
+                uint32_t *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
+                hipLaunchKernelGGL((kz_wf_trace_dq<2, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, tuneDq,
+                                   c.litQueue, litCount);
+                KZ_TRACE(2, (const uint32_t *)c.litQueue, (const uint32_t *)litCount, 0u, litHead);      // the few rays that cross an invisible light
+            }
+            else if (traceKernel) KZ_TRACE(2, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3);
             else if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
             else hipLaunchKernelGGL(kz_wf_shadow<false>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
         }
         { int rc_ = stageMark(c, stream, 3); if (rc_) return rc_; }
-        if (needExtend) { KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2); int rc_ = stageMark(c, stream, 1); if (rc_) return rc_; }
+        if (needExtend) {
+            if (dq) hipLaunchKernelGGL((kz_wf_trace_dq<0, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, tuneDq,
+                                       (uint32_t *)nullptr, (uint32_t *)nullptr);
+            else KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2);
+            int rc_ = stageMark(c, stream, 1); if (rc_) return rc_;
+        }
         cur = nextQ; curCount = nextCount;
     }
 #undef KZ_EXTEND

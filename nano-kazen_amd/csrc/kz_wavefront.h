@@ -419,7 +419,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // the bounce before: both only depend on the same shade stage, and one launch has one tail instead of two.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment; such
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
-struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop, filmGather; uint32_t *ovf; uint32_t ovfStride; };
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop, filmGather, leafQueue; uint32_t *ovf; uint32_t ovfStride; };
 
 template <int MODE, bool STATS, bool WIDE, bool KEYS = false, bool TOP = false>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
@@ -701,6 +701,224 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 //   * at a leaf every lane runs the same Moeller-Trumbore test (triTest) and keeps its own closest hit.
 // Every lane sees a superset of the nodes its own traversal would visit and the boxes are conservative, so each lane's closest
 // hit (t, u, v, triangle; ties to the lower triangle id) is the one kz_wf_trace finds: the films stay bit-identical.
+// ---- traversal with a decoupled leaf phase (tune.leafQueue) --------------------------------------------------------------
+// kz_wf_trace alternates a node phase and a leaf phase per wave; the lane statistics of the bounce rays (-DKZ_LANESTAT) show what that
+// costs: of 51 lanes that hold a ray, 37 step through a node while 14 wait with a leaf, and every 2.8 node steps a leaf phase runs
+// with 22 lanes. Here a lane that reaches a leaf does not wait: it appends a (lane, leaf) JOB to a per-wave queue in LDS and goes on
+// with its next stack entry; whenever 64 jobs are waiting (or no lane can descend) the whole wave runs them, one job per lane:
+// the job lane fetches the OWNER's ray with ds_bpermute, runs Mesh::rayIntersect on the leaf's triangles and publishes a hit with a
+// 64-bit LDS atomicMin on (bits of t, triangle id) - exactly the tie rule of the closest hit (lower id on equal t) - or, for an any-hit
+// shadow ray, by raising the owner's flag. An owner picks up its current closest distance from LDS before every node step (a stale,
+// larger tmax only costs visits, never a hit), and publishes its result once its stack is empty AND its last job has run.
+// MODE 0: closest hit -> W.hit; MODE 2: any-hit shadow test -> adds W.shL (rays that would need the literal walk-through of an
+// invisible light are not handled here: the host uses this kernel only when shadowFast holds and routes those rays to kz_wf_trace).
+#define KZ_DQ_JOBS 128                       // ring capacity (a batch of 64 is run before a step could overflow it)
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace_dq(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
+                                                        const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune,
+                                                        uint32_t *__restrict__ literalQueue, uint32_t *__restrict__ literalCount) {
+    extern __shared__ uint32_t s_dq[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int LS = tune.ldsStack;
+    // per-wave LDS: [LS + 1][64] stack | best[64] u64 | res[3][64] | jobLeaf[128] | jobOwner[128]
+    const int waveWords = (LS + 1) * 64 + 128 + 192 + 2 * KZ_DQ_JOBS;
+    uint32_t *const wbase = s_dq + wave * waveWords;
+    uint32_t *const stk = wbase + lane;                                          // row stride 64
+    unsigned long long *const best = reinterpret_cast<unsigned long long *>(wbase + (LS + 1) * 64);
+    uint32_t *const res = wbase + (LS + 1) * 64 + 128;                           // [3][64]: triangle, u, v
+    uint32_t *const jobLeaf = res + 192, *const jobOwner = jobLeaf + KZ_DQ_JOBS;
+    uint32_t *const ovfBase = tune.ovf;
+    const uint32_t ovfLane = blockIdx.x * KZ_BLOCK + threadIdx.x;
+    const size_t ovfStride = tune.ovfStride;
+    const uint32_t count = countPtr ? *countPtr : countImm;
+    const uint32_t root = P.rootRef4;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    const uint32_t nWaves = gridDim.x * (KZ_BLOCK / 64), waveId = blockIdx.x * (KZ_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t batch = max(64u, min((uint32_t)tune.batch, ((count + nWaves - 1) / nWaves + 63u) & ~63u));
+    const bool staticOnly = (unsigned long long)nWaves * batch >= count;
+    uint32_t poolNext = min(waveId * batch, count), poolEnd = min(poolNext + batch, count);
+    bool exhausted = false;
+    // lane state: 0 idle, 1 traversing (cur valid), 2 draining (stack empty, waiting for its last job)
+    int state = 0;
+    V3 o = mk(0.f), d = mk(0.f);
+    float rx = 0.f, ry = 0.f, rz = 0.f, tmin = 0.f, tmax = 0.f;
+    uint32_t cur = 0, slot = 0, lastSeq = 0; int sp = 0;
+    uint32_t jobHead = 0, jobCount = 0, enq = 0, done = 0;                       // wave-uniform
+
+    auto popNext = [&]() {                                                       // next stack entry -> cur, or start draining
+        if (sp > 0) {
+            --sp;
+            const int row = min(sp, LS) * 64;
+            uint32_t v = stk[row];
+            if (sp >= LS) v = ovfBase[(size_t)(sp - LS) * ovfStride + ovfLane];
+            cur = v;
+        } else state = 2;
+    };
+    auto push = [&](uint32_t v) {
+        if (sp < LS) stk[sp * 64] = v; else ovfBase[(size_t)(sp - LS) * ovfStride + ovfLane] = v;
+        ++sp;
+    };
+
+    for (;;) {
+        // ---- refill idle lanes
+        const unsigned long long busy = __ballot(state != 0);
+        const int nBusy = __popcll(busy);
+        if (nBusy < tune.refill && !exhausted) {
+            if (poolNext >= poolEnd) {
+                uint32_t b = count;
+                if (!staticOnly) {
+                    if (lane == 0) b = atomicAdd(head, batch);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    b = (b < 0xFFFFFFFFu - nWaves * batch) ? b + nWaves * batch : count;
+                }
+                if (b >= count) { exhausted = true; poolNext = poolEnd = 0; }
+                else { poolNext = b; poolEnd = min(b + batch, count); }
+            }
+            if (!exhausted) {
+                const uint32_t take = min((uint32_t)(64 - nBusy), poolEnd - poolNext);
+                const unsigned long long idle = ~busy;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (state == 0 && rank < take) {
+                    const uint32_t qi = poolNext + rank;
+                    slot = queue ? queue[qi] : qi;
+                    float4 a, b;
+                    if (MODE == 0) { a = W.rayA[slot]; b = W.rayB[slot]; }
+                    else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w); }
+                    o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); tmin = a.w; tmax = b.w;
+                    if (STATS) cn.rays++;
+                    rx = 1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
+                    ry = 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
+                    rz = 1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
+                    bool go = (root != 0xFFFFFFFFu) && rayIsFinite(o, d);
+                    if (go && MODE == 2 && invisibleLightOnSegment(P, T, o, d, rx, ry, rz, tmin, tmax)) {
+                        // the reference's walk-through of an invisible light (integrator.cpp:257-278): left to kz_wf_trace<2>
+                        literalQueue[atomicAdd(literalCount, 1u)] = slot;
+                        go = false;
+                    } else if (!go) {
+                        // a ray that cannot hit anything (empty scene, non-finite origin / direction)
+                        if (MODE == 0) W.hit[slot] = make_float4(KZ_INF, 0.f, 0.f, 0.f);
+                        else { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; }
+                    }
+                    if (go) {
+                        cur = root; sp = 0; state = 1; lastSeq = done;
+                        best[lane] = ~0ull;                                       // no hit yet (MODE 2: raised to 0 by an occluding triangle)
+                    }
+                }
+                poolNext += take;
+            }
+        }
+        const unsigned long long trav = __ballot(state == 1);
+        if (trav == 0ull && jobCount == 0u && __ballot(state == 2) == 0ull) { if (exhausted) break; continue; }
+
+        // ---- node step for every traversing lane that holds an inner node
+        if (state == 1 && !(cur & 0x80000000u)) {
+            // the closest hit the job lanes have found for this ray so far (MODE 2: an occluder ends the ray)
+            const uint32_t bestHi = (uint32_t)(best[lane] >> 32);
+            if (MODE == 2 && bestHi == 0u) { state = 2; sp = 0; }
+            else {
+                if (MODE == 0) tmax = __uint_as_float(min(__float_as_uint(tmax), bestHi));       // positive floats order as their bits; ~0 = no hit
+                if (STATS) cn.nodes++;
+                uint32_t key[4]; uint4 refs;
+                node4Keys(T, cur, o, rx, ry, rz, tmin, tmax, key, refs);
+                bool p0, p1, p2, p3; uint32_t nxt; bool any;
+                if (MODE == 2) {                                                     // any hit: children in slot order
+                    const bool h0 = key[0] != 0xFFFFFFFFu, h1 = key[1] != 0xFFFFFFFFu, h2 = key[2] != 0xFFFFFFFFu, h3 = key[3] != 0xFFFFFFFFu;
+                    any = h0 || h1 || h2 || h3;
+                    nxt = h0 ? refs.x : (h1 ? refs.y : (h2 ? refs.z : refs.w));
+                    p0 = false; p1 = h1 && h0; p2 = h2 && (h0 || h1); p3 = h3 && (h0 || h1 || h2);
+                } else {                                                             // nearest hit child first, the others in slot order
+                    const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+                    any = kmin != 0xFFFFFFFFu;
+                    nxt = pick4b(refs, kmin);
+                    p0 = key[0] != 0xFFFFFFFFu && key[0] != kmin; p1 = key[1] != 0xFFFFFFFFu && key[1] != kmin;
+                    p2 = key[2] != 0xFFFFFFFFu && key[2] != kmin; p3 = key[3] != 0xFFFFFFFFu && key[3] != kmin;
+                }
+                const int c1 = (int)p0, c2 = c1 + (int)p1, c3 = c2 + (int)p2, np = c3 + (int)p3;
+                if (sp + 3 <= LS) {                                                  // branch-free: a missed child lands on the scratch row
+                    if (MODE != 2) stk[(p0 ? sp : LS) * 64] = refs.x;
+                    stk[(p1 ? sp + c1 : LS) * 64] = refs.y; stk[(p2 ? sp + c2 : LS) * 64] = refs.z; stk[(p3 ? sp + c3 : LS) * 64] = refs.w;
+                    sp += np;
+                } else {
+                    if (p0) push(refs.x);
+                    if (p1) push(refs.y);
+                    if (p2) push(refs.z);
+                    if (p3) push(refs.w);
+                }
+                if (any) cur = nxt; else popNext();
+            }
+        }
+        // ---- room for this step's leaves? run a batch first if the ring could overflow
+        bool runJobs = jobCount > KZ_DQ_JOBS - 64;
+        if (!runJobs) {
+            // ---- lanes that hold a leaf hand it to the job queue and move on
+            const bool atLeaf = state == 1 && (cur & 0x80000000u);
+            const unsigned long long lm = __ballot(atLeaf);
+            if (lm) {
+                if (atLeaf) {
+                    const uint32_t pos = (jobHead + jobCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u))) & (KZ_DQ_JOBS - 1);
+                    jobLeaf[pos] = cur; jobOwner[pos] = (uint32_t)lane;
+                }
+                const uint32_t n = (uint32_t)__popcll(lm);
+                jobCount += n; enq += n;
+                if (atLeaf) { lastSeq = enq; popNext(); }
+            }
+            // run a batch when a full wave of jobs waits, or when no lane can take a node step
+            runJobs = jobCount >= 64u || (jobCount > 0u && __ballot(state == 1 && !(cur & 0x80000000u)) == 0ull);
+        }
+        if (runJobs) {
+            const uint32_t n = min(64u, jobCount);
+            const bool mine = (uint32_t)lane < n;
+            const uint32_t jp = (jobHead + (uint32_t)lane) & (KZ_DQ_JOBS - 1);
+            const uint32_t leaf = mine ? jobLeaf[jp] : 0x80000000u, owner = mine ? jobOwner[jp] : (uint32_t)lane;
+            // the owner's ray (every lane takes part in the permutes)
+            const int oa = (int)(owner << 2);
+            const V3 jo = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(o.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(o.y))),
+                             __int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(o.z))));
+            const V3 jd = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(d.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(d.y))),
+                             __int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(d.z))));
+            const float jtmin = __int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(tmin)));
+            float jtmax = __int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(tmax)));
+            unsigned long long myKey = ~0ull; uint32_t myTri = 0; float myU = 0.f, myV = 0.f;
+            if (mine) {
+                const uint32_t bh = (uint32_t)(best[owner] >> 32);
+                if (MODE == 0) jtmax = __uint_as_float(min(__float_as_uint(jtmax), bh));
+                if (!(MODE == 2 && bh == 0u)) {
+                    const uint32_t start = (leaf & 0x7fffffffu) >> 3, cnt = (leaf & 7u) + 1;
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        float t, u, v; uint32_t g;
+                        if (STATS) cn.tris++;
+                        if (!triTest(T.tris + start + i, jo, jd, jtmin, jtmax, t, u, v, g)) continue;
+                        if (MODE == 2) { myKey = 0ull; break; }
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(t) << 32) | g;
+                        if (k < myKey) { myKey = k; myTri = start + i; myU = u; myV = v; jtmax = t; }
+                    }
+                    if (myKey != ~0ull) atomicMin(&best[owner], myKey);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (MODE == 0 && mine && myKey != ~0ull && best[owner] == myKey) {       // the winner leaves the triangle and its barycentrics
+                res[owner] = myTri; res[64 + owner] = __float_as_uint(myU); res[128 + owner] = __float_as_uint(myV);
+            }
+            jobHead = (jobHead + n) & (KZ_DQ_JOBS - 1); jobCount -= n; done += n;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // ---- publish: stack empty and the last job of the ray has run (sequence numbers wrap consistently)
+        if (state == 2 && (int)(done - lastSeq) >= 0) {
+            const unsigned long long b = best[lane];
+            if (MODE == 0) {
+                W.hit[slot] = (b != ~0ull) ? make_float4(__uint_as_float((uint32_t)(b >> 32)), __uint_as_float(res[64 + lane]), __uint_as_float(res[128 + lane]), __uint_as_float(res[lane]))
+                                           : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+            } else if (b != 0ull) { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; }     // nothing on the segment
+            state = 0;
+        }
+    }
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+}
+
 // v_writelane_b32: one lane of a VGPR takes a wave-uniform value (this clang has a builtin for v_readlane only). On gfx9 the
 // instruction may read one SGPR besides M0, so the lane select travels in M0 (saved and restored around it).
 __device__ __forceinline__ void kzWriteLane(uint32_t &reg, uint32_t value, int laneSel) {
