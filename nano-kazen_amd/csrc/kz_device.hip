@@ -706,7 +706,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
         tune.ovf = c.ovf; tune.ovfStride = (uint32_t)stride;
     }
     // decoupled leaf queue (kz_wf_trace_dq): bounce rays, and shadow rays when the exact any-hit form applies (shadowFast)
-    const bool dq = tune.wide && tune.leafQueue == 2 && !st;
+    const bool dq = tune.wide && tune.leafQueue == 2;
     const int dqLS = std::max(2, std::min(tune.ldsStack, std::min(stackBound, 9)));                 // 9 rows + queue + results = 19.4 KB per workgroup: 8 per CU
     const size_t dqLds = (size_t)4 * ((size_t)(dqLS + 1) * 64 + 128 + 192 + 2 * KZ_DQ_JOBS) * sizeof(uint32_t);
     KzTune tuneDq = tune; tuneDq.ldsStack = dqLS;
@@ -784,8 +784,10 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
         if (P.nLights > 0) {
             if (dq && P.shadowFast) {
                 uint32_t *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
-                hipLaunchKernelGGL((kz_wf_trace_dq<2, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, tuneDq,
-                                   c.litQueue, litCount);
+                if (st) hipLaunchKernelGGL((kz_wf_trace_dq<2, true>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, tuneDq,
+                                           c.litQueue, litCount);
+                else hipLaunchKernelGGL((kz_wf_trace_dq<2, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, tuneDq,
+                                        c.litQueue, litCount);
                 KZ_TRACE(2, (const uint32_t *)c.litQueue, (const uint32_t *)litCount, 0u, litHead);      // the few rays that cross an invisible light
             }
             else if (traceKernel) KZ_TRACE(2, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3);
@@ -794,8 +796,10 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
         }
         { int rc_ = stageMark(c, stream, 3); if (rc_) return rc_; }
         if (needExtend) {
-            if (dq) hipLaunchKernelGGL((kz_wf_trace_dq<0, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, tuneDq,
-                                       (uint32_t *)nullptr, (uint32_t *)nullptr);
+            if (dq && st) hipLaunchKernelGGL((kz_wf_trace_dq<0, true>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, tuneDq,
+                                             (uint32_t *)nullptr, (uint32_t *)nullptr);
+            else if (dq) hipLaunchKernelGGL((kz_wf_trace_dq<0, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, tuneDq,
+                                            (uint32_t *)nullptr, (uint32_t *)nullptr);
             else KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2);
             int rc_ = stageMark(c, stream, 1); if (rc_) return rc_;
         }

@@ -104,8 +104,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_generate(KzParams P, KzDevTabl
     cameraRay(P, sx, sy, ax, ay, ro, rd, mint, maxt);
     W.rayA[item] = make_float4(ro.x, ro.y, ro.z, mint);
     W.rayB[item] = make_float4(rd.x, rd.y, rd.z, maxt);
-    W.thr[item] = make_float4(1.f, 1.f, 1.f, 1.f);
-    W.misc[item] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (throughput = 1, eta = 1, bsdfPdf / accumulatedRoughness / discrete = 0 are what shade(0) assumes for a camera path: not stored)
     wfStoreSampler(P, W, item, smp);
     W.outJx[item] = jx; W.outJy[item] = jy; W.outR[item] = 0.f; W.outG[item] = 0.f; W.outB[item] = 0.f;
 }
@@ -218,7 +217,8 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                 const KzMeshRow mrow = T.meshes[its.mesh];
                 if (mrow.light >= 0) {                                                        // integrator.cpp:226-231, 322-327
                     const KzLightRow &lr = T.lights[mrow.light];
-                    const float4 ra = W.rayA[slot], th = W.thr[slot], mi = W.misc[slot];
+                    const float4 ra = W.rayA[slot];
+                    const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot], mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : W.misc[slot];
                     const V3 ro = mk(ra.x, ra.y, ra.z);
                     const V3 wi = normalized(its.p - ro);
                     float bsdfWeight = 1.f;
@@ -297,10 +297,10 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
             const KzMeshRow mrow = T.meshes[its.mesh];
             const float4 rb = W.rayB[slot];
             const V3 rd = mk(rb.x, rb.y, rb.z);
-            float4 th = W.thr[slot];
+            float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot];              // a camera path: generate stores neither (initial values)
             V3 throughput = mk(th.x, th.y, th.z);
             const float eta = th.w;
-            const float4 mi = W.misc[slot];
+            const float4 mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : W.misc[slot];
             float accRough = mi.y;
             const uint32_t pl = slot / S;
             const uint32_t pxy = pixList[pl];

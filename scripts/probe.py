@@ -24,6 +24,15 @@ def scene(name):
             "c4": lambda: S.random_triangles(1000000, 1920, 1080, 1024), "c5": lambda: S.random_triangles(1000000, 3840, 2160, 4096)}[name]()
 
 
+def all_kiss(desc):
+    """experiment: every non-emitting diffuse mesh gets a kiss row (does the shade kernel pay for BSDF-type divergence?)"""
+    kiss = next(m["bsdf"] for m in desc.meshes if m["bsdf"] and m["bsdf"].get("type") == "kazenstandard")
+    for m in desc.meshes:
+        if m["bsdf"] and m["bsdf"].get("type") == "diffuse" and not m["light"]:
+            m["bsdf"] = dict(kiss, baseColor=list(m["bsdf"].get("albedo", [0.7, 0.7, 0.7])))
+    return desc
+
+
 def kv(s, cast=int):
     return {k: cast(v) for k, v in (p.split("=") for p in s.split(",") if p)} if s else {}
 
@@ -64,7 +73,10 @@ def one(sc, spp, tune, opts):
 
 
 def cmd_stages(a):
-    sc = kz.Scene(scene(a.scene), device=0)
+    desc = scene(a.scene)
+    if a.all_kiss:
+        desc = all_kiss(desc)
+    sc = kz.Scene(desc, device=0)
     spp = a.spp or min(sc.sample_count, 128)
     print(json.dumps({"scene": a.scene, "tune": kv(a.tune), "opts": kv(a.opts), **one(sc, spp, kv(a.tune), kv(a.opts))}), flush=True)
 
@@ -104,6 +116,6 @@ ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "count
 ap.add_argument("c5", nargs="?")
 ap.add_argument("--scene", default="c4"); ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--tune", default=""); ap.add_argument("--opts", default="")
-ap.add_argument("--knob", default="refill"); ap.add_argument("--values", default="")
+ap.add_argument("--all-kiss", action="store_true"); ap.add_argument("--knob", default="refill"); ap.add_argument("--values", default="")
 a = ap.parse_args()
 {"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters}[a.cmd](a)
