@@ -201,11 +201,21 @@ typedef struct KzIntegrator {
     float accumulatedRoughness; /* default 0.5                                         */
 } KzIntegrator;
 
-/* "background" texture with one nested "constanttexture" (texture.cpp:104-145). */
+/* "background" texture (texture.cpp:104-145) with its nested texture, looked up by DIRECTION (Scene::getBackgroundColor,
+ * scene.cpp:54-79 -> BackgroundTexture::eval(Vector3f) -> nested->eval(Vector3f)):
+ *   texture == 0                  the nested texture is the constant `color` (ConstantTexture::eval(Vector3f), texture.cpp:20-22)
+ *   texture == k > 0              textures[k-1] is the nested texture: CONSTANT -> its colour; IMAGE -> the environment lookup of
+ *                                 ImageTexture::eval(Vector3f) (texture.cpp:66-80: no `scale`, no colour-space conversion);
+ *                                 COLORRAMP / BLEND -> 0 (they inherit Texture::eval(Vector3f), texture.h:13)
+ * The environment lookup is OpenImageIO's TextureSystem::environment (un-vendored). This library DECLARES it as the latitude-longitude
+ * map with y up that OpenImageIO applies to OpenEXR environment maps:
+ *     s = atan2f(-d.x, d.z) / (2 pi) + 0.5      t = 0.5 - atan2f(d.y, hypotf(d.z, -d.x)) / pi      (NaN -> 0)
+ * bilinear over the full-resolution level, texel centres at (i + 0.5) / res, s periodic, t clamped at the poles. */
 typedef struct KzBackground {
     int32_t present;            /* 0: Scene::getBackgroundColor returns 0 (scene.cpp:55-56) */
     float color[3];
     float intensity;            /* default 1                                           */
+    int32_t texture;            /* 0 = `color`; k > 0 = textures[k-1] (see above)      */
 } KzBackground;
 
 typedef struct KzSceneDesc {

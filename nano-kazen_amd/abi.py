@@ -79,7 +79,7 @@ class KzIntegrator(C.Structure):
 
 
 class KzBackground(C.Structure):
-    _fields_ = [("present", C.c_int32), ("color", C.c_float * 3), ("intensity", C.c_float)]
+    _fields_ = [("present", C.c_int32), ("color", C.c_float * 3), ("intensity", C.c_float), ("texture", C.c_int32)]
 
 
 class KzSceneDesc(C.Structure):

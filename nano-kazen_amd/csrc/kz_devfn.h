@@ -868,6 +868,35 @@ __device__ V3 imageLookup(const KzDevTables &T, uint32_t image, float scale, uin
     }
     return mk(r[0], r[1], r[2]);
 }
+// ImageTexture::eval(Vector3f) (texture.cpp:66-80): the environment lookup, as include/kazen_mi355x.h declares it (y-up latitude-longitude
+// map, bilinear, s periodic, t clamped; no scale, no colour-space conversion)
+__device__ V3 envLookup(const KzDevTables &T, uint32_t image, V3 d) {
+    const KzImageRow im = T.images[image];
+    const uint8_t *base = T.texels + im.offset;
+    float s = atan2f(-d.x, d.z) / (2.0f * KZ_PI_F) + 0.5f;
+    float t = 0.5f - atan2f(d.y, hypotf(d.z, -d.x)) / KZ_PI_F;
+    if (isnan(s)) s = 0.0f;
+    if (isnan(t)) t = 0.0f;
+    const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float fx = x - fx0, fy = y - fy0;
+    const int x0 = wrapPeriodic((int)fx0, im.width), x1 = wrapPeriodic((int)fx0 + 1, im.width);
+    const int y0 = min(max((int)fy0, 0), im.height - 1), y1 = min(max((int)fy0 + 1, 0), im.height - 1);
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float top = (1.0f - fx) * texelAt(im, base, x0, y0, c) + fx * texelAt(im, base, x1, y0, c);
+        const float bot = (1.0f - fx) * texelAt(im, base, x0, y1, c) + fx * texelAt(im, base, x1, y1, c);
+        r[c] = (1.0f - fy) * top + fy * bot;
+    }
+    return mk(r[0], r[1], r[2]);
+}
+// Scene::getBackgroundColor (scene.cpp:54-79) -> BackgroundTexture::eval(Vector3f) (texture.cpp:121-126); the caller has checked bgPresent
+__device__ __forceinline__ V3 backgroundRadiance(const KzParams &P, const KzDevTables &T, V3 d) {
+    if (isnan(d.x) || isnan(d.y) || isnan(d.z)) return mk(0.f);
+    if (P.bgImage >= 0) return P.bgIntensity * envLookup(T, (uint32_t)P.bgImage, d);
+    return mk(P.bgRadiance[0], P.bgRadiance[1], P.bgRadiance[2]);
+}
 __device__ __forceinline__ float clampRef(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   // common.h:237-243
 // texId is 1-based (KzBSDF::*Tex); the postfix program was flattened by kz_scene_create
 __device__ V3 texEval(const KzDevTables &T, int32_t texId, float u, float v) {
@@ -1105,8 +1134,7 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
         float bpdf = surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, solid);
         ro = its.p; rd = toWorld(its.sh, woLocal);                                            // H9: not re-normalised
         if (!closestHit<STATS>(T, P.rootRef, ro, rd, eps, KZ_INF, rh, stk, cn)) {
-            if (P.bgPresent && !(isnan(rd.x) || isnan(rd.y) || isnan(rd.z)))                  // scene.cpp:54-79
-                L = L + throughput * mk(P.bgRadiance[0], P.bgRadiance[1], P.bgRadiance[2]);
+            if (P.bgPresent) L = L + throughput * backgroundRadiance(P, T, rd);             // scene.cpp:54-79
             break;
         }
         postIntersect<false>(T, rh, its); if (STATS) cn.hits++;

@@ -808,7 +808,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #undef KZ_EXTEND
 #undef KZ_TRACE
 #undef KZ_TRACE2
-    if (P.bgPresent) hipLaunchKernelGGL(kz_wf_final, gShade, blk, 0, stream, P, W, cur, curCount);
+    if (P.bgPresent) hipLaunchKernelGGL(kz_wf_final, gShade, blk, 0, stream, P, ds->T, W, cur, curCount);
     if (st) hipLaunchKernelGGL(kz_wf_count, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, W, items);
     HIP_TRY(hipGetLastError());
     return KZ_OK;

@@ -333,7 +333,23 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     p.nLights = (uint32_t)sc->lightRows.size();
     p.lightPickPdf = p.nLights ? 1.f / (float)p.nLights : 0.f;
     p.bgPresent = d->background.present ? 1 : 0;
-    for (int a = 0; a < 3; ++a) p.bgRadiance[a] = d->background.present ? d->background.intensity * d->background.color[a] : 0.f;
+    p.bgImage = -1; p.bgIntensity = d->background.intensity;
+    {
+        // the nested texture by DIRECTION (texture.cpp:20-22, 66-80, texture.h:13): constant -> colour, image -> environment lookup,
+        // colorramp / blend -> 0
+        float col[3] = {d->background.color[0], d->background.color[1], d->background.color[2]};
+        if (d->background.present && d->background.texture != 0) {
+            const int32_t t = d->background.texture - 1;
+            if (t < 0 || (uint32_t)t >= d->nTextures) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "background texture id %d out of range", d->background.texture); }
+            const KzTexture &k = d->textures[t];
+            if (k.type == KZ_TEX_CONSTANT) { col[0] = k.color[0]; col[1] = k.color[1]; col[2] = k.color[2]; }
+            else if (k.type == KZ_TEX_IMAGE) {
+                if (k.image < 0 || (uint32_t)k.image >= d->nImages) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "background image index %d out of range", k.image); }
+                p.bgImage = k.image; col[0] = col[1] = col[2] = 0.f;
+            } else col[0] = col[1] = col[2] = 0.f;
+        }
+        for (int a = 0; a < 3; ++a) p.bgRadiance[a] = d->background.present ? d->background.intensity * col[a] : 0.f;
+    }
     // ---- sampler
     p.samplerType = d->sampler.type;
     p.seed = d->sampler.seed;

@@ -93,7 +93,8 @@ struct KzParams {
     int32_t cameraType; float apertureRadius, focusDistance;
     // lights / background
     uint32_t nLights; float lightPickPdf;
-    int32_t bgPresent; float bgRadiance[3];
+    int32_t bgPresent; float bgRadiance[3];          // constant background: intensity * colour
+    int32_t bgImage; float bgIntensity;             // environment map: row of `images` (-1: none) and the intensity it is scaled by
     // film (block.cpp:13-21)
     float filterRadius, lookupFactor; int32_t tapLo, tapHi;
     uint32_t rootRef;

@@ -205,9 +205,9 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
             const V3 rd = mk(rb.x, rb.y, rb.z);
             if (!(h.x < KZ_INF)) {
                 // miss: black for the primary ray (H5), background after a bounce (integrator.cpp:315-318)
-                if (iter > 0 && P.bgPresent && !(isnan(rd.x) || isnan(rd.y) || isnan(rd.z))) {
+                if (iter > 0 && P.bgPresent) {
                     const float4 th = W.thr[slot];
-                    const V3 c = mk(th.x, th.y, th.z) * mk(P.bgRadiance[0], P.bgRadiance[1], P.bgRadiance[2]);
+                    const V3 c = mk(th.x, th.y, th.z) * backgroundRadiance(P, T, rd);
                     W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
                 }
             } else {
@@ -1038,15 +1038,15 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 }
 
 // ---- final: the ray after the last bounce contributes only the background on a miss (integrator.cpp:315-318) ------------
-__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_final(KzParams P, KzWf W, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ countPtr) {
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_final(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ countPtr) {
     const uint32_t count = *countPtr;
     for (uint32_t qi = blockIdx.x * KZ_BLOCK + threadIdx.x; qi < count; qi += gridDim.x * KZ_BLOCK) {
         const uint32_t slot = queue[qi];
         const float4 h = W.hit[slot];
         if (h.x < KZ_INF) continue;
         const float4 rb = W.rayB[slot], th = W.thr[slot];
-        if (isnan(rb.x) || isnan(rb.y) || isnan(rb.z)) continue;
-        W.outR[slot] += th.x * P.bgRadiance[0]; W.outG[slot] += th.y * P.bgRadiance[1]; W.outB[slot] += th.z * P.bgRadiance[2];
+        const V3 bg = backgroundRadiance(P, T, mk(rb.x, rb.y, rb.z));
+        W.outR[slot] += th.x * bg.x; W.outG[slot] += th.y * bg.y; W.outB[slot] += th.z * bg.z;
     }
 }
 

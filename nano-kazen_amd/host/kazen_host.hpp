@@ -205,7 +205,7 @@ class ImageTexture : public Texture {
 public:
     explicit ImageTexture(const PropertyList &p) {
         m_filename = p.getString("filename", ""); m_colorspace = p.getString("colorspace", "srgb"); m_scale = p.getFloat("scale", 1.0f);
-        if (!m_filename.empty()) load(m_filename);
+        if (!m_filename.empty()) load(resolveFile(m_filename));          // texture.cpp:40: getFileResolver()->resolve(fileName)
     }
     void setRaster(int width, int height, int channels, int format, const void *pixels) {
         m_w = width; m_h = height; m_c = channels; m_fmt = format;
@@ -288,13 +288,12 @@ public:
     ~BackgroundTexture() override { delete m_nested; }
     void addChild(Object *o) override {
         if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than nested Texture");
-        auto *c = dynamic_cast<ConstantTexture *>(o);
-        if (!c) throw Exception("background: only a nested constanttexture is on the MI355X hot path");
-        m_nested = c;
+        delete m_nested;                       // texture.cpp:128-136: the last texture child is the nested one
+        m_nested = static_cast<Texture *>(o);  // constanttexture -> colour, imagetexture -> environment lookup, colorramp / blend -> 0 (texture.h:13)
     }
     EClassType getClassType() const override { return ETexture; }
     std::string toString() const override { return "Background[]"; }
-    float m_intensity; ConstantTexture *m_nested = nullptr;
+    float m_intensity; Texture *m_nested = nullptr;
 };
 
 // ---- BSDFs ----------------------------------------------------------------------------------------------------------
@@ -635,7 +634,13 @@ public:
         d.camera = m_camera->m_c; d.sampler = m_sampler->m_s; d.integrator = m_integrator->m_i;
         if (m_background && m_background->m_nested) {
             d.background.present = 1; d.background.intensity = m_background->m_intensity;
-            d.background.color[0] = m_background->m_nested->m_color.r; d.background.color[1] = m_background->m_nested->m_color.g; d.background.color[2] = m_background->m_nested->m_color.b;
+            if (auto *c = dynamic_cast<ConstantTexture *>(m_background->m_nested)) {
+                d.background.color[0] = c->m_color.r; d.background.color[1] = c->m_color.g; d.background.color[2] = c->m_color.b;
+            } else {
+                d.background.texture = m_rb.tex(m_background->m_nested);                                // 1-based id of the nested texture's row
+                d.textures = m_rb.textures.data(); d.nTextures = (uint32_t)m_rb.textures.size();
+                d.images = m_rb.images.data(); d.nImages = (uint32_t)m_rb.images.size();
+            }
         }
         m_desc = d;
         if (m_handle) { kz_scene_destroy(m_handle); m_handle = nullptr; }

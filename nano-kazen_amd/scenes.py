@@ -160,7 +160,7 @@ class SceneDescription:
         self.sampler = {"type": "independent", "sampleCount": 1, "seed": 0}
         self.integrator = {"type": "path_mis", "maxDepth": 5, "traceBias": 1e-3, "regularization": False,
                            "accumulatedRoughness": 0.5}
-        self.background = None          # {"color": (r,g,b), "intensity": 1.0}
+        self.background = None          # {"color": (r,g,b), "intensity": 1.0} or {"texture": <texture dict>, "intensity": 1.0}
         self.tables = None              # (pmj02bn u32 [5,65536,2], bluenoise u16 [48,128,128])
         self._keep = []
 
@@ -271,6 +271,7 @@ class SceneDescription:
                 k.nested = b["_nested"]
             else:
                 k.type = 99      # unsupported plugin: the library must answer KZ_ERR_UNSUPPORTED
+        bg_tex = tex_id(self.background.get("texture")) if self.background is not None else 0
         ct = (abi.KzTexture * max(1, len(textures)))()
         for i, row in enumerate(textures):
             t, k = row["t"], ct[i]
@@ -334,8 +335,9 @@ class SceneDescription:
         d.integrator.accumulatedRoughness = it["accumulatedRoughness"]
         if self.background is not None:
             d.background.present = 1
-            d.background.color[:] = self.background["color"]
+            d.background.color[:] = self.background.get("color", (0.0, 0.0, 0.0))
             d.background.intensity = self.background.get("intensity", 1.0)
+            d.background.texture = bg_tex
         keep += [cm, cb, cl, ct, ci, images]
         self._keep = keep
         return d

@@ -307,8 +307,12 @@ def load_xml(path, overrides=None):
             if t != "background":
                 raise ValueError("scene-level texture \"%s\" is not supported" % t)
             nested = _children(node, "texture")
-            if nested:
-                s.background = {"color": _const_texture(nested[0]), "intensity": _props(node).get("intensity", 1.0)}
+            if nested:                                                       # texture.cpp:128-136: the last texture child is the nested one
+                tx = _texture(nested[-1], base, folded=True)
+                if isinstance(tx, tuple):
+                    s.background = {"color": tx, "intensity": _props(node).get("intensity", 1.0)}
+                else:                                                        # imagetexture: environment lookup; colorramp / blend: 0 (texture.h:13)
+                    s.background = {"texture": tx, "intensity": _props(node).get("intensity", 1.0)}
         elif node.tag == "mesh":
             if t != "obj":
                 raise ValueError("mesh type \"%s\" is not supported" % t)

@@ -1485,9 +1485,36 @@ static V3 lightSample(const Scene &sc, const KzLight &l, const MeshData &md, LRe
     return V3(0.f);
 }
 
+// ImageTexture::eval(Vector3f) (texture.cpp:66-80): OpenImageIO's TextureSystem::environment is not part of the checkout; the lookup is
+// the one include/kazen_mi355x.h declares (y-up latitude-longitude map, bilinear, s periodic, t clamped; no scale, no toLinearRGB)
+static V3 envLookup(const Scene &sc, int image, V3 d) {
+    const Scene::Image &im = sc.images[image];
+    float s = std::atan2(-d.x, d.z) / (2.0f * 3.14159265358979323846f) + 0.5f;
+    float t = 0.5f - std::atan2(d.y, std::hypot(d.z, -d.x)) / 3.14159265358979323846f;
+    if (std::isnan(s)) s = 0.0f;
+    if (std::isnan(t)) t = 0.0f;
+    float x = s * (float)im.w - 0.5f, y = t * (float)im.h - 0.5f;
+    float fx0 = std::floor(x), fy0 = std::floor(y);
+    float fx = x - fx0, fy = y - fy0;
+    int x0 = wrapPeriodic((int)fx0, im.w), x1 = wrapPeriodic((int)fx0 + 1, im.w);
+    int y0 = std::min(std::max((int)fy0, 0), im.h - 1), y1 = std::min(std::max((int)fy0 + 1, 0), im.h - 1);
+    float r[3];
+    for (int c = 0; c < 3; ++c) {
+        float top = (1.0f - fx) * texelAt(im, x0, y0, c) + fx * texelAt(im, x1, y0, c);
+        float bot = (1.0f - fx) * texelAt(im, x0, y1, c) + fx * texelAt(im, x1, y1, c);
+        r[c] = (1.0f - fy) * top + fy * bot;
+    }
+    return V3(r[0], r[1], r[2]);
+}
 static V3 backgroundColor(const Scene &sc, V3 dir) {                              // scene.cpp:54-79, texture.cpp:121-126
     if (!sc.bg.present) return V3(0.f);
     if (std::isnan(dir.x) || std::isnan(dir.y) || std::isnan(dir.z)) return V3(0.f);
+    if (sc.bg.texture != 0) {                                                    // nested->eval(Vector3f) by texture class
+        const KzTexture &k = sc.textures[sc.bg.texture - 1];
+        if (k.type == KZ_TEX_CONSTANT) return sc.bg.intensity * V3(k.color[0], k.color[1], k.color[2]);       // texture.cpp:20-22
+        if (k.type == KZ_TEX_IMAGE) return sc.bg.intensity * envLookup(sc, k.image, dir);                    // texture.cpp:66-80
+        return V3(0.f);                                                                                      // texture.h:13 (colorramp, blend)
+    }
     return sc.bg.intensity * V3(sc.bg.color[0], sc.bg.color[1], sc.bg.color[2]);
 }
 
@@ -1847,6 +1874,11 @@ void kzo_sampler_stream(void *s, int32_t px, int32_t py, uint32_t idx, int n1, f
     sm.generateSample(px, py, idx);
     sm.nextPixel2D(out[0], out[1]); sm.next2D(out[2], out[3]);
     for (int i = 0; i < n1; ++i) out[4 + i] = sm.next1D();
+}
+// Scene::getBackgroundColor(dir) (scene.cpp:54-79)
+void kzo_background(void *s, const float *dir, float *rgb) { FtzScope ftz_;
+    V3 c = backgroundColor(*(Scene *)s, V3(dir[0], dir[1], dir[2]));
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
 }
 void kzo_camera_ray(void *s, float sx, float sy, float *o6, float *mint, float *maxt) { FtzScope ftz_;
     Scene &sc = *(Scene *)s; Ray r; cameraSampleRay(sc, sx, sy, 0.5f, 0.5f, r);

@@ -65,6 +65,8 @@ def lib():
         L.kzo_sampler_stream.restype = None
         L.kzo_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, abi.f32p, abi.f32p, abi.f32p]
         L.kzo_camera_ray.restype = None
+        L.kzo_background.argtypes = [C.c_void_p, abi.f32p, abi.f32p]
+        L.kzo_background.restype = None
         L.kzo_filter_table.argtypes = [C.c_void_p, abi.f32p, abi.f32p, C.POINTER(C.c_int)]
         L.kzo_filter_table.restype = None
         L.kzo_cosine_hemisphere.argtypes = [C.c_float, C.c_float, abi.f32p]
@@ -169,6 +171,12 @@ class OracleScene:
     def sampler_stream(self, px, py, idx, n1):
         out = np.zeros(4 + n1, np.float32)
         self.L.kzo_sampler_stream(self.h, px, py, idx, n1, _fp(out))
+        return out
+
+    def background(self, direction):
+        d = np.ascontiguousarray(direction, np.float32)
+        out = np.zeros(3, np.float32)
+        self.L.kzo_background(self.h, _fp(d), _fp(out))
         return out
 
     def camera_ray(self, sx, sy):

@@ -126,9 +126,10 @@ int main(int argc, char **argv) {
         std::printf("], \"camera\": [%d, %d, %d, %.9g, %.9g, %.9g, %d, %.9g], \"toWorld\": [", d.camera.type, d.camera.width, d.camera.height, d.camera.fov, d.camera.nearClip,
                     d.camera.farClip, d.camera.rfilter.type, d.camera.rfilter.radius);
         for (int i = 0; i < 16; ++i) std::printf("%s%.9g", i ? ", " : "", d.camera.toWorld[i]);
-        std::printf("], \"sampler\": [%d, %u, %llu], \"integrator\": [%d, %.9g, %d, %.9g], \"background\": [%d, %.9g, %.9g, %.9g, %.9g], \"lights\": [", d.sampler.type,
+        std::printf("], \"sampler\": [%d, %u, %llu], \"integrator\": [%d, %.9g, %d, %.9g], \"background\": [%d, %.9g, %.9g, %.9g, %.9g], \"backgroundTexture\": %d, \"lights\": [", d.sampler.type,
                     d.sampler.sampleCount, (unsigned long long)d.sampler.seed, d.integrator.maxDepth, d.integrator.traceBias, d.integrator.regularization,
-                    d.integrator.accumulatedRoughness, d.background.present, d.background.color[0], d.background.color[1], d.background.color[2], d.background.intensity);
+                    d.integrator.accumulatedRoughness, d.background.present, d.background.color[0], d.background.color[1], d.background.color[2], d.background.intensity,
+                    d.background.texture);
         for (uint32_t i = 0; i < d.nLights; ++i) std::printf("%s[%.9g, %.9g, %.9g, %.9g, %d]", i ? ", " : "", d.lights[i].color[0], d.lights[i].color[1], d.lights[i].color[2], d.lights[i].intensity, d.lights[i].primaryVisibility);
         std::printf("]}\n");
         return 0;

@@ -176,6 +176,13 @@ def test_cpp_xml_loader_errors(exe, tmp_path):
         assert msg in d.get("error", ""), (msg, d)
 
 
+def test_cpp_xml_loader_environment_background(exe, kz):
+    """the C++ loader hands the background's nested imagetexture over as a texture row (KzBackground.texture) + a raster"""
+    d = json.loads(subprocess.check_output([exe, "--xml", os.path.join(ROOT, "tests", "golden", "xml", "envmap.xml")]).decode())
+    assert "error" not in d, d
+    assert d["background"][0] == 1 and np.isclose(d["background"][4], 0.5) and d["backgroundTexture"] >= 1 and d["nImages"] == 1
+
+
 @pytest.mark.gpu
 def test_cpp_xml_render_equals_python_render(exe, kz, gpu_lib, tmp_path):
     out = str(tmp_path / "rgb.bin")

@@ -255,3 +255,69 @@ def test_textured_scene_matches_oracle(gpu_lib, kz, O, sampler):
     assert _l2(sc.rgb(film), o.rgb(film_c)) < 1e-3
     sc.render(pipeline=1)                                                               # megakernel: same film bit for bit
     assert np.array_equal(sc.film(), film)
+
+
+# ---------------------------------------------------------------- environment lookup behind the background texture (texture.cpp:66-80, 104-145)
+def _env_image(h=32, w=64):
+    """a smooth HDR latitude-longitude map: sky gradient + a bright lobe, float32"""
+    t = (np.arange(h, dtype=np.float32)[:, None] + 0.5) / h
+    s = (np.arange(w, dtype=np.float32)[None, :] + 0.5) / w
+    img = np.zeros((h, w, 3), np.float32)
+    img[..., 0] = 0.3 + 0.7 * (1 - t) + 0 * s
+    img[..., 1] = 0.2 + 0.5 * np.cos(2 * np.pi * s) ** 2 + 0 * t
+    img[..., 2] = 1.5 * np.exp(-((s - 0.25) ** 2 + (t - 0.3) ** 2) * 40.0)
+    return img
+
+
+def _env_scene(kz, w=96, h=80, spp=8, nested="image"):
+    d = kz.scenes.sphere_env(w, h, spp)
+    tex = {"image": kz.scenes.imagetexture(_env_image(), 3.0, "srgb"),                      # scale / colorspace must be IGNORED by the direction lookup
+           "ramp": kz.scenes.colorramp(kz.scenes.constanttexture((0.5, 0.5, 0.5)), 0.0, 1.0),
+           "const": kz.scenes.constanttexture((0.25, 0.5, 1.0))}[nested]
+    d.background = {"texture": tex, "intensity": 2.0}
+    return d
+
+
+def test_environment_lookup_known_answers(kz, O):
+    """The declared mapping (include/kazen_mi355x.h): y-up latitude-longitude, s = atan2(-x, z) / 2pi + 0.5, t = 0.5 - atan2(y, hypot(z, -x)) / pi,
+    bilinear, texel centres at (i + 0.5) / res. A 4 x 2 map whose texel (row r, column c) holds (r, c, 0): straight up reads the top row,
+    +z reads the seam s = 0.5 (between columns 1 and 2), -x reads s = 0.75 (between columns 2 and 3: bilinear mid-point 2.5)."""
+    img = np.zeros((2, 4, 3), np.float32)
+    img[..., 0] = np.arange(2)[:, None]
+    img[..., 1] = np.arange(4)[None, :]
+    d = kz.scenes.sphere_env(16, 16, 1)
+    d.meshes = d.meshes[:0]                                               # no geometry ... the scene needs one mesh: a far-away tiny triangle
+    d.add_mesh(np.array([[100, 100, 100], [100.001, 100, 100], [100, 100.001, 100]], np.float32), np.array([[0, 1, 2]], np.uint32),
+               np.tile([0, 0, 1], (3, 1)).astype(np.float32), None, bsdf=kz.scenes.diffuse((0.5, 0.5, 0.5)))
+    d.background = {"texture": kz.scenes.imagetexture(img, 1.0, "linear"), "intensity": 1.0}
+    o = O.OracleScene(d)
+    bg = lambda v: o.background(np.asarray(v, np.float32))
+    assert np.allclose(bg((0, 1, 0)), (0.0, bg((0, 1, 0))[1], 0.0)) and bg((0, 1, 0))[0] == 0.0          # zenith: row 0
+    assert bg((0, -1, 0))[0] == 1.0                                                                    # nadir: row 1 (t clamped)
+    assert np.allclose(bg((0, 0, 1)), (0.5, 1.5, 0.0), atol=1e-5)                                        # +z: s = 0.5, t = 0.5
+    assert np.allclose(bg((-1, 0, 0)), (0.5, 2.5, 0.0), atol=1e-5)                                       # -x: s = 0.75
+    assert np.allclose(bg((0, 0, -1)), (0.5, 1.5, 0.0), atol=1e-5)                                       # -z: s = 0 = 1: columns 3 and 0 wrap (periodic) -> 1.5
+    assert np.allclose(bg((np.nan, 0, 1)), 0.0)                                                          # scene.cpp:71-76
+
+
+def test_background_nested_texture_classes(kz, O):
+    """BackgroundTexture::eval(Vector3f) -> nested->eval(Vector3f): constanttexture gives its colour, colorramp / blend inherit Texture::eval(Vector3f) = 0."""
+    for nested, want in (("const", (0.5, 1.0, 2.0)), ("ramp", (0.0, 0.0, 0.0))):
+        o = O.OracleScene(_env_scene(kz, 16, 16, 1, nested))
+        assert np.allclose(o.background(np.array([0.3, 0.4, 0.5], np.float32)), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nested", ["image", "const", "ramp"])
+def test_environment_background_matches_oracle(gpu_lib, kz, O, nested):
+    d = _env_scene(kz, nested=nested)
+    sc = kz.Scene(d, device=0)
+    sc.render()
+    gpu = sc.rgb()
+    ora = O.OracleScene(d)
+    cpu = ora.rgb(ora.render(threads=0))
+    assert float(np.sqrt(np.mean((gpu - cpu) ** 2))) < 1e-3
+    if nested == "image":
+        assert gpu.mean() > 0.05                                          # the sphere is lit by the map (primary misses stay black, H5)
+    sc.render(pipeline=1)                                                  # the reference-shaped megakernel looks the map up the same way
+    assert np.array_equal(sc.rgb(), gpu)

@@ -93,9 +93,23 @@ def test_mini_scene_oracle_render(kz, O):
     assert o.sample_count == 9 and np.isfinite(rgb).all() and rgb.mean() > 0.05
 
 
+ENVMAP = os.path.join(HERE, "golden", "xml", "envmap.xml")
+
+
+def test_background_with_an_environment_map_loads(kz, O):
+    """<texture type="background"><texture type="imagetexture" .../></texture>: the nested texture is looked up by direction."""
+    d = kz.xmlscene.load_xml(ENVMAP)
+    assert d.background["texture"]["type"] == "imagetexture" and d.background["texture"]["image"].shape == (8, 16, 3) and d.background["intensity"] == 0.5
+    o = O.OracleScene(d)
+    up, down = o.background(np.array([0, 1, 0], np.float32)), o.background(np.array([0, -1, 0], np.float32))
+    assert up[0] > 0.35 and down[0] < 0.05 and down[2] > up[2]                       # red fades towards the nadir, blue grows (x intensity 0.5)
+    assert o.rgb(o.render(threads=0)).mean() > 0.02
+
+
 @pytest.mark.gpu
-def test_mini_scene_gpu_matches_oracle(kz, O, gpu_lib):
-    d = kz.xmlscene.load_xml(MINI)
+@pytest.mark.parametrize("path", [MINI, ENVMAP])
+def test_mini_scene_gpu_matches_oracle(kz, O, gpu_lib, path):
+    d = kz.xmlscene.load_xml(path)
     sc = kz.Scene(d, device=0)
     sc.render()
     o = O.OracleScene(d)
