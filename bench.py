@@ -52,10 +52,22 @@ def git_head():
         return None
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) of the kernel and ABI sources: the counter facts of a profile describe ONE build"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "include", "kazen_mi355x.h")]):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_profile_facts(live_ms_per_pass_alone):
     """Counter-derived facts come from a committed rocprofv3 --pmc run of THIS command (profiles/pmc_latest.json, written by
-    scripts/summarize_profile.py with the commit and the profile directory). They describe the code, not this run: they are
-    printed only while the live per-pass time agrees with the profiled build's to 5 %, otherwise they are withheld (null)."""
+    scripts/summarize_profile.py with the commit, the profile directory and a hash of the kernel sources). They describe one
+    build, not this run: they are printed only when the sources are the profiled ones AND the live per-pass time agrees with the
+    profiled build's to 5 %, otherwise they are withheld (null + the reason)."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(path):
         return None, "no profiles/pmc_latest.json"
@@ -63,6 +75,9 @@ def load_profile_facts(live_ms_per_pass_alone):
         facts = json.load(open(path))
     except Exception as e:
         return None, "unreadable: %s" % e
+    if facts.get("source_sha16") != source_hash():
+        return None, "stale: profile %s (commit %s) was taken from other kernel sources (%s, now %s)" % (
+            facts.get("profile"), facts.get("commit"), facts.get("source_sha16"), source_hash())
     ref = facts.get("path_kernels_ms_one_pass_alone")
     if not ref or abs(live_ms_per_pass_alone - ref) > 0.05 * ref:
         return None, "stale: profile %s (commit %s) measured %.2f ms per pass alone, this run %.2f ms" % (

@@ -22,7 +22,9 @@
 #pragma once
 #include "kz_devfn.h"
 
+#ifndef KZ_WF_QCAP
 #define KZ_WF_QCAP 1024            // LDS staging entries per output queue per workgroup
+#endif
 
 struct KzWf {
     float4 *rayA, *rayB;           // o.xyz tmin | d.xyz tmax

@@ -23,7 +23,7 @@ if st:
 # roofline.pass_ms_in_flight is the steady-state distance between the ends of consecutive film kernels (one per pass).
 tr = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
 if tr:
-    ends = sorted(int(r["End_Timestamp"]) for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith("kz_film_gather"))
+    ends = sorted(int(r["End_Timestamp"]) for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith(("kz_film_gather", "kz_film_apply")))
     gaps = sorted((b - a) / 1e6 for a, b in zip(ends, ends[1:]))
     if gaps:
         med = gaps[len(gaps) // 2]
@@ -49,7 +49,7 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
 ids = sorted(disp)
 # bench.py --steps 1 --warmup 0: the first kz_wf_generate .. kz_film_gather run is pass 1 of the step
 first = next((i for i in ids if names[i] == "kz_wf_generate"), None)
-last = next((i for i in ids if i > (first or 0) and names[i] == "kz_film_gather"), None)
+last = next((i for i in ids if i > (first or 0) and names[i] in ("kz_film_gather", "kz_film_apply")), None)
 one_pass = [i for i in ids if first is not None and last is not None and first <= i <= last]
 def derived(c):
     g = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
@@ -89,7 +89,7 @@ def group(prefix):
     return c
 kernels = {}
 for label, prefix in (("kz_wf_trace<0>", "kz_wf_trace<0"), ("kz_wf_trace<2>", "kz_wf_trace<2"), ("kz_wf_shade", "kz_wf_shade"), ("kz_wf_trace_packet", "kz_wf_trace_packet"),
-                      ("kz_film_gather", "kz_film_gather"), ("kz_wf_generate", "kz_wf_generate")):
+                      ("kz_film_gather", "kz_film_gather"), ("kz_film_taps", "kz_film_taps"), ("kz_film_apply", "kz_film_apply"), ("kz_wf_generate", "kz_wf_generate")):
     c = group(prefix)
     if not c.get("SQ_INSTS_VALU"):
         continue
@@ -102,7 +102,9 @@ try:
     commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
 except Exception:
     commit = None
-facts = {"profile": "profiles/" + name, "commit": commit, "bench_value": bench["value"],
+sys.path.insert(0, root)
+from bench import source_hash
+facts = {"profile": "profiles/" + name, "commit": commit, "source_sha16": source_hash(), "bench_value": bench["value"],
          "path_kernels_ms_one_pass_alone": bench["roofline"]["pass_ms_alone"], "samples_per_pass": samples,
          "hbm_bytes_per_sample": round((2 * fetch + write) * 1024 / samples, 1) if fetch else None,
          "fetch_size_kib_raw": fetch, "write_size_kib": write, "kernels": kernels,
