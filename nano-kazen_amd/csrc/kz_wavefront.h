@@ -23,7 +23,7 @@
 #include "kz_devfn.h"
 
 #ifndef KZ_WF_QCAP
-#define KZ_WF_QCAP 1024            // LDS staging entries per output queue per workgroup
+#define KZ_WF_QCAP 960             // LDS staging entries per output queue per workgroup (960: four shade workgroups fit the CU's 160 KB)
 #endif
 
 struct KzWf {
@@ -169,24 +169,34 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
 }
 
 // ---- shade(iter): everything between two ray queries of Li ---------------------------------------------------------------
+// Waves per SIMD the shade kernel is compiled for. The lean variant (constant diffuse / kiss rows) at 4 = 128 VGPRs (18 spilled to
+// scratch) + 40.5 KB LDS: alone it is 4 % slower than at 3 waves / 150 VGPRs, but with two passes in flight the smaller workgroups get
+// onto the CUs between the other pass's persistent traversal workgroups: +1.7 % on C4, +2.1 % on C3 (same gpurun call, r02e). The EXT
+// variant (textures, other BSDF models) needs 168 VGPRs and 48.7 KB: 3.
 #ifndef KZ_SHADE_WAVES
-#define KZ_SHADE_WAVES 3
+#define KZ_SHADE_WAVES 4
 #endif
 // Two passes per round of 256 queue entries, because on many scenes about half of the hits end the path before any shading
 // happens (a one-sided BSDF seen from behind, an emitter, a miss): pass A rebuilds the intersection record and classifies;
 // the entries that still need the light sample and the BSDF sample are compacted through LDS (record = slot + frame + uv),
 // and pass B — which carries ~85 % of the kernel's instructions — only ever runs on full waves.
 #define KZ_SV_CAP (2 * KZ_BLOCK)
+#ifndef KZ_SHADE_CLASSES
+#define KZ_SHADE_CLASSES 1          // 0: every survivor is class 0 (the single stack of round 1)
+#endif
 template <bool STATS, bool EXT>
-__global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
+__global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
                                                         uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm,
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
                                                         uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
     constexpr int SVW = EXT ? 20 : 16;                       // words per survivor: slot, p, s, t, n, uv, mesh (+ dpdu)
     __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
-    __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svN;
-    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svN = 0; }
+    // The survivor table holds TWO stacks (KZ_SHADE_CLASSES): kazenstandard hits grow from entry 0 upwards, all other BSDFs from the last
+    // entry downwards, and pass B always runs on ONE class: the lanes of a wave then walk the same BSDF code (after the first bounce a
+    // third of the hits are on the diffuse room, whose lanes idled through two kiss evaluations and a kiss sample).
+    __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svN, s_svM;
+    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svN = 0; s_svM = 0; }
     __syncthreads();
     WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
     const uint32_t count = countPtr ? *countPtr : countImm;
@@ -197,6 +207,7 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
         const bool more = base < count;                                               // uniform over the workgroup
         // ================= pass A: hit record -> intersection, miss / emitter / back-face end here =================
         bool survivor = false;
+        int svClass = 0;
         uint32_t slot = 0;
         Its its;
         if (more && base + threadIdx.x < count) {
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                     bool twoSided = false;
                     if (EXT) { const int bt = T.bsdfs[mrow.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
                     survivor = (wz > 0.f) || twoSided || isnan(wz);
+                    if (KZ_SHADE_CLASSES && survivor) svClass = T.bsdfs[mrow.bsdf].type == KZ_BSDF_KAZENSTANDARD ? 0 : 1;
                     if (survivor && iter >= 3) {
                         // Russian roulette (integrator.cpp:237-244) here, in front of the compaction: a path it ends does not take a lane of
                         // pass B (at depth 3 and 4 that was 2 of 3 lanes). The survivor's scaled throughput and advanced sampler go back to
@@ -266,13 +278,16 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
                 }
             }
         }
-        {   // compaction of the survivors into the LDS record table
-            const unsigned long long m = __ballot(survivor);
-            uint32_t b = 0;
+        {   // compaction of the survivors into the LDS record table (class 0 from the front, class 1 from the back)
+            const unsigned long long m = __ballot(survivor && svClass == 0), m1 = __ballot(survivor && svClass != 0);
+            uint32_t b = 0, b1 = 0;
             if (lane == 0 && m) b = atomicAdd(&s_svN, (uint32_t)__popcll(m));
-            b = __shfl(b, 0, 64);
+            if (lane == 0 && m1) b1 = atomicAdd(&s_svM, (uint32_t)__popcll(m1));
+            b = __shfl(b, 0, 64); b1 = __shfl(b1, 0, 64);
             if (survivor) {
-                uint32_t *r = s_sv + b + __popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t e = svClass == 0 ? b + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))
+                                                : (uint32_t)KZ_SV_CAP - 1u - (b1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)));
+                uint32_t *r = s_sv + e;
                 r[0] = slot; r[KZ_SV_CAP] = __float_as_uint(its.p.x); r[2 * KZ_SV_CAP] = __float_as_uint(its.p.y); r[3 * KZ_SV_CAP] = __float_as_uint(its.p.z);
                 r[4 * KZ_SV_CAP] = __float_as_uint(its.sh.s.x); r[5 * KZ_SV_CAP] = __float_as_uint(its.sh.s.y); r[6 * KZ_SV_CAP] = __float_as_uint(its.sh.s.z);
                 r[7 * KZ_SV_CAP] = __float_as_uint(its.sh.t.x); r[8 * KZ_SV_CAP] = __float_as_uint(its.sh.t.y); r[9 * KZ_SV_CAP] = __float_as_uint(its.sh.t.z);
@@ -283,12 +298,17 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
         }
         __syncthreads();
         // ================= pass B: one survivor per thread once a full workgroup of them is waiting (or at the end) =================
-        const uint32_t nsv = s_svN;
+        // Before pass A the two stacks hold at most 256 entries together, pass A adds at most 256: the table (512) cannot overflow.
+        // A class with a full workgroup waiting runs; failing that, once more than 256 wait in all (or at the end), the larger class runs
+        // as it is - at least half of what waits, so at most 255 stay.
+        const uint32_t n0 = s_svN, n1 = s_svM;
         bool pushNext = false, pushShadow = false;
-        uint32_t take = 0;
-        if (nsv >= KZ_BLOCK || (!more && nsv > 0)) take = min(nsv, (uint32_t)KZ_BLOCK);
+        uint32_t take = 0; int runClass = 0;
+        if (n0 >= KZ_BLOCK) { take = KZ_BLOCK; runClass = 0; }
+        else if (n1 >= KZ_BLOCK) { take = KZ_BLOCK; runClass = 1; }
+        else if (more ? (n0 + n1 > KZ_BLOCK) : (n0 + n1 > 0)) { runClass = n1 > n0 ? 1 : 0; take = runClass ? n1 : n0; }
         if (threadIdx.x < take) {
-            const uint32_t *r = s_sv + (nsv - take) + threadIdx.x;
+            const uint32_t *r = s_sv + (runClass == 0 ? (n0 - take) + threadIdx.x : (uint32_t)KZ_SV_CAP - 1u - ((n1 - take) + threadIdx.x));
             slot = r[0];
             its.p = mk(__uint_as_float(r[KZ_SV_CAP]), __uint_as_float(r[2 * KZ_SV_CAP]), __uint_as_float(r[3 * KZ_SV_CAP]));
             its.sh.s = mk(__uint_as_float(r[4 * KZ_SV_CAP]), __uint_as_float(r[5 * KZ_SV_CAP]), __uint_as_float(r[6 * KZ_SV_CAP]));
@@ -374,12 +394,12 @@ __global__ __launch_bounds__(KZ_BLOCK, KZ_SHADE_WAVES) void kz_wf_shade(KzParams
             }
         }
         __syncthreads();                                   // every record of this batch has been read
-        if (threadIdx.x == 0 && take) s_svN = nsv - take;
+        if (threadIdx.x == 0 && take) { if (runClass == 0) s_svN = n0 - take; else s_svM = n1 - take; }
         apN.push(pushNext, slot);
         apS.push(pushShadow, slot);
         apN.maybeFlush(false);                             // (syncs: the new s_svN is visible before the next pass A)
         apS.maybeFlush(false);
-        if (!more && nsv - take == 0) break;
+        if (!more && n0 + n1 - take == 0) break;
         if (!more) base -= gridDim.x * KZ_BLOCK;           // stay past the end while the table drains
     }
     apN.maybeFlush(true);
