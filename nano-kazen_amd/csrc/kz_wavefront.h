@@ -182,7 +182,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
 // and pass B — which carries ~85 % of the kernel's instructions — only ever runs on full waves.
 #define KZ_SV_CAP (2 * KZ_BLOCK)
 #ifndef KZ_SHADE_CLASSES
-#define KZ_SHADE_CLASSES 1          // 0: every survivor is class 0 (the single stack of round 1)
+#define KZ_SHADE_CLASSES 0          // 1: two stacks in the survivor table by BSDF class, see kz_wf_shade (measured slower: off)
 #endif
 template <bool STATS, bool EXT>
 __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
@@ -192,9 +192,10 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                                                         uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
     constexpr int SVW = EXT ? 20 : 16;                       // words per survivor: slot, p, s, t, n, uv, mesh (+ dpdu)
     __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
-    // The survivor table holds TWO stacks (KZ_SHADE_CLASSES): kazenstandard hits grow from entry 0 upwards, all other BSDFs from the last
-    // entry downwards, and pass B always runs on ONE class: the lanes of a wave then walk the same BSDF code (after the first bounce a
-    // third of the hits are on the diffuse room, whose lanes idled through two kiss evaluations and a kiss sample).
+    // -DKZ_SHADE_CLASSES=1 (experiment, off): the survivor table holds TWO stacks - kazenstandard hits grow from entry 0 upwards, all other
+    // BSDFs from the last entry downwards - and pass B always runs on ONE class, so that the lanes of a wave walk the same BSDF code.
+    // Measured (same gpurun call, r02e): shade 29.0 -> 31.0 ms on C4, 35.2 -> 37.7 ms on C3: the partial workgroups the smaller class
+    // leaves behind cost more than the divergence between the diffuse and the kiss code did. With the default 0 everything is class 0.
     __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svN, s_svM;
     if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svN = 0; s_svM = 0; }
     __syncthreads();
