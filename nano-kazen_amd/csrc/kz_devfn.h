@@ -276,33 +276,6 @@ __device__ __forceinline__ void node4KeysOf(const uint4 q0, const uint4 q1, cons
         else key[i] = (n <= f) ? 0u : 0xFFFFFFFFu;        // any-hit rays only ask WHETHER a child is hit: no entry distance, no slot bits
     }
 }
-// The same test, returning for every child whether it is hit and max(tnear, tmin) (+inf when missed): the per-lane closest-hit kernel
-// picks the nearest child with float minima and compares instead of building sortable integer keys (8 VALU instructions less per step;
-// the hit flags are wave masks in SGPRs, so the logic on them is scalar).
-__device__ __forceinline__ void node4Near(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax,
-                                          float (&nn)[4], bool (&hit)[4], uint4 &refs) {
-    const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + node);
-    const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
-    refs = np[3];
-    const float ax = __uint_as_float((q0.w & 0xffu) << 23) * rx, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * ry,
-                az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * rz;
-    const float bx = (__uint_as_float(q0.x) - o.x) * rx, by = (__uint_as_float(q0.y) - o.y) * ry, bz = (__uint_as_float(q0.z) - o.z) * rz;
-    const uint32_t nX = rx >= 0.f ? q1.x : q1.w, fX = rx >= 0.f ? q1.w : q1.x;
-    const uint32_t nY = ry >= 0.f ? q1.y : q2.x, fY = ry >= 0.f ? q2.x : q1.y;
-    const uint32_t nZ = rz >= 0.f ? q1.z : q2.y, fZ = rz >= 0.f ? q2.y : q1.z;
-    const kz_f2 AX = {ax, ax}, AY = {ay, ay}, AZ = {az, az}, BX = {bx, bx}, BY = {by, by}, BZ = {bz, bz};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const kz_f2 qx = {(float)((nX >> (8 * i)) & 0xffu), (float)((fX >> (8 * i)) & 0xffu)};
-        const kz_f2 qy = {(float)((nY >> (8 * i)) & 0xffu), (float)((fY >> (8 * i)) & 0xffu)};
-        const kz_f2 qz = {(float)((nZ >> (8 * i)) & 0xffu), (float)((fZ >> (8 * i)) & 0xffu)};
-        const kz_f2 tx = __builtin_elementwise_fma(qx, AX, BX), ty = __builtin_elementwise_fma(qy, AY, BY), tz = __builtin_elementwise_fma(qz, AZ, BZ);
-        const float n = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), tmin);
-        const float f = fminf(fminf(fminf(tx.y, ty.y), tz.y) * 1.0000004f, tmax);
-        hit[i] = n <= f;
-        nn[i] = hit[i] ? n : KZ_INF;
-    }
-}
 template <bool ORDERED = true>
 __device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax,
                                           uint32_t (&key)[4], uint4 &refs) {

@@ -619,17 +619,6 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                     bool p0, p1, p2, p3;                                          // child i goes on the stack
                     uint32_t nxt; bool any;
                     constexpr bool ORDERED = !(MODE == 2 && KZ_SHADOW_SLOT_ORDER);      // shadow launches take the hit children in slot order
-                    constexpr bool FLOATMIN = ORDERED && !KEYS && !TOP && (MODE == 0 || MODE == 1);
-                    if (FLOATMIN) {
-                        // nearest hit child by float minima; equal distances go to the lower slot; the flags are scalar masks
-                        float nn[4]; bool h[4];
-                        node4Near(T, cur, o, rx, ry, rz, tmin, tmax, nn, h, refs);
-                        const float kmin = fminf(fminf(nn[0], nn[1]), fminf(nn[2], nn[3]));
-                        any = h[0] || h[1] || h[2] || h[3];
-                        const bool e0 = nn[0] == kmin, e1 = nn[1] == kmin && !e0, e2 = nn[2] == kmin && !(e0 || nn[1] == kmin), e3 = !(e0 || e1 || e2);
-                        nxt = e0 ? refs.x : (e1 ? refs.y : (e2 ? refs.z : refs.w));
-                        p0 = h[0] && !e0; p1 = h[1] && !e1; p2 = h[2] && !e2; p3 = h[3] && !e3;
-                    } else {
                     if (TOP) {
                         uint4 q0, q1, q2;
                         if (cur < nTop) { const uint4 *lp = s_top + cur * 4u; q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; refs = lp[3]; }
@@ -647,7 +636,6 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                         nxt = pick4b(refs, kmin);
                         p0 = key[0] != 0xFFFFFFFFu && key[0] != kmin; p1 = key[1] != 0xFFFFFFFFu && key[1] != kmin;
                         p2 = key[2] != 0xFFFFFFFFu && key[2] != kmin; p3 = key[3] != 0xFFFFFFFFu && key[3] != kmin;
-                    }
                     }
                     const int c1 = (int)p0, c2 = c1 + (int)p1, c3 = c2 + (int)p2, np = c3 + (int)p3;
                     if (sp + 3 <= LS) {                                              // common case: everything stays in LDS
