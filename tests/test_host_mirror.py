@@ -70,6 +70,19 @@ def test_cpp_render_equals_python_render(exe, kz, O, gpu_lib, tmp_path):
     assert float(np.sqrt(np.mean((rgb - cpu) ** 2))) < 1e-3
 
 
+@pytest.mark.gpu
+def test_cpp_multi_device_render_equals_single_device(exe, kz, gpu_lib, tmp_path):
+    """kazen::renderer::render(scene, devices) (kz_render_multi: one host thread per device, 64x64 tiles dealt by area, films summed on
+    the host) on the devices of this box against renderer::render(scene, device)."""
+    one, multi = str(tmp_path / "one.bin"), str(tmp_path / "multi.bin")
+    subprocess.check_output([exe, "--render", one])
+    devs = ",".join(str(d) for d in range(min(gpu_lib.kz_device_count(), 8)))
+    info = json.loads(subprocess.check_output([exe, "--render-multi", multi, devs]).decode())
+    assert info["pixels"] == 64 * 48 and info["devices"] == len(devs.split(","))
+    a, b = np.fromfile(one, np.float32), np.fromfile(multi, np.float32)
+    assert a.shape == b.shape and float(np.sqrt(np.mean((a - b) ** 2))) < 1e-5
+
+
 # ---------------------------------------------------------------- SURVEY 8f rank 4 through the plugin surface
 def _write_ppm(path, img):
     with open(path, "wb") as f:
