@@ -257,7 +257,9 @@ typedef struct KzTuning {
                                    gather otherwise), 1 = always the staged gather kernel of round 1 */
     int32_t leafQueue;          /* bounce / shadow traversal with a decoupled leaf phase (kz_wf_trace_dq: per-wave job queue in LDS): 0 = default,
                                    1 = off, 2 = on */
-    int32_t reserved[4];
+    int32_t binRays;            /* shade orders each staged window of its output queues by a 4-bit bin (next ray: direction octant + dominant
+                                   axis; shadow ray: light index) before it goes to the global queue: 0 = default, 1 = off, 2 = on */
+    int32_t reserved[3];
 } KzTuning;
 
 typedef struct KzRenderOpts {

@@ -100,7 +100,7 @@ class KzTile(C.Structure):
 class KzTuning(C.Structure):
     _fields_ = [("refill", C.c_int32), ("postpone", C.c_int32), ("batch", C.c_int32), ("traceBlocksPerCU", C.c_int32),
                 ("shadeBlocksPerCU", C.c_int32), ("ldsStack", C.c_int32), ("bvh2", C.c_int32), ("packetPrimary", C.c_int32),
-                ("keyStack", C.c_int32), ("ldsTop", C.c_int32), ("filmGather", C.c_int32), ("leafQueue", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("keyStack", C.c_int32), ("ldsTop", C.c_int32), ("filmGather", C.c_int32), ("leafQueue", C.c_int32), ("binRays", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class KzRenderOpts(C.Structure):

@@ -446,7 +446,7 @@ static const EnvOverride &envOverride() {
         auto I = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
         o.tune.refill = I("KZ_TUNE_REFILL", 0); o.tune.postpone = I("KZ_TUNE_POSTPONE", 0); o.tune.batch = I("KZ_TUNE_BATCH", 0);
         o.tune.traceBlocksPerCU = I("KZ_TUNE_TRAV_BLOCKS", 0); o.tune.shadeBlocksPerCU = I("KZ_TUNE_SHADE_BLOCKS", 0);
-        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0); o.tune.ldsTop = I("KZ_TUNE_LDS_TOP", 0); o.tune.filmGather = I("KZ_TUNE_FILM_GATHER", 0); o.tune.leafQueue = I("KZ_TUNE_LEAF_QUEUE", 0);
+        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0); o.tune.ldsTop = I("KZ_TUNE_LDS_TOP", 0); o.tune.filmGather = I("KZ_TUNE_FILM_GATHER", 0); o.tune.leafQueue = I("KZ_TUNE_LEAF_QUEUE", 0); o.tune.binRays = I("KZ_TUNE_BIN_RAYS", 0);
         if (const char *e = std::getenv("KZ_PASS_ITEMS")) { long long v = std::atoll(e); if (v >= 1024) o.passItems = (uint64_t)v; }
         if (const char *e = std::getenv("KZ_DUAL_STREAM")) o.passesInFlight = std::atoi(e) ? 2 : 1;
         o.pipeline = I("KZ_PIPELINE", 0); o.traceKernel = I("KZ_TRACE_KERNEL", 1); o.mixed = I("KZ_TUNE_MIXED", 0);
@@ -461,7 +461,7 @@ static KzTune resolveTune(const KzTuning &t) {
     r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
     r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 6));
     r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
-    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0); r.leafQueue = pick(t.leafQueue, e.leafQueue, 0);
+    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0); r.leafQueue = pick(t.leafQueue, e.leafQueue, 0); r.binRays = pick(t.binRays, e.binRays, 0);
     r.ovf = nullptr; r.ovfStride = 0;
     return r;
 }
@@ -729,6 +729,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
             c.litCap = items;
         }
     }
+    const int binRays = (tune.binRays == 2 && items < (1u << 28)) ? 1 : 0;        // the bin travels in bits 28-31 of the staged slot index
     const int maxDepth = P.maxDepth;
     c.stageUsed = 0;
     HIP_TRY(hipMemsetAsync(W.counts, 0, 8 * 520 * sizeof(uint32_t), stream));
@@ -767,7 +768,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     const uint32_t *cur = nullptr, *curCount = nullptr;
     for (int iter = 0; iter < maxDepth; ++iter) {
         uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
-#define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
+#define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount, binRays)
         if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
         else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
 #undef KZ_SHADE

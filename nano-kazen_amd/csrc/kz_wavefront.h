@@ -50,21 +50,40 @@ struct WfAppender {
         base = __shfl(base, 0, 64);
         if (pred) s_buf[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
     }
-    // all threads of the workgroup call this; flushes when another 256-item chunk might not fit (or always, if force)
-    __device__ __forceinline__ void maybeFlush(bool force) {
+    // all threads of the workgroup call this; flushes when another 256-item chunk might not fit (or always, if force).
+    // BINNED: the staged values carry a 4-bit bin in bits 28-31 (the slot index of a pass is < 2^28); the flush is a counting sort of
+    // the staged window by bin (histogram and cursors in s_bins[16], LDS atomics), so that the global queue consists of runs of
+    // entries of one bin - rays of one neighbourhood of pixels that point the same way (shade: direction bin of the next ray, light
+    // index of the shadow ray). Only the ORDER of the queue changes, which no result depends on.
+    template <bool BINNED>
+    __device__ __forceinline__ void maybeFlush(bool force, uint32_t *s_bins = nullptr) {
         __syncthreads();
         const uint32_t n = *s_n;
         if (force ? (n > 0) : (n > KZ_WF_QCAP - KZ_BLOCK)) {
             if (threadIdx.x == 0) *s_gb = atomicAdd(gCount, n);
+            if (BINNED) {
+                if (threadIdx.x < 16) s_bins[threadIdx.x] = 0;
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) atomicAdd(&s_bins[s_buf[i] >> 28], 1u);
+                __syncthreads();
+                if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 16; ++b) { const uint32_t c = s_bins[b]; s_bins[b] = acc; acc += c; } }
+            }
             __syncthreads();
             const uint32_t gb = *s_gb;
-            for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) gQueue[gb + i] = s_buf[i];
+            if (BINNED) for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) { const uint32_t v = s_buf[i]; gQueue[gb + atomicAdd(&s_bins[v >> 28], 1u)] = v & 0x0FFFFFFFu; }
+            else for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) gQueue[gb + i] = s_buf[i];
             __syncthreads();
             if (threadIdx.x == 0) *s_n = 0;
         }
         __syncthreads();
     }
+    __device__ __forceinline__ void maybeFlush(bool force) { maybeFlush<false>(force); }
 };
+
+// 4-bit direction bin of a ray: octant + whether z is the dominant axis
+__device__ __forceinline__ uint32_t wfDirBin(V3 d) {
+    return (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u) | ((fabsf(d.z) > fabsf(d.x) && fabsf(d.z) > fabsf(d.y)) ? 8u : 0u);
+}
 
 __device__ __forceinline__ void wfStatsFlush(unsigned long long *stats, const Counters &cn, uint32_t samples) {
     unsigned long long v[7] = {samples, cn.rays, cn.nodes, cn.tris, cn.hits, cn.lsamples, cn.dropped};
@@ -189,14 +208,14 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                                                         uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm,
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
-                                                        uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
+                                                        uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount, int binRays) {
     constexpr int SVW = EXT ? 20 : 16;                       // words per survivor: slot, p, s, t, n, uv, mesh (+ dpdu)
     __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
     // -DKZ_SHADE_CLASSES=1 (experiment, off): the survivor table holds TWO stacks - kazenstandard hits grow from entry 0 upwards, all other
     // BSDFs from the last entry downwards - and pass B always runs on ONE class, so that the lanes of a wave walk the same BSDF code.
     // Measured (same gpurun call, r02e): shade 29.0 -> 31.0 ms on C4, 35.2 -> 37.7 ms on C3: the partial workgroups the smaller class
     // leaves behind cost more than the divergence between the diffuse and the kiss code did. With the default 0 everything is class 0.
-    __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svN, s_svM;
+    __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svN, s_svM; __shared__ uint32_t s_bins[16];
     if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svN = 0; s_svM = 0; }
     __syncthreads();
     WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
@@ -304,6 +323,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
         // as it is - at least half of what waits, so at most 255 stay.
         const uint32_t n0 = s_svN, n1 = s_svM;
         bool pushNext = false, pushShadow = false;
+        uint32_t binNext = 0, binShadow = 0;
         uint32_t take = 0; int runClass = 0;
         if (n0 >= KZ_BLOCK) { take = KZ_BLOCK; runClass = 0; }
         else if (n1 >= KZ_BLOCK) { take = KZ_BLOCK; runClass = 1; }
@@ -369,7 +389,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         W.shA[slot] = make_float4(its.p.x, its.p.y, its.p.z, dist - eps);
                         W.shB[slot] = make_float4(lwi.x, lwi.y, lwi.z, eps);
                         W.shL[slot] = make_float4(pend.x, pend.y, pend.z, 0.f);
-                        pushShadow = true;
+                        pushShadow = true; binShadow = li & 15u;
                     }
                 }
                 if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
@@ -389,22 +409,27 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, etaNext);
                         W.misc[slot] = make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f);
                         wfStoreSampler(P, W, slot, smp);
-                        pushNext = true;
+                        pushNext = true; binNext = wfDirBin(nd);
                     }
                 }
             }
         }
         __syncthreads();                                   // every record of this batch has been read
         if (threadIdx.x == 0 && take) { if (runClass == 0) s_svN = n0 - take; else s_svM = n1 - take; }
-        apN.push(pushNext, slot);
-        apS.push(pushShadow, slot);
-        apN.maybeFlush(false);                             // (syncs: the new s_svN is visible before the next pass A)
-        apS.maybeFlush(false);
+        if (binRays) {
+            apN.push(pushNext, slot | (binNext << 28)); apS.push(pushShadow, slot | (binShadow << 28));
+            apN.maybeFlush<true>(false, s_bins);           // (syncs: the new s_svN is visible before the next pass A)
+            apS.maybeFlush<true>(false, s_bins);
+        } else {
+            apN.push(pushNext, slot); apS.push(pushShadow, slot);
+            apN.maybeFlush(false);
+            apS.maybeFlush(false);
+        }
         if (!more && n0 + n1 - take == 0) break;
         if (!more) base -= gridDim.x * KZ_BLOCK;           // stay past the end while the table drains
     }
-    apN.maybeFlush(true);
-    apS.maybeFlush(true);
+    if (binRays) { apN.maybeFlush<true>(true, s_bins); apS.maybeFlush<true>(true, s_bins); }
+    else { apN.maybeFlush(true); apS.maybeFlush(true); }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
 }
 
@@ -442,7 +467,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // the bounce before: both only depend on the same shade stage, and one launch has one tail instead of two.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment; such
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
-struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop, filmGather, leafQueue; uint32_t *ovf; uint32_t ovfStride; };
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop, filmGather, leafQueue, binRays; uint32_t *ovf; uint32_t ovfStride; };
 
 template <int MODE, bool STATS, bool WIDE, bool KEYS = false, bool TOP = false>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,

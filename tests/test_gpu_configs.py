@@ -182,7 +182,7 @@ def test_state_budget_and_pass_options(gpu_lib, kz, O):
     sc.render(pass_items=npx * 4, tune={"packetPrimary": 2})
     assert np.array_equal(sc.film(), one_at_a_time)
     # stack entries that carry their entry distance (culled at pop time) change the visits, not the hits
-    for t in ({"keyStack": 1}, {"keyStack": 2, "ldsStack": 3}, {"ldsTop": 5}, {"leafQueue": 2}, {"leafQueue": 2, "ldsStack": 2, "refill": 64, "batch": 64}, {"ldsTop": 1000, "ldsStack": 6, "keyStack": 2}, {"keyStack": 1, "packetPrimary": 1}, {"keyStack": 2, "packetPrimary": 1, "ldsStack": 2}):
+    for t in ({"keyStack": 1}, {"keyStack": 2, "ldsStack": 3}, {"ldsTop": 5}, {"binRays": 2}, {"leafQueue": 2}, {"leafQueue": 2, "ldsStack": 2, "refill": 64, "batch": 64}, {"ldsTop": 1000, "ldsStack": 6, "keyStack": 2}, {"keyStack": 1, "packetPrimary": 1}, {"keyStack": 2, "packetPrimary": 1, "ldsStack": 2}):
         sc.render(pass_items=npx * 4, tune=t)
         assert np.array_equal(sc.film(), one_at_a_time), t
     # film reconstruction: per-pixel tap sums + apply (default) vs the staged gather of round 1: same weights, another summation order
