@@ -95,6 +95,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON record: everything else that may write to file descriptor 1 (gloo's "[Gloo] Rank ... is
+    # connected" banner comes from C++ and lands on stdout) is sent to stderr; the record goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -264,7 +270,7 @@ def main():
                           "samples_per_step": int(float(px.item()) * spp_step), "bvh_nodes": bvh["nNodes"], "bvh_depth": bvh["maxDepth"],
                           "film_merge_s": round(merge_s, 4), "image_mean": round(float(rgb.mean()), 5), "commit": git_head()},
                "roofline": roofline, "cpu_baseline": cpu}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
