@@ -144,6 +144,35 @@ __global__ __launch_bounds__(256) void op_loop(int iters, float seed, unsigned l
     if (r == 1234.5678f) sink[0] = r;
 }
 
+// ---- does a wave64 instruction whose upper (or lower) 32 lanes are all masked off issue in one pass of the SIMD-32 instead of two? ----
+template <int MASKMODE>
+__global__ __launch_bounds__(256) void exec_loop(int iters, float seed, unsigned long long *__restrict__ cycles, float *__restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = seed + threadIdx.x + i;
+    const float m = 0.999f, c = 1e-3f;
+    const bool on = MASKMODE == 0 ? true : MASKMODE == 1 ? lane < 32 : MASKMODE == 2 ? (lane & 1) == 0 : MASKMODE == 3 ? lane < 16 : lane >= 32;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (on) {
+        for (int it = 0; it < iters; ++it) {
+            asm volatile(
+                "v_max3_f32 %0, %0, %16, %17\n v_max3_f32 %1, %1, %16, %17\n v_max3_f32 %2, %2, %16, %17\n v_max3_f32 %3, %3, %16, %17\n"
+                "v_max3_f32 %4, %4, %16, %17\n v_max3_f32 %5, %5, %16, %17\n v_max3_f32 %6, %6, %16, %17\n v_max3_f32 %7, %7, %16, %17\n"
+                "v_fma_f32 %8, %8, %16, %17\n v_fma_f32 %9, %9, %16, %17\n v_fma_f32 %10, %10, %16, %17\n v_fma_f32 %11, %11, %16, %17\n"
+                "v_fma_f32 %12, %12, %16, %17\n v_fma_f32 %13, %13, %16, %17\n v_fma_f32 %14, %14, %16, %17\n v_fma_f32 %15, %15, %16, %17\n"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                  "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                : "v"(m), "v"(c));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 || lane == 32) cycles[(blockIdx.x * 256 + threadIdx.x) >> 5] = t1 - t0;
+    float r = 0; for (int i = 0; i < 16; ++i) r += a[i];
+    if (r == 1234.5678f) sink[0] = r;
+}
+
 int main(int argc, char **argv) {
     int only = argc > 1 ? atoi(argv[1]) : -1;
     int iters = argc > 2 ? atoi(argv[2]) : 20000;
@@ -151,7 +180,7 @@ int main(int argc, char **argv) {
     const int cus = prop.multiProcessorCount;
     printf("{\"device\": \"%s\", \"cus\": %d, \"iters\": %d, \"results\": [\n", prop.name, cus, iters);
     unsigned long long *dC; float *dS;
-    CK(hipMalloc(&dC, sizeof(unsigned long long) * cus * 8 * 4)); CK(hipMalloc(&dS, 64));
+    CK(hipMalloc(&dC, sizeof(unsigned long long) * cus * 8 * 8)); CK(hipMalloc(&dS, 64));
     bool first = true;
     for (int v = 0; v < 5; ++v) {
         if (only >= 0 && only != v) continue;
@@ -202,6 +231,22 @@ int main(int argc, char **argv) {
         const double perSimdPerCycle = 8.0 * (v == 15 ? 64 : 32) * iters / (ms * 1e-3 * 2.4e9);
         printf(", {\"op\": \"%s\", \"waves_per_simd\": 8, \"ms\": %.3f, \"asm_instr_per_iter\": 32, \"wave_instr_per_cycle_per_simd_at_2p4GHz\": %.4f, "
                "\"cycles_per_instr_at_2p4GHz\": %.3f}\n", opName[v], ms, perSimdPerCycle, 1.0 / perSimdPerCycle);
+    }
+
+    static const char *maskName[] = {"all 64 lanes", "lanes 0-31", "even lanes (32 active, both halves)", "lanes 0-15", "lanes 32-63"};
+    for (int v = 0; v < 5 && only < 0; ++v) {
+        const int wps = 8, blocks = cus * wps;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            switch (v) {
+#define LAUNCHX(K) case K: hipLaunchKernelGGL(exec_loop<K>, dim3(blocks), dim3(256), 0, 0, iters, 1.0f, dC, dS); break;
+                LAUNCHX(0) LAUNCHX(1) LAUNCHX(2) LAUNCHX(3) LAUNCHX(4)
+            }
+            CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        }
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf(", {\"exec_mask\": \"%s\", \"waves_per_simd\": 8, \"ms\": %.3f, \"asm_instr_per_iter\": 16}\n", maskName[v], ms);
     }
     printf("]}\n");
     return 0;
