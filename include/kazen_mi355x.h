@@ -389,6 +389,14 @@ int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *
 /* Texture<Color3f>::eval(uv) (texture.h) of textures[tex[i]] at uv (n x 2); out n x 3. */
 int kz_texture_query(KzScene *scene, uint32_t n, const int32_t *tex, const float *uv, float *out);
 
+/* Camera::sampleRay (camera.cpp:70-91 perspective, 191-223 thinlens) of the scene's camera for n pixel-sample positions
+ * sxy (n x 2, pixel units) and aperture samples axy (n x 2, NULL = 0.5,0.5); out n x 8 = o xyz, d xyz, mint, maxt. */
+int kz_camera_rays(KzScene *scene, uint32_t n, const float *sxy, const float *axy, float *out);
+/* AreaLight::sample (light.cpp:16-34) via Mesh::sample (mesh.cpp:108-133) of light light[i] (index in Scene::m_lights
+ * order) seen from ref (n x 3) with Mesh::sample's three next1D draws u3 (n x 3); out n x 14 = p xyz, n xyz, wi xyz,
+ * pdf (solid angle, light.cpp:36-51), eval/pdf rgb (0 where the pdf is 0, nan or inf), triangle index. */
+int kz_light_query(KzScene *scene, uint32_t n, const int32_t *light, const float *ref, const float *u3, float *out);
+
 /* Statistics: enable=1 switches to the counting kernel variant (slower). */
 int kz_set_stats(KzScene *scene, int enable);
 int kz_get_stats(KzScene *scene, KzStats *out, int reset);

@@ -143,7 +143,7 @@ EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
            "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8",
            "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
-           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info"]
+           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KZ_LIB_PATH: a development build of the library (scripts/build_variant.sh) instead of the in-tree one; probes only
@@ -188,6 +188,9 @@ def load_library():
     lib.kz_bsdf_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p]
     lib.kz_film_to_srgb8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
     lib.kz_texture_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p]
+    if hasattr(lib, "kz_camera_rays"):        # absent only in a KZ_LIB_PATH development build of older sources (same-call A/B runs)
+        lib.kz_camera_rays.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, f32p]
+        lib.kz_light_query.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), f32p, f32p, f32p]
     lib.kz_scene_evict.argtypes = [C.c_void_p, C.c_int]
     lib.kz_scene_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, u32p]
     lib.kz_render_tiles.argtypes = [C.c_void_p, C.POINTER(KzRenderOpts), C.POINTER(KzTile), C.c_uint32, C.c_int, f32p, C.c_size_t]

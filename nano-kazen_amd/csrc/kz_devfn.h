@@ -1016,6 +1016,37 @@ __device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, floa
     return min((uint32_t)idx, n - 1);
 }
 
+// Light::sample of an area light (light.cpp:16-34) through Mesh::sample (mesh.cpp:108-133): the triangle by the area cdf, then
+// the sqrt warp; `draw()` supplies Mesh::sample's three next1D values IN ORDER (the path kernels hand in the sampler, the
+// kz_light_query kernel a table). Ls = eval / pdf (0 when the pdf is 0, nan or inf), not yet divided by the pick pdf.
+struct LightSample { V3 p, n, wi, Ls; float dist, pdf; uint32_t tri; };
+template <class Draw>
+__device__ __forceinline__ LightSample lightSample(const KzDevTables &T, const KzLightRow &lrow, V3 ref, Draw draw) {
+    LightSample r;
+    r.tri = cdfSample(T.cdf + lrow.cdfOffset, lrow.nF, draw());
+    const float su0 = sqrtf(draw());
+    const float u = 1 - su0;
+    const float v = draw() * su0;
+    const float4 *sp = reinterpret_cast<const float4 *>(T.shade + lrow.triOffset + r.tri);
+    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+    const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
+    r.p = p0 + u * (p1 - p0) + v * (p2 - p0);
+    if (T.meshes[lrow.mesh].flags & 1u) {
+        const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
+        r.n = n0 + u * (n1 - n0) + v * (n2 - n0);                                         // H8: not normalised
+    } else r.n = normalized(cross(p1 - p0, p2 - p0));
+    const V3 toL = r.p - ref;
+    r.wi = normalized(toL);
+    r.dist = norm(toL);
+    r.pdf = lightPdfSolidAngle(lrow.normalization, r.n, r.wi, r.p, ref);
+    r.Ls = mk(0.f);
+    if (r.pdf > 0.f && !isnan(r.pdf) && !isinf(r.pdf)) {
+        const V3 ev = dot(r.n, -r.wi) > 0.f ? mk(lrow.radiance[0], lrow.radiance[1], lrow.radiance[2]) : mk(0.f);
+        r.Ls = ev / r.pdf;
+    }
+    return r;
+}
+
 __device__ __forceinline__ float powerHeuristic(float a, float b) { a *= a; b *= b; return a > 0.f ? a / (a + b) : 0.f; }   // integrator.cpp:340-344
 
 // a3 PerspectiveCamera::sampleRay (camera.cpp:70-91, transform.h:49-62)
@@ -1090,29 +1121,9 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
             const KzLightRow lrow = T.lights[li];
             if (STATS) cn.lsamples++;
-            // Mesh::sample: three 1-D draws
-            uint32_t tri = cdfSample(T.cdf + lrow.cdfOffset, lrow.nF, smp.next1D(P, T));
-            float su0 = sqrtf(smp.next1D(P, T));
-            float u = 1 - su0;
-            float v = smp.next1D(P, T) * su0;
-            const float4 *sp = reinterpret_cast<const float4 *>(T.shade + lrow.triOffset + tri);
-            const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-            const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
-            V3 lp = p0 + u * (p1 - p0) + v * (p2 - p0);
-            V3 ln;
-            if (T.meshes[lrow.mesh].flags & 1u) {
-                const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
-                ln = n0 + u * (n1 - n0) + v * (n2 - n0);                                      // H8: not normalised
-            } else ln = normalized(cross(p1 - p0, p2 - p0));
-            V3 toL = lp - its.p;
-            V3 lwi = normalized(toL);
-            float dist = norm(toL);
-            float lpdf = lightPdfSolidAngle(lrow.normalization, ln, lwi, lp, its.p);
-            V3 Ls = mk(0.f);
-            if (lpdf > 0.f && !isnan(lpdf) && !isinf(lpdf)) {
-                V3 ev = dot(ln, -lwi) > 0.f ? mk(lrow.radiance[0], lrow.radiance[1], lrow.radiance[2]) : mk(0.f);
-                Ls = ev / lpdf;
-            }
+            const LightSample ls = lightSample(T, lrow, its.p, [&]() { return smp.next1D(P, T); });     // Mesh::sample: three 1-D draws
+            const V3 lwi = ls.wi; const float dist = ls.dist, lpdf = ls.pdf;
+            V3 Ls = ls.Ls;
             Ls = Ls / P.lightPickPdf;
             // shadow ray with the invisible-light walk-through (integrator.cpp:257-278); closest-hit, like the reference
             const bool occluded = shadowOccluded<STATS>(P, T, its.p, lwi, eps, dist - eps, stk, cn);

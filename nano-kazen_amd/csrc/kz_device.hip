@@ -340,6 +340,30 @@ __global__ void kz_texture_kernel(KzDevTables T, uint32_t n, const int32_t *__re
     out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
 }
 
+// a3 / a18: the camera and area-light functions the path kernels call, on explicit inputs (known-answer tests on the device).
+// camera: out 8 = o xyz, d xyz, mint, maxt for pixel-sample position sxy and aperture sample axy (NULL = the 0.5,0.5 a pinhole ignores).
+__global__ void kz_camera_kernel(KzParams P, uint32_t n, const float *__restrict__ sxy, const float *__restrict__ axy, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o, d; float mint, maxt;
+    cameraRay(P, sxy[2 * i], sxy[2 * i + 1], axy ? axy[2 * i] : 0.5f, axy ? axy[2 * i + 1] : 0.5f, o, d, mint, maxt);
+    float *r = out + 8 * (size_t)i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = mint; r[7] = maxt;
+}
+// light: out 14 = p xyz, n xyz, wi xyz, pdf (solid angle), Ls rgb (eval / pdf), triangle index, for light row light[i] seen from ref
+// with Mesh::sample's three draws u3.
+__global__ void kz_light_kernel(KzDevTables T, uint32_t n, const int32_t *__restrict__ light, const float *__restrict__ ref, const float *__restrict__ u3,
+                                float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const KzLightRow lrow = T.lights[light[i]];
+    uint32_t k = 0;
+    const LightSample ls = lightSample(T, lrow, mk(ref[3 * i], ref[3 * i + 1], ref[3 * i + 2]), [&]() { return u3[3 * i + (k++)]; });
+    float *r = out + 14 * (size_t)i;
+    r[0] = ls.p.x; r[1] = ls.p.y; r[2] = ls.p.z; r[3] = ls.n.x; r[4] = ls.n.y; r[5] = ls.n.z; r[6] = ls.wi.x; r[7] = ls.wi.y; r[8] = ls.wi.z;
+    r[9] = ls.pdf; r[10] = ls.Ls.x; r[11] = ls.Ls.y; r[12] = ls.Ls.z; r[13] = (float)ls.tri;
+}
+
 // ============================================================================================
 // host side: replicas (one device state per GPU the scene is resident on), upload, passes, the multi-device driver
 // ============================================================================================
@@ -1252,6 +1276,43 @@ int kz_texture_query(KzScene *scene, uint32_t n, const int32_t *tex, const float
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dO, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return KZ_OK;
+}
+
+// PerspectiveCamera / ThinLensCamera::sampleRay (camera.cpp:70-91, 191-223) of the scene's camera: out n x 8.
+int kz_camera_rays(KzScene *scene, uint32_t n, const float *sxy, const float *axy, float *out) {
+    KzDeviceState *ds; int rc;
+    if ((rc = requireDevice(scene, &ds))) return rc;
+    if (n == 0) return KZ_OK;
+    if (!sxy || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
+    DevMem dF;
+    KZ_ALLOC(&dF.p, (size_t)n * 12 * 4);
+    float *d = dF.as<float>(), *dS = d, *dA = d + 2 * (size_t)n, *dO = d + 4 * (size_t)n;
+    HIP_TRY(hipMemcpy(dS, sxy, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (axy) HIP_TRY(hipMemcpy(dA, axy, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_camera_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, scene->prm, n, dS, axy ? dA : (const float *)nullptr, dO);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dO, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return KZ_OK;
+}
+
+// AreaLight::sample (light.cpp:16-34) of light rows (the order of Scene::m_lights) from reference points: out n x 14.
+int kz_light_query(KzScene *scene, uint32_t n, const int32_t *light, const float *ref, const float *u3, float *out) {
+    KzDeviceState *ds; int rc;
+    if ((rc = requireDevice(scene, &ds))) return rc;
+    if (n == 0) return KZ_OK;
+    if (!light || !ref || !u3 || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
+    for (uint32_t i = 0; i < n; ++i) if (light[i] < 0 || (uint32_t)light[i] >= scene->prm.nLights) return kz_fail(KZ_ERR_INVALID_ARG, "light index %d", light[i]);
+    DevMem dF, dL;
+    KZ_ALLOC(&dF.p, (size_t)n * 20 * 4); KZ_ALLOC(&dL.p, (size_t)n * 4);
+    float *d = dF.as<float>(), *dR = d, *dU = d + 3 * (size_t)n, *dO = d + 6 * (size_t)n;
+    HIP_TRY(hipMemcpy(dL.p, light, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dR, ref, (size_t)n * 12, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dU, u3, (size_t)n * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_light_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, ds->T, n, dL.as<int32_t>(), dR, dU, dO);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dO, (size_t)n * 56, hipMemcpyDeviceToHost));
     return KZ_OK;
 }
 

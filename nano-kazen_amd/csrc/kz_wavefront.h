@@ -357,28 +357,9 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     const uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
                     const KzLightRow lrow = T.lights[li];
                     if (STATS) cn.lsamples++;
-                    const uint32_t tri = cdfSample(T.cdf + lrow.cdfOffset, lrow.nF, smp.next1D(P, T));
-                    const float su0 = sqrtf(smp.next1D(P, T));
-                    const float u = 1 - su0;
-                    const float v = smp.next1D(P, T) * su0;
-                    const float4 *sp = reinterpret_cast<const float4 *>(T.shade + lrow.triOffset + tri);
-                    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-                    const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
-                    const V3 lp = p0 + u * (p1 - p0) + v * (p2 - p0);
-                    V3 ln;
-                    if (T.meshes[lrow.mesh].flags & 1u) {
-                        const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
-                        ln = n0 + u * (n1 - n0) + v * (n2 - n0);                      // H8
-                    } else ln = normalized(cross(p1 - p0, p2 - p0));
-                    const V3 toL = lp - its.p;
-                    const V3 lwi = normalized(toL);
-                    const float dist = norm(toL);
-                    const float lpdf = lightPdfSolidAngle(lrow.normalization, ln, lwi, lp, its.p);
-                    V3 Ls = mk(0.f);
-                    if (lpdf > 0.f && !isnan(lpdf) && !isinf(lpdf)) {
-                        const V3 ev = dot(ln, -lwi) > 0.f ? mk(lrow.radiance[0], lrow.radiance[1], lrow.radiance[2]) : mk(0.f);
-                        Ls = ev / lpdf;
-                    }
+                    const LightSample ls = lightSample(T, lrow, its.p, [&]() { return smp.next1D(P, T); });
+                    const V3 lwi = ls.wi; const float dist = ls.dist, lpdf = ls.pdf;
+                    V3 Ls = ls.Ls;
                     Ls = Ls / P.lightPickPdf;
                     const V3 woL = toLocal(its.sh, lwi);
                     const V3 f = surfEval<EXT>(bsdf, nm, its, wiLocal, woL, accRough);

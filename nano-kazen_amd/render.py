@@ -171,6 +171,24 @@ class Scene:
                                                       out.ctypes.data_as(abi.f32p)))
         return out
 
+    def camera_rays(self, sxy, axy=None):
+        """Camera::sampleRay for pixel-sample positions sxy (n,2) and aperture samples axy (n,2) -> (n,8) = o, d, mint, maxt."""
+        sxy = np.ascontiguousarray(sxy, np.float32)
+        axy = None if axy is None else np.ascontiguousarray(axy, np.float32)
+        out = np.zeros((sxy.shape[0], 8), np.float32)
+        f = lambda a: a.ctypes.data_as(abi.f32p)
+        abi.check(self.lib, self.lib.kz_camera_rays(self.h, sxy.shape[0], f(sxy), None if axy is None else f(axy), f(out)))
+        return out
+
+    def light_query(self, light, ref, u3):
+        """AreaLight::sample of light rows from ref with Mesh::sample's three draws -> (n,14) = p, n, wi, pdf, eval/pdf, triangle."""
+        light = np.ascontiguousarray(light, np.int32)
+        ref, u3 = np.ascontiguousarray(ref, np.float32), np.ascontiguousarray(u3, np.float32)
+        out = np.zeros((light.shape[0], 14), np.float32)
+        f = lambda a: a.ctypes.data_as(abi.f32p)
+        abi.check(self.lib, self.lib.kz_light_query(self.h, light.shape[0], light.ctypes.data_as(C.POINTER(C.c_int32)), f(ref), f(u3), f(out)))
+        return out
+
     def srgb8(self):
         """(h, w, 3) uint8: the raster Bitmap::savePNG writes (bitmap.cpp:39-62), resolved on the device."""
         out = np.zeros((self.height, self.width, 3), np.uint8)

@@ -1884,6 +1884,11 @@ void kzo_camera_ray(void *s, float sx, float sy, float *o6, float *mint, float *
     Scene &sc = *(Scene *)s; Ray r; cameraSampleRay(sc, sx, sy, 0.5f, 0.5f, r);
     o6[0] = r.o.x; o6[1] = r.o.y; o6[2] = r.o.z; o6[3] = r.d.x; o6[4] = r.d.y; o6[5] = r.d.z; *mint = r.mint; *maxt = r.maxt;
 }
+// the same with the aperture sample given (ThinLensCamera::sampleRay, camera.cpp:191-223; a pinhole ignores it)
+void kzo_camera_ray_lens(void *s, float sx, float sy, float ax, float ay, float *o6, float *mint, float *maxt) { FtzScope ftz_;
+    Scene &sc = *(Scene *)s; Ray r; cameraSampleRay(sc, sx, sy, ax, ay, r);
+    o6[0] = r.o.x; o6[1] = r.o.y; o6[2] = r.o.z; o6[3] = r.d.x; o6[4] = r.d.y; o6[5] = r.d.z; *mint = r.mint; *maxt = r.maxt;
+}
 void kzo_filter_table(void *s, float *tab33, float *radius, int *border) {
     Scene &sc = *(Scene *)s; std::memcpy(tab33, sc.filter, sizeof sc.filter); *radius = sc.filterRadius; *border = sc.border;
 }

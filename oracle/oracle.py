@@ -65,6 +65,8 @@ def lib():
         L.kzo_sampler_stream.restype = None
         L.kzo_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, abi.f32p, abi.f32p, abi.f32p]
         L.kzo_camera_ray.restype = None
+        L.kzo_camera_ray_lens.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, abi.f32p, abi.f32p, abi.f32p]
+        L.kzo_camera_ray_lens.restype = None
         L.kzo_background.argtypes = [C.c_void_p, abi.f32p, abi.f32p]
         L.kzo_background.restype = None
         L.kzo_filter_table.argtypes = [C.c_void_p, abi.f32p, abi.f32p, C.POINTER(C.c_int)]
@@ -179,10 +181,13 @@ class OracleScene:
         self.L.kzo_background(self.h, _fp(d), _fp(out))
         return out
 
-    def camera_ray(self, sx, sy):
+    def camera_ray(self, sx, sy, ax=None, ay=None):
         o6 = np.zeros(6, np.float32)
         a, b = C.c_float(), C.c_float()
-        self.L.kzo_camera_ray(self.h, sx, sy, _fp(o6), C.byref(a), C.byref(b))
+        if ax is None:
+            self.L.kzo_camera_ray(self.h, sx, sy, _fp(o6), C.byref(a), C.byref(b))
+        else:
+            self.L.kzo_camera_ray_lens(self.h, sx, sy, ax, ay, _fp(o6), C.byref(a), C.byref(b))
         return o6, a.value, b.value
 
     def filter_table(self):

@@ -436,3 +436,76 @@ def test_two_passes_in_flight_equal_one_at_a_time(gpu_lib, kz, O):
     assert l2(sc.rgb(one_at_a_time), ora.rgb(ora.render(threads=0))) < L2_TOL
     sc.render()                                                      # one pass
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- a3 camera rays and a18 light samples as stand-alone device tables
+def _camera_cases(S):
+    pin = S.cornell_box(160, 96, 4)
+    lens = _thinlens(S)
+    off = S.hero_scene(77, 45, 4, detail=0.3)
+    off.camera.update(fov=63.0, nearClip=0.25, farClip=300.0)
+    return {"pinhole": pin, "thinlens": lens, "ragged_fov": off}
+
+
+@pytest.mark.parametrize("name", ["pinhole", "thinlens", "ragged_fov"])
+def test_camera_rays_match_oracle(gpu_lib, kz, O, name):
+    """Camera::sampleRay (camera.cpp:70-91, 191-223) on the device for explicit pixel-sample and aperture positions, against the
+    oracle's cameraSampleRay: corners, centres, out-of-frame positions (the reconstruction filter never asks for them, the function
+    is still defined there) and the aperture rim."""
+    desc = _camera_cases(kz.scenes)[name]
+    sc, ora = kz.Scene(desc, device=0), O.OracleScene(desc)
+    w, h = desc.camera["width"], desc.camera["height"]
+    rng = np.random.default_rng(11)
+    sxy = np.concatenate([np.array([[0, 0], [w, h], [w, 0], [0, h], [w / 2, h / 2], [0.5, 0.5], [-1.5, h + 2.0]], np.float32),
+                          (rng.random((249, 2)) * [w, h]).astype(np.float32)])
+    axy = np.concatenate([np.array([[0, 0], [1, 1], [0.5, 0.5], [1, 0], [0, 1], [0.999999, 0.25], [0.25, 0.999999]], np.float32),
+                          rng.random((249, 2)).astype(np.float32)])
+    got = sc.camera_rays(sxy, axy)
+    ref = np.zeros_like(got)
+    for i in range(len(sxy)):
+        o6, a, b = ora.camera_ray(float(sxy[i, 0]), float(sxy[i, 1]), float(axy[i, 0]), float(axy[i, 1]))
+        ref[i, :6], ref[i, 6], ref[i, 7] = o6, a, b
+    assert np.allclose(got, ref, rtol=2e-6, atol=1e-7), np.abs(got - ref).max()
+    # without aperture samples the entry uses (0.5, 0.5), the oracle's plain entry
+    got0 = sc.camera_rays(sxy[:16])
+    for i in range(16):
+        o6, a, b = ora.camera_ray(float(sxy[i, 0]), float(sxy[i, 1]))
+        assert np.allclose(got0[i, :6], o6, rtol=2e-6, atol=1e-7) and np.isclose(got0[i, 6], a, rtol=2e-6) and np.isclose(got0[i, 7], b, rtol=2e-6)
+    # unit directions; mint/maxt are the clip planes over cos(theta) to the optical axis
+    assert np.allclose(np.linalg.norm(got[:, 3:6], axis=1), 1.0, atol=1e-6)
+    assert (got[:, 7] > got[:, 6]).all() and (got[:, 6] > 0).all()
+
+
+def _light_scenes(S):
+    return {"cornell": S.cornell_box(64, 64, 4), "hero": S.hero_scene(64, 36, 4, detail=0.3), "fuzz3": _fuzz_scene(S, 3), "fuzz7": _fuzz_scene(S, 7)}
+
+
+@pytest.mark.parametrize("name", ["cornell", "hero", "fuzz3", "fuzz7"])
+def test_light_samples_match_oracle(gpu_lib, kz, O, name):
+    """AreaLight::sample / pdf / eval (light.cpp:16-51) through Mesh::sample (mesh.cpp:108-133, dpdf.h:99-104) on the device — the function
+    the shade kernel calls — for every light of the scene: triangle picked by the area cdf (bit exact, including draws of 0, on cdf
+    entries and next to 1), position, normal (interpolated, not normalised, when the mesh has normals: H8), direction, solid-angle pdf
+    (0 behind the light), and eval/pdf."""
+    desc = _light_scenes(kz.scenes)[name]
+    sc, ora = kz.Scene(desc, device=0), O.OracleScene(desc)
+    n_lights = sum(1 for m in desc.meshes if m.get("light"))
+    assert n_lights > 0
+    rng = np.random.default_rng(5)
+    per = 192
+    light = np.repeat(np.arange(n_lights, dtype=np.int32), per)
+    n = len(light)
+    ref = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    u3 = rng.random((n, 3)).astype(np.float32)
+    edge = np.array([0.0, np.nextafter(np.float32(1), np.float32(0)), 0.5, 0.25, 0.75, np.float32(1e-8)], np.float32)
+    for li in range(n_lights):
+        u3[li * per:li * per + 6, 0] = edge
+        u3[li * per + 6:li * per + 12, 1] = edge
+        u3[li * per + 12:li * per + 18, 2] = edge
+    got = sc.light_query(light, ref, u3)
+    want = np.stack([ora.light_sample(int(light[i]), ref[i], float(u3[i, 0]), float(u3[i, 1]), float(u3[i, 2])) for i in range(n)])
+    assert (got[:, 13] == want[:, 13]).all()                                  # the triangle: integer work
+    assert np.array_equal(got[:, 9] == 0, want[:, 9] == 0)                    # back-facing samples have pdf 0 on both sides
+    assert np.allclose(got[:, :13], want[:, :13], rtol=2e-6, atol=1e-7), np.abs(got[:, :13] - want[:, :13]).max()
+    assert (got[:, 9] > 0).any() and (got[:, 9] == 0).any()
+    z = got[:, 9] == 0
+    assert (got[z, 10:13] == 0).all()
