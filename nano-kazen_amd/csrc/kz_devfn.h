@@ -83,6 +83,7 @@ __device__ __forceinline__ uint32_t permuteIdx(uint32_t i, uint32_t l, uint32_t 
         i *= 0x6935fa69; i ^= (i & w) >> 11; i *= 0x74dcb303; i ^= (i & w) >> 2;
         i *= 0x9e501cc3; i ^= (i & w) >> 2; i *= 0xc860a3df; i &= w; i ^= i >> 5;
     } while (i >= l);
+    if ((l & w) == 0) return (i + p) & w;         // l a power of two (w = l - 1): the same value as the modulo, without the division
     return (i + p) % l;
 }
 
@@ -124,7 +125,7 @@ struct Sampler {
     __device__ __forceinline__ float blueNoise(const KzDevTables &T, uint32_t tex) const {            // bluenoise.h:16-23
         uint32_t t = tex % KZ_BLUENOISE_TEXTURES;
         uint32_t x = (uint32_t)px % KZ_BLUENOISE_RES, y = (uint32_t)py % KZ_BLUENOISE_RES;
-        return (float)T.bn[(t * KZ_BLUENOISE_RES + x) * KZ_BLUENOISE_RES + y] / 65535.f;
+        return T.bn[(t * KZ_BLUENOISE_RES + x) * KZ_BLUENOISE_RES + y];
     }
     __device__ float next1D(const KzParams &P, const KzDevTables &T) {
         if (type == KZ_SAMPLER_INDEPENDENT) return nextFloat();
@@ -146,7 +147,8 @@ struct Sampler {
         int index = (int)permuteIdx(idx, P.sampleCount, (uint32_t)h);
         float delta = blueNoise(T, dim);
         ++dim;
-        return fminf(((float)index + delta) / (float)P.sampleCount, KZ_ONE_MINUS_EPS);
+        const float num = (float)index + delta;
+        return fminf(P.sppPow2 ? num * P.invSpp : num / (float)P.sampleCount, KZ_ONE_MINUS_EPS);    // exact either way (kz_internal.h)
     }
     __device__ void next2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
         if (type == KZ_SAMPLER_INDEPENDENT) { y = nextFloat(); x = nextFloat(); return; }
@@ -180,8 +182,8 @@ struct Sampler {
             index = permuteIdx(idx, P.sampleCount, (uint32_t)h);
         }
         inst %= KZ_PMJ02BN_SETS; index %= KZ_PMJ02BN_SAMPLES;
-        const uint2 e = *reinterpret_cast<const uint2 *>(T.pmj + ((size_t)inst * KZ_PMJ02BN_SAMPLES + index) * 2);
-        float ux = (float)((double)e.x * 0x1p-32), uy = (float)((double)e.y * 0x1p-32);     // pmj02table.h:28-29 (double, then narrowed)
+        const float2 e = reinterpret_cast<const float2 *>(T.pmj)[(size_t)inst * KZ_PMJ02BN_SAMPLES + index];                 // pmj02table.h:28-29, narrowed on the host
+        float ux = e.x, uy = e.y;
         ux += blueNoise(T, dim); uy += blueNoise(T, dim + 1);
         if (ux >= 1) ux -= 1;
         if (uy >= 1) uy -= 1;
@@ -511,7 +513,7 @@ __device__ __forceinline__ V3 squareToCosineHemisphere(float sx, float sy) {
     if (r1 == 0 && r2 == 0) { r = phi = 0; }
     else if (r1 * r1 > r2 * r2) { r = r1; phi = (KZ_PI_F / 4.0f) * (r2 / r1); }
     else { r = r2; phi = (KZ_PI_F / 2.0f) - (r1 / r2) * (KZ_PI_F / 4.0f); }
-    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    float sinPhi, cosPhi; sincosf(phi, &sinPhi, &cosPhi);             // one argument reduction for both (the values of sinf / cosf)
     float px = r * cosPhi, py = r * sinPhi;
     float z = sqrtf(1.0f - px * px - py * py);
     if (z == 0) z = 1e-10f;
@@ -519,7 +521,11 @@ __device__ __forceinline__ V3 squareToCosineHemisphere(float sx, float sy) {
 }
 struct A2 { float x, y; };
 __device__ __forceinline__ V3 schlickFresnel(V3 f0, float cosTheta) {            // ggx_brdf.h:15-24
-    float t = powf(1.0f - cosTheta, 5.0f);
+    // pow(1 - cosTheta, 5.0f) (ggx_brdf.h:23; glibc powf, < 0.53 ulp): the fifth power in double, narrowed once - within 2^-51 of the exact
+    // value before the narrowing, so it equals the correctly rounded float except for ~1 argument in 2^27; ocml's powf costs 168 VALU
+    // instructions per call and is the less accurate of the two (scripts/micro/shade_cost.sh)
+    const double xd = (double)(1.0f - cosTheta), xd2 = xd * xd;
+    float t = (float)(xd2 * xd2 * xd);
     return f0 * 1.0f + (mk(1.f) - f0) * t;
 }
 __device__ __forceinline__ A2 roughnessToAlpha(float roughness, float anisotropy) {   // ggx_brdf.h:28-37
@@ -552,7 +558,8 @@ __device__ __forceinline__ V3 sampleGGXVNDF(V3 V, A2 a, float rx, float ry) {   
     V3 T2 = normalized(cross(Vh, T1));
     float r = sqrtf(rx);
     float phi = 2.0f * KZ_PI_F * ry;
-    float t1 = r * cosf(phi), t2 = r * sinf(phi);
+    float sinPhi, cosPhi; sincosf(phi, &sinPhi, &cosPhi);
+    float t1 = r * cosPhi, t2 = r * sinPhi;
     float s = 0.5f * (1.0f + Vh.z);
     t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
     V3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
@@ -573,38 +580,70 @@ __device__ __forceinline__ float schlickWeight(float x) { x = fminf(fmaxf(1.f - 
 __device__ __forceinline__ float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
 __device__ __forceinline__ V3 reflectV(V3 wi, V3 n) { return 2 * dot(n, wi) * n - wi; }
 
-__device__ V3 kissEval(const KzBSDF &m, V3 V, V3 L, float accRough) {            // bsdf.cpp:1215-1267
-    if (V.z <= 0 || L.z <= 0) return mk(0.f);
-    V3 H = normalized(V + L);
-    V3 Cdlin = mk(m.baseColor[0], m.baseColor[1], m.baseColor[2]);
-    float metallic = m.metallic;
-    float roughness = fminf(1.f, m.roughness + accRough);
-    float Cdlum = luminance(Cdlin);
-    V3 Ctint = Cdlum > 0.f ? Cdlin / Cdlum : mk(1.f);
-    V3 Ctintmix = 0.08f * m.specular * lerp3(mk(1.f), Ctint, m.specularTint);
-    V3 Cspec0 = lerp3(Ctintmix, Cdlin, metallic);
-    float FL = schlickWeight(L.z), FV = schlickWeight(V.z), FH = schlickWeight(dot(L, H));
-    float cosThetaD = dot(V, H);
-    float Lambert = (1.f - 0.5f * FL) * (1.f - 0.5f * FV);
-    float RR = 2.f * roughness * cosThetaD * cosThetaD;
-    float retro = RR * (FL + FV + FL * FV * (RR - 1.f));
-    V3 Csheen = lerp3(mk(1.f), Ctint, m.sheenTint);
-    V3 Fsheen = FH * m.sheen * Csheen;
-    V3 specTerm = evalGGXSmithBRDF(V, L, Cspec0, roughness, m.anisotropy);
-    float ccR = lerpf(m.clearcoatRoughness, .01f, .3f);
-    V3 coatTerm = 0.25f * m.clearcoat * evalGGXSmithBRDF(V, L, mk(0.04f), ccR, m.anisotropy);
-    return ((1.f - metallic) * (Cdlin * KZ_INV_PI * (Lambert + retro) + Fsheen) + (specTerm + coatTerm)) * L.z;
+// The terms of KazenStandard::eval that depend on the material alone (bsdf.cpp:1221-1232, 1244-1245): computed once per hit (the light
+// sample and the BSDF sample of a bounce evaluate the same row) instead of once per eval() call; the same operations on the same values.
+struct KissMat { V3 Cdlin, Cspec0, Csheen; };
+__device__ __forceinline__ KissMat kissMat(const KzBSDF &m) {
+    KissMat k;
+    k.Cdlin = mk(m.baseColor[0], m.baseColor[1], m.baseColor[2]);
+    const float Cdlum = luminance(k.Cdlin);
+    const V3 Ctint = Cdlum > 0.f ? k.Cdlin / Cdlum : mk(1.f);
+    const V3 Ctintmix = 0.08f * m.specular * lerp3(mk(1.f), Ctint, m.specularTint);
+    k.Cspec0 = lerp3(Ctintmix, k.Cdlin, m.metallic);
+    k.Csheen = lerp3(mk(1.f), Ctint, m.sheenTint);
+    return k;
 }
-__device__ float kissPdf(const KzBSDF &m, V3 wi, V3 wo, float accRough) {        // bsdf.cpp:1269-1299
-    if (wi.z <= 0 || wo.z <= 0) return 0.f;
-    float diffuse = (1.f - m.metallic) * 0.5f;
-    float GTR2 = 1.f / (1.f + m.clearcoat);
-    V3 H = normalized(wi + wo);
-    float jacobian = 4.0f * dot(wi, H);
-    float roughness = fminf(1.f, m.roughness + accRough);
-    float specPdf = ggxVNDF(wi, H, roughnessToAlpha(roughness, m.anisotropy)) / jacobian;
-    float coatPdf = ggxVNDF(wi, H, roughnessToAlpha(lerpf(m.clearcoatRoughness, .01f, .3f), 0.f)) / jacobian;
-    return diffuse * KZ_INV_PI * wo.z + (1.f - diffuse) * (GTR2 * specPdf + (1.f - GTR2) * coatPdf);
+// KazenStandard::eval (bsdf.cpp:1215-1267) and ::pdf (bsdf.cpp:1269-1299) of one (V, L) pair. The integrator always asks for both (the
+// light sample: eval + pdf for the MIS weight; sample(): pdf, then eval / pdf), and both are built from the same half vector, the same
+// GGX normal distribution D(H, alpha) and the same Smith Lambda(V, alpha) of the specular and of the clearcoat lobe: each of those
+// (1 normalisation, 2 x 3 divisions, 2 x division + square root: ~650 SIMD cycles of IEEE division, scripts/micro/op_cost.hip) is computed
+// once here and used by both results, operation for operation what the two functions compute on their own. WANT selects the outputs.
+template <bool WANT_F, bool WANT_PDF>
+__device__ __forceinline__ void kissEvalPdf(const KzBSDF &m, const KissMat &k, V3 V, V3 L, float accRough, V3 &f, float &pdf) {
+    f = mk(0.f); pdf = 0.f;
+    if (V.z <= 0 || L.z <= 0) return;
+    const V3 H = normalized(V + L);
+    const float metallic = m.metallic;
+    const float roughness = fminf(1.f, m.roughness + accRough);
+    const float ccR = lerpf(m.clearcoatRoughness, .01f, .3f);
+    const float VdotH = dot(V, H), LdotH = dot(L, H);
+    const A2 aS = roughnessToAlpha(roughness, m.anisotropy);
+    const A2 aC = roughnessToAlpha(ccR, m.anisotropy);                 // the coat of eval(): with the row's anisotropy (evalGGXSmithBRDF's argument)
+    const float DS = ggxNDF(H, aS), lamVS = ggxLambda(V, aS);
+    const float DC = ggxNDF(H, aC), lamVC = ggxLambda(V, aC);
+    if (WANT_F) {
+        const float FL = schlickWeight(L.z), FV = schlickWeight(V.z), FH = schlickWeight(LdotH);
+        const float cosThetaD = VdotH;
+        const float Lambert = (1.f - 0.5f * FL) * (1.f - 0.5f * FV);
+        const float RR = 2.f * roughness * cosThetaD * cosThetaD;
+        const float retro = RR * (FL + FV + FL * FV * (RR - 1.f));
+        const V3 Fsheen = FH * m.sheen * k.Csheen;
+        // evalGGXSmithBRDF (ggx_brdf.h:151-170) twice; V.z * L.z < 0 cannot happen here; smithG2 (ggx_brdf.h:58-66)
+        const bool gZero = VdotH <= 0.0f || LdotH < 0.0f;
+        const float denom = 4.0f * fabsf(V.z) * fabsf(L.z);
+        const float GS = gZero ? 0.0f : 1.0f / (1.0f + lamVS + ggxLambda(L, aS));
+        const V3 specTerm = (DS * GS) * schlickFresnel(k.Cspec0, VdotH) / denom;
+        const float GC = gZero ? 0.0f : 1.0f / (1.0f + lamVC + ggxLambda(L, aC));
+        const V3 coatTerm = 0.25f * m.clearcoat * ((DC * GC) * schlickFresnel(mk(0.04f), VdotH) / denom);
+        f = ((1.f - metallic) * (k.Cdlin * KZ_INV_PI * (Lambert + retro) + Fsheen) + (specTerm + coatTerm)) * L.z;
+    }
+    if (WANT_PDF) {
+        const float diffuse = (1.f - metallic) * 0.5f;
+        const float GTR2 = 1.f / (1.f + m.clearcoat);
+        const float jacobian = 4.0f * VdotH;
+        // ggxVNDF (ggx_brdf.h:80-91) = D * G1 * VdotH / V.z, G1 = 1 / (1 + Lambda(V)) (0 when VdotH <= 0)
+        const float specPdf = (VdotH <= 0.0f ? 0.0f : DS * (1.0f / (1.0f + lamVS)) * VdotH / V.z) / jacobian;
+        float DCp = DC, lamVCp = lamVC;                                // pdf()'s coat has anisotropy 0: alpha * (1 +- 0) is the same alpha
+        if (m.anisotropy != 0.f) { const A2 aP = roughnessToAlpha(ccR, 0.f); DCp = ggxNDF(H, aP); lamVCp = ggxLambda(V, aP); }
+        const float coatPdf = (VdotH <= 0.0f ? 0.0f : DCp * (1.0f / (1.0f + lamVCp)) * VdotH / V.z) / jacobian;
+        pdf = diffuse * KZ_INV_PI * L.z + (1.f - diffuse) * (GTR2 * specPdf + (1.f - GTR2) * coatPdf);
+    }
+}
+__device__ __forceinline__ V3 kissEval(const KzBSDF &m, const KissMat &k, V3 V, V3 L, float accRough) {           // bsdf.cpp:1215-1267
+    V3 f; float pdf; kissEvalPdf<true, false>(m, k, V, L, accRough, f, pdf); return f;
+}
+__device__ __forceinline__ float kissPdf(const KzBSDF &m, const KissMat &k, V3 wi, V3 wo, float accRough) {      // bsdf.cpp:1269-1299
+    V3 f; float pdf; kissEvalPdf<false, true>(m, k, wi, wo, accRough, f, pdf); return pdf;
 }
 // fresnel (common.cpp:447-475) and refract (common.cpp:526-534)
 __device__ __forceinline__ float fresnelIOR(float cosThetaI, float extIOR, float intIOR) {
@@ -645,7 +684,8 @@ __device__ __forceinline__ float smithBeckmannG1(V3 v, V3 m, float alpha) {
 __device__ __forceinline__ V3 squareToBeckmann(float sx, float sy, float alpha) {
     float phi = 2 * KZ_PI_F * sx;
     float theta = atanf(alpha * sqrtf(logf(1 / (1 - sy))));
-    return mk(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
+    float sinTheta, cosTheta, sinPhi, cosPhi; sincosf(theta, &sinTheta, &cosTheta); sincosf(phi, &sinPhi, &cosPhi);
+    return mk(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 __device__ __forceinline__ float squareToBeckmannPdf(V3 m, float alpha) {
     float theta = acosf(m.z / norm(m));
@@ -781,7 +821,7 @@ template <bool EXT>
 // pdfOut: BSDF::pdf at the sampled direction when the model computes it on the way (diffuse, kiss) — the integrator's own
 // pdf(bRec) call right after sample() (integrator.cpp:314) is the same function of the same arguments, so it is reused, not
 // recomputed; pdfOut < 0 means "not provided".
-__device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive, bool &discrete, float &etaScale, float &pdfOut) {
+__device__ V3 bsdfSample(const KzBSDF &m, const KissMat &km, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive, bool &discrete, float &etaScale, float &pdfOut) {
     wo = mk(0.f, 0.f, 1.f); discrete = false; etaScale = 1.0f; pdfOut = -1.f;
     if (EXT && m.type == KZ_BSDF_DIELECTRIC) {                                            // bsdf.cpp:119-143 (no back-side test)
         alive = true; discrete = true;
@@ -813,27 +853,39 @@ __device__ V3 bsdfSample(const KzBSDF &m, V3 wi, float accRough, float s1, float
         wo = normalized(reflectV(wi, H));
     }
     bool invalid = isnan(wo.x) || isnan(wo.y) || isnan(wo.z);
-    float pdf = kissPdf(m, wi, wo, accRough);
+    V3 f; float pdf;
+    kissEvalPdf<true, true>(m, km, wi, wo, accRough, f, pdf);
     if (wo.z <= 0 || pdf <= KZ_EPSILON || invalid) return mk(0.f);
     pdfOut = pdf;
-    return kissEval(m, wi, wo, accRough) / pdf;
+    return f / pdf;
 }
 template <bool EXT>
-__device__ __forceinline__ V3 bsdfEval(const KzBSDF &m, V3 wi, V3 wo, float accRough) {
+__device__ __forceinline__ V3 bsdfEval(const KzBSDF &m, const KissMat &km, V3 wi, V3 wo, float accRough) {
     if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:27-37 (measure is ESolidAngle at every call site)
         if (wi.z <= 0 || wo.z <= 0) return mk(0.f);
         return mk(m.albedo[0], m.albedo[1], m.albedo[2]) * KZ_INV_PI * wo.z;
     }
     if (EXT && m.type >= KZ_BSDF_GGX) return roughEval(m, wi, wo);
     if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) return mk(0.f);                           // discrete BRDFs evaluate to zero
-    return kissEval(m, wi, wo, accRough);
+    return kissEval(m, km, wi, wo, accRough);
 }
 template <bool EXT>
-__device__ __forceinline__ float bsdfPdf(const KzBSDF &m, V3 wi, V3 wo, float accRough) {
+__device__ __forceinline__ float bsdfPdf(const KzBSDF &m, const KissMat &km, V3 wi, V3 wo, float accRough) {
     if (m.type == KZ_BSDF_DIFFUSE) { if (wi.z <= 0 || wo.z <= 0) return 0.f; return KZ_INV_PI * wo.z; }   // bsdf.cpp:40-56
     if (EXT && m.type >= KZ_BSDF_GGX) return roughPdf(m, wi, wo);
     if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) return 0.f;
-    return kissPdf(m, wi, wo, accRough);
+    return kissPdf(m, km, wi, wo, accRough);
+}
+// eval and pdf of one direction pair (the light sample of a bounce asks for both): the kiss row shares its half-vector terms between the two
+template <bool EXT>
+__device__ __forceinline__ void bsdfEvalPdf(const KzBSDF &m, const KissMat &km, V3 wi, V3 wo, float accRough, V3 &f, float &pdf) {
+    if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:27-37, 40-56
+        const bool up = wi.z > 0 && wo.z > 0;
+        f = up ? mk(m.albedo[0], m.albedo[1], m.albedo[2]) * KZ_INV_PI * wo.z : mk(0.f);
+        pdf = up ? KZ_INV_PI * wo.z : 0.f;
+    } else if (EXT && m.type >= KZ_BSDF_GGX) { f = roughEval(m, wi, wo); pdf = roughPdf(m, wi, wo); }
+    else if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) { f = mk(0.f); pdf = 0.f; }       // discrete BRDFs evaluate to zero
+    else kissEvalPdf<true, true>(m, km, wi, wo, accRough, f, pdf);
 }
 
 
@@ -939,7 +991,7 @@ __device__ __forceinline__ void resolveTextures(const KzDevTables &T, KzBSDF &b,
 
 // NormalMap (bsdf.cpp:281-417). n = 2*rgb-1 in the local shading frame (not normalised for the dot(n, wi) tests);
 // pf = getFrame(its, n.normalized(), wi) (bsdf.cpp:365-374).
-struct NMap { bool on; V3 n; Frame3 pf; };
+struct NMap { bool on; V3 n; Frame3 pf; KissMat km; };        // + the material-only terms of a kiss row (kissMat), computed once per hit
 __device__ __forceinline__ void nmapSetup(const KzDevTables &T, const KzBSDF &outer, const Its &its, NMap &nm) {
     const V3 rgb = texEval(T, outer.normalTex, its.uvx, its.uvy);
     nm.on = true;
@@ -956,39 +1008,47 @@ __device__ __forceinline__ void surfaceSetup(const KzDevTables &T, const Its &it
         if (b.type == KZ_BSDF_NORMALMAP) { nmapSetup(T, b, its, nm); b = T.bsdfs[b.nested]; }
         resolveTextures(T, b, its.uvx, its.uvy);
     }
+    if (b.type == KZ_BSDF_KAZENSTANDARD) nm.km = kissMat(b);
+    else { nm.km.Cdlin = mk(0.f); nm.km.Cspec0 = mk(0.f); nm.km.Csheen = mk(0.f); }
 }
 // solid: bRec.measure == ESolidAngle. Only Diffuse checks it (bsdf.cpp:30,43,213,225); it is lost when NormalMap::sample goes
 // through the perturbed record, whose measure is never copied back (bsdf.cpp:348-362).
 template <bool EXT>
 __device__ __forceinline__ V3 surfEval(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, V3 wo, float accRough) {
-    if (!EXT || !nm.on) return bsdfEval<EXT>(b, wi, wo, accRough);
-    if (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0) return bsdfEval<EXT>(b, wi, wo, accRough);          // bsdf.cpp:295-296
+    if (!EXT || !nm.on) return bsdfEval<EXT>(b, nm.km, wi, wo, accRough);
+    if (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0) return bsdfEval<EXT>(b, nm.km, wi, wo, accRough);          // bsdf.cpp:295-296
     const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi)), woP = toLocal(nm.pf, toWorld(its.sh, wo));
     if (wo.z * woP.z <= 0) return mk(0.f);
-    return bsdfEval<EXT>(b, wiP, woP, 0.0f);            // the perturbed record carries a fresh Intersection: accumulatedRoughness 0
+    return bsdfEval<EXT>(b, nm.km, wiP, woP, 0.0f);            // the perturbed record carries a fresh Intersection: accumulatedRoughness 0
 }
 template <bool EXT>
 __device__ __forceinline__ float surfPdf(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, V3 wo, float accRough, bool solid) {
-    if (!EXT || !nm.on) return bsdfPdf<EXT>(b, wi, wo, accRough);
+    if (!EXT || !nm.on) return bsdfPdf<EXT>(b, nm.km, wi, wo, accRough);
     if (!solid && b.type == KZ_BSDF_DIFFUSE) return 0.0f;
-    if (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0) return bsdfPdf<EXT>(b, wi, wo, accRough);
+    if (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0) return bsdfPdf<EXT>(b, nm.km, wi, wo, accRough);
     const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi)), woP = toLocal(nm.pf, toWorld(its.sh, wo));
     if (wo.z * woP.z <= 0) return 0.0f;
-    return bsdfPdf<EXT>(b, wiP, woP, 0.0f);
+    return bsdfPdf<EXT>(b, nm.km, wiP, woP, 0.0f);
+}
+// surfEval and surfPdf (solid angle measure) of one direction pair
+template <bool EXT>
+__device__ __forceinline__ void surfEvalPdf(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, V3 wo, float accRough, V3 &f, float &pdf) {
+    if (!EXT || !nm.on) { bsdfEvalPdf<EXT>(b, nm.km, wi, wo, accRough, f, pdf); return; }
+    f = surfEval<EXT>(b, nm, its, wi, wo, accRough); pdf = surfPdf<EXT>(b, nm, its, wi, wo, accRough, true);
 }
 template <bool EXT>
 __device__ __forceinline__ V3 surfSample(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, float accRough, float s1, float s2x, float s2y,
                                          V3 &wo, bool &alive, bool &discrete, float &etaScale, float &pdfOut, bool &solid) {
     solid = true;
-    if (!EXT || !nm.on) return bsdfSample<EXT>(b, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
+    if (!EXT || !nm.on) return bsdfSample<EXT>(b, nm.km, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
     if (wi.z > 0 && dot(nm.n, wi) <= 0) {                                                                // bsdf.cpp:342-345
-        const V3 w = bsdfSample<EXT>(b, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
+        const V3 w = bsdfSample<EXT>(b, nm.km, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
         pdfOut = -1.f;                                   // NormalMap::pdf may take the other branch: let the caller evaluate it
         return w;
     }
     const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi));
     V3 woP; bool discN; float pdfN;
-    const V3 w = bsdfSample<EXT>(b, wiP, 0.0f, s1, s2x, s2y, woP, alive, discN, etaScale, pdfN);
+    const V3 w = bsdfSample<EXT>(b, nm.km, wiP, 0.0f, s1, s2x, s2y, woP, alive, discN, etaScale, pdfN);
     discrete = false; solid = false; pdfOut = -1.f;      // measure stays EUnknownMeasure in the caller's record
     if (!alive || (w.x == 0.f && w.y == 0.f && w.z == 0.f)) { wo = mk(0.f, 0.f, 1.f); return mk(0.f); }
     wo = toLocal(its.sh, toWorld(nm.pf, woP));
@@ -1063,7 +1123,8 @@ __device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy,
     if (P.cameraType == KZ_CAMERA_THINLENS) {                                      // camera.cpp:191-223, warp.cpp:41-50
         const float r = sqrtf(ax);
         const float ang = 2.0f * KZ_PI_F * ay;
-        const float tx = cosf(ang) * r * P.apertureRadius, ty = sinf(ang) * r * P.apertureRadius;
+        float sinAng, cosAng; sincosf(ang, &sinAng, &cosAng);
+        const float tx = cosAng * r * P.apertureRadius, ty = sinAng * r * P.apertureRadius;
         const V3 focusP = nearP * (P.focusDistance / nearP.z);
         dl = normalized(focusP - mk(tx, ty, 0.0f));
         const float pw = w[12] * tx + w[13] * ty + w[14] * 0.0f + w[15];
@@ -1129,8 +1190,8 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             const bool occluded = shadowOccluded<STATS>(P, T, its.p, lwi, eps, dist - eps, stk, cn);
             if (!occluded) {
                 V3 woLocal = toLocal(its.sh, lwi);
-                V3 f = surfEval<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough);
-                float bpdf = surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, true);
+                V3 f; float bpdf;
+                surfEvalPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, f, bpdf);
                 float lightWeight = powerHeuristic(lpdf, bpdf);
                 L = L + throughput * Ls * f * lightWeight;
             }

@@ -369,8 +369,12 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     if (d->sampler.type == KZ_SAMPLER_PMJ02BN) {
         if (!d->sampler.pmj02bnSamples || !d->sampler.blueNoise) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "pmj02bn sampler without its tables"); }
         if (p.sampleCount > KZ_PMJ02BN_SAMPLES) p.sampleCount = KZ_PMJ02BN_SAMPLES;               // sampler.cpp:284-287
-        sc->pmj.assign(d->sampler.pmj02bnSamples, d->sampler.pmj02bnSamples + (size_t)KZ_PMJ02BN_SETS * KZ_PMJ02BN_SAMPLES * 2);
-        sc->bn.assign(d->sampler.blueNoise, d->sampler.blueNoise + (size_t)KZ_BLUENOISE_TEXTURES * KZ_BLUENOISE_RES * KZ_BLUENOISE_RES);
+        // the device reads both tables as the floats the reference's accessors return: the conversions (pmj02table.h:28-29 in double then
+        // narrowed; bluenoise.h:22 an fp32 division) are done here, once, with the same IEEE operations
+        const size_t nPmj = (size_t)KZ_PMJ02BN_SETS * KZ_PMJ02BN_SAMPLES * 2, nBn = (size_t)KZ_BLUENOISE_TEXTURES * KZ_BLUENOISE_RES * KZ_BLUENOISE_RES;
+        sc->pmj.resize(nPmj); sc->bn.resize(nBn);
+        for (size_t i = 0; i < nPmj; ++i) sc->pmj[i] = (float)((double)d->sampler.pmj02bnSamples[i] * 0x1p-32);
+        for (size_t i = 0; i < nBn; ++i) sc->bn[i] = (float)d->sampler.blueNoise[i] / 65535.f;
         // PMJ02BN constructor: sort set 0 into a tile x tile x spp pixel table (sampler.cpp:291-309)
         uint32_t spp = p.sampleCount;
         int tile = 1 << (log4i(KZ_PMJ02BN_SAMPLES) - log4i((uint32_t)roundUpPow4((int)spp)));
@@ -378,7 +382,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
         sc->pixelSamples.assign((size_t)tile * tile * spp * 2, 0.f);
         std::vector<uint32_t> nStored((size_t)tile * tile, 0);
         for (int i = 0; i < KZ_PMJ02BN_SAMPLES; ++i) {
-            float x = (float)(sc->pmj[2 * (size_t)i] * 0x1p-32), y = (float)(sc->pmj[2 * (size_t)i + 1] * 0x1p-32);   // pmj02table.h:28-29
+            float x = sc->pmj[2 * (size_t)i], y = sc->pmj[2 * (size_t)i + 1];
             x *= tile; y *= tile;
             int ix = (int)x, iy = (int)y;
             if (ix >= tile || iy >= tile) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "pmj02bn table entry %d rounds to 1.0f (the reference would index out of range)", i); }
@@ -404,6 +408,8 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
             sc->jump[s].mult = acc_mult; sc->jump[s].plus = acc_plus;
         }
     }
+    p.sppPow2 = (p.sampleCount & (p.sampleCount - 1)) == 0 ? 1 : 0;
+    p.invSpp = 1.0f / (float)p.sampleCount;
     kz_device_init(sc);
     *out = sc;
     return KZ_OK;

@@ -90,6 +90,7 @@ struct KzParams {
     // sampler
     int32_t samplerType; uint32_t sampleCount; uint64_t seed; int32_t pixelTileSize;
     int32_t resX, resY;                  // stratified resolution / correlated m_resolution
+    int32_t sppPow2; float invSpp;       // sampleCount is a power of two: x / sampleCount == x * invSpp bit for bit (no underflow: x >= 2^-17 or 0)
     int32_t cameraType; float apertureRadius, focusDistance;
     // lights / background
     uint32_t nLights; float lightPickPdf;
@@ -117,8 +118,8 @@ struct KzDevTables {
     const KzBSDF *bsdfs;
     const KzLightRow *lights;
     const float *cdf;
-    const uint32_t *pmj;        // [5][65536][2]
-    const uint16_t *bn;         // [48][128][128]
+    const float *pmj;           // [5][65536][2]: the table entries as the floats GetPMJ02BNSample returns, (float)(u32 * 0x1p-32) (pmj02table.h:28-29), converted once on the host
+    const float *bn;            // [48][128][128]: BlueNoise()'s value / 65535.f (bluenoise.h:16-23), divided once on the host (same IEEE division)
     const float *pixelSamples;  // pmj02bn pixel table (sampler.cpp:291-309), 2 floats per entry
     const KzPcgJump *jump;      // [sampleCount]
     const float *filter;        // [33]
@@ -139,8 +140,8 @@ struct KzScene {
     std::vector<KzBSDF> bsdfs;
     std::vector<KzLightRow> lightRows;
     std::vector<float> cdf;
-    std::vector<uint32_t> pmj;
-    std::vector<uint16_t> bn;
+    std::vector<float> pmj;             // 2 floats per entry
+    std::vector<float> bn;
     std::vector<float> pixelSamples;
     std::vector<KzPcgJump> jump;
     std::vector<KzTri> ilTris;

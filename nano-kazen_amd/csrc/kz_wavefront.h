@@ -97,7 +97,12 @@ __device__ __forceinline__ void wfStatsFlush(unsigned long long *stats, const Co
 __device__ __forceinline__ void wfLoadSampler(const KzParams &P, const KzWf &W, uint32_t slot, int px, int py, uint32_t sampleIndex, Sampler &s) {
     const uint4 v = W.smp[slot];
     s.type = P.samplerType; s.px = px; s.py = py; s.idx = sampleIndex;
-    s.state = (uint64_t)v.x | ((uint64_t)v.y << 32); s.dim = v.z;
+    s.state = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    // Every path of one shade launch is at the same depth and has drawn the same number of dimensions (the draws of a bounce do not depend on
+    // the path: roulette from depth 3, pick, 3 light draws when there are lights, 2-D + 1-D for the BSDF), so the dimension counter is
+    // wave-uniform: taken from the first active lane it lives in an SGPR and the dimension/seed block of Hash(p, dim, seed) (two 64-bit
+    // multiplies per draw) and the blue-noise texture index are computed on the scalar unit. The megakernel keeps the per-lane counter.
+    s.dim = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z);
     s.inc = (P.samplerType == KZ_SAMPLER_PMJ02BN) ? 0ull : ((hashPixelSeed(px, py, P.seed) << 1u) | 1u);      // pcg32 stream id: a function of the pixel
     s.hp = (P.samplerType != KZ_SAMPLER_INDEPENDENT) ? hashPixelBlock(px, py) : 0ull;
 }
@@ -362,8 +367,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     V3 Ls = ls.Ls;
                     Ls = Ls / P.lightPickPdf;
                     const V3 woL = toLocal(its.sh, lwi);
-                    const V3 f = surfEval<EXT>(bsdf, nm, its, wiLocal, woL, accRough);
-                    const float bpdfL = surfPdf<EXT>(bsdf, nm, its, wiLocal, woL, accRough, true);
+                    V3 f; float bpdfL;
+                    surfEvalPdf<EXT>(bsdf, nm, its, wiLocal, woL, accRough, f, bpdfL);
                     const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
                     // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
                     if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
