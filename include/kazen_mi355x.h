@@ -245,7 +245,7 @@ typedef struct KzTuning {
     int32_t postpone;           /* node phase goes on while at least this many lanes hold inner nodes (default 28)  */
     int32_t batch;              /* queue entries a wave reserves per global atomic (default 128)                     */
     int32_t traceBlocksPerCU;   /* 256-thread workgroups per CU of the traversal kernels (default 8)                 */
-    int32_t shadeBlocksPerCU;   /* same for the shade kernel (default 6)                                             */
+    int32_t shadeBlocksPerCU;   /* same for the shade kernel (default 4; 6 with extended BSDFs)                       */
     int32_t ldsStack;           /* per-lane traversal stack entries kept in LDS before the global overflow (default 16) */
     int32_t bvh2;               /* 1 = traverse the BVH2 instead of the quantised BVH4 (default 0)                    */
     int32_t packetPrimary;      /* primary rays: 0 = default (shared-stack packet traversal), 1 = per-lane, 2 = packet */

@@ -483,7 +483,7 @@ static KzTune resolveTune(const KzTuning &t) {
     auto pick = [](int a, int b, int d) { return a > 0 ? a : (b > 0 ? b : d); };
     KzTune r{};
     r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
-    r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 6));
+    r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 0));
     r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
     r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0); r.leafQueue = pick(t.leafQueue, e.leafQueue, 0); r.binRays = pick(t.binRays, e.binRays, 0);
     r.ovf = nullptr; r.ovfStride = 0;
@@ -704,7 +704,12 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     const bool st = ds->statsOn;
     const size_t stackBytes = (size_t)P.stackDepth * KZ_BLOCK * sizeof(uint32_t);
     const dim3 blk(KZ_BLOCK);
-    const dim3 gTrav((unsigned)(ds->numCU * tune.travBlocksPerCU)), gShade((unsigned)(ds->numCU * tune.shadeBlocksPerCU));
+    // shade: the lean variant runs 4 workgroups per CU at once (its launch bounds), so the default grid is exactly those, each looping over
+    // its share: with 6 per CU the kernel ran 1.5 rounds, the second with half the CUs idle (same-call sweep, profiles/r02h_shade: shade alone
+    // 24.1 ms at 6, 23.0 at 4, 22.6 at 8, 22.3 at 12 - and with two passes in flight the small grid leaves the most room for the other pass:
+    // 1246 Msamples/s at 4 against 1214-1218 at 6 / 8 / 12). The EXT variant (3 resident) shows no preference on C3 and stays at 6.
+    const int shadeBlocks = tune.shadeBlocksPerCU > 0 ? tune.shadeBlocksPerCU : (P.bsdfExt ? 6 : KZ_SHADE_WAVES);
+    const dim3 gTrav((unsigned)(ds->numCU * tune.travBlocksPerCU)), gShade((unsigned)(ds->numCU * shadeBlocks));
     // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
     tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));

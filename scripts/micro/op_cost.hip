@@ -14,6 +14,30 @@
 #define OPS(X, TXT) asm volatile(TXT TXT : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]), "+v"(X[8]), "+v"(X[9]), \
                               "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15]) : "v"(m), "v"(c), "v"(u0), "v"(u1), "v"(dm) : "vcc", "s20", "s21")
 
+
+// three numerators over one denominator: the compiler's division arithmetic (rcp, one Newton step on the reciprocal, quotient, two residual
+// corrections) with the reciprocal shared, the residuals computed with fp32 denormals enabled (ONE s_setreg pair), no v_div_scale / v_div_fixup:
+// bit-identical to a/s for in-range operands, which the caller's guard selects
+__device__ __forceinline__ void div3asm(float ax, float ay, float az, float s, float &qx, float &qy, float &qz) {
+    float r, e1, e2, e3;
+    asm volatile(
+        "v_rcp_f32 %3, %10\n"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 4, 2), 3\n"
+        "v_fma_f32 %4, -%10, %3, 1.0\n"
+        "v_fma_f32 %3, %4, %3, %3\n"
+        "v_mul_f32 %0, %7, %3\n v_mul_f32 %1, %8, %3\n v_mul_f32 %2, %9, %3\n"
+        "v_fma_f32 %4, -%10, %0, %7\n v_fma_f32 %5, -%10, %1, %8\n v_fma_f32 %6, -%10, %2, %9\n"
+        "v_fma_f32 %0, %4, %3, %0\n v_fma_f32 %1, %5, %3, %1\n v_fma_f32 %2, %6, %3, %2\n"
+        "v_fma_f32 %4, -%10, %0, %7\n v_fma_f32 %5, -%10, %1, %8\n v_fma_f32 %6, -%10, %2, %9\n"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 4, 2), 0\n"
+        "v_fma_f32 %0, %4, %3, %0\n v_fma_f32 %1, %5, %3, %1\n v_fma_f32 %2, %6, %3, %2\n"
+        : "=&v"(qx), "=&v"(qy), "=&v"(qz), "=&v"(r), "=&v"(e1), "=&v"(e2), "=&v"(e3) : "v"(ax), "v"(ay), "v"(az), "v"(s));
+}
+__device__ __forceinline__ void div3guarded(float ax, float ay, float az, float s, float &qx, float &qy, float &qz) {
+    const float as = fabsf(s), am = fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fabsf(az));
+    if (as >= 0x1p-60f && as <= 0x1p60f && am <= 0x1p60f) div3asm(ax, ay, az, s, qx, qy, qz);
+    else { qx = ax / s; qy = ay / s; qz = az / s; }
+}
 template <int V>
 __global__ __launch_bounds__(256) void op_loop(int iters, float seed, float *__restrict__ sink) {
     float a[16]; double d[16];
@@ -49,6 +73,14 @@ __global__ __launch_bounds__(256) void op_loop(int iters, float seed, float *__r
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = sqrtf(a[i] + a[i + 8]);
             asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+        } else if (V == 23) {          // 3 x (three numerators over one denominator) per iteration through the shared-reciprocal sequence + guard: 9 divisions
+#pragma unroll
+            for (int i = 0; i < 3; ++i) div3guarded(a[3 * i + 4], a[3 * i + 5], a[3 * i + 6], a[i], a[3 * i + 4], a[3 * i + 5], a[3 * i + 6]);
+            asm volatile("" : "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]));
+        } else if (V == 24) {          // the same 9 divisions as the compiler emits them
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { a[3 * i + 4] /= a[i]; a[3 * i + 5] /= a[i]; a[3 * i + 6] /= a[i]; }
+            asm volatile("" : "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]));
         } else {                       // 22: the unscaled core of the division (rcp + 2 fma, then mul + 4 fma): same arithmetic for in-range operands
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -73,10 +105,10 @@ int main(int argc, char **argv) {
     float *dS; CK(hipMalloc(&dS, 64));
     static const char *name[] = {"v_fma_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_mul_f64", "v_fma_f64", "v_cvt_f64_f32",
                                  "v_cvt_f32_f64", "v_mad_u64_u32", "v_mul_hi_u32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_ldexp_f32", "v_cvt_f32_u32", "v_mul_lo_u32",
-                                 "v_fma_f32 between two s_setreg MODE", "ieee_div (a/b as compiled, FTZ)", "ieee_sqrt (sqrtf as compiled, FTZ)", "div core without scale/fixup/setreg"};
-    static const int per[] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 8, 8, 8};
+                                 "v_fma_f32 between two s_setreg MODE", "ieee_div (a/b as compiled, FTZ)", "ieee_sqrt (sqrtf as compiled, FTZ)", "div core without scale/fixup/setreg", "div3 shared reciprocal + guard (per division)", "3 x a/s as compiled (per division)"};
+    static const int per[] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 8, 8, 8, 9, 9};
     printf("{\"device\": \"%s\", \"cus\": %d, \"iters\": %d, \"clock_assumed_GHz\": 2.4, \"results\": [\n", prop.name, cus, iters);
-    for (int v = 0; v < 23; ++v) {
+    for (int v = 0; v < 25; ++v) {
         for (int wps : {4, 8}) {
             const int blocks = cus * wps;
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -84,7 +116,7 @@ int main(int argc, char **argv) {
                 CK(hipEventRecord(e0));
                 switch (v) {
 #define L(K) case K: hipLaunchKernelGGL(op_loop<K>, dim3(blocks), dim3(256), 0, 0, iters, 1.0f, dS); break;
-                    L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15) L(16) L(17) L(18) L(19) L(20) L(21) L(22)
+                    L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15) L(16) L(17) L(18) L(19) L(20) L(21) L(22) L(23) L(24)
                 }
                 CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
             }
