@@ -390,6 +390,10 @@ __device__ __forceinline__ bool anyHit(const KzDevTables &T, uint32_t rootRef, V
 
 // The reference's shadow test, literally (integrator.cpp:257-278): closest hits, walking through lights whose
 // lightPrimaryVisibility is false; note that the far end moves out by traceBias per walk-through (maxt - t).
+// light row of the mesh a triangle belongs to (-1: not an emitter), from the last quad of its shading record
+__device__ __forceinline__ int lightOfGid(const KzDevTables &T, uint32_t gid) {
+    return (int)(__float_as_uint(reinterpret_cast<const float4 *>(T.shade + gid)[6].w) >> 2) - 1;
+}
 template <bool STATS>
 __device__ __forceinline__ bool shadowOccludedLiteral(const KzParams &P, const KzDevTables &T, V3 so, V3 dir, float smin, float smax,
                                                       uint32_t *stk, Counters &cn) {
@@ -397,8 +401,7 @@ __device__ __forceinline__ bool shadowOccludedLiteral(const KzParams &P, const K
     for (;;) {
         RawHit sh;
         if (!closestHit<STATS>(T, P.rootRef, so, dir, smin, smax, sh, stk, cn)) return false;
-        uint32_t om = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + sh.tri)[2].y);
-        int ol = T.meshes[om].light;
+        const int ol = lightOfGid(T, sh.gid);
         if (ol < 0 || T.lights[ol].primaryVisibility) return true;
         so = so + dir * (sh.t + eps); smin = eps; smax = smax - sh.t;
     }
@@ -449,19 +452,18 @@ __device__ __forceinline__ V3 toWorld(const Frame3 &f, V3 v) { return f.s * v.x 
 
 struct Its {
     V3 p; float t; float uvx, uvy; Frame3 sh; V3 geoN; uint32_t mesh; uint32_t prim; float bu, bv;
+    uint32_t bsdf; int32_t light;        // the mesh's BSDF row and light row (-1: none), from the shading record
     V3 dpdu;        // accel.cpp:185,209 — only NormalMap::getFrame reads it (dead code in the kernels without normal maps)
 };
 
 template <bool GEO>
 __device__ __forceinline__ void postIntersect(const KzDevTables &T, const RawHit &rh, Its &its) {
-    const float4 *tp = reinterpret_cast<const float4 *>(T.tris + rh.tri);
-    const float4 c = tp[2];
-    const uint32_t mesh = __float_as_uint(c.y);
-    its.mesh = mesh; its.prim = __float_as_uint(c.z); its.t = rh.t; its.bu = rh.u; its.bv = rh.v;
-    const uint32_t flags = T.meshes[mesh].flags;
-    const bool hasN = flags & 1u, hasUV = flags & 2u;
     const float4 *sp = reinterpret_cast<const float4 *>(T.shade + rh.gid);
-    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];
+    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
+    const uint32_t lf = __float_as_uint(s6.w);
+    its.mesh = __float_as_uint(s6.x); its.prim = __float_as_uint(s6.y); its.bsdf = __float_as_uint(s6.z); its.light = (int32_t)(lf >> 2) - 1;
+    its.t = rh.t; its.bu = rh.u; its.bv = rh.v;
+    const bool hasN = lf & 1u, hasUV = lf & 2u;
     const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
     const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
     const float uv0x = s4.z, uv0y = s4.w, uv1x = s5.x, uv1y = s5.y, uv2x = s5.z, uv2y = s5.w;
@@ -1066,15 +1068,28 @@ __device__ __forceinline__ float lightPdfSolidAngle(float meshPdf, V3 n, V3 wi, 
 }
 __device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, float v) {              // dpdf.h:99-104 (n entries, n+1 floats)
     // std::lower_bound over cdf[0..n]: first element >= v
-    uint32_t lo = 0, len = n + 1;
-    while (len > 0) {
-        uint32_t half = len >> 1, mid = lo + half;
-        if (cdf[mid] < v) { lo = mid + 1; len -= half + 1; } else len = half;
+    uint32_t lo = 0;
+    if (n <= 7u && v < 1.0f) {
+        // Light meshes are mostly a quad or a few triangles. The table is non-decreasing up to its last entry, which is 1 (dpdf.h:85-88) and never
+        // below a sample < 1, so the first element >= v is the NUMBER of elements < v: eight independent loads (the table is padded) instead of
+        // the binary search's chain of dependent ones.
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) { const float e = cdf[k]; lo += (k <= n && e < v) ? 1u : 0u; }
+    } else {
+        uint32_t len = n + 1;
+        while (len > 0) {
+            uint32_t half = len >> 1, mid = lo + half;
+            if (cdf[mid] < v) { lo = mid + 1; len -= half + 1; } else len = half;
+        }
     }
     int idx = (int)lo - 1;
     if (idx < 0) idx = 0;
     return min((uint32_t)idx, n - 1);
 }
+
+// Ls / m_lightPdf.getNormalization() (integrator.cpp:252): with a power-of-two number of lights the divisor is a power of two and the three
+// IEEE divisions are three multiplications with the same results
+__device__ __forceinline__ V3 lightPickDivide(const KzParams &P, V3 Ls) { return P.lightPickScale > 0.f ? Ls * P.lightPickScale : Ls / P.lightPickPdf; }
 
 // Light::sample of an area light (light.cpp:16-34) through Mesh::sample (mesh.cpp:108-133): the triangle by the area cdf, then
 // the sqrt warp; `draw()` supplies Mesh::sample's three next1D values IN ORDER (the path kernels hand in the sampler, the
@@ -1091,7 +1106,7 @@ __device__ __forceinline__ LightSample lightSample(const KzDevTables &T, const K
     const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
     const V3 p0 = mk(s0.x, s0.y, s0.z), p1 = mk(s0.w, s1.x, s1.y), p2 = mk(s1.z, s1.w, s2.x);
     r.p = p0 + u * (p1 - p0) + v * (p2 - p0);
-    if (T.meshes[lrow.mesh].flags & 1u) {
+    if (lrow.hasN) {
         const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
         r.n = n0 + u * (n1 - n0) + v * (n2 - n0);                                         // H8: not normalised
     } else r.n = normalized(cross(p1 - p0, p2 - p0));
@@ -1153,7 +1168,7 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
     if (!closestHit<STATS>(T, P.rootRef, ro, rd, rmint, rmaxt, rh, stk, cn)) return L;       // H5: primary miss is black
     postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
     {
-        int li = T.meshes[its.mesh].light;
+        const int li = its.light;
         if (li >= 0 && !T.lights[li].primaryVisibility) {                                     // integrator.cpp:214-219 (H6)
             V3 no = its.p + eps * rd;
             if (closestHit<STATS>(T, P.rootRef, no, rd, KZ_EPSILON, KZ_INF, rh, stk, cn)) { postIntersect<false>(T, rh, its); if (STATS) cn.hits++; }
@@ -1161,9 +1176,8 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
     }
     int depth = 0;
     while (depth < P.maxDepth) {
-        const KzMeshRow mrow = T.meshes[its.mesh];
-        if (mrow.light >= 0) {                                                                // integrator.cpp:226-231
-            const KzLightRow &lr = T.lights[mrow.light];
+        if (its.light >= 0) {                                                                 // integrator.cpp:226-231
+            const KzLightRow &lr = T.lights[its.light];
             V3 wi = normalized(its.p - ro);
             if (dot(its.sh.n, -wi) > 0.f) L = L + (bsdfWeight * throughput) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
             break;
@@ -1173,7 +1187,7 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             if (probability <= smp.next1D(P, T)) break;
             throughput = throughput / probability;
         }
-        KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+        KzBSDF bsdf = T.bsdfs[its.bsdf];
         NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
         const V3 wiLocal = toLocal(its.sh, -rd);
         // ---- light sampling (integrator.cpp:247-295); the pick is drawn even when there are no lights
@@ -1185,7 +1199,7 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             const LightSample ls = lightSample(T, lrow, its.p, [&]() { return smp.next1D(P, T); });     // Mesh::sample: three 1-D draws
             const V3 lwi = ls.wi; const float dist = ls.dist, lpdf = ls.pdf;
             V3 Ls = ls.Ls;
-            Ls = Ls / P.lightPickPdf;
+            Ls = lightPickDivide(P, Ls);
             // shadow ray with the invisible-light walk-through (integrator.cpp:257-278); closest-hit, like the reference
             const bool occluded = shadowOccluded<STATS>(P, T, its.p, lwi, eps, dist - eps, stk, cn);
             if (!occluded) {
@@ -1213,7 +1227,7 @@ __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 r
             break;
         }
         postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
-        int nl = T.meshes[its.mesh].light;
+        const int nl = its.light;
         if (nl >= 0) {                                                                        // integrator.cpp:322-327
             V3 wi = normalized(its.p - ro);
             float lpdf = lightPdfSolidAngle(T.lights[nl].normalization, its.sh.n, wi, its.p, ro);

@@ -1187,6 +1187,17 @@ int kz_get_stats(KzScene *scene, KzStats *out, int reset) {
         if (reset) HIP_TRY(hipMemset(ds->stats + 8, 0, sizeof ls));
     }
 #endif
+#ifdef KZ_SHADESTAT
+    {
+        unsigned long long ss[14]; double tot = 0;
+        HIP_TRY(hipMemcpy(ss, ds->stats + 8, sizeof ss, hipMemcpyDeviceToHost));
+        static const char *nm[14] = {"passA: rest (emitter, classification, roulette)", "compact+barrier", "B:loads+setup", "B:light draws+sample", "B:eval+pdf+shadow stores", "B:bsdf draws", "B:bsdf sample", "B:next-ray stores",
+                                     "barrier+staging+flush", "loop head", "passA: queue+hit+ray loads", "passA: shading record arrives", "passA: postIntersect", "-"};
+        for (int k = 0; k < 14; ++k) tot += (double)ss[k];
+        for (int k = 0; k < 14; ++k) std::fprintf(stderr, "shadestat %-48s %6.2f %%\n", nm[k], tot > 0 ? 100.0 * (double)ss[k] / tot : 0.0);
+        if (reset) HIP_TRY(hipMemset(ds->stats + 8, 0, sizeof ss));
+    }
+#endif
     if (reset) HIP_TRY(hipMemset(ds->stats, 0, sizeof h));
     return KZ_OK;
 }

@@ -213,10 +213,12 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
         }
         row.flags = (km.N ? 1u : 0u) | (km.UV ? 2u : 0u);
         row.triOffset = gid; row.nF = km.nF;
+        const int32_t lightRow = km.light >= 0 ? (int32_t)sc->lightRows.size() : -1;      // the row pushed below
         for (uint32_t f = 0; f < km.nF; ++f, ++gid) {
             uint32_t idx[3] = {km.F[3 * f], km.F[3 * f + 1], km.F[3 * f + 2]};
             KzBuildTri t; t.mesh = m; t.prim = f; t.gid = gid;
             KzTriShade s; std::memset(&s, 0, sizeof s);
+            s.mesh = m; s.prim = f; s.bsdf = (uint32_t)row.bsdf; s.lightFlags = ((uint32_t)(lightRow + 1) << 2) | row.flags;
             for (int v = 0; v < 3; ++v) {
                 if (idx[v] >= km.nV) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "mesh %u face %u: vertex index %u >= %u", m, f, idx[v], km.nV); }
                 for (int a = 0; a < 3; ++a) {
@@ -234,7 +236,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
             KzLightRow lr; std::memset(&lr, 0, sizeof lr);
             for (int a = 0; a < 3; ++a) lr.radiance[a] = kl.intensity * kl.color[a];
             lr.primaryVisibility = kl.primaryVisibility ? 1 : 0;
-            lr.mesh = m; lr.triOffset = row.triOffset; lr.nF = km.nF; lr.cdfOffset = (uint32_t)sc->cdf.size();
+            lr.mesh = m; lr.triOffset = row.triOffset; lr.nF = km.nF; lr.cdfOffset = (uint32_t)sc->cdf.size(); lr.hasN = km.N ? 1u : 0u;
             size_t base = sc->cdf.size();
             sc->cdf.push_back(0.0f);
             for (uint32_t f = 0; f < km.nF; ++f) {
@@ -256,6 +258,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
         }
         sc->meshRows.push_back(row);
     }
+    sc->cdf.insert(sc->cdf.end(), 8, 2.0f);          // padding: the device reads eight entries of a short table at once (cdfSample)
     std::string berr;
     uint32_t rootRef = 0xFFFFFFFFu;
     int rc = kz_build_bvh(bt, sc->nodes, sc->tris, rootRef, sc->bvh, berr);
@@ -332,6 +335,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     // ---- lights / background (scene.h:45-56, texture.cpp:121-126)
     p.nLights = (uint32_t)sc->lightRows.size();
     p.lightPickPdf = p.nLights ? 1.f / (float)p.nLights : 0.f;
+    p.lightPickScale = (p.nLights && (p.nLights & (p.nLights - 1)) == 0) ? (float)p.nLights : 0.f;
     p.bgPresent = d->background.present ? 1 : 0;
     p.bgImage = -1; p.bgIntensity = d->background.intensity;
     {

@@ -34,10 +34,12 @@ static_assert(sizeof(KzNode4) == 64, "BVH4 packet must be 64 B");
 struct KzTri { float p0[3]; float e1[3]; float e2[3]; uint32_t mesh, prim, gid; };
 static_assert(sizeof(KzTri) == 48, "leaf triangle must be 48 B");
 
-// Shading record per triangle (indexed by gid), 96 B, six quads: p0 p1 p2 n0 n1 n2 uv0 uv1 uv2.
-// One hop replaces the reference's F -> V/N/UV double gather (accel.cpp:133-136,167-169).
-struct KzTriShade { float p[9]; float n[9]; float uv[6]; };
-static_assert(sizeof(KzTriShade) == 96, "shading record must be 96 B");
+// Shading record per triangle (indexed by gid), 112 B, seven quads: p0 p1 p2 n0 n1 n2 uv0 uv1 uv2 | mesh prim bsdf lightFlags.
+// One hop replaces the reference's F -> V/N/UV double gather (accel.cpp:133-136,167-169), and the last quad the leaf-triangle -> mesh row
+// hops (geomID -> mesh -> getBSDF / getLight / hasNormals): a hit record names the gid, everything shading needs hangs off this record.
+// lightFlags = (light row + 1) << 2 | mesh flags (bit0 hasN, bit1 hasUV); light row -1 = not an emitter.
+struct KzTriShade { float p[9]; float n[9]; float uv[6]; uint32_t mesh, prim, bsdf, lightFlags; };
+static_assert(sizeof(KzTriShade) == 112, "shading record must be 112 B");
 
 // Per-mesh row, 32 B.
 struct KzMeshRow {
@@ -57,7 +59,8 @@ struct KzLightRow {
     uint32_t nF;
     uint32_t cdfOffset;    // into cdf[] (nF+1 floats, dpdf.h)
     float normalization;   // DiscretePDF::m_normalization = Mesh::pdf() (mesh.h:165-168)
-    uint32_t pad[3];
+    uint32_t hasN;         // the light mesh has vertex normals (Mesh::sample interpolates them, mesh.cpp:122-128)
+    uint32_t pad[2];
 };
 // Flattened texture trees (texture.cpp): every KzTexture root becomes a postfix program over a small operand stack,
 // so the device needs no recursion. 32 B per op.
@@ -94,6 +97,7 @@ struct KzParams {
     int32_t cameraType; float apertureRadius, focusDistance;
     // lights / background
     uint32_t nLights; float lightPickPdf;
+    float lightPickScale;                // nLights when that is a power of two (x / lightPickPdf == x * nLights bit for bit), else 0
     int32_t bgPresent; float bgRadiance[3];          // constant background: intensity * colour
     int32_t bgImage; float bgIntensity;             // environment map: row of `images` (-1: none) and the intensity it is scaled by
     // film (block.cpp:13-21)

@@ -28,7 +28,7 @@
 
 struct KzWf {
     float4 *rayA, *rayB;           // o.xyz tmin | d.xyz tmax
-    float4 *hit;                   // t u v tri(bits); t = +inf: miss
+    float4 *hit;                   // t u v gid(bits) - the shading record of the triangle; t = +inf: miss
     float4 *thr;                   // throughput.xyz eta
     float4 *misc;                  // bsdfPdf accumulatedRoughness discrete(EDiscrete) -
     uint4 *smp;                    // pcg32 state (.x,.y) + dimension index (.z); the pcg32 stream id is recomputed from the pixel
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_extend(KzParams P, KzDevTables
         else { a = W.rayA[slot]; b = W.rayB[slot]; }
         RawHit rh;
         const bool found = closestHit<STATS>(T, P.rootRef, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), a.w, b.w, rh, s_stack + threadIdx.x, cn);
-        if (found) W.hit[slot] = make_float4(rh.t, rh.u, rh.v, __uint_as_float(rh.tri));
+        if (found) W.hit[slot] = make_float4(rh.t, rh.u, rh.v, __uint_as_float(rh.gid));
         else if (!KEEP) W.hit[slot] = make_float4(KZ_INF, 0.f, 0.f, 0.f);
     }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
@@ -171,10 +171,8 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
         if (slot < nItems) {
             const float4 h = W.hit[slot];
             if (h.x < KZ_INF) {
-                RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = __float_as_uint(h.w);
-                const float4 c = reinterpret_cast<const float4 *>(T.tris + rh.tri)[2];
-                rh.gid = __float_as_uint(c.w);
-                const int li = T.meshes[__float_as_uint(c.y)].light;
+                RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
+                const int li = lightOfGid(T, rh.gid);
                 if (li >= 0 && !T.lights[li].primaryVisibility) {
                     Its its; postIntersect<false>(T, rh, its);
                     const float4 b = W.rayB[slot];
@@ -199,6 +197,18 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
 // variant (textures, other BSDF models) needs 168 VGPRs and 48.7 KB: 3.
 #ifndef KZ_SHADE_WAVES
 #define KZ_SHADE_WAVES 4
+#endif
+// development build only (-DKZ_SHADESTAT): wall-clock cycles (s_memtime, per wave, stalls included) each section of the shade kernel takes,
+// summed over the waves into stats[8..23]; the shares say where the waves' time goes, whatever bounds it
+#ifdef KZ_SHADESTAT
+#define KZ_SST_DECL unsigned long long sstT = __builtin_amdgcn_s_memtime(), sstAcc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+// the same after every outstanding load has returned: the wait is charged to the section that issued the loads
+#define KZ_SSTW(k) do { __builtin_amdgcn_s_waitcnt(0); KZ_SST(k); } while (0)
+#define KZ_SST(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sstAcc[k] += t_ - sstT; sstT = t_; } while (0)
+#else
+#define KZ_SST_DECL do { } while (0)
+#define KZ_SST(k) do { } while (0)
+#define KZ_SSTW(k) do { } while (0)
 #endif
 // Two passes per round of 256 queue entries, because on many scenes about half of the hits end the path before any shading
 // happens (a one-sided BSDF seen from behind, an emitter, a miss): pass A rebuilds the intersection record and classifies;
@@ -228,8 +238,10 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
     const float eps = P.traceBias;
     const int lane = threadIdx.x & 63;
     Counters cn = {0, 0, 0, 0, 0, 0};
+    KZ_SST_DECL;
     for (uint32_t base = blockIdx.x * KZ_BLOCK;; base += gridDim.x * KZ_BLOCK) {
         const bool more = base < count;                                               // uniform over the workgroup
+        KZ_SST(9);
         // ================= pass A: hit record -> intersection, miss / emitter / back-face end here =================
         bool survivor = false;
         int svClass = 0;
@@ -241,6 +253,11 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             const float4 h = W.hit[slot];
             const float4 rb = W.rayB[slot];
             const V3 rd = mk(rb.x, rb.y, rb.z);
+#ifdef KZ_SHADESTAT
+            KZ_SSTW(10);                                    // pass A: queue entry, hit record, ray
+            if (h.x < KZ_INF) { const float4 *sp_ = reinterpret_cast<const float4 *>(T.shade + __float_as_uint(h.w)); const float4 a_ = sp_[0], b_ = sp_[6]; asm volatile("" :: "v"(a_.x), "v"(b_.x)); }
+            KZ_SSTW(11);                                    // pass A: the shading record arrives
+#endif
             if (!(h.x < KZ_INF)) {
                 // miss: black for the primary ray (H5), background after a bounce (integrator.cpp:315-318)
                 if (iter > 0 && P.bgPresent) {
@@ -249,12 +266,11 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
                 }
             } else {
-                RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = __float_as_uint(h.w);
-                rh.gid = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + rh.tri)[2].w);
+                RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
                 postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
-                const KzMeshRow mrow = T.meshes[its.mesh];
-                if (mrow.light >= 0) {                                                        // integrator.cpp:226-231, 322-327
-                    const KzLightRow &lr = T.lights[mrow.light];
+                KZ_SSTW(12);                                // pass A: postIntersect
+                if (its.light >= 0) {                                                         // integrator.cpp:226-231, 322-327
+                    const KzLightRow &lr = T.lights[its.light];
                     const float4 ra = W.rayA[slot];
                     const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot], mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : W.misc[slot];
                     const V3 ro = mk(ra.x, ra.y, ra.z);
@@ -271,9 +287,9 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     // transmissive models go on; a normal map can turn a below-the-horizon wi into an above-the-horizon one.
                     const float wz = dot(-rd, its.sh.n);                                       // toLocal(its.sh, -rd).z
                     bool twoSided = false;
-                    if (EXT) { const int bt = T.bsdfs[mrow.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
+                    if (EXT) { const int bt = T.bsdfs[its.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
                     survivor = (wz > 0.f) || twoSided || isnan(wz);
-                    if (KZ_SHADE_CLASSES && survivor) svClass = T.bsdfs[mrow.bsdf].type == KZ_BSDF_KAZENSTANDARD ? 0 : 1;
+                    if (KZ_SHADE_CLASSES && survivor) svClass = T.bsdfs[its.bsdf].type == KZ_BSDF_KAZENSTANDARD ? 0 : 1;
                     if (survivor && iter >= 3) {
                         // Russian roulette (integrator.cpp:237-244) here, in front of the compaction: a path it ends does not take a lane of
                         // pass B (at depth 3 and 4 that was 2 of 3 lanes). The survivor's scaled throughput and advanced sampler go back to
@@ -303,6 +319,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                 }
             }
         }
+        KZ_SST(0);                                          // pass A
         {   // compaction of the survivors into the LDS record table (class 0 from the front, class 1 from the back)
             const unsigned long long m = __ballot(survivor && svClass == 0), m1 = __ballot(survivor && svClass != 0);
             uint32_t b = 0, b1 = 0;
@@ -317,11 +334,12 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                 r[4 * KZ_SV_CAP] = __float_as_uint(its.sh.s.x); r[5 * KZ_SV_CAP] = __float_as_uint(its.sh.s.y); r[6 * KZ_SV_CAP] = __float_as_uint(its.sh.s.z);
                 r[7 * KZ_SV_CAP] = __float_as_uint(its.sh.t.x); r[8 * KZ_SV_CAP] = __float_as_uint(its.sh.t.y); r[9 * KZ_SV_CAP] = __float_as_uint(its.sh.t.z);
                 r[10 * KZ_SV_CAP] = __float_as_uint(its.sh.n.x); r[11 * KZ_SV_CAP] = __float_as_uint(its.sh.n.y); r[12 * KZ_SV_CAP] = __float_as_uint(its.sh.n.z);
-                r[13 * KZ_SV_CAP] = __float_as_uint(its.uvx); r[14 * KZ_SV_CAP] = __float_as_uint(its.uvy); r[15 * KZ_SV_CAP] = its.mesh;
+                r[13 * KZ_SV_CAP] = __float_as_uint(its.uvx); r[14 * KZ_SV_CAP] = __float_as_uint(its.uvy); r[15 * KZ_SV_CAP] = its.bsdf;
                 if (EXT) { r[16 * KZ_SV_CAP] = __float_as_uint(its.dpdu.x); r[17 * KZ_SV_CAP] = __float_as_uint(its.dpdu.y); r[18 * KZ_SV_CAP] = __float_as_uint(its.dpdu.z); }
             }
         }
         __syncthreads();
+        KZ_SST(1);                                          // compaction + barrier
         // ================= pass B: one survivor per thread once a full workgroup of them is waiting (or at the end) =================
         // Before pass A the two stacks hold at most 256 entries together, pass A adds at most 256: the table (512) cannot overflow.
         // A class with a full workgroup waiting runs; failing that, once more than 256 wait in all (or at the end), the larger class runs
@@ -340,9 +358,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             its.sh.s = mk(__uint_as_float(r[4 * KZ_SV_CAP]), __uint_as_float(r[5 * KZ_SV_CAP]), __uint_as_float(r[6 * KZ_SV_CAP]));
             its.sh.t = mk(__uint_as_float(r[7 * KZ_SV_CAP]), __uint_as_float(r[8 * KZ_SV_CAP]), __uint_as_float(r[9 * KZ_SV_CAP]));
             its.sh.n = mk(__uint_as_float(r[10 * KZ_SV_CAP]), __uint_as_float(r[11 * KZ_SV_CAP]), __uint_as_float(r[12 * KZ_SV_CAP]));
-            its.uvx = __uint_as_float(r[13 * KZ_SV_CAP]); its.uvy = __uint_as_float(r[14 * KZ_SV_CAP]); its.mesh = r[15 * KZ_SV_CAP];
+            its.uvx = __uint_as_float(r[13 * KZ_SV_CAP]); its.uvy = __uint_as_float(r[14 * KZ_SV_CAP]); its.bsdf = r[15 * KZ_SV_CAP];
             if (EXT) its.dpdu = mk(__uint_as_float(r[16 * KZ_SV_CAP]), __uint_as_float(r[17 * KZ_SV_CAP]), __uint_as_float(r[18 * KZ_SV_CAP]));
-            const KzMeshRow mrow = T.meshes[its.mesh];
             const float4 rb = W.rayB[slot];
             const V3 rd = mk(rb.x, rb.y, rb.z);
             float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot];              // a camera path: generate stores neither (initial values)
@@ -354,9 +371,10 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             const uint32_t pxy = pixList[pl];
             Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
             {                                                                         // (the roulette of integrator.cpp:237-244 was played in pass A)
-                KzBSDF bsdf = T.bsdfs[mrow.bsdf];
+                KzBSDF bsdf = T.bsdfs[its.bsdf];
                 NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
                 const V3 wiLocal = toLocal(its.sh, -rd);
+                KZ_SST(2);                                  // pass B: record, state loads, sampler setup, BSDF row, frame
                 const float pick = smp.next1D(P, T);                                  // drawn even without lights
                 if (P.nLights > 0) {                                                  // integrator.cpp:247-295
                     const uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
@@ -365,7 +383,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     const LightSample ls = lightSample(T, lrow, its.p, [&]() { return smp.next1D(P, T); });
                     const V3 lwi = ls.wi; const float dist = ls.dist, lpdf = ls.pdf;
                     V3 Ls = ls.Ls;
-                    Ls = Ls / P.lightPickPdf;
+                    Ls = lightPickDivide(P, Ls);
+                    KZ_SST(3);                              // pick + 3 draws + light sample
                     const V3 woL = toLocal(its.sh, lwi);
                     V3 f; float bpdfL;
                     surfEvalPdf<EXT>(bsdf, nm, its, wiLocal, woL, accRough, f, bpdfL);
@@ -378,11 +397,14 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         pushShadow = true; binShadow = li & 15u;
                     }
                 }
+                KZ_SST(4);                                  // eval + pdf towards the light, shadow ray stores
                 if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
                 float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
                 const float s1 = smp.next1D(P, T);
+                KZ_SST(5);                                  // 2-D + 1-D draw
                 V3 woLocal; bool ok, discrete, solid; float etaScale, pdfS;
                 const V3 weight = surfSample<EXT>(bsdf, nm, its, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale, pdfS, solid);
+                KZ_SST(6);                                  // BSDF sample
                 throughput = throughput * weight;
                 const float etaNext = eta * etaScale;
                 if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
@@ -400,6 +422,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                 }
             }
         }
+        KZ_SST(7);                                          // next-ray stores (and, for lanes without a survivor, nothing)
         __syncthreads();                                   // every record of this batch has been read
         if (threadIdx.x == 0 && take) { if (runClass == 0) s_svN = n0 - take; else s_svM = n1 - take; }
         if (binRays) {
@@ -411,12 +434,16 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             apN.maybeFlush(false);
             apS.maybeFlush(false);
         }
+        KZ_SST(8);                                          // barrier + queue staging + flushes
         if (!more && n0 + n1 - take == 0) break;
         if (!more) base -= gridDim.x * KZ_BLOCK;           // stay past the end while the table drains
     }
     if (binRays) { apN.maybeFlush<true>(true, s_bins); apS.maybeFlush<true>(true, s_bins); }
     else { apN.maybeFlush(true); apS.maybeFlush(true); }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
+#ifdef KZ_SHADESTAT
+    if (lane == 0) for (int k = 0; k < 14; ++k) atomicAdd(W.stats + 8 + k, sstAcc[k]);
+#endif
 }
 
 // ---- shadow(iter): occlusion test, adds the pending radiance (integrator.cpp:257-295) -----------------------------------
@@ -532,12 +559,12 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     // the lane's stack ran empty: publish the result (or, for a literal shadow lane, decide / walk through the light)
     auto finish = [&]() {
         active = false;
-        if (kind == 0) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
-        if (kind == 1) { if (found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(btri)); }
+        if (kind == 0) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(bgid)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+        if (kind == 1) { if (found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid)); }
         if (kind == 2) {
             if (!literal || !found) addPending();                                    // nothing on the segment
             else {
-                const uint32_t om = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + btri)[2].y);
+                const uint32_t om = __float_as_uint(reinterpret_cast<const float4 *>(T.tris + btri)[2].y);      // (the leaf triangle is in cache; its shading record is not)
                 const int ol = T.meshes[om].light;
                 if (ol >= 0 && !T.lights[ol].primaryVisibility) {                     // walk through (integrator.cpp:273-274)
                     o = o + d * (bt + eps); tmin = eps; segMax = segMax - bt; tmax = segMax;
@@ -945,7 +972,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         if (state == 2 && (int)(done - lastSeq) >= 0) {
             const unsigned long long b = best[lane];
             if (MODE == 0) {
-                W.hit[slot] = (b != ~0ull) ? make_float4(__uint_as_float((uint32_t)(b >> 32)), __uint_as_float(res[64 + lane]), __uint_as_float(res[128 + lane]), __uint_as_float(res[lane]))
+                W.hit[slot] = (b != ~0ull) ? make_float4(__uint_as_float((uint32_t)(b >> 32)), __uint_as_float(res[64 + lane]), __uint_as_float(res[128 + lane]), __uint_as_float((uint32_t)b))        // the key's low word is the gid
                                            : make_float4(KZ_INF, 0.f, 0.f, 0.f);
             } else if (b != 0ull) { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; }     // nothing on the segment
             state = 0;
@@ -1003,7 +1030,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         const float rx = 1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
         const float ry = 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
         const float rz = 1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
-        bool found = false; float bt = KZ_INF, bu = 0.f, bv = 0.f; uint32_t btri = 0, bgid = 0;
+        bool found = false; float bt = KZ_INF, bu = 0.f, bv = 0.f; uint32_t bgid = 0;
         if (STATS && have) cn.rays++;
         if (__ballot(live) != 0ull) {
             uint32_t cur = root;                       // wave-uniform
@@ -1050,7 +1077,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                         float t, u, v; uint32_t g;
                         if (STATS && live) cn.tris++;
                         if (!triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, g)) continue;
-                        if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; btri = start + i; bgid = g; tmax = t; }
+                        if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; bgid = g; tmax = t; }
                     }
                 }
                 bool more = false;
@@ -1067,7 +1094,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (!more) break;
             }
         }
-        if (have) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(btri)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+        if (have) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(bgid)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
     }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
 }

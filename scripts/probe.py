@@ -9,6 +9,8 @@
                                                          executed node visits / triangle tests / rays per sample for each tuning
     KZ_LIB_PATH=nano-kazen_amd/csrc/variants/lanestat/libkazen_mi355x.so python scripts/probe.py lanestat
                                                          where the lanes of the traversal loop are (needs scripts/build_variant.sh lanestat -DKZ_LANESTAT)
+    KZ_LIB_PATH=nano-kazen_amd/csrc/variants/shadestat/libkazen_mi355x.so python scripts/probe.py shadestat
+                                                         shares of the shade kernel's wave time per section (scripts/build_variant.sh shadestat -DKZ_SHADESTAT)
 """
 import argparse, importlib, json, os, sys, time
 import numpy as np
@@ -111,11 +113,20 @@ def cmd_lanestat(a):
     print(json.dumps(sc.stats(reset=True)), flush=True)          # the library prints the lane statistics on stderr
 
 
+def cmd_shadestat(a):
+    """KZ_LIB_PATH=.../variants/shadestat/... : shares of the shade kernel's wave time per section (scripts/build_variant.sh shadestat -DKZ_SHADESTAT)"""
+    sc = kz.Scene(scene(a.scene), device=0)
+    spp = a.spp or 64
+    sc.stats(reset=True)
+    sc.render(0, spp, passes_in_flight=1, tune=kv(a.tune)); sc.sync()
+    print(json.dumps(sc.stats(reset=True)), flush=True)          # the library prints the section shares on stderr
+
+
 ap = argparse.ArgumentParser()
-ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters"])
+ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters", "shadestat"])
 ap.add_argument("c5", nargs="?")
 ap.add_argument("--scene", default="c4"); ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--tune", default=""); ap.add_argument("--opts", default="")
 ap.add_argument("--all-kiss", action="store_true"); ap.add_argument("--knob", default="refill"); ap.add_argument("--values", default="")
 a = ap.parse_args()
-{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters}[a.cmd](a)
+{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters, "shadestat": cmd_shadestat}[a.cmd](a)
