@@ -27,6 +27,35 @@ __device__ __forceinline__ V3 normalized(V3 a) { float n2 = dot(a, a); return n2
 __device__ __forceinline__ float maxCoeff(V3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 __device__ __forceinline__ float sqr(float x) { return x * x; }
 
+// 1.0f / x, bit for bit. The compiler expands an IEEE division into v_div_scale x2, v_rcp, Newton, v_div_fmas, v_div_fixup and two switches
+// of the denormal mode (42-47 SIMD cycles, scripts/micro/op_cost.hip). For a numerator of 1 the hardware reciprocal followed by two
+// Newton-Raphson steps in FMA form gives THE SAME BITS for every one of the 3 355 443 202 floats with 2^-100 <= |x| <= 2^100 - checked
+// exhaustively on the GPU against that division (scripts/micro/rcp_exact.hip -> profiles/rcp_exact.json; 0 mismatches) - in ~20 cycles.
+// Everything else (zero, denormal, huge, inf, nan) takes the division.
+__device__ __forceinline__ float rcpExact(float x) {
+    const float ax = fabsf(x);
+    if (__builtin_expect(ax >= 0x1p-100f && ax <= 0x1p100f, 1)) {
+        float r = __builtin_amdgcn_rcpf(x);
+        float e = __builtin_fmaf(-x, r, 1.0f); r = __builtin_fmaf(e, r, r);
+        e = __builtin_fmaf(-x, r, 1.0f); r = __builtin_fmaf(e, r, r);
+        return r;
+    }
+    return 1.0f / x;
+}
+// sqrtf(x), bit for bit: the compiler's own correctly rounded sequence (v_rsq_f32, g = x*y, h = y/2, one coupled Newton step, one residual
+// correction) without its input scaling for tiny x, the un-scaling and the class test for 0 / inf, which only matter outside
+// 2^-95 <= x < 2^96: 54-58 -> ~36 SIMD cycles. All 1 602 224 128 floats of that range checked against sqrtf on the GPU (rcp_exact.hip).
+__device__ __forceinline__ float sqrtExact(float x) {
+    if (__builtin_expect((__float_as_uint(x) - 0x10000000u) < (0x6F800000u - 0x10000000u), 1)) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        float g = x * y, h = 0.5f * y;
+        const float r = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, r, g); h = __builtin_fmaf(h, r, h);
+        const float d = __builtin_fmaf(-g, g, x);
+        return __builtin_fmaf(d, h, g);
+    }
+    return sqrtf(x);
+}
 #define KZ_EPSILON 1e-5f                      // common.h:27
 #define KZ_ONE_MINUS_EPS 0x1.fffffep-1f       // common.h:28
 #define KZ_INV_PI 0.31830988618379067154f     // common.h:34
@@ -235,7 +264,7 @@ __device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin
     V3 pvec = cross(d, e2);
     float det = dot(e1, pvec);
     if (det > -1e-8f && det < 1e-8f) return false;
-    float inv_det = 1.0f / det;
+    float inv_det = rcpExact(det);
     V3 tvec = o - p0;
     u = dot(tvec, pvec) * inv_det;
     if (u < 0.0f || u > 1.0f) return false;
@@ -316,7 +345,7 @@ __device__ __forceinline__ bool closestHit(const KzDevTables &T, uint32_t rootRe
     // A ray with a non-finite origin or direction can hit nothing (every Moeller-Trumbore comparison fails on NaN),
     // but fminf/fmaxf would let it pass EVERY slab test: one such lane would walk the whole tree. Miss at once.
     if (!(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z) < KZ_INF)) return false;
-    const float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;      // ray.h:56-58 cwiseInverse
+    const float rx = rcpExact(d.x), ry = rcpExact(d.y), rz = rcpExact(d.z);      // ray.h:56-58 cwiseInverse
     uint32_t cur = rootRef;
     int sp = 0;
     for (;;) {
@@ -357,7 +386,7 @@ __device__ __forceinline__ bool anyHit(const KzDevTables &T, uint32_t rootRef, V
     if (STATS) cn.rays++;
     if (rootRef == 0xFFFFFFFFu) return false;
     if (!(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(d.x) + fabsf(d.y) + fabsf(d.z) < KZ_INF)) return false;
-    const float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
+    const float rx = rcpExact(d.x), ry = rcpExact(d.y), rz = rcpExact(d.z);
     uint32_t cur = rootRef;
     int sp = 0;
     for (;;) {
@@ -430,7 +459,7 @@ __device__ __forceinline__ bool invisibleLightOnSegment(const KzParams &P, const
 template <bool STATS>
 __device__ __forceinline__ bool shadowOccluded(const KzParams &P, const KzDevTables &T, V3 so, V3 dir, float smin, float smax,
                                                uint32_t *stk, Counters &cn) {
-    if (P.shadowFast && !invisibleLightOnSegment(P, T, so, dir, 1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z, smin, smax))
+    if (P.shadowFast && !invisibleLightOnSegment(P, T, so, dir, rcpExact(dir.x), rcpExact(dir.y), rcpExact(dir.z), smin, smax))
         return anyHit<STATS>(T, P.rootRef, so, dir, smin, smax, stk, cn);
     return shadowOccludedLiteral<STATS>(P, T, so, dir, smin, smax, stk, cn);
 }
@@ -442,8 +471,8 @@ struct Frame3 { V3 s, t, n; };
 __device__ __forceinline__ Frame3 frameFromNormal(V3 a) {
     Frame3 f; f.n = a;
     V3 c;
-    if (fabsf(a.x) > fabsf(a.y)) { float invLen = 1.0f / sqrtf(a.x * a.x + a.z * a.z); c = mk(a.z * invLen, 0.0f, -a.x * invLen); }
-    else { float invLen = 1.0f / sqrtf(a.y * a.y + a.z * a.z); c = mk(0.0f, a.z * invLen, -a.y * invLen); }
+    if (fabsf(a.x) > fabsf(a.y)) { float invLen = rcpExact(sqrtExact(a.x * a.x + a.z * a.z)); c = mk(a.z * invLen, 0.0f, -a.x * invLen); }
+    else { float invLen = rcpExact(sqrtExact(a.y * a.y + a.z * a.z)); c = mk(0.0f, a.z * invLen, -a.y * invLen); }
     f.t = c; f.s = cross(c, a);
     return f;
 }
@@ -490,7 +519,7 @@ __device__ __forceinline__ void postIntersect(const KzDevTables &T, const RawHit
             const float length = norm(gx);
             const float determinant = duv0x * duv1y - duv0y * duv1x;
             if (length > 0.f && determinant > 0.f) {
-                const float invDet = 1.0f / determinant;
+                const float invDet = rcpExact(determinant);
                 const V3 dpdu = (duv1y * dp0 - duv0y * dp1) * invDet;
                 its.sh.n = normalized(shN);
                 its.sh.s = normalized(dpdu - shN * dot(shN, dpdu));
@@ -517,7 +546,7 @@ __device__ __forceinline__ V3 squareToCosineHemisphere(float sx, float sy) {
     else { r = r2; phi = (KZ_PI_F / 2.0f) - (r1 / r2) * (KZ_PI_F / 4.0f); }
     float sinPhi, cosPhi; sincosf(phi, &sinPhi, &cosPhi);             // one argument reduction for both (the values of sinf / cosf)
     float px = r * cosPhi, py = r * sinPhi;
-    float z = sqrtf(1.0f - px * px - py * py);
+    float z = sqrtExact(1.0f - px * px - py * py);
     if (z == 0) z = 1e-10f;
     return mk(px, py, z);
 }
@@ -537,16 +566,16 @@ __device__ __forceinline__ A2 roughnessToAlpha(float roughness, float anisotropy
 }
 __device__ __forceinline__ float ggxLambda(V3 v, A2 a) {                          // ggx_brdf.h:41-45
     float squared = (sqr(a.x) * sqr(v.x) + sqr(a.y) * sqr(v.y)) / sqr(v.z);
-    return (-1.0f + sqrtf(1.0f + squared)) * 0.5f;
+    return (-1.0f + sqrtExact(1.0f + squared)) * 0.5f;
 }
-__device__ __forceinline__ float smithG1(V3 V, V3 H, A2 a) { return dot(V, H) <= 0.0f ? 0.0f : 1.0f / (1.0f + ggxLambda(V, a)); }
+__device__ __forceinline__ float smithG1(V3 V, V3 H, A2 a) { return dot(V, H) <= 0.0f ? 0.0f : rcpExact(1.0f + ggxLambda(V, a)); }
 __device__ __forceinline__ float smithG2(V3 V, V3 L, V3 H, A2 a) {
     if (dot(V, H) <= 0.0f || dot(L, H) < 0.0f) return 0.0f;
-    return 1.0f / (1.0f + ggxLambda(V, a) + ggxLambda(L, a));
+    return rcpExact(1.0f + ggxLambda(V, a) + ggxLambda(L, a));
 }
 __device__ __forceinline__ float ggxNDF(V3 H, A2 a) {                             // ggx_brdf.h:71-75
     float ellipse = sqr(H.x) / sqr(a.x) + sqr(H.y) / sqr(a.y) + sqr(H.z);
-    return 1.0f / (KZ_PI_F * a.x * a.y * sqr(ellipse));
+    return rcpExact(KZ_PI_F * a.x * a.y * sqr(ellipse));
 }
 __device__ __forceinline__ float ggxVNDF(V3 V, V3 H, A2 a) {                      // ggx_brdf.h:80-91
     float VDotH = dot(V, H);
@@ -556,15 +585,15 @@ __device__ __forceinline__ float ggxVNDF(V3 V, V3 H, A2 a) {                    
 __device__ __forceinline__ V3 sampleGGXVNDF(V3 V, A2 a, float rx, float ry) {     // ggx_brdf.h:96-120
     V3 Vh = normalized(mk(a.x * V.x, a.y * V.y, V.z));
     float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
-    V3 T1 = lensq > 0.0f ? mk(-Vh.y, Vh.x, 0.0f) / sqrtf(lensq) : mk(1.0f, 0.0f, 0.0f);
+    V3 T1 = lensq > 0.0f ? mk(-Vh.y, Vh.x, 0.0f) / sqrtExact(lensq) : mk(1.0f, 0.0f, 0.0f);
     V3 T2 = normalized(cross(Vh, T1));
-    float r = sqrtf(rx);
+    float r = sqrtExact(rx);
     float phi = 2.0f * KZ_PI_F * ry;
     float sinPhi, cosPhi; sincosf(phi, &sinPhi, &cosPhi);
     float t1 = r * cosPhi, t2 = r * sinPhi;
     float s = 0.5f * (1.0f + Vh.z);
-    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
-    V3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
+    t2 = (1.0f - s) * sqrtExact(1.0f - t1 * t1) + s * t2;
+    V3 Nh = t1 * T1 + t2 * T2 + sqrtExact(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
     return normalized(mk(a.x * Nh.x, a.y * Nh.y, fmaxf(1e-6f, Nh.z)));
 }
 __device__ __forceinline__ V3 evalGGXSmithBRDF(V3 V, V3 L, V3 f0, float roughness, float anisotropy) {   // ggx_brdf.h:151-170
@@ -623,21 +652,21 @@ __device__ __forceinline__ void kissEvalPdf(const KzBSDF &m, const KissMat &k, V
         // evalGGXSmithBRDF (ggx_brdf.h:151-170) twice; V.z * L.z < 0 cannot happen here; smithG2 (ggx_brdf.h:58-66)
         const bool gZero = VdotH <= 0.0f || LdotH < 0.0f;
         const float denom = 4.0f * fabsf(V.z) * fabsf(L.z);
-        const float GS = gZero ? 0.0f : 1.0f / (1.0f + lamVS + ggxLambda(L, aS));
+        const float GS = gZero ? 0.0f : rcpExact(1.0f + lamVS + ggxLambda(L, aS));
         const V3 specTerm = (DS * GS) * schlickFresnel(k.Cspec0, VdotH) / denom;
-        const float GC = gZero ? 0.0f : 1.0f / (1.0f + lamVC + ggxLambda(L, aC));
+        const float GC = gZero ? 0.0f : rcpExact(1.0f + lamVC + ggxLambda(L, aC));
         const V3 coatTerm = 0.25f * m.clearcoat * ((DC * GC) * schlickFresnel(mk(0.04f), VdotH) / denom);
         f = ((1.f - metallic) * (k.Cdlin * KZ_INV_PI * (Lambert + retro) + Fsheen) + (specTerm + coatTerm)) * L.z;
     }
     if (WANT_PDF) {
         const float diffuse = (1.f - metallic) * 0.5f;
-        const float GTR2 = 1.f / (1.f + m.clearcoat);
+        const float GTR2 = rcpExact(1.f + m.clearcoat);
         const float jacobian = 4.0f * VdotH;
         // ggxVNDF (ggx_brdf.h:80-91) = D * G1 * VdotH / V.z, G1 = 1 / (1 + Lambda(V)) (0 when VdotH <= 0)
-        const float specPdf = (VdotH <= 0.0f ? 0.0f : DS * (1.0f / (1.0f + lamVS)) * VdotH / V.z) / jacobian;
+        const float specPdf = (VdotH <= 0.0f ? 0.0f : DS * (rcpExact(1.0f + lamVS)) * VdotH / V.z) / jacobian;
         float DCp = DC, lamVCp = lamVC;                                // pdf()'s coat has anisotropy 0: alpha * (1 +- 0) is the same alpha
         if (m.anisotropy != 0.f) { const A2 aP = roughnessToAlpha(ccR, 0.f); DCp = ggxNDF(H, aP); lamVCp = ggxLambda(V, aP); }
-        const float coatPdf = (VdotH <= 0.0f ? 0.0f : DCp * (1.0f / (1.0f + lamVCp)) * VdotH / V.z) / jacobian;
+        const float coatPdf = (VdotH <= 0.0f ? 0.0f : DCp * (rcpExact(1.0f + lamVCp)) * VdotH / V.z) / jacobian;
         pdf = diffuse * KZ_INV_PI * L.z + (1.f - diffuse) * (GTR2 * specPdf + (1.f - GTR2) * coatPdf);
     }
 }
@@ -654,21 +683,21 @@ __device__ __forceinline__ float fresnelIOR(float cosThetaI, float extIOR, float
     if (cosThetaI < 0.0f) { float t = etaI; etaI = etaT; etaT = t; cosThetaI = -cosThetaI; }
     float eta = etaI / etaT, sinThetaTSqr = eta * eta * (1 - cosThetaI * cosThetaI);
     if (sinThetaTSqr > 1.0f) return 1.0f;
-    float cosThetaT = sqrtf(1.0f - sinThetaTSqr);
+    float cosThetaT = sqrtExact(1.0f - sinThetaTSqr);
     float Rs = (etaI * cosThetaI - etaT * cosThetaT) / (etaI * cosThetaI + etaT * cosThetaT);
     float Rp = (etaT * cosThetaI - etaI * cosThetaT) / (etaT * cosThetaI + etaI * cosThetaT);
     return (Rs * Rs + Rp * Rp) / 2.0f;
 }
 __device__ __forceinline__ V3 refractV(V3 wi, V3 n, float eta) {
     float cosThetaI = dot(wi, n);
-    if (cosThetaI < 0) eta = 1.0f / eta;
+    if (cosThetaI < 0) eta = rcpExact(eta);
     float cosThetaT2 = 1 - (1 - cosThetaI * cosThetaI) * (eta * eta);
     if (cosThetaT2 <= 0.0f) return mk(0.0f);
     float sign = cosThetaI >= 0.0f ? 1.0f : -1.0f;
-    return n * (-cosThetaI * eta + sign * sqrtf(cosThetaT2)) + wi * eta;
+    return n * (-cosThetaI * eta + sign * sqrtExact(cosThetaT2)) + wi * eta;
 }
 // ---- Beckmann helpers of roughconductor / roughplastic / roughdielectric (bsdf.cpp:721-750, warp.cpp:120-129, frame.h:63-68)
-__device__ __forceinline__ float tanThetaV(V3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return sqrtf(temp) / v.z; }
+__device__ __forceinline__ float tanThetaV(V3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return sqrtExact(temp) / v.z; }
 __device__ __forceinline__ float alphaOf(float x) { return fmaxf(0.001f, sqr(x)); }
 __device__ __forceinline__ float evalBeckmann(V3 m, float alpha) {
     float temp = tanThetaV(m) / alpha, ct = m.z, ct2 = ct * ct;
@@ -678,14 +707,14 @@ __device__ __forceinline__ float smithBeckmannG1(V3 v, V3 m, float alpha) {
     if (dot(v, m) * v.z <= 0.0f) return 0.0f;
     float tt = fabsf(tanThetaV(v));
     if (tt == 0.0f) return 1.0f;
-    float a = 1.0f / (alpha * tt);
+    float a = rcpExact(alpha * tt);
     if (a >= 1.6f) return 1.0f;
     float aSqr = a * a;
     return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
 }
 __device__ __forceinline__ V3 squareToBeckmann(float sx, float sy, float alpha) {
     float phi = 2 * KZ_PI_F * sx;
-    float theta = atanf(alpha * sqrtf(logf(1 / (1 - sy))));
+    float theta = atanf(alpha * sqrtExact(logf(rcpExact(1 - sy))));
     float sinTheta, cosTheta, sinPhi, cosPhi; sincosf(theta, &sinTheta, &cosTheta); sincosf(phi, &sinPhi, &cosPhi);
     return mk(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
@@ -695,9 +724,9 @@ __device__ __forceinline__ float squareToBeckmannPdf(V3 m, float alpha) {
     return ok * expf(-powf(tanf(theta), 2.f) / (alpha * alpha)) / (KZ_PI_F * alpha * alpha * powf(cosf(theta), 3.f));
 }
 __device__ __forceinline__ float fresnelDielectricT(float cosThetaI_, float eta, float &cosThetaT_) {        // common.cpp:492-518
-    float scale = (cosThetaI_ > 0.f) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    float scale = (cosThetaI_ > 0.f) ? rcpExact(eta) : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
     if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
-    float cosThetaI = fabsf(cosThetaI_), cosThetaT = sqrtf(cosThetaTSqr);
+    float cosThetaI = fabsf(cosThetaI_), cosThetaT = sqrtExact(cosThetaTSqr);
     float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
     float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
     cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
@@ -754,7 +783,7 @@ __device__ float roughPdf(const KzBSDF &m, V3 wi, V3 wo) {
         const bool refl = wi.z * wo.z > 0.f;
         const float eta = wi.z > 0.f ? mEta : mInvEta;
         V3 wm; float dwm_dwo;
-        if (refl) { wm = normalized(wi + wo); dwm_dwo = 1.0f / (4.0f * dot(wo, wm)); }
+        if (refl) { wm = normalized(wi + wo); dwm_dwo = rcpExact(4.0f * dot(wo, wm)); }
         else { wm = normalized(wi + wo * eta); const float sd = dot(wi, wm) + eta * dot(wo, wm); dwm_dwo = (eta * eta * dot(wo, wm)) / (sd * sd); }
         wm = wm * signf1(wm.z);
         float ct; const float F = fresnelDielectricT(dot(wi, wm), mEta, ct);
@@ -766,15 +795,15 @@ __device__ float roughPdf(const KzBSDF &m, V3 wi, V3 wo) {
     const V3 wh = normalized(wi + wo);
     if (m.type == KZ_BSDF_GGX) return ggxVNDF(wi, wh, roughnessToAlpha(m.alpha, m.anisotropy)) / (4.0f * dot(wi, wh));
     const float D = evalBeckmann(wh, alphaOf(m.alpha));
-    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) return D * wh.z * (1.f / (4.f * dot(wh, wo)));
+    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) return D * wh.z * (rcpExact(4.f * dot(wh, wo)));
     const float ks = 1 - fmaxf(m.albedo[0], fmaxf(m.albedo[1], m.albedo[2]));
-    return ks * D * wh.z * (1.f / (4.f * fabsf(dot(wh, wo)))) + (1 - ks) * wo.z * KZ_INV_PI;
+    return ks * D * wh.z * (rcpExact(4.f * fabsf(dot(wh, wo)))) + (1 - ks) * wo.z * KZ_INV_PI;
 }
 __device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y, V3 &wo, bool &alive, float &etaScale) {
     alive = true;
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {
         const float mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
-        const float alpha = alphaOf(m.alpha) * (1.2f - 0.2f * sqrtf(fabsf(wi.z)));
+        const float alpha = alphaOf(m.alpha) * (1.2f - 0.2f * sqrtExact(fabsf(wi.z)));
         const V3 wm = squareToBeckmann(s2x, s2y, alpha);
         const float pdf = squareToBeckmannPdf(wm, alpha);
         if (pdf == 0.f) return mk(0.f);
@@ -784,7 +813,7 @@ __device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y
             if (wi.z * wo.z <= 0) return mk(0.f);
         } else {
             if (cosThetaT == 0) return mk(0.f);
-            float e = mEta; if (cosThetaT < 0) e = 1.f / e;
+            float e = mEta; if (cosThetaT < 0) e = rcpExact(e);
             wo = wm * (dot(wi, wm) * e + cosThetaT) - wi * e;
             etaScale = cosThetaT < 0.f ? mEta : mInvEta;
             if (wi.z * wo.z >= 0) return mk(0.f);
@@ -848,7 +877,7 @@ __device__ V3 bsdfSample(const KzBSDF &m, const KissMat &km, V3 wi, float accRou
     if (s1 < diffuse) wo = squareToCosineHemisphere(s2x, s2y);
     else {
         float sample = (s1 - diffuse) / (1.f - diffuse);
-        float GTR2 = 1.f / (1.f + m.clearcoat);
+        float GTR2 = rcpExact(1.f + m.clearcoat);
         A2 alpha = (sample < GTR2) ? roughnessToAlpha(m.roughness, m.anisotropy)   // H7: un-regularised roughness, anisotropy 0 for the coat
                                    : roughnessToAlpha(lerpf(m.clearcoatRoughness, 0.01f, .3f), 0.f);
         V3 H = sampleGGXVNDF(wi, alpha, s2x, s2y);                                 // wi.z > 0 here: never flipped
@@ -1099,7 +1128,7 @@ template <class Draw>
 __device__ __forceinline__ LightSample lightSample(const KzDevTables &T, const KzLightRow &lrow, V3 ref, Draw draw) {
     LightSample r;
     r.tri = cdfSample(T.cdf + lrow.cdfOffset, lrow.nF, draw());
-    const float su0 = sqrtf(draw());
+    const float su0 = sqrtExact(draw());
     const float u = 1 - su0;
     const float v = draw() * su0;
     const float4 *sp = reinterpret_cast<const float4 *>(T.shade + lrow.triOffset + r.tri);
@@ -1136,7 +1165,7 @@ __device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy,
     const float *w = P.c2w;
     V3 dl;
     if (P.cameraType == KZ_CAMERA_THINLENS) {                                      // camera.cpp:191-223, warp.cpp:41-50
-        const float r = sqrtf(ax);
+        const float r = sqrtExact(ax);
         const float ang = 2.0f * KZ_PI_F * ay;
         float sinAng, cosAng; sincosf(ang, &sinAng, &cosAng);
         const float tx = cosAng * r * P.apertureRadius, ty = sinAng * r * P.apertureRadius;
@@ -1150,7 +1179,7 @@ __device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy,
         const float ow = w[15];
         o = mk(w[3] / ow, w[7] / ow, w[11] / ow);
     }
-    float invZ = 1.0f / dl.z;
+    float invZ = rcpExact(dl.z);
     d = mk(w[0] * dl.x + w[1] * dl.y + w[2] * dl.z, w[4] * dl.x + w[5] * dl.y + w[6] * dl.z, w[8] * dl.x + w[9] * dl.y + w[10] * dl.z);
     mint = P.nearClip * invZ; maxt = P.farClip * invZ;
 }

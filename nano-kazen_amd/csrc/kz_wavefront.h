@@ -575,7 +575,15 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         }
     };
 
+#ifdef KZ_TRACESTAT
+    // development build only (-DKZ_TRACESTAT): wall-clock cycles (s_memtime, per wave) of the refill / node / leaf parts of the loop
+    unsigned long long tsT = __builtin_amdgcn_s_memtime(), tsAcc[4] = {0, 0, 0, 0};
+#define KZ_TST(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsAcc[k] += t_ - tsT; tsT = t_; } while (0)
+#else
+#define KZ_TST(k) do { } while (0)
+#endif
     for (;;) {
+        KZ_TST(3);
         // ---- refill idle lanes
         const unsigned long long act = __ballot(active);
         const int nAct = __popcll(act);
@@ -612,10 +620,10 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                             // The FMA slab form q*(s*rcp) + (p-o)*rcp turns into inf - inf = NaN for a zero direction component,
                             // which would switch that axis off (a huge slab of the tree gets walked). A tiny signed stand-in keeps
                             // every product finite; the sign of (box - origin) * 1e20 still decides the slab exactly as 1/0 would.
-                            rx = 1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
-                            ry = 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
-                            rz = 1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
-                        } else { rx = 1.0f / d.x; ry = 1.0f / d.y; rz = 1.0f / d.z; }
+                            rx = rcpExact(fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
+                            ry = rcpExact(fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
+                            rz = rcpExact(fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
+                        } else { rx = rcpExact(d.x); ry = rcpExact(d.y); rz = rcpExact(d.z); }
                         cur = root; sp = 0; active = true;
                         if (kind == 2) {
                             literal = !P.shadowFast || invisibleLightOnSegment(P, T, o, d, rx, ry, rz, tmin, tmax);
@@ -629,6 +637,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 poolNext += take;
             }
         }
+        KZ_TST(0);
         if (!__any(active)) { if (exhausted) break; continue; }
         // ---- node phase: descend until (almost) every busy lane holds a leaf
         for (;;) {
@@ -721,6 +730,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (empty) { if (!popNext()) finish(); }
             }
         }
+        KZ_TST(1);
         // ---- leaf phase
 #ifdef KZ_LANESTAT
         { const unsigned long long lm = __ballot(active && (cur & 0x80000000u)); if (lm) { lsLeafPhases++; lsLeafLanes += __popcll(lm);
@@ -739,8 +749,12 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
             if (occluded) active = false;
             else if (!popNext()) finish();
         }
+        KZ_TST(2);
     }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
+#ifdef KZ_TRACESTAT
+    if (lane == 0) for (int k = 0; k < 4; ++k) atomicAdd(W.stats + 8 + (MODE == 2 ? 4 : 0) + k, tsAcc[k]);
+#endif
 #ifdef KZ_LANESTAT
     if (lane == 0) {
         unsigned long long *ls = W.stats + 8 + (MODE == 2 ? 8 : 0);
@@ -848,9 +862,9 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                     else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w); }
                     o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); tmin = a.w; tmax = b.w;
                     if (STATS) cn.rays++;
-                    rx = 1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
-                    ry = 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
-                    rz = 1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
+                    rx = rcpExact(fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
+                    ry = rcpExact(fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
+                    rz = rcpExact(fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
                     bool go = (root != 0xFFFFFFFFu) && rayIsFinite(o, d);
                     if (go && MODE == 2 && invisibleLightOnSegment(P, T, o, d, rx, ry, rz, tmin, tmax)) {
                         // the reference's walk-through of an invisible light (integrator.cpp:257-278): left to kz_wf_trace<2>
@@ -1027,9 +1041,9 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         // a lane without a ray, or with a ray that can hit nothing (non-finite, see kz_wf_trace), carries tmax = -inf: it fails every box and triangle test
         const bool live = have && root != 0xFFFFFFFFu && rayIsFinite(o, d);
         float tmax = live ? b.w : -KZ_INF;
-        const float rx = 1.0f / (fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
-        const float ry = 1.0f / (fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
-        const float rz = 1.0f / (fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
+        const float rx = rcpExact(fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
+        const float ry = rcpExact(fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
+        const float rz = rcpExact(fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
         bool found = false; float bt = KZ_INF, bu = 0.f, bv = 0.f; uint32_t bgid = 0;
         if (STATS && have) cn.rays++;
         if (__ballot(live) != 0ull) {
