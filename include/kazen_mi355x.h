@@ -257,8 +257,9 @@ typedef struct KzTuning {
                                    gather otherwise), 1 = always the staged gather kernel of round 1 */
     int32_t leafQueue;          /* bounce / shadow traversal with a decoupled leaf phase (kz_wf_trace_dq: per-wave job queue in LDS): 0 = default,
                                    1 = off, 2 = on */
-    int32_t binRays;            /* shade orders each staged window of its output queues by a 4-bit bin (next ray: direction octant + dominant
-                                   axis; shadow ray: light index) before it goes to the global queue: 0 = default, 1 = off, 2 = on */
+    int32_t binRays;            /* accepted and ignored since round 2: the experiment it selected (shade ordering each staged window of its
+                                   output queues by direction octant / light index) lost 3-17 % per stage and its code is gone; the field
+                                   keeps the layout */
     int32_t reserved[3];
 } KzTuning;
 
@@ -425,6 +426,10 @@ int kz_abi_version(void);
 int kz_device_count(void);
 /* hipMemGetInfo of `device` (what the default state budget of kz_render is derived from). */
 int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes);
+/* Self-check of the library's exact reciprocal / square root (hardware v_rcp_f32 / v_rsq_f32 + Newton steps, used by the triangle test,
+ * the ray set-up and the BSDFs in place of the compiler's IEEE division / sqrt sequences): runs BOTH on every one of the 2^32 float
+ * bit patterns on the device and counts the inputs whose results differ in any bit (two NaNs count as equal). Both counts must be 0. */
+int kz_debug_exact_math_check(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked);
 
 #ifdef __cplusplus
 }

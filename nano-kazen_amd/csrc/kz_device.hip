@@ -364,6 +364,23 @@ __global__ void kz_light_kernel(KzDevTables T, uint32_t n, const int32_t *__rest
     r[9] = ls.pdf; r[10] = ls.Ls.x; r[11] = ls.Ls.y; r[12] = ls.Ls.z; r[13] = (float)ls.tri;
 }
 
+// Exhaustive self-check of rcpExact / sqrtExact (kz_devfn.h) as compiled into THIS library: every one of the 2^32 float bit patterns,
+// against the compiler's IEEE division / square root. counts[0] rcp mismatches, [1] sqrt mismatches, [2] patterns checked.
+__global__ void kz_exact_math_kernel(unsigned long long base, unsigned long long *__restrict__ counts) {
+    const uint32_t bits = (uint32_t)(base + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x);
+    const float x = __uint_as_float(bits);
+    const float r0 = 1.0f / x, r1 = rcpExact(x);
+    const float s0 = sqrtf(x), s1 = sqrtExact(x);
+    const bool rBad = __float_as_uint(r0) != __float_as_uint(r1) && !(isnan(r0) && isnan(r1));
+    const bool sBad = __float_as_uint(s0) != __float_as_uint(s1) && !(isnan(s0) && isnan(s1));
+    const unsigned long long mr = __ballot(rBad), ms = __ballot(sBad);
+    if ((threadIdx.x & 63) == 0) {
+        if (mr) atomicAdd(&counts[0], (unsigned long long)__popcll(mr));
+        if (ms) atomicAdd(&counts[1], (unsigned long long)__popcll(ms));
+        atomicAdd(&counts[2], 64ull);
+    }
+}
+
 // ============================================================================================
 // host side: replicas (one device state per GPU the scene is resident on), upload, passes, the multi-device driver
 // ============================================================================================
@@ -565,6 +582,26 @@ int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes) {
     return KZ_OK;
 }
 
+int kz_debug_exact_math_check(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked) {
+    int n = kz_device_count();
+    if (device < 0 || device >= n) return kz_fail(n ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    DevMem dC;
+    KZ_ALLOC(&dC.p, 3 * sizeof(unsigned long long));
+    HIP_TRY(hipMemset(dC.p, 0, 3 * sizeof(unsigned long long)));
+    for (unsigned long long base = 0; base < (1ull << 32); base += (1ull << 28)) {
+        hipLaunchKernelGGL(kz_exact_math_kernel, dim3(1u << 20), dim3(256), 0, 0, base, dC.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[3];
+    HIP_TRY(hipMemcpy(h, dC.p, sizeof h, hipMemcpyDeviceToHost));
+    if (rcpMismatches) *rcpMismatches = h[0];
+    if (sqrtMismatches) *sqrtMismatches = h[1];
+    if (checked) *checked = h[2];
+    return KZ_OK;
+}
+
 int kz_scene_upload(KzScene *scene, int device) {
     if (!scene) return kz_fail(KZ_ERR_INVALID_ARG, "null scene");
     int n = 0;
@@ -758,7 +795,6 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
             c.litCap = items;
         }
     }
-    const int binRays = (tune.binRays == 2 && items < (1u << 28)) ? 1 : 0;        // the bin travels in bits 28-31 of the staged slot index
     const int maxDepth = P.maxDepth;
     c.stageUsed = 0;
     HIP_TRY(hipMemsetAsync(W.counts, 0, 8 * 520 * sizeof(uint32_t), stream));
@@ -797,7 +833,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     const uint32_t *cur = nullptr, *curCount = nullptr;
     for (int iter = 0; iter < maxDepth; ++iter) {
         uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
-#define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount, binRays)
+#define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
         if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
         else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
 #undef KZ_SHADE

@@ -215,36 +215,46 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
 // the entries that still need the light sample and the BSDF sample are compacted through LDS (record = slot + frame + uv),
 // and pass B — which carries ~85 % of the kernel's instructions — only ever runs on full waves.
 #define KZ_SV_CAP (2 * KZ_BLOCK)
-#ifndef KZ_SHADE_CLASSES
-#define KZ_SHADE_CLASSES 0          // 1: two stacks in the survivor table by BSDF class, see kz_wf_shade (measured slower: off)
-#endif
 template <bool STATS, bool EXT>
 __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
                                                         uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm,
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
-                                                        uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount, int binRays) {
-    constexpr int SVW = EXT ? 20 : 16;                       // words per survivor: slot, p, s, t, n, uv, mesh (+ dpdu)
+                                                        uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
+    constexpr int SVW = EXT ? 20 : 16;                       // words per survivor: slot, p, s, t, n, uv, bsdf row (+ dpdu)
     __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
-    // -DKZ_SHADE_CLASSES=1 (experiment, off): the survivor table holds TWO stacks - kazenstandard hits grow from entry 0 upwards, all other
-    // BSDFs from the last entry downwards - and pass B always runs on ONE class, so that the lanes of a wave walk the same BSDF code.
-    // Measured (same gpurun call, r02e): shade 29.0 -> 31.0 ms on C4, 35.2 -> 37.7 ms on C3: the partial workgroups the smaller class
-    // leaves behind cost more than the divergence between the diffuse and the kiss code did. With the default 0 everything is class 0.
-    __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svN, s_svM; __shared__ uint32_t s_bins[16];
-    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svN = 0; s_svM = 0; }
+    // The survivor table is a stack; its fill count is double-buffered by round (s_svCnt[round & 1]) so that the count for the NEXT round can
+    // be written while this round's is still being read: a round then needs two workgroup barriers (records written | records read, output
+    // entries staged) instead of six; the two output queues are flushed together, with their own barriers, only when one of them is nearly full.
+    __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svCnt[2];
+    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svCnt[0] = 0; s_svCnt[1] = 0; }
     __syncthreads();
     WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
+    // both queues: flush the one(s) that another 256 entries might not fit into (or, at the end, whatever is staged); called by every thread
+    // after a barrier that made the staged entries visible
+    auto flushBoth = [&](bool force) {
+        const uint32_t nN = s_nN, nS = s_nS;
+        const bool fN = force ? (nN > 0) : (nN > KZ_WF_QCAP - KZ_BLOCK), fS = force ? (nS > 0) : (nS > KZ_WF_QCAP - KZ_BLOCK);
+        if (fN || fS) {                                     // uniform over the workgroup
+            if (threadIdx.x == 0) { if (fN) s_gbN = atomicAdd(nextCount, nN); if (fS) s_gbS = atomicAdd(shadowCount, nS); }
+            __syncthreads();
+            if (fN) { const uint32_t gb = s_gbN; for (uint32_t i = threadIdx.x; i < nN; i += KZ_BLOCK) nextQueue[gb + i] = s_bufN[i]; }
+            if (fS) { const uint32_t gb = s_gbS; for (uint32_t i = threadIdx.x; i < nS; i += KZ_BLOCK) shadowQueue[gb + i] = s_bufS[i]; }
+            __syncthreads();
+            if (threadIdx.x == 0) { if (fN) s_nN = 0; if (fS) s_nS = 0; }      // (the next entries are staged behind the next round's first barrier)
+        }
+    };
     const uint32_t count = countPtr ? *countPtr : countImm;
     const float eps = P.traceBias;
     const int lane = threadIdx.x & 63;
     Counters cn = {0, 0, 0, 0, 0, 0};
     KZ_SST_DECL;
-    for (uint32_t base = blockIdx.x * KZ_BLOCK;; base += gridDim.x * KZ_BLOCK) {
+    uint32_t round = 0;
+    for (uint32_t base = blockIdx.x * KZ_BLOCK;; base += gridDim.x * KZ_BLOCK, ++round) {
         const bool more = base < count;                                               // uniform over the workgroup
         KZ_SST(9);
         // ================= pass A: hit record -> intersection, miss / emitter / back-face end here =================
         bool survivor = false;
-        int svClass = 0;
         uint32_t slot = 0;
         Its its;
         if (more && base + threadIdx.x < count) {
@@ -289,7 +299,6 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     bool twoSided = false;
                     if (EXT) { const int bt = T.bsdfs[its.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
                     survivor = (wz > 0.f) || twoSided || isnan(wz);
-                    if (KZ_SHADE_CLASSES && survivor) svClass = T.bsdfs[its.bsdf].type == KZ_BSDF_KAZENSTANDARD ? 0 : 1;
                     if (survivor && iter >= 3) {
                         // Russian roulette (integrator.cpp:237-244) here, in front of the compaction: a path it ends does not take a lane of
                         // pass B (at depth 3 and 4 that was 2 of 3 lanes). The survivor's scaled throughput and advanced sampler go back to
@@ -320,15 +329,13 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             }
         }
         KZ_SST(0);                                          // pass A
-        {   // compaction of the survivors into the LDS record table (class 0 from the front, class 1 from the back)
-            const unsigned long long m = __ballot(survivor && svClass == 0), m1 = __ballot(survivor && svClass != 0);
-            uint32_t b = 0, b1 = 0;
-            if (lane == 0 && m) b = atomicAdd(&s_svN, (uint32_t)__popcll(m));
-            if (lane == 0 && m1) b1 = atomicAdd(&s_svM, (uint32_t)__popcll(m1));
-            b = __shfl(b, 0, 64); b1 = __shfl(b1, 0, 64);
+        {   // compaction of the survivors onto the LDS record stack
+            const unsigned long long m = __ballot(survivor);
+            uint32_t b = 0;
+            if (lane == 0 && m) b = atomicAdd(&s_svCnt[round & 1u], (uint32_t)__popcll(m));
+            b = __shfl(b, 0, 64);
             if (survivor) {
-                const uint32_t e = svClass == 0 ? b + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))
-                                                : (uint32_t)KZ_SV_CAP - 1u - (b1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)));
+                const uint32_t e = b + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 uint32_t *r = s_sv + e;
                 r[0] = slot; r[KZ_SV_CAP] = __float_as_uint(its.p.x); r[2 * KZ_SV_CAP] = __float_as_uint(its.p.y); r[3 * KZ_SV_CAP] = __float_as_uint(its.p.z);
                 r[4 * KZ_SV_CAP] = __float_as_uint(its.sh.s.x); r[5 * KZ_SV_CAP] = __float_as_uint(its.sh.s.y); r[6 * KZ_SV_CAP] = __float_as_uint(its.sh.s.z);
@@ -341,18 +348,13 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
         __syncthreads();
         KZ_SST(1);                                          // compaction + barrier
         // ================= pass B: one survivor per thread once a full workgroup of them is waiting (or at the end) =================
-        // Before pass A the two stacks hold at most 256 entries together, pass A adds at most 256: the table (512) cannot overflow.
-        // A class with a full workgroup waiting runs; failing that, once more than 256 wait in all (or at the end), the larger class runs
-        // as it is - at least half of what waits, so at most 255 stay.
-        const uint32_t n0 = s_svN, n1 = s_svM;
+        // Before pass A at most 255 records wait, pass A adds at most 256: the table (512) cannot overflow.
+        const uint32_t n0 = s_svCnt[round & 1u];
         bool pushNext = false, pushShadow = false;
-        uint32_t binNext = 0, binShadow = 0;
-        uint32_t take = 0; int runClass = 0;
-        if (n0 >= KZ_BLOCK) { take = KZ_BLOCK; runClass = 0; }
-        else if (n1 >= KZ_BLOCK) { take = KZ_BLOCK; runClass = 1; }
-        else if (more ? (n0 + n1 > KZ_BLOCK) : (n0 + n1 > 0)) { runClass = n1 > n0 ? 1 : 0; take = runClass ? n1 : n0; }
+        const uint32_t take = n0 >= KZ_BLOCK ? (uint32_t)KZ_BLOCK : (more ? 0u : n0);
+        if (threadIdx.x == 0) s_svCnt[(round + 1u) & 1u] = n0 - take;        // what the next round's pass A appends to (visible behind the barrier below)
         if (threadIdx.x < take) {
-            const uint32_t *r = s_sv + (runClass == 0 ? (n0 - take) + threadIdx.x : (uint32_t)KZ_SV_CAP - 1u - ((n1 - take) + threadIdx.x));
+            const uint32_t *r = s_sv + (n0 - take) + threadIdx.x;
             slot = r[0];
             its.p = mk(__uint_as_float(r[KZ_SV_CAP]), __uint_as_float(r[2 * KZ_SV_CAP]), __uint_as_float(r[3 * KZ_SV_CAP]));
             its.sh.s = mk(__uint_as_float(r[4 * KZ_SV_CAP]), __uint_as_float(r[5 * KZ_SV_CAP]), __uint_as_float(r[6 * KZ_SV_CAP]));
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         W.shA[slot] = make_float4(its.p.x, its.p.y, its.p.z, dist - eps);
                         W.shB[slot] = make_float4(lwi.x, lwi.y, lwi.z, eps);
                         W.shL[slot] = make_float4(pend.x, pend.y, pend.z, 0.f);
-                        pushShadow = true; binShadow = li & 15u;
+                        pushShadow = true;
                     }
                 }
                 KZ_SST(4);                                  // eval + pdf towards the light, shadow ray stores
@@ -417,29 +419,21 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, etaNext);
                         W.misc[slot] = make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f);
                         wfStoreSampler(P, W, slot, smp);
-                        pushNext = true; binNext = wfDirBin(nd);
+                        pushNext = true;
                     }
                 }
             }
         }
         KZ_SST(7);                                          // next-ray stores (and, for lanes without a survivor, nothing)
-        __syncthreads();                                   // every record of this batch has been read
-        if (threadIdx.x == 0 && take) { if (runClass == 0) s_svN = n0 - take; else s_svM = n1 - take; }
-        if (binRays) {
-            apN.push(pushNext, slot | (binNext << 28)); apS.push(pushShadow, slot | (binShadow << 28));
-            apN.maybeFlush<true>(false, s_bins);           // (syncs: the new s_svN is visible before the next pass A)
-            apS.maybeFlush<true>(false, s_bins);
-        } else {
-            apN.push(pushNext, slot); apS.push(pushShadow, slot);
-            apN.maybeFlush(false);
-            apS.maybeFlush(false);
-        }
+        apN.push(pushNext, slot); apS.push(pushShadow, slot);
+        __syncthreads();                                   // every record of this batch has been read, the output entries are staged
+        flushBoth(false);
         KZ_SST(8);                                          // barrier + queue staging + flushes
-        if (!more && n0 + n1 - take == 0) break;
+        if (!more && n0 - take == 0) break;
         if (!more) base -= gridDim.x * KZ_BLOCK;           // stay past the end while the table drains
     }
-    if (binRays) { apN.maybeFlush<true>(true, s_bins); apS.maybeFlush<true>(true, s_bins); }
-    else { apN.maybeFlush(true); apS.maybeFlush(true); }
+    __syncthreads();
+    flushBoth(true);
     if (STATS) wfStatsFlush(W.stats, cn, 0);
 #ifdef KZ_SHADESTAT
     if (lane == 0) for (int k = 0; k < 14; ++k) atomicAdd(W.stats + 8 + k, sstAcc[k]);

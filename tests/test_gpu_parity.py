@@ -509,3 +509,14 @@ def test_light_samples_match_oracle(gpu_lib, kz, O, name):
     assert (got[:, 9] > 0).any() and (got[:, 9] == 0).any()
     z = got[:, 9] == 0
     assert (got[z, 10:13] == 0).all()
+
+
+def test_exact_reciprocal_and_sqrt_equal_ieee_for_every_float(gpu_lib, kz):
+    """rcpExact / sqrtExact (kz_devfn.h: v_rcp_f32 / v_rsq_f32 + Newton steps with a range guard) replace the compiler's IEEE division by
+    1 and sqrtf in the triangle test, the ray set-up and the BSDFs. They must not change a single bit: the library checks them against
+    the compiler's sequences on ALL 2^32 float bit patterns (~1 s on the device)."""
+    import ctypes as C
+    r, s, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    kz.abi.check(gpu_lib, gpu_lib.kz_debug_exact_math_check(0, C.byref(r), C.byref(s), C.byref(n)))
+    assert n.value == 1 << 32
+    assert r.value == 0 and s.value == 0, (r.value, s.value)
