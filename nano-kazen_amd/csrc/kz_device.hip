@@ -1225,12 +1225,12 @@ int kz_get_stats(KzScene *scene, KzStats *out, int reset) {
 #endif
 #ifdef KZ_TRACESTAT
     {
-        unsigned long long ts[8];
+        unsigned long long ts[10];
         HIP_TRY(hipMemcpy(ts, ds->stats + 8, sizeof ts, hipMemcpyDeviceToHost));
         for (int m = 0; m < 2; ++m) {
             const unsigned long long *a = ts + 4 * m; const double tot = (double)(a[0] + a[1] + a[2] + a[3]);
-            std::fprintf(stderr, "tracestat %s: refill %.2f %%  node phase %.2f %%  leaf phase (+ pop / finish) %.2f %%  loop %.2f %%\n", m ? "shadow " : "closest",
-                         tot > 0 ? 100.0 * a[0] / tot : 0.0, tot > 0 ? 100.0 * a[1] / tot : 0.0, tot > 0 ? 100.0 * a[2] / tot : 0.0, tot > 0 ? 100.0 * a[3] / tot : 0.0);
+            std::fprintf(stderr, "tracestat %s: refill %.2f %%  node phase %.2f %%  leaf phase (+ pop / finish) %.2f %% (triangle loop alone %.2f %%)  loop %.2f %%\n", m ? "shadow " : "closest",
+                         tot > 0 ? 100.0 * a[0] / tot : 0.0, tot > 0 ? 100.0 * a[1] / tot : 0.0, tot > 0 ? 100.0 * a[2] / tot : 0.0, tot > 0 ? 100.0 * ts[8 + m] / tot : 0.0, tot > 0 ? 100.0 * a[3] / tot : 0.0);
         }
         if (reset) HIP_TRY(hipMemset(ds->stats + 8, 0, sizeof ts));
     }

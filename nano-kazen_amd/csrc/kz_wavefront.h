@@ -571,7 +571,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 
 #ifdef KZ_TRACESTAT
     // development build only (-DKZ_TRACESTAT): wall-clock cycles (s_memtime, per wave) of the refill / node / leaf parts of the loop
-    unsigned long long tsT = __builtin_amdgcn_s_memtime(), tsAcc[4] = {0, 0, 0, 0};
+    unsigned long long tsT = __builtin_amdgcn_s_memtime(), tsAcc[4] = {0, 0, 0, 0}, tsTri = 0;
 #define KZ_TST(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsAcc[k] += t_ - tsT; tsT = t_; } while (0)
 #else
 #define KZ_TST(k) do { } while (0)
@@ -740,6 +740,9 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (kind == 2 && !literal) { occluded = true; break; }                // any hit blocks: nothing to add
                 if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; btri = start + i; bgid = g; tmax = t; }
             }
+#ifdef KZ_TRACESTAT
+            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsTri += t_ - tsT; }
+#endif
             if (occluded) active = false;
             else if (!popNext()) finish();
         }
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
 #ifdef KZ_TRACESTAT
-    if (lane == 0) for (int k = 0; k < 4; ++k) atomicAdd(W.stats + 8 + (MODE == 2 ? 4 : 0) + k, tsAcc[k]);
+    if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(W.stats + 8 + (MODE == 2 ? 4 : 0) + k, tsAcc[k]); atomicAdd(W.stats + 16 + (MODE == 2 ? 1 : 0), tsTri); }
 #endif
 #ifdef KZ_LANESTAT
     if (lane == 0) {
