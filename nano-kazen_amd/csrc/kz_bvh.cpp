@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <functional>
 #include <future>
 #include <limits>
 #include <array>
@@ -265,8 +266,89 @@ int kz_collapse_bvh4(const std::vector<KzNode> &nodes, uint32_t rootRef, std::ve
     struct Item { uint32_t bvh2; };
     std::vector<uint32_t> order; order.push_back(rootRef);       // BVH2 node that roots each BVH4 node, BFS
     std::vector<std::array<ChildBox, 4>> kids; std::vector<int> nk;
+    // ---- SAH-optimal collapse (dynamic programming over the BVH2, after Ylitie, Karras, Laine 2017, section 3.1, for width 4):
+    // c[n][i] = least cost of representing the subtree of BVH2 node n by at most i+1 child slots of a wide node, where a slot is a wide
+    // node (area * nodeCost + the best distribution of its subtree over 4 slots), a leaf of <= maxLeaf triangles (area * count * primCost;
+    // the triangles of a subtree are contiguous in the leaf array) or an opened BVH2 node whose two sides share the slots. The greedy rule
+    // (open the child with the largest area) is kept as KZ_BVH4_COLLAPSE=0. Only the SHAPE of the tree changes: boxes stay conservative,
+    // the triangle tests stay the reference's, so every hit is the same.
+    const size_t N = nodes.size();
+    int mode = 1; float nodeCost4 = 1.0f, primCost4 = 1.5f; uint32_t maxLeaf4 = 4;      // measured: scripts/bvh4_sweep.sh (0.3 merges too much: +11 % time; 1.0-4.0 flat)
+    if (const char *e = std::getenv("KZ_BVH4_COLLAPSE")) mode = std::atoi(e);
+    if (const char *e = std::getenv("KZ_BVH4_PRIM_COST")) { float v = (float)std::atof(e); if (v > 0.f && v < 100.f) primCost4 = v; }
+    if (const char *e = std::getenv("KZ_BVH4_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) maxLeaf4 = (uint32_t)v; }
+    struct Dp { float c[3]; float area; uint32_t start, count; uint8_t contig, leaf1, k2, k3, k4, open2, open3; };
+    std::vector<Dp> dp;
+    auto leafStart = [](uint32_t ref) { return (ref & 0x7fffffffu) >> 3; };
+    auto leafCount = [](uint32_t ref) { return (ref & 7u) + 1u; };
+    if (mode == 1) {
+        dp.resize(N);
+        const float INF = std::numeric_limits<float>::infinity();
+        for (size_t nn = N; nn-- > 0;) {                            // BFS numbering: children come after their parent
+            ChildBox cb[2]; childBoxesOf(nodes, (uint32_t)nn, cb);
+            float cc[2][3]; uint32_t st[2], ct[2]; bool cg[2];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (cb[s2].ref & 0x80000000u) {
+                    st[s2] = leafStart(cb[s2].ref); ct[s2] = leafCount(cb[s2].ref); cg[s2] = true;
+                    const float c = boxArea(cb[s2]) * (float)ct[s2] * primCost4;
+                    cc[s2][0] = cc[s2][1] = cc[s2][2] = c;
+                } else {
+                    const Dp &d = dp[cb[s2].ref];
+                    st[s2] = d.start; ct[s2] = d.count; cg[s2] = d.contig != 0;
+                    for (int i = 0; i < 3; ++i) cc[s2][i] = d.c[i];
+                }
+            }
+            Dp d; std::memset(&d, 0, sizeof d);
+            ChildBox u = cb[0];
+            for (int a = 0; a < 3; ++a) { u.lo[a] = std::min(u.lo[a], cb[1].lo[a]); u.hi[a] = std::max(u.hi[a], cb[1].hi[a]); }
+            d.area = boxArea(u);
+            d.start = std::min(st[0], st[1]); d.count = ct[0] + ct[1];
+            d.contig = (cg[0] && cg[1] && (st[0] + ct[0] == st[1] || st[1] + ct[1] == st[0])) ? 1 : 0;
+            float dist[5]; uint8_t kk[5] = {0, 0, 0, 0, 0};
+            for (int j = 2; j <= 4; ++j) {
+                dist[j] = INF;
+                for (int k = 1; k < j; ++k) {
+                    if (k > 3 || j - k > 3) continue;
+                    const float v = cc[0][k - 1] + cc[1][j - k - 1];
+                    if (v < dist[j]) { dist[j] = v; kk[j] = (uint8_t)k; }
+                }
+            }
+            const float leafC = (d.contig && d.count <= maxLeaf4) ? d.area * (float)d.count * primCost4 : INF;
+            const float innerC = d.area * nodeCost4 + dist[4];
+            d.leaf1 = leafC <= innerC ? 1 : 0;
+            d.c[0] = std::min(leafC, innerC);
+            d.open2 = dist[2] < d.c[0] ? 1 : 0; d.c[1] = std::min(dist[2], d.c[0]);
+            d.open3 = dist[3] < d.c[1] ? 1 : 0; d.c[2] = std::min(dist[3], d.c[1]);
+            d.k2 = kk[2]; d.k3 = kk[3]; d.k4 = kk[4];
+            dp[nn] = d;
+        }
+    }
+    // the slots the DP assigns to the subtree of BVH2 node n given `budget` slots (1..4; 4 only for the root of a wide node)
+    std::function<void(uint32_t, int, bool, ChildBox *, int &)> expand = [&](uint32_t nref, int budget, bool forceOpen, ChildBox *out4, int &cnt) {
+        ChildBox cb[2]; childBoxesOf(nodes, nref, cb);
+        const Dp &d = dp[nref];
+        (void)forceOpen;
+        const int k = budget == 4 ? d.k4 : (budget == 3 ? d.k3 : d.k2);
+        const int share[2] = {k, budget - k};
+        for (int s2 = 0; s2 < 2; ++s2) {
+            int b = share[s2];
+            if (cb[s2].ref & 0x80000000u) { out4[cnt++] = cb[s2]; continue; }
+            const Dp &m = dp[cb[s2].ref];
+            // the cheapest representation within b slots: opened over b, or over b-1, ..., or a single slot
+            while (b >= 2) {
+                const bool open = b == 3 ? m.open3 != 0 : m.open2 != 0;
+                if (open) break;
+                --b;
+            }
+            if (b >= 2) expand(cb[s2].ref, b, true, out4, cnt);
+            else if (m.leaf1) { ChildBox lf = cb[s2]; lf.ref = 0x80000000u | (m.start << 3) | (m.count - 1); out4[cnt++] = lf; }
+            else out4[cnt++] = cb[s2];
+        }
+    };
     for (size_t h = 0; h < order.size(); ++h) {
         ChildBox cb[4]; int n = 2;
+        if (mode == 1) { n = 0; expand(order[h], 4, true, cb, n); }
+        else {
         childBoxesOf(nodes, order[h], cb);
         while (n < 4) {
             int best = -1; float bestA = -1.f;
@@ -274,6 +356,7 @@ int kz_collapse_bvh4(const std::vector<KzNode> &nodes, uint32_t rootRef, std::ve
             if (best < 0) break;
             ChildBox two[2]; childBoxesOf(nodes, cb[best].ref, two);
             cb[best] = two[0]; cb[n++] = two[1];
+        }
         }
         std::array<ChildBox, 4> arr;
         for (int i = 0; i < 4; ++i) arr[i] = cb[i < n ? i : 0];
