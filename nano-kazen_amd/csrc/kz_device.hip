@@ -500,7 +500,7 @@ static KzTune resolveTune(const KzTuning &t) {
     auto pick = [](int a, int b, int d) { return a > 0 ? a : (b > 0 ? b : d); };
     KzTune r{};
     r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
-    r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, 8)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 0));
+    r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, KZ_TRACE_WAVES)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 0));
     r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
     r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0); r.leafQueue = pick(t.leafQueue, e.leafQueue, 0); r.binRays = pick(t.binRays, e.binRays, 0);
     r.ovf = nullptr; r.ovfStride = 0;
@@ -747,6 +747,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     // 1246 Msamples/s at 4 against 1214-1218 at 6 / 8 / 12). The EXT variant (3 resident) shows no preference on C3 and stays at 6.
     const int shadeBlocks = tune.shadeBlocksPerCU > 0 ? tune.shadeBlocksPerCU : (P.bsdfExt ? 6 : KZ_SHADE_WAVES);
     const dim3 gTrav((unsigned)(ds->numCU * tune.travBlocksPerCU)), gShade((unsigned)(ds->numCU * shadeBlocks));
+    const dim3 gPacket((unsigned)(ds->numCU * 8));                  // the packet kernel is compiled for 8 waves per SIMD whatever KZ_TRACE_WAVES is
     // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
     tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
@@ -820,7 +821,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     // camera rays: the wave-level packet traversal (kz_wf_trace_packet) unless the caller asks for the per-lane kernel
     const bool packet = traceKernel && tune.wide && tune.packet != 1 && P.stackBound4 <= 128;
     if (packet) {
-#define KZ_PACKET(ST, KY) hipLaunchKernelGGL((kz_wf_trace_packet<ST, KY>), gTrav, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8)
+#define KZ_PACKET(ST, KY) hipLaunchKernelGGL((kz_wf_trace_packet<ST, KY>), gPacket, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8)
         if (tune.keyStack != 1) { if (st) KZ_PACKET(true, true); else KZ_PACKET(false, true); }
         else { if (st) KZ_PACKET(true, false); else KZ_PACKET(false, false); }
 #undef KZ_PACKET

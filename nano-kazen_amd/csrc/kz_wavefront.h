@@ -476,8 +476,11 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_shadow(KzParams P, KzDevTables
 // a lane runs the reference's closest-hit walk-through (integrator.cpp:257-278) through this same loop ("literal" lanes).
 struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, wide, packet, keyStack, ldsTop, filmGather, leafQueue, binRays; uint32_t *ovf; uint32_t ovfStride; };
 
+#ifndef KZ_TRACE_WAVES
+#define KZ_TRACE_WAVES 8            // waves per SIMD the per-lane traversal is compiled for (64 VGPRs); 7 = 72 VGPRs measured in r02i
+#endif
 template <int MODE, bool STATS, bool WIDE, bool KEYS = false, bool TOP = false>
-__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRACE_WAVES, KZ_TRACE_WAVES))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune,
                                                         const uint32_t *__restrict__ queueB, const uint32_t *__restrict__ countPtrB) {
     extern __shared__ uint32_t s_stack[];
