@@ -857,6 +857,13 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
                                         c.litQueue, litCount);
                 KZ_TRACE(2, (const uint32_t *)c.litQueue, (const uint32_t *)litCount, 0u, litHead);      // the few rays that cross an invisible light
             }
+            else if (traceKernel && P.shadowFast && tune.wide && tune.ldsTop == 0) {
+                // any-hit kernel without the walk-through machinery; the (rare) rays whose segment crosses an invisible-light triangle go to a
+                // queue - the ping-pong path queue this bounce's shade has just consumed - and are walked through by the general kernel
+                uint32_t *litQ = W.queue[(iter & 1) ^ 1], *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
+                KZ_TRACE2(4, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, (const uint32_t *)litQ, (const uint32_t *)litCount);
+                if (P.anyInvisibleLight) KZ_TRACE(2, (const uint32_t *)litQ, (const uint32_t *)litCount, 0u, litHead);
+            }
             else if (traceKernel) KZ_TRACE(2, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3);
             else if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
             else hipLaunchKernelGGL(kz_wf_shadow<false>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
