@@ -242,7 +242,7 @@ typedef struct KzTile { int32_t x0, y0, w, h; } KzTile;
  * ABI v2 survive only as a debug override that is read ONCE, when the library is first used). */
 typedef struct KzTuning {
     int32_t refill;             /* a wave refills idle lanes once fewer than this many are busy (default 40)       */
-    int32_t postpone;           /* node phase goes on while at least this many lanes hold inner nodes (default 28)  */
+    int32_t postpone;           /* node phase goes on while at least this many lanes hold inner nodes (default 24)  */
     int32_t batch;              /* queue entries a wave reserves per global atomic (default 128)                     */
     int32_t traceBlocksPerCU;   /* 256-thread workgroups per CU of the traversal kernels (default 8)                 */
     int32_t shadeBlocksPerCU;   /* same for the shade kernel (default 4; 6 with extended BSDFs)                       */

@@ -499,7 +499,7 @@ static KzTune resolveTune(const KzTuning &t) {
     const KzTuning &e = envOverride().tune;
     auto pick = [](int a, int b, int d) { return a > 0 ? a : (b > 0 ? b : d); };
     KzTune r{};
-    r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 28); r.batch = pick(t.batch, e.batch, 128);
+    r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 24); r.batch = pick(t.batch, e.batch, 128);
     r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, KZ_TRACE_WAVES)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 0));
     r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
     r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0); r.leafQueue = pick(t.leafQueue, e.leafQueue, 0); r.binRays = pick(t.binRays, e.binRays, 0);
