@@ -383,7 +383,7 @@ int kz_collapse_bvh4(const std::vector<KzNode> &nodes, uint32_t rootRef, std::ve
             scale[a] = std::ldexp(1.0f, e);
             exps |= (uint32_t)(e + 127) << (8 * a);
         }
-        nd.exps = exps;
+        (void)exps; nd.scaleX = scale[0]; nd.scaleY = scale[1]; nd.scaleZ = scale[2];
         for (int i = 0; i < 4; ++i) {
             if (i >= n) { for (int a = 0; a < 3; ++a) { nd.qlo[a] |= 255u << (8 * i); } nd.child[i] = 0; continue; }     // qhi = 0: inverted, never hit
             nd.child[i] = cb[i].ref;

@@ -284,8 +284,7 @@ typedef float kz_f2 __attribute__((ext_vector_type(2)));
 template <bool ORDERED = true>
 __device__ __forceinline__ void node4KeysOf(const uint4 q0, const uint4 q1, const uint4 q2, V3 o, float rx, float ry, float rz, float tmin, float tmax,
                                             uint32_t (&key)[4]) {
-    const float ax = __uint_as_float((q0.w & 0xffu) << 23) * rx, ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * ry,
-                az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * rz;
+    const float ax = __uint_as_float(q0.w) * rx, ay = __uint_as_float(q2.z) * ry, az = __uint_as_float(q2.w) * rz;      // the packet carries 2^e per axis as floats
     const float bx = (__uint_as_float(q0.x) - o.x) * rx, by = (__uint_as_float(q0.y) - o.y) * ry, bz = (__uint_as_float(q0.z) - o.z) * rz;
     // The sign of the direction says which plane of a slab is entered first: pick the packed near / far words for all four
     // children at once (rcp is finite and non-zero here, see the caller), so each child needs only 6 cvt + 3 packed fma (the

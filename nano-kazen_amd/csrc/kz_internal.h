@@ -22,12 +22,12 @@ static_assert(sizeof(KzNode) == 64, "node packet must be 64 B");
 // kz_trace_rays keep the BVH2): one packet fetch tests FOUR children, which halves both the number of per-lane 16-B
 // gathers and the length of the dependent-load chain (and, per ray, the instructions spent on loop control and stack traffic:
 // the traversal is VALU-issue-bound on MI355X).
-//   q0 = p.x p.y p.z | ex,ey,ez (biased float exponents, one byte each)   child box = p + q * 2^(e-127)
+//   q0 = p.x p.y p.z | 2^ex (float)                                        child box = p + q * 2^e per axis
 //   q1 = qlo.x[4] qlo.y[4] qlo.z[4] qhi.x[4]   (4 x u8 per word, child i in byte i)
-//   q2 = qhi.y[4] qhi.z[4] - -
+//   q2 = qhi.y[4] qhi.z[4] | 2^ey 2^ez (floats)
 //   q3 = child[4] (same encoding as KzNode::child; an empty slot has qlo = 255, qhi = 0)
 // Quantisation rounds outward against the SAME float expression the kernel evaluates, so the boxes stay conservative.
-struct KzNode4 { float p[3]; uint32_t exps; uint32_t qlo[3]; uint32_t qhi[3]; uint32_t pad[2]; uint32_t child[4]; };
+struct KzNode4 { float p[3]; float scaleX; uint32_t qlo[3]; uint32_t qhi[3]; float scaleY, scaleZ; uint32_t child[4]; };      // scale = 2^e per axis, as floats (the node step multiplies them by 1/d: no exponent unpacking)
 static_assert(sizeof(KzNode4) == 64, "BVH4 packet must be 64 B");
 
 // Leaf triangle in Moeller-Trumbore form, 48 B, three quads: p0.xyz e1.x | e1.y e1.z e2.x e2.y | e2.z mesh prim gid
