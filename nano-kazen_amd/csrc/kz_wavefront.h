@@ -94,9 +94,20 @@ __device__ __forceinline__ void wfStatsFlush(unsigned long long *stats, const Co
     }
 }
 
-__device__ __forceinline__ void wfLoadSampler(const KzParams &P, const KzWf &W, uint32_t slot, int px, int py, uint32_t sampleIndex, Sampler &s) {
-    const uint4 v = W.smp[slot];
+// dimPmj: the dimension counter of a pmj02bn path at this point of this bounce (wfPmjDim). That sampler has no other state, so its paths
+// neither load nor store a sampler record (16 B each way per shaded hit).
+__device__ __forceinline__ uint32_t wfPmjDim(const KzParams &P, int iter) {
+    // generate leaves the counter at 4 (max(2, 0), then the aperture's 2-D draw); bounce j draws the roulette sample (j >= 3), the light pick,
+    // three light-sample dimensions when there are lights, and 2 + 1 for the BSDF sample
+    return 4u + (uint32_t)iter * (4u + (P.nLights > 0 ? 3u : 0u)) + (iter > 3 ? (uint32_t)(iter - 3) : 0u);
+}
+__device__ __forceinline__ void wfLoadSampler(const KzParams &P, const KzWf &W, uint32_t slot, int px, int py, uint32_t sampleIndex, Sampler &s, uint32_t dimPmj) {
     s.type = P.samplerType; s.px = px; s.py = py; s.idx = sampleIndex;
+    if (P.samplerType == KZ_SAMPLER_PMJ02BN) {
+        s.state = 0ull; s.inc = 0ull; s.dim = dimPmj; s.hp = hashPixelBlock(px, py);
+        return;
+    }
+    const uint4 v = W.smp[slot];
     s.state = (uint64_t)v.x | ((uint64_t)v.y << 32);
     // Every path of one shade launch is at the same depth and has drawn the same number of dimensions (the draws of a bounce do not depend on
     // the path: roulette from depth 3, pick, 3 light draws when there are lights, 2-D + 1-D for the BSDF), so the dimension counter is
@@ -108,8 +119,8 @@ __device__ __forceinline__ void wfLoadSampler(const KzParams &P, const KzWf &W, 
 }
 __device__ __forceinline__ void wfStoreSampler(const KzParams &P, const KzWf &W, uint32_t slot, const Sampler &s) {
     uint4 v;
+    if (P.samplerType == KZ_SAMPLER_PMJ02BN) return;                // (the dimension counter is a function of the bounce: wfPmjDim)
     v.x = (uint32_t)s.state; v.y = (uint32_t)(s.state >> 32); v.z = s.dim; v.w = 0;
-    (void)P;
     W.smp[slot] = v;
 }
 
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         // pass B (at depth 3 and 4 that was 2 of 3 lanes). The survivor's scaled throughput and advanced sampler go back to
                         // the path state, where pass B reads them.
                         const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
-                        Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
+                        Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
                         const float4 th = W.thr[slot];
                         V3 throughput = mk(th.x, th.y, th.z);
                         const float probability = fminf(maxCoeff(throughput) * th.w * th.w, 0.95f);
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         bool alive = true;
                         if (iter >= 3) {
                             const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
-                            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
+                            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
                             const float4 th = W.thr[slot];
                             if (fminf(maxCoeff(mk(th.x, th.y, th.z)) * th.w * th.w, 0.95f) <= smp.next1D(P, T)) alive = false;
                         }
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             float accRough = mi.y;
             const uint32_t pl = slot / S;
             const uint32_t pxy = pixList[pl];
-            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp);
+            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter) + (iter >= 3 ? 1u : 0u));
             {                                                                         // (the roulette of integrator.cpp:237-244 was played in pass A)
                 KzBSDF bsdf = T.bsdfs[its.bsdf];
                 NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
