@@ -1099,10 +1099,14 @@ __device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, floa
     uint32_t lo = 0;
     if (n <= 7u && v < 1.0f) {
         // Light meshes are mostly a quad or a few triangles. The table is non-decreasing up to its last entry, which is 1 (dpdf.h:85-88) and never
-        // below a sample < 1, so the first element >= v is the NUMBER of elements < v: eight independent loads (the table is padded) instead of
-        // the binary search's chain of dependent ones.
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) { const float e = cdf[k]; lo += (k <= n && e < v) ? 1u : 0u; }
+        // below a sample < 1, so the first element >= v is the NUMBER of elements < v: no chain of dependent loads.
+        // (a table starts on a 16-B boundary and the array is padded: one or two float4 loads)
+        const float4 c0 = reinterpret_cast<const float4 *>(cdf)[0];
+        lo = (c0.x < v ? 1u : 0u) + ((1u <= n && c0.y < v) ? 1u : 0u) + ((2u <= n && c0.z < v) ? 1u : 0u) + ((3u <= n && c0.w < v) ? 1u : 0u);
+        if (n > 3u) {
+            const float4 c1 = reinterpret_cast<const float4 *>(cdf)[1];
+            lo += (c1.x < v ? 1u : 0u) + ((5u <= n && c1.y < v) ? 1u : 0u) + ((6u <= n && c1.z < v) ? 1u : 0u) + ((7u <= n && c1.w < v) ? 1u : 0u);
+        }
     } else {
         uint32_t len = n + 1;
         while (len > 0) {

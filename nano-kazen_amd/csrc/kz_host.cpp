@@ -236,6 +236,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
             KzLightRow lr; std::memset(&lr, 0, sizeof lr);
             for (int a = 0; a < 3; ++a) lr.radiance[a] = kl.intensity * kl.color[a];
             lr.primaryVisibility = kl.primaryVisibility ? 1 : 0;
+            while (sc->cdf.size() & 3u) sc->cdf.push_back(2.0f);            // every light's table starts on a 16-B boundary (cdfSample reads short tables as float4s)
             lr.mesh = m; lr.triOffset = row.triOffset; lr.nF = km.nF; lr.cdfOffset = (uint32_t)sc->cdf.size(); lr.hasN = km.N ? 1u : 0u;
             size_t base = sc->cdf.size();
             sc->cdf.push_back(0.0f);
