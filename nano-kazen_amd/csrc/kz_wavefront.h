@@ -29,7 +29,7 @@
 struct KzWf {
     float4 *rayA, *rayB;           // o.xyz tmin | d.xyz tmax
     float4 *hit;                   // t u v gid(bits) - the shading record of the triangle; t = +inf: miss
-    float4 *thr;                   // throughput.xyz eta
+    float4 *thr;                   // throughput.xyz eta (compact state, see kz_wf_shade: throughput.xyz bsdfPdf)
     float4 *misc;                  // bsdfPdf accumulatedRoughness discrete(EDiscrete) -
     uint4 *smp;                    // pcg32 state (.x,.y) + dimension index (.z); the pcg32 stream id is recomputed from the pixel
     float4 *shA, *shB, *shL;       // shadow (or walk-through) ray o.xyz tmax | d.xyz tmin | pending radiance
@@ -258,6 +258,10 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
     const uint32_t count = countPtr ? *countPtr : countImm;
     const float eps = P.traceBias;
     const int lane = threadIdx.x & 63;
+    // Path state between bounces. The lean variant has no BSDF that changes eta or samples a discrete lobe, and without regularisation the
+    // accumulated roughness stays 0: the only thing `misc` would carry is the pdf of the sampled direction, which then rides in the free fourth
+    // word of the throughput record (16 B less to write and to read back per bounce and path; the state arrays are the kernel's HBM traffic).
+    const bool compact = !EXT && !P.regularization;
     Counters cn = {0, 0, 0, 0, 0, 0};
     KZ_SST_DECL;
     uint32_t round = 0;
@@ -293,7 +297,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                 if (its.light >= 0) {                                                         // integrator.cpp:226-231, 322-327
                     const KzLightRow &lr = T.lights[its.light];
                     const float4 ra = W.rayA[slot];
-                    const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot], mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : W.misc[slot];
+                    const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot];
+                    const float4 mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : (compact ? make_float4(th.w, 0.f, 0.f, 0.f) : W.misc[slot]);
                     const V3 ro = mk(ra.x, ra.y, ra.z);
                     const V3 wi = normalized(its.p - ro);
                     float bsdfWeight = 1.f;
@@ -318,7 +323,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
                         const float4 th = W.thr[slot];
                         V3 throughput = mk(th.x, th.y, th.z);
-                        const float probability = fminf(maxCoeff(throughput) * th.w * th.w, 0.95f);
+                        const float etaA = compact ? 1.f : th.w;
+                        const float probability = fminf(maxCoeff(throughput) * etaA * etaA, 0.95f);
                         if (probability <= smp.next1D(P, T)) survivor = false;
                         else {
                             throughput = throughput / probability;
@@ -332,7 +338,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                             const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
                             Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
                             const float4 th = W.thr[slot];
-                            if (fminf(maxCoeff(mk(th.x, th.y, th.z)) * th.w * th.w, 0.95f) <= smp.next1D(P, T)) alive = false;
+                            const float etaA = compact ? 1.f : th.w;
+                            if (fminf(maxCoeff(mk(th.x, th.y, th.z)) * etaA * etaA, 0.95f) <= smp.next1D(P, T)) alive = false;
                         }
                         if (alive) cn.lsamples++;
                     }
@@ -377,9 +384,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             const V3 rd = mk(rb.x, rb.y, rb.z);
             float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot];              // a camera path: generate stores neither (initial values)
             V3 throughput = mk(th.x, th.y, th.z);
-            const float eta = th.w;
-            const float4 mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : W.misc[slot];
-            float accRough = mi.y;
+            const float eta = compact ? 1.f : th.w;
+            float accRough = (iter == 0 || compact) ? 0.f : W.misc[slot].y;
             const uint32_t pl = slot / S;
             const uint32_t pxy = pixList[pl];
             Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter) + (iter >= 3 ? 1u : 0u));
@@ -427,8 +433,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     if (iter + 1 < P.maxDepth || P.bgPresent) {
                         W.rayA[slot] = make_float4(its.p.x, its.p.y, its.p.z, eps);
                         W.rayB[slot] = make_float4(nd.x, nd.y, nd.z, KZ_INF);
-                        W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, etaNext);
-                        W.misc[slot] = make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f);
+                        W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, compact ? bpdf : etaNext);
+                        if (!compact) W.misc[slot] = make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f);
                         wfStoreSampler(P, W, slot, smp);
                         pushNext = true;
                     }
