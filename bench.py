@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
     args = ap.parse_args()
+    commit = os.environ.get("GRAFT_HEAD") or git_head()          # before torch / HIP are loaded: no fork from a process that has initialised the GPU
 
     # stdout carries ONE line, the JSON record: everything else that may write to file descriptor 1 (gloo's "[Gloo] Rank ... is
     # connected" banner comes from C++ and lands on stdout) is sent to stderr; the record goes to the saved descriptor.
@@ -153,6 +154,9 @@ def main():
             scene.render(0, s1 - SPP, tiles=tiles, accumulate=True, stream=stream, **kw)
 
     def barrier():
+        # device first, then the ranks, then the device again: a rank must not start (or stop) its clock while its own earlier kernels still
+        # run (with one rank per GPU the order is immaterial; with several ranks rehearsing on ONE GPU it is not: profiles/r03b_multiprocess)
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -268,7 +272,7 @@ def main():
                                       "%dx%d tiles dealt by area over ranks, host film gather"
                                       % (args.tris, W, H, SPP, spp_step, info["passes"], info["passesInFlight"], TILE, TILE),
                           "samples_per_step": int(float(px.item()) * spp_step), "bvh_nodes": bvh["nNodes"], "bvh_depth": bvh["maxDepth"],
-                          "film_merge_s": round(merge_s, 4), "image_mean": round(float(rgb.mean()), 5), "commit": git_head()},
+                          "film_merge_s": round(merge_s, 4), "image_mean": round(float(rgb.mean()), 5), "commit": commit},
                "roofline": roofline, "cpu_baseline": cpu}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -237,9 +237,11 @@ typedef struct KzSceneDesc {
  * reference's 32x32 KAZEN_BLOCK_SIZE, include/kazen/block.h:8, are natural). */
 typedef struct KzTile { int32_t x0, y0, w, h; } KzTile;
 
-/* Knobs of the persistent kernels. Zero = the library default, which is what the measured numbers use;
- * they are part of the ABI so that nothing behind it depends on process-global state (the KZ_* environment variables of
- * ABI v2 survive only as a debug override that is read ONCE, when the library is first used). */
+/* Knobs of the persistent kernels. Zero = the library default, which is what the measured numbers use. They are part
+ * of the ABI so that nothing behind it depends on process-global state: the library reads no environment variable.
+ * Fields marked [experiment] select a kernel of a rejected experiment (nano-kazen_amd/csrc/kz_experiments.h); only a library built
+ * with -DKZ_EXPERIMENTS (kz_build_flags() & KZ_BUILD_EXPERIMENTS) contains those kernels, the default library answers a non-zero
+ * value with KZ_ERR_UNSUPPORTED. */
 typedef struct KzTuning {
     int32_t refill;             /* a wave refills idle lanes once fewer than this many are busy (default 40)       */
     int32_t postpone;           /* node phase goes on while at least this many lanes hold inner nodes (default 24)  */
@@ -247,20 +249,20 @@ typedef struct KzTuning {
     int32_t traceBlocksPerCU;   /* 256-thread workgroups per CU of the traversal kernels (default 8)                 */
     int32_t shadeBlocksPerCU;   /* same for the shade kernel (default 4; 6 with extended BSDFs)                       */
     int32_t ldsStack;           /* per-lane traversal stack entries kept in LDS before the global overflow (default 16) */
-    int32_t bvh2;               /* 1 = traverse the BVH2 instead of the quantised BVH4 (default 0)                    */
+    int32_t bvh2;               /* [experiment] 1 = per-lane traversal of the BVH2 instead of the quantised BVH4       */
     int32_t packetPrimary;      /* primary rays: 0 = default (shared-stack packet traversal), 1 = per-lane, 2 = packet */
-    int32_t keyStack;           /* stack entries carry their box entry distance and are culled at pop time: 0 = default (packet kernel only),
-                                   1 = off, 2 = also in the per-lane closest-hit kernel (measured slower on C4) */
-    int32_t ldsTop;             /* BVH4 packets of the top of the tree (breadth-first prefix) staged in LDS by the per-lane traversal
-                                   kernels: 0 = default (off: measured no gain on C4, profiles/r02c_lds_top), n = that many (<= 1536) */
+    int32_t keyStack;           /* [experiment] 1 = packet kernel without per-lane entry distances, 2 = per-lane kernel with them */
+    int32_t ldsTop;             /* [experiment] n = that many BVH4 packets of the top of the tree staged in LDS (<= 1536) */
     int32_t filmGather;         /* film reconstruction: 0 = default (per-pixel tap sums + apply for filters of <= 5 taps per axis, the staged
                                    gather otherwise), 1 = always the staged gather kernel of round 1 */
-    int32_t leafQueue;          /* bounce / shadow traversal with a decoupled leaf phase (kz_wf_trace_dq: per-wave job queue in LDS): 0 = default,
-                                   1 = off, 2 = on */
-    int32_t binRays;            /* accepted and ignored since round 2: the experiment it selected (shade ordering each staged window of its
-                                   output queues by direction octant / light index) lost 3-17 % per stage and its code is gone; the field
-                                   keeps the layout */
-    int32_t reserved[3];
+    int32_t leafQueue;          /* [experiment] 2 = bounce / shadow traversal with a decoupled leaf phase (kz_wf_trace_dq) */
+    int32_t sppPerPass;         /* samples of a pixel per pass: 0 = default. A pass covers pixPerPass x sppPerPass = passItems (pixel, sample)
+                                   items: sppPerPass = 0 means "every pixel of the tile set, as many samples as fit"; n > 0 means n samples
+                                   (or all the call asks for, if fewer) of as many pixels as fit, pixel chunks in tile order           */
+    int32_t legacyTrace;        /* [experiment] 1 = the non-persistent round-1 traversal launches (kz_wf_extend / kz_wf_shadow) */
+    int32_t mixedLaunch;        /* [experiment] 1 = one launch for the shadow rays of a bounce and the closest-hit rays of the next */
+    int32_t streamPriority;     /* HIP priorities of the internal pass streams: 0 = default, 1 = all at the default priority, 2 = alternating
+                                   least / greatest, 3 = cycling least / default / greatest */
 } KzTuning;
 
 typedef struct KzRenderOpts {
@@ -273,12 +275,14 @@ typedef struct KzRenderOpts {
     void *stream;               /* hipStream_t to launch on (NULL = the null stream)                     */
     /* ---- ABI v3 (all zero = defaults) ---- */
     int32_t device;             /* the replica to render on: a HIP device index kz_scene_upload was called with */
-    int32_t passesInFlight;     /* 0 = default (2: two passes kept in flight on two internal streams), 1 = one   */
+    int32_t passesInFlight;     /* passes kept in flight on internal streams: 0 = default (KZ_DEFAULT_PASSES_IN_FLIGHT), 1 .. 8 */
     uint64_t passItems;         /* (pixel, sample) items per pass; 0 = default 2^27, lowered to fit maxStateBytes */
-    uint64_t maxStateBytes;     /* cap on this replica's path state + sample records; 0 = min(half of the device's
+    uint64_t maxStateBytes;     /* cap on this replica's path state + sample records + film tap sums; 0 = min(3/4 of the device's
                                    memory, what is free + what the replica already holds for this purpose)       */
     KzTuning tune;
 } KzRenderOpts;
+#define KZ_MAX_PASSES_IN_FLIGHT 8
+#define KZ_DEFAULT_PASSES_IN_FLIGHT 2
 
 /* Counters the kernels keep (all optional; zero unless requested with kz_set_stats). */
 typedef struct KzStats {
@@ -414,7 +418,8 @@ int kz_last_kernel_ms(KzScene *scene, float *ms);
 int kz_last_stage_ms(KzScene *scene, float *out5);
 
 /* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass, passes in flight. */
-typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes; } KzPassInfo;
+typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes;
+                            uint32_t pixelsPerPass; uint32_t reserved; } KzPassInfo;
 int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
 
 /* Test hook: the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off). Used by
@@ -423,6 +428,9 @@ void kz_debug_fail_alloc(int nth);
 
 const char *kz_last_error(void);
 int kz_abi_version(void);
+/* How the library was built: bit 0 (KZ_BUILD_EXPERIMENTS) = it contains the kernels of kz_experiments.h. */
+#define KZ_BUILD_EXPERIMENTS 1
+int kz_build_flags(void);
 int kz_device_count(void);
 /* hipMemGetInfo of `device` (what the default state budget of kz_render is derived from). */
 int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes);

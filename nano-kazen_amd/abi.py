@@ -100,7 +100,8 @@ class KzTile(C.Structure):
 class KzTuning(C.Structure):
     _fields_ = [("refill", C.c_int32), ("postpone", C.c_int32), ("batch", C.c_int32), ("traceBlocksPerCU", C.c_int32),
                 ("shadeBlocksPerCU", C.c_int32), ("ldsStack", C.c_int32), ("bvh2", C.c_int32), ("packetPrimary", C.c_int32),
-                ("keyStack", C.c_int32), ("ldsTop", C.c_int32), ("filmGather", C.c_int32), ("leafQueue", C.c_int32), ("binRays", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("keyStack", C.c_int32), ("ldsTop", C.c_int32), ("filmGather", C.c_int32), ("leafQueue", C.c_int32), ("sppPerPass", C.c_int32), ("legacyTrace", C.c_int32),
+                ("mixedLaunch", C.c_int32), ("streamPriority", C.c_int32)]
 
 
 class KzRenderOpts(C.Structure):
@@ -112,7 +113,7 @@ class KzRenderOpts(C.Structure):
 
 class KzPassInfo(C.Structure):
     _fields_ = [("passes", C.c_uint32), ("passesInFlight", C.c_uint32), ("itemsPerPass", C.c_uint64), ("sppPerPass", C.c_uint32),
-                ("pixels", C.c_uint32), ("stateBytes", C.c_uint64)]
+                ("pixels", C.c_uint32), ("stateBytes", C.c_uint64), ("pixelsPerPass", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -143,7 +144,7 @@ EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
            "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8",
            "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
-           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check"]
+           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check", "kz_build_flags"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KZ_LIB_PATH: a development build of the library (scripts/build_variant.sh) instead of the in-tree one; probes only

@@ -166,8 +166,10 @@ int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, 
     nodes.clear(); tris.clear();
     rootRef = 0xFFFFFFFFu;     // empty scene
     Ctx cx;
+#ifdef KZ_EXPERIMENTS      // builder parameter sweeps (scripts/bvh_sweep.sh) of a development build; the product library reads no environment variable
     if (const char *e = std::getenv("KZ_BVH_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= KZ_MAX_LEAF) cx.maxLeaf = (uint32_t)v; }
     if (const char *e = std::getenv("KZ_BVH_NODE_COST")) { float v = (float)std::atof(e); if (v >= 0.f && v < 100.f) cx.nodeCost = v; }
+#endif
     cx.refs.reserve(in.size());
     for (uint32_t i = 0; i < in.size(); ++i) {
         const KzBuildTri &t = in[i];
@@ -274,9 +276,11 @@ int kz_collapse_bvh4(const std::vector<KzNode> &nodes, uint32_t rootRef, std::ve
     // the triangle tests stay the reference's, so every hit is the same.
     const size_t N = nodes.size();
     int mode = 1; float nodeCost4 = 1.0f, primCost4 = 1.5f; uint32_t maxLeaf4 = 4;      // measured: scripts/bvh4_sweep.sh (0.3 merges too much: +11 % time; 1.0-4.0 flat)
+#ifdef KZ_EXPERIMENTS      // scripts/bvh4_sweep.sh, development build only
     if (const char *e = std::getenv("KZ_BVH4_COLLAPSE")) mode = std::atoi(e);
     if (const char *e = std::getenv("KZ_BVH4_PRIM_COST")) { float v = (float)std::atof(e); if (v > 0.f && v < 100.f) primCost4 = v; }
     if (const char *e = std::getenv("KZ_BVH4_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) maxLeaf4 = (uint32_t)v; }
+#endif
     struct Dp { float c[3]; float area; uint32_t start, count; uint8_t contig, leaf1, k2, k3, k4, open2, open3; };
     std::vector<Dp> dp;
     auto leafStart = [](uint32_t ref) { return (ref & 0x7fffffffu) >> 3; };

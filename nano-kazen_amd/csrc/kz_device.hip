@@ -13,6 +13,9 @@
 #include "kz_internal.h"
 #include "kz_devfn.h"
 #include "kz_wavefront.h"
+#ifdef KZ_EXPERIMENTS
+#include "kz_experiments.h"
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDev
 // is left with five LDS reads and the multiply-adds of block.cpp:84. A sample that is invalid, absent or out of bounds carries
 // weight 0 and adds an exact zero, so the sums are the ones the reference forms.
 __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *__restrict__ filter, const int32_t *__restrict__ pixIndex,
-                                                      uint32_t S, int chunk, const float *__restrict__ inJx, const float *__restrict__ inJy,
+                                                      uint32_t p0, uint32_t nPixPass, uint32_t S, int chunk, const float *__restrict__ inJx, const float *__restrict__ inJy,
                                                       const float *__restrict__ inR, const float *__restrict__ inG, const float *__restrict__ inB,
                                                       float4 *__restrict__ film) {
     __shared__ float s_filter[KZ_FILTER_RESOLUTION + 1];
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *_
         const int x = sx0 + q % R, y = sy0 + q / R;
         int pl = -1;
         if (x >= 0 && x < P.width && y >= 0 && y < P.height) pl = pixIndex[y * P.width + x];
+        if (pl >= 0) { pl -= (int)p0; if (pl < 0 || pl >= (int)nPixPass) pl = -1; }       // a pass covers pixels [p0, p0 + nPixPass) of the pixel list
         s_pl[q] = pl;
         anySrc |= pl >= 0;
     }
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(64) void kz_film_taps(KzParams P, const float *__re
     }
 }
 
-__global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *__restrict__ pixIndex, const float4 *__restrict__ tapSums, uint32_t nPix, float4 *__restrict__ film) {
+__global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *__restrict__ pixIndex, const float4 *__restrict__ tapSums, uint32_t p0, uint32_t nPix, float4 *__restrict__ film) {
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border;
     const int fx = blockIdx.x * 16 + (threadIdx.x & 15), fy = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (fx >= cols || fy >= rows) return;
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *
         for (int tx = 0; tx < taps; ++tx) {
             const int x = fx - P.border + P.tapLo + tx;
             if (x < 0 || x >= P.width) continue;
-            const int32_t pl = pixIndex[y * P.width + x];
-            if (pl < 0) continue;
+            const int32_t pl = pixIndex[y * P.width + x] - (int32_t)p0;      // the pass covers pixels [p0, p0 + nPix) of the pixel list
+            if (pl < 0 || pl >= (int32_t)nPix) continue;
             const float4 t = tapSums[(size_t)(ty * taps + tx) * nPix + (size_t)pl];
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             any = true;
@@ -434,10 +438,11 @@ struct KzDeviceState {
     unsigned long long *stats = nullptr; bool statsOn = false;
     hipStream_t lastStream = nullptr;
     int numCU = 256; size_t totalMem = 0;
-    PassCtx ctx[2];
+    PassCtx ctx[KZ_MAX_PASSES_IN_FLIGHT];
     std::vector<EventPair> events; size_t eventsUsed = 0;
-    hipStream_t passStream[2] = {nullptr, nullptr}; hipEvent_t evFork = nullptr, evFilm[2] = {nullptr, nullptr}, evCallA = nullptr, evCallB = nullptr;
-    int lastCtx = 0; bool lastDual = false;
+    hipStream_t passStream[KZ_MAX_PASSES_IN_FLIGHT] = {}; hipEvent_t evFork = nullptr, evFilm[KZ_MAX_PASSES_IN_FLIGHT] = {}, evCallA = nullptr, evCallB = nullptr;
+    int lastCtx = 0; bool lastDual = false; int streamMode = 0;
+    size_t ctxBytes() const { size_t b = 0; for (const PassCtx &c : ctx) b += c.bytes(); return b; }
     KzPassInfo lastInfo{};
 };
 struct KzReplicaSet { std::mutex m; std::vector<KzDeviceState *> v; };
@@ -464,7 +469,8 @@ static void releaseReplica(KzDeviceState *ds) {
     for (auto &c : ds->ctx) { c.release(); for (auto &e : c.stageEv) (void)hipEventDestroy(e); }
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipStream_t st : ds->passStream) if (st) (void)hipStreamDestroy(st);
-    for (hipEvent_t e : {ds->evFork, ds->evFilm[0], ds->evFilm[1], ds->evCallA, ds->evCallB}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ds->evFilm) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ds->evFork, ds->evCallA, ds->evCallB}) if (e) (void)hipEventDestroy(e);
     delete ds;
 }
 
@@ -478,33 +484,25 @@ void kz_device_release(KzScene *scene) {
     scene->dev = nullptr;
 }
 
-// The KZ_* environment variables of ABI v2, kept as a debug override: read once per process, applied only where the caller's
-// KzRenderOpts leaves a field at 0.
-struct EnvOverride { KzTuning tune{}; uint64_t passItems = 0; int passesInFlight = 0, pipeline = 0, traceKernel = 1, mixed = 0; };
-static const EnvOverride &envOverride() {
-    static const EnvOverride eo = [] {
-        EnvOverride o;
-        auto I = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
-        o.tune.refill = I("KZ_TUNE_REFILL", 0); o.tune.postpone = I("KZ_TUNE_POSTPONE", 0); o.tune.batch = I("KZ_TUNE_BATCH", 0);
-        o.tune.traceBlocksPerCU = I("KZ_TUNE_TRAV_BLOCKS", 0); o.tune.shadeBlocksPerCU = I("KZ_TUNE_SHADE_BLOCKS", 0);
-        o.tune.ldsStack = I("KZ_TUNE_LDS_STACK", 0); o.tune.bvh2 = I("KZ_TUNE_WIDE", 1) ? 0 : 1; o.tune.packetPrimary = I("KZ_TUNE_PACKET", 0); o.tune.keyStack = I("KZ_TUNE_KEYSTACK", 0); o.tune.ldsTop = I("KZ_TUNE_LDS_TOP", 0); o.tune.filmGather = I("KZ_TUNE_FILM_GATHER", 0); o.tune.leafQueue = I("KZ_TUNE_LEAF_QUEUE", 0); o.tune.binRays = I("KZ_TUNE_BIN_RAYS", 0);
-        if (const char *e = std::getenv("KZ_PASS_ITEMS")) { long long v = std::atoll(e); if (v >= 1024) o.passItems = (uint64_t)v; }
-        if (const char *e = std::getenv("KZ_DUAL_STREAM")) o.passesInFlight = std::atoi(e) ? 2 : 1;
-        o.pipeline = I("KZ_PIPELINE", 0); o.traceKernel = I("KZ_TRACE_KERNEL", 1); o.mixed = I("KZ_TUNE_MIXED", 0);
-        return o;
-    }();
-    return eo;
-}
-static KzTune resolveTune(const KzTuning &t) {
-    const KzTuning &e = envOverride().tune;
-    auto pick = [](int a, int b, int d) { return a > 0 ? a : (b > 0 ? b : d); };
-    KzTune r{};
-    r.refill = pick(t.refill, e.refill, 40); r.postpone = pick(t.postpone, e.postpone, 24); r.batch = pick(t.batch, e.batch, 128);
-    r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, e.traceBlocksPerCU, KZ_TRACE_WAVES)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, e.shadeBlocksPerCU, 0));
-    r.ldsStack = pick(t.ldsStack, e.ldsStack, 16); r.wide = (t.bvh2 || e.bvh2) ? 0 : 1;
-    r.packet = pick(t.packetPrimary, e.packetPrimary, 0); r.keyStack = pick(t.keyStack, e.keyStack, 0); r.ldsTop = pick(t.ldsTop, e.ldsTop, 0); r.filmGather = pick(t.filmGather, e.filmGather, 0); r.leafQueue = pick(t.leafQueue, e.leafQueue, 0); r.binRays = pick(t.binRays, e.binRays, 0);
+// KzTuning -> the kernels' KzTune. Zero = the library default. (The KZ_* environment overrides of ABI v2 / v3 are gone: nothing in the
+// library reads the environment.) Fields that select a kernel of kz_experiments.h are honoured only by a -DKZ_EXPERIMENTS build; the
+// default library refuses them loudly instead of ignoring them.
+static int resolveTune(const KzTuning &t, KzTune &r) {
+    auto pick = [](int a, int d) { return a > 0 ? a : d; };
+    r = KzTune{};
+    r.refill = pick(t.refill, 40); r.postpone = pick(t.postpone, 24); r.batch = pick(t.batch, 128);
+    r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, KZ_TRACE_WAVES)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, 0));
+    r.ldsStack = pick(t.ldsStack, 16);
+    r.packet = pick(t.packetPrimary, 0); r.filmGather = pick(t.filmGather, 0);
+    r.wide = t.bvh2 ? 0 : 1; r.keyStack = pick(t.keyStack, 0); r.ldsTop = pick(t.ldsTop, 0); r.leafQueue = pick(t.leafQueue, 0);
+    r.legacyTrace = pick(t.legacyTrace, 0); r.mixed = pick(t.mixedLaunch, 0);
+#ifndef KZ_EXPERIMENTS
+    if (t.bvh2 || t.keyStack > 0 || t.ldsTop > 0 || t.leafQueue > 1 || t.legacyTrace > 0 || t.mixedLaunch > 0)
+        return kz_fail(KZ_ERR_UNSUPPORTED, "KzTuning.bvh2 / keyStack / ldsTop / leafQueue / legacyTrace / mixedLaunch select kernels of rejected experiments: "
+                                           "this library was built without -DKZ_EXPERIMENTS (kz_build_flags)");
+#endif
     r.ovf = nullptr; r.ovfStride = 0;
-    return r;
+    return KZ_OK;
 }
 
 static int findReplica(const KzScene *scene, int device, KzDeviceState **out) {
@@ -700,14 +698,15 @@ static int stageMark(PassCtx &c, hipStream_t stream, int kind) {
 // Path state per (pixel, sample) item of a pass in flight: 8 float4 + uint4 + 3 queue words (wavefront) + 5 sample floats.
 static constexpr size_t KZ_STATE_BYTES_PER_ITEM = 8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t);
 static constexpr size_t KZ_SAMPLE_BYTES_PER_ITEM = 5 * sizeof(float);
+static constexpr size_t KZ_TAP_BYTES_PER_PIXEL = (size_t)KZ_TAPS_MAX * KZ_TAPS_MAX * sizeof(float4);
 
-// ---- buffers of one pass context: sized for `need` items; nothing is left half-allocated on failure ----
-static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, hipStream_t stream) {
-    if (nPix > c.tapsCap) {
+// ---- buffers of one pass context: sized for `need` items of `nPix` pixels; nothing is left half-allocated on failure ----
+static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool tapSums, hipStream_t stream) {
+    if (tapSums && nPix > c.tapsCap) {                               // (only the tap-sum film path has this buffer)
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.taps) (void)hipFree(c.taps);
         c.taps = nullptr; c.tapsCap = 0;
-        KZ_ALLOC(&c.taps, nPix * (size_t)(KZ_TAPS_MAX * KZ_TAPS_MAX * 16));
+        KZ_ALLOC(&c.taps, nPix * KZ_TAP_BYTES_PER_PIXEL);
         c.tapsCap = nPix;
     }
     if (need > c.sampCap) {
@@ -734,12 +733,127 @@ static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, hipSt
     return KZ_OK;
 }
 
-static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune) {
+#ifdef KZ_EXPERIMENTS
+// Launch code of the kernels of kz_experiments.h (development builds only): takes over a traversal launch of wfPass when the caller's
+// KzTuning selects one of the rejected experiments. The films stay bit-identical to the product kernels' (tests/test_gpu_configs.py).
+struct KzExpLaunch {
+    KzScene *scene; KzDeviceState *ds; PassCtx *c; hipStream_t stream; KzWf W; KzTune tune; dim3 gTrav; size_t traceLds; int stackBound; bool st; uint32_t items;
+    bool keys = false, dq = false, any = false; size_t ldsX = 0, dqLds = 0, stackBytes = 0; KzTune tuneDq{};
+    int prepare() {
+        const KzParams &P = scene->prm;
+        keys = tune.wide && tune.keyStack == 2;
+        dq = tune.wide && tune.leafQueue == 2;
+        tune.ldsTop = tune.wide ? (int)std::min<size_t>((size_t)std::max(0, tune.ldsTop), std::min<size_t>(scene->nodes4.size(), 1536)) : 0;
+        any = !tune.wide || keys || tune.ldsTop > 0 || dq || tune.legacyTrace || tune.mixed;
+        if (!any) return KZ_OK;
+        stackBytes = (size_t)P.stackDepth * KZ_BLOCK * sizeof(uint32_t);
+        ldsX = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t) * (keys ? 2 : 1) + (size_t)tune.ldsTop * sizeof(KzNode4);
+        if (ldsX > 64 * 1024) {
+            HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace_x<0, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace_x<2, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        if (dq) {
+            const int dqLS = std::max(2, std::min(tune.ldsStack, std::min(stackBound, 9)));             // 9 rows + queue + results = 19.4 KB per workgroup: 8 per CU
+            dqLds = (size_t)4 * ((size_t)(dqLS + 1) * 64 + 128 + 192 + 2 * KZ_DQ_JOBS) * sizeof(uint32_t);
+            tuneDq = tune; tuneDq.ldsStack = dqLS;
+            const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - dqLS);
+            if (needOvf > c->ovfCap) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (c->ovf) (void)hipFree(c->ovf);
+                c->ovf = nullptr; c->ovfCap = 0;
+                KZ_ALLOC(&c->ovf, needOvf * sizeof(uint32_t));
+                c->ovfCap = needOvf;
+                tune.ovf = c->ovf;
+            }
+            tuneDq.ovf = c->ovf; tuneDq.ovfStride = (uint32_t)stride;
+            if (items > c->litCap) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (c->litQueue) (void)hipFree(c->litQueue);
+                c->litQueue = nullptr; c->litCap = 0;
+                KZ_ALLOC(&c->litQueue, (size_t)items * sizeof(uint32_t));
+                c->litCap = items;
+            }
+        }
+        return KZ_OK;
+    }
+    bool allowsPacket() const { return tune.wide && !tune.legacyTrace; }
+    // the round-2 kernel with its options; MODE 0, 1, 2, 3
+    template <int MODE> void traceX(const uint32_t *q, const uint32_t *cptr, uint32_t cimm, uint32_t *head, const uint32_t *qb, const uint32_t *cb) {
+        const KzParams &P = scene->prm; const dim3 blk(KZ_BLOCK);
+        constexpr int M = MODE;
+        if (tune.wide && tune.ldsTop > 0 && !st && (M == 0 || M == 2)) hipLaunchKernelGGL((kz_wf_trace_x<(M == 0 || M == 2) ? M : 0, false, true, false, true>), gTrav, blk, ldsX, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+        else if (tune.wide && keys && (M == 0 || M == 1)) {
+            if (st) hipLaunchKernelGGL((kz_wf_trace_x<(M == 0 || M == 1) ? M : 0, true, true, true>), gTrav, blk, ldsX, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+            else hipLaunchKernelGGL((kz_wf_trace_x<(M == 0 || M == 1) ? M : 0, false, true, true>), gTrav, blk, ldsX, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+        } else if (tune.wide) {
+            if (st) hipLaunchKernelGGL((kz_wf_trace_x<M, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+            else hipLaunchKernelGGL((kz_wf_trace_x<M, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+        } else {
+            if (st) hipLaunchKernelGGL((kz_wf_trace_x<M, true, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+            else hipLaunchKernelGGL((kz_wf_trace_x<M, false, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+        }
+    }
+    // closest-hit launches outside the bounce loop (camera rays, first-hit walk-through) and the lit-ray walk-through
+    bool trace(int mode, const uint32_t *q, const uint32_t *cptr, uint32_t cimm, uint32_t *head, uint32_t *qb, uint32_t *cb) {
+        if (!any) return false;
+        const KzParams &P = scene->prm; const dim3 blk(KZ_BLOCK);
+        if (tune.legacyTrace && (mode == 0 || mode == 1)) {
+            if (mode == 0) { if (st) hipLaunchKernelGGL((kz_wf_extend<true, false>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); else hipLaunchKernelGGL((kz_wf_extend<false, false>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); }
+            else { if (st) hipLaunchKernelGGL((kz_wf_extend<true, true>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); else hipLaunchKernelGGL((kz_wf_extend<false, true>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); }
+            return true;
+        }
+        if (mode == 0) { traceX<0>(q, cptr, cimm, head, qb, cb); return true; }
+        if (mode == 1) { traceX<1>(q, cptr, cimm, head, qb, cb); return true; }
+        if (mode == 2) { traceX<2>(q, cptr, cimm, head, qb, cb); return true; }
+        return false;
+    }
+    // the traversal launches of one bounce (shadow rays of this bounce, closest-hit rays of the next)
+    bool bounce(int iter, bool needExtend, uint32_t *nextQ, uint32_t *nextCount, uint32_t *shQ, uint32_t *shCount) {
+        if (!any) return false;
+        const KzParams &P = scene->prm; const dim3 blk(KZ_BLOCK);
+        if (!tune.legacyTrace && tune.mixed && P.nLights > 0 && needExtend) {
+            traceX<3>(nextQ, nextCount, 0u, nextCount + 2, shQ, shCount);
+            (void)stageMark(*c, stream, 1);
+            return true;
+        }
+        if (P.nLights > 0) {
+            if (dq && P.shadowFast) {
+                uint32_t *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
+                if (st) hipLaunchKernelGGL((kz_wf_trace_dq<2, true>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, tuneDq, c->litQueue, litCount);
+                else hipLaunchKernelGGL((kz_wf_trace_dq<2, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, tuneDq, c->litQueue, litCount);
+                traceX<2>(c->litQueue, litCount, 0u, litHead, nullptr, nullptr);      // the few rays that cross an invisible light
+            } else if (tune.legacyTrace) {
+                if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
+                else hipLaunchKernelGGL(kz_wf_shadow<false>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
+            } else traceX<2>(shQ, shCount, 0u, nextCount + 3, nullptr, nullptr);
+        }
+        (void)stageMark(*c, stream, 3);
+        if (needExtend) {
+            if (dq && st) hipLaunchKernelGGL((kz_wf_trace_dq<0, true>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, tuneDq, (uint32_t *)nullptr, (uint32_t *)nullptr);
+            else if (dq) hipLaunchKernelGGL((kz_wf_trace_dq<0, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, tuneDq, (uint32_t *)nullptr, (uint32_t *)nullptr);
+            else trace(0, nextQ, nextCount, 0u, nextCount + 2, nullptr, nullptr);
+            (void)stageMark(*c, stream, 1);
+        }
+        return true;
+    }
+};
+#endif
+
+// kz_wf_trace instantiations by (mode, stats): the launch code picks from this table instead of a ladder of macros
+typedef void (*KzTraceFn)(KzParams, KzDevTables, KzWf, const uint32_t *, const uint32_t *, uint32_t, uint32_t *, KzTune, uint32_t *, uint32_t *);
+static KzTraceFn traceFn(int mode, bool stats) {
+    static const KzTraceFn tab[5][2] = {{kz_wf_trace<0, false>, kz_wf_trace<0, true>}, {kz_wf_trace<1, false>, kz_wf_trace<1, true>},
+                                        {kz_wf_trace<2, false>, kz_wf_trace<2, true>}, {nullptr, nullptr}, {kz_wf_trace<4, false>, kz_wf_trace<4, true>}};
+    return tab[mode][stats ? 1 : 0];
+}
+
+// One pass of the wavefront pipeline over `items` = nPixPass x Sp (pixel, sample) items: pixels pixList[0 .. nPixPass), sample indices
+// [sBegin, sBegin + Sp). Every launch goes to `stream`; queue counts stay on the device.
+static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, const uint32_t *pixList, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune) {
     const KzParams &P = scene->prm;
     KzWf W = c.wf;
     W.outJx = c.samp; W.outJy = c.samp + c.sampCap; W.outR = c.samp + 2 * c.sampCap; W.outG = c.samp + 3 * c.sampCap; W.outB = c.samp + 4 * c.sampCap; W.stats = ds->stats;
     const bool st = ds->statsOn;
-    const size_t stackBytes = (size_t)P.stackDepth * KZ_BLOCK * sizeof(uint32_t);
     const dim3 blk(KZ_BLOCK);
     // shade: the lean variant runs 4 workgroups per CU at once (its launch bounds), so the default grid is exactly those, each looping over
     // its share: with 6 per CU the kernel ran 1.5 rounds, the second with half the CUs idle (same-call sweep, profiles/r02h_shade: shade alone
@@ -751,18 +865,9 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     // stack: tune.ldsStack entries per lane in LDS, the rest of the worst case (known from the builder) in a global overflow area
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
     tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
-    // closest-hit rays on the BVH4 carry the entry distance with every stack entry (second column block in LDS, odd rows of the overflow area)
-    const bool keys = tune.wide && tune.keyStack == 2;      // per-lane kernel: measured slower on C4 (r02c), on request only
-    tune.ldsTop = tune.wide ? (int)std::min<size_t>((size_t)std::max(0, tune.ldsTop), std::min<size_t>(scene->nodes4.size(), 1536)) : 0;
-    const size_t topBytes = (size_t)tune.ldsTop * sizeof(KzNode4);
-    const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t) + topBytes;      // + one scratch slot per lane (branch-free pushes)
-    const size_t traceLdsK = 2 * (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);
-    if (traceLds > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace<0, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute((const void *)kz_wf_trace<2, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);      // + one scratch slot per lane (branch-free pushes)
     {
-        const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack) * (keys ? 2 : 1);
+        const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack) * 2;      // (x 2: the key stack of kz_experiments.h)
         if (needOvf > c.ovfCap) {
             HIP_TRY(hipStreamSynchronize(stream));
             if (c.ovf) (void)hipFree(c.ovf);
@@ -772,116 +877,70 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
         }
         tune.ovf = c.ovf; tune.ovfStride = (uint32_t)stride;
     }
-    // decoupled leaf queue (kz_wf_trace_dq): bounce rays, and shadow rays when the exact any-hit form applies (shadowFast)
-    const bool dq = tune.wide && tune.leafQueue == 2;
-    const int dqLS = std::max(2, std::min(tune.ldsStack, std::min(stackBound, 9)));                 // 9 rows + queue + results = 19.4 KB per workgroup: 8 per CU
-    const size_t dqLds = (size_t)4 * ((size_t)(dqLS + 1) * 64 + 128 + 192 + 2 * KZ_DQ_JOBS) * sizeof(uint32_t);
-    KzTune tuneDq = tune; tuneDq.ldsStack = dqLS;
-    if (dq) {
-        const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - dqLS);
-        if (needOvf > c.ovfCap) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (c.ovf) (void)hipFree(c.ovf);
-            c.ovf = nullptr; c.ovfCap = 0;
-            KZ_ALLOC(&c.ovf, needOvf * sizeof(uint32_t));
-            c.ovfCap = needOvf;
-            tune.ovf = c.ovf;
-        }
-        tuneDq.ovf = c.ovf; tuneDq.ovfStride = (uint32_t)stride;
-        if (items > c.litCap) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (c.litQueue) (void)hipFree(c.litQueue);
-            c.litQueue = nullptr; c.litCap = 0;
-            KZ_ALLOC(&c.litQueue, (size_t)items * sizeof(uint32_t));
-            c.litCap = items;
-        }
-    }
     const int maxDepth = P.maxDepth;
     c.stageUsed = 0;
     HIP_TRY(hipMemsetAsync(W.counts, 0, 8 * 520 * sizeof(uint32_t), stream));
     { int rc_ = stageMark(c, stream, -1); if (rc_) return rc_; }
-    hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, ds->pixList, items, Sp, sBegin);
+    hipLaunchKernelGGL(kz_wf_generate, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, P, ds->T, W, pixList, items, Sp, sBegin);
     { int rc_ = stageMark(c, stream, 0); if (rc_) return rc_; }
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
-    const int traceKernel = envOverride().traceKernel, mixed = envOverride().mixed;
-#define KZ_TRACE2(MODE, q, cptr, cimm, headp, qb, cb) do { \
-        if (tune.wide && tune.ldsTop > 0 && !st && (MODE == 0 || MODE == 2)) \
-                         hipLaunchKernelGGL((kz_wf_trace<MODE, false, true, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
-        else if (tune.wide && keys && (MODE == 0 || MODE == 1)) { \
-                         if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true, true>), gTrav, blk, traceLdsK, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
-                         else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true, true>), gTrav, blk, traceLdsK, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } \
-        else if (tune.wide) { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
-                         else hipLaunchKernelGGL((kz_wf_trace<MODE, false, true>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } \
-        else { if (st) hipLaunchKernelGGL((kz_wf_trace<MODE, true, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); \
-               else hipLaunchKernelGGL((kz_wf_trace<MODE, false, false>), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, headp, tune, qb, cb); } } while (0)
-#define KZ_TRACE(MODE, q, cptr, cimm, headp) KZ_TRACE2(MODE, q, cptr, cimm, headp, (const uint32_t *)nullptr, (const uint32_t *)nullptr)
-#define KZ_EXTEND(KEEP, q, cptr, cimm, headp) do { if (traceKernel) KZ_TRACE((KEEP ? 1 : 0), q, cptr, cimm, headp); \
-                                            else if (st) hipLaunchKernelGGL((kz_wf_extend<true, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); \
-                                            else hipLaunchKernelGGL((kz_wf_extend<false, KEEP>), gTrav, blk, stackBytes, stream, P, ds->T, W, q, cptr, cimm); } while (0)
+#ifdef KZ_EXPERIMENTS
+    KzExpLaunch X{scene, ds, &c, stream, W, tune, gTrav, traceLds, stackBound, st, items};
+    if (int rc_ = X.prepare()) return rc_;
+#endif
+    // mode 0 / 1 / 2 / 4 of kz_wf_trace on queue q (nullptr: identity) of *cptr (nullptr: cimm) entries
+    auto trace = [&](int mode, const uint32_t *q, const uint32_t *cptr, uint32_t cimm, uint32_t *head, uint32_t *qb, uint32_t *cb) {
+#ifdef KZ_EXPERIMENTS
+        if (X.trace(mode, q, cptr, cimm, head, qb, cb)) return;
+#endif
+        hipLaunchKernelGGL(traceFn(mode, st), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+    };
     // camera rays: the wave-level packet traversal (kz_wf_trace_packet) unless the caller asks for the per-lane kernel
-    const bool packet = traceKernel && tune.wide && tune.packet != 1 && P.stackBound4 <= 128;
+    bool packet = tune.packet != 1 && P.stackBound4 <= 128;
+#ifdef KZ_EXPERIMENTS
+    if (!X.allowsPacket()) packet = false;
+#endif
     if (packet) {
-#define KZ_PACKET(ST, KY) hipLaunchKernelGGL((kz_wf_trace_packet<ST, KY>), gPacket, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8)
-        if (tune.keyStack != 1) { if (st) KZ_PACKET(true, true); else KZ_PACKET(false, true); }
+        // (scenes with an invisible light: the epilogue queues the first hits on such a light for the walk-through launch below)
+#define KZ_PACKET(ST, FX) hipLaunchKernelGGL((kz_wf_trace_packet<ST, FX>), gPacket, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8, W.queue[2], W.counts + 0)
+        if (P.anyInvisibleLight) { if (st) KZ_PACKET(true, true); else KZ_PACKET(false, true); }
         else { if (st) KZ_PACKET(true, false); else KZ_PACKET(false, false); }
 #undef KZ_PACKET
-    } else KZ_EXTEND(false, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2);
-    if (P.anyInvisibleLight) {
-        hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);
-        KZ_EXTEND(true, (const uint32_t *)W.queue[2], (const uint32_t *)(W.counts + 0), 0u, W.counts + 3);
+    } else {
+        trace(0, nullptr, nullptr, items, W.counts + 2, nullptr, nullptr);
+        if (P.anyInvisibleLight) hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);
     }
+    if (P.anyInvisibleLight) trace(1, W.queue[2], W.counts + 0, 0u, W.counts + 3, nullptr, nullptr);      // H6 walk-through of the first hit
     { int rc_ = stageMark(c, stream, 1); if (rc_) return rc_; }
     const uint32_t *cur = nullptr, *curCount = nullptr;
     for (int iter = 0; iter < maxDepth; ++iter) {
         uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
-#define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, ds->pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
+#define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
         if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
         else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
 #undef KZ_SHADE
         { int rc_ = stageMark(c, stream, 2); if (rc_) return rc_; }
         const bool lastIter = iter == maxDepth - 1;
         const bool needExtend = !lastIter || P.bgPresent;
-        if (traceKernel && mixed && P.nLights > 0 && needExtend) {
-            // one launch for the shadow rays of this bounce and the closest-hit rays of the next (measured: no gain on C4, kept as an option)
-            KZ_TRACE2(3, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, (const uint32_t *)shQ, (const uint32_t *)shCount);
-            cur = nextQ; curCount = nextCount;
-            { int rc_ = stageMark(c, stream, 1); if (rc_) return rc_; }
-            continue;
-        }
+#ifdef KZ_EXPERIMENTS
+        if (X.bounce(iter, needExtend, nextQ, nextCount, shQ, shCount)) { cur = nextQ; curCount = nextCount; continue; }
+#endif
         if (P.nLights > 0) {
-            if (dq && P.shadowFast) {
-                uint32_t *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
-                if (st) hipLaunchKernelGGL((kz_wf_trace_dq<2, true>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, tuneDq,
-                                           c.litQueue, litCount);
-                else hipLaunchKernelGGL((kz_wf_trace_dq<2, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, tuneDq,
-                                        c.litQueue, litCount);
-                KZ_TRACE(2, (const uint32_t *)c.litQueue, (const uint32_t *)litCount, 0u, litHead);      // the few rays that cross an invisible light
-            }
-            else if (traceKernel && P.shadowFast && tune.wide && tune.ldsTop == 0) {
+            if (P.shadowFast) {
                 // any-hit kernel without the walk-through machinery; the (rare) rays whose segment crosses an invisible-light triangle go to a
                 // queue - the ping-pong path queue this bounce's shade has just consumed - and are walked through by the general kernel
                 uint32_t *litQ = W.queue[(iter & 1) ^ 1], *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
-                KZ_TRACE2(4, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3, (const uint32_t *)litQ, (const uint32_t *)litCount);
-                if (P.anyInvisibleLight) KZ_TRACE(2, (const uint32_t *)litQ, (const uint32_t *)litCount, 0u, litHead);
-            }
-            else if (traceKernel) KZ_TRACE(2, (const uint32_t *)shQ, (const uint32_t *)shCount, 0u, nextCount + 3);
-            else if (st) hipLaunchKernelGGL(kz_wf_shadow<true>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
-            else hipLaunchKernelGGL(kz_wf_shadow<false>, gTrav, blk, stackBytes, stream, P, ds->T, W, (const uint32_t *)shQ, (const uint32_t *)shCount);
+                trace(4, shQ, shCount, 0u, nextCount + 3, litQ, litCount);
+                if (P.anyInvisibleLight) trace(2, litQ, litCount, 0u, litHead, nullptr, nullptr);
+            } else trace(2, shQ, shCount, 0u, nextCount + 3, nullptr, nullptr);
         }
         { int rc_ = stageMark(c, stream, 3); if (rc_) return rc_; }
         if (needExtend) {
-            if (dq && st) hipLaunchKernelGGL((kz_wf_trace_dq<0, true>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, tuneDq,
-                                             (uint32_t *)nullptr, (uint32_t *)nullptr);
-            else if (dq) hipLaunchKernelGGL((kz_wf_trace_dq<0, false>), gTrav, blk, dqLds, stream, P, ds->T, W, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2, tuneDq,
-                                            (uint32_t *)nullptr, (uint32_t *)nullptr);
-            else KZ_EXTEND(false, (const uint32_t *)nextQ, (const uint32_t *)nextCount, 0u, nextCount + 2);
+            trace(0, nextQ, nextCount, 0u, nextCount + 2, nullptr, nullptr);
             int rc_ = stageMark(c, stream, 1); if (rc_) return rc_;
         }
         cur = nextQ; curCount = nextCount;
     }
-#undef KZ_EXTEND
-#undef KZ_TRACE
-#undef KZ_TRACE2
     if (P.bgPresent) hipLaunchKernelGGL(kz_wf_final, gShade, blk, 0, stream, P, ds->T, W, cur, curCount);
     if (st) hipLaunchKernelGGL(kz_wf_count, dim3((items + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, W, items);
     HIP_TRY(hipGetLastError());
@@ -891,10 +950,10 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts) {
     int rc;
     const KzParams &P = scene->prm;
-    const EnvOverride &eo = envOverride();
     if (opts->pipeline < 0 || opts->pipeline > 2) return kz_fail(KZ_ERR_INVALID_ARG, "pipeline %d (0 = default, 1 = megakernel, 2 = wavefront)", opts->pipeline);
-    if (opts->passesInFlight < 0 || opts->passesInFlight > 2) return kz_fail(KZ_ERR_INVALID_ARG, "passesInFlight %d (0 = default, 1, 2)", opts->passesInFlight);
-    int pipeline = opts->pipeline ? opts->pipeline : (eo.pipeline == 1 ? 1 : 2);
+    if (opts->passesInFlight < 0 || opts->passesInFlight > KZ_MAX_PASSES_IN_FLIGHT)
+        return kz_fail(KZ_ERR_INVALID_ARG, "passesInFlight %d (0 = default, 1 .. %d)", opts->passesInFlight, KZ_MAX_PASSES_IN_FLIGHT);
+    const int pipeline = opts->pipeline ? opts->pipeline : 2;
     uint32_t s0 = opts->sampleBegin, s1 = opts->sampleEnd;
     if (s0 == 0 && s1 == 0) s1 = P.sampleCount;
     if (s0 >= s1 || s1 > P.sampleCount) return kz_fail(KZ_ERR_INVALID_ARG, "sample range [%u,%u) outside [0,%u)", s0, s1, P.sampleCount);
@@ -902,114 +961,149 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     ds->lastStream = stream;
     if ((rc = prepareTiles(scene, ds, opts->tiles, opts->nTiles, stream))) return rc;
     if (!opts->accumulate) HIP_TRY(hipMemsetAsync(ds->film, 0, ds->filmPixels * sizeof(float4), stream));
-    const KzTune tune = resolveTune(opts->tune);
-    // ---- pass size. Measured on C4 with two passes in flight: 2^25 -> 981, 2^26 -> 1031, 2^27 -> 1061-1066, 2^28 -> 1071 Msamples/s
-    // (fewer launches and shorter relative tails per sample): default 2^27 items = 23.6 GB of path state + sample records per pass in flight.
-    // The state never takes more than the caller's limit; without one, not more than half of the device and not more than what
+    KzTune tune;
+    if ((rc = resolveTune(opts->tune, tune))) return rc;
+    const int ftaps = P.tapHi - P.tapLo + 1;
+    const bool tapSums = ftaps <= KZ_TAPS_MAX && tune.filmGather != 1;
+    // ---- pass geometry. A pass is pixPerPass pixels x S samples of each = up to passItems (pixel, sample) items (default 2^27: 23.6 GB of
+    // path state + sample records per pass in flight; 2^25 -> 981, 2^26 -> 1031, 2^27 -> 1061-1066, 2^28 -> 1071 Msamples/s on C4 in round 1:
+    // fewer launches and shorter relative tails per sample). opts->tune.sppPerPass = 0: every pixel of the tile set and as many samples as
+    // fit; n > 0: n samples (or all the call asks for) of as many pixels as fit, pixel chunks in the order of the pixel list.
+    // The state never takes more than the caller's limit; without one, not more than 3/4 of the device and not more than what
     // is free now plus what this replica already holds for the purpose (another process or replica may own the rest).
-    int nCtx = pipeline == 2 ? (opts->passesInFlight ? opts->passesInFlight : (eo.passesInFlight ? eo.passesInFlight : 2)) : 1;
+    int nCtx = pipeline == 2 ? (opts->passesInFlight ? opts->passesInFlight : KZ_DEFAULT_PASSES_IN_FLIGHT) : 1;
     const size_t perItem = (pipeline == 2 ? KZ_STATE_BYTES_PER_ITEM : 0) + KZ_SAMPLE_BYTES_PER_ITEM;
+    const size_t perPixel = tapSums ? KZ_TAP_BYTES_PER_PIXEL : 0;
     size_t limit = opts->maxStateBytes;
     if (!limit) {
         size_t freeB = 0, totalB = 0;
-        const size_t held = ds->ctx[0].bytes() + ds->ctx[1].bytes();
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) limit = std::min(totalB / 2, freeB + held - std::min(freeB + held, (size_t)256 << 20));
+        const size_t held = ds->ctxBytes();
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) limit = std::min(totalB / 4 * 3, freeB + held - std::min(freeB + held, (size_t)256 << 20));
         else limit = (size_t)32 << 30;
     }
-    size_t wantItems = opts->passItems ? (size_t)opts->passItems : (eo.passItems ? (size_t)eo.passItems : (size_t)1 << 27);
-    wantItems = std::max<size_t>(wantItems, ds->nPix);                   // at least one sample of every pixel per pass
     const uint32_t nSamples = s1 - s0;
-    uint32_t S = (uint32_t)std::min<size_t>(wantItems / std::max<uint32_t>(1, ds->nPix), nSamples);
-    auto fits = [&](int ctx) { return (uint32_t)std::min<size_t>(limit / ((size_t)ds->nPix * perItem * (size_t)ctx), 0xFFFFFFFFu); };   // largest S under the limit
-    if (S >= nSamples && fits(1) >= S) nCtx = 1;                          // the whole call is one pass
-    else if (nCtx == 2 && fits(2) >= 1) { S = std::min(S, fits(2)); if ((nSamples + S - 1) / S < 2) nCtx = 1; }
-    else {
-        nCtx = 1;
-        if (fits(1) < 1) return kz_fail(KZ_ERR_OOM, "one sample of the %u pixels of this tile set needs %zu bytes of path state, the limit is %zu: render fewer tiles per call",
-                                        ds->nPix, (size_t)ds->nPix * perItem, limit);
-        S = std::min(S, fits(1));
+    const size_t wantItems = std::max<size_t>(opts->passItems ? (size_t)opts->passItems : (size_t)1 << 27, 64);
+    uint32_t S, pixPerPass;
+    if (opts->tune.sppPerPass > 0) { S = std::min<uint32_t>((uint32_t)opts->tune.sppPerPass, nSamples); pixPerPass = (uint32_t)std::min<size_t>(ds->nPix, std::max<size_t>(64, wantItems / S / 64 * 64)); }
+    else { pixPerPass = ds->nPix; S = (uint32_t)std::min<size_t>(std::max<size_t>(1, wantItems / std::max<uint32_t>(1, ds->nPix)), nSamples); }
+    // the largest pass of the wanted shape that fits `room` bytes: fewer samples first, then (from one sample) fewer pixels
+    auto shape = [&](size_t room, uint32_t &s, uint32_t &px) {
+        s = S; px = pixPerPass;
+        if ((size_t)px * (s * perItem + perPixel) <= room) return;
+        const size_t sFit = room / px > perPixel ? (room / px - perPixel) / perItem : 0;
+        if (sFit >= 1) s = (uint32_t)std::min<size_t>(s, sFit);
+        else { s = 1; px = (uint32_t)std::min<size_t>(px, room / (perItem + perPixel) / 64 * 64); }
+    };
+    // as many contexts as wanted, but never more than there are passes (a call that is one pass runs it in one context at full size)
+    uint32_t nPasses = 0;
+    for (;; --nCtx) {
+        uint32_t s, px;
+        shape(limit / (size_t)nCtx, s, px);
+        if (px > 0) nPasses = ((ds->nPix + px - 1) / px) * ((nSamples + s - 1) / s);
+        if (nCtx > 1 && (px == 0 || nPasses < (uint32_t)nCtx)) continue;
+        if (px == 0) return kz_fail(KZ_ERR_OOM, "64 (pixel, sample) items need %zu bytes of path state, the limit is %zu", (size_t)64 * (perItem + perPixel), limit);
+        S = s; pixPerPass = px;
+        break;
     }
-    const uint32_t nPasses = (nSamples + S - 1) / S;
-    const size_t need = (size_t)ds->nPix * S;
+    const size_t need = (size_t)pixPerPass * S;
     if (need >= (1ull << 32)) return kz_fail(KZ_ERR_UNSUPPORTED, "pass of %zu items (limit 2^32)", need);
-    // Two passes in flight on two internal streams when the call has at least two: the persistent traversal kernels of one pass
-    // drain (fewer and fewer busy waves) while the other pass keeps the machine full (C4: 36.9 -> 33.5 ms per pass). The passes
-    // are independent except for the film, whose read-modify-write kernels are chained with events in pass order.
-    const bool dual = pipeline == 2 && nPasses >= 2 && nCtx == 2;
-    if (!dual && ds->ctx[1].bytes() && (size_t)ds->nPix * S * perItem + ds->ctx[1].bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[1].release(); }
+    // Several passes in flight on internal streams when the call has at least two: the persistent traversal kernels of one pass
+    // drain (fewer and fewer busy waves) while the other passes keep the machine full. The passes are independent except for the
+    // film, whose read-modify-write kernel is chained with events in pass order.
+    const bool multi = pipeline == 2 && nPasses >= 2 && nCtx >= 2;
+    if (!multi) nCtx = 1;
+    {   // contexts this call does not use are released when their memory is needed
+        size_t keep = 0;
+        for (int i = 0; i < nCtx; ++i) keep += std::max(ds->ctx[i].bytes(), need * perItem + pixPerPass * perPixel);
+        for (int i = KZ_MAX_PASSES_IN_FLIGHT - 1; i >= nCtx; --i)
+            if (ds->ctx[i].bytes() && keep + ds->ctx[i].bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i].release(); } else keep += ds->ctx[i].bytes();
+    }
     if (!ds->evCallA) { HIP_TRY(hipEventCreate(&ds->evCallA)); HIP_TRY(hipEventCreate(&ds->evCallB)); }
-    if (dual && !ds->passStream[0]) {
-        // Different priorities put the two streams on different hardware queues whatever other streams the process has created
-        // (streams of one priority share a small round-robin pool of queues and two of them may end up serialised on one).
+    if (multi) {
+        // Different priorities put streams on different hardware queues whatever other streams the process has created (streams of one
+        // priority share a small round-robin pool of queues and two of them may end up serialised on one): the pass streams cycle
+        // through the priority levels the device has.
         int prLeast = 0, prGreatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipStreamCreateWithPriority(&ds->passStream[i], hipStreamNonBlocking, i == 0 ? prLeast : prGreatest));
-            HIP_TRY(hipEventCreateWithFlags(&ds->evFilm[i], hipEventDisableTiming));
+        const int mode = opts->tune.streamPriority > 0 ? opts->tune.streamPriority : 3;
+        if (mode != ds->streamMode) {                                  // another policy than the streams were made with: make them again
+            HIP_TRY(hipDeviceSynchronize());
+            for (hipStream_t &st : ds->passStream) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+            ds->streamMode = mode;
         }
-        HIP_TRY(hipEventCreateWithFlags(&ds->evFork, hipEventDisableTiming));
+        const int nPr = std::max(1, prLeast - prGreatest + 1);
+        for (int i = 0; i < nCtx; ++i) {
+            if (!ds->evFilm[i]) HIP_TRY(hipEventCreateWithFlags(&ds->evFilm[i], hipEventDisableTiming));
+            if (ds->passStream[i]) continue;
+            const int pr = mode == 1 ? (prLeast + prGreatest) / 2 : mode == 2 ? ((i & 1) ? prGreatest : prLeast) : prLeast - (i % nPr);
+            HIP_TRY(hipStreamCreateWithPriority(&ds->passStream[i], hipStreamNonBlocking, pr));
+        }
+        if (!ds->evFork) HIP_TRY(hipEventCreateWithFlags(&ds->evFork, hipEventDisableTiming));
     }
     ds->eventsUsed = 0;
     HIP_TRY(hipEventRecord(ds->evCallA, stream));
-    if (dual) {
+    if (multi) {
         HIP_TRY(hipEventRecord(ds->evFork, stream));
-        HIP_TRY(hipStreamWaitEvent(ds->passStream[0], ds->evFork, 0)); HIP_TRY(hipStreamWaitEvent(ds->passStream[1], ds->evFork, 0));
+        for (int i = 0; i < nCtx; ++i) HIP_TRY(hipStreamWaitEvent(ds->passStream[i], ds->evFork, 0));
     }
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border;
     uint32_t pass = 0;
-    for (uint32_t s = s0; s < s1; s += S, ++pass) {
-        const uint32_t Sp = std::min(S, s1 - s);
-        const size_t items = (size_t)ds->nPix * Sp;
-        const int ci = dual ? (int)(pass & 1u) : 0;
-        PassCtx &c = ds->ctx[ci];
-        hipStream_t pst = dual ? ds->passStream[ci] : stream;
-        if ((rc = ctxEnsure(c, need, ds->nPix, pipeline == 2, pst))) return rc;
-        if (ds->eventsUsed == ds->events.size()) {
-            EventPair ep; HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); ds->events.push_back(ep);
-        }
-        EventPair &ep = ds->events[ds->eventsUsed++];
-        const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
-        float *sJx = c.samp, *sJy = c.samp + c.sampCap, *sR = c.samp + 2 * c.sampCap, *sG = c.samp + 3 * c.sampCap, *sB = c.samp + 4 * c.sampCap;
-        HIP_TRY(hipEventRecord(ep.a, pst));
-        if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, s, Sp, (uint32_t)items, tune))) return rc; }
-        else {
-#define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, ds->pixList, (uint32_t)items, Sp, s, \
+    for (uint32_t p0 = 0; p0 < ds->nPix; p0 += pixPerPass) {
+        const uint32_t nPixPass = std::min(pixPerPass, ds->nPix - p0);
+        const uint32_t *pixList = ds->pixList + p0;
+        for (uint32_t s = s0; s < s1; s += S, ++pass) {
+            const uint32_t Sp = std::min(S, s1 - s);
+            const size_t items = (size_t)nPixPass * Sp;
+            const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
+            PassCtx &c = ds->ctx[ci];
+            hipStream_t pst = multi ? ds->passStream[ci] : stream;
+            if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, pst))) return rc;
+            if (ds->eventsUsed == ds->events.size()) {
+                EventPair ep; HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); ds->events.push_back(ep);
+            }
+            EventPair &ep = ds->events[ds->eventsUsed++];
+            const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
+            float *sJx = c.samp, *sJy = c.samp + c.sampCap, *sR = c.samp + 2 * c.sampCap, *sG = c.samp + 3 * c.sampCap, *sB = c.samp + 4 * c.sampCap;
+            HIP_TRY(hipEventRecord(ep.a, pst));
+            if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, s, Sp, (uint32_t)items, tune))) return rc; }
+            else {
+#define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, pixList, (uint32_t)items, Sp, s, \
                                            (const uint32_t *)nullptr, sJx, sJy, sR, sG, sB, ds->stats)
-            if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, true); else KZ_MEGA(true, false); }
-            else { if (P.bsdfExt) KZ_MEGA(false, true); else KZ_MEGA(false, false); }
+                if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, true); else KZ_MEGA(true, false); }
+                else { if (P.bsdfExt) KZ_MEGA(false, true); else KZ_MEGA(false, false); }
 #undef KZ_MEGA
-        }
-        HIP_TRY(hipEventRecord(ep.b, pst));
-        HIP_TRY(hipGetLastError());
-        if (dual && pass > 0) HIP_TRY(hipStreamWaitEvent(pst, ds->evFilm[ci ^ 1], 0));       // film of the previous pass is in
-        const dim3 fgrid((cols + KZ_FILM_TILE - 1) / KZ_FILM_TILE, (rows + KZ_FILM_TILE - 1) / KZ_FILM_TILE);
-        const int ftaps = P.tapHi - P.tapLo + 1;
-        if (ftaps <= KZ_TAPS_MAX && tune.filmGather != 1) {
-            // two kernels, every sample record read once (the tap sums do not depend on the film, so only kz_film_apply waits for the previous pass's film)
-#define KZ_FILM_TAPS(N) hipLaunchKernelGGL(kz_film_taps<N>, dim3((ds->nPix + 63) / 64), dim3(64), 0, pst, P, ds->T.filter, ds->pixList, ds->nPix, Sp, sJx, sJy, sR, sG, sB, (float4 *)c.taps)
-            switch (ftaps) { case 1: KZ_FILM_TAPS(1); break; case 2: KZ_FILM_TAPS(2); break; case 3: KZ_FILM_TAPS(3); break; case 4: KZ_FILM_TAPS(4); break; default: KZ_FILM_TAPS(5); break; }
+            }
+            HIP_TRY(hipEventRecord(ep.b, pst));
+            HIP_TRY(hipGetLastError());
+            const dim3 fgrid((cols + KZ_FILM_TILE - 1) / KZ_FILM_TILE, (rows + KZ_FILM_TILE - 1) / KZ_FILM_TILE);
+            const int prev = (ci + nCtx - 1) % nCtx;
+            if (tapSums) {
+                // two kernels, every sample record read once. The tap sums do not depend on the film: only kz_film_apply waits for the film of the pass before.
+#define KZ_FILM_TAPS(N) hipLaunchKernelGGL(kz_film_taps<N>, dim3((nPixPass + 63) / 64), dim3(64), 0, pst, P, ds->T.filter, pixList, nPixPass, Sp, sJx, sJy, sR, sG, sB, (float4 *)c.taps)
+                switch (ftaps) { case 1: KZ_FILM_TAPS(1); break; case 2: KZ_FILM_TAPS(2); break; case 3: KZ_FILM_TAPS(3); break; case 4: KZ_FILM_TAPS(4); break; default: KZ_FILM_TAPS(5); break; }
 #undef KZ_FILM_TAPS
-            hipLaunchKernelGGL(kz_film_apply, fgrid, dim3(256), 0, pst, P, ds->pixIndex, (const float4 *)c.taps, ds->nPix, ds->film);
-        } else {
-            const int fr = KZ_FILM_TILE + ftaps - 1;
-            const size_t perSample = (size_t)(3 + 2 * ftaps) * fr * fr * sizeof(float);
-            const int fchunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)Sp, (size_t)8, (size_t)(64 * 1024) / perSample}));
-            const size_t fshm = perSample * fchunk;
-            hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, pst, P, ds->T.filter, ds->pixIndex, Sp, fchunk, sJx, sJy, sR, sG, sB, ds->film);
+                if (multi && pass > 0) HIP_TRY(hipStreamWaitEvent(pst, ds->evFilm[prev], 0));
+                hipLaunchKernelGGL(kz_film_apply, fgrid, dim3(256), 0, pst, P, ds->pixIndex, (const float4 *)c.taps, p0, nPixPass, ds->film);
+            } else {
+                const int fr = KZ_FILM_TILE + ftaps - 1;
+                const size_t perSample = (size_t)(3 + 2 * ftaps) * fr * fr * sizeof(float);
+                const int fchunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)Sp, (size_t)8, (size_t)(64 * 1024) / perSample}));
+                const size_t fshm = perSample * fchunk;
+                if (multi && pass > 0) HIP_TRY(hipStreamWaitEvent(pst, ds->evFilm[prev], 0));
+                hipLaunchKernelGGL(kz_film_gather, fgrid, dim3(256), fshm, pst, P, ds->T.filter, ds->pixIndex, p0, nPixPass, Sp, fchunk, sJx, sJy, sR, sG, sB, ds->film);
+            }
+            HIP_TRY(hipGetLastError());
+            if (multi) HIP_TRY(hipEventRecord(ds->evFilm[ci], pst));
+            if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
+            ds->lastCtx = ci;
         }
-        HIP_TRY(hipGetLastError());
-        if (dual) HIP_TRY(hipEventRecord(ds->evFilm[ci], pst));
-        if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
-        ds->lastCtx = ci;
     }
-    if (dual) {                                                        // join: everything after this call on `stream` sees the film
-        HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[0], 0));
-        HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[1], 0));
-    }
+    if (multi)                                                         // join: everything after this call on `stream` sees the film
+        for (int i = 0; i < nCtx && (uint32_t)i < pass; ++i) HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[i], 0));
     HIP_TRY(hipEventRecord(ds->evCallB, stream));
-    ds->lastDual = dual;
-    ds->lastInfo.passes = pass; ds->lastInfo.passesInFlight = dual ? 2 : 1; ds->lastInfo.itemsPerPass = need; ds->lastInfo.sppPerPass = S;
-    ds->lastInfo.pixels = ds->nPix; ds->lastInfo.stateBytes = ds->ctx[0].bytes() + ds->ctx[1].bytes();
+    ds->lastDual = multi;
+    ds->lastInfo.passes = pass; ds->lastInfo.passesInFlight = (uint32_t)nCtx; ds->lastInfo.itemsPerPass = need; ds->lastInfo.sppPerPass = S;
+    ds->lastInfo.pixels = ds->nPix; ds->lastInfo.stateBytes = ds->ctxBytes(); ds->lastInfo.pixelsPerPass = pixPerPass;
     return KZ_OK;
 }
 

@@ -149,6 +149,13 @@ extern "C" {
 
 const char *kz_last_error(void) { return g_err; }
 int kz_abi_version(void) { return KZ_ABI_VERSION; }
+int kz_build_flags(void) {
+#ifdef KZ_EXPERIMENTS
+    return KZ_BUILD_EXPERIMENTS;
+#else
+    return 0;
+#endif
+}
 
 int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     if (!d || !out) return kz_fail(KZ_ERR_INVALID_ARG, "kz_scene_create: null argument");
@@ -276,10 +283,12 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     for (const KzBSDF &b : sc->bsdfs) if (b.type > KZ_BSDF_KAZENSTANDARD || b.albedoTex || b.roughnessTex || b.metallicTex) p.bsdfExt = 1;
     // invisible-light triangles for the exact any-hit shadow test
     p.shadowFast = 1; p.nIlTris = 0; p.anyInvisibleLight = 0;
+    uint32_t ilGidLo = 0xFFFFFFFFu, ilGidHi = 0;
     for (int a = 0; a < 3; ++a) { p.ilLo[a] = INFINITY; p.ilHi[a] = -INFINITY; }
     for (const KzLightRow &lr : sc->lightRows) {
         if (lr.primaryVisibility) continue;
         p.anyInvisibleLight = 1;
+        if (lr.nF) { ilGidLo = std::min(ilGidLo, lr.triOffset); ilGidHi = std::max(ilGidHi, lr.triOffset + lr.nF - 1); }
         for (uint32_t f = 0; f < lr.nF; ++f) {
             const KzTriShade &s = sc->shade[lr.triOffset + f];
             KzTri t; std::memset(&t, 0, sizeof t);
@@ -293,6 +302,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     }
     if (sc->ilTris.size() > 64) { p.shadowFast = 0; sc->ilTris.clear(); }      // big emissive meshes: literal closest-hit loop
     p.nIlTris = (uint32_t)sc->ilTris.size();
+    p.ilGidLo = ilGidLo <= ilGidHi ? ilGidLo : 1u; p.ilGidSpan = ilGidLo <= ilGidHi ? ilGidHi - ilGidLo : 0u;
     for (int a = 0; a < 3; ++a) {        // same padding as BVH boxes
         float m = std::max(std::fabs(p.ilLo[a]), std::fabs(p.ilHi[a]));
         if (std::isfinite(m)) { float e = m * 4e-7f + 1e-30f; p.ilLo[a] -= e; p.ilHi[a] += e; }

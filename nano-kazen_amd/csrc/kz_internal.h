@@ -108,6 +108,7 @@ struct KzParams {
     // any-hit form of the shadow test exact (kz_devfn.h shadowOccluded)
     int32_t shadowFast; uint32_t nIlTris; float ilLo[3], ilHi[3];
     int32_t anyInvisibleLight; int32_t stackDepth;
+    uint32_t ilGidLo, ilGidSpan;         // every triangle of an invisible light has gid - ilGidLo <= ilGidSpan (a prefilter: other triangles may too)
     int32_t bsdfExt;                     // any BSDF row beyond constant diffuse / kazenstandard: other models, texture-backed
                                          // parameters, normal maps (selects the larger kernel variants)
 };

@@ -122,11 +122,31 @@ def cmd_shadestat(a):
     print(json.dumps(sc.stats(reset=True)), flush=True)          # the library prints the section shares on stderr
 
 
+def cmd_sched(a):
+    """the pass schedule: passes in flight x pass shape (sppPerPass) x pass size on one scene; every case renders the same --spp samples
+    of every pixel twice (warm + timed). --values 'n,sppPerPass,log2(passItems);...'"""
+    sc = kz.Scene(scene(a.scene), device=0)
+    spp = a.spp or min(sc.sample_count, 512)
+    ref = None
+    for case in a.values.split(";"):
+        n, sp, lg = (int(x) for x in case.split(","))
+        kw = dict(passes_in_flight=n, pass_items=1 << lg, tune=dict(kv(a.tune), sppPerPass=sp))
+        dt = timed(sc, 0, spp, **kw)
+        info = sc.last_pass_info()
+        film = sc.film()
+        if ref is None:
+            ref = film
+        print(json.dumps({"in_flight": n, "sppPerPass": sp, "log2_items": lg, "Msamples_per_s": round(sc.width * sc.height * spp / dt / 1e6, 1), "call_ms": round(dt * 1e3, 1),
+                          "passes": info["passes"], "ctx": info["passesInFlight"], "spp_per_pass": info["sppPerPass"], "pix_per_pass": info["pixelsPerPass"],
+                          "state_GB": round(info["stateBytes"] / 2**30, 1), "film_equal_first": bool(np.array_equal(film, ref)),
+                          "film_maxrel": float(np.max(np.abs(film - ref) / np.maximum(np.abs(ref), 1e-3)))}), flush=True)
+
+
 ap = argparse.ArgumentParser()
-ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters", "shadestat"])
+ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters", "shadestat", "sched"])
 ap.add_argument("c5", nargs="?")
 ap.add_argument("--scene", default="c4"); ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--tune", default=""); ap.add_argument("--opts", default="")
 ap.add_argument("--all-kiss", action="store_true"); ap.add_argument("--knob", default="refill"); ap.add_argument("--values", default="")
 a = ap.parse_args()
-{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters, "shadestat": cmd_shadestat}[a.cmd](a)
+{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters, "shadestat": cmd_shadestat, "sched": cmd_sched}[a.cmd](a)

@@ -8,12 +8,17 @@
 * replicas, budget limits and error paths of ABI v3.
 """
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 L2_TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXPERIMENTS_LIB = os.path.join(ROOT, "nano-kazen_amd", "csrc", "variants", "experiments", "libkazen_mi355x.so")
 
 
 def l2(a, b):
@@ -148,7 +153,7 @@ def test_replicas_and_device_addressing(gpu_lib, kz):
 
 
 def test_state_budget_and_pass_options(gpu_lib, kz, O):
-    """KzRenderOpts v3: pass size, passes in flight and the state cap are per-call options; every schedule gives the film of
+    """KzRenderOpts: pass size, pass shape, passes in flight and the state cap are per-call options; every schedule gives the film of
     pass-at-a-time up to the order of the film additions, and the cap is respected."""
     desc = kz.scenes.cornell_box(96, 80, 24, sampler="pmj02bn")
     sc = kz.Scene(desc, device=0)
@@ -156,40 +161,92 @@ def test_state_budget_and_pass_options(gpu_lib, kz, O):
     sc.render(pass_items=npx * 4, passes_in_flight=1)                 # 6 passes of 4 spp, one at a time
     one_at_a_time = sc.film()
     info = sc.last_pass_info()
-    assert (info["passes"], info["passesInFlight"], info["sppPerPass"], info["pixels"]) == (6, 1, 4, npx)
-    for _ in range(3):                                                # two in flight, repeated: an ordering bug would show as run-to-run differences
-        sc.render(pass_items=npx * 4, passes_in_flight=2)
-        assert np.array_equal(sc.film(), one_at_a_time)
-    assert sc.last_pass_info()["passesInFlight"] == 2
-    per_item = 8 * 16 + 16 + 12 + 20
-    sc.render(max_state_bytes=npx * 3 * per_item * 2)                 # room for two contexts of 3 spp
+    assert (info["passes"], info["passesInFlight"], info["sppPerPass"], info["pixels"], info["pixelsPerPass"]) == (6, 1, 4, npx, npx)
+    for n in (2, 2, 2, 3, 4, 6, 8):                                   # several in flight, repeated: an ordering bug would show as run-to-run differences
+        sc.render(pass_items=npx * 4, passes_in_flight=n)
+        assert np.array_equal(sc.film(), one_at_a_time), n
+        assert sc.last_pass_info()["passesInFlight"] == min(n, 6)     # never more contexts than passes
+    with pytest.raises(kz.abi.KzError):
+        sc.render(passes_in_flight=9)
+    # pass shape: n samples of as many pixels as fit instead of a few samples of every pixel. All 24 samples of a pixel in ONE pass
+    # add up in sample order; 4-sample slices of pixel chunks are the sums of the 4-spp passes above, bit for bit
+    sc.render(pass_items=npx * 4, passes_in_flight=1, tune={"sppPerPass": 4})
+    assert np.array_equal(sc.film(), one_at_a_time)
+    sc.render(pass_items=1920 * 4, passes_in_flight=3, tune={"sppPerPass": 4})            # 4 pixel chunks x 6 sample slices
     info = sc.last_pass_info()
-    assert info["sppPerPass"] == 3 and info["passes"] == 8 and info["stateBytes"] <= npx * 3 * per_item * 2 + (64 << 20)      # + the traversal kernels' overflow stacks
+    assert (info["passes"], info["passesInFlight"], info["sppPerPass"], info["pixelsPerPass"]) == (24, 3, 4, 1920)
+    chunked = sc.film()                                               # (film pixels fed from two chunks add their halves in another order)
+    assert np.allclose(chunked, one_at_a_time, rtol=2e-5, atol=1e-5)
+    sc.render(pass_items=1920 * 4, passes_in_flight=1, tune={"sppPerPass": 4})
+    assert np.array_equal(sc.film(), chunked)
+    sc.render(pass_items=1000 * 24, passes_in_flight=2, tune={"sppPerPass": 24})          # chunks of 960 pixels (a multiple of 64), all samples at once
+    info = sc.last_pass_info()
+    assert (info["passes"], info["sppPerPass"], info["pixelsPerPass"]) == (8, 24, 960)
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
-    sc.render(max_state_bytes=npx * per_item)                         # one context of one sample
-    assert sc.last_pass_info()["sppPerPass"] == 1 and sc.last_pass_info()["passesInFlight"] == 1
+    per_item, per_pixel = 8 * 16 + 16 + 12 + 20, 25 * 16            # path state + sample record per item, film tap sums per pixel
+    cap = 2 * npx * (3 * per_item + per_pixel)
+    sc.render(max_state_bytes=cap)                                    # room for two contexts of 3 spp
+    info = sc.last_pass_info()
+    assert info["sppPerPass"] == 3 and info["passes"] == 8 and info["stateBytes"] <= cap + (64 << 20)      # + the traversal kernels' overflow stacks
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    sc.render(max_state_bytes=npx * (per_item + per_pixel), passes_in_flight=1)           # one context of one sample
+    assert sc.last_pass_info()["sppPerPass"] == 1 and sc.last_pass_info()["passesInFlight"] == 1 and sc.last_pass_info()["pixelsPerPass"] == npx
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    sc.render(max_state_bytes=npx * (per_item + per_pixel) * 2 // 7, passes_in_flight=1)  # not even one sample of every pixel: pixel chunks
+    info = sc.last_pass_info()
+    chunk = npx * 2 // 7 // 64 * 64
+    assert info["sppPerPass"] == 1 and info["pixelsPerPass"] == chunk and info["passes"] == 24 * ((npx + chunk - 1) // chunk)
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
     with pytest.raises(kz.abi.KzError) as e:
         sc.render(max_state_bytes=1000)
     assert e.value.code == kz.abi.KZ_ERR_OOM
     sc.render(tune={"refill": 56, "postpone": 16, "batch": 64, "traceBlocksPerCU": 4, "shadeBlocksPerCU": 3, "ldsStack": 4})
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)     # knobs change the schedule, never the paths
-    sc.render(tune={"bvh2": 1})
-    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
     # camera rays: wave-level packet traversal (default) and the per-lane kernel find the same hits, bit for bit
     sc.render(pass_items=npx * 4, tune={"packetPrimary": 1})
     assert np.array_equal(sc.film(), one_at_a_time)
     sc.render(pass_items=npx * 4, tune={"packetPrimary": 2})
     assert np.array_equal(sc.film(), one_at_a_time)
-    # stack entries that carry their entry distance (culled at pop time) change the visits, not the hits
-    for t in ({"keyStack": 1}, {"keyStack": 2, "ldsStack": 3}, {"ldsTop": 5}, {"binRays": 2}, {"leafQueue": 2}, {"leafQueue": 2, "ldsStack": 2, "refill": 64, "batch": 64}, {"ldsTop": 1000, "ldsStack": 6, "keyStack": 2}, {"keyStack": 1, "packetPrimary": 1}, {"keyStack": 2, "packetPrimary": 1, "ldsStack": 2}):
-        sc.render(pass_items=npx * 4, tune=t)
-        assert np.array_equal(sc.film(), one_at_a_time), t
     # film reconstruction: per-pixel tap sums + apply (default) vs the staged gather of round 1: same weights, another summation order
     sc.render(pass_items=npx * 4, tune={"filmGather": 1})
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    sc.render(pass_items=1920 * 4, passes_in_flight=2, tune={"filmGather": 1, "sppPerPass": 4})
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
     ora = O.OracleScene(desc)
     assert l2(sc.rgb(one_at_a_time), ora.rgb(ora.render(threads=0))) < L2_TOL
+    # the kernels of rejected experiments are not in the default library: asking for one is an error, never a silent default
+    if not (gpu_lib.kz_build_flags() & 1):
+        for t in ({"bvh2": 1}, {"keyStack": 2}, {"ldsTop": 5}, {"leafQueue": 2}, {"legacyTrace": 1}, {"mixedLaunch": 1}):
+            with pytest.raises(kz.abi.KzError) as e:
+                sc.render(tune=t)
+            assert e.value.code == kz.abi.KZ_ERR_UNSUPPORTED, t
+
+
+@pytest.mark.skipif(not os.path.exists(EXPERIMENTS_LIB), reason="development variant not built (scripts/build_variant.sh experiments -DKZ_EXPERIMENTS)")
+def test_experiment_kernels_stay_bit_identical():
+    """The rejected experiments (kz_experiments.h: BVH2 per-lane traversal, per-lane key stack, LDS top-of-tree, decoupled leaf queue,
+    mixed launches, the non-persistent round-1 launches) live in a -DKZ_EXPERIMENTS build only. It is run in a child process (one
+    library per process) and every variant must reproduce the product kernels' film bit for bit."""
+    env = dict(os.environ, KZ_LIB_PATH=EXPERIMENTS_LIB)
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+kz = importlib.import_module("nano-kazen_amd")
+assert kz.abi.load_library().kz_build_flags() & 1
+desc = kz.scenes.cornell_box(96, 80, 24, sampler="pmj02bn")
+sc = kz.Scene(desc, device=0)
+npx = 96 * 80
+sc.render(pass_items=npx * 4, passes_in_flight=1)
+ref = sc.film()
+for t in ({"bvh2": 1}, {"keyStack": 2, "ldsStack": 3}, {"ldsTop": 5}, {"leafQueue": 2}, {"leafQueue": 2, "ldsStack": 2, "refill": 64, "batch": 64},
+          {"ldsTop": 1000, "ldsStack": 6, "keyStack": 2}, {"legacyTrace": 1}, {"mixedLaunch": 1}, {"bvh2": 1, "mixedLaunch": 1}):
+    sc.render(pass_items=npx * 4, tune=t)
+    f = sc.film()
+    assert (np.array_equal(f, ref) if not t.get("bvh2") else np.allclose(f, ref, rtol=2e-5, atol=1e-5)), t
+print("ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_failed_calls_release_their_device_memory(gpu_lib, kz):
