@@ -293,6 +293,9 @@ typedef struct KzStats {
     uint64_t shadedHits;        /* post-intersection gathers (accel.cpp:113-236)        */
     uint64_t lightSamples;      /* Mesh::sample calls (mesh.cpp:108-133)                */
     uint64_t droppedSamples;    /* invalid radiance dropped by ImageBlock::put (block.cpp:57-61) */
+    uint64_t beamPixels;        /* pixels whose camera rays were given a leaf list by kz_wf_beam (once per pixel chunk) */
+    uint64_t beamListEntries;   /* leaves on those lists                                  */
+    uint64_t beamCompletePixels;/* pixels whose list holds every leaf the beam reaches (the other lists end at a distance t_valid) */
 } KzStats;
 
 /* Ray-level record mirroring what Accel::rayIntersect fills (accel.cpp:99-110 + 113-236). */

@@ -121,7 +121,8 @@ class KzPassInfo(C.Structure):
 
 class KzStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("nodeVisits", C.c_uint64), ("triTests", C.c_uint64),
-                ("shadedHits", C.c_uint64), ("lightSamples", C.c_uint64), ("droppedSamples", C.c_uint64)]
+                ("shadedHits", C.c_uint64), ("lightSamples", C.c_uint64), ("droppedSamples", C.c_uint64),
+                ("beamPixels", C.c_uint64), ("beamListEntries", C.c_uint64), ("beamCompletePixels", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

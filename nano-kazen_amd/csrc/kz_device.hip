@@ -416,8 +416,10 @@ struct PassCtx {
     float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: taps^2 float4 per pixel of the tile set
     uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
+    uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0;      // kz_wf_beam: leaf lists of the pixels of a chunk ...
+    uint64_t beamGen = 0; uint32_t beamP0 = 0, beamN = 0;                                  // ... and the chunk (tile-set generation, first pixel, pixels) they were built for
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
-    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4; }
+    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4 + beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); }
     void release() {
         for (void *p : wfAllocs) (void)hipFree(p);
         wfAllocs.clear(); wfCap = 0; wf = KzWf{};
@@ -425,6 +427,7 @@ struct PassCtx {
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
         if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
         if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
+        if (beamEntries) (void)hipFree(beamEntries); beamEntries = nullptr; if (beamCount) (void)hipFree(beamCount); beamCount = nullptr; beamCap = 0; beamGen = 0;
     }
 };
 struct KzDeviceState {
@@ -434,7 +437,7 @@ struct KzDeviceState {
     float4 *film = nullptr; size_t filmPixels = 0;
     uint8_t *srgb = nullptr;                                     // staging raster of kz_film_to_srgb8 (allocated on first use)
     uint32_t *pixList = nullptr; int32_t *pixIndex = nullptr; size_t pixCap = 0; uint32_t nPix = 0;
-    std::vector<KzTile> curTiles; bool tilesValid = false;
+    std::vector<KzTile> curTiles; bool tilesValid = false; uint64_t tileGen = 0;      // tileGen: bumped whenever the pixel list changes
     unsigned long long *stats = nullptr; bool statsOn = false;
     hipStream_t lastStream = nullptr;
     int numCU = 256; size_t totalMem = 0;
@@ -551,8 +554,8 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     ds->filmPixels = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border);
     KZ_ALLOC(&ds->film, ds->filmPixels * sizeof(float4));
     HIP_TRY(hipMemset(ds->film, 0, ds->filmPixels * sizeof(float4)));
-    KZ_ALLOC(&ds->stats, 24 * sizeof(unsigned long long));             // 8 counters of KzStats + 16 lane statistics of the -DKZ_LANESTAT development build
-    HIP_TRY(hipMemset(ds->stats, 0, 24 * sizeof(unsigned long long)));
+    KZ_ALLOC(&ds->stats, 32 * sizeof(unsigned long long));             // 8 counters of KzStats + 16 lane statistics of the -DKZ_LANESTAT development build + 3 beam-list counters
+    HIP_TRY(hipMemset(ds->stats, 0, 32 * sizeof(unsigned long long)));
     { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, ds->device)); ds->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; ds->totalMem = prop.totalGlobalMem; }
     HIP_TRY(hipFuncSetAttribute((const void *)kz_film_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIP_TRY(hipDeviceSynchronize());
@@ -684,7 +687,7 @@ static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, 
     HIP_TRY(hipMemcpy(ds->pixIndex, index.data(), index.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     ds->nPix = (uint32_t)list.size();
     ds->curTiles.assign(tiles, tiles + nTiles);
-    ds->tilesValid = true;
+    ds->tilesValid = true; ++ds->tileGen;
     return KZ_OK;
 }
 
@@ -701,7 +704,16 @@ static constexpr size_t KZ_SAMPLE_BYTES_PER_ITEM = 5 * sizeof(float);
 static constexpr size_t KZ_TAP_BYTES_PER_PIXEL = (size_t)KZ_TAPS_MAX * KZ_TAPS_MAX * sizeof(float4);
 
 // ---- buffers of one pass context: sized for `need` items of `nPix` pixels; nothing is left half-allocated on failure ----
-static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool tapSums, hipStream_t stream) {
+static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool tapSums, bool beams, hipStream_t stream) {
+    if (beams && nPix > c.beamCap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c.beamEntries) (void)hipFree(c.beamEntries);
+        if (c.beamCount) (void)hipFree(c.beamCount);
+        c.beamEntries = nullptr; c.beamCount = nullptr; c.beamCap = 0; c.beamGen = 0;
+        KZ_ALLOC(&c.beamEntries, nPix * KZ_BEAM_CAP * sizeof(uint2));
+        KZ_ALLOC(&c.beamCount, nPix * sizeof(uint2));
+        c.beamCap = nPix;
+    }
     if (tapSums && nPix > c.tapsCap) {                               // (only the tap-sum film path has this buffer)
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.taps) (void)hipFree(c.taps);
@@ -849,7 +861,7 @@ static KzTraceFn traceFn(int mode, bool stats) {
 
 // One pass of the wavefront pipeline over `items` = nPixPass x Sp (pixel, sample) items: pixels pixList[0 .. nPixPass), sample indices
 // [sBegin, sBegin + Sp). Every launch goes to `stream`; queue counts stay on the device.
-static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, const uint32_t *pixList, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune) {
+static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune, bool beams) {
     const KzParams &P = scene->prm;
     KzWf W = c.wf;
     W.outJx = c.samp; W.outJy = c.samp + c.sampCap; W.outR = c.samp + 2 * c.sampCap; W.outG = c.samp + 3 * c.sampCap; W.outB = c.samp + 4 * c.sampCap; W.stats = ds->stats;
@@ -895,21 +907,38 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #endif
         hipLaunchKernelGGL(traceFn(mode, st), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
     };
-    // camera rays: the wave-level packet traversal (kz_wf_trace_packet) unless the caller asks for the per-lane kernel
+    // camera rays: pixel beams + per-sample triangle tests (kz_wf_beam / kz_wf_trace_list), the wave-level packet traversal
+    // (kz_wf_trace_packet) for what the beams cannot take, or the per-lane kernel on request
     bool packet = tune.packet != 1 && P.stackBound4 <= 128;
 #ifdef KZ_EXPERIMENTS
     if (!X.allowsPacket()) packet = false;
 #endif
-    if (packet) {
+#define KZ_PACKET(ST, FX, q, cptr, cimm, headp) hipLaunchKernelGGL((kz_wf_trace_packet<ST, FX>), gPacket, blk, 0, stream, P, ds->T, W, q, cptr, cimm, headp, 8, W.queue[2], W.counts + 0)
+#define KZ_PACKET4(q, cptr, cimm, headp) do { if (P.anyInvisibleLight) { if (st) KZ_PACKET(true, true, q, cptr, cimm, headp); else KZ_PACKET(false, true, q, cptr, cimm, headp); } \
+                                              else { if (st) KZ_PACKET(true, false, q, cptr, cimm, headp); else KZ_PACKET(false, false, q, cptr, cimm, headp); } } while (0)
+    if (packet && beams) {
+        if (c.beamGen != ds->tileGen || c.beamP0 != p0 || c.beamN != nPixPass) {          // the lists depend on the pixels only: built once per pixel chunk
+            const int LS = std::max(1, std::min(P.stackBound4, KZ_BEAM_STACK));      // a beam whose stack would grow beyond this gives its pixel to the packet kernel
+            hipLaunchKernelGGL(kz_wf_beam, dim3((nPixPass + KZ_BLOCK - 1) / KZ_BLOCK), blk, (size_t)2 * LS * KZ_BLOCK * sizeof(uint32_t), stream, P, ds->T, pixList, nPixPass, LS, c.beamEntries, c.beamCount);
+            c.beamGen = ds->tileGen; c.beamP0 = p0; c.beamN = nPixPass;
+            if (st) hipLaunchKernelGGL(kz_wf_beam_count, dim3((nPixPass + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, (const uint2 *)c.beamCount, nPixPass, ds->stats + 24);
+        }
+        uint32_t *fbQ = W.queue[0], *fbCount = W.counts + 8 * 520 - 8, *fbHead = fbCount + 1;      // rays of pixels whose list overflowed: the packet kernel's
+        const dim3 gList((items + KZ_BLOCK - 1) / KZ_BLOCK);
+#define KZ_LIST(ST, FX) hipLaunchKernelGGL((kz_wf_trace_list<ST, FX>), gList, blk, 0, stream, P, ds->T, W, items, Sp, (const uint2 *)c.beamEntries, (const uint2 *)c.beamCount, fbQ, fbCount, W.queue[2], W.counts + 0)
+        if (P.anyInvisibleLight) { if (st) KZ_LIST(true, true); else KZ_LIST(false, true); }
+        else { if (st) KZ_LIST(true, false); else KZ_LIST(false, false); }
+#undef KZ_LIST
+        KZ_PACKET4((const uint32_t *)fbQ, (const uint32_t *)fbCount, 0u, fbHead);
+    } else if (packet) {
         // (scenes with an invisible light: the epilogue queues the first hits on such a light for the walk-through launch below)
-#define KZ_PACKET(ST, FX) hipLaunchKernelGGL((kz_wf_trace_packet<ST, FX>), gPacket, blk, 0, stream, P, ds->T, W, (const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2, 8, W.queue[2], W.counts + 0)
-        if (P.anyInvisibleLight) { if (st) KZ_PACKET(true, true); else KZ_PACKET(false, true); }
-        else { if (st) KZ_PACKET(true, false); else KZ_PACKET(false, false); }
-#undef KZ_PACKET
+        KZ_PACKET4((const uint32_t *)nullptr, (const uint32_t *)nullptr, items, W.counts + 2);
     } else {
         trace(0, nullptr, nullptr, items, W.counts + 2, nullptr, nullptr);
         if (P.anyInvisibleLight) hipLaunchKernelGGL(kz_wf_primary_fix, gShade, blk, 0, stream, P, ds->T, W, items, W.queue[2], W.counts + 0);
     }
+#undef KZ_PACKET4
+#undef KZ_PACKET
     if (P.anyInvisibleLight) trace(1, W.queue[2], W.counts + 0, 0u, W.counts + 3, nullptr, nullptr);      // H6 walk-through of the first hit
     { int rc_ = stageMark(c, stream, 1); if (rc_) return rc_; }
     const uint32_t *cur = nullptr, *curCount = nullptr;
@@ -973,7 +1002,9 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     // is free now plus what this replica already holds for the purpose (another process or replica may own the rest).
     int nCtx = pipeline == 2 ? (opts->passesInFlight ? opts->passesInFlight : KZ_DEFAULT_PASSES_IN_FLIGHT) : 1;
     const size_t perItem = (pipeline == 2 ? KZ_STATE_BYTES_PER_ITEM : 0) + KZ_SAMPLE_BYTES_PER_ITEM;
-    const size_t perPixel = tapSums ? KZ_TAP_BYTES_PER_PIXEL : 0;
+    // camera rays by pixel beams: a pinhole camera with an affine sample map, a stack that fits LDS twice, unless the caller asks otherwise
+    const bool beams = pipeline == 2 && P.beamOk && tune.packet != 1 && tune.packet != 2 && P.maxDepth > 0;
+    const size_t perPixel = (tapSums ? KZ_TAP_BYTES_PER_PIXEL : 0) + (beams ? (KZ_BEAM_CAP + 1) * sizeof(uint2) : 0);
     size_t limit = opts->maxStateBytes;
     if (!limit) {
         size_t freeB = 0, totalB = 0;
@@ -1057,7 +1088,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
             const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
             PassCtx &c = ds->ctx[ci];
             hipStream_t pst = multi ? ds->passStream[ci] : stream;
-            if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, pst))) return rc;
+            if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, beams, pst))) return rc;
             if (ds->eventsUsed == ds->events.size()) {
                 EventPair ep; HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); ds->events.push_back(ep);
             }
@@ -1065,7 +1096,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
             const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
             float *sJx = c.samp, *sJy = c.samp + c.sampCap, *sR = c.samp + 2 * c.sampCap, *sG = c.samp + 3 * c.sampCap, *sB = c.samp + 4 * c.sampCap;
             HIP_TRY(hipEventRecord(ep.a, pst));
-            if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, s, Sp, (uint32_t)items, tune))) return rc; }
+            if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams))) return rc; }
             else {
 #define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, pixList, (uint32_t)items, Sp, s, \
                                            (const uint32_t *)nullptr, sJx, sJy, sR, sG, sB, ds->stats)
@@ -1311,6 +1342,8 @@ int kz_get_stats(KzScene *scene, KzStats *out, int reset) {
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, ds->stats, sizeof h, hipMemcpyDeviceToHost));
+    { unsigned long long b[3]; HIP_TRY(hipMemcpy(b, ds->stats + 24, sizeof b, hipMemcpyDeviceToHost)); out->beamPixels = b[0]; out->beamListEntries = b[1]; out->beamCompletePixels = b[2];
+      if (reset) HIP_TRY(hipMemset(ds->stats + 24, 0, sizeof b)); }
     out->samples = h[0]; out->rays = h[1]; out->nodeVisits = h[2]; out->triTests = h[3]; out->shadedHits = h[4]; out->lightSamples = h[5]; out->droppedSamples = h[6];
 #ifdef KZ_LANESTAT
     {

@@ -327,6 +327,25 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
         if (!mat4inv(M, Mi)) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "singular projection (fov %g, clip %g..%g)", c.fov, c.nearClip, c.farClip); }
         for (int i = 0; i < 16; ++i) p.s2c[i] = (float)Mi[i];
     }
+    {   // pixel beams (kz_wf_beam): only for a pinhole camera whose homogeneous divide does not depend on the sample position and an affine c2w
+        const float *m = p.s2c, *w = p.c2w;
+        p.beamOk = 0;
+        const float tiny = 1e-9f * std::fabs(m[15]);          // (a numerically formed inverse leaves 1e-17s where the zeros are: far inside the beams' margins)
+        if (c.type != KZ_CAMERA_THINLENS && std::fabs(m[12]) <= tiny && std::fabs(m[13]) <= tiny && m[15] != 0.f && w[12] == 0.f && w[13] == 0.f && w[14] == 0.f && w[15] != 0.f) {
+            const double rw = m[15];
+            const double A[3] = {m[3] / rw, m[7] / rw, m[11] / rw}, U[3] = {m[0] * (double)p.invW / rw, m[4] * (double)p.invW / rw, m[8] * (double)p.invW / rw},
+                         V[3] = {m[1] * (double)p.invH / rw, m[5] * (double)p.invH / rw, m[9] * (double)p.invH / rw};
+            bool fin = true;
+            for (int r = 0; r < 3; ++r) {
+                p.beamA[r] = (float)(w[4 * r] * A[0] + w[4 * r + 1] * A[1] + w[4 * r + 2] * A[2]);
+                p.beamU[r] = (float)(w[4 * r] * U[0] + w[4 * r + 1] * U[1] + w[4 * r + 2] * U[2]);
+                p.beamV[r] = (float)(w[4 * r] * V[0] + w[4 * r + 1] * V[1] + w[4 * r + 2] * V[2]);
+                p.beamO[r] = w[4 * r + 3] / w[15];
+                fin = fin && std::isfinite(p.beamA[r]) && std::isfinite(p.beamU[r]) && std::isfinite(p.beamV[r]) && std::isfinite(p.beamO[r]);
+            }
+            p.beamOk = fin ? 1 : 0;
+        }
+    }
     // ---- film filter table (block.cpp:13-21)
     const KzFilter &rf = c.rfilter;
     p.filterRadius = rf.radius;

@@ -109,6 +109,9 @@ struct KzParams {
     int32_t shadowFast; uint32_t nIlTris; float ilLo[3], ilHi[3];
     int32_t anyInvisibleLight; int32_t stackDepth;
     uint32_t ilGidLo, ilGidSpan;         // every triangle of an invisible light has gid - ilGidLo <= ilGidSpan (a prefilter: other triangles may too)
+    // pixel beams of a pinhole camera whose sample -> near-plane map is affine (kz_wf_beam): nearP(sx, sy) = beamA + sx * beamU + sy * beamV in WORLD
+    // axes (the 3x3 of c2w applied), apex beamO
+    int32_t beamOk; float beamO[3], beamA[3], beamU[3], beamV[3];
     int32_t bsdfExt;                     // any BSDF row beyond constant diffuse / kazenstandard: other models, texture-backed
                                          // parameters, normal maps (selects the larger kernel variants)
 };

@@ -831,6 +831,195 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     if (STATS) wfStatsFlush(W.stats, cn, 0);
 }
 
+// ---- pixel beams for the camera rays: one traversal per PIXEL, triangle tests per SAMPLE ----------------------------------------
+// The S camera rays of a pixel in a pass differ by sub-pixel jitter only; kz_wf_trace_packet lets every one of them repeat the same
+// ~35 node steps (61 VALU wave-instructions per ray on C4). Here the node work is done ONCE per pixel, by one lane:
+//   kz_wf_beam        one lane = one pixel of the pass. Every sample position of the pixel lies in [px, px+1] x [py, py+1], and for a pinhole
+//                     camera with an affine sample -> near-plane map (KzParams.beamOk) the rays of the pixel are the rays of the pyramid
+//                     from the pinhole through the pixel's corners: the BEAM. The lane walks the BVH4 with the beam's CENTRAL ray against
+//                     boxes padded by rho * (distance of the box's farthest point from the pinhole), rho = the largest chord between the
+//                     central and a corner unit direction: a ray of the beam at distance s from the pinhole is within rho * s of the central
+//                     ray's point at the same distance, so the central ray touches the padded box of every box a ray of the beam touches,
+//                     and enters it no later. It writes the LEAVES it reaches, nearest first, with that entry distance as a lower bound
+//                     of the ray parameter, until the list (KZ_BEAM_CAP) or its stack (KZ_BEAM_STACK) is full, and t_valid = the smallest
+//                     bound of anything it left unexplored (infinity when it saw everything): every leaf that a ray of the beam can enter
+//                     before t_valid is on the list.
+//   kz_wf_trace_list  one lane = one camera ray: runs Mesh::rayIntersect (triTest, unchanged) on the triangles of the pixel's leaves in
+//                     list order, skipping a leaf whose bound is behind the lane's closest hit so far. A hit in front of t_valid IS the
+//                     closest hit (a nearer one would lie in a leaf that begins before it, hence on the list), and so is "no hit" when
+//                     nothing was left unexplored; (t, u, v, triangle) come from the same function with the same tie rule: bit-identical
+//                     to kz_wf_trace / kz_wf_trace_packet. The other rays go to fbQueue for the packet kernel with what is known about them
+//                     (nothing in front of t_valid: tmin; the hit found so far: tmax).
+// The lists depend on the pixels only: a pass context keeps them for the pixel chunk it last built them for.
+#define KZ_BEAM_CAP 32
+#define KZ_BEAM_STACK 32              // open entries (ref + key) per beam in LDS
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T, const uint32_t *__restrict__ pixList, uint32_t nPix, int LS,
+                                                       uint2 *__restrict__ entries, uint2 *__restrict__ heads) {
+    // BEST-FIRST order: the open entries (child ref + entry distance of its padded box) of a lane form an unsorted set in LDS
+    // ([LS][KZ_BLOCK] refs, then keys); the lane always takes the NEAREST one next, so the leaves reach the list in the order of their
+    // bound and "everything unexplored begins behind the last key taken" holds at any time. A set that is full drops its farthest entry
+    // (t_valid then ends there at the latest).
+    extern __shared__ uint32_t s_stack[];
+    uint32_t *stk = s_stack + threadIdx.x, *kst = s_stack + LS * KZ_BLOCK + threadIdx.x;
+    const uint32_t pl = blockIdx.x * KZ_BLOCK + threadIdx.x;
+    const uint32_t root = P.rootRef4;
+    bool active = pl < nPix && root != 0xFFFFFFFFu;
+    const uint32_t pxy = pl < nPix ? pixList[pl] : 0u;
+    const float fx = (float)(pxy & 0xffffu), fy = (float)(pxy >> 16);
+    const V3 O = mk(P.beamO[0], P.beamO[1], P.beamO[2]), U = mk(P.beamU[0], P.beamU[1], P.beamU[2]), V = mk(P.beamV[0], P.beamV[1], P.beamV[2]);
+    // unit directions through the pixel's centre and corners (world axes; nearP = A + sx U + sy V)
+    const V3 c00 = mk(P.beamA[0], P.beamA[1], P.beamA[2]) + fx * U + fy * V;
+    const V3 uc = normalized(c00 + 0.5f * U + 0.5f * V);
+    float rho = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const V3 e = normalized(c00 + (float)(k & 1) * U + (float)(k >> 1) * V) - uc; rho = fmaxf(rho, sqrtf(dot(e, e))); }
+    rho = rho * 1.01f + 2e-6f;                            // + the rounding of a camera ray's direction (a few 1e-7) and of the corners
+    // slab constants of the central ray (a zero component gets a tiny signed stand-in, as in kz_wf_trace)
+    const float rx = 1.0f / (fabsf(uc.x) < 1e-20f ? copysignf(1e-20f, uc.x) : uc.x), ry = 1.0f / (fabsf(uc.y) < 1e-20f ? copysignf(1e-20f, uc.y) : uc.y),
+                rz = 1.0f / (fabsf(uc.z) < 1e-20f ? copysignf(1e-20f, uc.z) : uc.z);
+    float tvalid = KZ_INF;                                // distance from the pinhole before which nothing is left unexplored
+    uint32_t cur = root, count = 0; float curKey = 0.f; int n = 0;
+    uint2 *myList = entries + (size_t)pl * KZ_BEAM_CAP;
+    auto push = [&](uint32_t ref, uint32_t keyBits) {
+        if (n < LS) { stk[n * KZ_BLOCK] = ref; kst[n * KZ_BLOCK] = keyBits; ++n; return; }
+        int im = 0; uint32_t km = kst[0];                 // full: the farthest of the set and the newcomer stays out
+        for (int i = 1; i < LS; ++i) { const uint32_t k = kst[i * KZ_BLOCK]; if (k > km) { km = k; im = i; } }
+        if (keyBits < km) { stk[im * KZ_BLOCK] = ref; kst[im * KZ_BLOCK] = keyBits; tvalid = fminf(tvalid, __uint_as_float(km)); }
+        else tvalid = fminf(tvalid, __uint_as_float(keyBits));
+    };
+    auto popMin = [&]() -> bool {
+        if (n == 0) return false;
+        int im = 0; uint32_t km = kst[0];
+        for (int i = 1; i < n; ++i) { const uint32_t k = kst[i * KZ_BLOCK]; if (k < km) { km = k; im = i; } }
+        if (!(__uint_as_float(km) < tvalid)) return false;                     // what begins behind t_valid cannot be made use of
+        cur = stk[im * KZ_BLOCK]; curKey = __uint_as_float(km);
+        --n;
+        if (im != n) { stk[im * KZ_BLOCK] = stk[n * KZ_BLOCK]; kst[im * KZ_BLOCK] = kst[n * KZ_BLOCK]; }
+        return true;
+    };
+    for (;;) {
+        // ---- node phase
+        for (;;) {
+            const bool inner = active && !(cur & 0x80000000u);
+            if (__ballot(inner) == 0ull) break;
+            if (inner) {
+                const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + cur);
+                const uint4 q0 = np[0], q1 = np[1], q2 = np[2], refs = np[3];
+                const float sX = __uint_as_float(q0.w), sY = __uint_as_float(q2.z), sZ = __uint_as_float(q2.w);
+                const float pX = __uint_as_float(q0.x) - O.x, pY = __uint_as_float(q0.y) - O.y, pZ = __uint_as_float(q0.z) - O.z;     // box coordinates relative to the pinhole
+                const uint32_t r[4] = {refs.x, refs.y, refs.z, refs.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float qlx = (float)((q1.x >> (8 * i)) & 0xffu), qly = (float)((q1.y >> (8 * i)) & 0xffu), qlz = (float)((q1.z >> (8 * i)) & 0xffu);
+                    const float qhx = (float)((q1.w >> (8 * i)) & 0xffu), qhy = (float)((q2.x >> (8 * i)) & 0xffu), qhz = (float)((q2.y >> (8 * i)) & 0xffu);
+                    const float lx = fmaf(qlx, sX, pX), ly = fmaf(qly, sY, pY), lz = fmaf(qlz, sZ, pZ), hx = fmaf(qhx, sX, pX), hy = fmaf(qhy, sY, pY), hz = fmaf(qhz, sZ, pZ);
+                    // pad: rho x an upper bound of the distance of the box's farthest point, + 2^-19 of the coordinates (the quantised planes
+                    // are conservative for the kernels' own slab expression; this form rounds differently)
+                    const float reach = fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy)) + fmaxf(fabsf(lz), fabsf(hz));
+                    const float pad = rho * reach + 1.9e-6f * (reach + fabsf(O.x) + fabsf(O.y) + fabsf(O.z));
+                    const float t0x = (lx - pad) * rx, t1x = (hx + pad) * rx, t0y = (ly - pad) * ry, t1y = (hy + pad) * ry, t0z = (lz - pad) * rz, t1z = (hz + pad) * rz;
+                    const float nn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
+                    const float ff = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * 1.0000004f;
+                    // a child's bound is not below its parent's (its padded box lies inside the parent's; the max guards the rounding)
+                    const float key = fmaxf(nn * 0.999999f, curKey);
+                    if (qhx >= qlx && nn <= ff && key < tvalid) push(r[i], __float_as_uint(key));      // (an empty slot has qlo = 255 > qhi = 0)
+                }
+                if (!popMin()) active = false;
+            }
+        }
+        // ---- leaf phase
+        if (active && (cur & 0x80000000u)) {
+            if (count < KZ_BEAM_CAP) {
+                myList[count] = make_uint2(cur, __float_as_uint(curKey)); ++count;
+                if (!popMin()) active = false;
+            } else { tvalid = fminf(tvalid, curKey); active = false; }      // the list is full: this leaf and all that is open begin no nearer
+        }
+        if (!__any(active)) break;
+    }
+    if (pl < nPix) heads[pl] = make_uint2(count, __float_as_uint(tvalid));      // (distances from the pinhole: kz_wf_trace_list scales its ray parameters by |d|)
+}
+
+// stats only: pixels with a list, list entries, pixels whose list is complete (t_valid = infinity)
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam_count(const uint2 *__restrict__ heads, uint32_t nPix, unsigned long long *__restrict__ out) {
+    const uint32_t pl = blockIdx.x * KZ_BLOCK + threadIdx.x;
+    const uint2 h = pl < nPix ? heads[pl] : make_uint2(0u, 0u);
+    unsigned long long v[3] = {pl < nPix ? 1ull : 0ull, (unsigned long long)h.x, (pl < nPix && !(__uint_as_float(h.y) < KZ_INF)) ? 1ull : 0ull};
+    for (int k = 0; k < 3; ++k) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[k], x);
+    }
+}
+
+// closest hit of the camera rays from the pixel lists; rays the lists cannot decide go to fbQueue (kz_wf_trace_packet takes them)
+template <bool STATS, bool FIX>
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTables T, KzWf W, uint32_t nItems, uint32_t S, const uint2 *__restrict__ entries,
+                                                             const uint2 *__restrict__ heads, uint32_t *__restrict__ fbQueue, uint32_t *__restrict__ fbCount,
+                                                             uint32_t *__restrict__ fixQueue, uint32_t *__restrict__ fixCount) {
+    const uint32_t slot = blockIdx.x * KZ_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    const bool have = slot < nItems;
+    bool undecided = false;
+    if (have) {
+        const uint32_t pl = slot / S;
+        const uint2 head = heads[pl];
+        const float tvalidDist = __uint_as_float(head.y);                     // the list's bounds are DISTANCES from the pinhole: parameter x |d|
+        const float4 a = W.rayA[slot], b = W.rayB[slot];
+        const V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
+        const float tmin = a.w;
+        float tmax = b.w;
+        bool found = false; float bt = KZ_INF, bu = 0.f, bv = 0.f; uint32_t bgid = 0;
+        const bool finite = rayIsFinite(o, d);
+        const float len = sqrtf(dot(d, d)), lenUp = len * 1.000002f;
+        if (finite) {
+            const uint2 *lst = entries + (size_t)pl * KZ_BEAM_CAP;
+            for (uint32_t j = 0; j < head.x; ++j) {
+                const uint2 e = lst[j];
+                if (__uint_as_float(e.y) > tmax * lenUp) continue;         // the leaf begins behind the closest hit so far
+                const uint32_t start = (e.x & 0x7fffffffu) >> 3, cnt = (e.x & 7u) + 1;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    float t, u, v; uint32_t g;
+                    if (STATS) cn.tris++;
+                    if (!triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, g)) continue;
+                    if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; bgid = g; tmax = t; }
+                }
+            }
+        }
+        // decided: a hit in front of everything unexplored, or nothing unexplored at all (a non-finite ray hits nothing)
+        undecided = finite && !(found ? bt * lenUp < tvalidDist : !(tvalidDist < KZ_INF));
+        if (STATS && !undecided) cn.rays++;                                    // (an undecided ray is counted by the kernel that decides it)
+        if (undecided) {
+            // what the list has established travels with the ray: nothing is hit in front of t_valid, and nothing behind the hit found matters
+            W.rayA[slot] = make_float4(a.x, a.y, a.z, fmaxf(tmin, tvalidDist / lenUp * 0.999998f));
+            if (found) W.rayB[slot] = make_float4(b.x, b.y, b.z, bt);
+        } else {
+            W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(bgid)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+            if (FIX && found && bgid - P.ilGidLo <= P.ilGidSpan) {              // (rare) may be a triangle of an invisible light: see kz_wf_trace_packet
+                const int li = lightOfGid(T, bgid);
+                if (li >= 0 && !T.lights[li].primaryVisibility) {
+                    RawHit rh; rh.t = bt; rh.u = bu; rh.v = bv; rh.tri = 0; rh.gid = bgid;
+                    Its its; postIntersect<false>(T, rh, its);
+                    const V3 no = its.p + P.traceBias * d;
+                    W.shA[slot] = make_float4(no.x, no.y, no.z, KZ_INF);
+                    W.shB[slot] = make_float4(d.x, d.y, d.z, KZ_EPSILON);
+                    fixQueue[atomicAdd(fixCount, 1u)] = slot;
+                }
+            }
+        }
+    }
+    {   // undecided rays: appended in slot order within the wave (neighbours in the queue stay neighbours in the image)
+        const unsigned long long m = __ballot(undecided);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(fbCount, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (undecided) fbQueue[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = slot;
+        }
+    }
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+}
+
 // ---- final: the ray after the last bounce contributes only the background on a miss (integrator.cpp:315-318) ------------
 __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_final(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ countPtr) {
     const uint32_t count = *countPtr;

@@ -35,24 +35,24 @@ __global__ __launch_bounds__(256) void loop(int iters, float seed, Stamp *__rest
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int rep = 0; rep < KZ_BODY; ++rep) {
-        if (V == 0)
-            asm volatile(
-                "v_fma_f32 %0, %0, %16, %17\n v_fma_f32 %1, %1, %16, %17\n v_fma_f32 %2, %2, %16, %17\n v_fma_f32 %3, %3, %16, %17\n"
-                "v_fma_f32 %4, %4, %16, %17\n v_fma_f32 %5, %5, %16, %17\n v_fma_f32 %6, %6, %16, %17\n v_fma_f32 %7, %7, %16, %17\n"
-                "v_fma_f32 %8, %8, %16, %17\n v_fma_f32 %9, %9, %16, %17\n v_fma_f32 %10, %10, %16, %17\n v_fma_f32 %11, %11, %16, %17\n"
-                "v_fma_f32 %12, %12, %16, %17\n v_fma_f32 %13, %13, %16, %17\n v_fma_f32 %14, %14, %16, %17\n v_fma_f32 %15, %15, %16, %17\n"
-                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
-                  "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7)
-                : "v"(m), "v"(c));
-        else
-            asm volatile(
-                "v_max3_f32 %0, %0, %16, %17\n v_max3_f32 %1, %1, %16, %17\n v_max3_f32 %2, %2, %16, %17\n v_max3_f32 %3, %3, %16, %17\n"
-                "v_max3_f32 %4, %4, %16, %17\n v_max3_f32 %5, %5, %16, %17\n v_max3_f32 %6, %6, %16, %17\n v_max3_f32 %7, %7, %16, %17\n"
-                "v_max3_f32 %8, %8, %16, %17\n v_max3_f32 %9, %9, %16, %17\n v_max3_f32 %10, %10, %16, %17\n v_max3_f32 %11, %11, %16, %17\n"
-                "v_max3_f32 %12, %12, %16, %17\n v_max3_f32 %13, %13, %16, %17\n v_max3_f32 %14, %14, %16, %17\n v_max3_f32 %15, %15, %16, %17\n"
-                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
-                  "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7)
-                : "v"(m), "v"(c));
+#define KZ_OPS16(OP, TAIL) asm volatile( \
+                OP " %0, " TAIL(0) "\n " OP " %1, " TAIL(1) "\n " OP " %2, " TAIL(2) "\n " OP " %3, " TAIL(3) "\n " OP " %4, " TAIL(4) "\n " OP " %5, " TAIL(5) "\n " OP " %6, " TAIL(6) "\n " OP " %7, " TAIL(7) "\n " \
+                OP " %8, " TAIL(8) "\n " OP " %9, " TAIL(9) "\n " OP " %10, " TAIL(10) "\n " OP " %11, " TAIL(11) "\n " OP " %12, " TAIL(12) "\n " OP " %13, " TAIL(13) "\n " OP " %14, " TAIL(14) "\n " OP " %15, " TAIL(15) "\n" \
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : "v"(m), "v"(c))
+#define T_D_M_C(i) "%" #i ", %16, %17"          /* dst, m, c: three distinct VGPR sources, one of them the destination (a chain per register) */
+#define T_M_C_C(i) "%16, %17, %17"              /* m, c, c: two distinct sources, no chain (the form of round 2's valu_peak.hip) */
+#define T_D_M_M(i) "%" #i ", %16, %16"          /* dst, m, m: two distinct sources */
+#define T_D_D_D(i) "%" #i ", %" #i ", %" #i     /* one distinct source */
+#define T_M_C(i) "%16, %17"
+#define T_D_M(i) "%" #i ", %16"
+        if (V == 0) KZ_OPS16("v_fma_f32", T_D_M_C);
+        else if (V == 1) KZ_OPS16("v_max3_f32", T_D_M_C);
+        else if (V == 2) KZ_OPS16("v_fma_f32", T_M_C_C);
+        else if (V == 3) KZ_OPS16("v_fma_f32", T_D_M_M);
+        else if (V == 4) KZ_OPS16("v_fma_f32", T_D_D_D);
+        else if (V == 5) KZ_OPS16("v_mul_f32", T_D_M);
+        else if (V == 6) KZ_OPS16("v_mul_f32", T_M_C);
+        else KZ_OPS16("v_max3_f32", T_M_C_C);
       }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -71,13 +71,16 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf("{\"device\": \"%s\", \"cus\": %d, \"iters\": %d, \"results\": [\n", prop.name, nCU, iters);
     bool first = true;
-    for (int v = 0; v < 2; ++v)
-        for (int wps : {1, 2, 4, 8}) {
+    static const char *opName[] = {"v_fma_f32 d,d,m,c (3 distinct sources)", "v_max3_f32 d,d,m,c (3 distinct)", "v_fma_f32 d,m,c,c (2 distinct, no chain)", "v_fma_f32 d,d,m,m (2 distinct)",
+                                   "v_fma_f32 d,d,d,d (1 distinct)", "v_mul_f32 d,d,m (2 distinct)", "v_mul_f32 d,m,c (2 distinct, no chain)", "v_max3_f32 d,m,c,c (2 distinct, no chain)"};
+    for (int v = 0; v < 8; ++v)
+        for (int wps : {1, 2, 8}) {
             const int grid = nCU * wps;                     // 256-thread workgroups: one wave per SIMD each, wps of them per CU
-            auto launch = [&]() { if (v == 0) hipLaunchKernelGGL(loop<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dStamps, dSink);
-                                  else hipLaunchKernelGGL(loop<1>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dStamps, dSink); };
+            auto launch = [&]() { switch (v) {
+#define L(K) case K: hipLaunchKernelGGL(loop<K>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dStamps, dSink); break;
+                L(0) L(1) L(2) L(3) L(4) L(5) L(6) default: hipLaunchKernelGGL(loop<7>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dStamps, dSink); } };
             int occ = 0;
-            if (v == 0) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, loop<0>, 256, 0)); else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, loop<1>, 256, 0));
+            CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, loop<0>, 256, 0));
             // sustained load first: back-to-back launches for warmSeconds
             launch(); CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
@@ -101,7 +104,7 @@ int main(int argc, char **argv) {
             printf("%s{\"op\": \"%s\", \"waves_per_simd\": %d, \"occupancy_blocks_per_cu\": %d, \"kernel_ms\": %.4f, \"median_wave_shader_cycles\": %.0f, \"median_wave_us\": %.2f, "
                    "\"all_waves_span_over_median_wave\": %.3f, \"shader_clock_GHz_in_kernel\": %.4f, \"cycles_per_wave_instr_per_simd\": %.4f, "
                    "\"wave_instr_per_shader_cycle_per_simd\": %.4f, \"chip_G_wave_instr_per_s_wall\": %.1f, \"chip_G_wave_instr_per_s_at_2.4GHz_and_2cyc\": %.1f}",
-                   first ? "" : ",\n", v == 0 ? "v_fma_f32" : "v_max3_f32", wps, occ, ms, mc, mr / 100.0, (double)(rmax - rmin) / mr, mclk / 1e9, mc / (wps * instrPerWave),
+                   first ? "" : ",\n", opName[v], wps, occ, ms, mc, mr / 100.0, (double)(rmax - rmin) / mr, mclk / 1e9, mc / (wps * instrPerWave),
                    wps * instrPerWave / mc, total / (ms * 1e-3) / 1e9, nCU * 4 * 0.5 * 2.4);
             first = false;
         }

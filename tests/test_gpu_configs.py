@@ -183,7 +183,7 @@ def test_state_budget_and_pass_options(gpu_lib, kz, O):
     info = sc.last_pass_info()
     assert (info["passes"], info["sppPerPass"], info["pixelsPerPass"]) == (8, 24, 960)
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
-    per_item, per_pixel = 8 * 16 + 16 + 12 + 20, 25 * 16            # path state + sample record per item, film tap sums per pixel
+    per_item, per_pixel = 8 * 16 + 16 + 12 + 20, 25 * 16 + 33 * 8              # path state + sample record per item; film tap sums + beam list per pixel
     cap = 2 * npx * (3 * per_item + per_pixel)
     sc.render(max_state_bytes=cap)                                    # room for two contexts of 3 spp
     info = sc.last_pass_info()

@@ -240,7 +240,9 @@ def test_image_matches_oracle(gpu_lib, kz, O, name):
     assert st["samples"] == so["samples"] and st["droppedSamples"] == so["droppedSamples"]
     assert abs(st["lightSamples"] - so["lightSamples"]) <= 1e-5 * so["lightSamples"] + 2      # an ulp can flip one roulette decision
     assert 0.5 * so["rays"] <= st["rays"] <= so["rays"] and 0.9 * so["shadedHits"] <= st["shadedHits"] <= so["shadedHits"]
-    assert st["nodeVisits"] <= 1.1 * so["nodeVisits"] and st["triTests"] <= 1.1 * so["triTests"]
+    # (camera rays take the triangles of their pixel's leaf list - kz_wf_beam - instead of walking the tree: far fewer node visits, somewhat more triangle tests)
+    assert st["nodeVisits"] <= 1.1 * so["nodeVisits"] and st["triTests"] <= 1.5 * so["triTests"]
+    assert 64 * st["nodeVisits"] + 48 * st["triTests"] <= 1.1 * (64 * so["nodeVisits"] + 48 * so["triTests"])
     # the reference-shaped megakernel does exactly the oracle's work and produces the same film bit for bit
     sc.stats(reset=True)
     sc.render(pipeline=1)
