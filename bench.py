@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the path_mis hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--strong]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (BASELINE.json configs[3], "C4"): 1 M random triangles + 8 mesh lights in a closed diffuse room,
@@ -13,8 +13,14 @@ N GPUs (north_star: "the image tile grid shards embarrassingly across
 tiles"): one process per GPU, each with a full scene replica; the 64x64 tiles of the frame are dealt over the ranks by area
 (kz_deal_tiles, the dealing kz_render_multi uses in-process) and each rank renders 128*N spp of ITS tiles per step, so
 per-GPU work is fixed (weak scaling). There is NO device collective anywhere: torch.distributed runs on the CPU (gloo) for the
-barriers around the timed region and for the one host gather of the films after it (shard.gather_films = ImageBlock::put(ImageBlock&),
-block.cpp:87-96, in rank order). Scene tables, BVH and sampler tables are resident in HBM before the timed region starts.
+barriers around the timed region and for the one host gather after it: every rank downloads the packed film rects of ITS tiles
+(kz_film_download_tiles: one film's worth of texels in all, however many ranks) and rank 0 adds them in tile order
+(shard.gather_tiles = ImageBlock::put(ImageBlock&), block.cpp:87-96). `value` is the render rate of the timed steps; `end_to_end`
+adds that gather (download + gloo + merge, max over ranks) to the same steps' time. Scene tables, BVH and sampler tables are resident
+in HBM before the timed region starts.
+
+--strong: BASELINE.json configs[4], "C5" - the SAME scene at 3840x2160 x 4096 spp as ONE fixed job: a step is the whole frame, every rank
+renders all 4096 spp of its tiles (scaling "strong": the work per GPU shrinks with N). Not the default: at N = 1 the driver's run must be C4.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
 """
@@ -32,6 +38,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); 6.29 TB/s measured copy
 SPP_PER_RANK_STEP = 128        # two passes of 64 spp per call at 1920x1080 (2^27 items per pass)
 W, H, NTRIS, SPP = 1920, 1080, 1000000, 1024
+W5, H5, SPP5 = 3840, 2160, 4096
 TILE = 64
 
 
@@ -88,12 +95,17 @@ def load_profile_facts(live_ms_per_pass_alone):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--tris", type=int, default=NTRIS)
+    ap.add_argument("--strong", action="store_true", help="C5: 3840x2160 x 4096 spp as one fixed job split over the ranks (a step = the frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 1 if args.strong else 6
+    if args.warmup is None:
+        args.warmup = 0 if args.strong else 1
     commit = os.environ.get("GRAFT_HEAD") or git_head()          # before torch / HIP are loaded: no fork from a process that has initialised the GPU
 
     # stdout carries ONE line, the JSON record: everything else that may write to file descriptor 1 (gloo's "[Gloo] Rank ... is
@@ -121,8 +133,9 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)        # CPU process group: barriers + the host gather
 
     kz = importlib.import_module("nano-kazen_amd")
+    Wd, Hd, spp_table = (W5, H5, SPP5) if args.strong else (W, H, SPP)
     t0 = time.time()
-    desc = kz.scenes.random_triangles(args.tris, W, H, SPP, sampler="pmj02bn", seed=1)
+    desc = kz.scenes.random_triangles(args.tris, Wd, Hd, spp_table, sampler="pmj02bn", seed=1)
     t1 = time.time()
     scene = kz.Scene(desc)
     bvh = scene.bvh_info()
@@ -132,12 +145,16 @@ def main():
         log("scene: %d tris, synth %.1fs, BVH %d nodes depth %d SAH %.1f built in %.2fs, upload+build %.1fs"
             % (desc.n_tris(), t1 - t0, bvh["nNodes"], bvh["maxDepth"], bvh["sahCost"], bvh["buildSeconds"], t2 - t1))
 
-    tiles = kz.shard.deal_tiles(W, H, world, rank, TILE) if world > 1 else None
-    my_pixels = W * H if tiles is None else sum(t[2] * t[3] for t in tiles)
-    spp_step = SPP_PER_RANK_STEP * world                  # weak scaling: a rank owns 1/N of the pixels and renders N x the spp
-    if spp_step > SPP:
-        raise SystemExit("bench.py: %d ranks x %d spp per step exceed the %d-spp sampler table (use <= %d ranks)"
-                         % (world, SPP_PER_RANK_STEP, SPP, SPP // SPP_PER_RANK_STEP))
+    tiles = kz.shard.deal_tiles(Wd, Hd, world, rank, TILE)
+    render_tiles = tiles if world > 1 else None           # (one rank: the whole frame as one tile set - the same pixels, no list to walk)
+    my_pixels = sum(t[2] * t[3] for t in tiles)
+    if args.strong:
+        spp_step = spp_table                              # the whole job every step
+    else:
+        spp_step = SPP_PER_RANK_STEP * world              # weak scaling: a rank owns 1/N of the pixels and renders N x the spp
+        if spp_step > spp_table:
+            raise SystemExit("bench.py: %d ranks x %d spp per step exceed the %d-spp sampler table (use <= %d ranks)"
+                             % (world, SPP_PER_RANK_STEP, spp_table, spp_table // SPP_PER_RANK_STEP))
     stream = torch.cuda.current_stream().cuda_stream
     kw = {}
     if shared_device:
@@ -145,13 +162,13 @@ def main():
 
     def step(k, accumulate=True):
         # sample indices [s0, s0 + spp_step) modulo the table: a slice that wraps is rendered as its two halves
-        s0 = (k * spp_step) % SPP
+        s0 = (k * spp_step) % spp_table
         s1 = s0 + spp_step
-        if s1 <= SPP:
-            scene.render(s0, s1, tiles=tiles, accumulate=accumulate, stream=stream, **kw)
+        if s1 <= spp_table:
+            scene.render(s0, s1, tiles=render_tiles, accumulate=accumulate, stream=stream, **kw)
         else:
-            scene.render(s0, SPP, tiles=tiles, accumulate=accumulate, stream=stream, **kw)
-            scene.render(0, s1 - SPP, tiles=tiles, accumulate=True, stream=stream, **kw)
+            scene.render(s0, spp_table, tiles=render_tiles, accumulate=accumulate, stream=stream, **kw)
+            scene.render(0, s1 - spp_table, tiles=render_tiles, accumulate=True, stream=stream, **kw)
 
     def barrier():
         # device first, then the ranks, then the device again: a rank must not start (or stop) its clock while its own earlier kernels still
@@ -164,6 +181,8 @@ def main():
     scene.film_clear(stream)
     for k in range(args.warmup):
         step(k)
+    if world > 1 and args.warmup:                         # the gather's one-time costs (pinned staging buffer, /dev/shm pages) belong to the warm-up too
+        kz.shard.gather_tiles(scene, tiles, scene.film_tiles(tiles), rank, world, TILE)
     barrier()
     t_start = time.perf_counter()
     for k in range(args.steps):
@@ -172,43 +191,53 @@ def main():
     elapsed = time.perf_counter() - t_start
     kernel_ms_last = scene.last_kernel_ms()      # hipEvents on the launch stream around the last call / its passes
     info = scene.last_pass_info()
-    # film merge: once per render, outside the per-step loop but reported (a HOST gather, not a data-path collective)
-    t_m = time.perf_counter()
-    film_np = kz.shard.gather_films(scene.film(), rank, world)
-    merge_s = time.perf_counter() - t_m
+    # the gather, once per render: packed rects of the rank's tiles (D2H through pinned memory), gloo to rank 0, merge in tile order
+    t_g = time.perf_counter()
+    if world > 1:
+        packed = scene.film_tiles(tiles)
+        t_d = time.perf_counter()
+        film_np = kz.shard.gather_tiles(scene, tiles, packed, rank, world, TILE)
+    else:                                                 # one device: its film IS the frame
+        film_np = packed = scene.film()
+        t_d = time.perf_counter()
+    gather_s = time.perf_counter() - t_g
+    free_b, total_b = torch.cuda.mem_get_info(device_index)
+    # audit line per rank: did N distinct devices render? was a rank capped by its state budget?
+    log("rank %d/%d: device %d (%s), %d tiles = %d px, %.3f s for %d steps, passes %s, free %.1f of %.1f GB, download %.1f MB in %.1f ms, gather %.1f ms"
+        % (rank, world, device_index, torch.cuda.get_device_name(device_index), len(tiles), my_pixels, elapsed, args.steps, info, free_b / 2**30, total_b / 2**30,
+           packed.nbytes / 1e6, 1e3 * (t_d - t_g), 1e3 * gather_s))
 
-    el = torch.tensor([elapsed], dtype=torch.float64)
+    el = torch.tensor([elapsed, gather_s], dtype=torch.float64)
     px = torch.tensor([my_pixels], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(px, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
+    elapsed, gather_max = float(el[0].item()), float(el[1].item())
     total_samples = float(px.item()) * spp_step * args.steps
     value = total_samples / elapsed / 1e6
 
     if rank == 0:
         # ---- one pass run alone: per-stage device times (with two passes in flight the stage events of a pass overlap the other's)
         pass_spp = info["sppPerPass"]
-        scene.render(0, pass_spp, tiles=tiles, accumulate=True, stream=stream, **kw)
+        scene.render(0, pass_spp, tiles=render_tiles, accumulate=True, stream=stream, **kw)
         scene.sync()
         stage_ms = scene.last_stage_ms()
         alone_ms = scene.last_kernel_ms()
-        launch_samples = my_pixels * pass_spp                       # one pass: the unit of kernel_ms, traffic and the counter facts
-        # ---- counters of the executed (wavefront) and of the reference-shaped (megakernel) pipelines on the last slice
+        launch_samples = info["pixelsPerPass"] * pass_spp            # one pass: the unit of kernel_ms, traffic and the counter facts
+        # ---- counters of the executed (wavefront) and of the reference-shaped (megakernel) pipelines on one slice
         scene.set_stats(True)
-        s0 = ((args.warmup + args.steps - 1) * spp_step) % SPP
-        s1 = min(SPP, s0 + spp_step)
+        s1 = min(spp_table, 128)
         scene.stats(reset=True)
-        scene.render(s0, s1, tiles=tiles, accumulate=True, stream=stream, **kw)
+        scene.render(0, s1, tiles=render_tiles, accumulate=True, stream=stream, **kw)
         scene.sync()
         st_exec = scene.stats(reset=True)
-        scene.render(s0, s1, tiles=tiles, accumulate=True, pipeline=1, stream=stream, **kw)      # same slice, reference-shaped
+        scene.render(0, min(s1, 16 if args.strong else s1), tiles=render_tiles, accumulate=True, pipeline=1, stream=stream, **kw)      # reference-shaped
         scene.sync()
         st_ref = scene.stats(reset=True)
         scene.set_stats(False)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(desc, args.cpu_seconds)
+            cpu = cpu_baseline(desc, args.cpu_seconds, Wd, Hd)
         bps_gpu_ref = algorithmic_bytes_per_sample(st_ref)
         bps = cpu["bytes_per_sample_oracle"] if cpu else bps_gpu_ref          # SURVEY 8d takes the counts from the CPU oracle
         bps_exec = algorithmic_bytes_per_sample(st_exec)
@@ -226,29 +255,40 @@ def main():
         del a, b
 
         # ---- roofline of the dominant kernel. The path is NOT HBM-bound (the 174 MB of tables sit in L2 / Infinity Cache and the
-        # traversal is a VALU-issue problem): the roof is the VALU issue rate of the chip, calibrated with
-        # scripts/micro/valu_peak.hip (independent v_fma_f32 at 8 waves/SIMD, the fastest VALU stream gfx950 sustains).
-        # achieved = VALU wave-instructions the closest-hit traversal launches of one pass execute (a property of code + input,
-        # counted by rocprofv3 SQ_INSTS_VALU in the committed profile) / their LIVE device time (hipEvents, one pass alone).
+        # traversal is a VALU-issue problem): the roof is the VALU issue rate of the chip. `peak` is the guide's
+        # (MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD-32) at the in-kernel clock scripts/micro/valu_clock.hip
+        # measures under a saturated VALU stream; the rates that microbenchmark actually reaches (two-source VOP2 91 %, three-source VOP3
+        # 49-55 % of it) are printed beside it. `achieved` = VALU wave-instructions the kz_wf_trace<0> launches of one pass execute
+        # (a property of code + input, counted by rocprofv3 SQ_INSTS_VALU in the committed profile) / their LIVE device time
+        # (hipEvents, one pass alone).
         facts, why = load_profile_facts(alone_ms)
         peak = json.load(open(os.path.join(ROOT, "profiles", "valu_peak.json")))
-        peak_rate = peak["fma_wave_instr_per_s"] / 1e9
+        peak_rate = peak["guide_peak_wave_instr_per_s"] / 1e9
+        n_bounce = max(0, desc.integrator["maxDepth"] - 1)
         roofline = {"bound": "valu", "unit": "G wave-instr/s", "peak": round(peak_rate, 1),
-                    "peak_source": "scripts/micro/valu_peak.hip v_fma_f32, 8 waves/SIMD, measured (profiles/%s)" % peak["profile"],
+                    "peak_source": "0.5 wave64 VALU instructions per cycle per SIMD (MI355X_MICROARCH.md) x 1024 SIMDs x the in-kernel clock measured under a "
+                                   "saturated VALU stream (profiles/%s)" % peak["profile"],
+                    "peak_measured": {"vop2_two_sources": round(peak["vop2_wave_instr_per_s"] / 1e9, 1), "vop3_three_sources": round(peak["vop3_wave_instr_per_s"] / 1e9, 1),
+                                      "node_step_mix": peak.get("node_mix_wave_instr_per_s") and round(peak["node_mix_wave_instr_per_s"] / 1e9, 1)},
                     "achieved": None, "frac": None, "traffic": None,
-                    "kernel": "closest-hit traversal = kz_wf_trace_packet (camera rays) + %d launches of kz_wf_trace<0> (bounce rays) per pass" % (desc.integrator["maxDepth"] - 1),
-                    "kernel_ms_one_pass_alone": stage_ms["trace_closest"], "pass_ms_in_flight": round(kernel_ms_last, 3),
+                    "kernel": "kz_wf_trace<0> (closest hit of the bounce rays), %d launches per pass" % n_bounce,
+                    "kernel_ms_one_pass_alone": stage_ms["trace_bounce"], "pass_ms_in_flight": round(kernel_ms_last, 3),
                     "pass_ms_alone": round(alone_ms, 3), "stages_ms_one_pass_alone": stage_ms, "samples_per_launch": launch_samples,
                     "passes_per_step": info["passes"], "passes_in_flight": info["passesInFlight"]}
         if facts:
-            ks = [facts["kernels"][n] for n in ("kz_wf_trace_packet", "kz_wf_trace<0>") if n in facts["kernels"]]     # camera rays + bounce rays
-            instr = sum(k["valu_wave_instr_per_sample"] for k in ks)
-            lanes = sum(k["valu_wave_instr_per_sample"] * k["lanes"] for k in ks) / instr
-            ach = instr * launch_samples / (stage_ms["trace_closest"] * 1e-3) / 1e9
-            roofline.update({"achieved": round(ach, 1), "frac": round(ach / peak_rate, 4),
-                             "lanes_active_per_valu_instr": round(lanes, 1), "useful_frac": round(ach / peak_rate * lanes / 64.0, 4),
-                             "mix_ceiling": peak.get("node_mix_wave_instr_per_s") and round(peak["node_mix_wave_instr_per_s"] / 1e9, 1),
-                             "traffic": facts.get("hbm_bytes_per_sample") and int(facts["hbm_bytes_per_sample"] * launch_samples),
+            k0 = facts["kernels"].get("kz_wf_trace<0>")
+            if k0:
+                ach = k0["valu_wave_instr_per_sample"] * launch_samples / (stage_ms["trace_bounce"] * 1e-3) / 1e9
+                roofline.update({"achieved": round(ach, 1), "frac": round(ach / peak_rate, 4), "lanes_active_per_valu_instr": k0["lanes"],
+                                 "useful_frac": round(ach / peak_rate * k0["lanes"] / 64.0, 4)})
+            # the whole closest-hit side (camera rays: beam lists + list kernel + packet kernel; bounce rays) on its own line
+            ks = [facts["kernels"][n] for n in ("kz_wf_trace_list", "kz_wf_trace_packet", "kz_wf_trace<0>") if n in facts["kernels"]]
+            if ks and stage_ms["trace_closest"] > 0:
+                instr = sum(k["valu_wave_instr_per_sample"] for k in ks)
+                ach_all = instr * launch_samples / (stage_ms["trace_closest"] * 1e-3) / 1e9
+                roofline["closest_hit_all_kernels"] = {"achieved": round(ach_all, 1), "frac": round(ach_all / peak_rate, 4), "ms": stage_ms["trace_closest"],
+                                                       "valu_wave_instr_per_sample": round(instr, 2)}
+            roofline.update({"traffic": facts.get("hbm_bytes_per_sample") and int(facts["hbm_bytes_per_sample"] * launch_samples),
                              "counter_facts": {"profile": facts["profile"], "commit": facts["commit"], "per_kernel": facts["kernels"]}})
         else:
             roofline["counter_facts_withheld"] = why
@@ -264,15 +304,19 @@ def main():
                                  "note": "algorithmic bytes are served by L1/L2/Infinity Cache, so this ratio is not a fraction of anything physical; "
                                          "the physical HBM figure is traffic_frac_of_peak"}
         rgb = scene.rgb(film_np)
-        out = {"metric": "Msamples/s (w*h*spp/s) at 1920x1080, 1 M-tri scene", "value": round(value, 3), "unit": "Msamples/s",
+        name = "C5" if args.strong else "C4"
+        out = {"metric": "Msamples/s (w*h*spp/s) at %dx%d, 1 M-tri scene" % (Wd, Hd), "value": round(value, 3), "unit": "Msamples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "C4: %d random triangles + 8 mesh lights in a closed diffuse room, %dx%d, pmj02bn %d spp, "
+               "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "end_to_end": {"value": round(total_samples / (elapsed + gather_max) / 1e6, 3), "unit": "Msamples/s", "gather_s": round(gather_max, 4),
+                              "gather": "every rank: D2H of the packed rects of its tiles (%.1f MB on rank 0); rank 0: merge of all ranks' rects from shared memory, rank after rank" % (packed.nbytes / 1e6),
+                              "render_s": round(elapsed, 4)},
+               "config": {"workload": "%s: %d random triangles + 8 mesh lights in a closed diffuse room, %dx%d, pmj02bn %d spp, "
                                       "path_mis maxDepth 5; step = %d-spp slice of every rank-owned pixel = %d passes (%d in flight); "
-                                      "%dx%d tiles dealt by area over ranks, host film gather"
-                                      % (args.tris, W, H, SPP, spp_step, info["passes"], info["passesInFlight"], TILE, TILE),
+                                      "%dx%d tiles dealt by area over ranks, host gather of tile rects"
+                                      % (name, args.tris, Wd, Hd, spp_table, spp_step, info["passes"], info["passesInFlight"], TILE, TILE),
                           "samples_per_step": int(float(px.item()) * spp_step), "bvh_nodes": bvh["nNodes"], "bvh_depth": bvh["maxDepth"],
-                          "film_merge_s": round(merge_s, 4), "image_mean": round(float(rgb.mean()), 5), "commit": commit},
+                          "image_mean": round(float(rgb.mean()), 5), "commit": commit},
                "roofline": roofline, "cpu_baseline": cpu}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
@@ -280,7 +324,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(desc, target_seconds):
+def cpu_baseline(desc, target_seconds, Wd, Hd):
     """The oracle (kind "port": the reference binary cannot be built here) timed on the host cores on a
     bounded sample of the SAME workload: a centre crop of the frame at the first sample indices."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -294,15 +338,15 @@ def cpu_baseline(desc, target_seconds):
     ora = O.OracleScene(desc)
     build_s = time.time() - t0
     # calibrate on a small crop, then size the timed sample (crop x spp) for ~target_seconds of CPU work
-    cx, cy = W // 2, H // 2
+    cx, cy = Wd // 2, Hd // 2
     t0 = time.time()
     ora.render(0, 1, tiles=[(cx - 128, cy - 128, 256, 256)], threads=threads)
     rate = 256 * 256 / max(1e-3, time.time() - t0)
     want = rate * target_seconds
-    tw, th = W, H
-    if want < W * H * 2:
-        tw = min(W, max(128, int((want / 2 * 16 / 9) ** 0.5) // 32 * 32))
-        th = min(H, max(96, int(want / 2 / tw) // 32 * 32))
+    tw, th = Wd, Hd
+    if want < Wd * Hd * 2:
+        tw = min(Wd, max(128, int((want / 2 * 16 / 9) ** 0.5) // 32 * 32))
+        th = min(Hd, max(96, int(want / 2 / tw) // 32 * 32))
     spp = int(max(2, min(16, 0.5 * want // (tw * th))))
     tile = (cx - tw // 2, cy - th // 2, tw, th)
     ora.stats(reset=True)
@@ -319,7 +363,7 @@ def cpu_baseline(desc, target_seconds):
     except Exception:
         pass
     return {"value": round(tw * th * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "centre crop %dx%d px at sample indices [0,%d) of the same C4 frame = %d samples in %.1f s "
+            "sample": "centre crop %dx%d px at sample indices [0,%d) of the same frame = %d samples in %.1f s "
                       "(oracle BVH build %.1f s excluded)" % (tw, th, spp, tw * th * spp, dt, build_s),
             "cpu_model": model, "bytes_per_sample_oracle": round(algorithmic_bytes_per_sample(st), 1)}
 

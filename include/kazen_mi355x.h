@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 3
+#define KZ_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -280,6 +280,10 @@ typedef struct KzRenderOpts {
     uint64_t maxStateBytes;     /* cap on this replica's path state + sample records + film tap sums; 0 = min(3/4 of the device's
                                    memory, what is free + what the replica already holds for this purpose)       */
     KzTuning tune;
+    int32_t tileDealing;        /* kz_render_multi: 0 = static (kz_deal_tiles: by area), 1 = dynamic (the host threads pull batches of tiles from a
+                                   shared counter, the reference's BlockGenerator; the same paths and the same film up to the grouping of the float additions where the
+                                   shares of two devices or two batches meet, H10 - static dealing is bit-reproducible) */
+    int32_t reserved;
 } KzRenderOpts;
 #define KZ_MAX_PASSES_IN_FLIGHT 8
 #define KZ_DEFAULT_PASSES_IN_FLIGHT 2
@@ -293,7 +297,7 @@ typedef struct KzStats {
     uint64_t shadedHits;        /* post-intersection gathers (accel.cpp:113-236)        */
     uint64_t lightSamples;      /* Mesh::sample calls (mesh.cpp:108-133)                */
     uint64_t droppedSamples;    /* invalid radiance dropped by ImageBlock::put (block.cpp:57-61) */
-    uint64_t beamPixels;        /* pixels whose camera rays were given a leaf list by kz_wf_beam (once per pixel chunk) */
+    uint64_t beamPixels;        /* pixels whose camera rays were given a leaf list by the beam kernel, once per pixel chunk */
     uint64_t beamListEntries;   /* leaves on those lists                                  */
     uint64_t beamCompletePixels;/* pixels whose list holds every leaf the beam reaches (the other lists end at a distance t_valid) */
 } KzStats;
@@ -339,18 +343,32 @@ int kz_scene_devices(const KzScene *scene, int32_t *devices, uint32_t cap, uint3
  * Asynchronous on opts->stream. Re-entrant per (scene, device): one host thread per GPU may call it concurrently. */
 int kz_render(KzScene *scene, const KzRenderOpts *opts);
 
-/* SURVEY 8b tile variant, the unit of multi-GPU sharding: render `tiles` on `device` (overriding opts->tiles / opts->device),
- * wait for the device, and, when film != NULL, copy that replica's film ((h+2b)*(w+2b)*4 floats) to the host.
+/* SURVEY 8b tile variant, the unit of multi-GPU sharding: render `tiles` on `device` (overriding opts->tiles / opts->device), wait for the
+ * device, and hand back what those tiles produced. `film` may be NULL (nothing is copied: kz_film_download_tiles later), a buffer for the
+ * PACKED film rects of the tiles (nFloats = kz_tiles_packed_floats: tile t is its (h + 2b) x (w + 2b) rect - the tile with its filter apron, the
+ * extent of an ImageBlock of that size, block.cpp:14,30 - as consecutive rows, tiles in list order; where the rects of two tiles of the list
+ * overlap, the texel travels with the EARLIER tile and is zero in the later one, so the sum of the rects is the replica's film over their union,
+ * each texel once), or a whole-film buffer ((h+2b)*(w+2b)*4 floats).
+ * The packed form moves the tiles' own texels only: 1.13 x the film for a frame of 64 x 64 tiles however many devices share it.
  * Blocking; re-entrant per (scene, device). opts may be NULL (all samples, defaults). */
 int kz_render_tiles(KzScene *scene, const KzRenderOpts *opts, const KzTile *tiles, uint32_t nTiles, int device,
                     float *film, size_t nFloats);
+/* Size of that packed form, and the gather on its own: the packed rects of `tiles` from the film of replica `device` (device-side pack, one
+ * D2H copy through a pinned staging buffer). */
+int kz_tiles_packed_floats(const KzScene *scene, const KzTile *tiles, uint32_t nTiles, size_t *nFloats);
+int kz_film_download_tiles(KzScene *scene, int device, const KzTile *tiles, uint32_t nTiles, float *packed, size_t nFloats);
+/* ImageBlock::put(ImageBlock&) (block.cpp:87-96) for a list of blocks: adds the packed rects to a whole film ((height+2b) x (width+2b) x 4 floats)
+ * in LIST order, on nThreads host threads over disjoint row bands (0 = up to 16); the result does not depend on the number of threads. */
+int kz_film_merge_tiles(float *film, int32_t width, int32_t height, int32_t border, const KzTile *tiles, uint32_t nTiles, const float *packed,
+                        size_t nFloats, int32_t nThreads);
 
 /* The analogue of the reference's driver (renderer.cpp:94-127: tbb::parallel_for over blocks, then ImageBlock::put(ImageBlock&)
  * under a mutex, block.cpp:87-96) one level up: the image is cut into tileSize x tileSize tiles (a multiple of the 32-px
- * block; 0 = 64) that are dealt over `devices` by area (kz_deal_tiles), ONE HOST THREAD PER DEVICE renders its share with
- * kz_render_tiles, and the per-device films are summed on the host in the order of `devices` (deterministic, H10) into
- * `film`. No collective, no peer access. Replicas are uploaded on demand. deviceMs (may be NULL) receives each device's
- * wall time of render + download in ms. opts->tiles / opts->device / opts->stream are ignored. */
+ * block; 0 = 64), ONE HOST THREAD PER DEVICE renders its tiles with kz_render_tiles - dealt by area beforehand (kz_deal_tiles) or, with
+ * opts->tileDealing = 1, pulled in batches from a shared counter (the reference's BlockGenerator, block.cpp:117-148) - downloads the
+ * packed rects of ITS tiles, and the rects are added into `film` in TILE order on the host (H10: deterministic for static dealing;
+ * dynamic dealing regroups the additions where shares meet). No collective, no peer access. Replicas are uploaded on demand BEFORE the clocks start: deviceMs (may be NULL) receives
+ * each device's wall time of render + gather in ms. opts->tiles / opts->device / opts->stream are ignored. */
 int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *devices, uint32_t nDevices, int32_t tileSize,
                     float *film, size_t nFloats, float *deviceMs);
 
@@ -416,9 +434,10 @@ int kz_sync_on(KzScene *scene, int device);
 /* Average device time of the dominant kernel(s) of the last kz_render, in ms,
  * from hipEvents recorded on the launch stream (0 if none). */
 int kz_last_kernel_ms(KzScene *scene, float *ms);
-/* Device time per stage of the last pass (wavefront pipeline): out5 = generate, closest-hit traversal, shade, shadow
- * traversal, film gather — the per-kernel sums a rocprofv3 --kernel-trace of the same run shows. */
-int kz_last_stage_ms(KzScene *scene, float *out5);
+/* Device time per stage of the last pass (wavefront pipeline): out6 = generate, closest-hit traversal of the bounce rays, shade, shadow
+ * traversal, film, camera rays (beam lists / list kernel / packet kernel / first-hit walk-through) - the per-kernel sums a
+ * rocprofv3 --kernel-trace of the same run shows. */
+int kz_last_stage_ms(KzScene *scene, float *out6);
 
 /* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass, passes in flight. */
 typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes;

@@ -7,7 +7,7 @@ is missing: there is no CPU fallback in the product path.
 import ctypes as C
 import os
 
-KZ_ABI_VERSION = 3
+KZ_ABI_VERSION = 4
 
 KZ_OK, KZ_ERR_INVALID_ARG, KZ_ERR_UNSUPPORTED, KZ_ERR_NO_DEVICE, KZ_ERR_HIP, KZ_ERR_STATE, KZ_ERR_OOM = range(7)
 KZ_BSDF_DIFFUSE, KZ_BSDF_KAZENSTANDARD, KZ_BSDF_MIRROR, KZ_BSDF_DIELECTRIC = 0, 1, 2, 3
@@ -108,7 +108,7 @@ class KzRenderOpts(C.Structure):
     _fields_ = [("sampleBegin", C.c_uint32), ("sampleEnd", C.c_uint32), ("tiles", C.POINTER(KzTile)),
                 ("nTiles", C.c_uint32), ("pipeline", C.c_int32), ("accumulate", C.c_int32), ("stream", C.c_void_p),
                 ("device", C.c_int32), ("passesInFlight", C.c_int32), ("passItems", C.c_uint64), ("maxStateBytes", C.c_uint64),
-                ("tune", KzTuning)]
+                ("tune", KzTuning), ("tileDealing", C.c_int32), ("reserved", C.c_int32)]
 
 
 class KzPassInfo(C.Structure):
@@ -145,7 +145,8 @@ EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
            "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8",
            "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
-           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check", "kz_build_flags"]
+           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check", "kz_build_flags",
+           "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KZ_LIB_PATH: a development build of the library (scripts/build_variant.sh) instead of the in-tree one; probes only
@@ -199,6 +200,9 @@ def load_library():
     lib.kz_render_multi.argtypes = [C.c_void_p, C.POINTER(KzRenderOpts), C.POINTER(C.c_int32), C.c_uint32, C.c_int32, f32p, C.c_size_t, f32p]
     lib.kz_deal_tiles.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(KzTile), C.c_uint32, u32p]
     lib.kz_film_merge.argtypes = [f32p, f32p, C.c_size_t]
+    lib.kz_tiles_packed_floats.argtypes = [C.c_void_p, C.POINTER(KzTile), C.c_uint32, C.POINTER(C.c_size_t)]
+    lib.kz_film_download_tiles.argtypes = [C.c_void_p, C.c_int, C.POINTER(KzTile), C.c_uint32, f32p, C.c_size_t]
+    lib.kz_film_merge_tiles.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(KzTile), C.c_uint32, f32p, C.c_size_t, C.c_int32]
     lib.kz_film_download_on.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t]
     lib.kz_film_clear_on.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.kz_sync_on.argtypes = [C.c_void_p, C.c_int]

@@ -18,6 +18,7 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -269,6 +270,31 @@ __global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *
     }
 }
 
+// The film rects of a tile list, packed: tile t contributes its (h + 2b) x (w + 2b) rect (the tile with its filter apron) as consecutive rows
+// at offsets[t] (in float4s). The aprons of neighbouring tiles of the list overlap in the film; a texel that an EARLIER tile of the list has
+// already carried is written as zero, so that the sum of the packed rects is exactly the film over the union of the rects (each texel
+// once). `prev` lists, per tile, the earlier tiles whose rect overlaps it. One workgroup per (tile, row).
+struct KzTileRect { int32_t x0, y0, w, h; uint32_t offset; uint32_t prevStart, prevCount; };
+__global__ __launch_bounds__(128) void kz_film_pack(const float4 *__restrict__ film, int cols, const KzTileRect *__restrict__ rects, const uint32_t *__restrict__ prev,
+                                                    int border, float4 *__restrict__ out) {
+    const KzTileRect r = rects[blockIdx.y];
+    const int rw = r.w + 2 * border, rh = r.h + 2 * border;
+    const int row = blockIdx.x;
+    if (row >= rh) return;
+    const int fy = r.y0 + row;
+    const float4 *src = film + (size_t)fy * cols + r.x0;
+    float4 *dst = out + r.offset + (size_t)row * rw;
+    for (int x = threadIdx.x; x < rw; x += blockDim.x) {
+        const int fx = r.x0 + x;
+        bool mine = true;
+        for (uint32_t k = 0; k < r.prevCount; ++k) {
+            const KzTileRect q = rects[prev[r.prevStart + k]];
+            if (fx >= q.x0 && fx < q.x0 + q.w + 2 * border && fy >= q.y0 && fy < q.y0 + q.h + 2 * border) { mine = false; break; }
+        }
+        dst[x] = mine ? src[x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // Accel::rayIntersect(ray, its, false) for a batch of rays (ray-level parity tests)
 __global__ __launch_bounds__(KZ_BLOCK) void kz_trace_kernel(KzParams P, KzDevTables T, uint32_t n, const float *__restrict__ o,
                                                             const float *__restrict__ d, const float *__restrict__ tmin,
@@ -436,6 +462,8 @@ struct KzDeviceState {
     std::vector<void *> allocs;
     float4 *film = nullptr; size_t filmPixels = 0;
     uint8_t *srgb = nullptr;                                     // staging raster of kz_film_to_srgb8 (allocated on first use)
+    float4 *packDev = nullptr; size_t packCap = 0; KzTileRect *rectsDev = nullptr; size_t rectsCap = 0; uint32_t *prevDev = nullptr; size_t prevCap = 0;      // kz_film_download_tiles: packed tile rects + their tables
+    float4 *packHost = nullptr; size_t packHostCap = 0;           // pinned staging of the same (D2H at link rate)
     uint32_t *pixList = nullptr; int32_t *pixIndex = nullptr; size_t pixCap = 0; uint32_t nPix = 0;
     std::vector<KzTile> curTiles; bool tilesValid = false; uint64_t tileGen = 0;      // tileGen: bumped whenever the pixel list changes
     unsigned long long *stats = nullptr; bool statsOn = false;
@@ -468,7 +496,8 @@ static void releaseReplica(KzDeviceState *ds) {
     (void)hipSetDevice(ds->device);
     (void)hipDeviceSynchronize();
     for (void *p : ds->allocs) (void)hipFree(p);
-    for (void *p : {(void *)ds->film, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ds->film, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->packDev, (void *)ds->rectsDev, (void *)ds->prevDev}) if (p) (void)hipFree(p);
+    if (ds->packHost) (void)hipHostFree(ds->packHost);
     for (auto &c : ds->ctx) { c.release(); for (auto &e : c.stageEv) (void)hipEventDestroy(e); }
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipStream_t st : ds->passStream) if (st) (void)hipStreamDestroy(st);
@@ -940,7 +969,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #undef KZ_PACKET4
 #undef KZ_PACKET
     if (P.anyInvisibleLight) trace(1, W.queue[2], W.counts + 0, 0u, W.counts + 3, nullptr, nullptr);      // H6 walk-through of the first hit
-    { int rc_ = stageMark(c, stream, 1); if (rc_) return rc_; }
+    { int rc_ = stageMark(c, stream, 5); if (rc_) return rc_; }
     const uint32_t *cur = nullptr, *curCount = nullptr;
     for (int iter = 0; iter < maxDepth; ++iter) {
         uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
@@ -1138,6 +1167,101 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     return KZ_OK;
 }
 
+// Floats of the packed film rects of a tile list: tile t holds (h + 2b) x (w + 2b) x 4 floats - the tile with its filter apron.
+static size_t packedFloats(const KzParams &P, const KzTile *tiles, uint32_t nTiles) {
+    size_t n = 0;
+    for (uint32_t t = 0; t < nTiles; ++t) n += (size_t)(tiles[t].w + 2 * P.border) * (size_t)(tiles[t].h + 2 * P.border) * 4;
+    return n;
+}
+static int checkTiles(const KzParams &P, const KzTile *tiles, uint32_t nTiles) {
+    if (!tiles && nTiles) return kz_fail(KZ_ERR_INVALID_ARG, "null tile list");
+    for (uint32_t t = 0; t < nTiles; ++t) {
+        const KzTile &tl = tiles[t];
+        if (tl.x0 < 0 || tl.y0 < 0 || tl.w <= 0 || tl.h <= 0 || tl.x0 + tl.w > P.width || tl.y0 + tl.h > P.height)
+            return kz_fail(KZ_ERR_INVALID_ARG, "tile %u (%d,%d %dx%d) outside the %dx%d image", t, tl.x0, tl.y0, tl.w, tl.h, P.width, P.height);
+    }
+    return KZ_OK;
+}
+
+// the film rects of `tiles` of replica ds -> host `packed` (through a device-side pack and a pinned staging buffer: one D2H copy at link rate)
+static int downloadTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, uint32_t nTiles, float *packed, size_t nFloats, hipStream_t stream) {
+    const KzParams &P = scene->prm;
+    int rc;
+    if ((rc = checkTiles(P, tiles, nTiles))) return rc;
+    const size_t need = packedFloats(P, tiles, nTiles);
+    if (!packed || nFloats != need) return kz_fail(KZ_ERR_INVALID_ARG, "packed tile buffer must hold %zu floats (kz_tiles_packed_floats)", need);
+    if (nTiles == 0) return KZ_OK;
+    std::vector<KzTileRect> rects(nTiles);
+    std::vector<uint32_t> prev;
+    size_t off = 0; int maxRows = 0;
+    for (uint32_t t = 0; t < nTiles; ++t) {
+        rects[t] = KzTileRect{tiles[t].x0, tiles[t].y0, tiles[t].w, tiles[t].h, (uint32_t)off, (uint32_t)prev.size(), 0u};
+        off += (size_t)(tiles[t].w + 2 * P.border) * (size_t)(tiles[t].h + 2 * P.border);
+        maxRows = std::max(maxRows, tiles[t].h + 2 * P.border);
+    }
+    {   // earlier tiles whose rect (tile + apron) overlaps a tile's: a sweep over the tiles sorted by y keeps this near linear
+        std::vector<uint32_t> byY(nTiles);
+        for (uint32_t t = 0; t < nTiles; ++t) byY[t] = t;
+        std::sort(byY.begin(), byY.end(), [&](uint32_t a, uint32_t b) { return tiles[a].y0 < tiles[b].y0; });
+        std::vector<std::vector<uint32_t>> pv(nTiles);
+        const int b2 = 2 * P.border;
+        for (uint32_t i = 0; i < nTiles; ++i) {
+            const KzTile &a = tiles[byY[i]];
+            for (uint32_t j = i + 1; j < nTiles; ++j) {
+                const KzTile &c = tiles[byY[j]];
+                if (c.y0 >= a.y0 + a.h + b2) break;                       // sorted by y0: nothing further down overlaps a
+                if (c.x0 < a.x0 + a.w + b2 && a.x0 < c.x0 + c.w + b2) {   // (y ranges overlap by the break test and the sort)
+                    const uint32_t lo = std::min(byY[i], byY[j]), hi = std::max(byY[i], byY[j]);
+                    pv[hi].push_back(lo);
+                }
+            }
+        }
+        for (uint32_t t = 0; t < nTiles; ++t) { rects[t].prevStart = (uint32_t)prev.size(); rects[t].prevCount = (uint32_t)pv[t].size(); prev.insert(prev.end(), pv[t].begin(), pv[t].end()); }
+    }
+    if (off >= (1ull << 32)) return kz_fail(KZ_ERR_UNSUPPORTED, "tile set of %zu film pixels (limit 2^32)", off);
+    if (nTiles > ds->rectsCap) {
+        if (ds->rectsDev) (void)hipFree(ds->rectsDev);
+        ds->rectsDev = nullptr; ds->rectsCap = 0;
+        KZ_ALLOC(&ds->rectsDev, (size_t)nTiles * sizeof(KzTileRect));
+        ds->rectsCap = nTiles;
+    }
+    if (off > ds->packCap) {
+        if (ds->packDev) (void)hipFree(ds->packDev);
+        ds->packDev = nullptr; ds->packCap = 0;
+        const size_t cap = off + off / 8;                              // (headroom: the next tile set of about this size reuses the buffers)
+        KZ_ALLOC(&ds->packDev, cap * sizeof(float4));
+        ds->packCap = cap;
+    }
+    if (off > ds->packHostCap) {
+        if (ds->packHost) (void)hipHostFree(ds->packHost);
+        ds->packHost = nullptr; ds->packHostCap = 0;
+        const size_t cap = off + off / 8;
+        if (hipHostMalloc((void **)&ds->packHost, cap * sizeof(float4), hipHostMallocDefault) == hipSuccess) ds->packHostCap = cap;
+        else ds->packHost = nullptr;                                   // (no pinned memory to be had: the copy below goes to the caller's pageable buffer)
+    }
+    if (prev.size() + 1 > ds->prevCap) {
+        if (ds->prevDev) (void)hipFree(ds->prevDev);
+        ds->prevDev = nullptr; ds->prevCap = 0;
+        KZ_ALLOC(&ds->prevDev, (prev.size() + 1) * sizeof(uint32_t));
+        ds->prevCap = prev.size() + 1;
+    }
+    HIP_TRY(hipMemcpyAsync(ds->rectsDev, rects.data(), (size_t)nTiles * sizeof(KzTileRect), hipMemcpyHostToDevice, stream));
+    if (!prev.empty()) HIP_TRY(hipMemcpyAsync(ds->prevDev, prev.data(), prev.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));                              // (the tables are host vectors of this call)
+    hipLaunchKernelGGL(kz_film_pack, dim3((unsigned)maxRows, nTiles), dim3(128), 0, stream, (const float4 *)ds->film, P.width + 2 * P.border, (const KzTileRect *)ds->rectsDev,
+                       (const uint32_t *)ds->prevDev, P.border, ds->packDev);
+    HIP_TRY(hipGetLastError());
+    if (ds->packHost) {
+        HIP_TRY(hipMemcpyAsync(ds->packHost, ds->packDev, off * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::memcpy(packed, ds->packHost, off * sizeof(float4));
+    } else {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(packed, ds->packDev, off * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    return KZ_OK;
+}
+
 extern "C" {
 
 int kz_render(KzScene *scene, const KzRenderOpts *opts) {
@@ -1153,16 +1277,39 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts) {
     return renderOn(scene, ds, opts);
 }
 
+int kz_tiles_packed_floats(const KzScene *scene, const KzTile *tiles, uint32_t nTiles, size_t *nFloats) {
+    if (!scene || !nFloats) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
+    int rc;
+    if ((rc = checkTiles(scene->prm, tiles, nTiles))) return rc;
+    *nFloats = packedFloats(scene->prm, tiles, nTiles);
+    return KZ_OK;
+}
+
+int kz_film_download_tiles(KzScene *scene, int device, const KzTile *tiles, uint32_t nTiles, float *packed, size_t nFloats) {
+    KzDeviceState *ds; int rc;
+    if ((rc = findReplica(scene, device, &ds))) return rc;
+    HIP_TRY(hipStreamSynchronize(ds->lastStream));
+    return downloadTiles(scene, ds, tiles, nTiles, packed, nFloats, ds->lastStream);
+}
+
 int kz_render_tiles(KzScene *scene, const KzRenderOpts *opts, const KzTile *tiles, uint32_t nTiles, int device, float *film, size_t nFloats) {
     KzDeviceState *ds; int rc;
     if ((rc = findReplica(scene, device, &ds))) return rc;
-    if (film && nFloats != ds->filmPixels * 4) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold %zu floats", ds->filmPixels * 4);
+    const size_t full = ds->filmPixels * 4;
+    size_t packed = 0;
+    if (film) {
+        if ((rc = checkTiles(scene->prm, tiles, nTiles))) return rc;
+        packed = packedFloats(scene->prm, tiles, nTiles);
+        if (nFloats != full && !(nTiles && nFloats == packed))
+            return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold the tiles' packed rects (%zu floats, kz_tiles_packed_floats) or the whole film (%zu floats)", packed, full);
+    }
     KzRenderOpts o{};
     if (opts) o = *opts;
     o.tiles = tiles; o.nTiles = nTiles; o.device = device;
     if ((rc = renderOn(scene, ds, &o))) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)o.stream));
-    if (film) HIP_TRY(hipMemcpy(film, ds->film, nFloats * sizeof(float), hipMemcpyDeviceToHost));
+    if (film && nFloats == full && !(nTiles && packed == full)) HIP_TRY(hipMemcpy(film, ds->film, nFloats * sizeof(float), hipMemcpyDeviceToHost));
+    else if (film) return downloadTiles(scene, ds, tiles, nTiles, film, nFloats, (hipStream_t)o.stream);
     return KZ_OK;
 }
 
@@ -1198,6 +1345,40 @@ int kz_film_merge(float *dst, const float *src, size_t nFloats) {
     return KZ_OK;
 }
 
+// ImageBlock::put(ImageBlock&) (block.cpp:87-96) for a LIST of blocks: the packed rects of `tiles` are added to the film in list order.
+// Rows of the film are cut into bands, one host thread per band (disjoint destinations: no lock, and every film texel still receives
+// its rects in list order, so the result does not depend on the number of threads).
+int kz_film_merge_tiles(float *film, int32_t width, int32_t height, int32_t border, const KzTile *tiles, uint32_t nTiles, const float *packed, size_t nFloats, int32_t nThreads) {
+    if (!film || (nTiles && (!tiles || !packed)) || width <= 0 || height <= 0 || border < 0) return kz_fail(KZ_ERR_INVALID_ARG, "kz_film_merge_tiles: null or bad argument");
+    const int cols = width + 2 * border, rows = height + 2 * border;
+    std::vector<size_t> offs(nTiles);
+    size_t off = 0;
+    for (uint32_t t = 0; t < nTiles; ++t) {
+        const KzTile &tl = tiles[t];
+        if (tl.x0 < 0 || tl.y0 < 0 || tl.w <= 0 || tl.h <= 0 || tl.x0 + tl.w > width || tl.y0 + tl.h > height) return kz_fail(KZ_ERR_INVALID_ARG, "tile %u outside the %dx%d image", t, width, height);
+        offs[t] = off; off += (size_t)(tl.w + 2 * border) * (size_t)(tl.h + 2 * border) * 4;
+    }
+    if (off != nFloats) return kz_fail(KZ_ERR_INVALID_ARG, "packed buffer holds %zu floats, the tiles need %zu", nFloats, off);
+    int nt = nThreads > 0 ? nThreads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::max(1, std::min(nt, rows / 8 + 1));
+    auto band = [&](int r0, int r1) {
+        for (uint32_t t = 0; t < nTiles; ++t) {
+            const KzTile &tl = tiles[t];
+            const int rw = tl.w + 2 * border, y0 = std::max(tl.y0, r0), y1 = std::min(tl.y0 + tl.h + 2 * border, r1);
+            for (int y = y0; y < y1; ++y) {
+                float *d = film + ((size_t)y * cols + tl.x0) * 4;
+                const float *s = packed + offs[t] + (size_t)(y - tl.y0) * rw * 4;
+                for (int i = 0; i < rw * 4; ++i) d[i] += s[i];
+            }
+        }
+    };
+    if (nt == 1) { band(0, rows); return KZ_OK; }
+    std::vector<std::thread> th;
+    for (int i = 0; i < nt; ++i) th.emplace_back(band, (int)((int64_t)rows * i / nt), (int)((int64_t)rows * (i + 1) / nt));
+    for (auto &t : th) t.join();
+    return KZ_OK;
+}
+
 int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *devices, uint32_t nDevices, int32_t tileSize, float *film, size_t nFloats,
                     float *deviceMs) {
     if (!scene || !devices || nDevices == 0 || !film) return kz_fail(KZ_ERR_INVALID_ARG, "kz_render_multi: null argument");
@@ -1205,29 +1386,57 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
     const size_t filmFloats = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border) * 4;
     if (nFloats != filmFloats) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold %zu floats", filmFloats);
     for (uint32_t i = 0; i < nDevices; ++i) for (uint32_t j = 0; j < i; ++j) if (devices[i] == devices[j]) return kz_fail(KZ_ERR_INVALID_ARG, "device %d listed twice", devices[i]);
-    struct Job { std::vector<KzTile> tiles; std::vector<float> film; int rc = KZ_OK; std::string err; float ms = 0.f; };
+    // the frame's tiles in row-major order: the unit of dealing AND of the merge (a film texel receives the rects that reach it in TILE order,
+    // whichever device rendered them: the result is the same for static and for dynamic dealing, and from run to run)
+    uint32_t nAll = 0;
+    (void)kz_deal_tiles(P.width, P.height, tileSize, 1, 0, nullptr, 0, &nAll);
+    std::vector<KzTile> all(nAll);
+    int rc = nAll ? kz_deal_tiles(P.width, P.height, tileSize, 1, 0, all.data(), nAll, &nAll) : KZ_OK;
+    if (rc) return rc;
+    // replicas come up BEFORE the clocks start (deviceMs is render + gather; a first call pays the upload outside it)
+    for (uint32_t i = 0; i < nDevices; ++i) if ((rc = kz_scene_upload(scene, devices[i]))) { const std::string why = kz_last_error(); return kz_fail(rc, "device %d: %s", devices[i], why.c_str()); }
+    const bool dynamic = opts && opts->tileDealing == 1;
+    struct Job { std::vector<KzTile> tiles; std::vector<float> packed; int rc = KZ_OK; std::string err; float ms = 0.f; };
     std::vector<Job> jobs(nDevices);
-    for (uint32_t i = 0; i < nDevices; ++i) {
-        uint32_t n = 0;
-        (void)kz_deal_tiles(P.width, P.height, tileSize, nDevices, i, nullptr, 0, &n);
-        jobs[i].tiles.resize(n);
-        int rc = n ? kz_deal_tiles(P.width, P.height, tileSize, nDevices, i, jobs[i].tiles.data(), n, &n) : KZ_OK;
-        if (rc) return rc;
+    if (!dynamic) {
+        for (uint32_t i = 0; i < nDevices; ++i) {
+            uint32_t n = 0;
+            (void)kz_deal_tiles(P.width, P.height, tileSize, nDevices, i, nullptr, 0, &n);
+            jobs[i].tiles.resize(n);
+            if (n && (rc = kz_deal_tiles(P.width, P.height, tileSize, nDevices, i, jobs[i].tiles.data(), n, &n))) return rc;
+        }
     }
-    // one host thread per device (renderer.cpp:94-127 runs one TBB task per block; here a task is a GPU's whole tile share)
+    // dynamic dealing (the reference's BlockGenerator::next under a mutex, block.cpp:117-148): the workers pull batches of tiles - about two
+    // passes' worth of (pixel, sample) items each - from one counter until the frame is dealt; a slow device simply takes fewer batches
+    std::atomic<uint32_t> nextTile{0};
+    uint32_t s0 = opts ? opts->sampleBegin : 0, s1 = opts ? opts->sampleEnd : 0;
+    if (s0 == 0 && s1 == 0) s1 = P.sampleCount;
+    const uint64_t itemsPerTile = (uint64_t)(tileSize ? tileSize : 64) * (tileSize ? tileSize : 64) * std::max<uint32_t>(1, s1 - s0);
+    const uint64_t passItems = opts && opts->passItems ? opts->passItems : (1ull << 27);
+    const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((2 * passItems + itemsPerTile - 1) / itemsPerTile, std::max<uint32_t>(1, nAll / (4 * nDevices))));
+    // one host thread per device (renderer.cpp:94-127 runs one TBB task per block; here a task is a GPU's share of the tiles)
     std::vector<std::thread> threads;
     for (uint32_t i = 0; i < nDevices; ++i) {
         threads.emplace_back([&, i]() {
             Job &j = jobs[i];
             const auto t0 = std::chrono::steady_clock::now();
-            if (j.tiles.empty()) return;
-            j.rc = kz_scene_upload(scene, devices[i]);
-            if (!j.rc) {
-                if (i > 0) j.film.resize(filmFloats);                    // device 0 of the list renders straight into the caller's buffer
-                KzRenderOpts o{};
-                if (opts) o = *opts;
-                o.stream = nullptr; o.accumulate = 0;
-                j.rc = kz_render_tiles(scene, &o, j.tiles.data(), (uint32_t)j.tiles.size(), devices[i], i > 0 ? j.film.data() : film, filmFloats);
+            KzRenderOpts o{};
+            if (opts) o = *opts;
+            o.stream = nullptr; o.accumulate = 0;
+            if (dynamic) {
+                for (;;) {
+                    const uint32_t b = nextTile.fetch_add(batch);
+                    if (b >= nAll) break;
+                    const uint32_t e = std::min(nAll, b + batch);
+                    j.rc = kz_render_tiles(scene, &o, all.data() + b, e - b, devices[i], nullptr, 0);
+                    if (j.rc) break;
+                    j.tiles.insert(j.tiles.end(), all.begin() + b, all.begin() + e);
+                    o.accumulate = 1;                                    // the device film collects the batches
+                }
+            } else if (!j.tiles.empty()) j.rc = kz_render_tiles(scene, &o, j.tiles.data(), (uint32_t)j.tiles.size(), devices[i], nullptr, 0);
+            if (!j.rc && !j.tiles.empty()) {
+                j.packed.resize(packedFloats(P, j.tiles.data(), (uint32_t)j.tiles.size()));
+                j.rc = kz_film_download_tiles(scene, devices[i], j.tiles.data(), (uint32_t)j.tiles.size(), j.packed.data(), j.packed.size());
             }
             if (j.rc) j.err = kz_last_error();                             // the message is thread-local: carry it to the caller's thread
             j.ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1238,25 +1447,48 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
         if (deviceMs) deviceMs[i] = jobs[i].ms;
         if (jobs[i].rc) return kz_fail(jobs[i].rc, "device %d: %s", devices[i], jobs[i].err.c_str());
     }
-    // ImageBlock::put(ImageBlock&) (block.cpp:87-96) in the fixed order of `devices`
-    if (jobs[0].tiles.empty()) std::memset(film, 0, filmFloats * sizeof(float));
-    for (uint32_t i = 1; i < nDevices; ++i) if (!jobs[i].tiles.empty()) kz_film_merge(film, jobs[i].film.data(), filmFloats);
+    // ImageBlock::put(ImageBlock&) (block.cpp:87-96) in TILE order: a table (tile -> device, offset in that device's packed buffer), then one merge
+    // over row bands; the rects are gathered into one list so that kz_film_merge_tiles sees them in tile order
+    struct Rect { KzTile t; const float *src; };
+    std::vector<Rect> tab;
+    for (uint32_t i = 0; i < nDevices; ++i) {
+        size_t off = 0;
+        for (const KzTile &t : jobs[i].tiles) { tab.push_back(Rect{t, jobs[i].packed.data() + off}); off += (size_t)(t.w + 2 * P.border) * (size_t)(t.h + 2 * P.border) * 4; }
+    }
+    std::sort(tab.begin(), tab.end(), [](const Rect &a, const Rect &b) { return a.t.y0 != b.t.y0 ? a.t.y0 < b.t.y0 : a.t.x0 < b.t.x0; });
+    std::memset(film, 0, filmFloats * sizeof(float));
+    const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border, border = P.border;
+    const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto band = [&](int r0, int r1) {
+        for (const Rect &e : tab) {
+            const int rw = e.t.w + 2 * border, y0 = std::max(e.t.y0, r0), y1 = std::min(e.t.y0 + e.t.h + 2 * border, r1);
+            for (int y = y0; y < y1; ++y) {
+                float *d = film + ((size_t)y * cols + e.t.x0) * 4;
+                const float *sp = e.src + (size_t)(y - e.t.y0) * rw * 4;
+                for (int k = 0; k < rw * 4; ++k) d[k] += sp[k];
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < nt; ++i) th.emplace_back(band, (int)((int64_t)rows * i / nt), (int)((int64_t)rows * (i + 1) / nt));
+    for (auto &t : th) t.join();
     return KZ_OK;
 }
 
 // Device time of the stages of the LAST pass of the last kz_render (wavefront pipeline), from hipEvents on the launch stream:
-// out[0] generate, [1] closest-hit traversal (all kz_wf_trace<0>/<1> launches + primary fix), [2] shade, [3] shadow traversal, [4] film.
-int kz_last_stage_ms(KzScene *scene, float *out5) {
+// out[0] generate, [1] closest-hit traversal of the BOUNCE rays (the kz_wf_trace<0> launches), [2] shade, [3] shadow traversal, [4] film,
+// [5] camera rays (kz_wf_beam when the lists are rebuilt, kz_wf_trace_list, kz_wf_trace_packet, the first-hit walk-through).
+int kz_last_stage_ms(KzScene *scene, float *out6) {
     KzDeviceState *ds; int rc;
     if ((rc = requireDevice(scene, &ds))) return rc;
-    if (!out5) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
-    for (int i = 0; i < 5; ++i) out5[i] = 0.f;
+    if (!out6) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
+    for (int i = 0; i < 6; ++i) out6[i] = 0.f;
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
     const PassCtx &c = ds->ctx[ds->lastCtx];
     for (size_t i = 1; i < c.stageUsed; ++i) {
         float t = 0; HIP_TRY(hipEventElapsedTime(&t, c.stageEv[i - 1], c.stageEv[i]));
         const int k = c.stageKind[i];
-        if (k >= 0 && k < 5) out5[k] += t;
+        if (k >= 0 && k < 6) out6[k] += t;
     }
     return KZ_OK;
 }

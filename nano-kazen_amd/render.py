@@ -51,7 +51,8 @@ class Scene:
     def evict(self, device=-1):
         abi.check(self.lib, self.lib.kz_scene_evict(self.h, int(device)))
         if device < 0 or device == self.device:
-            self.device = None
+            left = self.devices()
+            self.device = left[0] if left else None            # the next replica becomes the one the calls without a device address
 
     def devices(self):
         buf = (C.c_int32 * 64)()
@@ -60,7 +61,7 @@ class Scene:
         return [int(buf[i]) for i in range(n.value)]
 
     def _opts(self, sample_begin=0, sample_end=0, tiles=None, accumulate=False, pipeline=0, stream=None, device=None,
-              passes_in_flight=0, pass_items=0, max_state_bytes=0, tune=None):
+              passes_in_flight=0, pass_items=0, max_state_bytes=0, tune=None, tile_dealing=0):
         o = abi.KzRenderOpts()
         o.sampleBegin, o.sampleEnd = sample_begin, sample_end
         keep = None
@@ -72,6 +73,7 @@ class Scene:
         o.stream = stream
         o.device = (self.device or 0) if device is None else int(device)
         o.passesInFlight, o.passItems, o.maxStateBytes = int(passes_in_flight), int(pass_items), int(max_state_bytes)
+        o.tileDealing = int(tile_dealing)
         for k, v in (tune or {}).items():
             setattr(o.tune, k, int(v))
         return o, keep
@@ -81,16 +83,45 @@ class Scene:
         o, keep = self._opts(sample_begin, sample_end, tiles, accumulate, pipeline, stream, **kw)
         abi.check(self.lib, self.lib.kz_render(self.h, C.byref(o)))
 
-    def render_tiles(self, tiles, device=None, sample_begin=0, sample_end=0, download=True, **kw):
-        """kz_render_tiles: blocking render of `tiles` on `device`; returns that replica's film (or None)."""
+    def render_tiles(self, tiles, device=None, sample_begin=0, sample_end=0, download=True, packed=False, **kw):
+        """kz_render_tiles: blocking render of `tiles` on `device`. download=True returns that replica's whole film, packed=True the
+        PACKED film rects of the tiles (1-D float32: every tile's (h+2b) x (w+2b) x 4 rect in list order), download=False nothing."""
         o, _ = self._opts(sample_begin, sample_end, **kw)
         arr = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
         dev = (self.device or 0) if device is None else int(device)
-        n = (self.height + 2 * self.border) * (self.width + 2 * self.border) * 4
-        out = np.empty(n, np.float32) if download else None
+        n = self.packed_floats(tiles) if packed else (self.height + 2 * self.border) * (self.width + 2 * self.border) * 4
+        out = np.empty(n, np.float32) if (download or packed) else None
         abi.check(self.lib, self.lib.kz_render_tiles(self.h, C.byref(o), arr, len(tiles), dev,
-                                                      out.ctypes.data_as(abi.f32p) if download else None, n if download else 0))
-        return out.reshape(self.height + 2 * self.border, self.width + 2 * self.border, 4) if download else None
+                                                      out.ctypes.data_as(abi.f32p) if out is not None else None, n if out is not None else 0))
+        if out is None or packed:
+            return out
+        return out.reshape(self.height + 2 * self.border, self.width + 2 * self.border, 4)
+
+    def packed_floats(self, tiles):
+        arr = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
+        n = C.c_size_t()
+        abi.check(self.lib, self.lib.kz_tiles_packed_floats(self.h, arr, len(tiles), C.byref(n)))
+        return int(n.value)
+
+    def film_tiles(self, tiles, device=None):
+        """kz_film_download_tiles: the packed film rects of `tiles` from the replica's film."""
+        arr = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
+        dev = (self.device or 0) if device is None else int(device)
+        out = np.empty(self.packed_floats(tiles), np.float32)
+        abi.check(self.lib, self.lib.kz_film_download_tiles(self.h, dev, arr, len(tiles), out.ctypes.data_as(abi.f32p), out.size))
+        return out
+
+    def merge_tiles(self, film, tiles, packed, threads=0):
+        """kz_film_merge_tiles: film += the packed rects, in list order (ImageBlock::put(ImageBlock&), block.cpp:87-96)."""
+        arr = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
+        packed = np.ascontiguousarray(packed, np.float32)
+        assert film.dtype == np.float32 and film.flags["C_CONTIGUOUS"]
+        abi.check(self.lib, self.lib.kz_film_merge_tiles(film.ctypes.data_as(abi.f32p), self.width, self.height, self.border, arr, len(tiles),
+                                                          packed.ctypes.data_as(abi.f32p), packed.size, int(threads)))
+        return film
+
+    def empty_film(self):
+        return np.zeros((self.height + 2 * self.border, self.width + 2 * self.border, 4), np.float32)
 
     def render_multi(self, devices, tile_size=0, sample_begin=0, sample_end=0, **kw):
         """kz_render_multi: one host thread per device, tiles dealt by area, films summed on the host in device order.
@@ -204,9 +235,11 @@ class Scene:
         return s.as_dict()
 
     def last_stage_ms(self):
-        out = np.zeros(5, np.float32)
+        out = np.zeros(6, np.float32)
         abi.check(self.lib, self.lib.kz_last_stage_ms(self.h, out.ctypes.data_as(abi.f32p)))
-        return dict(zip(("generate", "trace_closest", "shade", "trace_shadow", "film"), [round(float(x), 3) for x in out]))
+        d = dict(zip(("generate", "trace_bounce", "shade", "trace_shadow", "film", "trace_camera"), [round(float(x), 3) for x in out]))
+        d["trace_closest"] = round(d["trace_bounce"] + d["trace_camera"], 3)
+        return d
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -37,9 +37,9 @@ def deal_tiles(width, height, parts, part, tile=64):
 
 
 def gather_films(film, rank, world):
-    """The host gather of a multi-process launch (one rank per GPU): every rank hands its host film to rank 0 over the CPU
-    process group (gloo) and rank 0 adds them in rank order - ImageBlock::put(ImageBlock&), block.cpp:87-96. No RCCL, no
-    device collective: the films are (h+2b) x (w+2b) x 4 floats, 33 MB at 1920x1080. Returns the merged film on rank 0, None elsewhere."""
+    """The host gather of whole films (kept for the CPU-oracle test of the host logic): every rank hands its (h+2b) x (w+2b) x 4 film to
+    rank 0 over the CPU process group (gloo) and rank 0 adds them in rank order - ImageBlock::put(ImageBlock&), block.cpp:87-96.
+    The product path gathers TILES (gather_tiles): this one moves `world` whole films."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -52,6 +52,74 @@ def gather_films(film, rank, world):
         return merge_films([b.numpy() for b in bufs])
     dist.gather(t, None, dst=0)
     return None
+
+
+def gather_tiles(scene, tiles, packed, rank, world, tile=64):
+    """The host gather of a multi-process launch (one rank per GPU of ONE node), SURVEY 8e: every rank hands the PACKED film rects of ITS tiles
+    (kz_film_download_tiles: each tile with its filter apron, 1.13 x the tile's texels) to rank 0, and rank 0 adds them into one film, rank
+    after rank, tiles in list order (kz_film_merge_tiles = ImageBlock::put(ImageBlock&), block.cpp:87-96, over row bands on host threads).
+    The rects travel through shared memory (/dev/shm: the ranks share a host), the CPU process group (gloo) only carries the name and the
+    two barriers; without /dev/shm they travel by gloo. No RCCL, no device collective; the volume is one film in all, however many ranks.
+    Returns the film on rank 0, None elsewhere."""
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return scene.merge_tiles(scene.empty_film(), tiles, packed)
+    packed = np.ascontiguousarray(packed, np.float32)
+    token = [os.urandom(6).hex() if rank == 0 else None]
+    dist.broadcast_object_list(token, src=0)
+    path = lambda r: "/dev/shm/kz_gather_%s_%d.f32" % (token[0], r)
+    ok = torch.ones(1, dtype=torch.int32)
+    try:
+        packed.tofile(path(rank))
+    except OSError:
+        ok[0] = 0
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                  # every rank wrote its file (this is also the barrier behind the writes)
+    film = None
+    try:
+        if int(ok[0]):
+            if rank == 0:
+                film = scene.empty_film()
+                for r in range(world):
+                    tl = deal_tiles(scene.width, scene.height, world, r, tile)
+                    scene.merge_tiles(film, tl, np.memmap(path(r), dtype=np.float32, mode="r"))
+            dist.barrier()                                     # rank 0 has read everything
+        else:                                                  # no shared memory: the rects go through the process group
+            sizes = [scene.packed_floats(deal_tiles(scene.width, scene.height, world, r, tile)) for r in range(world)]
+            buf = np.zeros(max(sizes), np.float32)
+            buf[:packed.size] = packed
+            t = torch.from_numpy(buf)
+            if rank == 0:
+                bufs = [torch.empty_like(t) for _ in range(world)]
+                dist.gather(t, bufs, dst=0)
+                film = scene.empty_film()
+                for r in range(world):
+                    scene.merge_tiles(film, deal_tiles(scene.width, scene.height, world, r, tile), bufs[r].numpy()[:sizes[r]])
+            else:
+                dist.gather(t, None, dst=0)
+    finally:
+        try:
+            os.unlink(path(rank))
+        except OSError:
+            pass
+    return film
+
+
+def pack_rects_host(film, tiles, border):
+    """What kz_film_download_tiles hands back, formed on the host from a whole film (numpy; for hosts without a GPU: the CPU tests of the
+    gather): every tile's (h + 2b) x (w + 2b) rect in list order, a texel that an earlier tile of the list already carried written as zero."""
+    import numpy as np
+    taken = np.zeros(film.shape[:2], bool)
+    out = []
+    for (x0, y0, w, h) in tiles:
+        ys, xs = slice(y0, y0 + h + 2 * border), slice(x0, x0 + w + 2 * border)
+        r = film[ys, xs].copy()
+        r[taken[ys, xs]] = 0.0
+        taken[ys, xs] = True
+        out.append(r.ravel())
+    return np.concatenate(out) if out else np.zeros(0, np.float32)
 
 
 def merge_films(films):

@@ -89,7 +89,7 @@ def group(prefix):
     return c
 kernels = {}
 for label, prefix in (("kz_wf_trace<0>", "kz_wf_trace<0"), ("kz_wf_trace<4> (shadow)", "kz_wf_trace<4"), ("kz_wf_trace<2> (deferred walk-through)", "kz_wf_trace<2"), ("kz_wf_shade", "kz_wf_shade"), ("kz_wf_trace_packet", "kz_wf_trace_packet"),
-                      ("kz_film_gather", "kz_film_gather"), ("kz_film_taps", "kz_film_taps"), ("kz_film_apply", "kz_film_apply"), ("kz_wf_generate", "kz_wf_generate")):
+                      ("kz_wf_trace_list", "kz_wf_trace_list"), ("kz_wf_beam", "kz_wf_beam"), ("kz_film_gather", "kz_film_gather"), ("kz_film_taps", "kz_film_taps"), ("kz_film_apply", "kz_film_apply"), ("kz_wf_generate", "kz_wf_generate")):
     c = group(prefix)
     if not c.get("SQ_INSTS_VALU"):
         continue

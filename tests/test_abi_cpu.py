@@ -37,12 +37,12 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
     assert C.sizeof(a.KzBSDF) == 128 and C.sizeof(a.KzTexture) == 64
 
 
-def test_render_opts_layout_v3(kz):
-    """ABI v3: the v2 prefix of KzRenderOpts keeps its offsets (a v2 caller's zero-extended struct means "defaults")."""
+def test_render_opts_layout_v4(kz):
+    """ABI v4: the v2 / v3 prefix of KzRenderOpts keeps its offsets (a zero-extended older struct means "defaults"); v4 appends tileDealing."""
     o = kz.abi.KzRenderOpts
     assert (o.sampleBegin.offset, o.sampleEnd.offset, o.tiles.offset, o.nTiles.offset, o.pipeline.offset, o.accumulate.offset, o.stream.offset) == (0, 4, 8, 16, 20, 24, 32)
     assert o.device.offset == 40 and o.passItems.offset == 48 and o.maxStateBytes.offset == 56 and o.tune.offset == 64
-    assert C.sizeof(kz.abi.KzTuning) == 64 and C.sizeof(o) == 128
+    assert C.sizeof(kz.abi.KzTuning) == 64 and o.tileDealing.offset == 128 and C.sizeof(o) == 136
 
 
 @pytest.mark.parametrize("w,h,tile,parts", [(1920, 1080, 64, 8), (3840, 2160, 64, 8), (1920, 1080, 128, 3), (100, 70, 32, 5), (64, 64, 64, 4)])
@@ -178,3 +178,26 @@ def test_scene_generators(kz):
         y = (pmj[0, :k, 1].astype(np.float64) / 2 ** 32 * g).astype(int)
         assert len(set(zip(x, y))) == k
     assert float((pmj.astype(np.float64) * 2.0 ** -32).astype(np.float32).max()) < 1.0
+
+
+def test_film_merge_tiles_adds_rects_in_list_order(kz):
+    """kz_film_merge_tiles (host only): packed (h+2b) x (w+2b) rects are added into the film where the tiles sit, aprons overlapping;
+    the result does not depend on the number of host threads."""
+    lib = kz.abi.load_library()
+    W, H, b = 100, 70, 2
+    tiles = [(0, 0, 64, 64), (64, 0, 36, 64), (0, 64, 64, 6), (64, 64, 36, 6)]
+    rng = np.random.default_rng(5)
+    rects = [rng.random((t[3] + 2 * b, t[2] + 2 * b, 4), dtype=np.float32) for t in tiles]
+    packed = np.concatenate([r.ravel() for r in rects])
+    want = np.zeros((H + 2 * b, W + 2 * b, 4), np.float32)
+    for t, r in zip(tiles, rects):
+        want[t[1]:t[1] + t[3] + 2 * b, t[0]:t[0] + t[2] + 2 * b] += r
+    arr = (kz.abi.KzTile * len(tiles))(*[kz.abi.KzTile(*t) for t in tiles])
+    for threads in (1, 3, 0):
+        film = np.zeros_like(want)
+        assert lib.kz_film_merge_tiles(film.ctypes.data_as(kz.abi.f32p), W, H, b, arr, len(tiles), packed.ctypes.data_as(kz.abi.f32p), packed.size, threads) == 0
+        assert np.array_equal(film, want), threads
+    film = np.zeros_like(want)
+    assert lib.kz_film_merge_tiles(film.ctypes.data_as(kz.abi.f32p), W, H, b, arr, len(tiles), packed.ctypes.data_as(kz.abi.f32p), packed.size - 4, 1) == kz.abi.KZ_ERR_INVALID_ARG
+    bad = (kz.abi.KzTile * 1)(kz.abi.KzTile(90, 0, 64, 64))
+    assert lib.kz_film_merge_tiles(film.ctypes.data_as(kz.abi.f32p), W, H, b, bad, 1, packed.ctypes.data_as(kz.abi.f32p), 68 * 68 * 4, 1) == kz.abi.KZ_ERR_INVALID_ARG

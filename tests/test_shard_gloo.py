@@ -1,5 +1,5 @@
 """world_size-2 tests of the N>1 path (one process per GPU, CPU process group): kz_deal_tiles + the host gather that
-bench.py uses (shard.gather_films: gloo gather to rank 0, films summed in rank order = ImageBlock::put(ImageBlock&),
+bench.py uses (shard.gather_tiles: gloo gather of the packed tile rects to rank 0, added in tile order = ImageBlock::put(ImageBlock&),
 block.cpp:87-96) reproduce the single-process film.
 
 * not gpu: each rank renders ITS tiles with the CPU oracle (test infrastructure) - what is under test is the host logic;
@@ -34,13 +34,20 @@ def _worker(rank, world, port, out, use_gpu):
     desc = kz.scenes.cornell_box(W, H, SPP)
     tiles = kz.shard.deal_tiles(W, H, world, rank, 32)
     if use_gpu:
-        sc = kz.Scene(desc, device=0)
-        film = sc.render_tiles(tiles, device=0)
+        dev = rank % kz.abi.load_library().kz_device_count()          # distinct devices wherever the box has them
+        sc = kz.Scene(desc, device=dev)
+        packed = sc.render_tiles(tiles, device=dev, packed=True)       # the product path: every rank hands over the rects of ITS tiles
+        dist.barrier()
+        merged = kz.shard.gather_tiles(sc, tiles, packed, rank, world, 32)
     else:
         import oracle as O
         film = O.OracleScene(desc).render(tiles=tiles, threads=1)
-    dist.barrier()
-    merged = kz.shard.gather_films(film, rank, world)
+        sc = kz.Scene(desc)                                            # host side only (no replica): sizes and kz_film_merge_tiles
+        dist.barrier()
+        merged = kz.shard.gather_tiles(sc, tiles, kz.shard.pack_rects_host(film, tiles, sc.border), rank, world, 32)
+        whole = kz.shard.gather_films(film, rank, world)               # the same through whole films
+        if rank == 0:
+            assert np.array_equal(merged, whole)
     if rank == 0:
         np.save(out, merged)
     dist.barrier()
