@@ -764,7 +764,12 @@ static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool 
         KzWf W{};
         auto alloc = [&](void **p, size_t bytes) -> int { KZ_ALLOC(p, bytes); c.wfAllocs.push_back(*p); return KZ_OK; };
         int rc = KZ_OK;
-        for (float4 **p : {&W.rayA, &W.rayB, &W.hit, &W.thr, &W.misc, &W.shA, &W.shB, &W.shL}) if (!rc) rc = alloc((void **)p, need * sizeof(float4));
+        if (KZ_STATE_AOS) {                                             // two 64-B records per slot: (rayA rayB hit thr) and (shA shB shL misc)
+            float4 *rec[2] = {nullptr, nullptr};
+            for (int k = 0; k < 2; ++k) if (!rc) rc = alloc((void **)&rec[k], need * 4 * sizeof(float4));
+            if (!rc) { W.rayA.p = rec[0]; W.rayB.p = rec[0] + 1; W.hit.p = rec[0] + 2; W.thr.p = rec[0] + 3; W.shA.p = rec[1]; W.shB.p = rec[1] + 1; W.shL.p = rec[1] + 2; W.misc.p = rec[1] + 3; }
+        } else
+            for (KzField<float4> *f : {&W.rayA, &W.rayB, &W.hit, &W.thr, &W.misc, &W.shA, &W.shB, &W.shL}) if (!rc) rc = alloc((void **)&f->p, need * sizeof(float4));
         if (!rc) rc = alloc((void **)&W.smp, need * sizeof(uint4));
         for (int q = 0; q < 3; ++q) if (!rc) rc = alloc((void **)&W.queue[q], need * sizeof(uint32_t));
         if (!rc) rc = alloc((void **)&W.counts, 8 * 520 * sizeof(uint32_t));

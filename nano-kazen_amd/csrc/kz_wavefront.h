@@ -26,13 +26,25 @@
 #define KZ_WF_QCAP 960             // LDS staging entries per output queue per workgroup (960: four shade workgroups fit the CU's 160 KB)
 #endif
 
+// Path state in HBM: one array per field (SoA; 16-B records, coalesced for the stages that sweep all slots). -DKZ_STATE_AOS=1 builds the
+// alternative that round 3 measured and rejected (profiles/r03h_state_layout): one 64-B line per path for (ray origin | direction | hit |
+// throughput) and one for (shadow origin | direction | pending radiance | misc). It was meant to cut the lines fetched per path once the
+// queues hold a thinning, scattered subset of the slots; shade did not move (19.3 -> 19.4 ms: it is not bound by the bytes of these
+// arrays) and the stages that sweep every slot lost (generate 1.5 -> 4.0 ms, camera rays 5.8 -> 6.9): C4 1533-1562 -> 1464-1470 Msamples/s.
+#ifndef KZ_STATE_AOS
+#define KZ_STATE_AOS 0
+#endif
+template <class Tp> struct KzField {
+    Tp *p;
+    __device__ __forceinline__ Tp &operator[](uint32_t i) const { return p[KZ_STATE_AOS ? (size_t)i * 4u : (size_t)i]; }
+};
 struct KzWf {
-    float4 *rayA, *rayB;           // o.xyz tmin | d.xyz tmax
-    float4 *hit;                   // t u v gid(bits) - the shading record of the triangle; t = +inf: miss
-    float4 *thr;                   // throughput.xyz eta (compact state, see kz_wf_shade: throughput.xyz bsdfPdf)
-    float4 *misc;                  // bsdfPdf accumulatedRoughness discrete(EDiscrete) -
+    KzField<float4> rayA, rayB;    // o.xyz tmin | d.xyz tmax
+    KzField<float4> hit;           // t u v gid(bits) - the shading record of the triangle; t = +inf: miss
+    KzField<float4> thr;           // throughput.xyz eta (compact state, see kz_wf_shade: throughput.xyz bsdfPdf)
+    KzField<float4> misc;          // bsdfPdf accumulatedRoughness discrete(EDiscrete) -
     uint4 *smp;                    // pcg32 state (.x,.y) + dimension index (.z); the pcg32 stream id is recomputed from the pixel
-    float4 *shA, *shB, *shL;       // shadow (or walk-through) ray o.xyz tmax | d.xyz tmin | pending radiance
+    KzField<float4> shA, shB, shL; // shadow (or walk-through) ray o.xyz tmax | d.xyz tmin | pending radiance
     uint32_t *queue[3];            // two ping-pong path queues + the shadow queue
     uint32_t *counts;              // [stage][4] zeroed per pass
     float *outJx, *outJy, *outR, *outG, *outB;

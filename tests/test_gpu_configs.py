@@ -317,7 +317,7 @@ def test_failed_calls_release_their_device_memory(gpu_lib, kz):
     # a render whose state buffers fail half way: nothing half-allocated is used afterwards
     big = kz.Scene(kz.scenes.cornell_box(64, 64, 4), device=0)
     before = free_now()
-    for nth in (1, 2, 5, 9, 13):
+    for nth in (1, 2, 5, 6, 8):               # (beam lists, beam heads | path records | a queue | the overflow stacks: what is already there is kept)
         gpu_lib.kz_debug_fail_alloc(nth)
         with pytest.raises(kz.abi.KzError):
             big.render()
