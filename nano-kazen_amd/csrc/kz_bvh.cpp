@@ -26,6 +26,7 @@ const float kInf = std::numeric_limits<float>::infinity();
 const int NBINS = 32;
 const int DEPTH_CAP = KZ_STACK_DEPTH - 2;
 
+
 struct Box {
     float lo[3], hi[3];
     void reset() { for (int a = 0; a < 3; ++a) { lo[a] = kInf; hi[a] = -kInf; } }
@@ -157,6 +158,68 @@ static void padBox(Box &b, float absPad) {
     }
 }
 
+#ifdef KZ_EXPERIMENTS
+// (development build only: measured on C4 and C3 and rejected, profiles/r03j_presplit)
+// ---- pre-splitting (spatial splits before the build; Embree's RTC_BUILD_QUALITY_HIGH, which the reference asks for at accel.cpp:36, builds with
+// spatial splits too). A reference = (box, triangle): the references with the largest boxes are cut in two at the middle of their box's longest
+// axis - the triangle's polygon is clipped against the plane, each side gets the box of its part - until `factor` x the triangle count
+// extra references exist. The tree is then built over the references; a leaf may name a triangle that another leaf names too (its record
+// is simply stored twice: the same Moeller-Trumbore test, the same hit). Boxes only ever get tighter around the same surface.
+struct Poly { int n; float v[10][3]; };
+static void polyBox(const Poly &p, Box &b) { b.reset(); for (int i = 0; i < p.n; ++i) b.grow(p.v[i]); }
+static void clipPoly(const Poly &p, int axis, float pos, bool keepLow, Poly &out) {
+    out.n = 0;
+    for (int i = 0; i < p.n; ++i) {
+        const float *a = p.v[i], *b = p.v[(i + 1) % p.n];
+        const bool ina = keepLow ? a[axis] <= pos : a[axis] >= pos, inb = keepLow ? b[axis] <= pos : b[axis] >= pos;
+        if (ina && out.n < 10) { for (int k = 0; k < 3; ++k) out.v[out.n][k] = a[k]; out.n++; }
+        if (ina != inb && out.n < 10) {
+            const float t = (pos - a[axis]) / (b[axis] - a[axis]);
+            for (int k = 0; k < 3; ++k) out.v[out.n][k] = a[k] + t * (b[k] - a[k]);
+            out.v[out.n][axis] = pos;
+            out.n++;
+        }
+    }
+}
+static void presplit(const std::vector<KzBuildTri> &in, std::vector<Ref> &refs, float factor) {
+    if (!(factor > 0.f) || refs.empty()) return;
+    struct Item { float prio; Poly poly; Box box; uint32_t tri; };
+    auto cmp = [](const Item &x, const Item &y) { return x.prio < y.prio; };
+    std::vector<Item> heap; heap.reserve(refs.size());
+    for (const Ref &r : refs) {
+        Item it; it.tri = r.tri; it.box = r.b; it.poly.n = 3;
+        for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) it.poly.v[v][k] = in[r.tri].v[v][k];
+        it.prio = r.b.area();
+        heap.push_back(it);
+    }
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    size_t budget = (size_t)((double)factor * (double)refs.size());
+    std::vector<Item> done;
+    while (budget > 0 && !heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        Item it = heap.back(); heap.pop_back();
+        int a = 0; float ext = -1.f;
+        for (int k = 0; k < 3; ++k) { const float e = it.box.hi[k] - it.box.lo[k]; if (e > ext) { ext = e; a = k; } }
+        const float pos = 0.5f * (it.box.lo[a] + it.box.hi[a]);
+        Item L, R; L.tri = R.tri = it.tri;
+        clipPoly(it.poly, a, pos, true, L.poly); clipPoly(it.poly, a, pos, false, R.poly);
+        if (!(ext > 0.f) || it.poly.n >= 9 || L.poly.n < 3 || R.poly.n < 3 || !(pos > it.box.lo[a]) || !(pos < it.box.hi[a])) { it.prio = -1.f; done.push_back(it); continue; }
+        polyBox(L.poly, L.box); polyBox(R.poly, R.box);
+        // the parts stay inside the parent's box, and both reach the plane (no seam between them)
+        for (int k = 0; k < 3; ++k) { L.box.lo[k] = std::max(L.box.lo[k], it.box.lo[k]); L.box.hi[k] = std::min(L.box.hi[k], it.box.hi[k]); R.box.lo[k] = std::max(R.box.lo[k], it.box.lo[k]); R.box.hi[k] = std::min(R.box.hi[k], it.box.hi[k]); }
+        L.box.hi[a] = pos; R.box.lo[a] = pos;
+        L.prio = L.box.area(); R.prio = R.box.area();
+        heap.push_back(L); std::push_heap(heap.begin(), heap.end(), cmp);
+        heap.push_back(R); std::push_heap(heap.begin(), heap.end(), cmp);
+        --budget;
+    }
+    refs.clear();
+    auto emit = [&](const Item &it) { Ref r; r.b = it.box; r.tri = it.tri; for (int k = 0; k < 3; ++k) r.c[k] = 0.5f * (it.box.lo[k] + it.box.hi[k]); refs.push_back(r); };
+    for (const Item &it : heap) emit(it);
+    for (const Item &it : done) emit(it);
+}
+#endif
+
 } // namespace
 
 int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, std::vector<KzTri> &tris,
@@ -181,9 +244,12 @@ int kz_build_bvh(const std::vector<KzBuildTri> &in, std::vector<KzNode> &nodes, 
         for (int a = 0; a < 3; ++a) r.c[a] = 0.5f * (r.b.lo[a] + r.b.hi[a]);
         cx.refs.push_back(r);
     }
+    info.nTris = (uint32_t)cx.refs.size();
+#ifdef KZ_EXPERIMENTS
+    if (const char *e = std::getenv("KZ_BVH_PRESPLIT")) { float v = (float)std::atof(e); if (v > 0.f && v <= 8.f) presplit(in, cx.refs, v); }
+#endif
     uint32_t n = (uint32_t)cx.refs.size();
-    if (n >= (1u << 28)) { err = "more than 2^28 triangles"; return KZ_ERR_UNSUPPORTED; }
-    info.nTris = n;
+    if (n >= (1u << 28)) { err = "more than 2^28 triangle references"; return KZ_ERR_UNSUPPORTED; }
     if (n == 0) return KZ_OK;
     cx.tmp.resize(2 * (size_t)n + 2);
     uint32_t root = cx.alloc();
