@@ -333,7 +333,8 @@ int kz_scene_sample_count(const KzScene *scene, uint32_t *out);
  * the same device is a no-op). Calls that take no device argument address the PRIMARY replica, the one uploaded first.
  * Fails with KZ_ERR_NO_DEVICE when no GPU is usable. Thread-safe per (scene, device). */
 int kz_scene_upload(KzScene *scene, int device);
-/* Release the replica on `device` (-1: every replica). */
+/* Release the replica on `device` (-1: every replica). Must not run concurrently with any other call on that replica (the per-(scene, device)
+ * re-entrancy covers rendering and downloading, not tearing a replica down under them); the same holds for kz_scene_destroy. */
 int kz_scene_evict(KzScene *scene, int device);
 /* The devices the scene is resident on, primary first. */
 int kz_scene_devices(const KzScene *scene, int32_t *devices, uint32_t cap, uint32_t *count);

@@ -62,40 +62,21 @@ struct WfAppender {
         base = __shfl(base, 0, 64);
         if (pred) s_buf[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
     }
-    // all threads of the workgroup call this; flushes when another 256-item chunk might not fit (or always, if force).
-    // BINNED: the staged values carry a 4-bit bin in bits 28-31 (the slot index of a pass is < 2^28); the flush is a counting sort of
-    // the staged window by bin (histogram and cursors in s_bins[16], LDS atomics), so that the global queue consists of runs of
-    // entries of one bin - rays of one neighbourhood of pixels that point the same way (shade: direction bin of the next ray, light
-    // index of the shadow ray). Only the ORDER of the queue changes, which no result depends on.
-    template <bool BINNED>
-    __device__ __forceinline__ void maybeFlush(bool force, uint32_t *s_bins = nullptr) {
+    // all threads of the workgroup call this; flushes when another 256-item chunk might not fit (or always, if force)
+    __device__ __forceinline__ void maybeFlush(bool force) {
         __syncthreads();
         const uint32_t n = *s_n;
         if (force ? (n > 0) : (n > KZ_WF_QCAP - KZ_BLOCK)) {
             if (threadIdx.x == 0) *s_gb = atomicAdd(gCount, n);
-            if (BINNED) {
-                if (threadIdx.x < 16) s_bins[threadIdx.x] = 0;
-                __syncthreads();
-                for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) atomicAdd(&s_bins[s_buf[i] >> 28], 1u);
-                __syncthreads();
-                if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 16; ++b) { const uint32_t c = s_bins[b]; s_bins[b] = acc; acc += c; } }
-            }
             __syncthreads();
             const uint32_t gb = *s_gb;
-            if (BINNED) for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) { const uint32_t v = s_buf[i]; gQueue[gb + atomicAdd(&s_bins[v >> 28], 1u)] = v & 0x0FFFFFFFu; }
-            else for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) gQueue[gb + i] = s_buf[i];
+            for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) gQueue[gb + i] = s_buf[i];
             __syncthreads();
             if (threadIdx.x == 0) *s_n = 0;
         }
         __syncthreads();
     }
-    __device__ __forceinline__ void maybeFlush(bool force) { maybeFlush<false>(force); }
 };
-
-// 4-bit direction bin of a ray: octant + whether z is the dominant axis
-__device__ __forceinline__ uint32_t wfDirBin(V3 d) {
-    return (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u) | ((fabsf(d.z) > fabsf(d.x) && fabsf(d.z) > fabsf(d.y)) ? 8u : 0u);
-}
 
 __device__ __forceinline__ void wfStatsFlush(unsigned long long *stats, const Counters &cn, uint32_t samples) {
     unsigned long long v[7] = {samples, cn.rays, cn.nodes, cn.tris, cn.hits, cn.lsamples, cn.dropped};

@@ -88,6 +88,14 @@ def test_c5_workload_as_eight_tile_shares(gpu_lib, kz, O):
     assert sc.sample_count == 4096 and sc.bvh_info()["nTris"] == 1000028
     sc.render(100, 104)
     whole = sc.film()
+    # the camera rays of this frame (33 M of them) through all three kernels: pixel beams + leaf lists (default), the per-lane traversal, the packet kernel
+    for kernel in (1, 2):
+        sc.render(100, 104, tune={"packetPrimary": kernel})
+        assert np.array_equal(sc.film(), whole), kernel
+    sc.set_stats(True); sc.stats(reset=True)
+    sc.render(100, 101, tiles=[(0, 0, 1920, 1088)])                   # (another pixel set: the lists are rebuilt, and counted)
+    st = sc.stats(reset=True); sc.set_stats(False)
+    assert st["beamPixels"] == 1920 * 1088 and 0 < st["beamListEntries"] <= 32 * 1920 * 1088 and st["droppedSamples"] == 0
     total, areas, shares = None, [], []
     for part in range(8):
         tiles = kz.shard.deal_tiles(Wd, Hd, 8, part, 64)
