@@ -445,45 +445,27 @@ int kz_collapse_bvh4(const std::vector<KzNode> &nodes, uint32_t rootRef, std::ve
             nd.p[a] = lo[a];
             float ext = hi[a] - lo[a];
             int e = 0;
-            if (ext > 0.f) { std::frexp(ext / (float)KZ_NODE_QMAX, &e); }            // ext/QMAX = m * 2^e, m in [0.5,1) -> 2^e >= ext/QMAX
+            if (ext > 0.f) { std::frexp(ext / 255.0f, &e); }            // ext/255 = m * 2^e, m in [0.5,1) -> 2^e >= ext/255
             else e = -126;
             e = std::max(-126, std::min(127, e));
-            // make sure QMAX steps reach hi even after the rounding of p + QMAX*s
-            while (e < 127 && deq(lo[a], (uint32_t)KZ_NODE_QMAX, std::ldexp(1.0f, e)) < hi[a]) ++e;
+            // make sure 255 steps reach hi even after the rounding of p + 255*s
+            while (e < 127 && deq(lo[a], 255u, std::ldexp(1.0f, e)) < hi[a]) ++e;
             scale[a] = std::ldexp(1.0f, e);
             exps |= (uint32_t)(e + 127) << (8 * a);
         }
         (void)exps; nd.scaleX = scale[0]; nd.scaleY = scale[1]; nd.scaleZ = scale[2];
-        // binary16 bits of an integer 0 .. 2047 (exact: 11 significant bits)
-        auto half = [](int q) -> uint16_t {
-            if (q <= 0) return 0;
-            int e = 0; while ((q >> (e + 1)) != 0) ++e;                    // q = 1.m x 2^e
-            return (uint16_t)(((e + 15) << 10) | (((uint32_t)q << (10 - e)) & 0x3ffu));
-        };
-        (void)half;
         for (int i = 0; i < 4; ++i) {
-            if (i >= n) {                                                  // qlo = QMAX > qhi = 0: inverted, never hit
-#if KZ_NODE_FP16
-                for (int a = 0; a < 3; ++a) { nd.qlo[a][i] = half(KZ_NODE_QMAX); nd.qhi[a][i] = 0; }
-#else
-                for (int a = 0; a < 3; ++a) { nd.qlo[a] |= 255u << (8 * i); }
-#endif
-                nd.child[i] = 0; continue;
-            }
+            if (i >= n) { for (int a = 0; a < 3; ++a) { nd.qlo[a] |= 255u << (8 * i); } nd.child[i] = 0; continue; }     // qhi = 0: inverted, never hit
             nd.child[i] = cb[i].ref;
             for (int a = 0; a < 3; ++a) {
                 int ql = (int)std::floor((cb[i].lo[a] - lo[a]) / scale[a]);
-                ql = std::max(0, std::min(KZ_NODE_QMAX, ql));
+                ql = std::max(0, std::min(255, ql));
                 while (ql > 0 && deq(lo[a], (uint32_t)ql, scale[a]) > cb[i].lo[a]) --ql;
                 int qh = (int)std::ceil((cb[i].hi[a] - lo[a]) / scale[a]);
-                qh = std::max(0, std::min(KZ_NODE_QMAX, qh));
-                while (qh < KZ_NODE_QMAX && deq(lo[a], (uint32_t)qh, scale[a]) < cb[i].hi[a]) ++qh;
-#if KZ_NODE_FP16
-                nd.qlo[a][i] = half(ql); nd.qhi[a][i] = half(qh);
-#else
+                qh = std::max(0, std::min(255, qh));
+                while (qh < 255 && deq(lo[a], (uint32_t)qh, scale[a]) < cb[i].hi[a]) ++qh;
                 nd.qlo[a] |= (uint32_t)ql << (8 * i);
                 nd.qhi[a] |= (uint32_t)qh << (8 * i);
-#endif
             }
         }
     }

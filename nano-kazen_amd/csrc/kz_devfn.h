@@ -306,35 +306,6 @@ __device__ __forceinline__ void node4KeysOf(const uint4 q0, const uint4 q1, cons
         else key[i] = (n <= f) ? 0u : 0xFFFFFFFFu;        // any-hit rays only ask WHETHER a child is hit: no entry distance, no slot bits
     }
 }
-#if KZ_NODE_FP16
-// the 96-B packet with binary16 planes: the same t = q * (s * rcp) + (p - o) * rcp, the plane read by the FMA itself (v_fma_mix_f32)
-typedef _Float16 kz_h2 __attribute__((ext_vector_type(2)));
-template <bool ORDERED = true>
-__device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax,
-                                          uint32_t (&key)[4], uint4 &refs) {
-    const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + node);
-    const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
-    refs = np[5];
-    const float ax = __uint_as_float(q0.w) * rx, ay = __uint_as_float(q1.x) * ry, az = __uint_as_float(q1.y) * rz;
-    const float bx = (__uint_as_float(q0.x) - o.x) * rx, by = (__uint_as_float(q0.y) - o.y) * ry, bz = (__uint_as_float(q0.z) - o.z) * rz;
-    // q2 = loX[0..3] loY[0..3], q3 = loZ[0..3] hiX[0..3], q4 = hiY[0..3] hiZ[0..3] (two children per word): near / far planes by the sign of the direction
-    const uint32_t nX[2] = {rx >= 0.f ? q2.x : q3.z, rx >= 0.f ? q2.y : q3.w}, fX[2] = {rx >= 0.f ? q3.z : q2.x, rx >= 0.f ? q3.w : q2.y};
-    const uint32_t nY[2] = {ry >= 0.f ? q2.z : q4.x, ry >= 0.f ? q2.w : q4.y}, fY[2] = {ry >= 0.f ? q4.x : q2.z, ry >= 0.f ? q4.y : q2.w};
-    const uint32_t nZ[2] = {rz >= 0.f ? q3.x : q4.z, rz >= 0.f ? q3.y : q4.w}, fZ[2] = {rz >= 0.f ? q4.z : q3.x, rz >= 0.f ? q4.w : q3.y};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const kz_h2 hnx = __builtin_bit_cast(kz_h2, nX[i >> 1]), hfx = __builtin_bit_cast(kz_h2, fX[i >> 1]), hny = __builtin_bit_cast(kz_h2, nY[i >> 1]),
-                    hfy = __builtin_bit_cast(kz_h2, fY[i >> 1]), hnz = __builtin_bit_cast(kz_h2, nZ[i >> 1]), hfz = __builtin_bit_cast(kz_h2, fZ[i >> 1]);
-        const float tnx = __builtin_fmaf((float)((i & 1) ? hnx.y : hnx.x), ax, bx), tfx = __builtin_fmaf((float)((i & 1) ? hfx.y : hfx.x), ax, bx);
-        const float tny = __builtin_fmaf((float)((i & 1) ? hny.y : hny.x), ay, by), tfy = __builtin_fmaf((float)((i & 1) ? hfy.y : hfy.x), ay, by);
-        const float tnz = __builtin_fmaf((float)((i & 1) ? hnz.y : hnz.x), az, bz), tfz = __builtin_fmaf((float)((i & 1) ? hfz.y : hfz.x), az, bz);
-        const float n = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);
-        const float f = fminf(fminf(fminf(tfx, tfy), tfz) * 1.0000004f, tmax);
-        if (ORDERED) key[i] = (n <= f) ? ((__float_as_uint(n) & ~3u) | (uint32_t)i) : 0xFFFFFFFFu;
-        else key[i] = (n <= f) ? 0u : 0xFFFFFFFFu;
-    }
-}
-#else
 template <bool ORDERED = true>
 __device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax,
                                           uint32_t (&key)[4], uint4 &refs) {
@@ -343,7 +314,6 @@ __device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V
     refs = np[3];
     node4KeysOf<ORDERED>(q0, q1, q2, o, rx, ry, rz, tmin, tmax, key);
 }
-#endif
 __device__ __forceinline__ Node4Test node4Test(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax) {
     Node4Test r; uint32_t key[4];
     node4Keys(T, node, o, rx, ry, rz, tmin, tmax, key, r.refs);

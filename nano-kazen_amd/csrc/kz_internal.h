@@ -27,20 +27,8 @@ static_assert(sizeof(KzNode) == 64, "node packet must be 64 B");
 //   q2 = qhi.y[4] qhi.z[4] | 2^ey 2^ez (floats)
 //   q3 = child[4] (same encoding as KzNode::child; an empty slot has qlo = 255, qhi = 0)
 // Quantisation rounds outward against the SAME float expression the kernel evaluates, so the boxes stay conservative.
-// -DKZ_NODE_FP16=1 (experiment, profiles/r03n_node_fp16): the child planes as fp16 INTEGERS 0 .. 2047 (exact in binary16) in a 96-B packet, read by the
-// kernels through v_fma_mix_f32 (the conversion is part of the FMA: no v_cvt_f32_ubyte, 11-bit instead of 8-bit planes).
-#ifndef KZ_NODE_FP16
-#define KZ_NODE_FP16 0
-#endif
-#if KZ_NODE_FP16
-#define KZ_NODE_QMAX 2047
-struct KzNode4 { float p[3]; float scaleX; float scaleY, scaleZ; uint32_t pad[2]; uint16_t qlo[3][4]; uint16_t qhi[3][4]; uint32_t child[4]; };      // [axis][child]: binary16 bits
-static_assert(sizeof(KzNode4) == 96, "fp16 BVH4 packet must be 96 B");
-#else
-#define KZ_NODE_QMAX 255
 struct KzNode4 { float p[3]; float scaleX; uint32_t qlo[3]; uint32_t qhi[3]; float scaleY, scaleZ; uint32_t child[4]; };      // scale = 2^e per axis, as floats (the node step multiplies them by 1/d: no exponent unpacking)
 static_assert(sizeof(KzNode4) == 64, "BVH4 packet must be 64 B");
-#endif
 
 // Leaf triangle in Moeller-Trumbore form, 48 B, three quads: p0.xyz e1.x | e1.y e1.z e2.x e2.y | e2.z mesh prim gid
 struct KzTri { float p0[3]; float e1[3]; float e2[3]; uint32_t mesh, prim, gid; };

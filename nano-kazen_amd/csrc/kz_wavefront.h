@@ -897,25 +897,14 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T
             if (__ballot(inner) == 0ull) break;
             if (inner) {
                 const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + cur);
-#if KZ_NODE_FP16
-                const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], refs = np[5];
-                const float sX = __uint_as_float(q0.w), sY = __uint_as_float(q1.x), sZ = __uint_as_float(q1.y);
-                const uint32_t wlx[2] = {q2.x, q2.y}, wly[2] = {q2.z, q2.w}, wlz[2] = {q3.x, q3.y}, whx[2] = {q3.z, q3.w}, why[2] = {q4.x, q4.y}, whz[2] = {q4.z, q4.w};
-#else
                 const uint4 q0 = np[0], q1 = np[1], q2 = np[2], refs = np[3];
                 const float sX = __uint_as_float(q0.w), sY = __uint_as_float(q2.z), sZ = __uint_as_float(q2.w);
-#endif
                 const float pX = __uint_as_float(q0.x) - O.x, pY = __uint_as_float(q0.y) - O.y, pZ = __uint_as_float(q0.z) - O.z;     // box coordinates relative to the pinhole
                 const uint32_t r[4] = {refs.x, refs.y, refs.z, refs.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-#if KZ_NODE_FP16
-                    auto hv = [&](const uint32_t (&w)[2]) { const kz_h2 h = __builtin_bit_cast(kz_h2, w[i >> 1]); return (float)((i & 1) ? h.y : h.x); };
-                    const float qlx = hv(wlx), qly = hv(wly), qlz = hv(wlz), qhx = hv(whx), qhy = hv(why), qhz = hv(whz);
-#else
                     const float qlx = (float)((q1.x >> (8 * i)) & 0xffu), qly = (float)((q1.y >> (8 * i)) & 0xffu), qlz = (float)((q1.z >> (8 * i)) & 0xffu);
                     const float qhx = (float)((q1.w >> (8 * i)) & 0xffu), qhy = (float)((q2.x >> (8 * i)) & 0xffu), qhz = (float)((q2.y >> (8 * i)) & 0xffu);
-#endif
                     const float lx = fmaf(qlx, sX, pX), ly = fmaf(qly, sY, pY), lz = fmaf(qlz, sZ, pZ), hx = fmaf(qhx, sX, pX), hy = fmaf(qhy, sY, pY), hz = fmaf(qhz, sZ, pZ);
                     // pad: rho x an upper bound of the distance of the box's farthest point, + 2^-19 of the coordinates (the quantised planes
                     // are conservative for the kernels' own slab expression; this form rounds differently)
