@@ -844,7 +844,9 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 //                     to kz_wf_trace / kz_wf_trace_packet. The other rays go to fbQueue for the packet kernel with what is known about them
 //                     (nothing in front of t_valid: tmin; the hit found so far: tmax).
 // The lists depend on the pixels only: a pass context keeps them for the pixel chunk it last built them for.
-#define KZ_BEAM_CAP 32
+#ifndef KZ_BEAM_CAP
+#define KZ_BEAM_CAP 32                // leaves per pixel list (16 / 24 / 48 measured in r03o: 32 stays)
+#endif
 #define KZ_BEAM_STACK 32              // open entries (ref + key) per beam in LDS
 __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T, const uint32_t *__restrict__ pixList, uint32_t nPix, int LS,
                                                        uint2 *__restrict__ entries, uint2 *__restrict__ heads) {
