@@ -958,8 +958,6 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
     bool undecided = false;
     if (have) {
         const uint32_t pl = slot / S;
-        const uint2 head = heads[pl];
-        const float tvalidDist = __uint_as_float(head.y);                     // the list's bounds are DISTANCES from the pinhole: parameter x |d|
         const float4 a = W.rayA[slot], b = W.rayB[slot];
         const V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
         const float tmin = a.w;
@@ -967,8 +965,10 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
         bool found = false; float bt = KZ_INF, bu = 0.f, bv = 0.f; uint32_t bgid = 0;
         const bool finite = rayIsFinite(o, d);
         const float len = sqrtf(dot(d, d)), lenUp = len * 1.000002f;
-        if (finite) {
-            const uint2 *lst = entries + (size_t)pl * KZ_BEAM_CAP;
+        float tvalidDist = KZ_INF;                                             // the list's bounds are DISTANCES from the pinhole: parameter x |d|
+        auto walk = [&](const uint2 *__restrict__ lst, const uint2 head) {
+            tvalidDist = __uint_as_float(head.y);
+            if (!finite) return;
             for (uint32_t j = 0; j < head.x; ++j) {
                 const uint2 e = lst[j];
                 if (__uint_as_float(e.y) > tmax * lenUp) continue;         // the leaf begins behind the closest hit so far
@@ -980,7 +980,13 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
                     if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; bgid = g; tmax = t; }
                 }
             }
-        }
+        };
+        // When the 64 rays of the wave belong to ONE pixel (S a multiple of 64: every default), the list is wave-uniform: its address comes from the
+        // first lane's pixel (an SGPR), so the head and the entries arrive through the scalar cache and an entry's load no longer queues behind the
+        // lanes' vector loads of the triangle before it. Waves that span pixels walk per-lane lists.
+        const uint32_t plU = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl);
+        if (__all(pl == plU)) walk(entries + (size_t)plU * KZ_BEAM_CAP, heads[plU]);
+        else walk(entries + (size_t)pl * KZ_BEAM_CAP, heads[pl]);
         // decided: a hit in front of everything unexplored, or nothing unexplored at all (a non-finite ray hits nothing)
         undecided = finite && !(found ? bt * lenUp < tvalidDist : !(tvalidDist < KZ_INF));
         if (STATS && !undecided) cn.rays++;                                    // (an undecided ray is counted by the kernel that decides it)
