@@ -444,6 +444,7 @@ struct PassCtx {
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
     uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0;      // kz_wf_beam: leaf lists of the pixels of a chunk ...
     uint64_t beamGen = 0; uint32_t beamP0 = 0, beamN = 0;                                  // ... and the chunk (tile-set generation, first pixel, pixels) they were built for
+    uint64_t sharedSeen = 0;                                                              // the generation of the replica's shared lists this context's stream has waited for
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
     size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4 + beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); }
     void release() {
@@ -473,7 +474,10 @@ struct KzDeviceState {
     std::vector<EventPair> events; size_t eventsUsed = 0;
     hipStream_t passStream[KZ_MAX_PASSES_IN_FLIGHT] = {}; hipEvent_t evFork = nullptr, evFilm[KZ_MAX_PASSES_IN_FLIGHT] = {}, evCallA = nullptr, evCallB = nullptr;
     int lastCtx = 0; bool lastDual = false; int streamMode = 0;
-    size_t ctxBytes() const { size_t b = 0; for (const PassCtx &c : ctx) b += c.bytes(); return b; }
+    // beam lists of the WHOLE pixel set (the default pass shape: every pass covers every pixel), shared by the contexts: built once per tile set on the
+    // stream of the pass that needs them first, the other contexts wait for evBeam once
+    uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0; uint64_t beamGen = 0; hipEvent_t evBeam = nullptr;
+    size_t ctxBytes() const { size_t b = beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); for (const PassCtx &c : ctx) b += c.bytes(); return b; }
     KzPassInfo lastInfo{};
 };
 struct KzReplicaSet { std::mutex m; std::vector<KzDeviceState *> v; };
@@ -496,7 +500,8 @@ static void releaseReplica(KzDeviceState *ds) {
     (void)hipSetDevice(ds->device);
     (void)hipDeviceSynchronize();
     for (void *p : ds->allocs) (void)hipFree(p);
-    for (void *p : {(void *)ds->film, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->packDev, (void *)ds->rectsDev, (void *)ds->prevDev}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ds->film, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->packDev, (void *)ds->rectsDev, (void *)ds->prevDev, (void *)ds->beamEntries, (void *)ds->beamCount}) if (p) (void)hipFree(p);
+    if (ds->evBeam) (void)hipEventDestroy(ds->evBeam);
     if (ds->packHost) (void)hipHostFree(ds->packHost);
     for (auto &c : ds->ctx) { c.release(); for (auto &e : c.stageEv) (void)hipEventDestroy(e); }
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -734,7 +739,7 @@ static constexpr size_t KZ_TAP_BYTES_PER_PIXEL = (size_t)KZ_TAPS_MAX * KZ_TAPS_M
 
 // ---- buffers of one pass context: sized for `need` items of `nPix` pixels; nothing is left half-allocated on failure ----
 static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool tapSums, bool beams, hipStream_t stream) {
-    if (beams && nPix > c.beamCap) {
+    if (beams && nPix > c.beamCap) {                                // (beams: lists of this context's own pixel chunks; the whole-set lists live with the replica)
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.beamEntries) (void)hipFree(c.beamEntries);
         if (c.beamCount) (void)hipFree(c.beamCount);
@@ -951,15 +956,29 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #define KZ_PACKET4(q, cptr, cimm, headp) do { if (P.anyInvisibleLight) { if (st) KZ_PACKET(true, true, q, cptr, cimm, headp); else KZ_PACKET(false, true, q, cptr, cimm, headp); } \
                                               else { if (st) KZ_PACKET(true, false, q, cptr, cimm, headp); else KZ_PACKET(false, false, q, cptr, cimm, headp); } } while (0)
     if (packet && beams) {
-        if (c.beamGen != ds->tileGen || c.beamP0 != p0 || c.beamN != nPixPass) {          // the lists depend on the pixels only: built once per pixel chunk
-            const int LS = std::max(1, std::min(P.stackBound4, KZ_BEAM_STACK));      // a beam whose stack would grow beyond this gives its pixel to the packet kernel
-            hipLaunchKernelGGL(kz_wf_beam, dim3((nPixPass + KZ_BLOCK - 1) / KZ_BLOCK), blk, (size_t)2 * LS * KZ_BLOCK * sizeof(uint32_t), stream, P, ds->T, pixList, nPixPass, LS, c.beamEntries, c.beamCount);
-            c.beamGen = ds->tileGen; c.beamP0 = p0; c.beamN = nPixPass;
-            if (st) hipLaunchKernelGGL(kz_wf_beam_count, dim3((nPixPass + KZ_BLOCK - 1) / KZ_BLOCK), blk, 0, stream, (const uint2 *)c.beamCount, nPixPass, ds->stats + 24);
+        const uint2 *lstEntries, *lstHeads;
+        const int LS = std::max(1, std::min(P.stackBound4, KZ_BEAM_STACK));      // a beam whose open set would grow beyond this leaves the rest unexplored (t_valid)
+        const dim3 gBeam((nPixPass + KZ_BLOCK - 1) / KZ_BLOCK);
+        const size_t beamLds = (size_t)2 * LS * KZ_BLOCK * sizeof(uint32_t);
+        if (p0 == 0 && nPixPass == ds->nPix) {                                 // the whole pixel set: ONE list for all contexts of the replica
+            if (ds->beamGen != ds->tileGen) {                                   // (a call's pass streams all start behind the previous call: nobody reads the old lists any more)
+                hipLaunchKernelGGL(kz_wf_beam, gBeam, blk, beamLds, stream, P, ds->T, pixList, nPixPass, LS, ds->beamEntries, ds->beamCount);
+                if (st) hipLaunchKernelGGL(kz_wf_beam_count, gBeam, blk, 0, stream, (const uint2 *)ds->beamCount, nPixPass, ds->stats + 24);
+                HIP_TRY(hipEventRecord(ds->evBeam, stream));
+                ds->beamGen = ds->tileGen; c.sharedSeen = ds->tileGen;
+            } else if (c.sharedSeen != ds->tileGen) { HIP_TRY(hipStreamWaitEvent(stream, ds->evBeam, 0)); c.sharedSeen = ds->tileGen; }
+            lstEntries = ds->beamEntries; lstHeads = ds->beamCount;
+        } else {                                                                // a pixel chunk: the context's own lists, built once per chunk
+            if (c.beamGen != ds->tileGen || c.beamP0 != p0 || c.beamN != nPixPass) {
+                hipLaunchKernelGGL(kz_wf_beam, gBeam, blk, beamLds, stream, P, ds->T, pixList, nPixPass, LS, c.beamEntries, c.beamCount);
+                c.beamGen = ds->tileGen; c.beamP0 = p0; c.beamN = nPixPass;
+                if (st) hipLaunchKernelGGL(kz_wf_beam_count, gBeam, blk, 0, stream, (const uint2 *)c.beamCount, nPixPass, ds->stats + 24);
+            }
+            lstEntries = c.beamEntries; lstHeads = c.beamCount;
         }
         uint32_t *fbQ = W.queue[0], *fbCount = W.counts + 8 * 520 - 8, *fbHead = fbCount + 1;      // rays of pixels whose list overflowed: the packet kernel's
         const dim3 gList((items + KZ_BLOCK - 1) / KZ_BLOCK);
-#define KZ_LIST(ST, FX) hipLaunchKernelGGL((kz_wf_trace_list<ST, FX>), gList, blk, 0, stream, P, ds->T, W, items, Sp, (const uint2 *)c.beamEntries, (const uint2 *)c.beamCount, fbQ, fbCount, W.queue[2], W.counts + 0)
+#define KZ_LIST(ST, FX) hipLaunchKernelGGL((kz_wf_trace_list<ST, FX>), gList, blk, 0, stream, P, ds->T, W, items, Sp, lstEntries, lstHeads, fbQ, fbCount, W.queue[2], W.counts + 0)
         if (P.anyInvisibleLight) { if (st) KZ_LIST(true, true); else KZ_LIST(false, true); }
         else { if (st) KZ_LIST(true, false); else KZ_LIST(false, false); }
 #undef KZ_LIST
@@ -1084,6 +1103,18 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
             if (ds->ctx[i].bytes() && keep + ds->ctx[i].bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i].release(); } else keep += ds->ctx[i].bytes();
     }
     if (!ds->evCallA) { HIP_TRY(hipEventCreate(&ds->evCallA)); HIP_TRY(hipEventCreate(&ds->evCallB)); }
+    if (beams && pixPerPass == ds->nPix) {                            // the shared lists of the whole pixel set
+        if (!ds->evBeam) HIP_TRY(hipEventCreateWithFlags(&ds->evBeam, hipEventDisableTiming));
+        if (ds->nPix > ds->beamCap) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (ds->beamEntries) (void)hipFree(ds->beamEntries);
+            if (ds->beamCount) (void)hipFree(ds->beamCount);
+            ds->beamEntries = nullptr; ds->beamCount = nullptr; ds->beamCap = 0; ds->beamGen = 0;
+            KZ_ALLOC(&ds->beamEntries, (size_t)ds->nPix * KZ_BEAM_CAP * sizeof(uint2));
+            KZ_ALLOC(&ds->beamCount, (size_t)ds->nPix * sizeof(uint2));
+            ds->beamCap = ds->nPix;
+        }
+    }
     if (multi) {
         // Different priorities put streams on different hardware queues whatever other streams the process has created (streams of one
         // priority share a small round-robin pool of queues and two of them may end up serialised on one): the pass streams cycle
@@ -1122,7 +1153,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
             const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
             PassCtx &c = ds->ctx[ci];
             hipStream_t pst = multi ? ds->passStream[ci] : stream;
-            if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, beams, pst))) return rc;
+            if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, beams && pixPerPass != ds->nPix, pst))) return rc;
             if (ds->eventsUsed == ds->events.size()) {
                 EventPair ep; HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); ds->events.push_back(ep);
             }
