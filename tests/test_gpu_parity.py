@@ -417,6 +417,38 @@ def test_randomized_scenes_match_oracle(gpu_lib, kz, O, seed):
     assert np.array_equal(sc.film(), film)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_pixel_beams_equal_per_ray_traversal_under_random_cameras(gpu_lib, kz, seed):
+    """The camera rays through the pixel-beam lists (kz_wf_beam + kz_wf_trace_list, the default), the packet kernel and the per-lane traversal give
+    the SAME film bit for bit, for cameras the beams' margins have to survive: scaled / sheared / mirrored toWorld matrices (|d| != 1: the lists'
+    bounds are distances, the rays' parameters are not), 2 to 150 degrees of view, the pinhole inside a dense soup, far away from a tiny one,
+    single-sample passes, tile sets with ragged edges."""
+    rng = np.random.default_rng(4000 + seed)
+    S = kz.scenes
+    w, h = int(rng.integers(33, 97)), int(rng.integers(17, 71))
+    d = S.random_triangles(int(rng.integers(200, 6000)), w, h, 4, sampler="pmj02bn" if seed % 2 else "independent", s_edge=float(rng.choice([0.02, 0.1, 0.5])))
+    eye = rng.uniform(-1.0, 1.0, 3) if seed % 3 == 0 else rng.uniform(-1, 1, 3) + np.array([0, 0, rng.uniform(2.5, 40.0)])      # inside the soup / outside, near to far
+    tw = S.look_at(tuple(eye), tuple(rng.uniform(-0.5, 0.5, 3)), (0, 1, 0)).astype(np.float64)
+    M = np.eye(4)
+    if seed % 4 == 1: M[:3, :3] = np.diag(rng.uniform(0.3, 3.0, 3))                        # non-uniform scale of the camera's axes
+    if seed % 4 == 2: M[:3, :3] = np.eye(3) + np.triu(rng.uniform(-0.4, 0.4, (3, 3)), 1)   # shear
+    if seed % 4 == 3: M[0, 0] = -1.0                                                       # mirrored
+    d.camera.update(toWorld=(tw @ M).astype(np.float32), fov=float(rng.choice([2.0, 20.0, 60.0, 120.0, 150.0])), nearClip=float(rng.choice([1e-4, 0.05])), farClip=float(rng.choice([50.0, 1e4])))
+    d.sampler["sampleCount"] = int(rng.choice([1, 3, 4, 16]))
+    sc = kz.Scene(d, device=0)
+    tiles = None if seed % 2 else [(0, 0, 32, 17), (32, 0, w - 32, 17)]
+    films = []
+    for kernel in (0, 1, 2):
+        sc.render(tiles=tiles, tune={"packetPrimary": kernel})
+        films.append(sc.film())
+    assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2]), seed
+    assert np.isfinite(films[0]).all()
+    sc.render(tiles=tiles, pass_items=max(64, (w * h // 3) // 64 * 64), tune={"sppPerPass": 1})      # pixel chunks: the contexts' own lists, rebuilt per chunk
+    assert np.allclose(sc.film(), films[0], rtol=2e-5, atol=1e-5)
+    sc.render(tiles=tiles, pipeline=1)                                                     # the reference-shaped megakernel (BVH2, one ray at a time)
+    assert np.array_equal(sc.film(), films[0])
+
+
 def test_two_passes_in_flight_equal_one_at_a_time(gpu_lib, kz, O):
     """kz_render splits a call into passes (KzRenderOpts.passItems) and keeps two of them in flight on two internal streams; the
     film is accumulated in pass order either way, so both schedules give the same bits as pass-at-a-time, and the oracle's film
