@@ -509,7 +509,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRA
     // the lane's stack ran empty: publish the result (or, for a literal shadow lane, decide / walk through the light)
     auto finish = [&]() {
         active = false;
-        if (kind == 0) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(bgid)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+        if (kind == 0) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid));      // (without a hit the record still holds what the refill put there: +inf, 0, 0, 0 = the miss record)
         if (kind == 1) { if (found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid)); }
         if (kind == 2) {
             if (MODE == 4 || !literal || !found) addPending();                       // nothing on the segment
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (!more) break;
             }
         }
-        if (have) W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(bgid)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+        if (have) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid))        /* no hit: still +inf, 0, 0, 0 */;
         if (FIX && found && bgid - P.ilGidLo <= P.ilGidSpan) {              // (rare) may be a triangle of an invisible light: look
             const int li = lightOfGid(T, bgid);
             if (li >= 0 && !T.lights[li].primaryVisibility) {
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
             W.rayA[slot] = make_float4(a.x, a.y, a.z, fmaxf(tmin, tvalidDist / lenUp * 0.999998f));
             if (found) W.rayB[slot] = make_float4(b.x, b.y, b.z, bt);
         } else {
-            W.hit[slot] = found ? make_float4(bt, bu, bv, __uint_as_float(bgid)) : make_float4(KZ_INF, 0.f, 0.f, 0.f);
+            W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid))        /* no hit: still +inf, 0, 0, 0 */;
             if (FIX && found && bgid - P.ilGidLo <= P.ilGidSpan) {              // (rare) may be a triangle of an invisible light: see kz_wf_trace_packet
                 const int li = lightOfGid(T, bgid);
                 if (li >= 0 && !T.lights[li].primaryVisibility) {
