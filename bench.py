@@ -60,12 +60,12 @@ def git_head():
 
 
 def source_hash():
-    """sha256 (first 16 hex digits) of the kernel and ABI sources: the counter facts of a profile describe ONE build"""
+    """sha256 (first 16 hex digits) of the kernel and ABI sources and of the build recipe (compiler flags): the counter facts of a profile describe ONE build"""
     import glob
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.hip")) +
-                    glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "include", "kazen_mi355x.h")]):
+                    glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "nano-kazen_amd", "csrc", "build.sh"), os.path.join(ROOT, "include", "kazen_mi355x.h")]):
         h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
     return h.hexdigest()[:16]
 

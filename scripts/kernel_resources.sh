@@ -1,7 +1,7 @@
 #!/bin/sh
 # VGPRs / SGPRs / spills / scratch / LDS / occupancy of every kernel of the product library (hipcc -Rpass-analysis=kernel-resource-usage).
 cd "$(dirname "$0")/../nano-kazen_amd/csrc"
-hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fgpu-flush-denormals-to-zero ${KZ_EXTRA_HIPFLAGS} -Rpass-analysis=kernel-resource-usage -c kz_device.hip -o /tmp/kz_res.o 2>&1 |
+hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fgpu-flush-denormals-to-zero -fno-slp-vectorize ${KZ_EXTRA_HIPFLAGS} -Rpass-analysis=kernel-resource-usage -c kz_device.hip -o /tmp/kz_res.o 2>&1 |
 python3 -c '
 import re, sys, subprocess
 cur = None; rows = {}
