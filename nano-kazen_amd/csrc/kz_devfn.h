@@ -274,6 +274,12 @@ __device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin
     t = dot(e2, qvec) * inv_det;
     return t >= tmin && t <= tmax;
 }
+// LDS through explicit 32-bit byte addresses (address space 3): ds_read_b32 / ds_write_b32 at a VGPR the kernel keeps as state
+typedef __attribute__((address_space(3))) uint32_t KzLds32;
+__device__ __forceinline__ uint32_t kzLdsAddr(const uint32_t *p) { return (uint32_t)(uintptr_t)(const KzLds32 *)p; }
+__device__ __forceinline__ void kzLdsPut(uint32_t a, uint32_t v) { *(KzLds32 *)(uintptr_t)a = v; }
+__device__ __forceinline__ uint32_t kzLdsGet(uint32_t a) { return *(const KzLds32 *)(uintptr_t)a; }
+
 // One 64-B BVH4 packet (KzNode4): four quantised child boxes, slab tests in the FMA form t = q * (s * rcp) + (p - o) * rcp
 // (s is a power of two, so s * rcp is exact; the leaf boxes carry an absolute pad that covers the rounding of the rest).
 // Returns the four children as sortable keys: (bits of max(tnear, tmin) with the two low bits replaced by the child slot),
@@ -306,10 +312,15 @@ __device__ __forceinline__ void node4KeysOf(const uint4 q0, const uint4 q1, cons
         else key[i] = (n <= f) ? 0u : 0xFFFFFFFFu;        // any-hit rays only ask WHETHER a child is hit: no entry distance, no slot bits
     }
 }
+// The packet of node `node`: table base (scalar) + a 32-BIT byte offset, so the fetches take the base from SGPRs and the offset from one
+// VGPR (v_lshlrev_b32) instead of a 64-bit shift and a 64-bit add per visit. kz_scene_create refuses trees above 2^26 packets (4 GB).
+__device__ __forceinline__ const uint4 *kzNode4Ptr(const KzDevTables &T, uint32_t node) {
+    return reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(T.nodes4) + (uint32_t)(node << 6));
+}
 template <bool ORDERED = true>
 __device__ __forceinline__ void node4Keys(const KzDevTables &T, uint32_t node, V3 o, float rx, float ry, float rz, float tmin, float tmax,
                                           uint32_t (&key)[4], uint4 &refs) {
-    const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + node);
+    const uint4 *np = kzNode4Ptr(T, node);
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
     refs = np[3];
     node4KeysOf<ORDERED>(q0, q1, q2, o, rx, ry, rz, tmin, tmax, key);

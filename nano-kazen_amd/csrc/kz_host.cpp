@@ -277,6 +277,8 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     { int sb = 1; uint32_t r4 = rootRef;
       rc = kz_collapse_bvh4(sc->nodes, rootRef, sc->nodes4, r4, sb);
       if (rc != KZ_OK) { delete sc; return kz_fail(rc, "BVH4 collapse failed"); }
+      // (the kernels address a packet as table base + a 32-bit byte offset, kz_devfn.h kzNode4Ptr)
+      if (sc->nodes4.size() > (size_t(1) << 26)) { delete sc; return kz_fail(KZ_ERR_UNSUPPORTED, "scene too large: %zu BVH4 packets (limit 2^26 = 4 GB of packets)", sc->nodes4.size()); }
       p.rootRef4 = r4; p.stackBound4 = sb; }
     p.stackDepth = (int32_t)std::max<uint32_t>(2u, sc->bvh.maxDepth + 1);
     p.bsdfExt = 0;

@@ -453,25 +453,31 @@ struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, 
 #define KZ_TRACE_WAVES 8            // waves per SIMD the per-lane traversal is compiled for (64 VGPRs); 7 = 72 VGPRs measured in r02i
 #endif
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRACE_WAVES, KZ_TRACE_WAVES))) void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(STATS ? KZ_TRACE_WAVES - 1 : KZ_TRACE_WAVES, STATS ? KZ_TRACE_WAVES - 1 : KZ_TRACE_WAVES)))
+void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm, uint32_t *__restrict__ head, KzTune tune,
                                                         uint32_t *__restrict__ queueB, uint32_t *__restrict__ countPtrB) {
     extern __shared__ uint32_t s_stack[];
-    uint32_t *stk = s_stack + threadIdx.x;
     const uint32_t count = countPtr ? *countPtr : countImm;
     constexpr bool SHADOW = MODE == 2 || MODE == 4;
     constexpr int kind = MODE == 4 ? 2 : MODE;                        // ray kind: 0 closest hit, 1 closest hit on the walk-through ray, 2 shadow
     const int lane = threadIdx.x & 63;
-    const int LS = tune.ldsStack;
+    // The lane's stack is a column of the [entry][lane] LDS array (+ one scratch row). Its state is `top`, the LDS BYTE ADDRESS of the next
+    // free entry: pushes and pops are ds_write / ds_read at that address, one v_add_u32 apart (an entry index costs a v_lshl_add_u32 - a
+    // 4-cycle instruction on gfx950, scripts/micro/valu_ops.hip - per access).
+    constexpr uint32_t rowB = KZ_BLOCK * 4u;
+    const uint32_t stkBase = kzLdsAddr(s_stack + threadIdx.x), ldsRows = (uint32_t)tune.ldsStack * rowB;
+    uint32_t top = stkBase;
     // overflow rows live at tune.ovf[row * ovfStride + thread]: the (rare) deep case forms its address from the scalar base and a 32-bit
     // thread index instead of keeping a 64-bit per-lane pointer alive through the loop
     uint32_t *const ovfBase = tune.ovf;
     const uint32_t ovfLane = blockIdx.x * KZ_BLOCK + threadIdx.x;
     const size_t ovfStride = tune.ovfStride;
 #define ovf(row) ovfBase[(size_t)(row) * ovfStride + ovfLane]
-    auto push = [&](int &sp_, uint32_t v) {
-        if (sp_ < LS) stk[sp_ * KZ_BLOCK] = v; else ovf((size_t)(sp_ - LS)) = v;
-        ++sp_;
+    auto push = [&](uint32_t v) {
+        const uint32_t dB = top - stkBase;
+        if (dB < ldsRows) kzLdsPut(top, v); else ovf((dB - ldsRows) / rowB) = v;
+        top += rowB;
     };
     const uint32_t root = P.rootRef4;
     const float eps = P.traceBias;
@@ -487,17 +493,19 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRA
     bool active = false, literal = false;
     V3 o = mk(0.f), d = mk(0.f);
     float rx = 0.f, ry = 0.f, rz = 0.f, tmin = 0.f, tmax = 0.f, segMax = 0.f;
-    uint32_t cur = 0, slot = 0; int sp = 0;
+    uint32_t cur = 0, slot = 0;
     bool found = false; float bt = 0.f, bu = 0.f, bv = 0.f; uint32_t btri = 0, bgid = 0;
 
     // next stack entry -> cur; false when the stack is empty
     auto popNext = [&]() -> bool {
-        if (sp == 0) return false;
-        --sp;
-        // (LDS read of the entry or of the scratch row, replaced by the global entry in the rare deep case: a select between an LDS and a
-        // global address would become a generic-pointer load)
-        uint32_t v = stk[min(sp, LS) * KZ_BLOCK];
-        if (sp >= LS) v = ovf((size_t)(sp - LS));
+        if (top == stkBase) return false;
+        top -= rowB;
+        const uint32_t dB = top - stkBase;
+        // LDS read of the entry (of the scratch row in the rare deep case, where the global entry replaces it). The address-space-3 form
+        // matters: through generic pointers the compiler merged the two loads into ONE flat_load at a selected address - a vector-memory
+        // instruction per pop beside the node fetches, where a ds_read costs that pipeline nothing.
+        uint32_t v = kzLdsGet(min(top, stkBase + ldsRows));
+        if (dB >= ldsRows) v = ovf((dB - ldsRows) / rowB);
         cur = v;
         return true;
     };
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRA
                 const int ol = T.meshes[om].light;
                 if (ol >= 0 && !T.lights[ol].primaryVisibility) {                     // walk through (integrator.cpp:273-274)
                     o = o + d * (bt + eps); tmin = eps; segMax = segMax - bt; tmax = segMax;
-                    found = false; bt = KZ_INF; cur = root; sp = 0; active = true;
+                    found = false; bt = KZ_INF; cur = root; top = stkBase; active = true;
                     if (STATS) cn.rays++;
                 }
             }
@@ -558,6 +566,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRA
                 if (!active && rank < take) {
                     const uint32_t qi = poolNext + rank;
                     slot = queue ? queue[qi] : qi;
+                    top = stkBase;                                    // (an idle lane's stack is empty, or abandoned by an occluded shadow ray)
                     float4 a, b;
                     if (kind == 0) { a = W.rayA[slot]; b = W.rayB[slot]; }
                     else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w); }
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRA
                         rx = rcpExact(fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x);
                         ry = rcpExact(fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y);
                         rz = rcpExact(fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z);
-                        cur = root; sp = 0; active = true;
+                        cur = root; active = true;
                         if (MODE == 4) {
                             if (invisibleLightOnSegment(P, T, o, d, rx, ry, rz, tmin, tmax)) {       // (launched only when P.shadowFast)
                                 queueB[atomicAdd(countPtrB, 1u)] = slot;
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRA
                 // Child order. Closest-hit rays descend into the NEAREST hit child and leave the other hit children on the
                 // stack in slot order (a full sort of the siblings buys 6 % fewer node visits and costs 12 % more
                 // instructions per visit); any-hit shadow rays take the hit children in slot order altogether. Pushes
-                // are branch-free: a hit child lands on the next free slot, a missed one on the lane's scratch slot.
+                // are branch-free (below).
                 uint32_t key[4]; uint4 refs;
                 bool p0, p1, p2, p3;                                          // child i goes on the stack
                 uint32_t nxt; bool any;
@@ -621,17 +630,20 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_TRA
                     p0 = key[0] != 0xFFFFFFFFu && key[0] != kmin; p1 = key[1] != 0xFFFFFFFFu && key[1] != kmin;
                     p2 = key[2] != 0xFFFFFFFFu && key[2] != kmin; p3 = key[3] != 0xFFFFFFFFu && key[3] != kmin;
                 }
-                const int c1 = (int)p0, c2 = c1 + (int)p1, c3 = c2 + (int)p2, np = c3 + (int)p3;
-                if (sp + 3 <= LS) {                                              // common case: everything stays in LDS
-                    const int o0 = (p0 ? sp : LS) * KZ_BLOCK, o1 = (p1 ? sp + c1 : LS) * KZ_BLOCK, o2 = (p2 ? sp + c2 : LS) * KZ_BLOCK, o3 = (p3 ? sp + c3 : LS) * KZ_BLOCK;
-                    if (!SHADOW) stk[o0] = refs.x;
-                    stk[o1] = refs.y; stk[o2] = refs.z; stk[o3] = refs.w;
-                    sp += np;
+                if (top - stkBase + 3u * rowB <= ldsRows) {                      // common case: everything stays in LDS
+                    // every child is written at the running top, which advances only past the children that stay: one that does not is
+                    // overwritten by the next store or left above the top (the last row it can reach is the scratch row). No address selects.
+                    uint32_t a = top;
+                    if (!SHADOW) { kzLdsPut(a, refs.x); a += p0 ? rowB : 0u; }
+                    kzLdsPut(a, refs.y); a += p1 ? rowB : 0u;
+                    kzLdsPut(a, refs.z); a += p2 ? rowB : 0u;
+                    kzLdsPut(a, refs.w); a += p3 ? rowB : 0u;
+                    top = a;
                 } else {
-                    if (p0) push(sp, refs.x);
-                    if (p1) push(sp, refs.y);
-                    if (p2) push(sp, refs.z);
-                    if (p3) push(sp, refs.w);
+                    if (p0) push(refs.x);
+                    if (p1) push(refs.y);
+                    if (p2) push(refs.z);
+                    if (p3) push(refs.w);
                 }
                 if (any) cur = nxt;
                 else if (!popNext()) finish();
@@ -898,7 +910,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T
             const bool inner = active && !(cur & 0x80000000u);
             if (__ballot(inner) == 0ull) break;
             if (inner) {
-                const uint4 *np = reinterpret_cast<const uint4 *>(T.nodes4 + cur);
+                const uint4 *np = kzNode4Ptr(T, cur);
                 const uint4 q0 = np[0], q1 = np[1], q2 = np[2], refs = np[3];
                 const float sX = __uint_as_float(q0.w), sY = __uint_as_float(q2.z), sZ = __uint_as_float(q2.w);
                 const float pX = __uint_as_float(q0.x) - O.x, pY = __uint_as_float(q0.y) - O.y, pZ = __uint_as_float(q0.z) - O.z;     // box coordinates relative to the pinhole

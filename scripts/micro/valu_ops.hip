@@ -1,0 +1,244 @@
+// Microbenchmark: sustained issue rate (wave64, 8 waves per SIMD, every CU) of the VALU instructions the hot kernels are made of, with
+// valu_clock.hip's method (16 independent registers, 256-instruction loop bodies, warm-up launches first). Found with it (profiles/r03u_valu_ops):
+// a gfx950 SIMD issues a wave64 instruction in 4 cycles, and only a SUBSET runs at the doubled rate the guide quotes for v_fma_f32
+// (2.2 cycles): fma / mul / add / sub / fmac, and / or / xor / shifts / mov. Everything else the BVH4 node step uses - min / max / min3 / max3,
+// every v_cmp, v_cndmask, every conversion, bfe / perm / and_or / add3 / lshl_add / mad_u24 - takes the 4 cycles.
+// It also checks the idea that started it:
+//     byte q as the binary16 DENORMAL 0x00qq = q * 2^-24, read by v_fma_mix_f32 together with a * 2^24 and b:   fl(q * a + b), bit for bit
+//     what v_cvt_f32_ubyteN + v_fma_f32 give (true; but v_fma_mix_f32 is a 4-cycle instruction, so the pair cvt + packed fma stays cheaper).
+// Build: hipcc -O3 --offload-arch=gfx950 -fgpu-flush-denormals-to-zero valu_ops.hip -o valu_ops   (binary not tracked)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+#define KZ_OPS16(OP, TAIL) asm volatile( \
+    OP " %0, " TAIL(0) "\n " OP " %1, " TAIL(1) "\n " OP " %2, " TAIL(2) "\n " OP " %3, " TAIL(3) "\n " OP " %4, " TAIL(4) "\n " OP " %5, " TAIL(5) "\n " OP " %6, " TAIL(6) "\n " OP " %7, " TAIL(7) "\n " \
+    OP " %8, " TAIL(8) "\n " OP " %9, " TAIL(9) "\n " OP " %10, " TAIL(10) "\n " OP " %11, " TAIL(11) "\n " OP " %12, " TAIL(12) "\n " OP " %13, " TAIL(13) "\n " OP " %14, " TAIL(14) "\n " OP " %15, " TAIL(15) "\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : "v"(m), "v"(c), "s"(sel) : "vcc", "s20", "s21")
+#define T_1(i) "%16"
+#define T_2(i) "%16, %" #i
+#define T_2C(i) "%16, %17"
+#define T_3(i) "%16, %17, %" #i
+#define T_3D0(i) "%" #i ", %16, %17"
+#define T_3NOD(i) "%16, %17, %16"
+#define T_MIX_LO(i) "%16, %17, %" #i " op_sel_hi:[1,0,0]"
+#define T_MIX_HI(i) "%16, %17, %" #i " op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+#define T_PERM_S(i) "%16, %17, %18"
+#define T_BFE(i) "%16, 8, 8"
+#define T_CND32(i) "%16, %" #i ", vcc"
+#define T_CND64(i) "%16, %" #i ", s[20:21]"
+#define T_LSHLADD(i) "%16, 2, %" #i
+#define T_CO(i) "vcc, %16, %" #i
+#define T_1DPP(i) "%16 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define T_2DPP(i) "%16, %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define T_1SDWA(i) "%16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1"
+
+// (index, mnemonic, operand tail, description)
+#define OPS(X) \
+    X(0, "v_fma_f32", T_3, "v_fma_f32 d, m, c, d") X(1, "v_fma_f32", T_3D0, "v_fma_f32 d, d, m, c") X(2, "v_fma_f32", T_3NOD, "v_fma_f32 d, m, c, m (no chain)") \
+    X(3, "v_fmac_f32", T_2C, "v_fmac_f32 d, m, c") X(4, "v_mul_f32", T_2, "v_mul_f32 d, m, d") X(5, "v_add_f32", T_2, "v_add_f32 d, m, d") X(6, "v_sub_f32", T_2, "v_sub_f32 d, m, d") \
+    X(7, "v_add_f32_e64", T_2, "v_add_f32_e64 d, m, d") X(8, "v_max_f32", T_2, "v_max_f32 d, m, d") X(9, "v_min_f32", T_2, "v_min_f32 d, m, d") X(10, "v_max3_f32", T_3, "v_max3_f32 d, m, c, d") \
+    X(11, "v_med3_f32", T_3, "v_med3_f32 d, m, c, d") X(12, "v_fma_mix_f32", T_MIX_LO, "v_fma_mix_f32 d, m.lo(f16), c, d") X(13, "v_fma_mix_f32", T_MIX_HI, "v_fma_mix_f32 d, m.hi(f16), c, d") \
+    X(14, "v_cvt_f32_ubyte0", T_1, "v_cvt_f32_ubyte0 d, m") X(15, "v_cvt_f32_ubyte2", T_1, "v_cvt_f32_ubyte2 d, m") X(16, "v_cvt_f32_u32", T_1, "v_cvt_f32_u32 d, m") X(17, "v_cvt_u32_f32", T_1, "v_cvt_u32_f32 d, m") \
+    X(18, "v_cvt_f32_f16", T_1, "v_cvt_f32_f16 d, m") X(19, "v_floor_f32", T_1, "v_floor_f32 d, m") X(20, "v_fract_f32", T_1, "v_fract_f32 d, m") X(21, "v_rcp_f32", T_1, "v_rcp_f32 d, m") \
+    X(22, "v_sqrt_f32", T_1, "v_sqrt_f32 d, m") X(23, "v_rsq_f32", T_1, "v_rsq_f32 d, m") X(24, "v_exp_f32", T_1, "v_exp_f32 d, m") X(25, "v_log_f32", T_1, "v_log_f32 d, m") X(26, "v_sin_f32", T_1, "v_sin_f32 d, m") \
+    X(27, "v_ldexp_f32", T_2, "v_ldexp_f32 d, m, d") X(28, "v_mov_b32", T_1, "v_mov_b32 d, m") X(29, "v_and_b32", T_2, "v_and_b32 d, m, d") X(30, "v_or_b32", T_2, "v_or_b32 d, m, d") X(31, "v_xor_b32", T_2, "v_xor_b32 d, m, d") \
+    X(32, "v_lshrrev_b32", T_2, "v_lshrrev_b32 d, m, d") X(33, "v_lshlrev_b32", T_2, "v_lshlrev_b32 d, m, d") X(34, "v_ashrrev_i32", T_2, "v_ashrrev_i32 d, m, d") X(35, "v_add_u32", T_2, "v_add_u32 d, m, d") \
+    X(36, "v_sub_u32", T_2, "v_sub_u32 d, m, d") X(37, "v_add_co_u32", T_CO, "v_add_co_u32 d, vcc, m, d") X(38, "v_min_u32", T_2, "v_min_u32 d, m, d") X(39, "v_max_i32", T_2, "v_max_i32 d, m, d") \
+    X(40, "v_mul_u32_u24", T_2, "v_mul_u32_u24 d, m, d") X(41, "v_mul_lo_u32", T_2, "v_mul_lo_u32 d, m, d") X(42, "v_mul_hi_u32", T_2, "v_mul_hi_u32 d, m, d") X(43, "v_mad_u32_u24", T_3, "v_mad_u32_u24 d, m, c, d") \
+    X(44, "v_min3_u32", T_3, "v_min3_u32 d, m, c, d") X(45, "v_and_or_b32", T_3, "v_and_or_b32 d, m, c, d") X(46, "v_or3_b32", T_3, "v_or3_b32 d, m, c, d") X(47, "v_add3_u32", T_3, "v_add3_u32 d, m, c, d") \
+    X(48, "v_lshl_add_u32", T_LSHLADD, "v_lshl_add_u32 d, m, 2, d") X(49, "v_lshl_or_b32", T_LSHLADD, "v_lshl_or_b32 d, m, 2, d") X(50, "v_bfe_u32", T_BFE, "v_bfe_u32 d, m, 8, 8") X(51, "v_bfi_b32", T_3, "v_bfi_b32 d, m, c, d") \
+    X(52, "v_perm_b32", T_PERM_S, "v_perm_b32 d, m, c, s") X(53, "v_alignbit_b32", T_3, "v_alignbit_b32 d, m, c, d") X(54, "v_bcnt_u32_b32", T_2, "v_bcnt_u32_b32 d, m, d") X(55, "v_ffbl_b32", T_1, "v_ffbl_b32 d, m") \
+    X(56, "v_mbcnt_lo_u32_b32", T_2, "v_mbcnt_lo_u32_b32 d, m, d") X(57, "v_cndmask_b32_e64", T_CND64, "v_cndmask_b32_e64 d, m, d, s[20:21]") X(58, "v_cndmask_b32_e32", T_CND32, "v_cndmask_b32_e32 d, m, d, vcc (vcc written by a v_cmp per 16)") \
+    X(59, "v_mov_b32_dpp", T_1DPP, "v_mov_b32_dpp d, m quad_perm") X(60, "v_add_f32_dpp", T_2DPP, "v_add_f32_dpp d, m, d quad_perm") X(61, "v_max_f32_dpp", T_2DPP, "v_max_f32_dpp d, m, d quad_perm") \
+    X(62, "v_cvt_f32_u32_sdwa", T_1SDWA, "v_cvt_f32_u32_sdwa d, m src0_sel:BYTE_1") X(63, "v_xad_u32", T_3, "v_xad_u32 d, m, c, d") X(64, "v_cvt_pk_f32_fp8", T_1PK, "v_cvt_pk_f32_fp8 d[2], m")
+#define N_OPS 65
+
+template <int V>
+__global__ __launch_bounds__(256) void loop(int iters, float seed, unsigned sel, float *__restrict__ sink) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * 0.5f, b3 = a3 * 0.5f, b4 = a4 * 0.5f, b5 = a5 * 0.5f, b6 = a6 * 0.5f, b7 = a7 * 0.5f;
+    const float m = __uint_as_float(0x00370012u + threadIdx.x), c = 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 16; ++rep) {
+            if (V == 58) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(m), "v"(a0) : "vcc");
+#define T_1PK(i) "%16"
+#define X(K, OP, TAIL, DESC) if (V == K && K != 64) KZ_OPS16(OP, TAIL);
+            OPS(X)
+#undef X
+        }
+    }
+    const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7;
+    if (s == 12345.678f) sink[0] = s;
+}
+
+// 64-bit destinations / sources: v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, v_cvt_pk_f32_fp8, v_fma_f64
+template <int V>
+__global__ __launch_bounds__(256) void loopPk(int iters, float seed, float *__restrict__ sink) {
+    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const double m = a0 * 0.5, c = 1e-3; const float ms = (float)a0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 32; ++rep) {
+#define KZ_PK8(OP, T) asm volatile(OP " %0, " T(0) "\n " OP " %1, " T(1) "\n " OP " %2, " T(2) "\n " OP " %3, " T(3) "\n " OP " %4, " T(4) "\n " OP " %5, " T(5) "\n " OP " %6, " T(6) "\n " OP " %7, " T(7) "\n" \
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c), "v"(ms))
+#define P_3(i) "%8, %9, %" #i
+#define P_2(i) "%8, %" #i
+#define P_CVT(i) "%10"
+            if (V == 0) KZ_PK8("v_pk_fma_f32", P_3);
+            else if (V == 1) KZ_PK8("v_pk_mul_f32", P_2);
+            else if (V == 2) KZ_PK8("v_pk_add_f32", P_2);
+            else if (V == 3) KZ_PK8("v_cvt_pk_f32_fp8", P_CVT);
+            else KZ_PK8("v_fma_f64", P_3);
+        }
+    }
+    const double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (s == 12345.678) sink[0] = (float)s;
+}
+
+// v_cmp writing vcc (e32) or an SGPR pair (e64)
+template <int V>
+__global__ __launch_bounds__(256) void loopCmp(int iters, float seed, float *__restrict__ sink) {
+    float a0 = seed + threadIdx.x, m = a0 * 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 16; ++rep) {
+            if (V == 0) asm volatile("v_cmp_le_f32_e32 vcc, %0, %1\n v_cmp_lt_f32_e32 vcc, %0, %1\n v_cmp_le_f32_e32 vcc, %1, %0\n v_cmp_lt_f32_e32 vcc, %1, %0\n v_cmp_le_f32_e32 vcc, %0, %1\n v_cmp_lt_f32_e32 vcc, %0, %1\n v_cmp_le_f32_e32 vcc, %1, %0\n v_cmp_lt_f32_e32 vcc, %1, %0\n"
+                                     "v_cmp_le_f32_e32 vcc, %0, %1\n v_cmp_lt_f32_e32 vcc, %0, %1\n v_cmp_le_f32_e32 vcc, %1, %0\n v_cmp_lt_f32_e32 vcc, %1, %0\n v_cmp_le_f32_e32 vcc, %0, %1\n v_cmp_lt_f32_e32 vcc, %0, %1\n v_cmp_le_f32_e32 vcc, %1, %0\n v_cmp_lt_f32_e32 vcc, %1, %0\n" : : "v"(a0), "v"(m) : "vcc");
+            else asm volatile("v_cmp_le_f32_e64 s[20:21], %0, %1\n v_cmp_lt_f32_e64 s[22:23], %0, %1\n v_cmp_le_f32_e64 s[24:25], %1, %0\n v_cmp_lt_f32_e64 s[26:27], %1, %0\n v_cmp_le_f32_e64 s[20:21], %0, %1\n v_cmp_lt_f32_e64 s[22:23], %0, %1\n v_cmp_le_f32_e64 s[24:25], %1, %0\n v_cmp_lt_f32_e64 s[26:27], %1, %0\n"
+                              "v_cmp_le_f32_e64 s[20:21], %0, %1\n v_cmp_lt_f32_e64 s[22:23], %0, %1\n v_cmp_le_f32_e64 s[24:25], %1, %0\n v_cmp_lt_f32_e64 s[26:27], %1, %0\n v_cmp_le_f32_e64 s[20:21], %0, %1\n v_cmp_lt_f32_e64 s[22:23], %0, %1\n v_cmp_le_f32_e64 s[24:25], %1, %0\n v_cmp_lt_f32_e64 s[26:27], %1, %0\n" : : "v"(a0), "v"(m) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        }
+    }
+    if (a0 == 12345.678f) sink[0] = a0;
+}
+
+// instructions that read vcc implicitly, alone and diluted in a stream of v_fma_f32 (per block of 16: 4 of the instruction + 12 fma)
+template <int V>
+__global__ __launch_bounds__(256) void loopVcc(int iters, float seed, float *__restrict__ sink) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * 0.5f, b3 = a3 * 0.5f;
+    const float m = a0 * 0.25f, c = 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 16; ++rep) {
+#define MIX4(I) I(0) "\n v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n" I(1) "\n v_fma_f32 %7, %8, %9, %7\n v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n" \
+                I(2) "\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7\n v_fma_f32 %4, %8, %9, %4\n" I(3) "\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7\n"
+#define ALL16(I) I(0) "\n" I(1) "\n" I(2) "\n" I(3) "\n" I(0) "\n" I(1) "\n" I(2) "\n" I(3) "\n" I(0) "\n" I(1) "\n" I(2) "\n" I(3) "\n" I(0) "\n" I(1) "\n" I(2) "\n" I(3) "\n"
+#define I_CND32(i) "v_cndmask_b32_e32 %" #i ", %8, %" #i ", vcc"
+#define I_CND64(i) "v_cndmask_b32_e64 %" #i ", %8, %" #i ", s[20:21]"
+#define I_CND64V(i) "v_cndmask_b32_e64 %" #i ", %8, %" #i ", vcc"
+#define I_ADDC(i) "v_addc_co_u32_e32 %" #i ", vcc, %8, %" #i ", vcc"
+#define I_ADDC64(i) "v_addc_co_u32_e64 %" #i ", s[20:21], %8, %" #i ", s[20:21]"
+#define I_ADDCO(i) "v_add_co_u32_e32 %" #i ", vcc, %8, %" #i
+#define I_LSHLADD64(i) "v_lshl_add_u64 %" #i ", %10, 2, %" #i
+#define OUTS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "v"(m), "v"(c) : "vcc", "s20", "s21"
+            if (V == 0) asm volatile(MIX4(I_CND32) OUTS);
+            else if (V == 1) asm volatile(MIX4(I_CND64) OUTS);
+            else if (V == 2) asm volatile(MIX4(I_CND64V) OUTS);
+            else if (V == 3) asm volatile(MIX4(I_ADDC) OUTS);
+            else if (V == 4) asm volatile(MIX4(I_ADDC64) OUTS);
+            else if (V == 5) asm volatile(ALL16(I_ADDC) OUTS);
+            else if (V == 6) asm volatile(ALL16(I_ADDC64) OUTS);
+            else if (V == 7) asm volatile(ALL16(I_ADDCO) OUTS);
+            else asm volatile("v_cmp_lt_f32_e32 vcc, %8, %9\n" ALL16(I_CND32) OUTS);
+        }
+    }
+    const float s = a0 + a1 + a2 + a3 + b0 + b1 + b2 + b3;
+    if (s == 12345.678f) sink[0] = s;
+}
+
+// fl(q * a + b) three ways for every byte q and 4096 (a, b) pairs per byte
+__global__ void checkMix(const float *__restrict__ A, const float *__restrict__ B, int n, unsigned *__restrict__ bad, float *__restrict__ sample) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 256) return;
+    const unsigned q = i & 255u; const float a = A[i >> 8], b = B[i >> 8];
+    const unsigned word = q * 0x01010101u;                          // the byte in every position
+    float viaCvt;
+    { const float qf = (float)((word >> 8) & 0xffu); viaCvt = __builtin_fmaf(qf, a, b); }
+    const float a24 = a * 16777216.f;
+    const unsigned h = word & 0x00ff00ffu;                          // two f16 denormals 0x00qq
+    float lo, hi;
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(h), "v"(a24), "v"(b));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(h), "v"(a24), "v"(b));
+    if (__float_as_uint(lo) != __float_as_uint(viaCvt) || __float_as_uint(hi) != __float_as_uint(viaCvt)) atomicAdd(bad, 1u);
+    if (i == 77 * 256 + 200) { sample[0] = viaCvt; sample[1] = lo; sample[2] = hi; }
+}
+
+int main(int argc, char **argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 1500;
+    const double warmSeconds = argc > 2 ? atof(argv[2]) : 0.5;
+    const int firstOp = argc > 3 ? atoi(argv[3]) : 0;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int nCU = prop.multiProcessorCount;
+    float *dSink; CK(hipMalloc(&dSink, 64));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // ---- correctness of the denormal-f16 read
+    const int n = 4096;
+    std::vector<float> hA(n), hB(n);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xFFFFFF) / 16777216.f; };
+    for (int i = 0; i < n; ++i) {                                   // a = 2^e / d over many magnitudes and both signs, b = (p - o) / d
+        const float d = (rnd() * 2.f - 1.f) * std::ldexp(1.f, (int)(rnd() * 40.f) - 30);
+        hA[i] = std::ldexp(1.f, (int)(rnd() * 24.f) - 16) / (d == 0.f ? 1e-20f : d);
+        hB[i] = (rnd() * 2.f - 1.f) * 10.f / (d == 0.f ? 1e-20f : d);
+    }
+    float *dA, *dB, *dSample; unsigned *dBad;
+    CK(hipMalloc(&dA, n * 4)); CK(hipMalloc(&dB, n * 4)); CK(hipMalloc(&dBad, 4)); CK(hipMalloc(&dSample, 16));
+    CK(hipMemcpy(dA, hA.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemset(dBad, 0, 4));
+    hipLaunchKernelGGL(checkMix, dim3(n), dim3(256), 0, 0, dA, dB, n, dBad, dSample);
+    unsigned bad = 0; float smp[3]; CK(hipMemcpy(&bad, dBad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(smp, dSample, 12, hipMemcpyDeviceToHost));
+    printf("{\"device\": \"%s\", \"cus\": %d, \"fma_mix_denormal_f16_check\": {\"cases\": %d, \"different_from_cvt_fma\": %u, \"sample\": [%.9g, %.9g, %.9g]},\n \"results\": [\n",
+           prop.name, nCU, n * 256, bad, smp[0], smp[1], smp[2]);
+    static const char *opName[N_OPS + 16] = {
+#define X(K, OP, TAIL, DESC) DESC,
+        OPS(X)
+#undef X
+        "v_pk_fma_f32 d[2], m[2], c[2], d[2]", "v_pk_mul_f32 d[2], m[2], d[2]", "v_pk_add_f32 d[2], m[2], d[2]", "v_cvt_pk_f32_fp8 d[2], m", "v_fma_f64 d, m, c, d", "v_cmp_*_f32_e32 vcc", "v_cmp_*_f32_e64 s[n:n+1]",
+        "MIX 4 v_cndmask_b32_e32 ..vcc + 12 v_fma_f32", "MIX 4 v_cndmask_b32_e64 ..s[20:21] + 12 v_fma_f32", "MIX 4 v_cndmask_b32_e64 ..vcc + 12 v_fma_f32", "MIX 4 v_addc_co_u32_e32 + 12 v_fma_f32",
+        "MIX 4 v_addc_co_u32_e64 s[20:21] + 12 v_fma_f32", "v_addc_co_u32_e32 d, vcc, m, d, vcc", "v_addc_co_u32_e64 d, s[20:21], m, d, s[20:21]", "v_add_co_u32_e32 d, vcc, m, d", "v_cmp + 16 v_cndmask_b32_e32 on 4 registers"};
+    bool first = true;
+    const int grid = nCU * 8;
+    for (int v = 0; v < N_OPS + 16; ++v) {
+        if (v == 64 || v < firstOp) continue;                                     // (measured by loopPk<3>)
+        auto launch = [&]() { switch (v) {
+#define X(K, OP, TAIL, DESC) case K: hipLaunchKernelGGL(loop<K>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, 0x0c010c00u, dSink); break;
+            OPS(X)
+#undef X
+            case N_OPS + 0: hipLaunchKernelGGL(loopPk<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 1: hipLaunchKernelGGL(loopPk<1>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 2: hipLaunchKernelGGL(loopPk<2>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 3: hipLaunchKernelGGL(loopPk<3>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 4: hipLaunchKernelGGL(loopPk<4>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 5: hipLaunchKernelGGL(loopCmp<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 6: hipLaunchKernelGGL(loopCmp<1>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 7: hipLaunchKernelGGL(loopVcc<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 8: hipLaunchKernelGGL(loopVcc<1>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 9: hipLaunchKernelGGL(loopVcc<2>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 10: hipLaunchKernelGGL(loopVcc<3>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 11: hipLaunchKernelGGL(loopVcc<4>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 12: hipLaunchKernelGGL(loopVcc<5>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 13: hipLaunchKernelGGL(loopVcc<6>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 14: hipLaunchKernelGGL(loopVcc<7>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            default: hipLaunchKernelGGL(loopVcc<8>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); } };
+        launch(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        float one = 0; CK(hipEventElapsedTime(&one, e0, e1));
+        const int nWarm = std::max(1, (int)(warmSeconds * 1e3 / std::max(one, 1e-3f)));
+        for (int i = 0; i < nWarm; ++i) launch();
+        const int nTimed = 8;
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < nTimed; ++i) launch();
+        CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= nTimed;
+        const double total = 256.0 * iters * (double)grid * 4.0, rate = total / (ms * 1e-3) / 1e9;
+        printf("%s{\"op\": \"%s\", \"kernel_ms\": %.4f, \"chip_G_wave_instr_per_s\": %.1f, \"cycles_per_wave_instr_per_simd_at_2.383GHz\": %.3f}", first ? "" : ",\n", opName[v], ms, rate,
+               nCU * 4 * 2.383 / rate);
+        first = false;
+    }
+    printf("\n]}\n");
+    return 0;
+}
