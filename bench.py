@@ -268,8 +268,11 @@ def main():
         roofline = {"bound": "valu", "unit": "G wave-instr/s", "peak": round(peak_rate, 1),
                     "peak_source": "0.5 wave64 VALU instructions per cycle per SIMD (MI355X_MICROARCH.md) x 1024 SIMDs x the in-kernel clock measured under a "
                                    "saturated VALU stream (profiles/%s)" % peak["profile"],
-                    "peak_measured": {"vop2_two_sources": round(peak["vop2_wave_instr_per_s"] / 1e9, 1), "vop3_three_sources": round(peak["vop3_wave_instr_per_s"] / 1e9, 1),
-                                      "node_step_mix": peak.get("node_mix_wave_instr_per_s") and round(peak["node_mix_wave_instr_per_s"] / 1e9, 1)},
+                    "peak_measured": {"full_rate_class": round(peak["full_rate_class_wave_instr_per_s"] / 1e9, 1), "half_rate_class": round(peak["half_rate_class_wave_instr_per_s"] / 1e9, 1),
+                                      "transcendental": round(peak["transcendental_wave_instr_per_s"] / 1e9, 1),
+                                      "node_step_mix": peak.get("node_mix_wave_instr_per_s") and round(peak["node_mix_wave_instr_per_s"] / 1e9, 1),
+                                      "classes": "mul/add/sub/fma f32, mov, and/or/xor, lshr/ashr, add/sub u32 issue in 2.2 cycles; min/max, cmp, cndmask, cvt, bfe/perm/lshl and 3-operand integer ops in 4; "
+                                                 "rcp/sqrt/exp in 8 (profiles/r03u_valu_ops): the node step is mostly the 4-cycle class"},
                     "achieved": None, "frac": None, "traffic": None,
                     "kernel": "kz_wf_trace<0> (closest hit of the bounce rays), %d launches per pass" % n_bounce,
                     "kernel_ms_one_pass_alone": stage_ms["trace_bounce"], "pass_ms_in_flight": round(kernel_ms_last, 3),

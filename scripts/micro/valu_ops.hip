@@ -1,8 +1,10 @@
 // Microbenchmark: sustained issue rate (wave64, 8 waves per SIMD, every CU) of the VALU instructions the hot kernels are made of, with
 // valu_clock.hip's method (16 independent registers, 256-instruction loop bodies, warm-up launches first). Found with it (profiles/r03u_valu_ops):
 // a gfx950 SIMD issues a wave64 instruction in 4 cycles, and only a SUBSET runs at the doubled rate the guide quotes for v_fma_f32
-// (2.2 cycles): fma / mul / add / sub / fmac, and / or / xor / shifts / mov. Everything else the BVH4 node step uses - min / max / min3 / max3,
-// every v_cmp, v_cndmask, every conversion, bfe / perm / and_or / add3 / lshl_add / mad_u24 - takes the 4 cycles.
+// (2.2 cycles): mul / add / sub, and / or / xor / lshr / ashr / add_u32 / sub_u32 / mov - and v_fma_f32 / v_fmac_f32 only while a factor is zero: with
+// real numbers they take 3.6 cycles (the same on ONE busy CU as on 256: not a power limit). Everything else the BVH4 node step uses - min / max /
+// min3 / max3, every v_cmp, v_cndmask, every conversion, lshl / bfe / perm / and_or / add3 / lshl_add / mad_u24, the packed f32 ops - takes the 4 cycles
+// (transcendentals 8; back-to-back v_cndmask_b32_e32 16).
 // It also checks the idea that started it:
 //     byte q as the binary16 DENORMAL 0x00qq = q * 2^-24, read by v_fma_mix_f32 together with a * 2^24 and b:   fl(q * a + b), bit for bit
 //     what v_cvt_f32_ubyteN + v_fma_f32 give (true; but v_fma_mix_f32 is a 4-cycle instruction, so the pair cvt + packed fma stays cheaper).
@@ -39,7 +41,7 @@
 
 // (index, mnemonic, operand tail, description)
 #define OPS(X) \
-    X(0, "v_fma_f32", T_3, "v_fma_f32 d, m, c, d") X(1, "v_fma_f32", T_3D0, "v_fma_f32 d, d, m, c") X(2, "v_fma_f32", T_3NOD, "v_fma_f32 d, m, c, m (no chain)") \
+    X(0, "v_fma_f32", T_3, "v_fma_f32 d, m, c, d with m flushed to zero") X(1, "v_fma_f32", T_3D0, "v_fma_f32 d, d, m, c with m flushed to zero") X(2, "v_fma_f32", T_3NOD, "v_fma_f32 d, m, c, m (no chain) with m flushed to zero") \
     X(3, "v_fmac_f32", T_2C, "v_fmac_f32 d, m, c") X(4, "v_mul_f32", T_2, "v_mul_f32 d, m, d") X(5, "v_add_f32", T_2, "v_add_f32 d, m, d") X(6, "v_sub_f32", T_2, "v_sub_f32 d, m, d") \
     X(7, "v_add_f32_e64", T_2, "v_add_f32_e64 d, m, d") X(8, "v_max_f32", T_2, "v_max_f32 d, m, d") X(9, "v_min_f32", T_2, "v_min_f32 d, m, d") X(10, "v_max3_f32", T_3, "v_max3_f32 d, m, c, d") \
     X(11, "v_med3_f32", T_3, "v_med3_f32 d, m, c, d") X(12, "v_fma_mix_f32", T_MIX_LO, "v_fma_mix_f32 d, m.lo(f16), c, d") X(13, "v_fma_mix_f32", T_MIX_HI, "v_fma_mix_f32 d, m.hi(f16), c, d") \
@@ -55,14 +57,18 @@
     X(52, "v_perm_b32", T_PERM_S, "v_perm_b32 d, m, c, s") X(53, "v_alignbit_b32", T_3, "v_alignbit_b32 d, m, c, d") X(54, "v_bcnt_u32_b32", T_2, "v_bcnt_u32_b32 d, m, d") X(55, "v_ffbl_b32", T_1, "v_ffbl_b32 d, m") \
     X(56, "v_mbcnt_lo_u32_b32", T_2, "v_mbcnt_lo_u32_b32 d, m, d") X(57, "v_cndmask_b32_e64", T_CND64, "v_cndmask_b32_e64 d, m, d, s[20:21]") X(58, "v_cndmask_b32_e32", T_CND32, "v_cndmask_b32_e32 d, m, d, vcc (vcc written by a v_cmp per 16)") \
     X(59, "v_mov_b32_dpp", T_1DPP, "v_mov_b32_dpp d, m quad_perm") X(60, "v_add_f32_dpp", T_2DPP, "v_add_f32_dpp d, m, d quad_perm") X(61, "v_max_f32_dpp", T_2DPP, "v_max_f32_dpp d, m, d quad_perm") \
-    X(62, "v_cvt_f32_u32_sdwa", T_1SDWA, "v_cvt_f32_u32_sdwa d, m src0_sel:BYTE_1") X(63, "v_xad_u32", T_3, "v_xad_u32 d, m, c, d") X(64, "v_cvt_pk_f32_fp8", T_1PK, "v_cvt_pk_f32_fp8 d[2], m")
-#define N_OPS 65
+    X(62, "v_cvt_f32_u32_sdwa", T_1SDWA, "v_cvt_f32_u32_sdwa d, m src0_sel:BYTE_1") X(63, "v_xad_u32", T_3, "v_xad_u32 d, m, c, d") X(64, "v_cvt_pk_f32_fp8", T_1PK, "v_cvt_pk_f32_fp8 d[2], m") \
+    X(65, "v_fma_f32", T_3D0, "v_fma_f32 d, d, m, c with m = 0.999, c = 1e-3 (values that move: valu_clock.hip's operands)") X(66, "v_fma_f32", T_3, "v_fma_f32 d, m, c, d with m = 0.999, c = 1e-3") \
+    X(67, "v_mul_f32", T_2, "v_mul_f32 d, m, d with m = 0.999") X(68, "v_max_f32", T_2, "v_max_f32 d, m, d with m = 0.999")
+#define N_OPS 69
 
 template <int V>
-__global__ __launch_bounds__(256) void loop(int iters, float seed, unsigned sel, float *__restrict__ sink) {
+__global__ __launch_bounds__(1024) void loop(int iters, float seed, unsigned sel, float *__restrict__ sink) {
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * 0.5f, b3 = a3 * 0.5f, b4 = a4 * 0.5f, b5 = a5 * 0.5f, b6 = a6 * 0.5f, b7 = a7 * 0.5f;
-    const float m = __uint_as_float(0x00370012u + threadIdx.x), c = 1e-3f;
+    // operands whose values MOVE (x <- 0.999 x + 1e-3 and the like): v_fma_f32 issues in 2.2 cycles when a factor is zero or flushed to zero and the
+    // result does not change, in 3.6 with real numbers. V 0..2: the denormal (flushed) factor kept, to show exactly that.
+    const float m = V <= 2 ? __uint_as_float(0x00370012u + threadIdx.x) : 0.999f + 1e-6f * (threadIdx.x & 7), c = 1e-3f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int rep = 0; rep < 16; ++rep) {
@@ -80,8 +86,12 @@ __global__ __launch_bounds__(256) void loop(int iters, float seed, unsigned sel,
 // 64-bit destinations / sources: v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32, v_cvt_pk_f32_fp8, v_fma_f64
 template <int V>
 __global__ __launch_bounds__(256) void loopPk(int iters, float seed, float *__restrict__ sink) {
-    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
-    const double m = a0 * 0.5, c = 1e-3; const float ms = (float)a0;
+    // (V < 5: the register pairs hold two floats each - values that move, 0.999 x + 1e-3 per lane half; V == 4 / 5: doubles)
+    auto pair = [](float lo, float hi) { return __hiloint2double(__float_as_int(hi), __float_as_int(lo)); };
+    const float f0 = seed + threadIdx.x;
+    double a0 = V >= 4 ? (double)f0 : pair(f0, f0 + 0.5f), a1 = V >= 4 ? a0 + 1 : pair(f0 + 1, f0 + 1.5f), a2 = V >= 4 ? a0 + 2 : pair(f0 + 2, f0 + 2.5f), a3 = V >= 4 ? a0 + 3 : pair(f0 + 3, f0 + 3.5f),
+           a4 = V >= 4 ? a0 + 4 : pair(f0 + 4, f0 + 4.5f), a5 = V >= 4 ? a0 + 5 : pair(f0 + 5, f0 + 5.5f), a6 = V >= 4 ? a0 + 6 : pair(f0 + 6, f0 + 6.5f), a7 = V >= 4 ? a0 + 7 : pair(f0 + 7, f0 + 7.5f);
+    const double m = V >= 4 ? 0.999 : pair(0.999f, 0.998f), c = V >= 4 ? 1e-3 : pair(1e-3f, 2e-3f); const float ms = f0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int rep = 0; rep < 32; ++rep) {
@@ -94,7 +104,8 @@ __global__ __launch_bounds__(256) void loopPk(int iters, float seed, float *__re
             else if (V == 1) KZ_PK8("v_pk_mul_f32", P_2);
             else if (V == 2) KZ_PK8("v_pk_add_f32", P_2);
             else if (V == 3) KZ_PK8("v_cvt_pk_f32_fp8", P_CVT);
-            else KZ_PK8("v_fma_f64", P_3);
+            else if (V == 4) KZ_PK8("v_fma_f64", P_3);
+            else KZ_PK8("v_mul_f64", P_2);
         }
     }
     const double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -172,6 +183,8 @@ int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 1500;
     const double warmSeconds = argc > 2 ? atof(argv[2]) : 0.5;
     const int firstOp = argc > 3 ? atoi(argv[3]) : 0;
+    const int blockArg = argc > 5 ? atoi(argv[5]) : 256;          // threads per workgroup of the plain-op kernels (1024 = 4 waves per SIMD of ONE CU per workgroup)
+    const int gridArg = argc > 4 ? atoi(argv[4]) : 0;              // workgroups (0 = 8 per CU): a small grid keeps the chip far from its power limit
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int nCU = prop.multiProcessorCount;
     float *dSink; CK(hipMalloc(&dSink, 64));
@@ -193,19 +206,20 @@ int main(int argc, char **argv) {
     unsigned bad = 0; float smp[3]; CK(hipMemcpy(&bad, dBad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(smp, dSample, 12, hipMemcpyDeviceToHost));
     printf("{\"device\": \"%s\", \"cus\": %d, \"fma_mix_denormal_f16_check\": {\"cases\": %d, \"different_from_cvt_fma\": %u, \"sample\": [%.9g, %.9g, %.9g]},\n \"results\": [\n",
            prop.name, nCU, n * 256, bad, smp[0], smp[1], smp[2]);
-    static const char *opName[N_OPS + 16] = {
+    static const char *opName[N_OPS + 17] = {
 #define X(K, OP, TAIL, DESC) DESC,
         OPS(X)
 #undef X
-        "v_pk_fma_f32 d[2], m[2], c[2], d[2]", "v_pk_mul_f32 d[2], m[2], d[2]", "v_pk_add_f32 d[2], m[2], d[2]", "v_cvt_pk_f32_fp8 d[2], m", "v_fma_f64 d, m, c, d", "v_cmp_*_f32_e32 vcc", "v_cmp_*_f32_e64 s[n:n+1]",
+        "v_pk_fma_f32 d[2], m[2], c[2], d[2]", "v_pk_mul_f32 d[2], m[2], d[2]", "v_pk_add_f32 d[2], m[2], d[2]", "v_cvt_pk_f32_fp8 d[2], m", "v_fma_f64 d, m, c, d", "v_mul_f64 d, m, d", "v_cmp_*_f32_e32 vcc", "v_cmp_*_f32_e64 s[n:n+1]",
         "MIX 4 v_cndmask_b32_e32 ..vcc + 12 v_fma_f32", "MIX 4 v_cndmask_b32_e64 ..s[20:21] + 12 v_fma_f32", "MIX 4 v_cndmask_b32_e64 ..vcc + 12 v_fma_f32", "MIX 4 v_addc_co_u32_e32 + 12 v_fma_f32",
         "MIX 4 v_addc_co_u32_e64 s[20:21] + 12 v_fma_f32", "v_addc_co_u32_e32 d, vcc, m, d, vcc", "v_addc_co_u32_e64 d, s[20:21], m, d, s[20:21]", "v_add_co_u32_e32 d, vcc, m, d", "v_cmp + 16 v_cndmask_b32_e32 on 4 registers"};
     bool first = true;
-    const int grid = nCU * 8;
-    for (int v = 0; v < N_OPS + 16; ++v) {
+    const int grid = gridArg > 0 ? gridArg : nCU * 8;
+    printf("{\"workgroups\": %d},\n", grid);
+    for (int v = 0; v < N_OPS + 17; ++v) {
         if (v == 64 || v < firstOp) continue;                                     // (measured by loopPk<3>)
         auto launch = [&]() { switch (v) {
-#define X(K, OP, TAIL, DESC) case K: hipLaunchKernelGGL(loop<K>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, 0x0c010c00u, dSink); break;
+#define X(K, OP, TAIL, DESC) case K: hipLaunchKernelGGL(loop<K>, dim3(grid), dim3(blockArg), 0, 0, iters, 1.0f, 0x0c010c00u, dSink); break;
             OPS(X)
 #undef X
             case N_OPS + 0: hipLaunchKernelGGL(loopPk<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
@@ -213,16 +227,17 @@ int main(int argc, char **argv) {
             case N_OPS + 2: hipLaunchKernelGGL(loopPk<2>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
             case N_OPS + 3: hipLaunchKernelGGL(loopPk<3>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
             case N_OPS + 4: hipLaunchKernelGGL(loopPk<4>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 5: hipLaunchKernelGGL(loopCmp<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 6: hipLaunchKernelGGL(loopCmp<1>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 7: hipLaunchKernelGGL(loopVcc<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 8: hipLaunchKernelGGL(loopVcc<1>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 9: hipLaunchKernelGGL(loopVcc<2>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 10: hipLaunchKernelGGL(loopVcc<3>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 11: hipLaunchKernelGGL(loopVcc<4>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 12: hipLaunchKernelGGL(loopVcc<5>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 13: hipLaunchKernelGGL(loopVcc<6>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
-            case N_OPS + 14: hipLaunchKernelGGL(loopVcc<7>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 5: hipLaunchKernelGGL(loopPk<5>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 6: hipLaunchKernelGGL(loopCmp<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 7: hipLaunchKernelGGL(loopCmp<1>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 8: hipLaunchKernelGGL(loopVcc<0>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 9: hipLaunchKernelGGL(loopVcc<1>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 10: hipLaunchKernelGGL(loopVcc<2>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 11: hipLaunchKernelGGL(loopVcc<3>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 12: hipLaunchKernelGGL(loopVcc<4>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 13: hipLaunchKernelGGL(loopVcc<5>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 14: hipLaunchKernelGGL(loopVcc<6>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
+            case N_OPS + 15: hipLaunchKernelGGL(loopVcc<7>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); break;
             default: hipLaunchKernelGGL(loopVcc<8>, dim3(grid), dim3(256), 0, 0, iters, 1.0f, dSink); } };
         launch(); CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
@@ -234,9 +249,9 @@ int main(int argc, char **argv) {
         for (int i = 0; i < nTimed; ++i) launch();
         CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= nTimed;
-        const double total = 256.0 * iters * (double)grid * 4.0, rate = total / (ms * 1e-3) / 1e9;
+        const double total = 256.0 * iters * (double)grid * (v < N_OPS ? blockArg / 64.0 : 4.0), rate = total / (ms * 1e-3) / 1e9;
         printf("%s{\"op\": \"%s\", \"kernel_ms\": %.4f, \"chip_G_wave_instr_per_s\": %.1f, \"cycles_per_wave_instr_per_simd_at_2.383GHz\": %.3f}", first ? "" : ",\n", opName[v], ms, rate,
-               nCU * 4 * 2.383 / rate);
+               (grid < nCU * 8 ? grid / 8.0 : (double)nCU) * 4 * 2.383 / rate);
         first = false;
     }
     printf("\n]}\n");
