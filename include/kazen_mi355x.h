@@ -318,7 +318,9 @@ typedef struct KzScene KzScene;
 
 /* Build the immutable scene: copy + flatten the description, build the BVH on the host
  * (replaces Accel::build, accel.cpp:25-61, and Mesh::activate's light CDF, mesh.cpp:24-45,
- * and PerspectiveCamera::activate, camera.cpp:35-68). No GPU needed. */
+ * and PerspectiveCamera::activate, camera.cpp:35-68). No GPU needed.
+ * Size limits (KZ_ERR_UNSUPPORTED beyond them): leaf references address 2^28 triangles; the traversal kernels fetch a BVH4 packet at
+ * table base + a 32-bit byte offset, so a tree may hold 2^26 packets (4 GB; a 1 M-triangle scene has ~0.5 M). */
 int kz_scene_create(const KzSceneDesc *desc, KzScene **out);
 void kz_scene_destroy(KzScene *scene);
 
