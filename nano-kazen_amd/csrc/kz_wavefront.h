@@ -513,7 +513,16 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
     // development build only (-DKZ_LANESTAT): where the lanes of the while-while loop are, summed per wave (wave-uniform counts)
     unsigned long long lsNodeIters = 0, lsActiveAtNode = 0, lsInnerAtNode = 0, lsLeafPhases = 0, lsLeafLanes = 0, lsRefills = 0, lsRefillLanes = 0, lsTriIters = 0;
 #endif
-    auto addPending = [&]() { const float4 l = W.shL[slot]; W.outR[slot] += l.x; W.outG[slot] += l.y; W.outB[slot] += l.z; };
+    // An unoccluded shadow ray adds its pending radiance to the path's sums. As plain read-modify-writes that was three dependent HBM round
+    // trips in the middle of the loop (load, wait, add, store - per colour, the compiler keeps them apart), with the whole wave waiting each time a
+    // lane's ray ended: the shadow kernel ran at VALU busy 0.75 where the closest-hit kernel, which only stores, reaches 0.99. The pending radiance
+    // now arrives with the ray at the refill (MODE 4) and the sums take it as returnless float atomics (one writer per slot: the same single
+    // rounding as the add): nothing to wait for.
+    float plR = 0.f, plG = 0.f, plB = 0.f;
+    auto addPending = [&]() {
+        if (MODE != 4) { const float4 l = W.shL[slot]; plR = l.x; plG = l.y; plB = l.z; }
+        unsafeAtomicAdd(W.outR + slot, plR); unsafeAtomicAdd(W.outG + slot, plG); unsafeAtomicAdd(W.outB + slot, plB);
+    };
     // the lane's stack ran empty: publish the result (or, for a literal shadow lane, decide / walk through the light)
     auto finish = [&]() {
         active = false;
@@ -569,7 +578,8 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
                     top = stkBase;                                    // (an idle lane's stack is empty, or abandoned by an occluded shadow ray)
                     float4 a, b;
                     if (kind == 0) { a = W.rayA[slot]; b = W.rayB[slot]; }
-                    else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w); }
+                    else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w);
+                           if (MODE == 4) { const float4 l = W.shL[slot]; plR = l.x; plG = l.y; plB = l.z; } }
                     o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); tmin = a.w; tmax = b.w; segMax = b.w;
                     found = false; bt = KZ_INF; bu = bv = 0.f; btri = 0; bgid = 0; literal = false;
                     if (STATS && MODE != 4) cn.rays++;
