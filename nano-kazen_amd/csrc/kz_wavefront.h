@@ -259,7 +259,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                 if (iter > 0 && P.bgPresent) {
                     const float4 th = W.thr[slot];
                     const V3 c = mk(th.x, th.y, th.z) * backgroundRadiance(P, T, rd);
-                    W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
+                    unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);      // (returnless: no wait, one writer per slot)
                 }
             } else {
                 RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     if (iter > 0 && mi.z == 0.f) bsdfWeight = powerHeuristic(mi.x, lightPdfSolidAngle(lr.normalization, its.sh.n, wi, its.p, ro));   // mi.z: EDiscrete (integrator.cpp:329-331)
                     if (dot(its.sh.n, -wi) > 0.f) {
                         const V3 c = (bsdfWeight * mk(th.x, th.y, th.z)) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
-                        W.outR[slot] += c.x; W.outG[slot] += c.y; W.outB[slot] += c.z;
+                        unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);      // (returnless: no wait, one writer per slot)
                     }
                 } else {
                     // A one-sided BSDF seen from below evaluates to 0 for every light sample (no shadow ray, nothing added) and its
@@ -520,8 +520,9 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
     // rounding as the add): nothing to wait for.
     float plR = 0.f, plG = 0.f, plB = 0.f;
     auto addPending = [&]() {
-        if (MODE != 4) { const float4 l = W.shL[slot]; plR = l.x; plG = l.y; plB = l.z; }
-        unsafeAtomicAdd(W.outR + slot, plR); unsafeAtomicAdd(W.outG + slot, plG); unsafeAtomicAdd(W.outB + slot, plB);
+        uint32_t s_ = slot; asm volatile("" : "+v"(s_));          // (the three addresses are formed here: hoisted to the refill they were six registers held through the loop)
+        if (MODE != 4) { const float4 l = W.shL[s_]; plR = l.x; plG = l.y; plB = l.z; }
+        unsafeAtomicAdd(W.outR + s_, plR); unsafeAtomicAdd(W.outG + s_, plG); unsafeAtomicAdd(W.outB + s_, plB);
     };
     // the lane's stack ran empty: publish the result (or, for a literal shadow lane, decide / walk through the light)
     auto finish = [&]() {
@@ -535,7 +536,7 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
                 const int ol = T.meshes[om].light;
                 if (ol >= 0 && !T.lights[ol].primaryVisibility) {                     // walk through (integrator.cpp:273-274)
                     o = o + d * (bt + eps); tmin = eps; segMax = segMax - bt; tmax = segMax;
-                    found = false; bt = KZ_INF; cur = root; top = stkBase; active = true;
+                    found = false; bt = KZ_INF; cur = root; top = stkBase; asm volatile("" : "+v"(top)); active = true;
                     if (STATS) cn.rays++;
                 }
             }
@@ -575,7 +576,10 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
                 if (!active && rank < take) {
                     const uint32_t qi = poolNext + rank;
                     slot = queue ? queue[qi] : qi;
-                    top = stkBase;                                    // (an idle lane's stack is empty, or abandoned by an occluded shadow ray)
+                    // (an idle lane's stack is empty, or abandoned by an occluded shadow ray. The empty asm makes the new top a value of its own: as a
+                    // plain copy of stkBase the compiler deferred the copy down some of the refill's paths and reused the register on the others -
+                    // the instantiations with counters walked garbage stacks, profiles/r03u_valu_ops)
+                    top = stkBase; asm volatile("" : "+v"(top));
                     float4 a, b;
                     if (kind == 0) { a = W.rayA[slot]; b = W.rayB[slot]; }
                     else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w);
@@ -599,7 +603,8 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
                         } else if (kind == 2) literal = !P.shadowFast || invisibleLightOnSegment(P, T, o, d, rx, ry, rz, tmin, tmax);
                     } else {
                         // a ray that cannot hit anything (empty scene, non-finite origin/direction)
-                        if (kind == 0) W.hit[slot] = make_float4(KZ_INF, 0.f, 0.f, 0.f);
+                        // (the constants are made HERE: hoisted out of the loop they took four registers for the whole kernel, then a spill slot)
+                        if (kind == 0) { float inf = KZ_INF, zero = 0.f; asm volatile("" : "+v"(inf), "+v"(zero)); W.hit[slot] = make_float4(inf, zero, zero, zero); }
                         if (kind == 2) addPending();
                         if (STATS && MODE == 4) cn.rays++;
                     }
@@ -1052,7 +1057,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_final(KzParams P, KzDevTables 
         if (h.x < KZ_INF) continue;
         const float4 rb = W.rayB[slot], th = W.thr[slot];
         const V3 bg = backgroundRadiance(P, T, mk(rb.x, rb.y, rb.z));
-        W.outR[slot] += th.x * bg.x; W.outG[slot] += th.y * bg.y; W.outB[slot] += th.z * bg.z;
+        unsafeAtomicAdd(W.outR + slot, th.x * bg.x); unsafeAtomicAdd(W.outG + slot, th.y * bg.y); unsafeAtomicAdd(W.outB + slot, th.z * bg.z);
     }
 }
 
