@@ -993,11 +993,14 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
         const bool finite = rayIsFinite(o, d);
         const float len = sqrtf(dot(d, d)), lenUp = len * 1.000002f;
         float tvalidDist = KZ_INF;                                             // the list's bounds are DISTANCES from the pinhole: parameter x |d|
-        auto walk = [&](const uint2 *__restrict__ lst, const uint2 head) {
+        auto walk = [&](const uint2 *__restrict__ lst, const uint2 head, const bool uniform) {
             tvalidDist = __uint_as_float(head.y);
             if (!finite) return;
             for (uint32_t j = 0; j < head.x; ++j) {
                 const uint2 e = lst[j];
+                // The list is in the order of the beam's best-first walk: its bounds never decrease. When the leaf begins behind the closest hit
+                // of EVERY ray of the wave, so do all the leaves after it (one shared list: the wave stops; per-lane lists: the lane skips).
+                if (uniform && !__any(__uint_as_float(e.y) <= tmax * lenUp)) break;
                 if (__uint_as_float(e.y) > tmax * lenUp) continue;         // the leaf begins behind the closest hit so far
                 const uint32_t start = (e.x & 0x7fffffffu) >> 3, cnt = (e.x & 7u) + 1;
                 for (uint32_t i = 0; i < cnt; ++i) {
@@ -1012,8 +1015,8 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
         // first lane's pixel (an SGPR), so the head and the entries arrive through the scalar cache and an entry's load no longer queues behind the
         // lanes' vector loads of the triangle before it. Waves that span pixels walk per-lane lists.
         const uint32_t plU = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl);
-        if (__all(pl == plU)) walk(entries + (size_t)plU * KZ_BEAM_CAP, heads[plU]);
-        else walk(entries + (size_t)pl * KZ_BEAM_CAP, heads[pl]);
+        if (__all(pl == plU)) walk(entries + (size_t)plU * KZ_BEAM_CAP, heads[plU], true);
+        else walk(entries + (size_t)pl * KZ_BEAM_CAP, heads[pl], false);
         // decided: a hit in front of everything unexplored, or nothing unexplored at all (a non-finite ray hits nothing)
         undecided = finite && !(found ? bt * lenUp < tvalidDist : !(tvalidDist < KZ_INF));
         if (STATS && !undecided) cn.rays++;                                    // (an undecided ray is counted by the kernel that decides it)
