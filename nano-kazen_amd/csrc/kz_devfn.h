@@ -256,9 +256,8 @@ __device__ __forceinline__ NodeTest nodeTest(const KzDevTables &T, uint32_t node
     return r;
 }
 // Mesh::rayIntersect (mesh.cpp:55-92), operation for operation, on one 48-B leaf triangle.
-__device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin, float tmax, float &t, float &u, float &v, uint32_t &gid) {
-    const float4 *tp = reinterpret_cast<const float4 *>(tri);
-    const float4 a = tp[0], b = tp[1], c = tp[2];
+// (triTestV: the same body on a triangle already in registers - the list kernel fetches the next triangle while it tests this one)
+__device__ __forceinline__ bool triTestV(const float4 a, const float4 b, const float4 c, V3 o, V3 d, float tmin, float tmax, float &t, float &u, float &v, uint32_t &gid) {
     const V3 p0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
     gid = __float_as_uint(c.w);
     V3 pvec = cross(d, e2);
@@ -273,6 +272,10 @@ __device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin
     if (v < 0.0f || u + v > 1.0f) return false;
     t = dot(e2, qvec) * inv_det;
     return t >= tmin && t <= tmax;
+}
+__device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin, float tmax, float &t, float &u, float &v, uint32_t &gid) {
+    const float4 *tp = reinterpret_cast<const float4 *>(tri);
+    return triTestV(tp[0], tp[1], tp[2], o, d, tmin, tmax, t, u, v, gid);
 }
 // LDS through explicit 32-bit byte addresses (address space 3): ds_read_b32 / ds_write_b32 at a VGPR the kernel keeps as state
 typedef __attribute__((address_space(3))) uint32_t KzLds32;

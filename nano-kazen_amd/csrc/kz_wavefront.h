@@ -993,30 +993,56 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
         const bool finite = rayIsFinite(o, d);
         const float len = sqrtf(dot(d, d)), lenUp = len * 1.000002f;
         float tvalidDist = KZ_INF;                                             // the list's bounds are DISTANCES from the pinhole: parameter x |d|
-        auto walk = [&](const uint2 *__restrict__ lst, const uint2 head, const bool uniform) {
+        auto consider = [&](float t, float u, float v, uint32_t g) { if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; bgid = g; tmax = t; } };
+        // per-lane lists (a wave that spans pixels)
+        auto walk = [&](const uint2 *__restrict__ lst, const uint2 head) {
             tvalidDist = __uint_as_float(head.y);
             if (!finite) return;
             for (uint32_t j = 0; j < head.x; ++j) {
                 const uint2 e = lst[j];
-                // The list is in the order of the beam's best-first walk: its bounds never decrease. When the leaf begins behind the closest hit
-                // of EVERY ray of the wave, so do all the leaves after it (one shared list: the wave stops; per-lane lists: the lane skips).
-                if (uniform && !__any(__uint_as_float(e.y) <= tmax * lenUp)) break;
                 if (__uint_as_float(e.y) > tmax * lenUp) continue;         // the leaf begins behind the closest hit so far
                 const uint32_t start = (e.x & 0x7fffffffu) >> 3, cnt = (e.x & 7u) + 1;
                 for (uint32_t i = 0; i < cnt; ++i) {
                     float t, u, v; uint32_t g;
                     if (STATS) cn.tris++;
-                    if (!triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, g)) continue;
-                    if (!found || t < bt || (t == bt && g < bgid)) { found = true; bt = t; bu = u; bv = v; bgid = g; tmax = t; }
+                    if (triTest(T.tris + start + i, o, d, tmin, tmax, t, u, v, g)) consider(t, u, v, g);
                 }
+            }
+        };
+        // ONE list for the wave: entries and triangles arrive through the scalar cache, and every one of those loads is a dependent round trip the
+        // whole wave waits for. So the next entry is fetched while this one is tested, and the triangles two at a time. The list is in the order of the
+        // beam's best-first walk - its bounds never decrease: when a leaf begins behind the closest hit of EVERY ray, so do all the leaves after it.
+        auto walkShared = [&](const uint2 *__restrict__ lst, const uint2 head) {
+            tvalidDist = __uint_as_float(head.y);
+            if (!finite || head.x == 0) return;
+            uint2 e = lst[0];
+            for (uint32_t j = 0; j < head.x; ++j) {
+                const uint2 eNext = lst[min(j + 1u, head.x - 1u)];
+                const bool inFront = __uint_as_float(e.y) <= tmax * lenUp;
+                if (!__any(inFront)) break;
+                if (inFront) {
+                    const uint32_t start = (e.x & 0x7fffffffu) >> 3, cnt = (e.x & 7u) + 1;
+                    for (uint32_t i = 0; i < cnt; i += 2) {
+                        const float4 *tp = reinterpret_cast<const float4 *>(T.tris + start + i), *tq = tp + (i + 1 < cnt ? 3 : 0);
+                        const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2], a1 = tq[0], b1 = tq[1], c1 = tq[2];
+                        float t, u, v; uint32_t g;
+                        if (STATS) cn.tris++;
+                        if (triTestV(a0, b0, c0, o, d, tmin, tmax, t, u, v, g)) consider(t, u, v, g);
+                        if (i + 1 < cnt) {
+                            if (STATS) cn.tris++;
+                            if (triTestV(a1, b1, c1, o, d, tmin, tmax, t, u, v, g)) consider(t, u, v, g);
+                        }
+                    }
+                }
+                e = eNext;
             }
         };
         // When the 64 rays of the wave belong to ONE pixel (S a multiple of 64: every default), the list is wave-uniform: its address comes from the
         // first lane's pixel (an SGPR), so the head and the entries arrive through the scalar cache and an entry's load no longer queues behind the
         // lanes' vector loads of the triangle before it. Waves that span pixels walk per-lane lists.
         const uint32_t plU = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl);
-        if (__all(pl == plU)) walk(entries + (size_t)plU * KZ_BEAM_CAP, heads[plU], true);
-        else walk(entries + (size_t)pl * KZ_BEAM_CAP, heads[pl], false);
+        if (__all(pl == plU)) walkShared(entries + (size_t)plU * KZ_BEAM_CAP, heads[plU]);
+        else walk(entries + (size_t)pl * KZ_BEAM_CAP, heads[pl]);
         // decided: a hit in front of everything unexplored, or nothing unexplored at all (a non-finite ray hits nothing)
         undecided = finite && !(found ? bt * lenUp < tvalidDist : !(tvalidDist < KZ_INF));
         if (STATS && !undecided) cn.rays++;                                    // (an undecided ray is counted by the kernel that decides it)
