@@ -1069,7 +1069,13 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     const size_t wantItems = std::max<size_t>(opts->passItems ? (size_t)opts->passItems : (size_t)1 << 27, 64);
     uint32_t S, pixPerPass;
     if (opts->tune.sppPerPass > 0) { S = std::min<uint32_t>((uint32_t)opts->tune.sppPerPass, nSamples); pixPerPass = (uint32_t)std::min<size_t>(ds->nPix, std::max<size_t>(64, wantItems / S / 64 * 64)); }
-    else { pixPerPass = ds->nPix; S = (uint32_t)std::min<size_t>(std::max<size_t>(1, wantItems / std::max<uint32_t>(1, ds->nPix)), nSamples); }
+    else {
+        pixPerPass = ds->nPix; S = (uint32_t)std::min<size_t>(std::max<size_t>(1, wantItems / std::max<uint32_t>(1, ds->nPix)), nSamples);
+        // A frame too large for 64 samples of every pixel per pass (C5 on one GPU: 16) is rendered in pixel chunks of 256 samples instead: a wave of the
+        // camera-ray kernels is then one pixel again (one shared list), the film stage touches a chunk per pass instead of the whole frame, and the paths of a pass
+        // stay in a part of the scene (C5, same call: 1 586 Msamples/s at 16 x all pixels, 1 708 at 64 x 2 M, 1 734 at 256 x 512 K).
+        if (S < 64 && nSamples >= 64) { S = std::min<uint32_t>(256u, nSamples); pixPerPass = (uint32_t)std::min<size_t>(ds->nPix, std::max<size_t>(64, wantItems / S / 64 * 64)); }
+    }
     // the largest pass of the wanted shape that fits `room` bytes: fewer samples first, then (from one sample) fewer pixels
     auto shape = [&](size_t room, uint32_t &s, uint32_t &px) {
         s = S; px = pixPerPass;

@@ -191,6 +191,23 @@ def test_replicas_and_device_addressing(gpu_lib, kz):
     assert np.array_equal(sc.film(), a)
 
 
+def test_frames_too_large_for_64_samples_per_pass_are_rendered_in_pixel_chunks(gpu_lib, kz, O):
+    """The default pass shape: every pixel x as many samples as fit - unless fewer than 64 samples would fit while the call asks for at least 64
+    (C5 on one GPU): then pixel chunks x up to 256 samples. Same film up to the order of the additions of neighbouring chunks."""
+    desc = kz.scenes.cornell_box(96, 80, 64, sampler="pmj02bn")
+    sc = kz.Scene(desc, device=0)
+    npx = 96 * 80
+    sc.render(pass_items=npx * 64, passes_in_flight=1)
+    whole = sc.film()
+    assert (sc.last_pass_info()["sppPerPass"], sc.last_pass_info()["pixelsPerPass"]) == (64, npx)
+    sc.render(pass_items=npx * 16)                                    # 16 samples of every pixel would fit: chunks of 1920 pixels x 64 samples instead
+    info = sc.last_pass_info()
+    assert (info["passes"], info["sppPerPass"], info["pixelsPerPass"]) == (4, 64, 1920)
+    assert np.allclose(sc.film(), whole, rtol=2e-5, atol=1e-5)
+    sc.render(0, 32, pass_items=npx * 16, passes_in_flight=1)         # a call of fewer than 64 samples keeps the plain shape
+    assert (sc.last_pass_info()["sppPerPass"], sc.last_pass_info()["pixelsPerPass"]) == (16, npx)
+
+
 def test_state_budget_and_pass_options(gpu_lib, kz, O):
     """KzRenderOpts: pass size, pass shape, passes in flight and the state cap are per-call options; every schedule gives the film of
     pass-at-a-time up to the order of the film additions, and the cap is respected."""
