@@ -277,6 +277,13 @@ __device__ __forceinline__ bool triTest(const KzTri *tri, V3 o, V3 d, float tmin
     const float4 *tp = reinterpret_cast<const float4 *>(tri);
     return triTestV(tp[0], tp[1], tp[2], o, d, tmin, tmax, t, u, v, gid);
 }
+// Streaming (non-temporal) accesses for the path state: every record is read or written once per kernel, 2^27 of them per pass - the `nt` hint
+// keeps them from displacing the BVH packets and leaf triangles, which are what the traversal kernels want to find in L2 again.
+typedef float kz_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 kzLoadStream(const float4 *p) { const kz_f4v v = __builtin_nontemporal_load(reinterpret_cast<const kz_f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void kzStoreStream(float4 *p, float4 v) { const kz_f4v t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<kz_f4v *>(p)); }
+__device__ __forceinline__ uint32_t kzLoadStream(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+
 // LDS through explicit 32-bit byte addresses (address space 3): ds_read_b32 / ds_write_b32 at a VGPR the kernel keeps as state
 typedef __attribute__((address_space(3))) uint32_t KzLds32;
 __device__ __forceinline__ uint32_t kzLdsAddr(const uint32_t *p) { return (uint32_t)(uintptr_t)(const KzLds32 *)p; }

@@ -132,8 +132,8 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_generate(KzParams P, KzDevTabl
     float ax, ay; smp.next2D(P, T, ax, ay);
     V3 ro, rd; float mint, maxt;
     cameraRay(P, sx, sy, ax, ay, ro, rd, mint, maxt);
-    W.rayA[item] = make_float4(ro.x, ro.y, ro.z, mint);
-    W.rayB[item] = make_float4(rd.x, rd.y, rd.z, maxt);
+    kzStoreStream(&W.rayA[item], make_float4(ro.x, ro.y, ro.z, mint));
+    kzStoreStream(&W.rayB[item], make_float4(rd.x, rd.y, rd.z, maxt));
     // (throughput = 1, eta = 1, bsdfPdf / accumulatedRoughness / discrete = 0 are what shade(0) assumes for a camera path: not stored)
     wfStoreSampler(P, W, item, smp);
     W.outJx[item] = jx; W.outJy[item] = jy; W.outR[item] = 0.f; W.outG[item] = 0.f; W.outB[item] = 0.f;
@@ -151,17 +151,17 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
         const uint32_t slot = base + threadIdx.x;
         bool need = false;
         if (slot < nItems) {
-            const float4 h = W.hit[slot];
+            const float4 h = kzLoadStream(&W.hit[slot]);
             if (h.x < KZ_INF) {
                 RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
                 const int li = lightOfGid(T, rh.gid);
                 if (li >= 0 && !T.lights[li].primaryVisibility) {
                     Its its; postIntersect<false>(T, rh, its);
-                    const float4 b = W.rayB[slot];
+                    const float4 b = kzLoadStream(&W.rayB[slot]);
                     const V3 rd = mk(b.x, b.y, b.z);
                     const V3 no = its.p + P.traceBias * rd;
-                    W.shA[slot] = make_float4(no.x, no.y, no.z, KZ_INF);            // Ray3f(o, d): mint = Epsilon, maxt = inf
-                    W.shB[slot] = make_float4(rd.x, rd.y, rd.z, KZ_EPSILON);
+                    kzStoreStream(&W.shA[slot], make_float4(no.x, no.y, no.z, KZ_INF));            // Ray3f(o, d): mint = Epsilon, maxt = inf
+                    kzStoreStream(&W.shB[slot], make_float4(rd.x, rd.y, rd.z, KZ_EPSILON));
                     need = true;
                 }
             }
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
         if (more && base + threadIdx.x < count) {
             const uint32_t qi = base + threadIdx.x;
             slot = queue ? queue[qi] : qi;
-            const float4 h = W.hit[slot];
-            const float4 rb = W.rayB[slot];
+            const float4 h = kzLoadStream(&W.hit[slot]);
+            const float4 rb = kzLoadStream(&W.rayB[slot]);
             const V3 rd = mk(rb.x, rb.y, rb.z);
 #ifdef KZ_SHADESTAT
             KZ_SSTW(10);                                    // pass A: queue entry, hit record, ray
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             if (!(h.x < KZ_INF)) {
                 // miss: black for the primary ray (H5), background after a bounce (integrator.cpp:315-318)
                 if (iter > 0 && P.bgPresent) {
-                    const float4 th = W.thr[slot];
+                    const float4 th = kzLoadStream(&W.thr[slot]);
                     const V3 c = mk(th.x, th.y, th.z) * backgroundRadiance(P, T, rd);
                     unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);      // (returnless: no wait, one writer per slot)
                 }
@@ -267,9 +267,9 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                 KZ_SSTW(12);                                // pass A: postIntersect
                 if (its.light >= 0) {                                                         // integrator.cpp:226-231, 322-327
                     const KzLightRow &lr = T.lights[its.light];
-                    const float4 ra = W.rayA[slot];
-                    const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot];
-                    const float4 mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : (compact ? make_float4(th.w, 0.f, 0.f, 0.f) : W.misc[slot]);
+                    const float4 ra = kzLoadStream(&W.rayA[slot]);
+                    const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : kzLoadStream(&W.thr[slot]);
+                    const float4 mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : (compact ? make_float4(th.w, 0.f, 0.f, 0.f) : kzLoadStream(&W.misc[slot]));
                     const V3 ro = mk(ra.x, ra.y, ra.z);
                     const V3 wi = normalized(its.p - ro);
                     float bsdfWeight = 1.f;
@@ -292,14 +292,14 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         // the path state, where pass B reads them.
                         const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
                         Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
-                        const float4 th = W.thr[slot];
+                        const float4 th = kzLoadStream(&W.thr[slot]);
                         V3 throughput = mk(th.x, th.y, th.z);
                         const float etaA = compact ? 1.f : th.w;
                         const float probability = fminf(maxCoeff(throughput) * etaA * etaA, 0.95f);
                         if (probability <= smp.next1D(P, T)) survivor = false;
                         else {
                             throughput = throughput / probability;
-                            W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, th.w);
+                            kzStoreStream(&W.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, th.w));
                             wfStoreSampler(P, W, slot, smp);
                         }
                     } else if (STATS && !survivor && P.nLights > 0) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                         if (iter >= 3) {
                             const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
                             Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
-                            const float4 th = W.thr[slot];
+                            const float4 th = kzLoadStream(&W.thr[slot]);
                             const float etaA = compact ? 1.f : th.w;
                             if (fminf(maxCoeff(mk(th.x, th.y, th.z)) * etaA * etaA, 0.95f) <= smp.next1D(P, T)) alive = false;
                         }
@@ -351,9 +351,9 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             its.sh.n = mk(__uint_as_float(r[10 * KZ_SV_CAP]), __uint_as_float(r[11 * KZ_SV_CAP]), __uint_as_float(r[12 * KZ_SV_CAP]));
             its.uvx = __uint_as_float(r[13 * KZ_SV_CAP]); its.uvy = __uint_as_float(r[14 * KZ_SV_CAP]); its.bsdf = r[15 * KZ_SV_CAP];
             if (EXT) its.dpdu = mk(__uint_as_float(r[16 * KZ_SV_CAP]), __uint_as_float(r[17 * KZ_SV_CAP]), __uint_as_float(r[18 * KZ_SV_CAP]));
-            const float4 rb = W.rayB[slot];
+            const float4 rb = kzLoadStream(&W.rayB[slot]);
             const V3 rd = mk(rb.x, rb.y, rb.z);
-            float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : W.thr[slot];              // a camera path: generate stores neither (initial values)
+            float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : kzLoadStream(&W.thr[slot]);              // a camera path: generate stores neither (initial values)
             V3 throughput = mk(th.x, th.y, th.z);
             const float eta = compact ? 1.f : th.w;
             float accRough = (iter == 0 || compact) ? 0.f : W.misc[slot].y;
@@ -381,9 +381,9 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
                     // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
                     if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
-                        W.shA[slot] = make_float4(its.p.x, its.p.y, its.p.z, dist - eps);
-                        W.shB[slot] = make_float4(lwi.x, lwi.y, lwi.z, eps);
-                        W.shL[slot] = make_float4(pend.x, pend.y, pend.z, 0.f);
+                        kzStoreStream(&W.shA[slot], make_float4(its.p.x, its.p.y, its.p.z, dist - eps));
+                        kzStoreStream(&W.shB[slot], make_float4(lwi.x, lwi.y, lwi.z, eps));
+                        kzStoreStream(&W.shL[slot], make_float4(pend.x, pend.y, pend.z, 0.f));
                         pushShadow = true;
                     }
                 }
@@ -402,10 +402,10 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                     const V3 nd = toWorld(its.sh, woLocal);                           // H9
                     // the ray after the LAST bounce only matters for the background term
                     if (iter + 1 < P.maxDepth || P.bgPresent) {
-                        W.rayA[slot] = make_float4(its.p.x, its.p.y, its.p.z, eps);
-                        W.rayB[slot] = make_float4(nd.x, nd.y, nd.z, KZ_INF);
-                        W.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, compact ? bpdf : etaNext);
-                        if (!compact) W.misc[slot] = make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f);
+                        kzStoreStream(&W.rayA[slot], make_float4(its.p.x, its.p.y, its.p.z, eps));
+                        kzStoreStream(&W.rayB[slot], make_float4(nd.x, nd.y, nd.z, KZ_INF));
+                        kzStoreStream(&W.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, compact ? bpdf : etaNext));
+                        if (!compact) kzStoreStream(&W.misc[slot], make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f));
                         wfStoreSampler(P, W, slot, smp);
                         pushNext = true;
                     }
@@ -527,8 +527,8 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
     // the lane's stack ran empty: publish the result (or, for a literal shadow lane, decide / walk through the light)
     auto finish = [&]() {
         active = false;
-        if (kind == 0) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid));      // (without a hit the record still holds what the refill put there: +inf, 0, 0, 0 = the miss record)
-        if (kind == 1) { if (found) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid)); }
+        if (kind == 0) kzStoreStream(&W.hit[slot], make_float4(bt, bu, bv, __uint_as_float(bgid)));      // (without a hit the record still holds what the refill put there: +inf, 0, 0, 0 = the miss record)
+        if (kind == 1) { if (found) kzStoreStream(&W.hit[slot], make_float4(bt, bu, bv, __uint_as_float(bgid))); }
         if (kind == 2) {
             if (MODE == 4 || !literal || !found) addPending();                       // nothing on the segment
             else {
@@ -575,15 +575,15 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));   // idle lanes below this one
                 if (!active && rank < take) {
                     const uint32_t qi = poolNext + rank;
-                    slot = queue ? queue[qi] : qi;
+                    slot = queue ? kzLoadStream(queue + qi) : qi;
                     // (an idle lane's stack is empty, or abandoned by an occluded shadow ray. The empty asm makes the new top a value of its own: as a
                     // plain copy of stkBase the compiler deferred the copy down some of the refill's paths and reused the register on the others -
                     // the instantiations with counters walked garbage stacks, profiles/r03u_valu_ops)
                     top = stkBase; asm volatile("" : "+v"(top));
                     float4 a, b;
-                    if (kind == 0) { a = W.rayA[slot]; b = W.rayB[slot]; }
-                    else { const float4 sa = W.shA[slot], sb = W.shB[slot]; a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w);
-                           if (MODE == 4) { const float4 l = W.shL[slot]; plR = l.x; plG = l.y; plB = l.z; } }
+                    if (kind == 0) { a = kzLoadStream(&W.rayA[slot]); b = kzLoadStream(&W.rayB[slot]); }
+                    else { const float4 sa = kzLoadStream(&W.shA[slot]), sb = kzLoadStream(&W.shB[slot]); a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w);
+                           if (MODE == 4) { const float4 l = kzLoadStream(&W.shL[slot]); plR = l.x; plG = l.y; plB = l.z; } }
                     o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); tmin = a.w; tmax = b.w; segMax = b.w;
                     found = false; bt = KZ_INF; bu = bv = 0.f; btri = 0; bgid = 0; literal = false;
                     if (STATS && MODE != 4) cn.rays++;
@@ -604,7 +604,7 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
                     } else {
                         // a ray that cannot hit anything (empty scene, non-finite origin/direction)
                         // (the constants are made HERE: hoisted out of the loop they took four registers for the whole kernel, then a spill slot)
-                        if (kind == 0) { float inf = KZ_INF, zero = 0.f; asm volatile("" : "+v"(inf), "+v"(zero)); W.hit[slot] = make_float4(inf, zero, zero, zero); }
+                        if (kind == 0) { float inf = KZ_INF, zero = 0.f; asm volatile("" : "+v"(inf), "+v"(zero)); kzStoreStream(&W.hit[slot], make_float4(inf, zero, zero, zero)); }
                         if (kind == 2) addPending();
                         if (STATS && MODE == 4) cn.rays++;
                     }
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         const bool have = qi < count;
         const uint32_t slot = have ? (queue ? queue[qi] : qi) : 0u;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 1.f, 0.f);
-        if (have) { a = W.rayA[slot]; b = W.rayB[slot]; }
+        if (have) { a = kzLoadStream(&W.rayA[slot]); b = kzLoadStream(&W.rayB[slot]); }
         const V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
         const float tmin = a.w;
         // a lane without a ray, or with a ray that can hit nothing (non-finite, see kz_wf_trace), carries tmax = -inf: it fails every box and triangle test
@@ -835,15 +835,15 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (!more) break;
             }
         }
-        if (have) W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid))        /* no hit: still +inf, 0, 0, 0 */;
+        if (have) kzStoreStream(&W.hit[slot], make_float4(bt, bu, bv, __uint_as_float(bgid)))        /* no hit: still +inf, 0, 0, 0 */;
         if (FIX && found && bgid - P.ilGidLo <= P.ilGidSpan) {              // (rare) may be a triangle of an invisible light: look
             const int li = lightOfGid(T, bgid);
             if (li >= 0 && !T.lights[li].primaryVisibility) {
                 RawHit rh; rh.t = bt; rh.u = bu; rh.v = bv; rh.tri = 0; rh.gid = bgid;
                 Its its; postIntersect<false>(T, rh, its);
                 const V3 no = its.p + P.traceBias * d;
-                W.shA[slot] = make_float4(no.x, no.y, no.z, KZ_INF);            // Ray3f(o, d): mint = Epsilon, maxt = inf
-                W.shB[slot] = make_float4(d.x, d.y, d.z, KZ_EPSILON);
+                kzStoreStream(&W.shA[slot], make_float4(no.x, no.y, no.z, KZ_INF));            // Ray3f(o, d): mint = Epsilon, maxt = inf
+                kzStoreStream(&W.shB[slot], make_float4(d.x, d.y, d.z, KZ_EPSILON));
                 fixQueue[atomicAdd(fixCount, 1u)] = slot;
             }
         }
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
     bool undecided = false;
     if (have) {
         const uint32_t pl = slot / S;
-        const float4 a = W.rayA[slot], b = W.rayB[slot];
+        const float4 a = kzLoadStream(&W.rayA[slot]), b = kzLoadStream(&W.rayB[slot]);
         const V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
         const float tmin = a.w;
         float tmax = b.w;
@@ -1048,18 +1048,18 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
         if (STATS && !undecided) cn.rays++;                                    // (an undecided ray is counted by the kernel that decides it)
         if (undecided) {
             // what the list has established travels with the ray: nothing is hit in front of t_valid, and nothing behind the hit found matters
-            W.rayA[slot] = make_float4(a.x, a.y, a.z, fmaxf(tmin, tvalidDist / lenUp * 0.999998f));
-            if (found) W.rayB[slot] = make_float4(b.x, b.y, b.z, bt);
+            kzStoreStream(&W.rayA[slot], make_float4(a.x, a.y, a.z, fmaxf(tmin, tvalidDist / lenUp * 0.999998f)));
+            if (found) kzStoreStream(&W.rayB[slot], make_float4(b.x, b.y, b.z, bt));
         } else {
-            W.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bgid))        /* no hit: still +inf, 0, 0, 0 */;
+            kzStoreStream(&W.hit[slot], make_float4(bt, bu, bv, __uint_as_float(bgid)))        /* no hit: still +inf, 0, 0, 0 */;
             if (FIX && found && bgid - P.ilGidLo <= P.ilGidSpan) {              // (rare) may be a triangle of an invisible light: see kz_wf_trace_packet
                 const int li = lightOfGid(T, bgid);
                 if (li >= 0 && !T.lights[li].primaryVisibility) {
                     RawHit rh; rh.t = bt; rh.u = bu; rh.v = bv; rh.tri = 0; rh.gid = bgid;
                     Its its; postIntersect<false>(T, rh, its);
                     const V3 no = its.p + P.traceBias * d;
-                    W.shA[slot] = make_float4(no.x, no.y, no.z, KZ_INF);
-                    W.shB[slot] = make_float4(d.x, d.y, d.z, KZ_EPSILON);
+                    kzStoreStream(&W.shA[slot], make_float4(no.x, no.y, no.z, KZ_INF));
+                    kzStoreStream(&W.shB[slot], make_float4(d.x, d.y, d.z, KZ_EPSILON));
                     fixQueue[atomicAdd(fixCount, 1u)] = slot;
                 }
             }
@@ -1082,9 +1082,9 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_final(KzParams P, KzDevTables 
     const uint32_t count = *countPtr;
     for (uint32_t qi = blockIdx.x * KZ_BLOCK + threadIdx.x; qi < count; qi += gridDim.x * KZ_BLOCK) {
         const uint32_t slot = queue[qi];
-        const float4 h = W.hit[slot];
+        const float4 h = kzLoadStream(&W.hit[slot]);
         if (h.x < KZ_INF) continue;
-        const float4 rb = W.rayB[slot], th = W.thr[slot];
+        const float4 rb = kzLoadStream(&W.rayB[slot]), th = kzLoadStream(&W.thr[slot]);
         const V3 bg = backgroundRadiance(P, T, mk(rb.x, rb.y, rb.z));
         unsafeAtomicAdd(W.outR + slot, th.x * bg.x); unsafeAtomicAdd(W.outG + slot, th.y * bg.y); unsafeAtomicAdd(W.outB + slot, th.z * bg.z);
     }
