@@ -245,7 +245,7 @@ typedef struct KzTile { int32_t x0, y0, w, h; } KzTile;
 typedef struct KzTuning {
     int32_t refill;             /* a wave refills idle lanes once fewer than this many are busy (default 40)       */
     int32_t postpone;           /* node phase goes on while at least this many lanes hold inner nodes (default 24)  */
-    int32_t batch;              /* queue entries a wave reserves per global atomic (default 128)                     */
+    int32_t batch;              /* queue entries a wave reserves per global atomic (default 128; up to 8 x as many while much of the queue is left) */
     int32_t traceBlocksPerCU;   /* 256-thread workgroups per CU of the traversal kernels (default 8)                 */
     int32_t shadeBlocksPerCU;   /* same for the shade kernel (default 4; 6 with extended BSDFs)                       */
     int32_t ldsStack;           /* per-lane traversal stack entries kept in LDS before the global overflow (default 16) */

@@ -527,7 +527,7 @@ void kz_device_release(KzScene *scene) {
 static int resolveTune(const KzTuning &t, KzTune &r) {
     auto pick = [](int a, int d) { return a > 0 ? a : d; };
     r = KzTune{};
-    r.refill = pick(t.refill, 40); r.postpone = pick(t.postpone, 24); r.batch = pick(t.batch, 128);
+    r.refill = pick(t.refill, 40); r.postpone = pick(t.postpone, 24); r.batch = pick(t.batch, 0);                      // 0: the default per ray kind (wfPass)
     r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, KZ_TRACE_WAVES)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, 0));
     r.ldsStack = pick(t.ldsStack, 16);
     r.packet = pick(t.packetPrimary, 0); r.filmGather = pick(t.filmGather, 0);
@@ -936,7 +936,8 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     { int rc_ = stageMark(c, stream, 0); if (rc_) return rc_; }
     if (maxDepth <= 0) return KZ_OK;           // Li returns 0 before the loop contributes anything
 #ifdef KZ_EXPERIMENTS
-    KzExpLaunch X{scene, ds, &c, stream, W, tune, gTrav, traceLds, stackBound, st, items};
+    KzTune tuneX = tune; if (tuneX.batch <= 0) tuneX.batch = 128;
+    KzExpLaunch X{scene, ds, &c, stream, W, tuneX, gTrav, traceLds, stackBound, st, items};
     if (int rc_ = X.prepare()) return rc_;
 #endif
     // mode 0 / 1 / 2 / 4 of kz_wf_trace on queue q (nullptr: identity) of *cptr (nullptr: cimm) entries
@@ -944,7 +945,9 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #ifdef KZ_EXPERIMENTS
         if (X.trace(mode, q, cptr, cimm, head, qb, cb)) return;
 #endif
-        hipLaunchKernelGGL(traceFn(mode, st), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, tune, qb, cb);
+        KzTune t = tune;
+        if (t.batch <= 0) t.batch = 128;                 // (the least a wave reserves per global atomic: kz_wf_trace asks for more while much is left)
+        hipLaunchKernelGGL(traceFn(mode, st), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, t, qb, cb);
     };
     // camera rays: pixel beams + per-sample triangle tests (kz_wf_beam / kz_wf_trace_list), the wave-level packet traversal
     // (kz_wf_trace_packet) for what the beams cannot take, or the per-lane kernel on request

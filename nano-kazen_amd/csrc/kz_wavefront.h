@@ -489,6 +489,10 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
     const uint32_t batch = max(64u, min((uint32_t)tune.batch, ((count + nWaves - 1) / nWaves + 63u) & ~63u));   // short queues: spread over all waves
     const bool staticOnly = (unsigned long long)nWaves * batch >= count;
     uint32_t poolNext = min(waveId * batch, count), poolEnd = min(poolNext + batch, count);
+    // Guided reservations: a wave asks for a quarter of its even share of what is LEFT (never less than `batch`, never more than 8 of them). The shared
+    // counter serves ~88 reservations per microsecond; rays that end quickly (the shadow rays of an open scene) otherwise queue up behind it, and a
+    // fixed larger batch pays for it at the tail of a launch, where the last waves sit on the last big batches.
+    uint32_t resv = batch;
     bool exhausted = false;
     bool active = false, literal = false;
     V3 o = mk(0.f), d = mk(0.f);
@@ -559,12 +563,15 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
             if (poolNext >= poolEnd) {
                 uint32_t b = count;
                 if (!staticOnly) {
-                    if (lane == 0) b = atomicAdd(head, batch);
+                    if (lane == 0) b = atomicAdd(head, resv);
                     b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
                     b = (b < 0xFFFFFFFFu - nWaves * batch) ? b + nWaves * batch : count;            // dynamic batches start behind the static ones
                 }
                 if (b >= count) { exhausted = true; poolNext = poolEnd = 0; }
-                else { poolNext = b; poolEnd = min(b + batch, count); }
+                else {
+                    poolNext = b; poolEnd = min(b + resv, count);
+                    resv = min(8u * batch, max(batch, (((count - poolEnd) / nWaves) >> 2) & ~63u));
+                }
             }
             if (!exhausted) {
                 const uint32_t take = min((uint32_t)(64 - nAct), poolEnd - poolNext);
