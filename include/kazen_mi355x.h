@@ -258,7 +258,8 @@ typedef struct KzTuning {
     int32_t leafQueue;          /* [experiment] 2 = bounce / shadow traversal with a decoupled leaf phase (kz_wf_trace_dq) */
     int32_t sppPerPass;         /* samples of a pixel per pass: 0 = default. A pass covers pixPerPass x sppPerPass = passItems (pixel, sample)
                                    items: sppPerPass = 0 means "every pixel of the tile set, as many samples as fit" - unless fewer than 64 would
-                                   fit and the call asks for at least 64: then 256 samples (or all, if fewer) of pixel chunks; n > 0 means n samples
+                                   fit and the call asks for at least 64: then 256 samples (or all, if fewer) of pixel chunks; above 64 the count is
+                                   rounded down to a multiple of 64 when that costs no extra pass; n > 0 means n samples
                                    (or all the call asks for, if fewer) of as many pixels as fit, pixel chunks in tile order           */
     int32_t legacyTrace;        /* [experiment] 1 = the non-persistent round-1 traversal launches (kz_wf_extend / kz_wf_shadow) */
     int32_t mixedLaunch;        /* [experiment] 1 = one launch for the shadow rays of a bounce and the closest-hit rays of the next */

@@ -1078,6 +1078,9 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         // camera-ray kernels is then one pixel again (one shared list), the film stage touches a chunk per pass instead of the whole frame, and the paths of a pass
         // stay in a part of the scene (C5, same call: 1 586 Msamples/s at 16 x all pixels, 1 708 at 64 x 2 M, 1 734 at 256 x 512 K).
         if (S < 64 && nSamples >= 64) { S = std::min<uint32_t>(256u, nSamples); pixPerPass = (uint32_t)std::min<size_t>(ds->nPix, std::max<size_t>(64, wantItems / S / 64 * 64)); }
+        // a multiple of 64 samples per pixel keeps every wave of the camera-ray kernels inside one pixel (one shared leaf list) - taken when it costs no extra pass
+        // (a rank's share of a frame: 2^27 / 1 036 800 pixels = 129 -> 128)
+        else if (S > 64 && S % 64 && (nSamples + S / 64 * 64 - 1) / (S / 64 * 64) == (nSamples + S - 1) / S) S = S / 64 * 64;
     }
     // the largest pass of the wanted shape that fits `room` bytes: fewer samples first, then (from one sample) fewer pixels
     auto shape = [&](size_t room, uint32_t &s, uint32_t &px) {

@@ -206,6 +206,12 @@ def test_frames_too_large_for_64_samples_per_pass_are_rendered_in_pixel_chunks(g
     assert np.allclose(sc.film(), whole, rtol=2e-5, atol=1e-5)
     sc.render(0, 32, pass_items=npx * 16, passes_in_flight=1)         # a call of fewer than 64 samples keeps the plain shape
     assert (sc.last_pass_info()["sppPerPass"], sc.last_pass_info()["pixelsPerPass"]) == (16, npx)
+    # more than 64 samples of every pixel fit: a multiple of 64 (every camera-ray wave inside one pixel) when that costs no extra pass
+    sc2 = kz.Scene(kz.scenes.cornell_box(96, 80, 256, sampler="pmj02bn"), device=0)
+    sc2.render(pass_items=npx * 129 + 77, passes_in_flight=1)
+    assert (sc2.last_pass_info()["sppPerPass"], sc2.last_pass_info()["passes"]) == (128, 2)
+    sc2.render(0, 129, pass_items=npx * 129 + 77, passes_in_flight=1)  # (129 samples asked for: one pass of 129, not two of 128 + 1)
+    assert (sc2.last_pass_info()["sppPerPass"], sc2.last_pass_info()["passes"]) == (129, 1)
 
 
 def test_state_budget_and_pass_options(gpu_lib, kz, O):
