@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *_
 // sample rows: rocprofv3 shows 23.5 GB fetched per pass for 2.65 GB of records, an HBM-bound 6.2 ms (profiles/r02b_packet_primary).
 // Here every record is read exactly once:
 //   kz_film_taps   one THREAD per SOURCE pixel, one wave per 64 consecutive pixels of the pass's pixel list (an 8x8 block). The wave copies
-//                  16 samples of its 64 pixels at a time into LDS with coalesced 64-byte pieces, transposed to [sample][pixel]; each thread
+//                  8 samples of its 64 pixels at a time into LDS with coalesced 32-byte pieces, transposed to [sample][pixel]; each thread
 //                  then walks ITS pixel's samples in sample order - validity, the separable filter weights of block.cpp:64-80 per tap, the
 //                  taps x taps weighted products of block.cpp:84 - into taps^2 (rgb*w, w) accumulators that never leave its registers,
 //                  and stores them tap-major ([tap][pixel]: coalesced).
@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void kz_film_gather(KzParams P, const float *_
 // Deterministic (per pixel the samples are added in index order, as the reference's put() loop does; fixed tap order in the second
 // kernel); the weights are the ones kz_film_gather forms (block-relative positions, same table look-ups).
 #define KZ_TAPS_MAX 5                        // gaussian / mitchell radius 2: taps -2..2
-#define KZ_TAPS_CHUNK 16                     // samples per staging round (64 B of every sample row)
+#ifndef KZ_TAPS_CHUNK
+#define KZ_TAPS_CHUNK 8                      // samples per staging round (32 B of every sample row). The staging area is what limits the waves per CU: 16 (20.8 KB
+#endif                                       // per wave, 7 per CU) 2.15 ms per pass, 8 (10.4 KB, 15 per CU) 1.95, 4 (16-B pieces) 3.46 - same call, C4 and C3 alike
 template <int TAPS>
 __global__ __launch_bounds__(64) void kz_film_taps(KzParams P, const float *__restrict__ filter, const uint32_t *__restrict__ pixList, uint32_t nPix, uint32_t S,
                                                    const float *__restrict__ inJx, const float *__restrict__ inJy, const float *__restrict__ inR,
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64) void kz_film_taps(KzParams P, const float *__re
     for (uint32_t c0 = 0; c0 < S; c0 += KZ_TAPS_CHUNK) {
         const uint32_t n = min((uint32_t)KZ_TAPS_CHUNK, S - c0);
         __syncthreads();
-        for (uint32_t i = lane; i < nRows * KZ_TAPS_CHUNK; i += 64u) {  // consecutive lanes: consecutive samples of one pixel (64-B pieces), then the next pixel
+        for (uint32_t i = lane; i < nRows * KZ_TAPS_CHUNK; i += 64u) {  // consecutive lanes: consecutive samples of one pixel (32-B pieces), then the next pixel
             const uint32_t p = i / KZ_TAPS_CHUNK, k = i % KZ_TAPS_CHUNK;
             if (k < n) {
                 const size_t gi = (size_t)(pl0 + p) * S + c0 + k;
