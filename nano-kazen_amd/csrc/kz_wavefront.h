@@ -632,15 +632,19 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
 #endif
             if (inner) {
                 if (STATS) cn.nodes++;
-                // Child order. Closest-hit rays descend into the NEAREST hit child and leave the other hit children on the
-                // stack in slot order (a full sort of the siblings buys 6 % fewer node visits and costs 12 % more
-                // instructions per visit); any-hit shadow rays take the hit children in slot order altogether. Pushes
-                // are branch-free (below).
+                // Child order. Rays descend into the NEAREST hit child and leave the other hit children on the stack in slot order (a full
+                // sort of the siblings buys 6 % fewer node visits and costs 12 % more instructions per visit). Any-hit shadow rays took the
+                // hit children in slot order altogether until the pushes got cheap (round 3): in dense geometry the nearest child is where
+                // the occluder is, and the selection now costs less than the visits it saves. Pushes are branch-free (below).
                 uint32_t key[4]; uint4 refs;
                 bool p0, p1, p2, p3;                                          // child i goes on the stack
                 uint32_t nxt; bool any;
-                node4Keys<!SHADOW>(T, cur, o, rx, ry, rz, tmin, tmax, key, refs);
-                if (SHADOW) {
+#ifndef KZ_SHADOW_ORDERED
+#define KZ_SHADOW_ORDERED 1             // any-hit rays descend into the nearest hit child first too: 0 = the slot order of round 2 (C4 shadow stage 21.2 ms, C3 21.4; 1: 20.3, 21.6)
+#endif
+                constexpr bool SLOTORDER = SHADOW && !KZ_SHADOW_ORDERED;
+                node4Keys<!SLOTORDER>(T, cur, o, rx, ry, rz, tmin, tmax, key, refs);
+                if (SLOTORDER) {
                     const bool h0 = key[0] != 0xFFFFFFFFu, h1 = key[1] != 0xFFFFFFFFu, h2 = key[2] != 0xFFFFFFFFu, h3 = key[3] != 0xFFFFFFFFu;
                     any = h0 || h1 || h2 || h3;
                     nxt = h0 ? refs.x : (h1 ? refs.y : (h2 ? refs.z : refs.w));
@@ -656,7 +660,7 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
                     // every child is written at the running top, which advances only past the children that stay: one that does not is
                     // overwritten by the next store or left above the top (the last row it can reach is the scratch row). No address selects.
                     uint32_t a = top;
-                    if (!SHADOW) { kzLdsPut(a, refs.x); a += p0 ? rowB : 0u; }
+                    if (!SLOTORDER) { kzLdsPut(a, refs.x); a += p0 ? rowB : 0u; }
                     kzLdsPut(a, refs.y); a += p1 ? rowB : 0u;
                     kzLdsPut(a, refs.z); a += p2 ? rowB : 0u;
                     kzLdsPut(a, refs.w); a += p3 ? rowB : 0u;
