@@ -243,7 +243,7 @@ typedef struct KzTile { int32_t x0, y0, w, h; } KzTile;
  * with -DKZ_EXPERIMENTS (kz_build_flags() & KZ_BUILD_EXPERIMENTS) contains those kernels, the default library answers a non-zero
  * value with KZ_ERR_UNSUPPORTED. */
 typedef struct KzTuning {
-    int32_t refill;             /* a wave refills idle lanes once fewer than this many are busy (default 40)       */
+    int32_t refill;             /* a wave refills idle lanes once fewer than this many are busy (default 40; shadow rays 32) */
     int32_t postpone;           /* node phase goes on while at least this many lanes hold inner nodes (default 24)  */
     int32_t batch;              /* queue entries a wave reserves per global atomic (default 128; up to 8 x as many while much of the queue is left) */
     int32_t traceBlocksPerCU;   /* 256-thread workgroups per CU of the traversal kernels (default 8)                 */
