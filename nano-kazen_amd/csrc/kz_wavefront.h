@@ -592,6 +592,7 @@ void kz_wf_trace(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__
                     else { const float4 sa = kzLoadStream(&W.shA[slot]), sb = kzLoadStream(&W.shB[slot]); a = make_float4(sa.x, sa.y, sa.z, sb.w); b = make_float4(sb.x, sb.y, sb.z, sa.w);
                            if (MODE == 4) { const float4 l = kzLoadStream(&W.shL[slot]); plR = l.x; plG = l.y; plB = l.z; } }
                     o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); tmin = a.w; tmax = b.w; segMax = b.w;
+                    if (MODE == 2) asm volatile("" : "+v"(segMax));          // (a value of its own, not a deferred copy of tmax's register: see `top` above)
                     found = false; bt = KZ_INF; bu = bv = 0.f; btri = 0; bgid = 0; literal = false;
                     if (STATS && MODE != 4) cn.rays++;
                     if ((root != 0xFFFFFFFFu) && rayIsFinite(o, d)) {
