@@ -122,8 +122,12 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_generate(KzParams P, KzDevTabl
                                                            uint32_t nItems, uint32_t S, uint32_t sampleBegin) {
     const uint32_t item = blockIdx.x * KZ_BLOCK + threadIdx.x;
     if (item >= nItems) return;
-    const uint32_t pl = item / S, so = item - pl * S;
-    const uint32_t pxy = pixList[pl];
+    // With a multiple of 64 samples per pixel (every default) the wave is ONE pixel: its index comes from the first lane's item, so the division, the
+    // pixel-list entry, the pixel's share of the sampler hash and the blue-noise shifts of the aperture draw are scalar work instead of 64 copies of it.
+    uint32_t pl, pxy;
+    if ((S & 63u) == 0) { pl = (uint32_t)__builtin_amdgcn_readfirstlane((int)item) / S; pxy = (uint32_t)__builtin_amdgcn_readfirstlane((int)pixList[pl]); }
+    else { pl = item / S; pxy = pixList[pl]; }
+    const uint32_t so = item - pl * S;
     const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
     Sampler smp; smp.type = P.samplerType;
     smp.generateSample(P, T, px, py, sampleBegin + so);
@@ -996,7 +1000,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
     const bool have = slot < nItems;
     bool undecided = false;
     if (have) {
-        const uint32_t pl = slot / S;
+        const uint32_t pl = (S & 63u) == 0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)slot) / S : slot / S;      // (a wave of 64 | S samples is one pixel: scalar division)
         const float4 a = kzLoadStream(&W.rayA[slot]), b = kzLoadStream(&W.rayB[slot]);
         const V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z);
         const float tmin = a.w;
