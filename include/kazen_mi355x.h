@@ -465,6 +465,9 @@ int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes);
  * the ray set-up and the BSDFs in place of the compiler's IEEE division / sqrt sequences): runs BOTH on every one of the 2^32 float
  * bit patterns on the device and counts the inputs whose results differ in any bit (two NaNs count as equal). Both counts must be 0. */
 int kz_debug_exact_math_check(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked);
+/* out[k] = random::permute(i[k], l[k], p[k]) (src/kazen/common.cpp:316-344) as the sampler kernels compute it: checked against vectors minted from
+ * the reference's own text (oracle/kat_ref_permute.cpp -> tests/golden/int_kats.json). */
+int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out);
 
 #ifdef __cplusplus
 }

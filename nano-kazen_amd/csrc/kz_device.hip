@@ -398,6 +398,10 @@ __global__ void kz_light_kernel(KzDevTables T, uint32_t n, const int32_t *__rest
 
 // Exhaustive self-check of rcpExact / sqrtExact (kz_devfn.h) as compiled into THIS library: every one of the 2^32 float bit patterns,
 // against the compiler's IEEE division / square root. counts[0] rcp mismatches, [1] sqrt mismatches, [2] patterns checked.
+__global__ void kz_permute_kernel(uint32_t n, const uint32_t *__restrict__ i, const uint32_t *__restrict__ l, const uint32_t *__restrict__ p, uint32_t *__restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = permuteIdx(i[k], l[k], p[k]);
+}
 __global__ void kz_exact_math_kernel(unsigned long long base, unsigned long long *__restrict__ counts) {
     const uint32_t bits = (uint32_t)(base + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x);
     const float x = __uint_as_float(bits);
@@ -533,6 +537,9 @@ static int resolveTune(const KzTuning &t, KzTune &r) {
     r.travBlocksPerCU = std::min(8, pick(t.traceBlocksPerCU, KZ_TRACE_WAVES)); r.shadeBlocksPerCU = std::min(16, pick(t.shadeBlocksPerCU, 0));
     r.ldsStack = pick(t.ldsStack, 16);
     r.packet = pick(t.packetPrimary, 0); r.filmGather = pick(t.filmGather, 0);
+#if defined(KZ_EXPERIMENTS) && defined(KZ_SHADE_SPLIT)
+    r.shadeSplit = KZ_SHADE_SPLIT;          // (development builds only: -DKZ_EXPERIMENTS -DKZ_SHADE_SPLIT=1, profiles/r04b_shade_split)
+#endif
     r.wide = t.bvh2 ? 0 : 1; r.keyStack = pick(t.keyStack, 0); r.ldsTop = pick(t.ldsTop, 0); r.leafQueue = pick(t.leafQueue, 0);
     r.legacyTrace = pick(t.legacyTrace, 0); r.mixed = pick(t.mixedLaunch, 0);
 #ifndef KZ_EXPERIMENTS
@@ -616,6 +623,23 @@ int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes) {
     HIP_TRY(hipMemGetInfo(&f, &t));
     if (freeBytes) *freeBytes = f;
     if (totalBytes) *totalBytes = t;
+    return KZ_OK;
+}
+
+// random::permute on the device (the function the sampler kernels call), for the known-answer vectors minted from the reference's own text
+int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out) {
+    int nd = kz_device_count();
+    if (device < 0 || device >= nd) return kz_fail(nd ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, nd);
+    if (!n) return KZ_OK;
+    if (!i || !l || !p || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    DevMem dI, dL, dP, dO;
+    const size_t bytes = (size_t)n * sizeof(uint32_t);
+    KZ_ALLOC(&dI.p, bytes); KZ_ALLOC(&dL.p, bytes); KZ_ALLOC(&dP.p, bytes); KZ_ALLOC(&dO.p, bytes);
+    HIP_TRY(hipMemcpy(dI.p, i, bytes, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dL.p, l, bytes, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dP.p, p, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_permute_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, dI.as<uint32_t>(), dL.as<uint32_t>(), dP.as<uint32_t>(), dO.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dO.p, bytes, hipMemcpyDeviceToHost));
     return KZ_OK;
 }
 
@@ -1004,12 +1028,29 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     if (P.anyInvisibleLight) trace(1, W.queue[2], W.counts + 0, 0u, W.counts + 3, nullptr, nullptr);      // H6 walk-through of the first hit
     { int rc_ = stageMark(c, stream, 5); if (rc_) return rc_; }
     const uint32_t *cur = nullptr, *curCount = nullptr;
+    const bool split = tune.shadeSplit != 0;
+    const dim3 gClassify((unsigned)(ds->numCU * 8));
     for (int iter = 0; iter < maxDepth; ++iter) {
-        uint32_t *nextQ = W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
+        // One kernel per bounce: the path queues ping-pong (W.queue[iter & 1] is written, the other one read). Two kernels (tune.shadeSplit): kz_wf_classify
+        // reads the path queue and writes the survivors to W.queue[0]; kz_wf_shade_b reads those and writes the next path queue to W.queue[1], which
+        // the classification has finished reading by then (one stream).
+        uint32_t *nextQ = split ? W.queue[1] : W.queue[iter & 1], *nextCount = W.counts + 4 * (iter + 1), *shQ = W.queue[2], *shCount = W.counts + 4 * (iter + 1) + 1;
+#ifdef KZ_EXPERIMENTS
+        if (split) {
+            uint32_t *svQ = W.queue[0], *svCount = W.counts + 6 * 520 + (iter + 1);
+#define KZ_SHADE2(ST, EX) do { hipLaunchKernelGGL((kz_wf_classify<ST, EX>), gClassify, blk, 0, stream, P, ds->T, W, pixList, Sp, sBegin, iter, cur, curCount, items, svQ, svCount); \
+                               hipLaunchKernelGGL((kz_wf_shade_b<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, pixList, Sp, sBegin, iter, (const uint32_t *)svQ, (const uint32_t *)svCount, nextQ, nextCount, shQ, shCount); } while (0)
+            if (st) { if (P.bsdfExt) KZ_SHADE2(true, true); else KZ_SHADE2(true, false); }
+            else { if (P.bsdfExt) KZ_SHADE2(false, true); else KZ_SHADE2(false, false); }
+#undef KZ_SHADE2
+        } else
+#endif
+        {
 #define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
-        if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
-        else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
+            if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
+            else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
 #undef KZ_SHADE
+        }
         { int rc_ = stageMark(c, stream, 2); if (rc_) return rc_; }
         const bool lastIter = iter == maxDepth - 1;
         const bool needExtend = !lastIter || P.bgPresent;
@@ -1020,7 +1061,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
             if (P.shadowFast) {
                 // any-hit kernel without the walk-through machinery; the (rare) rays whose segment crosses an invisible-light triangle go to a
                 // queue - the ping-pong path queue this bounce's shade has just consumed - and are walked through by the general kernel
-                uint32_t *litQ = W.queue[(iter & 1) ^ 1], *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
+                uint32_t *litQ = split ? W.queue[0] : W.queue[(iter & 1) ^ 1], *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
                 trace(4, shQ, shCount, 0u, nextCount + 3, litQ, litCount);
                 if (P.anyInvisibleLight) trace(2, litQ, litCount, 0u, litHead, nullptr, nullptr);
             } else trace(2, shQ, shCount, 0u, nextCount + 3, nullptr, nullptr);

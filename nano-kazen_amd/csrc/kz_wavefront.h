@@ -25,6 +25,7 @@
 #ifndef KZ_WF_QCAP
 #define KZ_WF_QCAP 960             // LDS staging entries per output queue per workgroup (960: four shade workgroups fit the CU's 160 KB)
 #endif
+#define KZ_WF_ROUNDS (KZ_WF_QCAP / KZ_BLOCK)   // rounds of one entry per thread the staging buffer takes
 
 // Path state in HBM: one array per field (SoA; 16-B records, coalesced for the stages that sweep all slots). -DKZ_STATE_AOS=1 builds the
 // alternative that round 3 measured and rejected (profiles/r03h_state_layout): one 64-B line per path for (ray origin | direction | hit |
@@ -184,20 +185,201 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_primary_fix(KzParams P, KzDevT
 #ifndef KZ_SHADE_WAVES
 #define KZ_SHADE_WAVES 4
 #endif
-// development build only (-DKZ_SHADESTAT): wall-clock cycles (s_memtime, per wave, stalls included) each section of the shade kernel takes,
+// development build only (-DKZ_SHADESTAT): wall-clock cycles (s_memtime, per wave, stalls included) each section of the shade kernels takes,
 // summed over the waves into stats[8..23]; the shares say where the waves' time goes, whatever bounds it
+struct KzSst {
 #ifdef KZ_SHADESTAT
-#define KZ_SST_DECL unsigned long long sstT = __builtin_amdgcn_s_memtime(), sstAcc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-// the same after every outstanding load has returned: the wait is charged to the section that issued the loads
-#define KZ_SSTW(k) do { __builtin_amdgcn_s_waitcnt(0); KZ_SST(k); } while (0)
-#define KZ_SST(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sstAcc[k] += t_ - sstT; sstT = t_; } while (0)
+    unsigned long long t = __builtin_amdgcn_s_memtime(), acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ void mark(int k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc[k] += t_ - t; t = t_; }
+    // the same after every outstanding load has returned: the wait is charged to the section that issued the loads
+    __device__ __forceinline__ void markw(int k) { __builtin_amdgcn_s_waitcnt(0); mark(k); }
+    __device__ __forceinline__ void flush(unsigned long long *stats) { if ((threadIdx.x & 63) == 0) for (int k = 0; k < 14; ++k) atomicAdd(stats + 8 + k, acc[k]); }
 #else
-#define KZ_SST_DECL do { } while (0)
-#define KZ_SST(k) do { } while (0)
-#define KZ_SSTW(k) do { } while (0)
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void markw(int) {}
+    __device__ __forceinline__ void flush(unsigned long long *) {}
 #endif
-// Two passes per round of 256 queue entries, because on many scenes about half of the hits end the path before any shading
-// happens (a one-sided BSDF seen from behind, an emitter, a miss): pass A rebuilds the intersection record and classifies;
+};
+
+// Pass A of shade(iter) for one queue entry: hit record -> intersection; a miss, an emitter hit and a one-sided BSDF seen from behind end the
+// path here (integrator.cpp:210-231, 315-327), the Russian roulette of integrator.cpp:237-244 is played. True = the path goes on to the light
+// sample and the BSDF sample (wfShadeSurvivor); `its` is then complete. `compact`: see kz_wf_shade.
+template <bool STATS, bool EXT>
+__device__ __forceinline__ bool wfClassify(const KzParams &P, const KzDevTables &T, const KzWf &W, const uint32_t *__restrict__ pixList, uint32_t S, uint32_t sampleBegin,
+                                           int iter, bool compact, uint32_t slot, Its &its, Counters &cn, KzSst &sst) {
+    bool survivor = false;
+    const float4 h = kzLoadStream(&W.hit[slot]);
+    const float4 rb = kzLoadStream(&W.rayB[slot]);
+    const V3 rd = mk(rb.x, rb.y, rb.z);
+#ifdef KZ_SHADESTAT
+    sst.markw(10);                                  // pass A: queue entry, hit record, ray
+    if (h.x < KZ_INF) { const float4 *sp_ = kzShadeRec(T, __float_as_uint(h.w)); const float4 a_ = sp_[0], b_ = sp_[3]; asm volatile("" :: "v"(a_.x), "v"(b_.x)); }
+    sst.markw(11);                                  // pass A: the shading record arrives
+#endif
+    if (!(h.x < KZ_INF)) {
+        // miss: black for the primary ray (H5), background after a bounce (integrator.cpp:315-318)
+        if (iter > 0 && P.bgPresent) {
+            const float4 th = kzLoadStream(&W.thr[slot]);
+            const V3 c = mk(th.x, th.y, th.z) * backgroundRadiance(P, T, rd);
+            unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);      // (returnless: no wait, one writer per slot)
+        }
+        return false;
+    }
+    RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
+    postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
+    sst.markw(12);                                  // pass A: postIntersect
+    if (its.light >= 0) {                                                         // integrator.cpp:226-231, 322-327
+        const KzLightRow &lr = T.lights[its.light];
+        const float4 ra = kzLoadStream(&W.rayA[slot]);
+        const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : kzLoadStream(&W.thr[slot]);
+        const float4 mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : (compact ? make_float4(th.w, 0.f, 0.f, 0.f) : kzLoadStream(&W.misc[slot]));
+        const V3 ro = mk(ra.x, ra.y, ra.z);
+        const V3 wi = normalized(its.p - ro);
+        float bsdfWeight = 1.f;
+        if (iter > 0 && mi.z == 0.f) bsdfWeight = powerHeuristic(mi.x, lightPdfSolidAngle(lr.normalization, its.sh.n, wi, its.p, ro));   // mi.z: EDiscrete (integrator.cpp:329-331)
+        if (dot(its.sh.n, -wi) > 0.f) {
+            const V3 c = (bsdfWeight * mk(th.x, th.y, th.z)) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
+            unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);      // (returnless: no wait, one writer per slot)
+        }
+        return false;
+    }
+    // A one-sided BSDF seen from below evaluates to 0 for every light sample (no shadow ray, nothing added) and its
+    // sample() returns 0 (the path ends): nothing after this point can be observed. Only the two-sided
+    // transmissive models go on; a normal map can turn a below-the-horizon wi into an above-the-horizon one.
+    const float wz = dot(-rd, its.sh.n);                                       // toLocal(its.sh, -rd).z
+    bool twoSided = false;
+    if (EXT) { const int bt = T.bsdfs[its.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
+    survivor = (wz > 0.f) || twoSided || isnan(wz);
+    if (survivor && iter >= 3) {
+        // Russian roulette (integrator.cpp:237-244) here, in front of the compaction: a path it ends does not take a lane of
+        // pass B (at depth 3 and 4 that was 2 of 3 lanes). The survivor's scaled throughput and advanced sampler go back to
+        // the path state, where pass B reads them.
+        const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
+        Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
+        const float4 th = kzLoadStream(&W.thr[slot]);
+        V3 throughput = mk(th.x, th.y, th.z);
+        const float etaA = compact ? 1.f : th.w;
+        const float probability = fminf(maxCoeff(throughput) * etaA * etaA, 0.95f);
+        if (probability <= smp.next1D(P, T)) survivor = false;
+        else {
+            throughput = throughput / probability;
+            kzStoreStream(&W.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, th.w));
+            wfStoreSampler(P, W, slot, smp);
+        }
+    } else if (STATS && !survivor && P.nLights > 0) {
+        // counters only: the reference draws the roulette sample before it takes the light sample (integrator.cpp:237-247)
+        bool alive = true;
+        if (iter >= 3) {
+            const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
+            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
+            const float4 th = kzLoadStream(&W.thr[slot]);
+            const float etaA = compact ? 1.f : th.w;
+            if (fminf(maxCoeff(mk(th.x, th.y, th.z)) * etaA * etaA, 0.95f) <= smp.next1D(P, T)) alive = false;
+        }
+        if (alive) cn.lsamples++;
+    }
+    return survivor;
+}
+
+// Pass B of shade(iter) for one surviving path: light sample + BSDF eval / pdf + MIS weight -> pending radiance and shadow ray
+// (integrator.cpp:247-295), BSDF sample -> throughput and next ray (:297-313). (The roulette of integrator.cpp:237-244 was played in pass A.)
+template <bool STATS, bool EXT>
+__device__ __forceinline__ void wfShadeSurvivor(const KzParams &P, const KzDevTables &T, const KzWf &W, const uint32_t *__restrict__ pixList, uint32_t S, uint32_t sampleBegin,
+                                                int iter, bool compact, uint32_t slot, const Its &its, bool &pushNext, bool &pushShadow, Counters &cn, KzSst &sst) {
+    const float eps = P.traceBias;
+    const float4 rb = kzLoadStream(&W.rayB[slot]);
+    const V3 rd = mk(rb.x, rb.y, rb.z);
+    float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : kzLoadStream(&W.thr[slot]);              // a camera path: generate stores neither (initial values)
+    V3 throughput = mk(th.x, th.y, th.z);
+    const float eta = compact ? 1.f : th.w;
+    float accRough = (iter == 0 || compact) ? 0.f : W.misc[slot].y;
+    const uint32_t pl = slot / S;
+    const uint32_t pxy = pixList[pl];
+    Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter) + (iter >= 3 ? 1u : 0u));
+    KzBSDF bsdf = T.bsdfs[its.bsdf];
+    NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
+    const V3 wiLocal = toLocal(its.sh, -rd);
+    sst.mark(2);                                    // pass B: record, state loads, sampler setup, BSDF row, frame
+    const float pick = smp.next1D(P, T);                                  // drawn even without lights
+    if (P.nLights > 0) {                                                  // integrator.cpp:247-295
+        const uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
+        const KzLightRow lrow = T.lights[li];
+        if (STATS) cn.lsamples++;
+        const LightSample ls = lightSample(T, lrow, its.p, [&]() { return smp.next1D(P, T); });
+        const V3 lwi = ls.wi; const float dist = ls.dist, lpdf = ls.pdf;
+        V3 Ls = ls.Ls;
+        Ls = lightPickDivide(P, Ls);
+        sst.mark(3);                                // pick + 3 draws + light sample
+        const V3 woL = toLocal(its.sh, lwi);
+        V3 f; float bpdfL;
+        surfEvalPdf<EXT>(bsdf, nm, its, wiLocal, woL, accRough, f, bpdfL);
+        const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
+        // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
+        if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
+            kzStoreStream(&W.shA[slot], make_float4(its.p.x, its.p.y, its.p.z, dist - eps));
+            kzStoreStream(&W.shB[slot], make_float4(lwi.x, lwi.y, lwi.z, eps));
+            kzStoreStream(&W.shL[slot], make_float4(pend.x, pend.y, pend.z, 0.f));
+            pushShadow = true;
+        }
+    }
+    sst.mark(4);                                    // eval + pdf towards the light, shadow ray stores
+    if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
+    float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
+    const float s1 = smp.next1D(P, T);
+    sst.mark(5);                                    // 2-D + 1-D draw
+    V3 woLocal; bool ok, discrete, solid; float etaScale, pdfS;
+    const V3 weight = surfSample<EXT>(bsdf, nm, its, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale, pdfS, solid);
+    sst.mark(6);                                    // BSDF sample
+    throughput = throughput * weight;
+    const float etaNext = eta * etaScale;
+    if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
+        const float bpdf = pdfS >= 0.f ? pdfS : surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, solid);
+        const V3 nd = toWorld(its.sh, woLocal);                           // H9
+        // the ray after the LAST bounce only matters for the background term
+        if (iter + 1 < P.maxDepth || P.bgPresent) {
+            kzStoreStream(&W.rayA[slot], make_float4(its.p.x, its.p.y, its.p.z, eps));
+            kzStoreStream(&W.rayB[slot], make_float4(nd.x, nd.y, nd.z, KZ_INF));
+            kzStoreStream(&W.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, compact ? bpdf : etaNext));
+            if (!compact) kzStoreStream(&W.misc[slot], make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f));
+            wfStoreSampler(P, W, slot, smp);
+            pushNext = true;
+        }
+    }
+}
+
+// The two output queues of a shade kernel, staged in LDS: flush the one(s) that another 256 entries might not fit into (or, at the end,
+// whatever is staged). Called by every thread of the workgroup after a barrier that made the staged entries visible.
+struct WfQueuePair {
+    uint32_t *s_bufN, *s_bufS, *s_nN, *s_nS, *s_gbN, *s_gbS;
+    uint32_t *nextQueue, *nextCount, *shadowQueue, *shadowCount;
+    __device__ __forceinline__ void flush(bool force) {
+        const uint32_t nN = *s_nN, nS = *s_nS;
+        const bool fN = force ? (nN > 0) : (nN > KZ_WF_QCAP - KZ_BLOCK), fS = force ? (nS > 0) : (nS > KZ_WF_QCAP - KZ_BLOCK);
+        if (fN || fS) {                                     // uniform over the workgroup
+            if (threadIdx.x == 0) { if (fN) *s_gbN = atomicAdd(nextCount, nN); if (fS) *s_gbS = atomicAdd(shadowCount, nS); }
+            __syncthreads();
+            if (fN) { const uint32_t gb = *s_gbN; for (uint32_t i = threadIdx.x; i < nN; i += KZ_BLOCK) nextQueue[gb + i] = s_bufN[i]; }
+            if (fS) { const uint32_t gb = *s_gbS; for (uint32_t i = threadIdx.x; i < nS; i += KZ_BLOCK) shadowQueue[gb + i] = s_bufS[i]; }
+            __syncthreads();
+            if (threadIdx.x == 0) { if (fN) *s_nN = 0; if (fS) *s_nS = 0; }      // (kz_wf_shade: the next entries are staged behind the next round's first barrier)
+        }
+    }
+    // Flush both whatever they hold, with the same barriers on every path: for callers that stage the next entries without a barrier of their own
+    // (nothing here branches on the shared counts, which a wave that has run ahead may already be adding to again after the last barrier).
+    __device__ __forceinline__ void flushAll() {
+        const uint32_t nN = *s_nN, nS = *s_nS;
+        if (threadIdx.x == 0) { if (nN) *s_gbN = atomicAdd(nextCount, nN); if (nS) *s_gbS = atomicAdd(shadowCount, nS); }
+        __syncthreads();
+        { const uint32_t gb = *s_gbN; for (uint32_t i = threadIdx.x; i < nN; i += KZ_BLOCK) nextQueue[gb + i] = s_bufN[i]; }
+        { const uint32_t gb = *s_gbS; for (uint32_t i = threadIdx.x; i < nS; i += KZ_BLOCK) shadowQueue[gb + i] = s_bufS[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) { *s_nN = 0; *s_nS = 0; }
+        __syncthreads();
+    }
+};
+
+// ONE kernel per bounce (KzTune.shadeSplit == 0). Two passes per round of 256 queue entries, because on many scenes about half of the hits end
+// the path before any shading happens (a one-sided BSDF seen from behind, an emitter, a miss): pass A rebuilds the intersection record and classifies;
 // the entries that still need the light sample and the BSDF sample are compacted through LDS (record = slot + frame + uv),
 // and pass B — which carries ~85 % of the kernel's instructions — only ever runs on full waves.
 #define KZ_SV_CAP (2 * KZ_BLOCK)
@@ -216,33 +398,19 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
     if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svCnt[0] = 0; s_svCnt[1] = 0; }
     __syncthreads();
     WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
-    // both queues: flush the one(s) that another 256 entries might not fit into (or, at the end, whatever is staged); called by every thread
-    // after a barrier that made the staged entries visible
-    auto flushBoth = [&](bool force) {
-        const uint32_t nN = s_nN, nS = s_nS;
-        const bool fN = force ? (nN > 0) : (nN > KZ_WF_QCAP - KZ_BLOCK), fS = force ? (nS > 0) : (nS > KZ_WF_QCAP - KZ_BLOCK);
-        if (fN || fS) {                                     // uniform over the workgroup
-            if (threadIdx.x == 0) { if (fN) s_gbN = atomicAdd(nextCount, nN); if (fS) s_gbS = atomicAdd(shadowCount, nS); }
-            __syncthreads();
-            if (fN) { const uint32_t gb = s_gbN; for (uint32_t i = threadIdx.x; i < nN; i += KZ_BLOCK) nextQueue[gb + i] = s_bufN[i]; }
-            if (fS) { const uint32_t gb = s_gbS; for (uint32_t i = threadIdx.x; i < nS; i += KZ_BLOCK) shadowQueue[gb + i] = s_bufS[i]; }
-            __syncthreads();
-            if (threadIdx.x == 0) { if (fN) s_nN = 0; if (fS) s_nS = 0; }      // (the next entries are staged behind the next round's first barrier)
-        }
-    };
+    WfQueuePair qp = {s_bufN, s_bufS, &s_nN, &s_nS, &s_gbN, &s_gbS, nextQueue, nextCount, shadowQueue, shadowCount};
     const uint32_t count = countPtr ? *countPtr : countImm;
-    const float eps = P.traceBias;
     const int lane = threadIdx.x & 63;
     // Path state between bounces. The lean variant has no BSDF that changes eta or samples a discrete lobe, and without regularisation the
     // accumulated roughness stays 0: the only thing `misc` would carry is the pdf of the sampled direction, which then rides in the free fourth
     // word of the throughput record (16 B less to write and to read back per bounce and path; the state arrays are the kernel's HBM traffic).
     const bool compact = !EXT && !P.regularization;
     Counters cn = {0, 0, 0, 0, 0, 0};
-    KZ_SST_DECL;
+    KzSst sst;
     uint32_t round = 0;
     for (uint32_t base = blockIdx.x * KZ_BLOCK;; base += gridDim.x * KZ_BLOCK, ++round) {
         const bool more = base < count;                                               // uniform over the workgroup
-        KZ_SST(9);
+        sst.mark(9);
         // ================= pass A: hit record -> intersection, miss / emitter / back-face end here =================
         bool survivor = false;
         uint32_t slot = 0;
@@ -250,78 +418,9 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
         if (more && base + threadIdx.x < count) {
             const uint32_t qi = base + threadIdx.x;
             slot = queue ? queue[qi] : qi;
-            const float4 h = kzLoadStream(&W.hit[slot]);
-            const float4 rb = kzLoadStream(&W.rayB[slot]);
-            const V3 rd = mk(rb.x, rb.y, rb.z);
-#ifdef KZ_SHADESTAT
-            KZ_SSTW(10);                                    // pass A: queue entry, hit record, ray
-            if (h.x < KZ_INF) { const float4 *sp_ = reinterpret_cast<const float4 *>(T.shade + __float_as_uint(h.w)); const float4 a_ = sp_[0], b_ = sp_[6]; asm volatile("" :: "v"(a_.x), "v"(b_.x)); }
-            KZ_SSTW(11);                                    // pass A: the shading record arrives
-#endif
-            if (!(h.x < KZ_INF)) {
-                // miss: black for the primary ray (H5), background after a bounce (integrator.cpp:315-318)
-                if (iter > 0 && P.bgPresent) {
-                    const float4 th = kzLoadStream(&W.thr[slot]);
-                    const V3 c = mk(th.x, th.y, th.z) * backgroundRadiance(P, T, rd);
-                    unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);      // (returnless: no wait, one writer per slot)
-                }
-            } else {
-                RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
-                postIntersect<false>(T, rh, its); if (STATS) cn.hits++;
-                KZ_SSTW(12);                                // pass A: postIntersect
-                if (its.light >= 0) {                                                         // integrator.cpp:226-231, 322-327
-                    const KzLightRow &lr = T.lights[its.light];
-                    const float4 ra = kzLoadStream(&W.rayA[slot]);
-                    const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : kzLoadStream(&W.thr[slot]);
-                    const float4 mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : (compact ? make_float4(th.w, 0.f, 0.f, 0.f) : kzLoadStream(&W.misc[slot]));
-                    const V3 ro = mk(ra.x, ra.y, ra.z);
-                    const V3 wi = normalized(its.p - ro);
-                    float bsdfWeight = 1.f;
-                    if (iter > 0 && mi.z == 0.f) bsdfWeight = powerHeuristic(mi.x, lightPdfSolidAngle(lr.normalization, its.sh.n, wi, its.p, ro));   // mi.z: EDiscrete (integrator.cpp:329-331)
-                    if (dot(its.sh.n, -wi) > 0.f) {
-                        const V3 c = (bsdfWeight * mk(th.x, th.y, th.z)) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
-                        unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);      // (returnless: no wait, one writer per slot)
-                    }
-                } else {
-                    // A one-sided BSDF seen from below evaluates to 0 for every light sample (no shadow ray, nothing added) and its
-                    // sample() returns 0 (the path ends): nothing after this point can be observed. Only the two-sided
-                    // transmissive models go on; a normal map can turn a below-the-horizon wi into an above-the-horizon one.
-                    const float wz = dot(-rd, its.sh.n);                                       // toLocal(its.sh, -rd).z
-                    bool twoSided = false;
-                    if (EXT) { const int bt = T.bsdfs[its.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
-                    survivor = (wz > 0.f) || twoSided || isnan(wz);
-                    if (survivor && iter >= 3) {
-                        // Russian roulette (integrator.cpp:237-244) here, in front of the compaction: a path it ends does not take a lane of
-                        // pass B (at depth 3 and 4 that was 2 of 3 lanes). The survivor's scaled throughput and advanced sampler go back to
-                        // the path state, where pass B reads them.
-                        const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
-                        Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
-                        const float4 th = kzLoadStream(&W.thr[slot]);
-                        V3 throughput = mk(th.x, th.y, th.z);
-                        const float etaA = compact ? 1.f : th.w;
-                        const float probability = fminf(maxCoeff(throughput) * etaA * etaA, 0.95f);
-                        if (probability <= smp.next1D(P, T)) survivor = false;
-                        else {
-                            throughput = throughput / probability;
-                            kzStoreStream(&W.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, th.w));
-                            wfStoreSampler(P, W, slot, smp);
-                        }
-                    } else if (STATS && !survivor && P.nLights > 0) {
-                        // counters only: the reference draws the roulette sample before it takes the light sample (integrator.cpp:237-247)
-                        bool alive = true;
-                        if (iter >= 3) {
-                            const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
-                            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
-                            const float4 th = kzLoadStream(&W.thr[slot]);
-                            const float etaA = compact ? 1.f : th.w;
-                            if (fminf(maxCoeff(mk(th.x, th.y, th.z)) * etaA * etaA, 0.95f) <= smp.next1D(P, T)) alive = false;
-                        }
-                        if (alive) cn.lsamples++;
-                    }
-                }
-            }
+            survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, cn, sst);
         }
-        KZ_SST(0);                                          // pass A
+        sst.mark(0);                                        // pass A
         {   // compaction of the survivors onto the LDS record stack
             const unsigned long long m = __ballot(survivor);
             uint32_t b = 0;
@@ -339,7 +438,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             }
         }
         __syncthreads();
-        KZ_SST(1);                                          // compaction + barrier
+        sst.mark(1);                                        // compaction + barrier
         // ================= pass B: one survivor per thread once a full workgroup of them is waiting (or at the end) =================
         // Before pass A at most 255 records wait, pass A adds at most 256: the table (512) cannot overflow.
         const uint32_t n0 = s_svCnt[round & 1u];
@@ -355,82 +454,121 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             its.sh.n = mk(__uint_as_float(r[10 * KZ_SV_CAP]), __uint_as_float(r[11 * KZ_SV_CAP]), __uint_as_float(r[12 * KZ_SV_CAP]));
             its.uvx = __uint_as_float(r[13 * KZ_SV_CAP]); its.uvy = __uint_as_float(r[14 * KZ_SV_CAP]); its.bsdf = r[15 * KZ_SV_CAP];
             if (EXT) its.dpdu = mk(__uint_as_float(r[16 * KZ_SV_CAP]), __uint_as_float(r[17 * KZ_SV_CAP]), __uint_as_float(r[18 * KZ_SV_CAP]));
-            const float4 rb = kzLoadStream(&W.rayB[slot]);
-            const V3 rd = mk(rb.x, rb.y, rb.z);
-            float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : kzLoadStream(&W.thr[slot]);              // a camera path: generate stores neither (initial values)
-            V3 throughput = mk(th.x, th.y, th.z);
-            const float eta = compact ? 1.f : th.w;
-            float accRough = (iter == 0 || compact) ? 0.f : W.misc[slot].y;
-            const uint32_t pl = slot / S;
-            const uint32_t pxy = pixList[pl];
-            Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter) + (iter >= 3 ? 1u : 0u));
-            {                                                                         // (the roulette of integrator.cpp:237-244 was played in pass A)
-                KzBSDF bsdf = T.bsdfs[its.bsdf];
-                NMap nm; surfaceSetup<EXT>(T, its, bsdf, nm);
-                const V3 wiLocal = toLocal(its.sh, -rd);
-                KZ_SST(2);                                  // pass B: record, state loads, sampler setup, BSDF row, frame
-                const float pick = smp.next1D(P, T);                                  // drawn even without lights
-                if (P.nLights > 0) {                                                  // integrator.cpp:247-295
-                    const uint32_t li = min((uint32_t)floorf((float)P.nLights * pick), P.nLights - 1);
-                    const KzLightRow lrow = T.lights[li];
-                    if (STATS) cn.lsamples++;
-                    const LightSample ls = lightSample(T, lrow, its.p, [&]() { return smp.next1D(P, T); });
-                    const V3 lwi = ls.wi; const float dist = ls.dist, lpdf = ls.pdf;
-                    V3 Ls = ls.Ls;
-                    Ls = lightPickDivide(P, Ls);
-                    KZ_SST(3);                              // pick + 3 draws + light sample
-                    const V3 woL = toLocal(its.sh, lwi);
-                    V3 f; float bpdfL;
-                    surfEvalPdf<EXT>(bsdf, nm, its, wiLocal, woL, accRough, f, bpdfL);
-                    const V3 pend = throughput * Ls * f * powerHeuristic(lpdf, bpdfL);
-                    // a contribution of exactly zero cannot change L whether or not the ray is blocked: skip the ray
-                    if (!(pend.x == 0.f && pend.y == 0.f && pend.z == 0.f)) {
-                        kzStoreStream(&W.shA[slot], make_float4(its.p.x, its.p.y, its.p.z, dist - eps));
-                        kzStoreStream(&W.shB[slot], make_float4(lwi.x, lwi.y, lwi.z, eps));
-                        kzStoreStream(&W.shL[slot], make_float4(pend.x, pend.y, pend.z, 0.f));
-                        pushShadow = true;
-                    }
-                }
-                KZ_SST(4);                                  // eval + pdf towards the light, shadow ray stores
-                if (P.regularization && bsdf.type == KZ_BSDF_KAZENSTANDARD) accRough += bsdf.roughness * P.accumulatedRoughness;
-                float s2x, s2y; smp.next2D(P, T, s2x, s2y);                           // H1: 2-D before 1-D
-                const float s1 = smp.next1D(P, T);
-                KZ_SST(5);                                  // 2-D + 1-D draw
-                V3 woLocal; bool ok, discrete, solid; float etaScale, pdfS;
-                const V3 weight = surfSample<EXT>(bsdf, nm, its, wiLocal, accRough, s1, s2x, s2y, woLocal, ok, discrete, etaScale, pdfS, solid);
-                KZ_SST(6);                                  // BSDF sample
-                throughput = throughput * weight;
-                const float etaNext = eta * etaScale;
-                if (ok && !(weight.x == 0.f && weight.y == 0.f && weight.z == 0.f)) {
-                    const float bpdf = pdfS >= 0.f ? pdfS : surfPdf<EXT>(bsdf, nm, its, wiLocal, woLocal, accRough, solid);
-                    const V3 nd = toWorld(its.sh, woLocal);                           // H9
-                    // the ray after the LAST bounce only matters for the background term
-                    if (iter + 1 < P.maxDepth || P.bgPresent) {
-                        kzStoreStream(&W.rayA[slot], make_float4(its.p.x, its.p.y, its.p.z, eps));
-                        kzStoreStream(&W.rayB[slot], make_float4(nd.x, nd.y, nd.z, KZ_INF));
-                        kzStoreStream(&W.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, compact ? bpdf : etaNext));
-                        if (!compact) kzStoreStream(&W.misc[slot], make_float4(bpdf, accRough, discrete ? 1.f : 0.f, 0.f));
-                        wfStoreSampler(P, W, slot, smp);
-                        pushNext = true;
-                    }
-                }
-            }
+            wfShadeSurvivor<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, pushNext, pushShadow, cn, sst);
         }
-        KZ_SST(7);                                          // next-ray stores (and, for lanes without a survivor, nothing)
+        sst.mark(7);                                        // next-ray stores (and, for lanes without a survivor, nothing)
         apN.push(pushNext, slot); apS.push(pushShadow, slot);
         __syncthreads();                                   // every record of this batch has been read, the output entries are staged
-        flushBoth(false);
-        KZ_SST(8);                                          // barrier + queue staging + flushes
+        qp.flush(false);
+        sst.mark(8);                                        // barrier + queue staging + flushes
         if (!more && n0 - take == 0) break;
         if (!more) base -= gridDim.x * KZ_BLOCK;           // stay past the end while the table drains
     }
     __syncthreads();
-    flushBoth(true);
+    qp.flush(true);
     if (STATS) wfStatsFlush(W.stats, cn, 0);
-#ifdef KZ_SHADESTAT
-    if (lane == 0) for (int k = 0; k < 14; ++k) atomicAdd(W.stats + 8 + k, sstAcc[k]);
-#endif
+    sst.flush(W.stats);
 }
+
+#ifdef KZ_EXPERIMENTS
+// TWO kernels per bounce (round 4; development builds only: -DKZ_EXPERIMENTS -DKZ_SHADE_SPLIT=1): pass A as a kernel of its own at
+// 8 waves per SIMD writes the slots of the surviving paths to a dense queue; pass B runs on full waves from that queue, rebuilds the intersection
+// record from the hit record and needs neither the 40-KB LDS record stack of the one-kernel form nor its two barriers per round. MEASURED AND REJECTED
+// (profiles/r04b_shade_split, same gpurun call, films bit-identical): C4 shade 18.1 -> 20.9 ms per pass (classification 6.1 ms - no faster at 8 or 7 waves
+// per SIMD than as pass A of the one kernel, 5.7 - and pass B 14.8 ms against 9.4 + 3.3 of compaction and barriers: the second walk down
+// queue -> hit record -> shading record costs more than the record stack did), C3 23.5 -> 28.5 ms. The kernel is bound by the DEPTH of its chains
+// of dependent loads, and a split adds two levels.
+#ifndef KZ_CLASSIFY_WAVES
+#define KZ_CLASSIFY_WAVES 8
+#endif
+template <bool STATS, bool EXT>
+__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_CLASSIFY_WAVES, KZ_CLASSIFY_WAVES))) void kz_wf_classify(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
+                                                           uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
+                                                           const uint32_t *__restrict__ countPtr, uint32_t countImm,
+                                                           uint32_t *__restrict__ survQueue, uint32_t *__restrict__ survCount) {
+    __shared__ uint32_t s_buf[KZ_WF_QCAP]; __shared__ uint32_t s_n, s_gb;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    WfAppender ap = {s_buf, &s_n, &s_gb, survQueue, survCount};
+    const uint32_t count = countPtr ? *countPtr : countImm;
+    const bool compact = !EXT && !P.regularization;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    KzSst sst;
+    int round = 0;
+    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
+        bool survivor = false;
+        uint32_t slot = 0;
+        if (base + threadIdx.x < count) {
+            const uint32_t qi = base + threadIdx.x;
+            slot = queue ? queue[qi] : qi;
+            Its its;
+            survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, cn, sst);
+        }
+        sst.mark(0);
+        ap.push(survivor, slot);
+        // The staging buffer takes KZ_WF_ROUNDS rounds of 256 entries: it is flushed every so many rounds whatever it holds, so the decision needs
+        // no look at the shared count (a wave that has run ahead into the next round may already be adding to it) and the rounds between two
+        // flushes need no barrier at all.
+        if (++round == KZ_WF_ROUNDS) {
+            round = 0;
+            __syncthreads();
+            const uint32_t n = s_n;                         // (stable: every wave's next push is behind the barriers below)
+            if (threadIdx.x == 0) s_gb = atomicAdd(survCount, n);
+            __syncthreads();
+            const uint32_t gb = s_gb;
+            for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) survQueue[gb + i] = s_buf[i];
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+        }
+        sst.mark(1);
+    }
+    ap.maybeFlush(true);
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+    sst.flush(W.stats);
+}
+
+template <bool STATS, bool EXT>
+__global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade_b(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
+                                                        uint32_t sampleBegin, int iter, const uint32_t *__restrict__ survQueue, const uint32_t *__restrict__ survCount,
+                                                        uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
+                                                        uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
+    __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
+    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; }
+    __syncthreads();
+    WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
+    WfQueuePair qp = {s_bufN, s_bufS, &s_nN, &s_nS, &s_gbN, &s_gbS, nextQueue, nextCount, shadowQueue, shadowCount};
+    const uint32_t count = *survCount;
+    const bool compact = !EXT && !P.regularization;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    KzSst sst;
+    int round = 0;
+    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
+        bool pushNext = false, pushShadow = false;
+        uint32_t slot = 0;
+        if (base + threadIdx.x < count) {
+            slot = kzLoadStream(survQueue + base + threadIdx.x);
+            const float4 h = kzLoadStream(&W.hit[slot]);
+            RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
+            Its its; postIntersect<false>(T, rh, its);                 // (counted by kz_wf_classify)
+            sst.markw(12);
+            wfShadeSurvivor<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, pushNext, pushShadow, cn, sst);
+        }
+        sst.mark(7);
+        apN.push(pushNext, slot); apS.push(pushShadow, slot);
+        if (++round == KZ_WF_ROUNDS) {                     // (see kz_wf_classify)
+            round = 0;
+            __syncthreads();
+            qp.flushAll();
+        }
+        sst.mark(8);
+    }
+    __syncthreads();
+    qp.flush(true);
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+    sst.flush(W.stats);
+}
+#endif
 
 
 // ---- persistent traversal kernel -----------------------------------------------------------------------------------------
@@ -449,7 +587,7 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
 // instantiation: 57 VGPRs and no spills instead of 64 with 9 spilled.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment.
 // (The BVH2 form, the per-lane key stack, the LDS top-of-tree and the mixed launches of round 2 live in kz_experiments.h.)
-struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, packet, filmGather, rareBlocksPerCU;
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, packet, filmGather, shadeSplit;
                 int wide, keyStack, ldsTop, leafQueue, legacyTrace, mixed;      // kz_experiments.h only
                 uint32_t *ovf; uint32_t ovfStride; };
 

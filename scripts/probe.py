@@ -7,6 +7,9 @@
                                                          the same for a list of values of one KzTuning field (or pass_items / passes_in_flight)
     python scripts/probe.py counters --values 'keyStack=1;keyStack=2'
                                                          executed node visits / triangle tests / rays per sample for each tuning
+    python scripts/probe.py ab --variants tree,NAME[,NAME2...] [--scenes c4,c3] [--reps 2] [--spp 256] [--tune ...] [--out DIR]
+                                                         same-call A/B: `stages` in a child process per (repetition, build, scene); NAME = a build made by
+                                                         scripts/build_variant.sh NAME <flags> (tree = the in-tree product). Lines go to gpurun_out/DIR/ab.txt
     KZ_LIB_PATH=nano-kazen_amd/csrc/variants/lanestat/libkazen_mi355x.so python scripts/probe.py lanestat
                                                          where the lanes of the traversal loop are (needs scripts/build_variant.sh lanestat -DKZ_LANESTAT)
     KZ_LIB_PATH=nano-kazen_amd/csrc/variants/shadestat/libkazen_mi355x.so python scripts/probe.py shadestat
@@ -142,11 +145,30 @@ def cmd_sched(a):
                           "film_maxrel": float(np.max(np.abs(film - ref) / np.maximum(np.abs(ref), 1e-3)))}), flush=True)
 
 
+def cmd_ab(a):
+    """Box-to-box variance is 3-6 %, so only numbers from ONE gpurun call compare: alternate the builds, each in its own child process."""
+    import subprocess
+    out = os.path.join(OUT, a.out or "ab"); os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "ab.txt"), "a") as f:
+        for rep in range(a.reps):
+            for lib in a.variants.split(","):
+                for sc in a.scenes.split(","):
+                    env = dict(os.environ)
+                    env.pop("KZ_LIB_PATH", None)
+                    if lib != "tree":
+                        env["KZ_LIB_PATH"] = os.path.join(ROOT, "nano-kazen_amd", "csrc", "variants", lib, "libkazen_mi355x.so")
+                    cmd = [sys.executable, os.path.abspath(__file__), "stages", "--scene", sc, "--spp", str(a.spp or 256), "--tune", a.tune, "--opts", a.opts]
+                    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                    line = "%s %s %s" % (lib, sc, (r.stdout.strip().splitlines() or ["FAILED rc=%d %s" % (r.returncode, r.stderr[-400:])])[-1])
+                    print(line, flush=True); f.write(line + "\n"); f.flush()
+
+
 ap = argparse.ArgumentParser()
-ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters", "shadestat", "sched"])
+ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters", "shadestat", "sched", "ab"])
+ap.add_argument("--variants", default="tree"); ap.add_argument("--scenes", default="c4,c3"); ap.add_argument("--reps", type=int, default=2); ap.add_argument("--out", default="")
 ap.add_argument("c5", nargs="?")
 ap.add_argument("--scene", default="c4"); ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--tune", default=""); ap.add_argument("--opts", default="")
 ap.add_argument("--all-kiss", action="store_true"); ap.add_argument("--knob", default="refill"); ap.add_argument("--values", default="")
 a = ap.parse_args()
-{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters, "shadestat": cmd_shadestat, "sched": cmd_sched}[a.cmd](a)
+{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters, "shadestat": cmd_shadestat, "sched": cmd_sched, "ab": cmd_ab}[a.cmd](a)

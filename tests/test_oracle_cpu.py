@@ -347,3 +347,17 @@ def test_rough_bsdfs_are_sane(O, kz):
     assert below > 100                                   # mostly transmission at near-normal incidence
     film = O.OracleScene(S.materials_scene(48, 32, 4)).render(threads=4)
     assert np.isfinite(film).all() and film[..., :3].sum() > 0
+
+
+def test_permute_and_tea32_match_reference_text(O, kats):
+    """random::permute / sampleTEA32 (common.cpp:304-344): vectors minted by compiling the reference's own text of that block
+    (oracle/kat_ref_permute.cpp); keys are the callers' 64-bit expressions, truncated to uint32 as the call does."""
+    L = O.lib()
+    for i, l, key64, out in kats["permute"]:
+        assert L.kzo_permute(i, l, int(key64) & 0xffffffff) == out, (i, l, key64)
+    for e in kats["permute_full"]:
+        got = [L.kzo_permute(i, e["l"], e["key"]) for i in range(e["l"])]
+        assert got == e["out"]
+        assert sorted(got) == list(range(e["l"]))                      # a permutation
+    for v0, v1, rounds, out in kats["tea32"]:
+        assert L.kzo_tea32(v0, v1, rounds) == int(out)
