@@ -5,10 +5,17 @@ set -e
 # v_pk_mul_f32 / v_pk_add_f32 with register shuffles around them - a packed f32 instruction issues no faster than its two halves on gfx950
 # (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever") and the shuffles are pure overhead: C4 1 588 -> 1 662 Msamples/s, same results
 # (profiles/r03s_no_slp). The one place where packing pays, the BVH4 node step, uses explicit two-lane vector FMAs (kz_devfn.h node4Keys).
+# usage: build.sh [output directory]   (default: this directory; scripts/build_variant.sh passes variants/<name>); extra compiler flags in KZ_EXTRA_HIPFLAGS
 cd "$(dirname "$0")"
+OUT=${1:-.}
+mkdir -p "$OUT"
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
-hipcc $FLAGS --offload-arch=gfx950 -fgpu-flush-denormals-to-zero -fno-slp-vectorize ${KZ_EXTRA_HIPFLAGS} -c kz_device.hip -o kz_device.o
-hipcc $FLAGS -c kz_host.cpp -o kz_host.o
-hipcc $FLAGS -c kz_bvh.cpp -o kz_bvh.o
-hipcc -shared -fPIC -o libkazen_mi355x.so kz_device.o kz_host.o kz_bvh.o -pthread
-echo "built $(pwd)/libkazen_mi355x.so"
+DEV="--offload-arch=gfx950 -fgpu-flush-denormals-to-zero -fno-slp-vectorize ${KZ_EXTRA_HIPFLAGS}"
+# the translation units compile side by side (kz_state.h says what lives where)
+for u in kz_render kz_film kz_debug; do hipcc $FLAGS $DEV -c $u.hip -o "$OUT/$u.o" & done
+for u in kz_multi kz_host kz_bvh; do hipcc $FLAGS ${KZ_EXTRA_HIPFLAGS} -c $u.cpp -o "$OUT/$u.o" & done
+wait
+for u in kz_render kz_film kz_debug kz_multi kz_host kz_bvh; do [ -f "$OUT/$u.o" ] || { echo "build failed: $u"; exit 1; }; done
+hipcc -shared -fPIC -o "$OUT/libkazen_mi355x.so" "$OUT/kz_render.o" "$OUT/kz_film.o" "$OUT/kz_debug.o" "$OUT/kz_multi.o" "$OUT/kz_host.o" "$OUT/kz_bvh.o" -pthread
+rm -f "$OUT"/kz_render.o "$OUT"/kz_film.o "$OUT"/kz_debug.o "$OUT"/kz_multi.o "$OUT"/kz_host.o "$OUT"/kz_bvh.o
+echo "built $(cd "$OUT" && pwd)/libkazen_mi355x.so"

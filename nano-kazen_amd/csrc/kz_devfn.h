@@ -1,5 +1,5 @@
 // kz_devfn.h — device functions of the path_mis hot path (vector math, sampler, traversal, post-intersection,
-// BSDFs, lights, camera, Li). Included by kz_device.hip only; every function cites the reference lines it follows.
+// BSDFs, lights, camera, Li). Included by the device translation units (kz_render.hip, kz_film.hip, kz_debug.hip); every function cites the reference lines it follows.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kz_internal.h"

@@ -4,7 +4,7 @@
 // + the ImageBlock / PMJ02BN constructors do in the reference (scene.cpp:29-52, accel.cpp:25-61,
 // mesh.cpp:24-45, camera.cpp:35-68, block.cpp:9-31, sampler.cpp:275-315) and leaves behind flat tables
 // that kz_scene_upload copies to HBM once. Nothing here renders: there is no CPU fallback for the
-// kernels in kz_device.hip.
+// kernels in kz_render.hip / kz_film.hip.
 #include "kz_internal.h"
 
 #include <algorithm>

@@ -160,7 +160,7 @@ struct KzScene {
     float filter[KZ_FILTER_RESOLUTION + 1];
     KzParams prm;
     KzBvhInfo bvh;
-    // device replicas, one per GPU the scene is resident on (KzReplicaSet, owned by kz_device.hip; created with the scene)
+    // device replicas, one per GPU the scene is resident on (KzReplicaSet, owned by kz_render.hip; created with the scene)
     void *dev = nullptr;
 };
 
@@ -173,6 +173,6 @@ int kz_collapse_bvh4(const std::vector<KzNode> &nodes, uint32_t rootRef, std::ve
 // kz_host.cpp
 int kz_fail(int code, const char *fmt, ...);
 
-// kz_device.hip
+// kz_render.hip
 void kz_device_init(KzScene *scene);          // empty replica set
 void kz_device_release(KzScene *scene);

@@ -1,0 +1,123 @@
+// kz_state.h - what the translation units of the device library share (not part of the ABI): the path-state arrays of the wavefront pipeline,
+// the per-pass contexts, the per-device replica state, error / allocation helpers, and the few host functions that cross a unit boundary.
+//   kz_render.hip   replicas + upload, pass schedule (renderOn / wfPass), every path kernel (kz_wavefront.h, the megakernel), kz_render*, stats
+//   kz_film.hip     film reconstruction kernels + their launcher, tile packing / download, kz_film_* entry points
+//   kz_multi.cpp    tile dealing, host merge of tile rects, kz_render_multi (host code only)
+//   kz_debug.hip    function-level query kernels and known-answer entry points of include/kazen_mi355x_dev.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kz_internal.h"
+
+#include <mutex>
+#include <vector>
+
+// Path state in HBM: one array per field (SoA; 16-B records, coalesced for the stages that sweep all slots). -DKZ_STATE_AOS=1 builds the
+// alternative that round 3 measured and rejected (profiles/r03h_state_layout): one 64-B line per path for (ray origin | direction | hit |
+// throughput) and one for (shadow origin | direction | pending radiance | misc). It was meant to cut the lines fetched per path once the
+// queues hold a thinning, scattered subset of the slots; shade did not move (19.3 -> 19.4 ms: it is not bound by the bytes of these
+// arrays) and the stages that sweep every slot lost (generate 1.5 -> 4.0 ms, camera rays 5.8 -> 6.9): C4 1533-1562 -> 1464-1470 Msamples/s.
+#ifndef KZ_STATE_AOS
+#define KZ_STATE_AOS 0
+#endif
+template <class Tp> struct KzField {
+    Tp *p;
+    __device__ __forceinline__ Tp &operator[](uint32_t i) const { return p[KZ_STATE_AOS ? (size_t)i * 4u : (size_t)i]; }
+};
+struct KzWf {
+    KzField<float4> rayA, rayB;    // o.xyz tmin | d.xyz tmax
+    KzField<float4> hit;           // t u v gid(bits) - the shading record of the triangle; t = +inf: miss
+    KzField<float4> thr;           // throughput.xyz eta (compact state, see kz_wf_shade: throughput.xyz bsdfPdf)
+    KzField<float4> misc;          // bsdfPdf accumulatedRoughness discrete(EDiscrete) -
+    uint4 *smp;                    // pcg32 state (.x,.y) + dimension index (.z); the pcg32 stream id is recomputed from the pixel
+    KzField<float4> shA, shB, shL; // shadow (or walk-through) ray o.xyz tmax | d.xyz tmin | pending radiance
+    uint32_t *queue[3];            // two ping-pong path queues + the shadow queue
+    uint32_t *counts;              // [stage][4] zeroed per pass
+    float *outJx, *outJy, *outR, *outG, *outB;
+    unsigned long long *stats;
+};
+
+struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, packet, filmGather, shadeSplit;
+                int wide, keyStack, ldsTop, leafQueue, legacyTrace, mixed;      // kz_experiments.h only
+                uint32_t *ovf; uint32_t ovfStride; };
+
+
+#ifndef KZ_BEAM_CAP
+#define KZ_BEAM_CAP 32                // leaves per pixel list (16 / 24 / 48 measured in r03o: 32 stays)
+#endif
+
+struct KzTileRect { int32_t x0, y0, w, h; uint32_t offset; uint32_t prevStart, prevCount; };
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return kz_fail(KZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// Every device allocation of the library goes through here (kz_debug_fail_alloc can make the nth one fail).
+hipError_t kzMalloc(void **p, size_t bytes);          // kz_render.hip
+#define KZ_ALLOC(pp, bytes) do { hipError_t e_ = kzMalloc((void **)(pp), (bytes)); if (e_ != hipSuccess) \
+    return kz_fail(e_ == hipErrorOutOfMemory ? KZ_ERR_OOM : KZ_ERR_HIP, "device allocation of %zu bytes failed: %s", (size_t)(bytes), hipGetErrorString(e_)); } while (0)
+// A device buffer that is released on every way out of the call that made it.
+struct DevMem {
+    void *p = nullptr;
+    DevMem() = default;
+    DevMem(const DevMem &) = delete; DevMem &operator=(const DevMem &) = delete;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    template <class Tp> Tp *as() const { return (Tp *)p; }
+};
+
+struct EventPair { hipEvent_t a, b; };
+// path state + sample records + stage events of one pass in flight
+struct PassCtx {
+    KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0;
+    float *samp = nullptr; size_t sampCap = 0;                   // five SoA planes: jx | jy | r | g | b
+    float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: taps^2 float4 per pixel of the tile set
+    uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
+    uint32_t *ovf = nullptr; size_t ovfCap = 0;
+    uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0;      // kz_wf_beam: leaf lists of the pixels of a chunk ...
+    uint64_t beamGen = 0; uint32_t beamP0 = 0, beamN = 0;                                  // ... and the chunk (tile-set generation, first pixel, pixels) they were built for
+    uint64_t sharedSeen = 0;                                                              // the generation of the replica's shared lists this context's stream has waited for
+    std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
+    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4 + beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); }
+    void release() {
+        for (void *p : wfAllocs) (void)hipFree(p);
+        wfAllocs.clear(); wfCap = 0; wf = KzWf{};
+        if (samp) (void)hipFree(samp); samp = nullptr; sampCap = 0;
+        if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
+        if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
+        if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
+        if (beamEntries) (void)hipFree(beamEntries); beamEntries = nullptr; if (beamCount) (void)hipFree(beamCount); beamCount = nullptr; beamCap = 0; beamGen = 0;
+    }
+};
+struct KzDeviceState {
+    int device = -1;
+    KzDevTables T{};
+    std::vector<void *> allocs;
+    float4 *film = nullptr; size_t filmPixels = 0;
+    uint8_t *srgb = nullptr;                                     // staging raster of kz_film_to_srgb8 (allocated on first use)
+    float4 *packDev = nullptr; size_t packCap = 0; KzTileRect *rectsDev = nullptr; size_t rectsCap = 0; uint32_t *prevDev = nullptr; size_t prevCap = 0;      // kz_film_download_tiles: packed tile rects + their tables
+    float4 *packHost = nullptr; size_t packHostCap = 0;           // pinned staging of the same (D2H at link rate)
+    uint32_t *pixList = nullptr; int32_t *pixIndex = nullptr; size_t pixCap = 0; uint32_t nPix = 0;
+    std::vector<KzTile> curTiles; bool tilesValid = false; uint64_t tileGen = 0;      // tileGen: bumped whenever the pixel list changes
+    unsigned long long *stats = nullptr; bool statsOn = false;
+    hipStream_t lastStream = nullptr;
+    int numCU = 256; size_t totalMem = 0;
+    PassCtx ctx[KZ_MAX_PASSES_IN_FLIGHT];
+    std::vector<EventPair> events; size_t eventsUsed = 0;
+    hipStream_t passStream[KZ_MAX_PASSES_IN_FLIGHT] = {}; hipEvent_t evFork = nullptr, evFilm[KZ_MAX_PASSES_IN_FLIGHT] = {}, evCallA = nullptr, evCallB = nullptr;
+    int lastCtx = 0; bool lastDual = false; int streamMode = 0;
+    // beam lists of the WHOLE pixel set (the default pass shape: every pass covers every pixel), shared by the contexts: built once per tile set on the
+    // stream of the pass that needs them first, the other contexts wait for evBeam once
+    uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0; uint64_t beamGen = 0; hipEvent_t evBeam = nullptr;
+    size_t ctxBytes() const { size_t b = beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); for (const PassCtx &c : ctx) b += c.bytes(); return b; }
+    KzPassInfo lastInfo{};
+};
+struct KzReplicaSet { std::mutex m; std::vector<KzDeviceState *> v; };
+
+static inline KzReplicaSet *replicaSet(const KzScene *scene) { return (KzReplicaSet *)scene->dev; }
+int findReplica(const KzScene *scene, int device, KzDeviceState **out);                                   // kz_render.hip
+static inline int requireDevice(KzScene *scene, KzDeviceState **out) { return findReplica(scene, -1, out); }
+// kz_film.hip
+size_t packedFloats(const KzParams &P, const KzTile *tiles, uint32_t nTiles);
+int checkTiles(const KzParams &P, const KzTile *tiles, uint32_t nTiles);
+int downloadTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, uint32_t nTiles, float *packed, size_t nFloats, hipStream_t stream);
+int kzFilmInit();
+// The film stage of one pass (ImageBlock::put for every sample record of the pass): launches on `pst`; `waitFilm` (or null) is the event the film's read-modify-write waits for.
+int kzFilmStage(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t pst, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t Sp, bool tapSums, hipEvent_t waitFilm);
+#define KZ_TAPS_MAX 5                        // gaussian / mitchell radius 2: taps -2..2

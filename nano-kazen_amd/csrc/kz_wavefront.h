@@ -20,37 +20,13 @@
 // The arithmetic per path and the order of its radiance additions are those of the megakernel, so both pipelines
 // produce bit-identical sample records.
 #pragma once
+#include "kz_state.h"
 #include "kz_devfn.h"
 
 #ifndef KZ_WF_QCAP
 #define KZ_WF_QCAP 960             // LDS staging entries per output queue per workgroup (960: four shade workgroups fit the CU's 160 KB)
 #endif
 #define KZ_WF_ROUNDS (KZ_WF_QCAP / KZ_BLOCK)   // rounds of one entry per thread the staging buffer takes
-
-// Path state in HBM: one array per field (SoA; 16-B records, coalesced for the stages that sweep all slots). -DKZ_STATE_AOS=1 builds the
-// alternative that round 3 measured and rejected (profiles/r03h_state_layout): one 64-B line per path for (ray origin | direction | hit |
-// throughput) and one for (shadow origin | direction | pending radiance | misc). It was meant to cut the lines fetched per path once the
-// queues hold a thinning, scattered subset of the slots; shade did not move (19.3 -> 19.4 ms: it is not bound by the bytes of these
-// arrays) and the stages that sweep every slot lost (generate 1.5 -> 4.0 ms, camera rays 5.8 -> 6.9): C4 1533-1562 -> 1464-1470 Msamples/s.
-#ifndef KZ_STATE_AOS
-#define KZ_STATE_AOS 0
-#endif
-template <class Tp> struct KzField {
-    Tp *p;
-    __device__ __forceinline__ Tp &operator[](uint32_t i) const { return p[KZ_STATE_AOS ? (size_t)i * 4u : (size_t)i]; }
-};
-struct KzWf {
-    KzField<float4> rayA, rayB;    // o.xyz tmin | d.xyz tmax
-    KzField<float4> hit;           // t u v gid(bits) - the shading record of the triangle; t = +inf: miss
-    KzField<float4> thr;           // throughput.xyz eta (compact state, see kz_wf_shade: throughput.xyz bsdfPdf)
-    KzField<float4> misc;          // bsdfPdf accumulatedRoughness discrete(EDiscrete) -
-    uint4 *smp;                    // pcg32 state (.x,.y) + dimension index (.z); the pcg32 stream id is recomputed from the pixel
-    KzField<float4> shA, shB, shL; // shadow (or walk-through) ray o.xyz tmax | d.xyz tmin | pending radiance
-    uint32_t *queue[3];            // two ping-pong path queues + the shadow queue
-    uint32_t *counts;              // [stage][4] zeroed per pass
-    float *outJx, *outJy, *outR, *outG, *outB;
-    unsigned long long *stats;
-};
 
 // ---- workgroup-level compaction: append `val` for lanes with pred into an LDS buffer, flush to the global queue ----
 struct WfAppender {
@@ -587,10 +563,6 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
 // instantiation: 57 VGPRs and no spills instead of 64 with 9 spilled.
 // Shadow test (exact, see kz_devfn.h shadowOccluded): any-hit unless an invisible-light triangle lies on the segment.
 // (The BVH2 form, the per-lane key stack, the LDS top-of-tree and the mixed launches of round 2 live in kz_experiments.h.)
-struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, ldsStack, packet, filmGather, shadeSplit;
-                int wide, keyStack, ldsTop, leafQueue, legacyTrace, mixed;      // kz_experiments.h only
-                uint32_t *ovf; uint32_t ovfStride; };
-
 #ifndef KZ_TRACE_WAVES
 #define KZ_TRACE_WAVES 8            // waves per SIMD the per-lane traversal is compiled for (64 VGPRs); 7 = 72 VGPRs measured in r02i
 #endif
@@ -1025,9 +997,6 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 //                     to kz_wf_trace / kz_wf_trace_packet. The other rays go to fbQueue for the packet kernel with what is known about them
 //                     (nothing in front of t_valid: tmin; the hit found so far: tmax).
 // The lists depend on the pixels only: a pass context keeps them for the pixel chunk it last built them for.
-#ifndef KZ_BEAM_CAP
-#define KZ_BEAM_CAP 32                // leaves per pixel list (16 / 24 / 48 measured in r03o: 32 stays)
-#endif
 #define KZ_BEAM_STACK 32              // open entries (ref + key) per beam in LDS
 __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T, const uint32_t *__restrict__ pixList, uint32_t nPix, int LS,
                                                        uint2 *__restrict__ entries, uint2 *__restrict__ heads) {

@@ -5,12 +5,4 @@
 set -e
 NAME=$1; shift
 SRC="$(cd "$(dirname "$0")/../nano-kazen_amd/csrc" && pwd)"
-OUT=$SRC/variants/$NAME
-mkdir -p $OUT
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
-hipcc $FLAGS --offload-arch=gfx950 -fgpu-flush-denormals-to-zero -fno-slp-vectorize "$@" -c $SRC/kz_device.hip -o $OUT/kz_device.o
-hipcc $FLAGS "$@" -c $SRC/kz_host.cpp -o $OUT/kz_host.o
-hipcc $FLAGS "$@" -c $SRC/kz_bvh.cpp -o $OUT/kz_bvh.o
-hipcc -shared -fPIC -o $OUT/libkazen_mi355x.so $OUT/kz_device.o $OUT/kz_host.o $OUT/kz_bvh.o -pthread
-rm -f $OUT/*.o
-echo "built $OUT/libkazen_mi355x.so"
+KZ_EXTRA_HIPFLAGS="$*" sh "$SRC/build.sh" "$SRC/variants/$NAME"

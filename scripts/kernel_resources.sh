@@ -1,7 +1,7 @@
 #!/bin/sh
 # VGPRs / SGPRs / spills / scratch / LDS / occupancy of every kernel of the product library (hipcc -Rpass-analysis=kernel-resource-usage).
 cd "$(dirname "$0")/../nano-kazen_amd/csrc"
-hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fgpu-flush-denormals-to-zero -fno-slp-vectorize ${KZ_EXTRA_HIPFLAGS} -Rpass-analysis=kernel-resource-usage -c kz_device.hip -o /tmp/kz_res.o 2>&1 |
+for u in kz_render kz_film kz_debug; do hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fgpu-flush-denormals-to-zero -fno-slp-vectorize ${KZ_EXTRA_HIPFLAGS} -Rpass-analysis=kernel-resource-usage -c $u.hip -o /tmp/kz_res_$u.o 2>&1; done |
 python3 -c '
 import re, sys, subprocess
 cur = None; rows = {}
