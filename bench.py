@@ -53,8 +53,13 @@ def algorithmic_bytes_per_sample(st):
 
 
 def git_head():
+    """The commit of the sources: git where there is a repository, else the VERSION file __graft_entry__.build() wrote beside the library (the GPU box has no .git)."""
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "VERSION")).read().strip() or None
     except Exception:
         return None
 
@@ -65,7 +70,7 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.hip")) +
-                    glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "nano-kazen_amd", "csrc", "build.sh"), os.path.join(ROOT, "include", "kazen_mi355x.h")]):
+                    glob.glob(os.path.join(ROOT, "nano-kazen_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "nano-kazen_amd", "csrc", "build.sh"), os.path.join(ROOT, "include", "kazen_mi355x.h"), os.path.join(ROOT, "include", "kazen_mi355x_dev.h")]):
         h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 4
+#define KZ_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -239,9 +239,8 @@ typedef struct KzTile { int32_t x0, y0, w, h; } KzTile;
 
 /* Knobs of the persistent kernels. Zero = the library default, which is what the measured numbers use. They are part
  * of the ABI so that nothing behind it depends on process-global state: the library reads no environment variable.
- * Fields marked [experiment] select a kernel of a rejected experiment (nano-kazen_amd/csrc/kz_experiments.h); only a library built
- * with -DKZ_EXPERIMENTS (kz_build_flags() & KZ_BUILD_EXPERIMENTS) contains those kernels, the default library answers a non-zero
- * value with KZ_ERR_UNSUPPORTED. */
+ * The dev* words keep the ABI v4 layout: they select kernels of rejected experiments in development builds of the library
+ * (named in kazen_mi355x_dev.h); the product library answers a non-zero value with KZ_ERR_UNSUPPORTED. Leave them 0. */
 typedef struct KzTuning {
     int32_t refill;             /* a wave refills idle lanes once fewer than this many are busy (default 40; shadow rays 32) */
     int32_t postpone;           /* node phase goes on while at least this many lanes hold inner nodes (default 24)  */
@@ -249,23 +248,35 @@ typedef struct KzTuning {
     int32_t traceBlocksPerCU;   /* 256-thread workgroups per CU of the traversal kernels (default 8)                 */
     int32_t shadeBlocksPerCU;   /* same for the shade kernel (default 4; 6 with extended BSDFs)                       */
     int32_t ldsStack;           /* per-lane traversal stack entries kept in LDS before the global overflow (default 16) */
-    int32_t bvh2;               /* [experiment] 1 = per-lane traversal of the BVH2 instead of the quantised BVH4       */
-    int32_t packetPrimary;      /* primary rays: 0 = default (shared-stack packet traversal), 1 = per-lane, 2 = packet */
-    int32_t keyStack;           /* [experiment] 1 = packet kernel without per-lane entry distances, 2 = per-lane kernel with them */
-    int32_t ldsTop;             /* [experiment] n = that many BVH4 packets of the top of the tree staged in LDS (<= 1536) */
+    int32_t dev0;
+    int32_t packetPrimary;      /* primary rays: 0 = default (pixel beams, else shared-stack packet traversal), 1 = per-lane, 2 = packet */
+    int32_t dev1, dev2;
     int32_t filmGather;         /* film reconstruction: 0 = default (per-pixel tap sums + apply for filters of <= 5 taps per axis, the staged
                                    gather otherwise), 1 = always the staged gather kernel of round 1 */
-    int32_t leafQueue;          /* [experiment] 2 = bounce / shadow traversal with a decoupled leaf phase (kz_wf_trace_dq) */
+    int32_t dev3;
     int32_t sppPerPass;         /* samples of a pixel per pass: 0 = default. A pass covers pixPerPass x sppPerPass = passItems (pixel, sample)
                                    items: sppPerPass = 0 means "every pixel of the tile set, as many samples as fit" - unless fewer than 64 would
                                    fit and the call asks for at least 64: then 256 samples (or all, if fewer) of pixel chunks; above 64 the count is
                                    rounded down to a multiple of 64 when that costs no extra pass; n > 0 means n samples
                                    (or all the call asks for, if fewer) of as many pixels as fit, pixel chunks in tile order           */
-    int32_t legacyTrace;        /* [experiment] 1 = the non-persistent round-1 traversal launches (kz_wf_extend / kz_wf_shadow) */
-    int32_t mixedLaunch;        /* [experiment] 1 = one launch for the shadow rays of a bounce and the closest-hit rays of the next */
+    int32_t dev4, dev5;
     int32_t streamPriority;     /* HIP priorities of the internal pass streams: 0 = default, 1 = all at the default priority, 2 = alternating
                                    least / greatest, 3 = cycling least / default / greatest */
 } KzTuning;
+
+/* Dynamic dealing of ONE tile list over several takers - devices of a process (kz_render_multi) or processes of a node (the counter then lives in
+ * memory they share) - the reference's BlockGenerator::next (block.cpp:117-148) with an atomic counter instead of a mutex. Every taker calls
+ * kz_render_tiles with the SAME list and a dealer pointing at the same counter: the call prepares the whole list as its tile set once, then renders
+ * the batches [b, b + batchTiles) it wins from the counter, keeping its passes in flight across batch boundaries, until the list is dealt. The batches
+ * it took come back in `taken` (pairs begin, end of tile indices), which is what the taker hands to kz_film_download_tiles afterwards. */
+typedef struct KzTileDealer {
+    volatile uint32_t *counter; /* index of the next undealt tile; zero it before the first taker starts */
+    uint32_t batchTiles;        /* tiles per batch; 0 = about two passes' worth of (pixel, sample) items, at most 1/(4 x takers) of the list */
+    uint32_t takers;            /* how many takers share the counter (only used for the default batch size; 0 = 1) */
+    uint32_t *taken;            /* out: begin0, end0, begin1, end1, ... */
+    uint32_t takenCap;          /* capacity of `taken` in uint32 (2 per batch): a call stops taking batches when it is full */
+    uint32_t *nTaken;           /* out: uint32 written to `taken` */
+} KzTileDealer;
 
 typedef struct KzRenderOpts {
     uint32_t sampleBegin;       /* render sample indices [sampleBegin, sampleEnd) of every pixel;       */
@@ -282,39 +293,16 @@ typedef struct KzRenderOpts {
     uint64_t maxStateBytes;     /* cap on this replica's path state + sample records + film tap sums; 0 = min(3/4 of the device's
                                    memory, what is free + what the replica already holds for this purpose)       */
     KzTuning tune;
-    int32_t tileDealing;        /* kz_render_multi: 0 = static (kz_deal_tiles: by area), 1 = dynamic (the host threads pull batches of tiles from a
-                                   shared counter, the reference's BlockGenerator; the same paths and the same film up to the grouping of the float additions where the
-                                   shares of two devices or two batches meet, H10 - static dealing is bit-reproducible) */
-    int32_t reserved;
+    int32_t tileDealing;        /* kz_render_multi: 0 = static (kz_deal_tiles: by area), 1 = dynamic (the devices take batches of tiles from a shared counter,
+                                   the reference's BlockGenerator; the same paths and the same film up to the grouping of the float additions where the
+                                   shares of two devices or two batches meet, H10 - only static dealing is bit-reproducible from run to run) */
+    int32_t packedOutput;       /* kz_render_tiles with a host buffer: 0 = the buffer receives the WHOLE film, 1 = the packed rects of the call's tiles
+                                   (kz_tiles_packed_floats). Never inferred from the buffer's size. */
+    /* ---- ABI v5 ---- */
+    const struct KzTileDealer *dealer;   /* kz_render_tiles: NULL = render every tile of the list; else take batches of it from the dealer's counter */
 } KzRenderOpts;
 #define KZ_MAX_PASSES_IN_FLIGHT 8
 #define KZ_DEFAULT_PASSES_IN_FLIGHT 2
-
-/* Counters the kernels keep (all optional; zero unless requested with kz_set_stats). */
-typedef struct KzStats {
-    uint64_t samples;           /* (pixel,sample) pairs rendered                        */
-    uint64_t rays;              /* closest-hit queries (Accel::rayIntersect calls)      */
-    uint64_t nodeVisits;        /* 64-B BVH2 node packets fetched                       */
-    uint64_t triTests;          /* 48-B leaf triangles tested (Moeller-Trumbore)        */
-    uint64_t shadedHits;        /* post-intersection gathers (accel.cpp:113-236)        */
-    uint64_t lightSamples;      /* Mesh::sample calls (mesh.cpp:108-133)                */
-    uint64_t droppedSamples;    /* invalid radiance dropped by ImageBlock::put (block.cpp:57-61) */
-    uint64_t beamPixels;        /* pixels whose camera rays were given a leaf list by the beam kernel, once per pixel chunk */
-    uint64_t beamListEntries;   /* leaves on those lists                                  */
-    uint64_t beamCompletePixels;/* pixels whose list holds every leaf the beam reaches (the other lists end at a distance t_valid) */
-} KzStats;
-
-/* Ray-level record mirroring what Accel::rayIntersect fills (accel.cpp:99-110 + 113-236). */
-typedef struct KzHit {
-    float t;                    /* +inf on miss                                          */
-    float u, v;                 /* prim barycentrics, P=(1-u-v)p0+u p1+v p2 (accel.cpp:122-123) */
-    int32_t mesh;               /* geomID, -1 on miss                                    */
-    int32_t prim;               /* primID within the mesh                                */
-    float p[3];                 /* its.p after the terminator offset                     */
-    float uv[2];                /* its.uv                                                */
-    float sh_s[3], sh_t[3], sh_n[3];  /* its.shFrame                                     */
-    float geo_n[3];             /* its.geoFrame.n                                        */
-} KzHit;
 
 typedef struct KzScene KzScene;
 
@@ -326,12 +314,6 @@ typedef struct KzScene KzScene;
 int kz_scene_create(const KzSceneDesc *desc, KzScene **out);
 void kz_scene_destroy(KzScene *scene);
 
-/* Host BVH statistics (node count, leaf count, max depth, SAH cost) for reports. */
-typedef struct KzBvhInfo { uint32_t nNodes, nLeaves, nTris, maxDepth, maxLeafSize; float sahCost; double buildSeconds; } KzBvhInfo;
-int kz_scene_bvh_info(const KzScene *scene, KzBvhInfo *out);
-/* Sampler::getSampleCount() after the constructor's rounding (sampler.cpp:87-92, :181-187, :284-287). */
-int kz_scene_sample_count(const KzScene *scene, uint32_t *out);
-
 /* Upload node/triangle/attribute/material/light/sampler tables to the HBM of `device` and allocate that device's film.
  * One KzScene (one host BVH build) can be resident on any number of devices: every call ADDS a replica (a second call for
  * the same device is a no-op). Calls that take no device argument address the PRIMARY replica, the one uploaded first.
@@ -340,9 +322,6 @@ int kz_scene_upload(KzScene *scene, int device);
 /* Release the replica on `device` (-1: every replica). Must not run concurrently with any other call on that replica (the per-(scene, device)
  * re-entrancy covers rendering and downloading, not tearing a replica down under them); the same holds for kz_scene_destroy. */
 int kz_scene_evict(KzScene *scene, int device);
-/* The devices the scene is resident on, primary first. */
-int kz_scene_devices(const KzScene *scene, int32_t *devices, uint32_t cap, uint32_t *count);
-
 /* The replacement for renderer.cpp:85-133: accumulate samples into the DEVICE film of replica opts->device
  * ((h+2b) x (w+2b) float4 = rgb*w, w; ImageBlock convention, block.cpp:30,56-85).
  * Asynchronous on opts->stream. Re-entrant per (scene, device): one host thread per GPU may call it concurrently. */
@@ -383,16 +362,9 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
  * entries) and its size to *count; returns KZ_ERR_INVALID_ARG if cap is too small (count is still set). */
 int kz_deal_tiles(int32_t width, int32_t height, int32_t tileSize, uint32_t nParts, uint32_t part, KzTile *out, uint32_t cap, uint32_t *count);
 
-/* ImageBlock::put(ImageBlock&) on the host (block.cpp:87-96): dst += src, element by element, in index order. */
-int kz_film_merge(float *dst, const float *src, size_t nFloats);
-
 /* Blocking copy of the device film to the host: film = (h+2b)*(w+2b)*4 floats. */
 int kz_film_download(KzScene *scene, float *film, size_t nFloats);
 int kz_film_clear(KzScene *scene, void *stream);
-/* The same for the replica on `device`. */
-int kz_film_download_on(KzScene *scene, int device, float *film, size_t nFloats);
-int kz_film_clear_on(KzScene *scene, int device, void *stream);
-/* Film geometry: border = ceil(radius-0.5) (block.cpp:14). */
 int kz_film_dims(const KzScene *scene, int32_t *width, int32_t *height, int32_t *border);
 /* ImageBlock::toBitmap (block.cpp:39-45): rgb = film.rgb / film.w (0 when w == 0). */
 int kz_film_to_rgb(const float *film, int32_t width, int32_t height, int32_t border, float *rgb);
@@ -402,72 +374,17 @@ int kz_film_to_rgb(const float *film, int32_t width, int32_t height, int32_t bor
  * reference hands to its PNG writer. */
 int kz_film_to_srgb8(KzScene *scene, uint8_t *rgb8, size_t nBytes);
 
-/* Ray-level entry mirroring Accel::rayIntersect(ray, its, shadowRay=false) for n rays
- * (host arrays; o,d = n x 3 floats). For parity tests of traversal + post-intersection. */
-int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d,
-                  const float *tmin, const float *tmax, KzHit *hits);
-
-/* Debug / known-answer entry points (used by the parity tests, not by a renderer):
- * kz_render_samples: radiance of explicit (pixel, sample index) pairs = renderSample (renderer.cpp:20-40) without
- * the block.put; pxy = n x (x,y), out = n x (pixelSample.x, pixelSample.y, r, g, b).
- * kz_bsdf_query: BSDF::eval / pdf / sample (bsdf.h:80-108) of row bsdf[i] for local directions wi/wo (n x 3), with
- * its.accumulatedRoughness accRough[i] and the (sample1, sample2.x, sample2.y) triple s3; evalOut n x 3,
- * pdfOut n, sampleOut n x 7 = (weight rgb, sampled wo xyz, alive). uv (n x 2, may be NULL = 0) feeds the texture-backed
- * parameters; the intersection record is the identity frame with dpdu = +x (what a normalmap row perturbs). */
-int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint32_t *idx, float *out);
-int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *wi, const float *wo, const float *accRough,
-                  const float *s3, const float *uv, float *evalOut, float *pdfOut, float *sampleOut);
-/* Texture<Color3f>::eval(uv) (texture.h) of textures[tex[i]] at uv (n x 2); out n x 3. */
-int kz_texture_query(KzScene *scene, uint32_t n, const int32_t *tex, const float *uv, float *out);
-
-/* Camera::sampleRay (camera.cpp:70-91 perspective, 191-223 thinlens) of the scene's camera for n pixel-sample positions
- * sxy (n x 2, pixel units) and aperture samples axy (n x 2, NULL = 0.5,0.5); out n x 8 = o xyz, d xyz, mint, maxt. */
-int kz_camera_rays(KzScene *scene, uint32_t n, const float *sxy, const float *axy, float *out);
-/* AreaLight::sample (light.cpp:16-34) via Mesh::sample (mesh.cpp:108-133) of light light[i] (index in Scene::m_lights
- * order) seen from ref (n x 3) with Mesh::sample's three next1D draws u3 (n x 3); out n x 14 = p xyz, n xyz, wi xyz,
- * pdf (solid angle, light.cpp:36-51), eval/pdf rgb (0 where the pdf is 0, nan or inf), triangle index. */
-int kz_light_query(KzScene *scene, uint32_t n, const int32_t *light, const float *ref, const float *u3, float *out);
-
-/* Statistics: enable=1 switches to the counting kernel variant (slower). */
-int kz_set_stats(KzScene *scene, int enable);
-int kz_get_stats(KzScene *scene, KzStats *out, int reset);
-
-/* Wait for everything queued on the primary replica's / that replica's launch stream. */
+/* Wait for everything queued on the primary replica's launch stream. */
 int kz_sync(KzScene *scene);
-int kz_sync_on(KzScene *scene, int device);
 
-/* Average device time of the dominant kernel(s) of the last kz_render, in ms,
- * from hipEvents recorded on the launch stream (0 if none). */
-int kz_last_kernel_ms(KzScene *scene, float *ms);
-/* Device time per stage of the last pass (wavefront pipeline): out6 = generate, closest-hit traversal of the bounce rays, shade, shadow
- * traversal, film, camera rays (beam lists / list kernel / packet kernel / first-hit walk-through) - the per-kernel sums a
- * rocprofv3 --kernel-trace of the same run shows. */
-int kz_last_stage_ms(KzScene *scene, float *out6);
-
-/* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass, passes in flight. */
-typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes;
-                            uint32_t pixelsPerPass; uint32_t reserved; } KzPassInfo;
-int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
-
-/* Test hook: the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off). Used by
- * the error-path tests to show that a failure in the middle of a call releases what the call had allocated. */
-void kz_debug_fail_alloc(int nth);
-
+/* Message of the last failing call of the calling thread (no exception crosses the ABI: int status + this string). */
 const char *kz_last_error(void);
 int kz_abi_version(void);
-/* How the library was built: bit 0 (KZ_BUILD_EXPERIMENTS) = it contains the kernels of kz_experiments.h. */
-#define KZ_BUILD_EXPERIMENTS 1
-int kz_build_flags(void);
+/* HIP devices visible to the process (0 without a GPU: kz_scene_upload then fails with KZ_ERR_NO_DEVICE - there is no CPU path). */
 int kz_device_count(void);
-/* hipMemGetInfo of `device` (what the default state budget of kz_render is derived from). */
-int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes);
-/* Self-check of the library's exact reciprocal / square root (hardware v_rcp_f32 / v_rsq_f32 + Newton steps, used by the triangle test,
- * the ray set-up and the BSDFs in place of the compiler's IEEE division / sqrt sequences): runs BOTH on every one of the 2^32 float
- * bit patterns on the device and counts the inputs whose results differ in any bit (two NaNs count as equal). Both counts must be 0. */
-int kz_debug_exact_math_check(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked);
-/* out[k] = random::permute(i[k], l[k], p[k]) (src/kazen/common.cpp:316-344) as the sampler kernels compute it: checked against vectors minted from
- * the reference's own text (oracle/kat_ref_permute.cpp -> tests/golden/int_kats.json). */
-int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out);
+
+/* Everything else the library exports - per-replica forms of the calls above, counters and timings, the function-level query kernels and
+ * known-answer checks the parity tests use, the names of the development tuning words - is declared in kazen_mi355x_dev.h. */
 
 #ifdef __cplusplus
 }

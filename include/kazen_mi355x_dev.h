@@ -1,0 +1,129 @@
+/* kazen_mi355x_dev.h - the development and test surface of libkazen_mi355x.so. A renderer that adopts the library needs
+ * kazen_mi355x.h only (its twenty entry points); this header adds what the parity tests, the benchmarks and the profiling
+ * scripts use: per-replica forms of the product calls, counters and stage timings, function-level query kernels (the very
+ * device functions the path kernels call, on caller-supplied inputs), known-answer self-checks, a failure-injection hook,
+ * and the names of the KzTuning words that select kernels of rejected experiments in -DKZ_EXPERIMENTS builds. */
+#ifndef KAZEN_MI355X_DEV_H
+#define KAZEN_MI355X_DEV_H
+#include "kazen_mi355x.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* KzTuning.dev*: honoured only by a library built with -DKZ_EXPERIMENTS (kz_build_flags() & KZ_BUILD_EXPERIMENTS); the product
+ * library answers a non-zero value with KZ_ERR_UNSUPPORTED (nano-kazen_amd/csrc/kz_experiments.h holds the kernels). */
+#define KZ_TUNE_BVH2         dev0   /* 1 = per-lane traversal of the BVH2 instead of the quantised BVH4 */
+#define KZ_TUNE_KEY_STACK    dev1   /* 1 = packet kernel without per-lane entry distances, 2 = per-lane kernel with them */
+#define KZ_TUNE_LDS_TOP      dev2   /* n = that many BVH4 packets of the top of the tree staged in LDS (<= 1536) */
+#define KZ_TUNE_LEAF_QUEUE   dev3   /* 2 = bounce / shadow traversal with a decoupled leaf phase (kz_wf_trace_dq) */
+#define KZ_TUNE_LEGACY_TRACE dev4   /* 1 = the non-persistent round-1 traversal launches (kz_wf_extend / kz_wf_shadow) */
+#define KZ_TUNE_MIXED_LAUNCH dev5   /* 1 = one launch for the shadow rays of a bounce and the closest-hit rays of the next */
+
+/* Counters the kernels keep (all optional; zero unless requested with kz_set_stats). */
+typedef struct KzStats {
+    uint64_t samples;           /* (pixel,sample) pairs rendered                        */
+    uint64_t rays;              /* closest-hit queries (Accel::rayIntersect calls)      */
+    uint64_t nodeVisits;        /* 64-B BVH2 node packets fetched                       */
+    uint64_t triTests;          /* 48-B leaf triangles tested (Moeller-Trumbore)        */
+    uint64_t shadedHits;        /* post-intersection gathers (accel.cpp:113-236)        */
+    uint64_t lightSamples;      /* Mesh::sample calls (mesh.cpp:108-133)                */
+    uint64_t droppedSamples;    /* invalid radiance dropped by ImageBlock::put (block.cpp:57-61) */
+    uint64_t beamPixels;        /* pixels whose camera rays were given a leaf list by the beam kernel, once per pixel chunk */
+    uint64_t beamListEntries;   /* leaves on those lists                                  */
+    uint64_t beamCompletePixels;/* pixels whose list holds every leaf the beam reaches (the other lists end at a distance t_valid) */
+} KzStats;
+
+/* Ray-level record mirroring what Accel::rayIntersect fills (accel.cpp:99-110 + 113-236). */
+typedef struct KzHit {
+    float t;                    /* +inf on miss                                          */
+    float u, v;                 /* prim barycentrics, P=(1-u-v)p0+u p1+v p2 (accel.cpp:122-123) */
+    int32_t mesh;               /* geomID, -1 on miss                                    */
+    int32_t prim;               /* primID within the mesh                                */
+    float p[3];                 /* its.p after the terminator offset                     */
+    float uv[2];                /* its.uv                                                */
+    float sh_s[3], sh_t[3], sh_n[3];  /* its.shFrame                                     */
+    float geo_n[3];             /* its.geoFrame.n                                        */
+} KzHit;
+
+/* Host BVH statistics (node count, leaf count, max depth, SAH cost) for reports. */
+typedef struct KzBvhInfo { uint32_t nNodes, nLeaves, nTris, maxDepth, maxLeafSize; float sahCost; double buildSeconds; } KzBvhInfo;
+int kz_scene_bvh_info(const KzScene *scene, KzBvhInfo *out);
+/* Sampler::getSampleCount() after the constructor's rounding (sampler.cpp:87-92, :181-187, :284-287). */
+int kz_scene_sample_count(const KzScene *scene, uint32_t *out);
+
+/* The devices the scene is resident on, primary first. */
+int kz_scene_devices(const KzScene *scene, int32_t *devices, uint32_t cap, uint32_t *count);
+
+/* ImageBlock::put(ImageBlock&) on the host (block.cpp:87-96): dst += src, element by element, in index order. */
+int kz_film_merge(float *dst, const float *src, size_t nFloats);
+
+/* kz_film_download / kz_film_clear / kz_sync for the replica on `device`. */
+int kz_film_download_on(KzScene *scene, int device, float *film, size_t nFloats);
+int kz_film_clear_on(KzScene *scene, int device, void *stream);
+int kz_sync_on(KzScene *scene, int device);
+
+/* Ray-level entry mirroring Accel::rayIntersect(ray, its, shadowRay=false) for n rays
+ * (host arrays; o,d = n x 3 floats). For parity tests of traversal + post-intersection. */
+int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d,
+                  const float *tmin, const float *tmax, KzHit *hits);
+
+/* Debug / known-answer entry points (used by the parity tests, not by a renderer):
+ * kz_render_samples: radiance of explicit (pixel, sample index) pairs = renderSample (renderer.cpp:20-40) without
+ * the block.put; pxy = n x (x,y), out = n x (pixelSample.x, pixelSample.y, r, g, b).
+ * kz_bsdf_query: BSDF::eval / pdf / sample (bsdf.h:80-108) of row bsdf[i] for local directions wi/wo (n x 3), with
+ * its.accumulatedRoughness accRough[i] and the (sample1, sample2.x, sample2.y) triple s3; evalOut n x 3,
+ * pdfOut n, sampleOut n x 7 = (weight rgb, sampled wo xyz, alive). uv (n x 2, may be NULL = 0) feeds the texture-backed
+ * parameters; the intersection record is the identity frame with dpdu = +x (what a normalmap row perturbs). */
+int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint32_t *idx, float *out);
+int kz_bsdf_query(KzScene *scene, uint32_t n, const int32_t *bsdf, const float *wi, const float *wo, const float *accRough,
+                  const float *s3, const float *uv, float *evalOut, float *pdfOut, float *sampleOut);
+/* Texture<Color3f>::eval(uv) (texture.h) of textures[tex[i]] at uv (n x 2); out n x 3. */
+int kz_texture_query(KzScene *scene, uint32_t n, const int32_t *tex, const float *uv, float *out);
+
+/* Camera::sampleRay (camera.cpp:70-91 perspective, 191-223 thinlens) of the scene's camera for n pixel-sample positions
+ * sxy (n x 2, pixel units) and aperture samples axy (n x 2, NULL = 0.5,0.5); out n x 8 = o xyz, d xyz, mint, maxt. */
+int kz_camera_rays(KzScene *scene, uint32_t n, const float *sxy, const float *axy, float *out);
+/* AreaLight::sample (light.cpp:16-34) via Mesh::sample (mesh.cpp:108-133) of light light[i] (index in Scene::m_lights
+ * order) seen from ref (n x 3) with Mesh::sample's three next1D draws u3 (n x 3); out n x 14 = p xyz, n xyz, wi xyz,
+ * pdf (solid angle, light.cpp:36-51), eval/pdf rgb (0 where the pdf is 0, nan or inf), triangle index. */
+int kz_light_query(KzScene *scene, uint32_t n, const int32_t *light, const float *ref, const float *u3, float *out);
+
+/* Statistics: enable=1 switches to the counting kernel variant (slower). */
+int kz_set_stats(KzScene *scene, int enable);
+int kz_get_stats(KzScene *scene, KzStats *out, int reset);
+
+/* Average device time of the dominant kernel(s) of the last kz_render, in ms,
+ * from hipEvents recorded on the launch stream (0 if none). */
+int kz_last_kernel_ms(KzScene *scene, float *ms);
+/* Device time per stage of the last pass (wavefront pipeline): out6 = generate, closest-hit traversal of the bounce rays, shade, shadow
+ * traversal, film, camera rays (beam lists / list kernel / packet kernel / first-hit walk-through) - the per-kernel sums a
+ * rocprofv3 --kernel-trace of the same run shows. */
+int kz_last_stage_ms(KzScene *scene, float *out6);
+
+/* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass, passes in flight. */
+typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes;
+                            uint32_t pixelsPerPass; uint32_t reserved; } KzPassInfo;
+int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
+
+/* Test hook: the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off). Used by
+ * the error-path tests to show that a failure in the middle of a call releases what the call had allocated. */
+void kz_debug_fail_alloc(int nth);
+
+/* How the library was built: bit 0 (KZ_BUILD_EXPERIMENTS) = it contains the kernels of kz_experiments.h. */
+#define KZ_BUILD_EXPERIMENTS 1
+int kz_build_flags(void);
+/* hipMemGetInfo of `device` (what the default state budget of kz_render is derived from). */
+int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes);
+/* Self-check of the library's exact reciprocal / square root (hardware v_rcp_f32 / v_rsq_f32 + Newton steps, used by the triangle test,
+ * the ray set-up and the BSDFs in place of the compiler's IEEE division / sqrt sequences): runs BOTH on every one of the 2^32 float
+ * bit patterns on the device and counts the inputs whose results differ in any bit (two NaNs count as equal). Both counts must be 0. */
+int kz_debug_exact_math_check(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked);
+/* out[k] = random::permute(i[k], l[k], p[k]) (src/kazen/common.cpp:316-344) as the sampler kernels compute it: checked against vectors minted from
+ * the reference's own text (oracle/kat_ref_permute.cpp -> tests/golden/int_kats.json). */
+int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAZEN_MI355X_DEV_H */

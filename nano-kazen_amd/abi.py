@@ -7,7 +7,7 @@ is missing: there is no CPU fallback in the product path.
 import ctypes as C
 import os
 
-KZ_ABI_VERSION = 4
+KZ_ABI_VERSION = 5
 
 KZ_OK, KZ_ERR_INVALID_ARG, KZ_ERR_UNSUPPORTED, KZ_ERR_NO_DEVICE, KZ_ERR_HIP, KZ_ERR_STATE, KZ_ERR_OOM = range(7)
 KZ_BSDF_DIFFUSE, KZ_BSDF_KAZENSTANDARD, KZ_BSDF_MIRROR, KZ_BSDF_DIELECTRIC = 0, 1, 2, 3
@@ -104,11 +104,15 @@ class KzTuning(C.Structure):
                 ("mixedLaunch", C.c_int32), ("streamPriority", C.c_int32)]
 
 
+class KzTileDealer(C.Structure):
+    _fields_ = [("counter", u32p), ("batchTiles", C.c_uint32), ("takers", C.c_uint32), ("taken", u32p), ("takenCap", C.c_uint32), ("nTaken", u32p)]
+
+
 class KzRenderOpts(C.Structure):
     _fields_ = [("sampleBegin", C.c_uint32), ("sampleEnd", C.c_uint32), ("tiles", C.POINTER(KzTile)),
                 ("nTiles", C.c_uint32), ("pipeline", C.c_int32), ("accumulate", C.c_int32), ("stream", C.c_void_p),
                 ("device", C.c_int32), ("passesInFlight", C.c_int32), ("passItems", C.c_uint64), ("maxStateBytes", C.c_uint64),
-                ("tune", KzTuning), ("tileDealing", C.c_int32), ("reserved", C.c_int32)]
+                ("tune", KzTuning), ("tileDealing", C.c_int32), ("packedOutput", C.c_int32), ("dealer", C.POINTER(KzTileDealer))]
 
 
 class KzPassInfo(C.Structure):
@@ -139,7 +143,10 @@ class KzBvhInfo(C.Structure):
                 ("maxLeafSize", C.c_uint32), ("sahCost", C.c_float), ("buildSeconds", C.c_double)]
 
 
-# every symbol include/kazen_mi355x.h declares (checked by tests/test_abi_cpu.py)
+# every symbol include/kazen_mi355x.h (the product surface, PRODUCT_EXPORTS) and include/kazen_mi355x_dev.h declare (checked by tests/test_abi_cpu.py)
+PRODUCT_EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_upload", "kz_scene_evict", "kz_render", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles",
+                   "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb",
+                   "kz_film_to_srgb8", "kz_sync", "kz_last_error", "kz_abi_version", "kz_device_count"]
 EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
            "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",

@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *
 // already carried is written as zero, so that the sum of the packed rects is exactly the film over the union of the rects (each texel
 // once). `prev` lists, per tile, the earlier tiles whose rect overlaps it. One workgroup per (tile, row).
 __global__ __launch_bounds__(128) void kz_film_pack(const float4 *__restrict__ film, int cols, const KzTileRect *__restrict__ rects, const uint32_t *__restrict__ prev,
-                                                    int border, float4 *__restrict__ out) {
-    const KzTileRect r = rects[blockIdx.y];
+                                                    int border, float4 *__restrict__ out, uint32_t nTiles) {
+    const uint32_t tile = blockIdx.y + blockIdx.z * 65535u;             // (a grid's y extent ends at 65535: longer tile lists continue in z)
+    if (tile >= nTiles) return;
+    const KzTileRect r = rects[tile];
     const int rw = r.w + 2 * border, rh = r.h + 2 * border;
     const int row = blockIdx.x;
     if (row >= rh) return;
@@ -372,8 +374,10 @@ int downloadTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, uint32
     HIP_TRY(hipMemcpyAsync(ds->rectsDev, rects.data(), (size_t)nTiles * sizeof(KzTileRect), hipMemcpyHostToDevice, stream));
     if (!prev.empty()) HIP_TRY(hipMemcpyAsync(ds->prevDev, prev.data(), prev.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));                              // (the tables are host vectors of this call)
-    hipLaunchKernelGGL(kz_film_pack, dim3((unsigned)maxRows, nTiles), dim3(128), 0, stream, (const float4 *)ds->film, P.width + 2 * P.border, (const KzTileRect *)ds->rectsDev,
-                       (const uint32_t *)ds->prevDev, P.border, ds->packDev);
+    if (nTiles > 65535u * 65535u) return kz_fail(KZ_ERR_UNSUPPORTED, "kz_film_download_tiles: %u tiles in one call", nTiles);
+    const unsigned gz = (nTiles + 65534u) / 65535u, gy = gz > 1 ? 65535u : nTiles;
+    hipLaunchKernelGGL(kz_film_pack, dim3((unsigned)maxRows, gy, gz), dim3(128), 0, stream, (const float4 *)ds->film, P.width + 2 * P.border, (const KzTileRect *)ds->rectsDev,
+                       (const uint32_t *)ds->prevDev, P.border, ds->packDev, nTiles);
     HIP_TRY(hipGetLastError());
     if (ds->packHost) {
         HIP_TRY(hipMemcpyAsync(ds->packHost, ds->packDev, off * sizeof(float4), hipMemcpyDeviceToHost, stream));

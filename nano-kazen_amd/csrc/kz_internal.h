@@ -1,7 +1,7 @@
 // kz_internal.h — host-side scene object and the flat device tables of the MI355X path-tracing core.
 // Not part of the ABI (that is include/kazen_mi355x.h).
 #pragma once
-#include "../../include/kazen_mi355x.h"
+#include "../../include/kazen_mi355x_dev.h"
 
 #include <cstdint>
 #include <string>

@@ -94,8 +94,9 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
     const size_t filmFloats = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border) * 4;
     if (nFloats != filmFloats) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold %zu floats", filmFloats);
     for (uint32_t i = 0; i < nDevices; ++i) for (uint32_t j = 0; j < i; ++j) if (devices[i] == devices[j]) return kz_fail(KZ_ERR_INVALID_ARG, "device %d listed twice", devices[i]);
-    // the frame's tiles in row-major order: the unit of dealing AND of the merge (a film texel receives the rects that reach it in TILE order,
-    // whichever device rendered them: the result is the same for static and for dynamic dealing, and from run to run)
+    // the frame's tiles in row-major order: the unit of dealing AND of the merge. A film texel receives the rects that reach it in TILE order, but each
+    // device's rects carry that device's whole sum for an apron texel, so WHICH tiles shared a device groups the float additions: only static dealing is
+    // bit-reproducible from run to run (H10); dynamic dealing agrees with it to rounding
     uint32_t nAll = 0;
     (void)kz_deal_tiles(P.width, P.height, tileSize, 1, 0, nullptr, 0, &nAll);
     std::vector<KzTile> all(nAll);
@@ -114,14 +115,11 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
             if (n && (rc = kz_deal_tiles(P.width, P.height, tileSize, nDevices, i, jobs[i].tiles.data(), n, &n))) return rc;
         }
     }
-    // dynamic dealing (the reference's BlockGenerator::next under a mutex, block.cpp:117-148): the workers pull batches of tiles - about two
-    // passes' worth of (pixel, sample) items each - from one counter until the frame is dealt; a slow device simply takes fewer batches
-    std::atomic<uint32_t> nextTile{0};
-    uint32_t s0 = opts ? opts->sampleBegin : 0, s1 = opts ? opts->sampleEnd : 0;
-    if (s0 == 0 && s1 == 0) s1 = P.sampleCount;
-    const uint64_t itemsPerTile = (uint64_t)(tileSize ? tileSize : 64) * (tileSize ? tileSize : 64) * std::max<uint32_t>(1, s1 - s0);
-    const uint64_t passItems = opts && opts->passItems ? opts->passItems : (1ull << 27);
-    const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((2 * passItems + itemsPerTile - 1) / itemsPerTile, std::max<uint32_t>(1, nAll / (4 * nDevices))));
+    // dynamic dealing (the reference's BlockGenerator::next under a mutex, block.cpp:117-148): ONE kz_render_tiles call per device with a KzTileDealer
+    // on a shared counter. Every device prepares the frame's whole tile list as its tile set once and takes batches of it - about two passes' worth of
+    // (pixel, sample) items each - whenever one of its pass contexts comes free; its passes stay in flight across batch boundaries (no per-batch
+    // synchronisation, tile-set change or beam rebuild), and a slow device simply comes back to the counter less often.
+    volatile uint32_t nextTile = 0;
     // one host thread per device (renderer.cpp:94-127 runs one TBB task per block; here a task is a GPU's share of the tiles)
     std::vector<std::thread> threads;
     for (uint32_t i = 0; i < nDevices; ++i) {
@@ -130,17 +128,15 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
             const auto t0 = std::chrono::steady_clock::now();
             KzRenderOpts o{};
             if (opts) o = *opts;
-            o.stream = nullptr; o.accumulate = 0;
+            o.stream = nullptr; o.accumulate = 0; o.packedOutput = 0; o.dealer = nullptr;
             if (dynamic) {
-                for (;;) {
-                    const uint32_t b = nextTile.fetch_add(batch);
-                    if (b >= nAll) break;
-                    const uint32_t e = std::min(nAll, b + batch);
-                    j.rc = kz_render_tiles(scene, &o, all.data() + b, e - b, devices[i], nullptr, 0);
-                    if (j.rc) break;
-                    j.tiles.insert(j.tiles.end(), all.begin() + b, all.begin() + e);
-                    o.accumulate = 1;                                    // the device film collects the batches
-                }
+                std::vector<uint32_t> taken(2 * (size_t)nAll + 2);
+                uint32_t nTaken = 0;
+                KzTileDealer dl{};
+                dl.counter = &nextTile; dl.batchTiles = 0; dl.takers = nDevices; dl.taken = taken.data(); dl.takenCap = (uint32_t)taken.size(); dl.nTaken = &nTaken;
+                o.dealer = &dl;
+                j.rc = kz_render_tiles(scene, &o, all.data(), nAll, devices[i], nullptr, 0);
+                for (uint32_t k = 0; !j.rc && k + 1 < nTaken; k += 2) j.tiles.insert(j.tiles.end(), all.begin() + taken[k], all.begin() + taken[k + 1]);
             } else if (!j.tiles.empty()) j.rc = kz_render_tiles(scene, &o, j.tiles.data(), (uint32_t)j.tiles.size(), devices[i], nullptr, 0);
             if (!j.rc && !j.tiles.empty()) {
                 j.packed.resize(packedFloats(P, j.tiles.data(), (uint32_t)j.tiles.size()));

@@ -94,7 +94,9 @@ static void releaseReplica(KzDeviceState *ds) {
     (void)hipSetDevice(ds->device);
     (void)hipDeviceSynchronize();
     for (void *p : ds->allocs) (void)hipFree(p);
-    for (void *p : {(void *)ds->film, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->packDev, (void *)ds->rectsDev, (void *)ds->prevDev, (void *)ds->beamEntries, (void *)ds->beamCount}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ds->film, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->packDev, (void *)ds->rectsDev, (void *)ds->prevDev, (void *)ds->beamEntries, (void *)ds->beamCount, (void *)ds->tileDev}) if (p) (void)hipFree(p);
+    if (ds->tileHost) (void)hipHostFree(ds->tileHost);
+    if (ds->evTiles) (void)hipEventDestroy(ds->evTiles);
     if (ds->evBeam) (void)hipEventDestroy(ds->evBeam);
     if (ds->packHost) (void)hipHostFree(ds->packHost);
     for (auto &c : ds->ctx) { c.release(); for (auto &e : c.stageEv) (void)hipEventDestroy(e); }
@@ -128,11 +130,11 @@ static int resolveTune(const KzTuning &t, KzTune &r) {
 #if defined(KZ_EXPERIMENTS) && defined(KZ_SHADE_SPLIT)
     r.shadeSplit = KZ_SHADE_SPLIT;          // (development builds only: -DKZ_EXPERIMENTS -DKZ_SHADE_SPLIT=1, profiles/r04b_shade_split)
 #endif
-    r.wide = t.bvh2 ? 0 : 1; r.keyStack = pick(t.keyStack, 0); r.ldsTop = pick(t.ldsTop, 0); r.leafQueue = pick(t.leafQueue, 0);
-    r.legacyTrace = pick(t.legacyTrace, 0); r.mixed = pick(t.mixedLaunch, 0);
+    r.wide = t.KZ_TUNE_BVH2 ? 0 : 1; r.keyStack = pick(t.KZ_TUNE_KEY_STACK, 0); r.ldsTop = pick(t.KZ_TUNE_LDS_TOP, 0); r.leafQueue = pick(t.KZ_TUNE_LEAF_QUEUE, 0);
+    r.legacyTrace = pick(t.KZ_TUNE_LEGACY_TRACE, 0); r.mixed = pick(t.KZ_TUNE_MIXED_LAUNCH, 0);
 #ifndef KZ_EXPERIMENTS
-    if (t.bvh2 || t.keyStack > 0 || t.ldsTop > 0 || t.leafQueue > 1 || t.legacyTrace > 0 || t.mixedLaunch > 0)
-        return kz_fail(KZ_ERR_UNSUPPORTED, "KzTuning.bvh2 / keyStack / ldsTop / leafQueue / legacyTrace / mixedLaunch select kernels of rejected experiments: "
+    if (t.dev0 || t.dev1 > 0 || t.dev2 > 0 || t.dev3 > 1 || t.dev4 > 0 || t.dev5 > 0)
+        return kz_fail(KZ_ERR_UNSUPPORTED, "KzTuning.dev0 .. dev5 (kazen_mi355x_dev.h: bvh2 / keyStack / ldsTop / leafQueue / legacyTrace / mixedLaunch) select kernels of rejected experiments: "
                                            "this library was built without -DKZ_EXPERIMENTS (kz_build_flags)");
 #endif
     r.ovf = nullptr; r.ovfStride = 0;
@@ -260,43 +262,109 @@ int kz_scene_devices(const KzScene *scene, int32_t *devices, uint32_t cap, uint3
 
 } // extern "C"
 
-// pixel list (8x8 blocks row-major inside each tile, row-major inside a block) + image-sized index map
+// The pixel list of a tile set (tile after tile; 8x8 blocks row-major inside a tile, row-major inside a block: a wave of 64 list entries is an 8x8
+// block of the image) and the frame-sized index map (pixel -> list position, -1 outside the set), written on the device from the tile descriptors:
+// one thread per list entry finds its tile by bisection over the tiles' first positions.
+__global__ __launch_bounds__(256) void kz_tiles_expand(const KzTileDesc *__restrict__ tiles, uint32_t nTiles, uint32_t nPix, int width,
+                                                       uint32_t *__restrict__ pixList, int32_t *__restrict__ pixIndex) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nPix) return;
+    uint32_t lo = 0, hi = nTiles;                          // the last tile whose pixOffset <= i
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tiles[mid].pixOffset <= i) lo = mid; else hi = mid; }
+    const KzTileDesc t = tiles[lo];
+    const uint32_t local = i - t.pixOffset, w = (uint32_t)t.w, h = (uint32_t)t.h;
+    const uint32_t r = local / (8u * w), rem = local - r * 8u * w, hb = min(8u, h - 8u * r);       // block row r holds hb rows of the tile
+    const uint32_t c = rem / (8u * hb), rem2 = rem - c * 8u * hb, wb = min(8u, w - 8u * c);        // block c of that row is wb pixels wide
+    const uint32_t yl = rem2 / wb, xl = rem2 - yl * wb;
+    const uint32_t x = (uint32_t)t.x0 + 8u * c + xl, y = (uint32_t)t.y0 + 8u * r + yl;
+    pixList[i] = x | (y << 16);
+    pixIndex[(size_t)y * (uint32_t)width + x] = (int32_t)i;
+}
+
+// Makes `tiles` the replica's tile set. Nothing here waits for the device: the descriptors go up through the call's stream, behind the end of the
+// previous call (evCallB), and the expansion kernel runs there - a change of tile set costs a few microseconds of host time and ~30 us of device
+// time (C5: 33 MB of index map), where it used to synchronise every stream, build both arrays on the host and copy them with blocking pageable copies.
 static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, uint32_t nTiles, hipStream_t stream) {
     const KzParams &P = scene->prm;
     KzTile whole = {0, 0, P.width, P.height};
     if (!tiles || nTiles == 0) { tiles = &whole; nTiles = 1; }
     bool same = ds->tilesValid && ds->curTiles.size() == nTiles && std::memcmp(ds->curTiles.data(), tiles, nTiles * sizeof(KzTile)) == 0;
     if (same) return KZ_OK;
-    std::vector<uint32_t> list;
-    std::vector<int32_t> index((size_t)P.width * P.height, -1);
+    // bounds, then overlaps: tiles on the 8-px grid (every tile the library deals) are marked on a coarse occupancy map, others compared pairwise
+    std::vector<KzTileDesc> desc(nTiles);
+    std::vector<uint32_t> offs(nTiles + 1);
+    bool grid = true;
+    uint64_t total = 0;
     for (uint32_t t = 0; t < nTiles; ++t) {
         const KzTile &tl = tiles[t];
         if (tl.x0 < 0 || tl.y0 < 0 || tl.w <= 0 || tl.h <= 0 || tl.x0 + tl.w > P.width || tl.y0 + tl.h > P.height)
             return kz_fail(KZ_ERR_INVALID_ARG, "tile %u (%d,%d %dx%d) outside the %dx%d image", t, tl.x0, tl.y0, tl.w, tl.h, P.width, P.height);
-        for (int by = tl.y0; by < tl.y0 + tl.h; by += 8)
-            for (int bx = tl.x0; bx < tl.x0 + tl.w; bx += 8)
-                for (int y = by; y < std::min(by + 8, tl.y0 + tl.h); ++y)
-                    for (int x = bx; x < std::min(bx + 8, tl.x0 + tl.w); ++x) {
-                        int32_t &slot = index[(size_t)y * P.width + x];
-                        if (slot >= 0) return kz_fail(KZ_ERR_INVALID_ARG, "tiles overlap at pixel (%d,%d)", x, y);
-                        slot = (int32_t)list.size();
-                        list.push_back((uint32_t)x | ((uint32_t)y << 16));
-                    }
+        if ((tl.x0 & 7) || (tl.y0 & 7) || ((tl.w & 7) && tl.x0 + tl.w != P.width) || ((tl.h & 7) && tl.y0 + tl.h != P.height)) grid = false;
+        desc[t] = KzTileDesc{tl.x0, tl.y0, tl.w, tl.h, (uint32_t)total};
+        offs[t] = (uint32_t)total;
+        total += (uint64_t)tl.w * (uint64_t)tl.h;
     }
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (hipStream_t st : ds->passStream) if (st) HIP_TRY(hipStreamSynchronize(st));
+    offs[nTiles] = (uint32_t)total;
+    if (total > (uint64_t)P.width * (uint64_t)P.height) return kz_fail(KZ_ERR_INVALID_ARG, "tiles overlap (%llu pixels in a %dx%d image)", (unsigned long long)total, P.width, P.height);
+    if (grid) {
+        const int gw = (P.width + 7) / 8, gh = (P.height + 7) / 8;
+        std::vector<uint8_t> occ((size_t)gw * gh, 0);
+        for (uint32_t t = 0; t < nTiles; ++t) {
+            const KzTile &tl = tiles[t];
+            for (int gy = tl.y0 / 8; gy < (tl.y0 + tl.h + 7) / 8; ++gy)
+                for (int gx = tl.x0 / 8; gx < (tl.x0 + tl.w + 7) / 8; ++gx) {
+                    uint8_t &o = occ[(size_t)gy * gw + gx];
+                    if (o) return kz_fail(KZ_ERR_INVALID_ARG, "tiles overlap at pixel (%d,%d)", gx * 8, gy * 8);
+                    o = 1;
+                }
+        }
+    } else {
+        for (uint32_t a = 0; a < nTiles; ++a) for (uint32_t b2 = a + 1; b2 < nTiles; ++b2) {
+            const KzTile &A = tiles[a], &B = tiles[b2];
+            if (A.x0 < B.x0 + B.w && B.x0 < A.x0 + A.w && A.y0 < B.y0 + B.h && B.y0 < A.y0 + A.h)
+                return kz_fail(KZ_ERR_INVALID_ARG, "tiles overlap at pixel (%d,%d)", std::max(A.x0, B.x0), std::max(A.y0, B.y0));
+        }
+    }
+    const size_t framePix = (size_t)P.width * P.height;
+    if (!ds->pixIndex || ds->pixCap < framePix || ds->tileDevCap < nTiles) {          // first use (or a longer tile list than ever before): allocate
+        HIP_TRY(hipDeviceSynchronize());
+        if (!ds->pixIndex) KZ_ALLOC(&ds->pixIndex, framePix * sizeof(int32_t));
+        if (ds->pixCap < framePix) {
+            if (ds->pixList) (void)hipFree(ds->pixList);
+            ds->pixList = nullptr; ds->pixCap = 0;
+            KZ_ALLOC(&ds->pixList, framePix * sizeof(uint32_t));
+            ds->pixCap = framePix;
+        }
+        if (ds->tileDevCap < nTiles) {
+            if (ds->tileDev) (void)hipFree(ds->tileDev);
+            ds->tileDev = nullptr; ds->tileDevCap = 0;
+            const size_t cap = std::max<size_t>(nTiles, 4096);
+            KZ_ALLOC(&ds->tileDev, cap * sizeof(KzTileDesc));
+            ds->tileDevCap = cap;
+        }
+    }
     ds->tilesValid = false;
-    if (!ds->pixIndex) KZ_ALLOC(&ds->pixIndex, index.size() * sizeof(int32_t));
-    if (list.size() > ds->pixCap) {
-        if (ds->pixList) (void)hipFree(ds->pixList);
-        ds->pixList = nullptr; ds->pixCap = 0;
-        KZ_ALLOC(&ds->pixList, list.size() * sizeof(uint32_t));
-        ds->pixCap = list.size();
+    if (ds->evCallB) HIP_TRY(hipStreamWaitEvent(stream, ds->evCallB, 0));        // behind everything the previous call (on whatever stream) queued
+    // the descriptors travel through a pinned buffer of the replica (the copy of the previous tile set has left it: evTiles)
+    if (ds->tileHostCap < nTiles) {
+        if (ds->evTiles) HIP_TRY(hipEventSynchronize(ds->evTiles));
+        if (ds->tileHost) (void)hipHostFree(ds->tileHost);
+        ds->tileHost = nullptr; ds->tileHostCap = 0;
+        const size_t cap = std::max<size_t>(nTiles, 4096);
+        HIP_TRY(hipHostMalloc((void **)&ds->tileHost, cap * sizeof(KzTileDesc), hipHostMallocDefault));
+        ds->tileHostCap = cap;
     }
-    HIP_TRY(hipMemcpy(ds->pixList, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ds->pixIndex, index.data(), index.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    ds->nPix = (uint32_t)list.size();
+    if (!ds->evTiles) HIP_TRY(hipEventCreateWithFlags(&ds->evTiles, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(ds->evTiles));
+    std::memcpy(ds->tileHost, desc.data(), nTiles * sizeof(KzTileDesc));
+    HIP_TRY(hipMemcpyAsync(ds->tileDev, ds->tileHost, nTiles * sizeof(KzTileDesc), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(ds->evTiles, stream));
+    HIP_TRY(hipMemsetAsync(ds->pixIndex, 0xFF, framePix * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(kz_tiles_expand, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const KzTileDesc *)ds->tileDev, nTiles, (uint32_t)total, P.width, ds->pixList, ds->pixIndex);
+    HIP_TRY(hipGetLastError());
+    ds->nPix = (uint32_t)total;
     ds->curTiles.assign(tiles, tiles + nTiles);
+    ds->tilePixOffset = std::move(offs);
     ds->tilesValid = true; ++ds->tileGen;
     return KZ_OK;
 }
@@ -314,16 +382,7 @@ static constexpr size_t KZ_SAMPLE_BYTES_PER_ITEM = 5 * sizeof(float);
 static constexpr size_t KZ_TAP_BYTES_PER_PIXEL = (size_t)KZ_TAPS_MAX * KZ_TAPS_MAX * sizeof(float4);
 
 // ---- buffers of one pass context: sized for `need` items of `nPix` pixels; nothing is left half-allocated on failure ----
-static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool tapSums, bool beams, hipStream_t stream) {
-    if (beams && nPix > c.beamCap) {                                // (beams: lists of this context's own pixel chunks; the whole-set lists live with the replica)
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (c.beamEntries) (void)hipFree(c.beamEntries);
-        if (c.beamCount) (void)hipFree(c.beamCount);
-        c.beamEntries = nullptr; c.beamCount = nullptr; c.beamCap = 0; c.beamGen = 0;
-        KZ_ALLOC(&c.beamEntries, nPix * KZ_BEAM_CAP * sizeof(uint2));
-        KZ_ALLOC(&c.beamCount, nPix * sizeof(uint2));
-        c.beamCap = nPix;
-    }
+static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool tapSums, hipStream_t stream) {
     if (tapSums && nPix > c.tapsCap) {                               // (only the tap-sum film path has this buffer)
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.taps) (void)hipFree(c.taps);
@@ -532,6 +591,34 @@ struct KzSortExp {
 static KzSortExp g_sortExp;
 #endif
 
+// Beam lists for pixels [p0, p0 + n) of the current pixel list: launched on `stream` (the call's stream) unless that range of this list has been
+// handed to the kernel before; the kernel itself skips pixels that already have a list (from another tile set or chunk). evBeam / beamSeq tell the
+// pass streams what to wait for.
+static int ensureBeams(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_t p0, uint32_t n) {
+    const KzParams &P = scene->prm;
+    const size_t framePix = (size_t)P.width * P.height;
+    if (!ds->evBeam) HIP_TRY(hipEventCreateWithFlags(&ds->evBeam, hipEventDisableTiming));
+    if (!ds->beamEntries) {
+        KZ_ALLOC(&ds->beamEntries, framePix * KZ_BEAM_CAP * sizeof(uint2));
+        KZ_ALLOC(&ds->beamCount, framePix * sizeof(uint2));
+        ds->beamCap = framePix;
+        HIP_TRY(hipMemsetAsync(ds->beamCount, 0xFF, framePix * sizeof(uint2), stream));       // every pixel: KZ_BEAM_UNBUILT
+        ds->beamDone.clear(); ds->beamDoneGen = ds->tileGen;
+    }
+    if (ds->beamDoneGen != ds->tileGen) { ds->beamDone.clear(); ds->beamDoneGen = ds->tileGen; }
+    for (const auto &r : ds->beamDone) if (r.first <= p0 && p0 + n <= r.first + r.second) return KZ_OK;
+    const int LS = std::max(1, std::min(P.stackBound4, KZ_BEAM_STACK));      // a beam whose open set would grow beyond this leaves the rest unexplored (t_valid)
+    const dim3 gBeam((n + KZ_BLOCK - 1) / KZ_BLOCK);
+    const size_t beamLds = (size_t)2 * LS * KZ_BLOCK * sizeof(uint32_t);
+    hipLaunchKernelGGL(kz_wf_beam, gBeam, dim3(KZ_BLOCK), beamLds, stream, P, ds->T, (const uint32_t *)(ds->pixList + p0), n, LS, ds->beamEntries, ds->beamCount);
+    if (ds->statsOn) hipLaunchKernelGGL(kz_wf_beam_count, gBeam, dim3(KZ_BLOCK), 0, stream, (const uint2 *)ds->beamCount, (const uint32_t *)(ds->pixList + p0), P.width, n, ds->stats + 24);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ds->evBeam, stream));
+    ++ds->beamSeq;
+    ds->beamDone.emplace_back(p0, n);
+    return KZ_OK;
+}
+
 // One pass of the wavefront pipeline over `items` = nPixPass x Sp (pixel, sample) items: pixels pixList[0 .. nPixPass), sample indices
 // [sBegin, sBegin + Sp). Every launch goes to `stream`; queue counts stay on the device.
 static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune, bool beams) {
@@ -597,29 +684,11 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #define KZ_PACKET4(q, cptr, cimm, headp) do { if (P.anyInvisibleLight) { if (st) KZ_PACKET(true, true, q, cptr, cimm, headp); else KZ_PACKET(false, true, q, cptr, cimm, headp); } \
                                               else { if (st) KZ_PACKET(true, false, q, cptr, cimm, headp); else KZ_PACKET(false, false, q, cptr, cimm, headp); } } while (0)
     if (packet && beams) {
-        const uint2 *lstEntries, *lstHeads;
-        const int LS = std::max(1, std::min(P.stackBound4, KZ_BEAM_STACK));      // a beam whose open set would grow beyond this leaves the rest unexplored (t_valid)
-        const dim3 gBeam((nPixPass + KZ_BLOCK - 1) / KZ_BLOCK);
-        const size_t beamLds = (size_t)2 * LS * KZ_BLOCK * sizeof(uint32_t);
-        if (p0 == 0 && nPixPass == ds->nPix) {                                 // the whole pixel set: ONE list for all contexts of the replica
-            if (ds->beamGen != ds->tileGen) {                                   // (a call's pass streams all start behind the previous call: nobody reads the old lists any more)
-                hipLaunchKernelGGL(kz_wf_beam, gBeam, blk, beamLds, stream, P, ds->T, pixList, nPixPass, LS, ds->beamEntries, ds->beamCount);
-                if (st) hipLaunchKernelGGL(kz_wf_beam_count, gBeam, blk, 0, stream, (const uint2 *)ds->beamCount, nPixPass, ds->stats + 24);
-                HIP_TRY(hipEventRecord(ds->evBeam, stream));
-                ds->beamGen = ds->tileGen; c.sharedSeen = ds->tileGen;
-            } else if (c.sharedSeen != ds->tileGen) { HIP_TRY(hipStreamWaitEvent(stream, ds->evBeam, 0)); c.sharedSeen = ds->tileGen; }
-            lstEntries = ds->beamEntries; lstHeads = ds->beamCount;
-        } else {                                                                // a pixel chunk: the context's own lists, built once per chunk
-            if (c.beamGen != ds->tileGen || c.beamP0 != p0 || c.beamN != nPixPass) {
-                hipLaunchKernelGGL(kz_wf_beam, gBeam, blk, beamLds, stream, P, ds->T, pixList, nPixPass, LS, c.beamEntries, c.beamCount);
-                c.beamGen = ds->tileGen; c.beamP0 = p0; c.beamN = nPixPass;
-                if (st) hipLaunchKernelGGL(kz_wf_beam_count, gBeam, blk, 0, stream, (const uint2 *)c.beamCount, nPixPass, ds->stats + 24);
-            }
-            lstEntries = c.beamEntries; lstHeads = c.beamCount;
-        }
+        // (the lists of this pass's pixels were handed to kz_wf_beam on the call's stream - ensureBeams - and this stream has waited for it)
+        const uint2 *lstEntries = ds->beamEntries, *lstHeads = ds->beamCount;
         uint32_t *fbQ = W.queue[0], *fbCount = W.counts + 8 * 520 - 8, *fbHead = fbCount + 1;      // rays of pixels whose list overflowed: the packet kernel's
         const dim3 gList((items + KZ_BLOCK - 1) / KZ_BLOCK);
-#define KZ_LIST(ST, FX) hipLaunchKernelGGL((kz_wf_trace_list<ST, FX>), gList, blk, 0, stream, P, ds->T, W, items, Sp, lstEntries, lstHeads, fbQ, fbCount, W.queue[2], W.counts + 0)
+#define KZ_LIST(ST, FX) hipLaunchKernelGGL((kz_wf_trace_list<ST, FX>), gList, blk, 0, stream, P, ds->T, W, pixList, items, Sp, lstEntries, lstHeads, fbQ, fbCount, W.queue[2], W.counts + 0)
         if (P.anyInvisibleLight) { if (st) KZ_LIST(true, true); else KZ_LIST(false, true); }
         else { if (st) KZ_LIST(true, false); else KZ_LIST(false, false); }
 #undef KZ_LIST
@@ -727,24 +796,38 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     const size_t perItem = (pipeline == 2 ? KZ_STATE_BYTES_PER_ITEM : 0) + KZ_SAMPLE_BYTES_PER_ITEM;
     // camera rays by pixel beams: a pinhole camera with an affine sample map, a stack that fits LDS twice, unless the caller asks otherwise
     const bool beams = pipeline == 2 && P.beamOk && tune.packet != 1 && tune.packet != 2 && P.maxDepth > 0;
-    const size_t perPixel = (tapSums ? KZ_TAP_BYTES_PER_PIXEL : 0) + (beams ? (KZ_BEAM_CAP + 1) * sizeof(uint2) : 0);
+    const size_t perPixel = tapSums ? KZ_TAP_BYTES_PER_PIXEL : 0;
     size_t limit = opts->maxStateBytes;
     if (!limit) {
         size_t freeB = 0, totalB = 0;
-        const size_t held = ds->ctxBytes();
+        const size_t held = ds->ctxBytes();          // (the beam lists - one per frame pixel, 264 B each - are the replica's, not part of this budget)
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) limit = std::min(totalB / 4 * 3, freeB + held - std::min(freeB + held, (size_t)256 << 20));
         else limit = (size_t)32 << 30;
     }
     const uint32_t nSamples = s1 - s0;
     const size_t wantItems = std::max<size_t>(opts->passItems ? (size_t)opts->passItems : (size_t)1 << 27, 64);
+    // Dynamic dealing (opts->dealer, ABI v5): the tile set is the whole list, a batch of tiles is a range of its pixel list, and the pass shape is
+    // chosen for the pixels of a BATCH instead of those of the set.
+    const KzTileDealer *dealer = opts->dealer;
+    const uint32_t nTilesSet = (uint32_t)ds->curTiles.size();
+    uint32_t batchTiles = 0;
+    if (dealer) {
+        if (!dealer->counter || (dealer->takenCap && (!dealer->taken || !dealer->nTaken))) return kz_fail(KZ_ERR_INVALID_ARG, "KzTileDealer: null counter / taken buffer");
+        if (pipeline != 2) return kz_fail(KZ_ERR_UNSUPPORTED, "dynamic tile dealing needs the wavefront pipeline");
+        const uint64_t itemsPerTile = std::max<uint64_t>(1, (uint64_t)ds->nPix / std::max<uint32_t>(1, nTilesSet)) * nSamples;
+        batchTiles = dealer->batchTiles ? dealer->batchTiles
+                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((2 * (uint64_t)wantItems + itemsPerTile - 1) / itemsPerTile, std::max<uint32_t>(1, nTilesSet / (4 * std::max<uint32_t>(1, dealer->takers)))));
+        if (dealer->nTaken) *dealer->nTaken = 0;
+    }
+    const uint32_t nPixSet = dealer ? (uint32_t)std::min<uint64_t>(ds->nPix, (uint64_t)batchTiles * std::max<uint32_t>(1, ds->nPix / std::max<uint32_t>(1, nTilesSet))) : ds->nPix;
     uint32_t S, pixPerPass;
-    if (opts->tune.sppPerPass > 0) { S = std::min<uint32_t>((uint32_t)opts->tune.sppPerPass, nSamples); pixPerPass = (uint32_t)std::min<size_t>(ds->nPix, std::max<size_t>(64, wantItems / S / 64 * 64)); }
+    if (opts->tune.sppPerPass > 0) { S = std::min<uint32_t>((uint32_t)opts->tune.sppPerPass, nSamples); pixPerPass = (uint32_t)std::min<size_t>(nPixSet, std::max<size_t>(64, wantItems / S / 64 * 64)); }
     else {
-        pixPerPass = ds->nPix; S = (uint32_t)std::min<size_t>(std::max<size_t>(1, wantItems / std::max<uint32_t>(1, ds->nPix)), nSamples);
+        pixPerPass = nPixSet; S = (uint32_t)std::min<size_t>(std::max<size_t>(1, wantItems / std::max<uint32_t>(1, nPixSet)), nSamples);
         // A frame too large for 64 samples of every pixel per pass (C5 on one GPU: 16) is rendered in pixel chunks of 256 samples instead: a wave of the
         // camera-ray kernels is then one pixel again (one shared list), the film stage touches a chunk per pass instead of the whole frame, and the paths of a pass
         // stay in a part of the scene (C5, same call: 1 586 Msamples/s at 16 x all pixels, 1 708 at 64 x 2 M, 1 734 at 256 x 512 K).
-        if (S < 64 && nSamples >= 64) { S = std::min<uint32_t>(256u, nSamples); pixPerPass = (uint32_t)std::min<size_t>(ds->nPix, std::max<size_t>(64, wantItems / S / 64 * 64)); }
+        if (S < 64 && nSamples >= 64) { S = std::min<uint32_t>(256u, nSamples); pixPerPass = (uint32_t)std::min<size_t>(nPixSet, std::max<size_t>(64, wantItems / S / 64 * 64)); }
         // a multiple of 64 samples per pixel keeps every wave of the camera-ray kernels inside one pixel (one shared leaf list) - taken when it costs no extra pass
         // (a rank's share of a frame: 2^27 / 1 036 800 pixels = 129 -> 128)
         else if (S > 64 && S % 64 && (nSamples + S / 64 * 64 - 1) / (S / 64 * 64) == (nSamples + S - 1) / S) S = S / 64 * 64;
@@ -762,7 +845,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     for (;; --nCtx) {
         uint32_t s, px;
         shape(limit / (size_t)nCtx, s, px);
-        if (px > 0) nPasses = ((ds->nPix + px - 1) / px) * ((nSamples + s - 1) / s);
+        if (px > 0) nPasses = dealer ? 0xFFFFu : ((ds->nPix + px - 1) / px) * ((nSamples + s - 1) / s);      // (a dealer: not known, assume many)
         if (nCtx > 1 && (px == 0 || nPasses < (uint32_t)nCtx)) continue;
         if (px == 0) return kz_fail(KZ_ERR_OOM, "64 (pixel, sample) items need %zu bytes of path state, the limit is %zu", (size_t)64 * (perItem + perPixel), limit);
         S = s; pixPerPass = px;
@@ -782,18 +865,6 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
             if (ds->ctx[i].bytes() && keep + ds->ctx[i].bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i].release(); } else keep += ds->ctx[i].bytes();
     }
     if (!ds->evCallA) { HIP_TRY(hipEventCreate(&ds->evCallA)); HIP_TRY(hipEventCreate(&ds->evCallB)); }
-    if (beams && pixPerPass == ds->nPix) {                            // the shared lists of the whole pixel set
-        if (!ds->evBeam) HIP_TRY(hipEventCreateWithFlags(&ds->evBeam, hipEventDisableTiming));
-        if (ds->nPix > ds->beamCap) {
-            HIP_TRY(hipDeviceSynchronize());
-            if (ds->beamEntries) (void)hipFree(ds->beamEntries);
-            if (ds->beamCount) (void)hipFree(ds->beamCount);
-            ds->beamEntries = nullptr; ds->beamCount = nullptr; ds->beamCap = 0; ds->beamGen = 0;
-            KZ_ALLOC(&ds->beamEntries, (size_t)ds->nPix * KZ_BEAM_CAP * sizeof(uint2));
-            KZ_ALLOC(&ds->beamCount, (size_t)ds->nPix * sizeof(uint2));
-            ds->beamCap = ds->nPix;
-        }
-    }
     if (multi) {
         // Different priorities put streams on different hardware queues whatever other streams the process has created (streams of one
         // priority share a small round-robin pool of queues and two of them may end up serialised on one): the pass streams cycle
@@ -821,43 +892,71 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         HIP_TRY(hipEventRecord(ds->evFork, stream));
         for (int i = 0; i < nCtx; ++i) HIP_TRY(hipStreamWaitEvent(ds->passStream[i], ds->evFork, 0));
     }
+    // evFilm[i] of a context that has not run a pass in this call must not be waited for: inFlight marks the ones that have
+    bool inFlight[KZ_MAX_PASSES_IN_FLIGHT] = {};
     uint32_t pass = 0;
-    for (uint32_t p0 = 0; p0 < ds->nPix; p0 += pixPerPass) {
-        const uint32_t nPixPass = std::min(pixPerPass, ds->nPix - p0);
+    // one pass: pixels [p0, p0 + nPixPass) of the pixel list x sample indices [s, s + Sp)
+    auto onePass = [&](uint32_t p0, uint32_t nPixPass, uint32_t s, uint32_t Sp) -> int {
         const uint32_t *pixList = ds->pixList + p0;
-        for (uint32_t s = s0; s < s1; s += S, ++pass) {
-            const uint32_t Sp = std::min(S, s1 - s);
-            const size_t items = (size_t)nPixPass * Sp;
-            const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
-            PassCtx &c = ds->ctx[ci];
-            hipStream_t pst = multi ? ds->passStream[ci] : stream;
-            if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, beams && pixPerPass != ds->nPix, pst))) return rc;
-            if (ds->eventsUsed == ds->events.size()) {
-                EventPair ep; HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); ds->events.push_back(ep);
-            }
-            EventPair &ep = ds->events[ds->eventsUsed++];
-            const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
-            HIP_TRY(hipEventRecord(ep.a, pst));
-            if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams))) return rc; }
-            else {
-                float *sJx = c.samp, *sJy = c.samp + c.sampCap, *sR = c.samp + 2 * c.sampCap, *sG = c.samp + 3 * c.sampCap, *sB = c.samp + 4 * c.sampCap;
+        const size_t items = (size_t)nPixPass * Sp;
+        const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
+        PassCtx &c = ds->ctx[ci];
+        hipStream_t pst = multi ? ds->passStream[ci] : stream;
+        // Back-pressure of dynamic dealing: the host takes the next batch only when the context it needs has finished its previous pass, so a device
+        // holds at most nCtx passes - never the whole frame - and a slower device simply comes back to the counter less often.
+        if (dealer && multi && inFlight[ci]) HIP_TRY(hipEventSynchronize(ds->evFilm[ci]));
+        if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, pst))) return rc;
+        if (beams) {
+            if ((rc = ensureBeams(scene, ds, stream, p0, nPixPass))) return rc;
+            if (pst != stream && c.beamSeen != ds->beamSeq) { HIP_TRY(hipStreamWaitEvent(pst, ds->evBeam, 0)); c.beamSeen = ds->beamSeq; }
+        }
+        if (ds->eventsUsed == ds->events.size()) {
+            EventPair ep; HIP_TRY(hipEventCreate(&ep.a)); HIP_TRY(hipEventCreate(&ep.b)); ds->events.push_back(ep);
+        }
+        EventPair &ep = ds->events[ds->eventsUsed++];
+        const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
+        HIP_TRY(hipEventRecord(ep.a, pst));
+        if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams))) return rc; }
+        else {
+            float *sJx = c.samp, *sJy = c.samp + c.sampCap, *sR = c.samp + 2 * c.sampCap, *sG = c.samp + 3 * c.sampCap, *sB = c.samp + 4 * c.sampCap;
 #define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, pixList, (uint32_t)items, Sp, s, \
-                                           (const uint32_t *)nullptr, sJx, sJy, sR, sG, sB, ds->stats)
-                if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, true); else KZ_MEGA(true, false); }
-                else { if (P.bsdfExt) KZ_MEGA(false, true); else KZ_MEGA(false, false); }
+                                       (const uint32_t *)nullptr, sJx, sJy, sR, sG, sB, ds->stats)
+            if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, true); else KZ_MEGA(true, false); }
+            else { if (P.bsdfExt) KZ_MEGA(false, true); else KZ_MEGA(false, false); }
 #undef KZ_MEGA
-            }
-            HIP_TRY(hipEventRecord(ep.b, pst));
-            HIP_TRY(hipGetLastError());
-            const int prev = (ci + nCtx - 1) % nCtx;
-            if ((rc = kzFilmStage(scene, ds, c, pst, pixList, p0, nPixPass, Sp, tapSums, (multi && pass > 0) ? ds->evFilm[prev] : nullptr))) return rc;
-            if (multi) HIP_TRY(hipEventRecord(ds->evFilm[ci], pst));
-            if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
-            ds->lastCtx = ci;
+        }
+        HIP_TRY(hipEventRecord(ep.b, pst));
+        HIP_TRY(hipGetLastError());
+        const int prev = (ci + nCtx - 1) % nCtx;
+        if ((rc = kzFilmStage(scene, ds, c, pst, pixList, p0, nPixPass, Sp, tapSums, (multi && pass > 0) ? ds->evFilm[prev] : nullptr))) return rc;
+        if (multi) { HIP_TRY(hipEventRecord(ds->evFilm[ci], pst)); inFlight[ci] = true; }
+        if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
+        ds->lastCtx = ci;
+        ++pass;
+        return KZ_OK;
+    };
+    // the passes of pixels [b0, b1) of the list: pixel chunks x sample ranges
+    auto passesOf = [&](uint32_t b0, uint32_t b1) -> int {
+        for (uint32_t p0 = b0; p0 < b1; p0 += pixPerPass) {
+            const uint32_t nPixPass = std::min(pixPerPass, b1 - p0);
+            for (uint32_t s = s0; s < s1; s += S) if ((rc = onePass(p0, nPixPass, s, std::min(S, s1 - s)))) return rc;
+        }
+        return KZ_OK;
+    };
+    if (!dealer) { if ((rc = passesOf(0, ds->nPix))) return rc; }
+    else {
+        // BlockGenerator::next (block.cpp:117-148): batches of the tile list from the shared counter (it may live in memory shared between processes)
+        for (;;) {
+            if (dealer->takenCap && *dealer->nTaken + 2 > dealer->takenCap) break;
+            const uint32_t tb = __atomic_fetch_add((uint32_t *)dealer->counter, batchTiles, __ATOMIC_RELAXED);
+            if (tb >= nTilesSet) break;
+            const uint32_t te = std::min(nTilesSet, tb + batchTiles);
+            if (dealer->takenCap) { dealer->taken[*dealer->nTaken] = tb; dealer->taken[*dealer->nTaken + 1] = te; *dealer->nTaken += 2; }
+            if ((rc = passesOf(ds->tilePixOffset[tb], ds->tilePixOffset[te]))) return rc;
         }
     }
     if (multi)                                                         // join: everything after this call on `stream` sees the film
-        for (int i = 0; i < nCtx && (uint32_t)i < pass; ++i) HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[i], 0));
+        for (int i = 0; i < nCtx; ++i) if (inFlight[i]) HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[i], 0));
     HIP_TRY(hipEventRecord(ds->evCallB, stream));
     ds->lastDual = multi;
     ds->lastInfo.passes = pass; ds->lastInfo.passesInFlight = (uint32_t)nCtx; ds->lastInfo.itemsPerPass = need; ds->lastInfo.sppPerPass = S;
@@ -884,19 +983,22 @@ int kz_render_tiles(KzScene *scene, const KzRenderOpts *opts, const KzTile *tile
     KzDeviceState *ds; int rc;
     if ((rc = findReplica(scene, device, &ds))) return rc;
     const size_t full = ds->filmPixels * 4;
-    size_t packed = 0;
+    const bool packedOut = opts && opts->packedOutput;
+    if (opts && opts->dealer && film) return kz_fail(KZ_ERR_INVALID_ARG, "kz_render_tiles with a dealer hands back no film: download the batches it took (KzTileDealer.taken) with kz_film_download_tiles");
     if (film) {
-        if ((rc = checkTiles(scene->prm, tiles, nTiles))) return rc;
-        packed = packedFloats(scene->prm, tiles, nTiles);
-        if (nFloats != full && !(nTiles && nFloats == packed))
-            return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold the tiles' packed rects (%zu floats, kz_tiles_packed_floats) or the whole film (%zu floats)", packed, full);
+        // what the buffer receives is SAID by opts->packedOutput, never inferred from its size (a full tiling with a border-less filter packs to exactly the film's size)
+        if (packedOut) {
+            if ((rc = checkTiles(scene->prm, tiles, nTiles))) return rc;
+            const size_t packed = packedFloats(scene->prm, tiles, nTiles);
+            if (!nTiles || nFloats != packed) return kz_fail(KZ_ERR_INVALID_ARG, "packedOutput: the buffer must hold the tiles' packed rects (%zu floats, kz_tiles_packed_floats), got %zu", packed, nFloats);
+        } else if (nFloats != full) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold the whole film (%zu floats; set opts->packedOutput for the tiles' packed rects), got %zu", full, nFloats);
     }
     KzRenderOpts o{};
     if (opts) o = *opts;
     o.tiles = tiles; o.nTiles = nTiles; o.device = device;
     if ((rc = renderOn(scene, ds, &o))) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)o.stream));
-    if (film && nFloats == full && !(nTiles && packed == full)) HIP_TRY(hipMemcpy(film, ds->film, nFloats * sizeof(float), hipMemcpyDeviceToHost));
+    if (film && !packedOut) HIP_TRY(hipMemcpy(film, ds->film, nFloats * sizeof(float), hipMemcpyDeviceToHost));
     else if (film) return downloadTiles(scene, ds, tiles, nTiles, film, nFloats, (hipStream_t)o.stream);
     return KZ_OK;
 }

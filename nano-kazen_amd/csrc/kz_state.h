@@ -46,6 +46,7 @@ struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, 
 #endif
 
 struct KzTileRect { int32_t x0, y0, w, h; uint32_t offset; uint32_t prevStart, prevCount; };
+struct KzTileDesc { int32_t x0, y0, w, h; uint32_t pixOffset; };      // a tile of the current set and the position of its first pixel in the pixel list
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return kz_fail(KZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
@@ -70,11 +71,9 @@ struct PassCtx {
     float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: taps^2 float4 per pixel of the tile set
     uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
-    uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0;      // kz_wf_beam: leaf lists of the pixels of a chunk ...
-    uint64_t beamGen = 0; uint32_t beamP0 = 0, beamN = 0;                                  // ... and the chunk (tile-set generation, first pixel, pixels) they were built for
-    uint64_t sharedSeen = 0;                                                              // the generation of the replica's shared lists this context's stream has waited for
+    uint64_t beamSeen = 0;                                       // the last beam-list build (KzDeviceState::beamSeq) this context's stream has waited for
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
-    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4 + beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); }
+    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4; }
     void release() {
         for (void *p : wfAllocs) (void)hipFree(p);
         wfAllocs.clear(); wfCap = 0; wf = KzWf{};
@@ -82,7 +81,6 @@ struct PassCtx {
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
         if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
         if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
-        if (beamEntries) (void)hipFree(beamEntries); beamEntries = nullptr; if (beamCount) (void)hipFree(beamCount); beamCount = nullptr; beamCap = 0; beamGen = 0;
     }
 };
 struct KzDeviceState {
@@ -93,8 +91,12 @@ struct KzDeviceState {
     uint8_t *srgb = nullptr;                                     // staging raster of kz_film_to_srgb8 (allocated on first use)
     float4 *packDev = nullptr; size_t packCap = 0; KzTileRect *rectsDev = nullptr; size_t rectsCap = 0; uint32_t *prevDev = nullptr; size_t prevCap = 0;      // kz_film_download_tiles: packed tile rects + their tables
     float4 *packHost = nullptr; size_t packHostCap = 0;           // pinned staging of the same (D2H at link rate)
+    // The tile set: pixList = its pixels (tile after tile, 8x8 blocks row-major inside a tile, row-major inside a block), pixIndex = the position of
+    // every pixel of the frame in that list (-1: not in the set). Both are written on the device from the tile descriptors (kz_tiles_expand).
     uint32_t *pixList = nullptr; int32_t *pixIndex = nullptr; size_t pixCap = 0; uint32_t nPix = 0;
-    std::vector<KzTile> curTiles; bool tilesValid = false; uint64_t tileGen = 0;      // tileGen: bumped whenever the pixel list changes
+    KzTileDesc *tileDev = nullptr; size_t tileDevCap = 0; KzTileDesc *tileHost = nullptr; size_t tileHostCap = 0; hipEvent_t evTiles = nullptr;
+    std::vector<KzTile> curTiles; std::vector<uint32_t> tilePixOffset;      // tilePixOffset[t]: first list position of tile t (+ the total at the end)
+    bool tilesValid = false; uint64_t tileGen = 0;                          // tileGen: bumped whenever the pixel list changes
     unsigned long long *stats = nullptr; bool statsOn = false;
     hipStream_t lastStream = nullptr;
     int numCU = 256; size_t totalMem = 0;
@@ -102,10 +104,13 @@ struct KzDeviceState {
     std::vector<EventPair> events; size_t eventsUsed = 0;
     hipStream_t passStream[KZ_MAX_PASSES_IN_FLIGHT] = {}; hipEvent_t evFork = nullptr, evFilm[KZ_MAX_PASSES_IN_FLIGHT] = {}, evCallA = nullptr, evCallB = nullptr;
     int lastCtx = 0; bool lastDual = false; int streamMode = 0;
-    // beam lists of the WHOLE pixel set (the default pass shape: every pass covers every pixel), shared by the contexts: built once per tile set on the
-    // stream of the pass that needs them first, the other contexts wait for evBeam once
-    uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0; uint64_t beamGen = 0; hipEvent_t evBeam = nullptr;
-    size_t ctxBytes() const { size_t b = beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); for (const PassCtx &c : ctx) b += c.bytes(); return b; }
+    // Beam lists (kz_wf_beam), one per pixel of the FRAME, built at most once per pixel and replica - the camera belongs to the scene - whatever tile
+    // sets and pixel chunks the pixel is rendered in. They are built on the call's stream (evBeam / beamSeq: the passes wait for the latest build);
+    // beamDone remembers the ranges of the CURRENT pixel list that have been handed to the kernel (it skips pixels that already have a list).
+    uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0; hipEvent_t evBeam = nullptr; uint64_t beamSeq = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> beamDone; uint64_t beamDoneGen = 0;
+    size_t beamBytes() const { return beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); }
+    size_t ctxBytes() const { size_t b = 0; for (const PassCtx &c : ctx) b += c.bytes(); return b; }
     KzPassInfo lastInfo{};
 };
 struct KzReplicaSet { std::mutex m; std::vector<KzDeviceState *> v; };

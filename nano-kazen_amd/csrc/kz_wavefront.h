@@ -998,6 +998,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 //                     (nothing in front of t_valid: tmin; the hit found so far: tmax).
 // The lists depend on the pixels only: a pass context keeps them for the pixel chunk it last built them for.
 #define KZ_BEAM_STACK 32              // open entries (ref + key) per beam in LDS
+#define KZ_BEAM_UNBUILT 0xFFFFFFFFu   // head count of a pixel whose list has not been built
 __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T, const uint32_t *__restrict__ pixList, uint32_t nPix, int LS,
                                                        uint2 *__restrict__ entries, uint2 *__restrict__ heads) {
     // BEST-FIRST order: the open entries (child ref + entry distance of its padded box) of a lane form an unsorted set in LDS
@@ -1008,8 +1009,12 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T
     uint32_t *stk = s_stack + threadIdx.x, *kst = s_stack + LS * KZ_BLOCK + threadIdx.x;
     const uint32_t pl = blockIdx.x * KZ_BLOCK + threadIdx.x;
     const uint32_t root = P.rootRef4;
-    bool active = pl < nPix && root != 0xFFFFFFFFu;
     const uint32_t pxy = pl < nPix ? pixList[pl] : 0u;
+    // The lists live per pixel of the FRAME (index y * width + x), whatever tile set or pixel chunk the pixel is rendered in: a pixel's list is built
+    // once per replica (the camera belongs to the scene) - a head count of KZ_BEAM_UNBUILT marks a pixel nobody has built yet.
+    const uint32_t fpix = (pxy >> 16) * (uint32_t)P.width + (pxy & 0xffffu);
+    const bool todo = pl < nPix && heads[fpix].x == KZ_BEAM_UNBUILT;
+    bool active = todo && root != 0xFFFFFFFFu;
     const float fx = (float)(pxy & 0xffffu), fy = (float)(pxy >> 16);
     const V3 O = mk(P.beamO[0], P.beamO[1], P.beamO[2]), U = mk(P.beamU[0], P.beamU[1], P.beamU[2]), V = mk(P.beamV[0], P.beamV[1], P.beamV[2]);
     // unit directions through the pixel's centre and corners (world axes; nearP = A + sx U + sy V)
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T
                 rz = 1.0f / (fabsf(uc.z) < 1e-20f ? copysignf(1e-20f, uc.z) : uc.z);
     float tvalid = KZ_INF;                                // distance from the pinhole before which nothing is left unexplored
     uint32_t cur = root, count = 0; float curKey = 0.f; int n = 0;
-    uint2 *myList = entries + (size_t)pl * KZ_BEAM_CAP;
+    uint2 *myList = entries + (size_t)fpix * KZ_BEAM_CAP;
     auto push = [&](uint32_t ref, uint32_t keyBits) {
         if (n < LS) { stk[n * KZ_BLOCK] = ref; kst[n * KZ_BLOCK] = keyBits; ++n; return; }
         int im = 0; uint32_t km = kst[0];                 // full: the farthest of the set and the newcomer stays out
@@ -1081,13 +1086,14 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T
         }
         if (!__any(active)) break;
     }
-    if (pl < nPix) heads[pl] = make_uint2(count, __float_as_uint(tvalid));      // (distances from the pinhole: kz_wf_trace_list scales its ray parameters by |d|)
+    if (todo) heads[fpix] = make_uint2(count, __float_as_uint(tvalid));      // (distances from the pinhole: kz_wf_trace_list scales its ray parameters by |d|)
 }
 
 // stats only: pixels with a list, list entries, pixels whose list is complete (t_valid = infinity)
-__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam_count(const uint2 *__restrict__ heads, uint32_t nPix, unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam_count(const uint2 *__restrict__ heads, const uint32_t *__restrict__ pixList, int width, uint32_t nPix, unsigned long long *__restrict__ out) {
     const uint32_t pl = blockIdx.x * KZ_BLOCK + threadIdx.x;
-    const uint2 h = pl < nPix ? heads[pl] : make_uint2(0u, 0u);
+    uint2 h = make_uint2(0u, 0u);
+    if (pl < nPix) { const uint32_t pxy = pixList[pl]; h = heads[(pxy >> 16) * (uint32_t)width + (pxy & 0xffffu)]; }
     unsigned long long v[3] = {pl < nPix ? 1ull : 0ull, (unsigned long long)h.x, (pl < nPix && !(__uint_as_float(h.y) < KZ_INF)) ? 1ull : 0ull};
     for (int k = 0; k < 3; ++k) {
         unsigned long long x = v[k];
@@ -1098,7 +1104,7 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam_count(const uint2 *__rest
 
 // closest hit of the camera rays from the pixel lists; rays the lists cannot decide go to fbQueue (kz_wf_trace_packet takes them)
 template <bool STATS, bool FIX>
-__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTables T, KzWf W, uint32_t nItems, uint32_t S, const uint2 *__restrict__ entries,
+__global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t nItems, uint32_t S, const uint2 *__restrict__ entries,
                                                              const uint2 *__restrict__ heads, uint32_t *__restrict__ fbQueue, uint32_t *__restrict__ fbCount,
                                                              uint32_t *__restrict__ fixQueue, uint32_t *__restrict__ fixCount) {
     const uint32_t slot = blockIdx.x * KZ_BLOCK + threadIdx.x;
@@ -1164,8 +1170,8 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_trace_list(KzParams P, KzDevTa
         // first lane's pixel (an SGPR), so the head and the entries arrive through the scalar cache and an entry's load no longer queues behind the
         // lanes' vector loads of the triangle before it. Waves that span pixels walk per-lane lists.
         const uint32_t plU = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl);
-        if (__all(pl == plU)) walkShared(entries + (size_t)plU * KZ_BEAM_CAP, heads[plU]);
-        else walk(entries + (size_t)pl * KZ_BEAM_CAP, heads[pl]);
+        if (__all(pl == plU)) { const uint32_t pxy = pixList[plU], fp = (pxy >> 16) * (uint32_t)P.width + (pxy & 0xffffu); walkShared(entries + (size_t)fp * KZ_BEAM_CAP, heads[fp]); }
+        else { const uint32_t pxy = pixList[pl], fp = (pxy >> 16) * (uint32_t)P.width + (pxy & 0xffffu); walk(entries + (size_t)fp * KZ_BEAM_CAP, heads[fp]); }
         // decided: a hit in front of everything unexplored, or nothing unexplored at all (a non-finite ray hits nothing)
         undecided = finite && !(found ? bt * lenUp < tvalidDist : !(tvalidDist < KZ_INF));
         if (STATS && !undecided) cn.rays++;                                    // (an undecided ray is counted by the kernel that decides it)

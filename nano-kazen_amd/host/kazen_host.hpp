@@ -788,7 +788,8 @@ inline std::vector<float> render(Scene *scene, int device = 0) {
     int32_t w, hh, b;
     kz_film_dims(h, &w, &hh, &b);
     std::vector<float> film((size_t)(w + 2 * b) * (hh + 2 * b) * 4), rgb((size_t)w * hh * 3);
-    if (kz_film_download_on(h, device, film.data(), film.size()) != KZ_OK) throw Exception(std::string("kz_film_download: ") + kz_last_error());
+    if (kz_film_download(h, film.data(), film.size()) != KZ_OK)      // (the scene is resident on that one device: its primary replica)
+        throw Exception(std::string("kz_film_download: ") + kz_last_error());
     kz_film_to_rgb(film.data(), w, hh, b, rgb.data());
     return rgb;
 }

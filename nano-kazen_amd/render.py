@@ -90,12 +90,31 @@ class Scene:
         arr = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
         dev = (self.device or 0) if device is None else int(device)
         n = self.packed_floats(tiles) if packed else (self.height + 2 * self.border) * (self.width + 2 * self.border) * 4
+        o.packedOutput = 1 if packed else 0
         out = np.empty(n, np.float32) if (download or packed) else None
         abi.check(self.lib, self.lib.kz_render_tiles(self.h, C.byref(o), arr, len(tiles), dev,
                                                       out.ctypes.data_as(abi.f32p) if out is not None else None, n if out is not None else 0))
         if out is None or packed:
             return out
         return out.reshape(self.height + 2 * self.border, self.width + 2 * self.border, 4)
+
+    def render_dealt(self, tiles, counter, takers=1, batch_tiles=0, device=None, sample_begin=0, sample_end=0, **kw):
+        """kz_render_tiles with a KzTileDealer: `tiles` is the WHOLE list every taker passes, `counter` a numpy uint32 array of one element that all
+        takers share (process-local, or a np.memmap of a file in /dev/shm for the ranks of a node; zeroed by the launcher). Renders the batches this
+        call wins and returns the tiles it took, in the order it took them (hand them to film_tiles for the gather)."""
+        o, _ = self._opts(sample_begin, sample_end, **kw)
+        arr = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
+        dev = (self.device or 0) if device is None else int(device)
+        taken = np.zeros(2 * len(tiles) + 2, np.uint32)
+        n_taken = np.zeros(1, np.uint32)
+        assert counter.dtype == np.uint32 and counter.size >= 1
+        dl = abi.KzTileDealer(counter.ctypes.data_as(abi.u32p), int(batch_tiles), int(takers), taken.ctypes.data_as(abi.u32p), taken.size, n_taken.ctypes.data_as(abi.u32p))
+        o.dealer = C.pointer(dl)
+        abi.check(self.lib, self.lib.kz_render_tiles(self.h, C.byref(o), arr, len(tiles), dev, None, 0))
+        out = []
+        for k in range(0, int(n_taken[0]), 2):
+            out += list(tiles[int(taken[k]):int(taken[k + 1])])
+        return out
 
     def packed_floats(self, tiles):
         arr = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])

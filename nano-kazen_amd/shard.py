@@ -54,57 +54,95 @@ def gather_films(film, rank, world):
     return None
 
 
-def gather_tiles(scene, tiles, packed, rank, world, tile=64):
-    """The host gather of a multi-process launch (one rank per GPU of ONE node), SURVEY 8e: every rank hands the PACKED film rects of ITS tiles
-    (kz_film_download_tiles: each tile with its filter apron, 1.13 x the tile's texels) to rank 0, and rank 0 adds them into one film, rank
-    after rank, tiles in list order (kz_film_merge_tiles = ImageBlock::put(ImageBlock&), block.cpp:87-96, over row bands on host threads).
-    The rects travel through shared memory (/dev/shm: the ranks share a host), the CPU process group (gloo) only carries the name and the
-    two barriers; without /dev/shm they travel by gloo. No RCCL, no device collective; the volume is one film in all, however many ranks.
-    Returns the film on rank 0, None elsewhere."""
+def gather_tiles(scene, tiles, packed, rank, world, tile=None):
+    """The host gather of a multi-process launch (one rank per GPU of ONE node), SURVEY 8e: every rank hands the PACKED film rects of the tiles IT
+    rendered (kz_film_download_tiles: each tile with its filter apron, 1.13 x the tile's texels) to rank 0, and rank 0 adds them into one film, rank
+    after rank, tiles in each rank's list order (kz_film_merge_tiles = ImageBlock::put(ImageBlock&), block.cpp:87-96, over row bands on host threads).
+    `tiles` is THIS rank's list - whatever dealt it (kz_deal_tiles, or the batches a KzTileDealer handed out): the lists travel with the rects, nothing
+    is recomputed on rank 0. The rects go through shared memory (/dev/shm: the ranks share a host), the CPU process group (gloo) carries the tile lists
+    and the flags; without /dev/shm the rects travel by gloo too. No RCCL, no device collective; the volume is one film in all, however many ranks.
+    A failure on any rank (or on rank 0 while it merges) is raised on EVERY rank instead of leaving the others in a barrier.
+    Returns the film on rank 0, None elsewhere. (`tile` is accepted for callers of the round-3 signature and ignored.)"""
     import os
     import numpy as np
     import torch
     import torch.distributed as dist
+    tiles = [tuple(int(v) for v in t) for t in tiles]
+    packed = np.ascontiguousarray(packed, np.float32)
     if world == 1:
         return scene.merge_tiles(scene.empty_film(), tiles, packed)
-    packed = np.ascontiguousarray(packed, np.float32)
+    if packed.size != scene.packed_floats(tiles):
+        raise ValueError("gather_tiles: %d floats for %d tiles, kz_tiles_packed_floats says %d" % (packed.size, len(tiles), scene.packed_floats(tiles)))
     token = [os.urandom(6).hex() if rank == 0 else None]
     dist.broadcast_object_list(token, src=0)
+    lists = [None] * world
+    dist.all_gather_object(lists, tiles)                       # every rank's tile list, as rendered
     path = lambda r: "/dev/shm/kz_gather_%s_%d.f32" % (token[0], r)
     ok = torch.ones(1, dtype=torch.int32)
     try:
-        packed.tofile(path(rank))
+        if packed.size:
+            packed.tofile(path(rank))
     except OSError:
         ok[0] = 0
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)                  # every rank wrote its file (this is also the barrier behind the writes)
-    film = None
+    film, err = None, None
     try:
         if int(ok[0]):
             if rank == 0:
-                film = scene.empty_film()
-                for r in range(world):
-                    tl = deal_tiles(scene.width, scene.height, world, r, tile)
-                    scene.merge_tiles(film, tl, np.memmap(path(r), dtype=np.float32, mode="r"))
-            dist.barrier()                                     # rank 0 has read everything
+                try:
+                    film = scene.empty_film()
+                    for r in range(world):
+                        if lists[r]:
+                            scene.merge_tiles(film, lists[r], np.fromfile(path(r), dtype=np.float32))
+                except Exception as e:                         # noqa: BLE001 - reported to every rank below
+                    err, film = e, None
         else:                                                  # no shared memory: the rects go through the process group
-            sizes = [scene.packed_floats(deal_tiles(scene.width, scene.height, world, r, tile)) for r in range(world)]
-            buf = np.zeros(max(sizes), np.float32)
+            sizes = [scene.packed_floats(lists[r]) if lists[r] else 0 for r in range(world)]
+            buf = np.zeros(max(max(sizes), 1), np.float32)
             buf[:packed.size] = packed
             t = torch.from_numpy(buf)
             if rank == 0:
                 bufs = [torch.empty_like(t) for _ in range(world)]
                 dist.gather(t, bufs, dst=0)
-                film = scene.empty_film()
-                for r in range(world):
-                    scene.merge_tiles(film, deal_tiles(scene.width, scene.height, world, r, tile), bufs[r].numpy()[:sizes[r]])
+                try:
+                    film = scene.empty_film()
+                    for r in range(world):
+                        if lists[r]:
+                            scene.merge_tiles(film, lists[r], bufs[r].numpy()[:sizes[r]])
+                except Exception as e:                         # noqa: BLE001
+                    err, film = e, None
             else:
                 dist.gather(t, None, dst=0)
+        done = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+        dist.broadcast(done, src=0)                            # rank 0 has read everything - or failed: every rank learns which
+        if not int(done[0]):
+            raise RuntimeError("gather_tiles: the merge on rank 0 failed%s" % (": %s" % err if err is not None else ""))
     finally:
         try:
             os.unlink(path(rank))
         except OSError:
             pass
     return film
+
+
+def shared_counter(rank, world, name=None):
+    """The counter of a KzTileDealer for the ranks of one node: a uint32 in a /dev/shm file that every rank maps (Scene.render_dealt takes the array).
+    Rank 0 creates and zeroes it; collective (two gloo barriers). Returns (array, path); the caller unlinks the path on rank 0 when done."""
+    import os
+    import numpy as np
+    import torch.distributed as dist
+    token = [name or (os.urandom(6).hex() if rank == 0 else None)]
+    if world > 1:
+        dist.broadcast_object_list(token, src=0)
+    path = "/dev/shm/kz_deal_%s.u32" % token[0]
+    if rank == 0:
+        np.zeros(16, np.uint32).tofile(path)                   # (one cache line: the counter is word 0)
+    if world > 1:
+        dist.barrier()
+    arr = np.memmap(path, dtype=np.uint32, mode="r+", shape=(16,))
+    if world > 1:
+        dist.barrier()
+    return arr, path
 
 
 def pack_rects_host(film, tiles, border):

@@ -20,7 +20,7 @@
 // /root/reference. Draw order hazards H1..H11 are listed in SURVEY.md section 7.
 // Compile: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
 // =====================================================================================
-#include "../include/kazen_mi355x.h"
+#include "../include/kazen_mi355x_dev.h"
 
 #include <algorithm>
 #include <atomic>

@@ -2,6 +2,7 @@
 // model (parser.cpp:116-301: children first, createInstance, addChild, activate), then either dumps the flattened
 // description as JSON (no GPU needed) or renders on GPU 0 and writes the linear rgb bitmap to a file.
 #include "../../nano-kazen_amd/host/kazen_host.hpp"
+#include "../../include/kazen_mi355x_dev.h"      // (the test also reads the BVH statistics: development surface)
 #include "../../nano-kazen_amd/host/kazen_sceneio.hpp"
 
 #include <cstdio>

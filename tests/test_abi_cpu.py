@@ -12,8 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol(kz):
     lib = kz.abi.load_library()
-    hdr = open(os.path.join(ROOT, "include", "kazen_mi355x.h")).read()
-    declared = set(re.findall(r"\b(kz_[a-z0-9_]+)\s*\(", hdr))
+    decl = lambda name: set(re.findall(r"^(?:int|void|const char \*)\s*\*?(kz_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", name)).read(), re.M))
+    product, dev = decl("kazen_mi355x.h"), decl("kazen_mi355x_dev.h")
+    # the product header is what a maintainer's adapter includes: at most twenty entry points; everything else is the development surface
+    assert product == set(kz.abi.PRODUCT_EXPORTS) and len(product) <= 20, product ^ set(kz.abi.PRODUCT_EXPORTS)
+    declared = product | dev
+    assert not (product & dev)
     assert declared == set(kz.abi.EXPORTS), declared ^ set(kz.abi.EXPORTS)
     for sym in declared:
         assert getattr(lib, sym) is not None
@@ -25,9 +29,9 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
     import subprocess
     a = kz.abi
     names = ["KzBSDF", "KzImage", "KzTexture", "KzLight", "KzMesh", "KzFilter", "KzCamera", "KzSampler", "KzIntegrator", "KzBackground",
-             "KzSceneDesc", "KzTile", "KzTuning", "KzRenderOpts", "KzPassInfo", "KzStats", "KzHit", "KzBvhInfo"]
+             "KzSceneDesc", "KzTile", "KzTuning", "KzTileDealer", "KzRenderOpts", "KzPassInfo", "KzStats", "KzHit", "KzBvhInfo"]
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include "kazen_mi355x.h"\nint main(void){' +
+    src.write_text('#include <stdio.h>\n#include "kazen_mi355x_dev.h"\nint main(void){' +
                    "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}\n")
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
@@ -37,12 +41,13 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
     assert C.sizeof(a.KzBSDF) == 128 and C.sizeof(a.KzTexture) == 64
 
 
-def test_render_opts_layout_v4(kz):
-    """ABI v4: the v2 / v3 prefix of KzRenderOpts keeps its offsets (a zero-extended older struct means "defaults"); v4 appends tileDealing."""
+def test_render_opts_layout_v5(kz):
+    """ABI v5: the v2 / v3 / v4 prefix of KzRenderOpts keeps its offsets (a zero-extended older struct means "defaults"); v4 appended tileDealing,
+    v5 names the word behind it (packedOutput) and appends the dealer. KzTuning keeps its 16 words (the experiment fields are dev0..dev5 now)."""
     o = kz.abi.KzRenderOpts
     assert (o.sampleBegin.offset, o.sampleEnd.offset, o.tiles.offset, o.nTiles.offset, o.pipeline.offset, o.accumulate.offset, o.stream.offset) == (0, 4, 8, 16, 20, 24, 32)
     assert o.device.offset == 40 and o.passItems.offset == 48 and o.maxStateBytes.offset == 56 and o.tune.offset == 64
-    assert C.sizeof(kz.abi.KzTuning) == 64 and o.tileDealing.offset == 128 and C.sizeof(o) == 136
+    assert C.sizeof(kz.abi.KzTuning) == 64 and o.tileDealing.offset == 128 and o.packedOutput.offset == 132 and o.dealer.offset == 136 and C.sizeof(o) == 144
 
 
 @pytest.mark.parametrize("w,h,tile,parts", [(1920, 1080, 64, 8), (3840, 2160, 64, 8), (1920, 1080, 128, 3), (100, 70, 32, 5), (64, 64, 64, 4)])

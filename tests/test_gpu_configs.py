@@ -169,6 +169,79 @@ def test_render_multi_equals_single_device(gpu_lib, kz, O):
         sc.render_multi([0, 0])
 
 
+def test_tile_sets_change_without_rebuilding_what_they_share(gpu_lib, kz, O):
+    """A change of tile set costs a tile-descriptor upload and one expansion kernel (no stream synchronisation, no host-built index), and the beam
+    lists live per pixel of the FRAME: rendering the frame as two tile sets, then as one, gives the one-shot film, and the whole-frame film is the same
+    bit for bit before and after (the lists built for the halves are the ones the whole frame uses)."""
+    desc = kz.scenes.cornell_box(200, 136, 8, sampler="pmj02bn")
+    sc = kz.Scene(desc, device=0)
+    sc.render()
+    whole = sc.film()
+    left = [(0, 0, 96, 136)]
+    right = [(96, 0, 64, 72), (160, 0, 40, 136), (96, 72, 64, 64)]         # ragged tiles: partial 8x8 blocks at their right / bottom edges
+    sc.set_stats(True); sc.stats(reset=True)
+    sc.render(tiles=left)
+    sc.render(tiles=right, accumulate=True)
+    st = sc.stats(reset=True); sc.set_stats(False)
+    assert st["samples"] == 200 * 136 * 8
+    assert np.allclose(sc.film(), whole, rtol=1e-5, atol=1e-6)
+    sc.render()
+    assert np.array_equal(sc.film(), whole)
+    # the pixel list of a ragged tile is what the host used to build: every pixel of the tile once, 8x8 blocks row-major
+    sc.render(tiles=[(160, 0, 40, 136)])
+    f = sc.film()
+    b = sc.border
+    assert (f[b:-b, b + 160 + b:, 3] > 0).all() and (f[:, :b + 160 - b, 3] == 0).all()
+    with pytest.raises(kz.abi.KzError) as e:
+        sc.render(tiles=[(0, 0, 64, 64), (32, 32, 64, 64)])
+    assert "overlap" in str(e.value)
+    with pytest.raises(kz.abi.KzError) as e:
+        sc.render(tiles=[(0, 0, 60, 60), (59, 10, 20, 20)])                # off the 8-px grid: pairwise test
+    assert "overlap" in str(e.value)
+
+
+def test_packed_output_is_said_not_inferred(gpu_lib, kz):
+    """with a border-less (box) filter a full tiling packs to exactly the film's size. kz_render_tiles learns which layout the buffer
+    has from KzRenderOpts.packedOutput, never from the size."""
+    desc = kz.scenes.cornell_box(96, 64, 4)
+    desc.camera["rfilter"] = {"type": "box"}
+    sc = kz.Scene(desc, device=0)
+    assert sc.border == 0
+    tiles = kz.shard.deal_tiles(96, 64, 1, 0, 32)
+    assert len(tiles) == 6 and sc.packed_floats(tiles) == 96 * 64 * 4
+    f = sc.render_tiles(tiles, device=0)                                 # whole film, although the packed rects would fit the buffer exactly
+    assert np.array_equal(f, sc.film())
+    packed = sc.render_tiles(tiles, device=0, packed=True)
+    assert not np.array_equal(packed.reshape(f.shape), f)                # tile-major rects, not scan lines
+    assert np.array_equal(sc.merge_tiles(sc.empty_film(), tiles, packed), f)
+    arr = (kz.abi.KzTile * 3)(*[kz.abi.KzTile(*t) for t in tiles[:3]])
+    o = kz.abi.KzRenderOpts()
+    o.packedOutput = 1                                                   # packed rects of three tiles do not fill a whole-film buffer: refused, not guessed
+    assert sc.lib.kz_render_tiles(sc.h, C.byref(o), arr, 3, 0, f.ctypes.data_as(kz.abi.f32p), f.size) == kz.abi.KZ_ERR_INVALID_ARG
+
+
+def test_tile_dealer_takes_every_tile_once(gpu_lib, kz, O):
+    """KzTileDealer (ABI v5): ONE kz_render_tiles call renders the batches it wins from the counter, passes in flight across batch boundaries; the
+    tiles it reports are the tiles on its film. One taker takes the whole list; a second call on a spent counter takes nothing."""
+    desc = kz.scenes.cornell_box(200, 136, 8, sampler="pmj02bn")
+    sc = kz.Scene(desc, device=0)
+    sc.render()
+    whole = sc.film()
+    tiles = kz.shard.deal_tiles(200, 136, 1, 0, 32)
+    counter = np.zeros(1, np.uint32)
+    took = sc.render_dealt(tiles, counter, takers=1, batch_tiles=3, pass_items=32 * 32 * 3 * 4)       # two passes per batch of three tiles
+    assert took == tiles and counter[0] >= len(tiles)
+    assert np.allclose(sc.film(), whole, rtol=1e-5, atol=1e-6)
+    assert np.allclose(sc.merge_tiles(sc.empty_film(), took, sc.film_tiles(took)), whole, rtol=1e-5, atol=1e-6)
+    assert sc.render_dealt(tiles, counter, takers=1, batch_tiles=3) == []
+    # two takers, one after the other on this GPU (an 8-GPU node runs them side by side): the second starts where the first was stopped
+    counter[0] = 0
+    a = sc.render_dealt(tiles[:], counter, takers=2, batch_tiles=0)
+    fa = sc.film_tiles(a)
+    assert a == tiles                                                     # (alone at the counter, it wins every batch)
+    assert np.allclose(sc.merge_tiles(sc.empty_film(), a, fa), whole, rtol=1e-5, atol=1e-6)
+
+
 def test_replicas_and_device_addressing(gpu_lib, kz):
     sc = kz.Scene(kz.scenes.cornell_box(48, 48, 2))
     with pytest.raises(kz.abi.KzError) as e:
@@ -245,7 +318,7 @@ def test_state_budget_and_pass_options(gpu_lib, kz, O):
     info = sc.last_pass_info()
     assert (info["passes"], info["sppPerPass"], info["pixelsPerPass"]) == (8, 24, 960)
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
-    per_item, per_pixel = 8 * 16 + 16 + 12 + 20, 25 * 16 + 33 * 8              # path state + sample record per item; film tap sums + beam list per pixel
+    per_item, per_pixel = 8 * 16 + 16 + 12 + 20, 25 * 16                       # path state + sample record per item; film tap sums per pixel (the beam lists, one per FRAME pixel, are the replica's)
     cap = 2 * npx * (3 * per_item + per_pixel)
     sc.render(max_state_bytes=cap)                                    # room for two contexts of 3 spp
     info = sc.last_pass_info()
@@ -289,7 +362,8 @@ def test_experiment_kernels_stay_bit_identical():
     """The rejected experiments (kz_experiments.h: BVH2 per-lane traversal, per-lane key stack, LDS top-of-tree, decoupled leaf queue,
     mixed launches, the non-persistent round-1 launches) live in a -DKZ_EXPERIMENTS build only. It is run in a child process (one
     library per process) and every variant must reproduce the product kernels' film bit for bit."""
-    env = dict(os.environ, KZ_LIB_PATH=EXPERIMENTS_LIB)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("KZ_BVH_")}      # (the development build reads its builder sweeps from KZ_BVH_*: build the product's tree)
+    env["KZ_LIB_PATH"] = EXPERIMENTS_LIB
     code = r"""
 import importlib, sys, numpy as np
 sys.path.insert(0, %r)

@@ -554,3 +554,19 @@ def test_exact_reciprocal_and_sqrt_equal_ieee_for_every_float(gpu_lib, kz):
     kz.abi.check(gpu_lib, gpu_lib.kz_debug_exact_math_check(0, C.byref(r), C.byref(s), C.byref(n)))
     assert n.value == 1 << 32
     assert r.value == 0 and s.value == 0, (r.value, s.value)
+
+
+def test_permute_on_the_device_matches_the_reference_text(gpu_lib, kz):
+    """random::permute as the sampler kernels compute it (kz_devfn.h permuteIdx, with its power-of-two shortcut) against the vectors minted by compiling
+    the reference's own text of common.cpp:300-346 (oracle/kat_ref_permute.cpp -> tests/golden/int_kats.json)."""
+    import json
+    import os
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "int_kats.json")))
+    rows = [(i, l, int(k) & 0xffffffff, o) for i, l, k, o in kats["permute"]]
+    for e in kats["permute_full"]:
+        rows += [(i, e["l"], e["key"], o) for i, o in enumerate(e["out"])]
+    i, l, p, want = (np.array(c, np.uint32) for c in zip(*rows))
+    got = np.zeros(len(rows), np.uint32)
+    f = lambda a: a.ctypes.data_as(kz.abi.u32p)
+    kz.abi.check(gpu_lib, gpu_lib.kz_debug_permute(0, len(rows), f(i), f(l), f(p), f(got)))
+    assert np.array_equal(got, want)

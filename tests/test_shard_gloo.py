@@ -24,7 +24,25 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, use_gpu):
+def _take_batches(counter, n_tiles, batch):
+    """What KzTileDealer does in the library (an atomic fetch-add on a counter the ranks share), spelt with a file lock for the CPU test of the host logic."""
+    import fcntl
+    got = []
+    with open(counter, "r+b") as f:
+        while True:
+            fcntl.flock(f, fcntl.LOCK_EX)
+            f.seek(0)
+            b = int(np.frombuffer(f.read(4), np.uint32)[0])
+            f.seek(0)
+            f.write(np.uint32(b + batch).tobytes())
+            f.flush()
+            fcntl.flock(f, fcntl.LOCK_UN)
+            if b >= n_tiles:
+                return got
+            got.append((b, min(n_tiles, b + batch)))
+
+
+def _worker(rank, world, port, out, use_gpu, dynamic=False):
     import importlib
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -33,23 +51,36 @@ def _worker(rank, world, port, out, use_gpu):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     desc = kz.scenes.cornell_box(W, H, SPP)
     tiles = kz.shard.deal_tiles(W, H, world, rank, 32)
+    all_tiles = kz.shard.deal_tiles(W, H, 1, 0, 32)
+    counter, cpath = kz.shard.shared_counter(rank, world) if dynamic else (None, None)
     if use_gpu:
         dev = rank % kz.abi.load_library().kz_device_count()          # distinct devices wherever the box has them
         sc = kz.Scene(desc, device=dev)
-        packed = sc.render_tiles(tiles, device=dev, packed=True)       # the product path: every rank hands over the rects of ITS tiles
+        if dynamic:                                                    # KzTileDealer on a counter in shared memory: every rank passes the WHOLE list
+            tiles = sc.render_dealt(all_tiles, counter, takers=world, batch_tiles=2, device=dev)
+            packed = sc.film_tiles(tiles, device=dev)
+        else:
+            packed = sc.render_tiles(tiles, device=dev, packed=True)   # the product path: every rank hands over the rects of ITS tiles
         dist.barrier()
-        merged = kz.shard.gather_tiles(sc, tiles, packed, rank, world, 32)
+        merged = kz.shard.gather_tiles(sc, tiles, packed, rank, world)
     else:
         import oracle as O
-        film = O.OracleScene(desc).render(tiles=tiles, threads=1)
+        if dynamic:
+            tiles = [t for b, e in _take_batches(cpath, len(all_tiles), 2) for t in all_tiles[b:e]]
+        film = O.OracleScene(desc).render(tiles=tiles, threads=1) if tiles else np.zeros((H + 4, W + 4, 4), np.float32)
         sc = kz.Scene(desc)                                            # host side only (no replica): sizes and kz_film_merge_tiles
         dist.barrier()
-        merged = kz.shard.gather_tiles(sc, tiles, kz.shard.pack_rects_host(film, tiles, sc.border), rank, world, 32)
+        merged = kz.shard.gather_tiles(sc, tiles, kz.shard.pack_rects_host(film, tiles, sc.border), rank, world)
         whole = kz.shard.gather_films(film, rank, world)               # the same through whole films
         if rank == 0:
             assert np.array_equal(merged, whole)
+    every = [None] * world
+    dist.all_gather_object(every, [tuple(t) for t in tiles])
     if rank == 0:
         np.save(out, merged)
+        assert sorted(t for l in every for t in l) == sorted(tuple(t) for t in all_tiles)      # every tile rendered exactly once, whoever took it
+        if cpath:
+            os.unlink(cpath)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,12 +94,24 @@ def test_two_rank_tile_sharding_matches_single_process(kz, O, tmp_path):
     assert np.allclose(merged, whole, rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.gpu
-def test_two_rank_hip_sharding_matches_one_shot(gpu_lib, kz, O, tmp_path):
-    """The N > 1 HIP path itself: two processes, each with its own replica on GPU 0, tiles dealt by kz_deal_tiles, host gather."""
+def test_two_rank_dynamic_dealing_gathers_what_each_rank_took(kz, O, tmp_path):
+    """Dynamic dealing across processes (host logic): the ranks take batches from a counter in /dev/shm, render what they won (CPU oracle) and the
+    gather merges each rank's own list - nothing on rank 0 assumes a static deal."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "film.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, False, True), nprocs=2, join=True)
+    whole = O.OracleScene(kz.scenes.cornell_box(W, H, SPP)).render(threads=1)
+    assert np.allclose(np.load(out), whole, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_two_rank_hip_sharding_matches_one_shot(gpu_lib, kz, O, tmp_path, dynamic):
+    """The N > 1 HIP path itself: two processes, each with its own replica on GPU 0, tiles dealt by kz_deal_tiles - or taken in batches from a
+    KzTileDealer whose counter lives in memory the two processes share -, host gather."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "film.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out, True, dynamic), nprocs=2, join=True)
     merged = np.load(out)
     desc = kz.scenes.cornell_box(W, H, SPP)
     sc = kz.Scene(desc, device=0)
