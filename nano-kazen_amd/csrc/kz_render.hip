@@ -814,12 +814,19 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     if (dealer) {
         if (!dealer->counter || (dealer->takenCap && (!dealer->taken || !dealer->nTaken))) return kz_fail(KZ_ERR_INVALID_ARG, "KzTileDealer: null counter / taken buffer");
         if (pipeline != 2) return kz_fail(KZ_ERR_UNSUPPORTED, "dynamic tile dealing needs the wavefront pipeline");
-        const uint64_t itemsPerTile = std::max<uint64_t>(1, (uint64_t)ds->nPix / std::max<uint32_t>(1, nTilesSet)) * nSamples;
+        // a batch = about two passes' worth of (pixel, sample) items, never more (so that its pixels x half its samples fill a pass exactly when the
+        // tiles are equal), at most 1 / (4 x takers) of the list; counted with the LARGEST tile, and the pass shape below with the largest batch
+        uint64_t maxTile = 1;
+        for (uint32_t t = 0; t < nTilesSet; ++t) maxTile = std::max<uint64_t>(maxTile, ds->tilePixOffset[t + 1] - ds->tilePixOffset[t]);
         batchTiles = dealer->batchTiles ? dealer->batchTiles
-                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((2 * (uint64_t)wantItems + itemsPerTile - 1) / itemsPerTile, std::max<uint32_t>(1, nTilesSet / (4 * std::max<uint32_t>(1, dealer->takers)))));
+                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(2 * (uint64_t)wantItems / std::max<uint64_t>(1, maxTile * nSamples), std::max<uint32_t>(1, nTilesSet / (4 * std::max<uint32_t>(1, dealer->takers)))));
         if (dealer->nTaken) *dealer->nTaken = 0;
     }
-    const uint32_t nPixSet = dealer ? (uint32_t)std::min<uint64_t>(ds->nPix, (uint64_t)batchTiles * std::max<uint32_t>(1, ds->nPix / std::max<uint32_t>(1, nTilesSet))) : ds->nPix;
+    uint32_t nPixSet = ds->nPix;
+    if (dealer) {                                            // (batches start at multiples of batchTiles: the counter only ever advances by that)
+        nPixSet = 1;
+        for (uint32_t tb = 0; tb < nTilesSet; tb += batchTiles) nPixSet = std::max(nPixSet, ds->tilePixOffset[std::min(nTilesSet, tb + batchTiles)] - ds->tilePixOffset[tb]);
+    }
     uint32_t S, pixPerPass;
     if (opts->tune.sppPerPass > 0) { S = std::min<uint32_t>((uint32_t)opts->tune.sppPerPass, nSamples); pixPerPass = (uint32_t)std::min<size_t>(nPixSet, std::max<size_t>(64, wantItems / S / 64 * 64)); }
     else {

@@ -10,6 +10,8 @@
     python scripts/probe.py ab --variants tree,NAME[,NAME2...] [--scenes c4,c3] [--reps 2] [--spp 256] [--tune ...] [--out DIR]
                                                          same-call A/B: `stages` in a child process per (repetition, build, scene); NAME = a build made by
                                                          scripts/build_variant.sh NAME <flags> (tree = the in-tree product). Lines go to gpurun_out/DIR/ab.txt
+    python scripts/probe.py dealing [--scene c5] [--spp 256] [--reps 2]
+                                                         kz_render_multi with static and with dynamic dealing (KzTileDealer) on the devices of this box, same process
     KZ_LIB_PATH=nano-kazen_amd/csrc/variants/lanestat/libkazen_mi355x.so python scripts/probe.py lanestat
                                                          where the lanes of the traversal loop are (needs scripts/build_variant.sh lanestat -DKZ_LANESTAT)
     KZ_LIB_PATH=nano-kazen_amd/csrc/variants/shadestat/libkazen_mi355x.so python scripts/probe.py shadestat
@@ -145,6 +147,47 @@ def cmd_sched(a):
                           "film_maxrel": float(np.max(np.abs(film - ref) / np.maximum(np.abs(ref), 1e-3)))}), flush=True)
 
 
+def cmd_dealing(a):
+    """static vs dynamic dealing of one fixed job on the devices of this box: kz_render_multi on C5 (or --scene) x --spp samples,
+    each form warmed once and timed --reps times, same process. Dynamic dealing = one kz_render_tiles call per device with a KzTileDealer."""
+    desc = scene(a.scene)
+    sc = kz.Scene(desc)
+    ndev = kz.abi.load_library().kz_device_count()
+    devs = list(range(min(ndev, 8)))
+    spp = a.spp or 256
+    n = sc.width * sc.height * spp
+    out = {"scene": a.scene, "spp": spp, "devices": devs}
+    ref = None
+    for name, kw in (("static", {}), ("dynamic", {"tile_dealing": 1}), ("static_again", {})):
+        sc.render_multi(devs, sample_begin=0, sample_end=spp, **kw)
+        ts = []
+        for _ in range(a.reps):
+            t0 = time.perf_counter(); film, ms = sc.render_multi(devs, sample_begin=0, sample_end=spp, **kw); ts.append(time.perf_counter() - t0)
+        if ref is None:
+            ref = film
+        out[name] = {"s": [round(t, 4) for t in ts], "Msamples_per_s": round(n / min(ts) / 1e6, 1), "device_ms": [round(float(x), 1) for x in ms],
+                     "max_abs_diff_vs_static": float(np.max(np.abs(film - ref)))}
+        print(name, out[name], flush=True)
+    out["dynamic_over_static"] = round(min(out["dynamic"]["s"]) / min(min(out["static"]["s"]), min(out["static_again"]["s"])), 4)
+    print(json.dumps(out), flush=True)
+    # one device, the dealer driven directly: batch sizes (tiles) and pass shapes
+    tiles = kz.shard.deal_tiles(sc.width, sc.height, 1, 0, 64)
+    counter = np.zeros(1, np.uint32)
+    for case in (a.values.split(";") if a.values else []):
+        bt, spass = (int(x) for x in case.split(","))
+        kw = {"tune": {"sppPerPass": spass}} if spass else {}
+        ts = []
+        for _ in range(a.reps + 1):
+            counter[0] = 0
+            t0 = time.perf_counter()
+            if bt >= 0:
+                took = sc.render_dealt(tiles, counter, takers=1, batch_tiles=bt, device=0, sample_begin=0, sample_end=spp, **kw)
+            else:
+                sc.render_tiles(tiles, device=0, sample_begin=0, sample_end=spp, download=False, **kw)
+            ts.append(time.perf_counter() - t0)
+        print(json.dumps({"batch_tiles": bt, "sppPerPass": spass, "s": [round(t, 4) for t in ts[1:]], "Msamples_per_s": round(n / min(ts[1:]) / 1e6, 1), "passes": sc.last_pass_info()}), flush=True)
+
+
 def cmd_ab(a):
     """Box-to-box variance is 3-6 %, so only numbers from ONE gpurun call compare: alternate the builds, each in its own child process."""
     import subprocess
@@ -164,11 +207,11 @@ def cmd_ab(a):
 
 
 ap = argparse.ArgumentParser()
-ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters", "shadestat", "sched", "ab"])
+ap.add_argument("cmd", choices=["configs", "stages", "sweep", "lanestat", "counters", "shadestat", "sched", "ab", "dealing"])
 ap.add_argument("--variants", default="tree"); ap.add_argument("--scenes", default="c4,c3"); ap.add_argument("--reps", type=int, default=2); ap.add_argument("--out", default="")
 ap.add_argument("c5", nargs="?")
 ap.add_argument("--scene", default="c4"); ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--tune", default=""); ap.add_argument("--opts", default="")
 ap.add_argument("--all-kiss", action="store_true"); ap.add_argument("--knob", default="refill"); ap.add_argument("--values", default="")
 a = ap.parse_args()
-{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters, "shadestat": cmd_shadestat, "sched": cmd_sched, "ab": cmd_ab}[a.cmd](a)
+{"configs": cmd_configs, "stages": cmd_stages, "sweep": cmd_sweep, "lanestat": cmd_lanestat, "counters": cmd_counters, "shadestat": cmd_shadestat, "sched": cmd_sched, "ab": cmd_ab, "dealing": cmd_dealing}[a.cmd](a)
