@@ -997,7 +997,9 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 //                     to kz_wf_trace / kz_wf_trace_packet. The other rays go to fbQueue for the packet kernel with what is known about them
 //                     (nothing in front of t_valid: tmin; the hit found so far: tmax).
 // The lists depend on the pixels only: a pass context keeps them for the pixel chunk it last built them for.
-#define KZ_BEAM_STACK 32              // open entries (ref + key) per beam in LDS
+#ifndef KZ_BEAM_STACK
+#define KZ_BEAM_STACK 16              // open entries (ref + key) per beam in LDS. 32 until round 4: 64 KB per workgroup = 2 waves per SIMD; 16 = 5 waves per SIMD and half the
+#endif                                // scan: kz_wf_beam 10.6 -> 6.4 ms on the C4 frame with the same lists downstream (list 2.8 ms, packet 0.5 ms per pass); 12: the packet kernel doubles, 8: x 16 (profiles/r04h_beam)
 #define KZ_BEAM_UNBUILT 0xFFFFFFFFu   // head count of a pixel whose list has not been built
 __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T, const uint32_t *__restrict__ pixList, uint32_t nPix, int LS,
                                                        uint2 *__restrict__ entries, uint2 *__restrict__ heads) {
@@ -1047,44 +1049,40 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_wf_beam(KzParams P, KzDevTables T
         if (im != n) { stk[im * KZ_BLOCK] = stk[n * KZ_BLOCK]; kst[im * KZ_BLOCK] = kst[n * KZ_BLOCK]; }
         return true;
     };
-    for (;;) {
-        // ---- node phase
-        for (;;) {
-            const bool inner = active && !(cur & 0x80000000u);
-            if (__ballot(inner) == 0ull) break;
-            if (inner) {
-                const uint4 *np = kzNode4Ptr(T, cur);
-                const uint4 q0 = np[0], q1 = np[1], q2 = np[2], refs = np[3];
-                const float sX = __uint_as_float(q0.w), sY = __uint_as_float(q2.z), sZ = __uint_as_float(q2.w);
-                const float pX = __uint_as_float(q0.x) - O.x, pY = __uint_as_float(q0.y) - O.y, pZ = __uint_as_float(q0.z) - O.z;     // box coordinates relative to the pinhole
-                const uint32_t r[4] = {refs.x, refs.y, refs.z, refs.w};
+    // One loop, one step per iteration for every lane that still works on its pixel: a lane that holds an inner node tests its four children, a lane that
+    // holds a leaf writes it to the list, and both take the nearest open entry next. (Until round 4 this was a while-while loop - all lanes descend, then all
+    // lanes at a leaf append - but a best-first walk reaches a leaf every few steps, each lane at another time, and the lanes spent their time waiting for
+    // one another: 19 of 64 busy.)
+    while (__any(active)) {
+        bool needPop = false;
+        if (active && !(cur & 0x80000000u)) {
+            const uint4 *np = kzNode4Ptr(T, cur);
+            const uint4 q0 = np[0], q1 = np[1], q2 = np[2], refs = np[3];
+            const float sX = __uint_as_float(q0.w), sY = __uint_as_float(q2.z), sZ = __uint_as_float(q2.w);
+            const float pX = __uint_as_float(q0.x) - O.x, pY = __uint_as_float(q0.y) - O.y, pZ = __uint_as_float(q0.z) - O.z;     // box coordinates relative to the pinhole
+            const uint32_t r[4] = {refs.x, refs.y, refs.z, refs.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float qlx = (float)((q1.x >> (8 * i)) & 0xffu), qly = (float)((q1.y >> (8 * i)) & 0xffu), qlz = (float)((q1.z >> (8 * i)) & 0xffu);
-                    const float qhx = (float)((q1.w >> (8 * i)) & 0xffu), qhy = (float)((q2.x >> (8 * i)) & 0xffu), qhz = (float)((q2.y >> (8 * i)) & 0xffu);
-                    const float lx = fmaf(qlx, sX, pX), ly = fmaf(qly, sY, pY), lz = fmaf(qlz, sZ, pZ), hx = fmaf(qhx, sX, pX), hy = fmaf(qhy, sY, pY), hz = fmaf(qhz, sZ, pZ);
-                    // pad: rho x an upper bound of the distance of the box's farthest point, + 2^-19 of the coordinates (the quantised planes
-                    // are conservative for the kernels' own slab expression; this form rounds differently)
-                    const float reach = fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy)) + fmaxf(fabsf(lz), fabsf(hz));
-                    const float pad = rho * reach + 1.9e-6f * (reach + fabsf(O.x) + fabsf(O.y) + fabsf(O.z));
-                    const float t0x = (lx - pad) * rx, t1x = (hx + pad) * rx, t0y = (ly - pad) * ry, t1y = (hy + pad) * ry, t0z = (lz - pad) * rz, t1z = (hz + pad) * rz;
-                    const float nn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
-                    const float ff = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * 1.0000004f;
-                    // a child's bound is not below its parent's (its padded box lies inside the parent's; the max guards the rounding)
-                    const float key = fmaxf(nn * 0.999999f, curKey);
-                    if (qhx >= qlx && nn <= ff && key < tvalid) push(r[i], __float_as_uint(key));      // (an empty slot has qlo = 255 > qhi = 0)
-                }
-                if (!popMin()) active = false;
+            for (int i = 0; i < 4; ++i) {
+                const float qlx = (float)((q1.x >> (8 * i)) & 0xffu), qly = (float)((q1.y >> (8 * i)) & 0xffu), qlz = (float)((q1.z >> (8 * i)) & 0xffu);
+                const float qhx = (float)((q1.w >> (8 * i)) & 0xffu), qhy = (float)((q2.x >> (8 * i)) & 0xffu), qhz = (float)((q2.y >> (8 * i)) & 0xffu);
+                const float lx = fmaf(qlx, sX, pX), ly = fmaf(qly, sY, pY), lz = fmaf(qlz, sZ, pZ), hx = fmaf(qhx, sX, pX), hy = fmaf(qhy, sY, pY), hz = fmaf(qhz, sZ, pZ);
+                // pad: rho x an upper bound of the distance of the box's farthest point, + 2^-19 of the coordinates (the quantised planes
+                // are conservative for the kernels' own slab expression; this form rounds differently)
+                const float reach = fmaxf(fabsf(lx), fabsf(hx)) + fmaxf(fabsf(ly), fabsf(hy)) + fmaxf(fabsf(lz), fabsf(hz));
+                const float pad = rho * reach + 1.9e-6f * (reach + fabsf(O.x) + fabsf(O.y) + fabsf(O.z));
+                const float t0x = (lx - pad) * rx, t1x = (hx + pad) * rx, t0y = (ly - pad) * ry, t1y = (hy + pad) * ry, t0z = (lz - pad) * rz, t1z = (hz + pad) * rz;
+                const float nn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.f));
+                const float ff = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * 1.0000004f;
+                // a child's bound is not below its parent's (its padded box lies inside the parent's; the max guards the rounding)
+                const float key = fmaxf(nn * 0.999999f, curKey);
+                if (qhx >= qlx && nn <= ff && key < tvalid) push(r[i], __float_as_uint(key));      // (an empty slot has qlo = 255 > qhi = 0)
             }
+            needPop = true;
+        } else if (active) {
+            if (count < KZ_BEAM_CAP) { myList[count] = make_uint2(cur, __float_as_uint(curKey)); ++count; needPop = true; }
+            else { tvalid = fminf(tvalid, curKey); active = false; }      // the list is full: this leaf and all that is open begin no nearer
         }
-        // ---- leaf phase
-        if (active && (cur & 0x80000000u)) {
-            if (count < KZ_BEAM_CAP) {
-                myList[count] = make_uint2(cur, __float_as_uint(curKey)); ++count;
-                if (!popMin()) active = false;
-            } else { tvalid = fminf(tvalid, curKey); active = false; }      // the list is full: this leaf and all that is open begin no nearer
-        }
-        if (!__any(active)) break;
+        if (needPop && !popMin()) active = false;
     }
     if (todo) heads[fpix] = make_uint2(count, __float_as_uint(tvalid));      // (distances from the pinhole: kz_wf_trace_list scales its ray parameters by |d|)
 }
