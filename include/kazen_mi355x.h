@@ -90,8 +90,15 @@ typedef struct KzImage {
  *   COLORRAMP: child[0] = nested (absent: evaluates to 0, texture.cpp:170)
  *   BLEND:     child[0] = "mask" (absent: 0.5), child[1] = "input1" (absent: 0), child[2] = "input2" (absent: 1)
  * IMAGE: texture.cpp:46-64 calls OpenImageIO's TextureSystem::texture(s = u*scale, t = (1-v)*scale, zero derivatives,
- * periodic wrap). OpenImageIO is not part of the reference checkout; this library defines the lookup as BILINEAR over the
- * full-resolution level, texel centres at (i+0.5)/width, then Color3f::toLinearRGB when srgb != 0. */
+ * periodic wrap) with a default-constructed TextureOpt. OpenImageIO is not part of the reference checkout, so the filter behind
+ * that call cannot be restated from source; it is an explicit FIELD here (`filter`), over the full-resolution level with texel
+ * centres at (i+0.5)/width, followed by Color3f::toLinearRGB when srgb != 0:
+ *   KZ_TEXFILTER_BILINEAR (0, the default)  the 2 x 2 lookup SURVEY 8f rank 4 specifies;
+ *   KZ_TEXFILTER_BICUBIC  (1)               the 4 x 4 cubic B-spline - what OpenImageIO's default interpolation mode ("smart bicubic": bicubic
+ *                                           whenever the lookup MAGNIFIES, which zero derivatives always do) most likely evaluates. HAZARD, recorded
+ *                                           in DESIGN.md 2: which of the two the reference's renders used cannot be settled without OpenImageIO. */
+#define KZ_TEXFILTER_BILINEAR 0
+#define KZ_TEXFILTER_BICUBIC 1
 typedef struct KzTexture {
     int32_t type;               /* KZ_TEX_*                                            */
     float color[3];             /* CONSTANT: "color" (default 0.5)                     */
@@ -101,7 +108,8 @@ typedef struct KzTexture {
     float rampMin, rampMax;     /* COLORRAMP: "min" (0), "max" (1)                     */
     int32_t blendMode;          /* BLEND: KZ_BLEND_* ("blendmode", default "mix")      */
     int32_t child[3];
-    int32_t pad_[3];
+    int32_t filter;             /* IMAGE (also as the nested texture of a background): KZ_TEXFILTER_*  */
+    int32_t pad_[2];
 } KzTexture;
 
 /* BSDF row. Replaces the BSDF subclasses; parameters that the reference reads through a Texture<Color3f> child
@@ -210,7 +218,8 @@ typedef struct KzIntegrator {
  * The environment lookup is OpenImageIO's TextureSystem::environment (un-vendored). This library DECLARES it as the latitude-longitude
  * map with y up that OpenImageIO applies to OpenEXR environment maps:
  *     s = atan2f(-d.x, d.z) / (2 pi) + 0.5      t = 0.5 - atan2f(d.y, hypotf(d.z, -d.x)) / pi      (NaN -> 0)
- * bilinear over the full-resolution level, texel centres at (i + 0.5) / res, s periodic, t clamped at the poles. */
+ * filtered as the nested texture's `filter` says (bilinear by default) over the full-resolution level, texel centres at (i + 0.5) / res,
+ * s periodic, t clamped at the poles. */
 typedef struct KzBackground {
     int32_t present;            /* 0: Scene::getBackgroundColor returns 0 (scene.cpp:55-56) */
     float color[3];

@@ -45,7 +45,7 @@ class KzImage(C.Structure):
 
 class KzTexture(C.Structure):
     _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("image", C.c_int32), ("scale", C.c_float), ("srgb", C.c_int32),
-                ("rampMin", C.c_float), ("rampMax", C.c_float), ("blendMode", C.c_int32), ("child", C.c_int32 * 3), ("pad_", C.c_int32 * 3)]
+                ("rampMin", C.c_float), ("rampMax", C.c_float), ("blendMode", C.c_int32), ("child", C.c_int32 * 3), ("filter", C.c_int32), ("pad_", C.c_int32 * 2)]
 
 
 class KzLight(C.Structure):

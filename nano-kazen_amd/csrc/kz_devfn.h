@@ -953,30 +953,55 @@ __device__ __forceinline__ int wrapPeriodic(int i, int n) { i %= n; return i < 0
 __device__ __forceinline__ float srgbToLinear(float v) {                           // Color3f::toLinearRGB, common.cpp:368-382
     return v <= 0.04045f ? v * (1.0f / 12.92f) : powf((v + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
-// ImageTexture::eval (texture.cpp:46-64): s = u*scale, t = (1-v)*scale, periodic wrap; bilinear as declared in kazen_mi355x.h
-__device__ V3 imageLookup(const KzDevTables &T, uint32_t image, float scale, uint32_t srgb, float u, float v) {
+// Taps and weights of one axis of an image lookup at continuous texel coordinate x (texel centres at i + 0.5, so x = s * res - 0.5): the two taps of the
+// bilinear filter or the four of the cubic B-spline (KzTexture.filter). The 2-tap form is the arithmetic the lookup had before the filter became a field:
+// (1 - f) * a + f * b.
+struct KzTaps { int first, n; float w[4]; };
+__device__ __forceinline__ KzTaps filterTaps(int filter, float x) {
+    KzTaps t;
+    const float x0 = floorf(x), f = x - x0;
+    if (filter == KZ_TEXFILTER_BICUBIC) {
+        const float omf = 1.0f - f, f2 = f * f, f3 = f2 * f;
+        t.first = (int)x0 - 1; t.n = 4;
+        t.w[0] = omf * omf * omf * (1.0f / 6.0f);
+        t.w[1] = (3.0f * f3 - 6.0f * f2 + 4.0f) * (1.0f / 6.0f);
+        t.w[2] = (-3.0f * f3 + 3.0f * f2 + 3.0f * f + 1.0f) * (1.0f / 6.0f);
+        t.w[3] = f3 * (1.0f / 6.0f);
+    } else { t.first = (int)x0; t.n = 2; t.w[0] = 1.0f - f; t.w[1] = f; t.w[2] = t.w[3] = 0.0f; }
+    return t;
+}
+// the filtered texel of channel c: rows left to right, then the rows top to bottom (the oracle adds in the same order)
+template <bool CLAMP_Y>
+__device__ __forceinline__ float filteredTexel(const KzImageRow &im, const uint8_t *base, const KzTaps &tx, const KzTaps &ty, int c) {
+    float r = 0.0f;
+    for (int j = 0; j < ty.n; ++j) {
+        const int y = CLAMP_Y ? min(max(ty.first + j, 0), im.height - 1) : wrapPeriodic(ty.first + j, im.height);
+        float row = tx.w[0] * texelAt(im, base, wrapPeriodic(tx.first, im.width), y, c);
+        for (int i = 1; i < tx.n; ++i) row = row + tx.w[i] * texelAt(im, base, wrapPeriodic(tx.first + i, im.width), y, c);
+        r = j == 0 ? ty.w[0] * row : r + ty.w[j] * row;
+    }
+    return r;
+}
+// ImageTexture::eval (texture.cpp:46-64): s = u*scale, t = (1-v)*scale, periodic wrap; the filter is KzTexture.filter (kazen_mi355x.h)
+__device__ V3 imageLookup(const KzDevTables &T, uint32_t image, float scale, uint32_t flags, float u, float v) {
     const KzImageRow im = T.images[image];
     const uint8_t *base = T.texels + im.offset;
+    const uint32_t srgb = flags & 1u; const int filter = (int)(flags >> 1);
     const float s = u * scale, t = (1.0f - v) * scale;
     const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
     if (!(fabsf(x) < 1.0e9f) || !(fabsf(y) < 1.0e9f)) return mk(0.f);             // non-finite uv: defined as black
-    const float fx0 = floorf(x), fy0 = floorf(y);
-    const float fx = x - fx0, fy = y - fy0;
-    const int x0 = wrapPeriodic((int)fx0, im.width), x1 = wrapPeriodic((int)fx0 + 1, im.width);
-    const int y0 = wrapPeriodic((int)fy0, im.height), y1 = wrapPeriodic((int)fy0 + 1, im.height);
+    const KzTaps tx = filterTaps(filter, x), ty = filterTaps(filter, y);
     float r[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float top = (1.0f - fx) * texelAt(im, base, x0, y0, c) + fx * texelAt(im, base, x1, y0, c);
-        const float bot = (1.0f - fx) * texelAt(im, base, x0, y1, c) + fx * texelAt(im, base, x1, y1, c);
-        r[c] = (1.0f - fy) * top + fy * bot;
+        r[c] = filteredTexel<false>(im, base, tx, ty, c);
         if (srgb) r[c] = srgbToLinear(r[c]);
     }
     return mk(r[0], r[1], r[2]);
 }
 // ImageTexture::eval(Vector3f) (texture.cpp:66-80): the environment lookup, as include/kazen_mi355x.h declares it (y-up latitude-longitude
-// map, bilinear, s periodic, t clamped; no scale, no colour-space conversion)
-__device__ V3 envLookup(const KzDevTables &T, uint32_t image, V3 d) {
+// map, s periodic, t clamped; no scale, no colour-space conversion; the nested texture's filter)
+__device__ V3 envLookup(const KzDevTables &T, uint32_t image, int filter, V3 d) {
     const KzImageRow im = T.images[image];
     const uint8_t *base = T.texels + im.offset;
     float s = atan2f(-d.x, d.z) / (2.0f * KZ_PI_F) + 0.5f;
@@ -984,23 +1009,16 @@ __device__ V3 envLookup(const KzDevTables &T, uint32_t image, V3 d) {
     if (isnan(s)) s = 0.0f;
     if (isnan(t)) t = 0.0f;
     const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
-    const float fx0 = floorf(x), fy0 = floorf(y);
-    const float fx = x - fx0, fy = y - fy0;
-    const int x0 = wrapPeriodic((int)fx0, im.width), x1 = wrapPeriodic((int)fx0 + 1, im.width);
-    const int y0 = min(max((int)fy0, 0), im.height - 1), y1 = min(max((int)fy0 + 1, 0), im.height - 1);
+    const KzTaps tx = filterTaps(filter, x), ty = filterTaps(filter, y);
     float r[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float top = (1.0f - fx) * texelAt(im, base, x0, y0, c) + fx * texelAt(im, base, x1, y0, c);
-        const float bot = (1.0f - fx) * texelAt(im, base, x0, y1, c) + fx * texelAt(im, base, x1, y1, c);
-        r[c] = (1.0f - fy) * top + fy * bot;
-    }
+    for (int c = 0; c < 3; ++c) r[c] = filteredTexel<true>(im, base, tx, ty, c);
     return mk(r[0], r[1], r[2]);
 }
 // Scene::getBackgroundColor (scene.cpp:54-79) -> BackgroundTexture::eval(Vector3f) (texture.cpp:121-126); the caller has checked bgPresent
 __device__ __forceinline__ V3 backgroundRadiance(const KzParams &P, const KzDevTables &T, V3 d) {
     if (isnan(d.x) || isnan(d.y) || isnan(d.z)) return mk(0.f);
-    if (P.bgImage >= 0) return P.bgIntensity * envLookup(T, (uint32_t)P.bgImage, d);
+    if (P.bgImage >= 0) return P.bgIntensity * envLookup(T, (uint32_t)P.bgImage, P.bgFilter, d);
     return mk(P.bgRadiance[0], P.bgRadiance[1], P.bgRadiance[2]);
 }
 __device__ __forceinline__ float clampRef(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   // common.h:237-243

@@ -98,7 +98,8 @@ static int emitTexture(const KzSceneDesc *d, KzScene *sc, int32_t t, int depthBu
         return KZ_OK;
     case KZ_TEX_IMAGE:
         if (k.image < 0 || k.image >= (int32_t)d->nImages) return kz_fail(KZ_ERR_INVALID_ARG, "texture %d: image index %d out of range", t, k.image);
-        op.op = KZ_TOP_IMAGE; op.a = (uint32_t)k.image; op.f0 = k.scale; op.b = k.srgb ? 1u : 0u;
+        if (k.filter != KZ_TEXFILTER_BILINEAR && k.filter != KZ_TEXFILTER_BICUBIC) return kz_fail(KZ_ERR_INVALID_ARG, "texture %d: filter %d (KZ_TEXFILTER_BILINEAR or KZ_TEXFILTER_BICUBIC)", t, k.filter);
+        op.op = KZ_TOP_IMAGE; op.a = (uint32_t)k.image; op.f0 = k.scale; op.b = (k.srgb ? 1u : 0u) | ((uint32_t)k.filter << 1);
         sc->texOps.push_back(op); stackNow++; stackMax = std::max(stackMax, stackNow);
         return KZ_OK;
     case KZ_TEX_COLORRAMP: {
@@ -381,7 +382,8 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
             if (k.type == KZ_TEX_CONSTANT) { col[0] = k.color[0]; col[1] = k.color[1]; col[2] = k.color[2]; }
             else if (k.type == KZ_TEX_IMAGE) {
                 if (k.image < 0 || (uint32_t)k.image >= d->nImages) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "background image index %d out of range", k.image); }
-                p.bgImage = k.image; col[0] = col[1] = col[2] = 0.f;
+                if (k.filter != KZ_TEXFILTER_BILINEAR && k.filter != KZ_TEXFILTER_BICUBIC) { delete sc; return kz_fail(KZ_ERR_INVALID_ARG, "background texture: filter %d", k.filter); }
+                p.bgImage = k.image; p.bgFilter = k.filter; col[0] = col[1] = col[2] = 0.f;
             } else col[0] = col[1] = col[2] = 0.f;
         }
         for (int a = 0; a < 3; ++a) p.bgRadiance[a] = d->background.present ? d->background.intensity * col[a] : 0.f;

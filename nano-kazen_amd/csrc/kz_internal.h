@@ -69,7 +69,7 @@ struct KzTexOp {
     uint32_t op;           // KZ_TOP_*
     uint32_t a;            // IMAGE: image row; BLEND: KZ_BLEND_*
     float f0, f1, f2;      // CONST: colour; IMAGE: f0 = scale; RAMP: f0 = min, f1 = max
-    uint32_t b;            // IMAGE: srgb flag
+    uint32_t b;            // IMAGE: bit 0 = srgb, bits 1.. = KZ_TEXFILTER_*
     uint32_t pad[2];
 };
 static_assert(sizeof(KzTexOp) == 32, "texture op must be 32 B");
@@ -100,6 +100,7 @@ struct KzParams {
     float lightPickScale;                // nLights when that is a power of two (x / lightPickPdf == x * nLights bit for bit), else 0
     int32_t bgPresent; float bgRadiance[3];          // constant background: intensity * colour
     int32_t bgImage; float bgIntensity;             // environment map: row of `images` (-1: none) and the intensity it is scaled by
+    int32_t bgFilter; int32_t bgPad_;               // KZ_TEXFILTER_* of that lookup (the nested texture's `filter`)
     // film (block.cpp:13-21)
     float filterRadius, lookupFactor; int32_t tapLo, tapHi;
     uint32_t rootRef;

@@ -205,6 +205,10 @@ class ImageTexture : public Texture {
 public:
     explicit ImageTexture(const PropertyList &p) {
         m_filename = p.getString("filename", ""); m_colorspace = p.getString("colorspace", "srgb"); m_scale = p.getFloat("scale", 1.0f);
+        // not a property of the reference: which filter stands in for OpenImageIO's TextureSystem::texture (KzTexture.filter; "bilinear" is the declared default)
+        const std::string f = p.getString("filter", "bilinear");
+        if (f != "bilinear" && f != "bicubic") throw Exception("imagetexture: filter \"" + f + "\" (bilinear or bicubic)");
+        m_filter = f == "bicubic" ? KZ_TEXFILTER_BICUBIC : KZ_TEXFILTER_BILINEAR;
         if (!m_filename.empty()) load(resolveFile(m_filename));          // texture.cpp:40: getFileResolver()->resolve(fileName)
     }
     void setRaster(int width, int height, int channels, int format, const void *pixels) {
@@ -217,6 +221,7 @@ public:
         KzImage im{}; im.pixels = m_px.data(); im.width = m_w; im.height = m_h; im.channels = m_c; im.format = m_fmt;
         rb.images.push_back(im);
         KzTexture k{}; k.type = KZ_TEX_IMAGE; k.image = (int32_t)rb.images.size() - 1; k.scale = m_scale; k.srgb = m_colorspace == "srgb" ? 1 : 0;
+        k.filter = m_filter;
         k.child[0] = k.child[1] = k.child[2] = -1;
         return k;
     }
@@ -251,7 +256,7 @@ private:
         } else { std::fclose(f); m_px.clear(); return; }     // another container (PNG, EXR, ...): the raster must come through setRaster
         std::fclose(f);
     }
-    std::string m_filename, m_colorspace; float m_scale; int m_w = 0, m_h = 0, m_c = 0, m_fmt = KZ_PIXEL_U8; std::vector<uint8_t> m_px;
+    std::string m_filename, m_colorspace; float m_scale; int m_filter = KZ_TEXFILTER_BILINEAR, m_w = 0, m_h = 0, m_c = 0, m_fmt = KZ_PIXEL_U8; std::vector<uint8_t> m_px;
 };
 class ColorRampTexture : public Texture {            // texture.cpp:149-195
 public:

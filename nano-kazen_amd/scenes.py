@@ -104,13 +104,14 @@ def constanttexture(color=(0.5, 0.5, 0.5)):
     return {"type": "constanttexture", "color": tuple(color)}
 
 
-def imagetexture(image, scale=1.0, colorspace="srgb"):
-    """image: (H, W, C) uint8 or float32 raster, row 0 = top scan line (what OpenImageIO decodes from the file)."""
+def imagetexture(image, scale=1.0, colorspace="srgb", filter="bilinear"):
+    """image: (H, W, C) uint8 or float32 raster, row 0 = top scan line (what OpenImageIO decodes from the file). filter: "bilinear" (the declared
+    default) or "bicubic" (cubic B-spline: KzTexture.filter, the OpenImageIO hazard of DESIGN.md 2)."""
     a = np.asarray(image)
     if a.ndim == 2:
         a = a[:, :, None]
     a = np.ascontiguousarray(a, np.uint8 if a.dtype == np.uint8 else np.float32)
-    return {"type": "imagetexture", "image": a, "scale": float(scale), "colorspace": colorspace}
+    return {"type": "imagetexture", "image": a, "scale": float(scale), "colorspace": colorspace, "filter": filter}
 
 
 def colorramp(nested=None, min=0.0, max=1.0):
@@ -279,6 +280,7 @@ class SceneDescription:
                       "blend": abi.KZ_TEX_BLEND}.get(t["type"], 99)
             k.color[:] = t.get("color", (0.5, 0.5, 0.5))
             k.image, k.scale, k.srgb = row["image"], t.get("scale", 1.0), 1 if t.get("colorspace", "srgb") == "srgb" else 0
+            k.filter = {"bilinear": 0, "bicubic": 1}[t.get("filter", "bilinear")]       # KZ_TEXFILTER_* (the OpenImageIO hazard: include/kazen_mi355x.h)
             k.rampMin, k.rampMax = t.get("min", 0.0), t.get("max", 1.0)
             k.blendMode = {"mix": abi.KZ_BLEND_MIX, "multiply": abi.KZ_BLEND_MULTIPLY}.get(t.get("blendmode", "mix"), abi.KZ_BLEND_NONE)
             k.child[:] = row["child"]
@@ -733,4 +735,23 @@ def random_triangles(n_tris=1000000, width=1920, height=1080, spp=1024, sampler=
     s.camera.update(width=width, height=height, fov=40.0, nearClip=0.01, farClip=100.0,
                     toWorld=look_at((0, 0, 3.4), (0, 0, 0), (0, 1, 0)))
     s.sampler = {"type": sampler, "sampleCount": spp, "seed": seed}
+    return s
+
+
+def load_npz(path, overrides=None):
+    """A SceneDescription from a flattened scene file (tests/golden/make_q1_scene.py: the arrays a scene's loader produced + its parameters as JSON).
+    `overrides`: dict of dicts merged into camera / sampler / integrator, as in xmlscene.load_xml."""
+    import json
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    s = SceneDescription()
+    for i, m in enumerate(meta["meshes"]):
+        a = {k: (z["m%d_%s" % (i, k)] if k in m["has"] else None) for k in ("V", "F", "N", "UV")}
+        s.add_mesh(a["V"], a["F"], a["N"], a["UV"], bsdf=m["bsdf"], light=m["light"])
+    s.camera.update(meta["camera"])
+    s.camera["toWorld"] = np.asarray(z["camera_toWorld"], np.float32)
+    s.sampler.update(meta["sampler"]); s.integrator.update(meta["integrator"])
+    s.background = meta["background"]
+    for k, v in (overrides or {}).items():
+        getattr(s, k).update(v)
     return s

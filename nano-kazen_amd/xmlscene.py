@@ -149,7 +149,7 @@ def _texture(node, base, folded=False):
         if "filename" not in p:
             raise ValueError("imagetexture needs a \"filename\"")
         fn = p["filename"] if os.path.isabs(p["filename"]) else os.path.join(base, p["filename"])     # the resolver appends the scene's directory (main.cpp)
-        return S.imagetexture(_load_image(fn), p.get("scale", 1.0), p.get("colorspace", "srgb"))
+        return S.imagetexture(_load_image(fn), p.get("scale", 1.0), p.get("colorspace", "srgb"), p.get("filter", "bilinear"))      # ("filter": this library's own property, KzTexture.filter)
     if t == "colorramp":
         if len(kids) > 1:
             raise ValueError("colorramp takes one nested texture")

@@ -708,8 +708,9 @@ static inline float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f +
 // textures (src/kazen/texture.cpp). ImageTexture::eval hands (u*scale, (1-v)*scale) with zero
 // derivatives and periodic wrap to OpenImageIO's TextureSystem::texture (texture.cpp:46-64). OpenImageIO (pinned only
 // as "find_package(OpenImageIO)" by the reference, no version, not vendored) is absent from the checkout, so its
-// filter cannot be restated from source: the lookup is DECLARED as bilinear over the full-resolution level with
-// texel centres at (i+0.5)/res, as SURVEY 8f row 4 specifies. Parity of this one function is unpinned.
+// filter cannot be restated from source: it is a FIELD of KzTexture (bilinear, as SURVEY 8f row 4 specifies, by default; cubic
+// B-spline = what OpenImageIO's default "smart bicubic" mode most likely evaluates for these magnifying lookups), over the
+// full-resolution level with texel centres at (i+0.5)/res. Parity of this one function is unpinned.
 // ---------------------------------------------------------------------------------
 static inline float texelAt(const Scene::Image &im, int x, int y, int c) {
     if (c >= im.c) return 0.0f;                                                  // missing channels: TextureOpt::fill = 0
@@ -721,20 +722,40 @@ static inline int wrapPeriodic(int i, int n) { i %= n; return i < 0 ? i + n : i;
 static inline float srgbToLinear(float v) {                                      // Color3f::toLinearRGB, common.cpp:368-382
     return v <= 0.04045f ? v * (1.0f / 12.92f) : std::pow((v + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
+// taps and weights of one axis: the two of the bilinear lookup or the four of the cubic B-spline (KzTexture.filter, include/kazen_mi355x.h)
+struct Taps { int first, n; float w[4]; };
+static inline Taps filterTaps(int filter, float x) {
+    Taps t;
+    const float x0 = std::floor(x), f = x - x0;
+    if (filter == KZ_TEXFILTER_BICUBIC) {
+        const float omf = 1.0f - f, f2 = f * f, f3 = f2 * f;
+        t.first = (int)x0 - 1; t.n = 4;
+        t.w[0] = omf * omf * omf * (1.0f / 6.0f);
+        t.w[1] = (3.0f * f3 - 6.0f * f2 + 4.0f) * (1.0f / 6.0f);
+        t.w[2] = (-3.0f * f3 + 3.0f * f2 + 3.0f * f + 1.0f) * (1.0f / 6.0f);
+        t.w[3] = f3 * (1.0f / 6.0f);
+    } else { t.first = (int)x0; t.n = 2; t.w[0] = 1.0f - f; t.w[1] = f; t.w[2] = t.w[3] = 0.0f; }
+    return t;
+}
+static inline float filteredTexel(const Scene::Image &im, const Taps &tx, const Taps &ty, int c, bool clampY) {
+    float r = 0.0f;
+    for (int j = 0; j < ty.n; ++j) {
+        const int y = clampY ? std::min(std::max(ty.first + j, 0), im.h - 1) : wrapPeriodic(ty.first + j, im.h);
+        float row = tx.w[0] * texelAt(im, wrapPeriodic(tx.first, im.w), y, c);
+        for (int i = 1; i < tx.n; ++i) row = row + tx.w[i] * texelAt(im, wrapPeriodic(tx.first + i, im.w), y, c);
+        r = j == 0 ? ty.w[0] * row : r + ty.w[j] * row;
+    }
+    return r;
+}
 static V3 imageLookup(const Scene &sc, const KzTexture &k, float u, float v) {
     const Scene::Image &im = sc.images[k.image];
     float s = u * k.scale, t = (1.0f - v) * k.scale;                             // texture.cpp:55
     float x = s * (float)im.w - 0.5f, y = t * (float)im.h - 0.5f;
     if (!(std::fabs(x) < 1.0e9f) || !(std::fabs(y) < 1.0e9f)) return V3(0.f);
-    float fx0 = std::floor(x), fy0 = std::floor(y);
-    float fx = x - fx0, fy = y - fy0;
-    int x0 = wrapPeriodic((int)fx0, im.w), x1 = wrapPeriodic((int)fx0 + 1, im.w);
-    int y0 = wrapPeriodic((int)fy0, im.h), y1 = wrapPeriodic((int)fy0 + 1, im.h);
+    const Taps tx = filterTaps(k.filter, x), ty = filterTaps(k.filter, y);
     float r[3];
     for (int c = 0; c < 3; ++c) {
-        float top = (1.0f - fx) * texelAt(im, x0, y0, c) + fx * texelAt(im, x1, y0, c);
-        float bot = (1.0f - fx) * texelAt(im, x0, y1, c) + fx * texelAt(im, x1, y1, c);
-        r[c] = (1.0f - fy) * top + fy * bot;
+        r[c] = filteredTexel(im, tx, ty, c, false);
         if (k.srgb) r[c] = srgbToLinear(r[c]);                                   // texture.cpp:60-61
     }
     return V3(r[0], r[1], r[2]);
@@ -1487,23 +1508,16 @@ static V3 lightSample(const Scene &sc, const KzLight &l, const MeshData &md, LRe
 
 // ImageTexture::eval(Vector3f) (texture.cpp:66-80): OpenImageIO's TextureSystem::environment is not part of the checkout; the lookup is
 // the one include/kazen_mi355x.h declares (y-up latitude-longitude map, bilinear, s periodic, t clamped; no scale, no toLinearRGB)
-static V3 envLookup(const Scene &sc, int image, V3 d) {
+static V3 envLookup(const Scene &sc, int image, int filter, V3 d) {
     const Scene::Image &im = sc.images[image];
     float s = std::atan2(-d.x, d.z) / (2.0f * 3.14159265358979323846f) + 0.5f;
     float t = 0.5f - std::atan2(d.y, std::hypot(d.z, -d.x)) / 3.14159265358979323846f;
     if (std::isnan(s)) s = 0.0f;
     if (std::isnan(t)) t = 0.0f;
     float x = s * (float)im.w - 0.5f, y = t * (float)im.h - 0.5f;
-    float fx0 = std::floor(x), fy0 = std::floor(y);
-    float fx = x - fx0, fy = y - fy0;
-    int x0 = wrapPeriodic((int)fx0, im.w), x1 = wrapPeriodic((int)fx0 + 1, im.w);
-    int y0 = std::min(std::max((int)fy0, 0), im.h - 1), y1 = std::min(std::max((int)fy0 + 1, 0), im.h - 1);
+    const Taps tx = filterTaps(filter, x), ty = filterTaps(filter, y);
     float r[3];
-    for (int c = 0; c < 3; ++c) {
-        float top = (1.0f - fx) * texelAt(im, x0, y0, c) + fx * texelAt(im, x1, y0, c);
-        float bot = (1.0f - fx) * texelAt(im, x0, y1, c) + fx * texelAt(im, x1, y1, c);
-        r[c] = (1.0f - fy) * top + fy * bot;
-    }
+    for (int c = 0; c < 3; ++c) r[c] = filteredTexel(im, tx, ty, c, true);
     return V3(r[0], r[1], r[2]);
 }
 static V3 backgroundColor(const Scene &sc, V3 dir) {                              // scene.cpp:54-79, texture.cpp:121-126
@@ -1512,7 +1526,7 @@ static V3 backgroundColor(const Scene &sc, V3 dir) {                            
     if (sc.bg.texture != 0) {                                                    // nested->eval(Vector3f) by texture class
         const KzTexture &k = sc.textures[sc.bg.texture - 1];
         if (k.type == KZ_TEX_CONSTANT) return sc.bg.intensity * V3(k.color[0], k.color[1], k.color[2]);       // texture.cpp:20-22
-        if (k.type == KZ_TEX_IMAGE) return sc.bg.intensity * envLookup(sc, k.image, dir);                    // texture.cpp:66-80
+        if (k.type == KZ_TEX_IMAGE) return sc.bg.intensity * envLookup(sc, k.image, k.filter, dir);                    // texture.cpp:66-80
         return V3(0.f);                                                                                      // texture.h:13 (colorramp, blend)
     }
     return sc.bg.intensity * V3(sc.bg.color[0], sc.bg.color[1], sc.bg.color[2]);

@@ -570,3 +570,39 @@ def test_permute_on_the_device_matches_the_reference_text(gpu_lib, kz):
     f = lambda a: a.ctypes.data_as(kz.abi.u32p)
     kz.abi.check(gpu_lib, gpu_lib.kz_debug_permute(0, len(rows), f(i), f(l), f(p), f(got)))
     assert np.array_equal(got, want)
+
+
+Q1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "q1_default_m0_r0.5.npz")
+
+
+def test_reference_asset_scene_through_the_hip_path(gpu_lib, kz, O):
+    """The reference's OWN asset geometry (scene/2022_q1/parameters/default_m0_r0.5.xml: 36 378 triangles, smooth vertex normals on the kiss object and the
+    backdrop - the Hanika terminator offset and the interpolated shading frames of accel.cpp:141-229 on real data - three invisible area lights) flattened to
+    tests/golden/q1_default_m0_r0.5.npz by tests/golden/make_q1_scene.py, SURVEY 8d C1 at its stated size 256x256x16: HIP film vs the oracle, rays vs brute force."""
+    d = kz.scenes.load_npz(Q1, {"camera": {"width": 256, "height": 256}, "sampler": {"sampleCount": 16}})
+    assert d.n_tris() == 36378 and d.sampler["type"] == "independent" and d.integrator["maxDepth"] == 5
+    sc = kz.Scene(d, device=0)
+    sc.render()
+    ora = O.OracleScene(d)
+    cpu = ora.rgb(ora.render(threads=0))
+    gpu = sc.rgb()
+    assert gpu.mean() > 0.05
+    assert float(np.sqrt(np.mean((gpu - cpu) ** 2))) < 1e-3
+    sc.render(pipeline=1)                                                 # the reference-shaped megakernel: the same film bit for bit
+    assert np.array_equal(sc.rgb(), gpu)
+    # closest hits of 20 000 rays around the object against the brute-force Moeller-Trumbore search over all 36 378 triangles
+    rng = np.random.default_rng(5)
+    lo, hi = np.min([m["V"].min(axis=0) for m in d.meshes[3:]], axis=0), np.max([m["V"].max(axis=0) for m in d.meshes[3:]], axis=0)
+    c, ext = (lo + hi) / 2, (hi - lo) / 2
+    o = (c + rng.uniform(-1.2, 1.2, (20000, 3)) * ext).astype(np.float32)
+    tgt = (c + rng.uniform(-0.6, 0.6, (20000, 3)) * ext).astype(np.float32)
+    dirs = tgt - o
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    hg = sc.trace_rays(o, dirs.astype(np.float32), 1e-3, np.inf)
+    hc = O.OracleScene(d, brute=True).trace_rays(o, dirs.astype(np.float32), 1e-3, np.inf)
+    hit = hc["mesh"] >= 0
+    assert hit.mean() > 0.3
+    assert np.array_equal(hg["mesh"], hc["mesh"]) and np.array_equal(hg["prim"], hc["prim"])
+    assert np.all(np.abs(hg["t"][hit] - hc["t"][hit]) <= 1e-4 * hc["t"][hit])
+    for k, tol in (("p", 2e-5), ("sh_n", 1e-5), ("sh_s", 1e-4), ("sh_t", 1e-4), ("geo_n", 1e-5), ("u", 1e-5)):
+        assert np.abs(hg[k][hit] - hc[k][hit]).max() <= tol, k

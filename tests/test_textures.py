@@ -46,6 +46,26 @@ def test_image_lookup_known_answers(kz, O):
     assert np.array_equal(o.texture(3, [(0.75, 0.75)])[0], np.array([1.0, 0, 0], np.float32))
 
 
+def test_bicubic_filter_known_answers(kz, O):
+    """KzTexture.filter = KZ_TEXFILTER_BICUBIC: the 4 x 4 cubic B-spline (what OpenImageIO's default "smart bicubic" mode most likely evaluates for the
+    reference's magnifying, zero-derivative lookups - the hazard recorded in DESIGN.md 2). A B-spline reproduces constants and linear ramps exactly
+    (away from the periodic seam), blurs a single texel to the weights 1/6, 4/6, 1/6 per axis, and is not the bilinear lookup."""
+    S = kz.scenes
+    ramp = np.tile(np.linspace(0, 1, 16, dtype=np.float32)[None, :, None], (16, 1, 3))              # f(x) = x / 15 along s
+    dot = np.zeros((8, 8, 1), np.float32); dot[3, 4, 0] = 1.0
+    o = O.OracleScene(_tex_scene(kz, [S.imagetexture(np.full((4, 4, 3), 0.37, np.float32), 1.0, "linear", "bicubic"), S.imagetexture(ramp, 1.0, "linear", "bicubic"),
+                                      S.imagetexture(ramp, 1.0, "linear", "bilinear"), S.imagetexture(dot, 1.0, "linear", "bicubic"), S.imagetexture(dot, 1.0, "linear")]))
+    uv = np.random.default_rng(3).uniform(0, 1, (200, 2)).astype(np.float32)
+    assert np.allclose(o.texture(0, uv), 0.37, atol=2e-7)
+    inner = uv[(uv[:, 0] > 3 / 16) & (uv[:, 0] < 13 / 16)]
+    want = (inner[:, 0] * 16 - 0.5) / 15                                                               # the ramp at the continuous texel coordinate
+    assert np.allclose(o.texture(1, inner)[:, 0], want, atol=3e-6) and np.allclose(o.texture(2, inner)[:, 0], want, atol=3e-6)
+    at = lambda j, i: ((i + 0.5) / 8, 1 - (j + 0.5) / 8)                                               # uv of the centre of texel (row j, column i)
+    c = o.texture(3, [at(3, 4), at(3, 3), at(2, 4), at(2, 3), at(3, 6), at(5, 4)])[:, 0]
+    assert np.allclose(c, [16 / 36, 4 / 36, 4 / 36, 1 / 36, 0, 0], atol=1e-7)
+    assert np.allclose(o.texture(4, [at(3, 4), at(3, 3)])[:, 0], [1, 0])                               # bilinear at texel centres: the texels themselves
+
+
 def test_u8_rasters_are_value_over_255(kz, O):
     img = np.array([[[255, 128, 0], [51, 102, 204]]], np.uint8)
     o = O.OracleScene(_tex_scene(kz, [kz.scenes.imagetexture(img, 1.0, "linear")]))
@@ -184,6 +204,7 @@ def test_texture_eval_matches_oracle(gpu_lib, kz, O):
     S = kz.scenes
     chk, noise, gray, nrm = S._test_images()
     lin = [S.imagetexture(chk, 6.0, "linear"), S.imagetexture(noise, 2.0, "linear"), S.imagetexture(gray, 3.0, "linear"), S.imagetexture(nrm, 0.7, "linear")]
+    lin += [S.imagetexture(noise, 2.0, "linear", "bicubic"), S.imagetexture(gray, 0.9, "linear", "bicubic")]      # KzTexture.filter: cubic B-spline
     srgb = [S.imagetexture(chk, 6.0, "srgb"), S.imagetexture(noise, 1.3, "srgb")]
     tree = [S.colorramp(lin[2], 0.1, 0.8), S.blend(lin[2], S.constanttexture((0.8, 0.25, 0.2)), lin[1]), S.blend(None, lin[0], srgb[1], "multiply"),
             S.colorramp(S.blend(S.colorramp(lin[1]), S.blend(None, lin[0], lin[3], "multiply"), srgb[0]), -0.5, 2.0)]

@@ -120,34 +120,54 @@ PIN_IMAGES = ["default_m0_r0.5", "m0.0_r0", "m0.0_r0.5", "m0.0_r1", "m0_r0_spec0
               "m1_r0", "m1_r0.5", "m1_r1", "r0.5_c0", "r0.5_c0.5", "r0.5_c1", "r0.5_c1_cr0.5", "r0.5_c1_cr1", "r0_s0", "r0_s0.5", "r0_s1", "r0_s1_st0.5", "r0_s1_st1"]
 
 
+# What the published pictures say about the scene DATA (scripts/pin_reference_pngs.py experiments, profiles/pin/): per-light basis images of
+# default_m0_r0.5 fitted to its picture by least squares give these factors on the three area lights (back, right, left). They are a property of the
+# lights the 22 scenes share, not of the object's BSDF: applied UNCHANGED to all 22 scene files they take the oracle from 0.953 of the picture (mean linear
+# radiance, every image) to 0.9967 ... 1.0009.
+PUBLISHED_LIGHT_FACTORS = (0.976, 1.135, 1.034)
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout is only present in the build container")
 @pytest.mark.parametrize("name", PIN_IMAGES)
 def test_reference_scene_files_match_their_published_pngs(kz, O, name):
     """ALL 22 scene/2022_q1/parameters/*.xml (36 378 triangles, SURVEY 8d C1 geometry; a kiss parameter sweep over metallic,
-    roughness, specular, specularTint, clearcoat, sheen) loaded UNCHANGED and rendered by the oracle at 240x135x64: the tone-mapped
-    result agrees with the reference's own 4096-spp PNG (doc/2022_q1/img/param/) at low frequency. This is the only image-level
-    pin the reference offers ('usable only as a statistical sanity check'). Blocks of the 16x9 grid in which the picture
-    is clipped (value 255: the mirror-like objects' highlights, whose HDR energy the 8-bit picture has lost) are left out.
+    roughness, specular, specularTint, clearcoat, sheen) loaded through the adapter and rendered by the oracle at 240x135x64 against the
+    reference's own 4096-spp PNG (doc/2022_q1/img/param/) - the only image-level pin the reference offers ('usable only as a
+    statistical sanity check'). Blocks of the 16x9 grid in which the picture is clipped (value 255: the mirror-like objects' highlights,
+    whose HDR energy the 8-bit picture has lost) are left out.
 
-    What the bound encodes (scripts/pin_reference_pngs.py, profiles/pin/table.json: 480x270x256 per image): in LINEAR radiance the
-    oracle is 0.953 of the picture on average, with the SAME shape in all 22 images whatever the object's BSDF is - floor 0.943
-    (0.9426-0.9438), top rows 1.016 (1.0142-1.0174), sigma 0.039 - i.e. max |d| 0.042-0.048 sRGB on this grid and a mean of
-    -0.014...-0.018. A transport or BSDF bug in the restatement would break that uniformity; the bound is set just above the
-    measured worst case so that any new deviation shows."""
+    Round 3 asserted the RESIDUAL (the oracle 1.0-2.2 % darker in sRGB, 4.7 % in linear radiance, the same in every image). This asserts the
+    EXPLANATION: the three light intensities of the checked-in scene files, multiplied by ONE set of factors fitted on ONE image
+    (PUBLISHED_LIGHT_FACTORS), reproduce the mean linear radiance of EVERY one of the 22 pictures to +-0.5 % and the mean of the 16x9 sRGB grid to
+    0.004 - whatever the object's BSDF parameters are. A transport or BSDF error in the restatement would show as a dependence on those
+    parameters, which is what the bound excludes; that the published renders used other light intensities than the checked-in XML stays a
+    hypothesis about the reference's data (profiles/pin/README.md), not about its code."""
     from PIL import Image
     d = kz.xmlscene.load_xml(os.path.join(REF, name + ".xml"), {"camera": {"width": 240, "height": 135}, "sampler": {"sampleCount": 64}})
     assert d.n_tris() == 36378
+    lights = [m["light"] for m in d.meshes if m["light"]]
+    assert [l["intensity"] for l in lights] == [1.0, 1.5, 4.0]                                       # what the scene files say
+    for l, f in zip(lights, PUBLISHED_LIGHT_FACTORS):
+        l["intensity"] *= f
     o = O.OracleScene(d)
-    rgb = o.rgb(o.render(threads=0))
+    rgb = o.rgb(o.render(threads=0)).astype(np.float64)
+    png = np.asarray(Image.open("/root/reference/doc/2022_q1/img/param/%s.png" % name).convert("RGB"), np.float64) / 255
+    lin_png = np.where(png <= 0.04045, png / 12.92, np.power((png + 0.055) / 1.055, 2.4))            # common.cpp:368-382
+    clipped = (png >= 1.0).any(axis=2).reshape(27, 40, 48, 40).any(axis=(1, 3))
+    lp = lin_png.mean(axis=2).reshape(27, 40, 48, 40).mean(axis=(1, 3))
+    lo = rgb.mean(axis=2).reshape(27, 5, 48, 5).mean(axis=(1, 3))
+    ok = ~clipped & (lp > 0.02)
+    assert ok.sum() >= 1000
+    ratio = lo[ok] / lp[ok]
+    assert abs(ratio.mean() - 1.0) < 0.005, ratio.mean()                                             # explained to +-0.5 % (unweighted: 0.953)
+    assert ratio.std() < 0.055                                                                       # the low-frequency shape no light factor removes (0.045-0.049)
     x = np.clip(rgb, 0, 1)
-    srgb = np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1 / 2.4) - 0.055)            # common.cpp:352-366
-    png = np.asarray(Image.open("/root/reference/doc/2022_q1/img/param/%s.png" % name).convert("RGB"), np.float32) / 255
-    clipped = (png >= 1.0).any(axis=2).reshape(9, 120, 16, 120).any(axis=(1, 3))
-    ref = png.reshape(9, 120, 16, 120, 3).mean(axis=(1, 3))
-    mine = srgb.reshape(9, 15, 16, 15, 3).mean(axis=(1, 3))
-    ok = ~clipped
-    assert ok.sum() >= 120
-    assert np.abs(mine - ref)[ok].max() < 0.055 and -0.022 < mine[ok].mean() - ref[ok].mean() < -0.010
+    srgb = np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1 / 2.4) - 0.055)                 # common.cpp:352-366
+    ok9 = ~(png >= 1.0).any(axis=2).reshape(9, 120, 16, 120).any(axis=(1, 3))
+    ref9, mine9 = png.reshape(9, 120, 16, 120, 3).mean(axis=(1, 3)), srgb.reshape(9, 15, 16, 15, 3).mean(axis=(1, 3))
+    assert ok9.sum() >= 120
+    # (the worst single block and channel: 0.028-0.032 for the rough objects, up to 0.057 next to the mirror-like objects' highlights at 64 spp)
+    assert np.abs(mine9 - ref9)[ok9].max() < 0.06 and abs(mine9[ok9].mean() - ref9[ok9].mean()) < 0.004
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout is only present in the build container")
@@ -162,3 +182,25 @@ def test_every_reference_scene_file_loads(kz):
         assert d.n_tris() > 0 and any(m["light"] for m in d.meshes), f
     sc = kz.Scene(d, device=None)                                                   # host-side build of the last one
     assert sc.bvh_info()["nTris"] == d.n_tris()
+
+
+Q1_NPZ = os.path.join(HERE, "golden", "q1_default_m0_r0.5.npz")
+
+
+def test_flattened_asset_scene_fixture(kz, O):
+    """tests/golden/q1_default_m0_r0.5.npz (made by tests/golden/make_q1_scene.py from the reference's own XML + OBJ files) loads on a box without the
+    reference and renders through the oracle; where the reference is present it is the loader's output array for array."""
+    d = kz.scenes.load_npz(Q1_NPZ, {"camera": {"width": 48, "height": 48}, "sampler": {"sampleCount": 2}})
+    assert d.n_tris() == 36378 and [m["F"].shape[0] for m in d.meshes] == [2, 12, 12, 1536, 34816]
+    assert [bool(m["light"]) for m in d.meshes] == [True, True, True, False, False] and d.meshes[4]["bsdf"]["type"] == "kazenstandard"
+    assert all(m["N"] is not None for m in d.meshes)
+    o = O.OracleScene(d)
+    assert 0.02 < o.rgb(o.render(threads=0)).mean() < 1.0
+    src = os.path.join(REF, "default_m0_r0.5.xml")
+    if os.path.exists(src):
+        x = kz.xmlscene.load_xml(src, {"camera": {"width": 48, "height": 48}, "sampler": {"sampleCount": 2}})
+        for ma, mb in zip(d.meshes, x.meshes):
+            for k in ("V", "F", "N", "UV"):
+                assert (ma[k] is None) == (mb[k] is None) and (ma[k] is None or np.array_equal(ma[k], mb[k]))
+            assert ma["bsdf"] == mb["bsdf"] or (ma["bsdf"] and {k: (list(v) if isinstance(v, tuple) else v) for k, v in mb["bsdf"].items()} == ma["bsdf"])
+        assert np.array_equal(np.asarray(d.camera["toWorld"]), np.asarray(x.camera["toWorld"]))
