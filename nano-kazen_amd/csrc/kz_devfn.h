@@ -133,7 +133,7 @@ struct Sampler {
         return (xs >> rot) | (xs << ((~rot + 1u) & 31));
     }
     __device__ __forceinline__ float nextFloat() { return __uint_as_float((nextUInt() >> 9) | 0x3f800000u) - 1.0f; }
-    __device__ void generateSample(const KzParams &P, const KzDevTables &T, int x, int y, uint32_t sampleIndex) {
+    __device__ __forceinline__ void generateSample(const KzParams &P, const KzDevTables &T, int x, int y, uint32_t sampleIndex) {
         px = x; py = y; idx = sampleIndex;
         hp = type != KZ_SAMPLER_INDEPENDENT ? hashPixelBlock(x, y) : 0ull;
         if (type != KZ_SAMPLER_PMJ02BN) {                 // independent, stratified, correlated: same pcg32 seeding
@@ -156,7 +156,9 @@ struct Sampler {
         uint32_t x = (uint32_t)px % KZ_BLUENOISE_RES, y = (uint32_t)py % KZ_BLUENOISE_RES;
         return T.bn[(t * KZ_BLUENOISE_RES + x) * KZ_BLUENOISE_RES + y];
     }
-    __device__ float next1D(const KzParams &P, const KzDevTables &T) {
+    // (forced inline, like next2D: as CALLS they take the kernel's KzParams / KzDevTables by address, which puts a copy of both - ~600 B per lane - into
+    // scratch memory; the EXT kernel variants, where the compiler stopped inlining them, carried 960 B of scratch until round 4)
+    __device__ __forceinline__ float next1D(const KzParams &P, const KzDevTables &T) {
         if (type == KZ_SAMPLER_INDEPENDENT) return nextFloat();
         if (type == KZ_SAMPLER_STRATIFIED) {                                       // sampler.cpp:119-127
             const uint64_t h = hashDimSeed(hp, dim, P.seed);
@@ -179,7 +181,7 @@ struct Sampler {
         const float num = (float)index + delta;
         return fminf(P.sppPow2 ? num * P.invSpp : num / (float)P.sampleCount, KZ_ONE_MINUS_EPS);    // exact either way (kz_internal.h)
     }
-    __device__ void next2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
+    __device__ __forceinline__ void next2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
         if (type == KZ_SAMPLER_INDEPENDENT) { y = nextFloat(); x = nextFloat(); return; }
         if (type == KZ_SAMPLER_STRATIFIED) {                                       // sampler.cpp:129-139
             const uint64_t h = hashDimSeed(hp, dim, P.seed);
@@ -219,7 +221,7 @@ struct Sampler {
         dim += 2;
         x = fminf(ux, KZ_ONE_MINUS_EPS); y = fminf(uy, KZ_ONE_MINUS_EPS);
     }
-    __device__ void nextPixel2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
+    __device__ __forceinline__ void nextPixel2D(const KzParams &P, const KzDevTables &T, float &x, float &y) {
         if (type != KZ_SAMPLER_PMJ02BN) { next2D(P, T, x, y); return; }
         int tile = P.pixelTileSize;
         int tx = px % tile, ty = py % tile;
@@ -954,50 +956,57 @@ __device__ __forceinline__ float srgbToLinear(float v) {                        
     return v <= 0.04045f ? v * (1.0f / 12.92f) : powf((v + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
 // Taps and weights of one axis of an image lookup at continuous texel coordinate x (texel centres at i + 0.5, so x = s * res - 0.5): the two taps of the
-// bilinear filter or the four of the cubic B-spline (KzTexture.filter). The 2-tap form is the arithmetic the lookup had before the filter became a field:
-// (1 - f) * a + f * b.
-struct KzTaps { int first, n; float w[4]; };
-__device__ __forceinline__ KzTaps filterTaps(int filter, float x) {
-    KzTaps t;
+// bilinear filter (N = 2) or the four of the cubic B-spline (N = 4; KzTexture.filter). The 2-tap form is the arithmetic the lookup had before the filter
+// became a field: (1 - f) * a + f * b. N is a compile-time constant: the weights stay in registers (a run-time tap count put them in scratch memory).
+template <int N> struct KzTaps { int first; float w[N]; };
+template <int N> __device__ __forceinline__ KzTaps<N> filterTaps(float x) {
+    KzTaps<N> t;
     const float x0 = floorf(x), f = x - x0;
-    if (filter == KZ_TEXFILTER_BICUBIC) {
+    if (N == 4) {
         const float omf = 1.0f - f, f2 = f * f, f3 = f2 * f;
-        t.first = (int)x0 - 1; t.n = 4;
+        t.first = (int)x0 - 1;
         t.w[0] = omf * omf * omf * (1.0f / 6.0f);
         t.w[1] = (3.0f * f3 - 6.0f * f2 + 4.0f) * (1.0f / 6.0f);
-        t.w[2] = (-3.0f * f3 + 3.0f * f2 + 3.0f * f + 1.0f) * (1.0f / 6.0f);
-        t.w[3] = f3 * (1.0f / 6.0f);
-    } else { t.first = (int)x0; t.n = 2; t.w[0] = 1.0f - f; t.w[1] = f; t.w[2] = t.w[3] = 0.0f; }
+        t.w[N - 2] = (-3.0f * f3 + 3.0f * f2 + 3.0f * f + 1.0f) * (1.0f / 6.0f);
+        t.w[N - 1] = f3 * (1.0f / 6.0f);
+    } else { t.first = (int)x0; t.w[0] = 1.0f - f; t.w[1] = f; }
     return t;
 }
 // the filtered texel of channel c: rows left to right, then the rows top to bottom (the oracle adds in the same order)
-template <bool CLAMP_Y>
-__device__ __forceinline__ float filteredTexel(const KzImageRow &im, const uint8_t *base, const KzTaps &tx, const KzTaps &ty, int c) {
+template <int N, bool CLAMP_Y>
+__device__ __forceinline__ float filteredTexel(const KzImageRow &im, const uint8_t *base, const KzTaps<N> &tx, const KzTaps<N> &ty, int c) {
     float r = 0.0f;
-    for (int j = 0; j < ty.n; ++j) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
         const int y = CLAMP_Y ? min(max(ty.first + j, 0), im.height - 1) : wrapPeriodic(ty.first + j, im.height);
         float row = tx.w[0] * texelAt(im, base, wrapPeriodic(tx.first, im.width), y, c);
-        for (int i = 1; i < tx.n; ++i) row = row + tx.w[i] * texelAt(im, base, wrapPeriodic(tx.first + i, im.width), y, c);
+#pragma unroll
+        for (int i = 1; i < N; ++i) row = row + tx.w[i] * texelAt(im, base, wrapPeriodic(tx.first + i, im.width), y, c);
         r = j == 0 ? ty.w[0] * row : r + ty.w[j] * row;
     }
     return r;
 }
+template <int N, bool CLAMP_Y>
+__device__ __forceinline__ V3 filteredRgb(const KzImageRow &im, const uint8_t *base, float x, float y) {
+    const KzTaps<N> tx = filterTaps<N>(x), ty = filterTaps<N>(y);
+    return mk(filteredTexel<N, CLAMP_Y>(im, base, tx, ty, 0), filteredTexel<N, CLAMP_Y>(im, base, tx, ty, 1), filteredTexel<N, CLAMP_Y>(im, base, tx, ty, 2));
+}
+// the 4 x 4 lookup is a CALL: inlined next to the 2 x 2 one it cost the path kernels registers (the lean megakernel went from 139 to 248 VGPRs) for a
+// filter that is off by default
+template <bool CLAMP_Y>
+__device__ __attribute__((noinline)) V3 filteredRgbCubic(KzImageRow im, const uint8_t *base, float x, float y) { return filteredRgb<4, CLAMP_Y>(im, base, x, y); }
 // ImageTexture::eval (texture.cpp:46-64): s = u*scale, t = (1-v)*scale, periodic wrap; the filter is KzTexture.filter (kazen_mi355x.h)
-__device__ V3 imageLookup(const KzDevTables &T, uint32_t image, float scale, uint32_t flags, float u, float v) {
+template <class Tables>
+__device__ V3 imageLookup(const Tables &T, uint32_t image, float scale, uint32_t flags, float u, float v) {
     const KzImageRow im = T.images[image];
     const uint8_t *base = T.texels + im.offset;
     const uint32_t srgb = flags & 1u; const int filter = (int)(flags >> 1);
     const float s = u * scale, t = (1.0f - v) * scale;
     const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
     if (!(fabsf(x) < 1.0e9f) || !(fabsf(y) < 1.0e9f)) return mk(0.f);             // non-finite uv: defined as black
-    const KzTaps tx = filterTaps(filter, x), ty = filterTaps(filter, y);
-    float r[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        r[c] = filteredTexel<false>(im, base, tx, ty, c);
-        if (srgb) r[c] = srgbToLinear(r[c]);
-    }
-    return mk(r[0], r[1], r[2]);
+    V3 r = filter == KZ_TEXFILTER_BICUBIC ? filteredRgbCubic<false>(im, base, x, y) : filteredRgb<2, false>(im, base, x, y);
+    if (srgb) r = mk(srgbToLinear(r.x), srgbToLinear(r.y), srgbToLinear(r.z));
+    return r;
 }
 // ImageTexture::eval(Vector3f) (texture.cpp:66-80): the environment lookup, as include/kazen_mi355x.h declares it (y-up latitude-longitude
 // map, s periodic, t clamped; no scale, no colour-space conversion; the nested texture's filter)
@@ -1009,11 +1018,7 @@ __device__ V3 envLookup(const KzDevTables &T, uint32_t image, int filter, V3 d) 
     if (isnan(s)) s = 0.0f;
     if (isnan(t)) t = 0.0f;
     const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
-    const KzTaps tx = filterTaps(filter, x), ty = filterTaps(filter, y);
-    float r[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) r[c] = filteredTexel<true>(im, base, tx, ty, c);
-    return mk(r[0], r[1], r[2]);
+    return filter == KZ_TEXFILTER_BICUBIC ? filteredRgbCubic<true>(im, base, x, y) : filteredRgb<2, true>(im, base, x, y);
 }
 // Scene::getBackgroundColor (scene.cpp:54-79) -> BackgroundTexture::eval(Vector3f) (texture.cpp:121-126); the caller has checked bgPresent
 __device__ __forceinline__ V3 backgroundRadiance(const KzParams &P, const KzDevTables &T, V3 d) {
@@ -1023,7 +1028,14 @@ __device__ __forceinline__ V3 backgroundRadiance(const KzParams &P, const KzDevT
 }
 __device__ __forceinline__ float clampRef(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   // common.h:237-243
 // texId is 1-based (KzBSDF::*Tex); the postfix program was flattened by kz_scene_create
-__device__ V3 texEval(const KzDevTables &T, int32_t texId, float u, float v) {
+// (a real call - the tree walk is big - so it takes the four tables it reads BY VALUE: a `const KzDevTables &` would force the caller's copy into scratch)
+struct KzTexTables { const KzTexProg *texProgs; const KzTexOp *texOps; const KzImageRow *images; const uint8_t *texels; };
+__device__ V3 texEvalT(const KzTexTables T, int32_t texId, float u, float v);
+__device__ __forceinline__ V3 texEval(const KzDevTables &T, int32_t texId, float u, float v) {
+    const KzTexTables tt = {T.texProgs, T.texOps, T.images, T.texels};
+    return texEvalT(tt, texId, u, v);
+}
+__device__ V3 texEvalT(const KzTexTables T, int32_t texId, float u, float v) {
     const KzTexProg pr = T.texProgs[texId - 1];
     V3 st[KZ_TEX_MAX_DEPTH];
     int sp = 0;

@@ -28,7 +28,9 @@ OUT = os.path.join(ROOT, "gpurun_out")
 
 def scene(name):
     return {"c1": lambda: S.cornell_box(256, 256, 16), "c2": lambda: S.sphere_env(512, 512, 64), "c3": lambda: S.hero_scene(1920, 1080, 256, detail=2.0),
-            "c4": lambda: S.random_triangles(1000000, 1920, 1080, 1024), "c5": lambda: S.random_triangles(1000000, 3840, 2160, 4096)}[name]()
+            "c4": lambda: S.random_triangles(1000000, 1920, 1080, 1024), "c5": lambda: S.random_triangles(1000000, 3840, 2160, 4096),
+            # outside BASELINE.json: the EXT kernel variants (rough / dielectric BSDFs; image textures + normal map) at C3's size, for one timing beside the lean C3
+            "ext_materials": lambda: S.materials_scene(1920, 1080, 256), "ext_textured": lambda: S.textured_scene(1920, 1080, 256)}[name]()
 
 
 def all_kiss(desc):
