@@ -415,6 +415,17 @@ def test_randomized_scenes_match_oracle(gpu_lib, kz, O, seed):
     assert err < L2_TOL * scale, (seed, err, scale)
     sc.render(pipeline=1)                                                               # reference-shaped megakernel: same film bit for bit
     assert np.array_equal(sc.film(), film)
+    # The counting and the product instantiations of every traversal MODE these scenes reach (0, 1, 4 + the deferred 2; 2 for all shadow rays where the
+    # invisible lights have more than 64 triangles) must render the SAME film, also with a 3-entry LDS stack (the global overflow path): ADVICE r03 - the
+    # stack reset of kz_wf_trace rests on empty asm barriers that once only the counting instantiations needed; a recurrence has to fail here.
+    sc.set_stats(False)
+    sc.render()
+    assert np.array_equal(sc.film(), film)
+    sc.render(tune={"ldsStack": 3})
+    assert np.array_equal(sc.film(), film)
+    sc.set_stats(True)
+    sc.render(tune={"ldsStack": 3})
+    assert np.array_equal(sc.film(), film)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
