@@ -121,6 +121,10 @@ int kz_debug_exact_math_check(int device, uint64_t *rcpMismatches, uint64_t *sqr
 /* out[k] = random::permute(i[k], l[k], p[k]) (src/kazen/common.cpp:316-344) as the sampler kernels compute it: checked against vectors minted from
  * the reference's own text (oracle/kat_ref_permute.cpp -> tests/golden/int_kats.json). */
 int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out);
+/* The Fresnel functions of the dielectric / rough BSDFs as the kernels compute them, against vectors minted from the reference's own text
+ * (oracle/kat_ref_fresnel.cpp): form 0 = fresnel(cosThetaI, extIOR = a, intIOR = b) (common.cpp:447-475), form 1 = fresnelDielectric(cosThetaI, eta = a,
+ * cosThetaT) (:492-518; b unused). out = n x (F, cosThetaT). */
+int kz_debug_fresnel(int device, uint32_t n, int form, const float *cosThetaI, const float *a, const float *b, float *out);
 
 
 #ifdef __cplusplus

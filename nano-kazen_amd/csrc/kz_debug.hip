@@ -104,6 +104,14 @@ __global__ void kz_permute_kernel(uint32_t n, const uint32_t *__restrict__ i, co
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = permuteIdx(i[k], l[k], p[k]);
 }
+// fresnel (common.cpp:447-475) / fresnelDielectric (:492-518) as the BSDF kernels compute them: out[2k] = F, out[2k + 1] = cosThetaT (0 for the three-IOR form)
+__global__ void kz_fresnel_kernel(uint32_t n, int form, const float *__restrict__ c, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float ct = 0.f;
+    out[2 * k] = form == 0 ? fresnelIOR(c[k], a[k], b[k]) : fresnelDielectricT(c[k], a[k], ct);
+    out[2 * k + 1] = ct;
+}
 __global__ void kz_exact_math_kernel(unsigned long long base, unsigned long long *__restrict__ counts) {
     const uint32_t bits = (uint32_t)(base + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x);
     const float x = __uint_as_float(bits);
@@ -135,6 +143,23 @@ int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *
     hipLaunchKernelGGL(kz_permute_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, dI.as<uint32_t>(), dL.as<uint32_t>(), dP.as<uint32_t>(), dO.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dO.p, bytes, hipMemcpyDeviceToHost));
+    return KZ_OK;
+}
+
+int kz_debug_fresnel(int device, uint32_t n, int form, const float *cosThetaI, const float *a, const float *b, float *out) {
+    int nd = kz_device_count();
+    if (device < 0 || device >= nd) return kz_fail(nd ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, nd);
+    if (!n) return KZ_OK;
+    if (!cosThetaI || !a || !out || (form == 0 && !b) || (form != 0 && form != 1)) return kz_fail(KZ_ERR_INVALID_ARG, "null argument or form %d (0 = fresnel(cos, extIOR, intIOR), 1 = fresnelDielectric(cos, eta))", form);
+    HIP_TRY(hipSetDevice(device));
+    DevMem dC, dA, dB, dO;
+    const size_t bytes = (size_t)n * sizeof(float);
+    KZ_ALLOC(&dC.p, bytes); KZ_ALLOC(&dA.p, bytes); KZ_ALLOC(&dB.p, bytes); KZ_ALLOC(&dO.p, 2 * bytes);
+    HIP_TRY(hipMemcpy(dC.p, cosThetaI, bytes, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dA.p, a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB.p, b ? b : a, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_fresnel_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, form, dC.as<float>(), dA.as<float>(), dB.as<float>(), dO.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dO.p, 2 * bytes, hipMemcpyDeviceToHost));
     return KZ_OK;
 }
 

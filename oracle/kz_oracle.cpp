@@ -1870,6 +1870,9 @@ uint64_t kzo_hash_pixel_dim_seed(int32_t x, int32_t y, uint32_t dim, uint64_t se
 uint64_t kzo_murmur64a(const unsigned char *key, size_t len, uint64_t seed) { return MurmurHash64A(key, len, seed); }
 uint64_t kzo_mixbits(uint64_t v) { return MixBits(v); }
 uint32_t kzo_permute(uint32_t i, uint32_t l, uint32_t p) { return permute(i, l, p); }
+// the Fresnel functions of the dielectric / rough BSDFs (common.cpp:447-475, :492-518), for the vectors minted from the reference's own text
+float kzo_fresnel_ior(float cosThetaI, float extIOR, float intIOR) { FtzScope ftz_; return fresnelIOR(cosThetaI, extIOR, intIOR); }
+float kzo_fresnel_dielectric(float cosThetaI, float eta, float *cosThetaT) { FtzScope ftz_; float ct = 0.f; const float F = fresnelDielectricT(cosThetaI, eta, ct); if (cosThetaT) *cosThetaT = ct; return F; }
 uint64_t kzo_tea32(uint32_t v0, uint32_t v1, int rounds) { return sampleTEA32(v0, v1, rounds); }
 // pcg32: seed(initseq) [1-arg form], advance(delta), then n draws -> uints and floats
 void kzo_pcg32_stream(uint64_t initseq, int64_t delta, int n, uint32_t *u, float *f, uint64_t *stateOut) {

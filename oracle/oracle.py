@@ -55,6 +55,10 @@ def lib():
         L.kzo_mixbits.restype = C.c_uint64
         L.kzo_permute.argtypes = [C.c_uint32] * 3
         L.kzo_permute.restype = C.c_uint32
+        L.kzo_fresnel_ior.argtypes = [C.c_float] * 3
+        L.kzo_fresnel_ior.restype = C.c_float
+        L.kzo_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.kzo_fresnel_dielectric.restype = C.c_float
         L.kzo_tea32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
         L.kzo_tea32.restype = C.c_uint64
         L.kzo_pcg32_stream.argtypes = [C.c_uint64, C.c_int64, C.c_int, abi.u32p, abi.f32p, C.POINTER(C.c_uint64)]

@@ -617,3 +617,21 @@ def test_reference_asset_scene_through_the_hip_path(gpu_lib, kz, O):
     assert np.all(np.abs(hg["t"][hit] - hc["t"][hit]) <= 1e-4 * hc["t"][hit])
     for k, tol in (("p", 2e-5), ("sh_n", 1e-5), ("sh_s", 1e-4), ("sh_t", 1e-4), ("geo_n", 1e-5), ("u", 1e-5)):
         assert np.abs(hg[k][hit] - hc[k][hit]).max() <= tol, k
+
+
+def test_fresnel_on_the_device_matches_the_reference_text(gpu_lib, kz):
+    """The device's fresnelIOR / fresnelDielectricT (kz_devfn.h) against the bit patterns minted from the reference's own text (oracle/kat_ref_fresnel.cpp):
+    the divisions are the compiler's IEEE sequences and the square roots sqrtExact, so every bit must agree."""
+    import json
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "int_kats.json")))
+    f = lambda a: a.ctypes.data_as(kz.abi.f32p)
+    rows = np.array(kats["fresnel_ior"], np.uint32)
+    c, e, i = (np.ascontiguousarray(rows[:, k]).view(np.float32) for k in range(3))
+    out = np.zeros((len(rows), 2), np.float32)
+    kz.abi.check(gpu_lib, gpu_lib.kz_debug_fresnel(0, len(rows), 0, f(c), f(e), f(i), f(out)))
+    assert np.array_equal(out[:, 0].view(np.uint32), rows[:, 3])
+    rows = np.array(kats["fresnel_dielectric"], np.uint32)
+    c, e = (np.ascontiguousarray(rows[:, k]).view(np.float32) for k in range(2))
+    out = np.zeros((len(rows), 2), np.float32)
+    kz.abi.check(gpu_lib, gpu_lib.kz_debug_fresnel(0, len(rows), 1, f(c), f(e), None, f(out)))
+    assert np.array_equal(out[:, 0].view(np.uint32), rows[:, 2]) and np.array_equal(out[:, 1].view(np.uint32), rows[:, 3])

@@ -361,3 +361,18 @@ def test_permute_and_tea32_match_reference_text(O, kats):
         assert sorted(got) == list(range(e["l"]))                      # a permutation
     for v0, v1, rounds, out in kats["tea32"]:
         assert L.kzo_tea32(v0, v1, rounds) == int(out)
+
+
+def test_fresnel_functions_match_reference_text_bit_for_bit(O, kats):
+    """fresnel(cosThetaI, extIOR, intIOR) and fresnelDielectric(cosThetaI, eta, cosThetaT) (common.cpp:447-475, :492-518; the dielectric and rough BSDFs of
+    SURVEY 8f rank 2): the one piece of the reference's FLOATING-POINT code that compiles without Eigen. Vectors = float bit patterns minted by compiling the
+    reference's own text (oracle/kat_ref_fresnel.cpp); the restatement must give the same bits."""
+    import ctypes as C
+    L = O.lib()
+    f = lambda u: np.array([u], np.uint32).view(np.float32)[0]
+    b = lambda x: int(np.array([x], np.float32).view(np.uint32)[0])
+    for c, e, i, out in kats["fresnel_ior"]:
+        assert b(L.kzo_fresnel_ior(f(c), f(e), f(i))) == out, (f(c), f(e), f(i))
+    for c, e, out, ct in kats["fresnel_dielectric"]:
+        t = C.c_float(123.0)
+        assert b(L.kzo_fresnel_dielectric(f(c), f(e), C.byref(t))) == out and b(t.value) == ct, (f(c), f(e))
