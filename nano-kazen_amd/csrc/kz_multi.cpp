@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -105,7 +106,8 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
     // replicas come up BEFORE the clocks start (deviceMs is render + gather; a first call pays the upload outside it)
     for (uint32_t i = 0; i < nDevices; ++i) if ((rc = kz_scene_upload(scene, devices[i]))) { const std::string why = kz_last_error(); return kz_fail(rc, "device %d: %s", devices[i], why.c_str()); }
     const bool dynamic = opts && opts->tileDealing == 1;
-    struct Job { std::vector<KzTile> tiles; std::vector<float> packed; int rc = KZ_OK; std::string err; float ms = 0.f; };
+    // (packed: new float[n] leaves the buffer uninitialised - a std::vector would zero 150 MB at C5 just to have the download overwrite them)
+    struct Job { std::vector<KzTile> tiles; std::unique_ptr<float[]> packed; size_t nPacked = 0; int rc = KZ_OK; std::string err; float ms = 0.f; };
     std::vector<Job> jobs(nDevices);
     if (!dynamic) {
         for (uint32_t i = 0; i < nDevices; ++i) {
@@ -139,8 +141,9 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
                 for (uint32_t k = 0; !j.rc && k + 1 < nTaken; k += 2) j.tiles.insert(j.tiles.end(), all.begin() + taken[k], all.begin() + taken[k + 1]);
             } else if (!j.tiles.empty()) j.rc = kz_render_tiles(scene, &o, j.tiles.data(), (uint32_t)j.tiles.size(), devices[i], nullptr, 0);
             if (!j.rc && !j.tiles.empty()) {
-                j.packed.resize(packedFloats(P, j.tiles.data(), (uint32_t)j.tiles.size()));
-                j.rc = kz_film_download_tiles(scene, devices[i], j.tiles.data(), (uint32_t)j.tiles.size(), j.packed.data(), j.packed.size());
+                j.nPacked = packedFloats(P, j.tiles.data(), (uint32_t)j.tiles.size());
+                j.packed.reset(new float[j.nPacked]);
+                j.rc = kz_film_download_tiles(scene, devices[i], j.tiles.data(), (uint32_t)j.tiles.size(), j.packed.get(), j.nPacked);
             }
             if (j.rc) j.err = kz_last_error();                             // the message is thread-local: carry it to the caller's thread
             j.ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -157,13 +160,13 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
     std::vector<Rect> tab;
     for (uint32_t i = 0; i < nDevices; ++i) {
         size_t off = 0;
-        for (const KzTile &t : jobs[i].tiles) { tab.push_back(Rect{t, jobs[i].packed.data() + off}); off += (size_t)(t.w + 2 * P.border) * (size_t)(t.h + 2 * P.border) * 4; }
+        for (const KzTile &t : jobs[i].tiles) { tab.push_back(Rect{t, jobs[i].packed.get() + off}); off += (size_t)(t.w + 2 * P.border) * (size_t)(t.h + 2 * P.border) * 4; }
     }
     std::sort(tab.begin(), tab.end(), [](const Rect &a, const Rect &b) { return a.t.y0 != b.t.y0 ? a.t.y0 < b.t.y0 : a.t.x0 < b.t.x0; });
-    std::memset(film, 0, filmFloats * sizeof(float));
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border, border = P.border;
     const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     auto band = [&](int r0, int r1) {
+        std::memset(film + (size_t)r0 * cols * 4, 0, (size_t)(r1 - r0) * cols * 4 * sizeof(float));      // (every thread clears its own band: 133 MB at C5)
         for (const Rect &e : tab) {
             const int rw = e.t.w + 2 * border, y0 = std::max(e.t.y0, r0), y1 = std::min(e.t.y0 + e.t.h + 2 * border, r1);
             for (int y = y0; y < y1; ++y) {

@@ -93,7 +93,7 @@ def gather_tiles(scene, tiles, packed, rank, world, tile=None):
                     film = scene.empty_film()
                     for r in range(world):
                         if lists[r]:
-                            scene.merge_tiles(film, lists[r], np.fromfile(path(r), dtype=np.float32))
+                            scene.merge_tiles(film, lists[r], np.memmap(path(r), dtype=np.float32, mode="r"))      # (mapped, not copied; ranks without tiles wrote no file)
                 except Exception as e:                         # noqa: BLE001 - reported to every rank below
                     err, film = e, None
         else:                                                  # no shared memory: the rects go through the process group
