@@ -893,6 +893,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         }
         if (!ds->evFork) HIP_TRY(hipEventCreateWithFlags(&ds->evFork, hipEventDisableTiming));
     }
+    if (dealer && !ds->evFilm[0]) HIP_TRY(hipEventCreateWithFlags(&ds->evFilm[0], hipEventDisableTiming));
     ds->eventsUsed = 0;
     HIP_TRY(hipEventRecord(ds->evCallA, stream));
     if (multi) {
@@ -911,7 +912,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         hipStream_t pst = multi ? ds->passStream[ci] : stream;
         // Back-pressure of dynamic dealing: the host takes the next batch only when the context it needs has finished its previous pass, so a device
         // holds at most nCtx passes - never the whole frame - and a slower device simply comes back to the counter less often.
-        if (dealer && multi && inFlight[ci]) HIP_TRY(hipEventSynchronize(ds->evFilm[ci]));
+        if (dealer && inFlight[ci]) HIP_TRY(hipEventSynchronize(ds->evFilm[ci]));
         if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, pst))) return rc;
         if (beams) {
             if ((rc = ensureBeams(scene, ds, stream, p0, nPixPass))) return rc;
@@ -936,7 +937,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         HIP_TRY(hipGetLastError());
         const int prev = (ci + nCtx - 1) % nCtx;
         if ((rc = kzFilmStage(scene, ds, c, pst, pixList, p0, nPixPass, Sp, tapSums, (multi && pass > 0) ? ds->evFilm[prev] : nullptr))) return rc;
-        if (multi) { HIP_TRY(hipEventRecord(ds->evFilm[ci], pst)); inFlight[ci] = true; }
+        if (multi || dealer) { HIP_TRY(hipEventRecord(ds->evFilm[ci], pst)); inFlight[ci] = true; }      // (a dealer paces itself on this event even with one context)
         if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
         ds->lastCtx = ci;
         ++pass;

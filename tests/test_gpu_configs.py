@@ -234,6 +234,9 @@ def test_tile_dealer_takes_every_tile_once(gpu_lib, kz, O):
     assert np.allclose(sc.film(), whole, rtol=1e-5, atol=1e-6)
     assert np.allclose(sc.merge_tiles(sc.empty_film(), took, sc.film_tiles(took)), whole, rtol=1e-5, atol=1e-6)
     assert sc.render_dealt(tiles, counter, takers=1, batch_tiles=3) == []
+    counter[0] = 0                                                        # one pass context: the dealer paces itself on that context's film event
+    assert sc.render_dealt(tiles, counter, takers=1, batch_tiles=5, passes_in_flight=1, pass_items=32 * 32 * 5 * 2) == tiles
+    assert np.allclose(sc.film(), whole, rtol=1e-5, atol=1e-6)
     # two takers, one after the other on this GPU (an 8-GPU node runs them side by side): the second starts where the first was stopped
     counter[0] = 0
     a = sc.render_dealt(tiles[:], counter, takers=2, batch_tiles=0)
