@@ -189,7 +189,7 @@ __device__ __forceinline__ bool wfClassify(const KzParams &P, const KzDevTables 
     const V3 rd = mk(rb.x, rb.y, rb.z);
 #ifdef KZ_SHADESTAT
     sst.markw(10);                                  // pass A: queue entry, hit record, ray
-    if (h.x < KZ_INF) { const float4 *sp_ = kzShadeRec(T, __float_as_uint(h.w)); const float4 a_ = sp_[0], b_ = sp_[3]; asm volatile("" :: "v"(a_.x), "v"(b_.x)); }
+    if (h.x < KZ_INF) { const float4 *sp_ = reinterpret_cast<const float4 *>(T.shade + __float_as_uint(h.w)); const float4 a_ = sp_[0], b_ = sp_[6]; asm volatile("" :: "v"(a_.x), "v"(b_.x)); }
     sst.markw(11);                                  // pass A: the shading record arrives
 #endif
     if (!(h.x < KZ_INF)) {
