@@ -565,3 +565,161 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     if (STATS) wfStatsFlush(W.stats, cn, 0);
 }
+
+// ---- round 4: shade(k) as two kernels (-DKZ_SHADE_SPLIT=1; launched from wfPass, kz_render.hip) ----
+// TWO kernels per bounce (round 4; development builds only: -DKZ_EXPERIMENTS -DKZ_SHADE_SPLIT=1): pass A as a kernel of its own at
+// 8 waves per SIMD writes the slots of the surviving paths to a dense queue; pass B runs on full waves from that queue, rebuilds the intersection
+// record from the hit record and needs neither the 40-KB LDS record stack of the one-kernel form nor its two barriers per round. MEASURED AND REJECTED
+// (profiles/r04b_shade_split, same gpurun call, films bit-identical): C4 shade 18.1 -> 20.9 ms per pass (classification 6.1 ms - no faster at 8 or 7 waves
+// per SIMD than as pass A of the one kernel, 5.7 - and pass B 14.8 ms against 9.4 + 3.3 of compaction and barriers: the second walk down
+// queue -> hit record -> shading record costs more than the record stack did), C3 23.5 -> 28.5 ms. The kernel is bound by the DEPTH of its chains
+// of dependent loads, and a split adds two levels.
+#ifndef KZ_CLASSIFY_WAVES
+#define KZ_CLASSIFY_WAVES 8
+#endif
+template <bool STATS, bool EXT>
+__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_CLASSIFY_WAVES, KZ_CLASSIFY_WAVES))) void kz_wf_classify(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
+                                                           uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
+                                                           const uint32_t *__restrict__ countPtr, uint32_t countImm,
+                                                           uint32_t *__restrict__ survQueue, uint32_t *__restrict__ survCount) {
+    __shared__ uint32_t s_buf[KZ_WF_QCAP]; __shared__ uint32_t s_n, s_gb;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    WfAppender ap = {s_buf, &s_n, &s_gb, survQueue, survCount};
+    const uint32_t count = countPtr ? *countPtr : countImm;
+    const bool compact = !EXT && !P.regularization;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    KzSst sst;
+    int round = 0;
+    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
+        bool survivor = false;
+        uint32_t slot = 0;
+        if (base + threadIdx.x < count) {
+            const uint32_t qi = base + threadIdx.x;
+            slot = queue ? queue[qi] : qi;
+            Its its;
+            survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, cn, sst);
+        }
+        sst.mark(0);
+        ap.push(survivor, slot);
+        // The staging buffer takes KZ_WF_ROUNDS rounds of 256 entries: it is flushed every so many rounds whatever it holds, so the decision needs
+        // no look at the shared count (a wave that has run ahead into the next round may already be adding to it) and the rounds between two
+        // flushes need no barrier at all.
+        if (++round == KZ_WF_ROUNDS) {
+            round = 0;
+            __syncthreads();
+            const uint32_t n = s_n;                         // (stable: every wave's next push is behind the barriers below)
+            if (threadIdx.x == 0) s_gb = atomicAdd(survCount, n);
+            __syncthreads();
+            const uint32_t gb = s_gb;
+            for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) survQueue[gb + i] = s_buf[i];
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+        }
+        sst.mark(1);
+    }
+    ap.maybeFlush(true);
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+    sst.flush(W.stats);
+}
+
+template <bool STATS, bool EXT>
+__global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade_b(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
+                                                        uint32_t sampleBegin, int iter, const uint32_t *__restrict__ survQueue, const uint32_t *__restrict__ survCount,
+                                                        uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
+                                                        uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
+    __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
+    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; }
+    __syncthreads();
+    WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
+    WfQueuePair qp = {s_bufN, s_bufS, &s_nN, &s_nS, &s_gbN, &s_gbS, nextQueue, nextCount, shadowQueue, shadowCount};
+    const uint32_t count = *survCount;
+    const bool compact = !EXT && !P.regularization;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    KzSst sst;
+    int round = 0;
+    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
+        bool pushNext = false, pushShadow = false;
+        uint32_t slot = 0;
+        if (base + threadIdx.x < count) {
+            slot = kzLoadStream(survQueue + base + threadIdx.x);
+            const float4 h = kzLoadStream(&W.hit[slot]);
+            RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
+            Its its; postIntersect<false>(T, rh, its);                 // (counted by kz_wf_classify)
+            sst.markw(12);
+            wfShadeSurvivor<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, pushNext, pushShadow, cn, sst);
+        }
+        sst.mark(7);
+        apN.push(pushNext, slot); apS.push(pushShadow, slot);
+        if (++round == KZ_WF_ROUNDS) {                     // (see kz_wf_classify)
+            round = 0;
+            __syncthreads();
+            qp.flushAll();
+        }
+        sst.mark(8);
+    }
+    __syncthreads();
+    qp.flush(true);
+    if (STATS) wfStatsFlush(W.stats, cn, 0);
+    sst.flush(W.stats);
+}
+
+// ---- round 4: sorted traversal queues (needs -DKZ_EXPERIMENTS -DKZ_SORT_EXPERIMENT; the call sites are in wfPass, kz_render.hip) ----
+#ifdef KZ_SORT_EXPERIMENT
+// Development build only (-DKZ_SORT_EXPERIMENT; profiles/r04d_sorted_queues): the UPPER BOUND of what ray reordering can buy the per-lane traversal kernels
+// ("dual queues"). After shade(k) the bounce-ray queue and the shadow-ray queue are each sorted by (Morton code of the ray origin in the
+// scene box, direction octant) with hipcub's radix sort into SEPARATE queues that only the traversal launches read - the next shade keeps the slot-order
+// queue. The count is fetched with a host sync: this measures the traversal on sorted input, not a pipeline one would ship.
+#include <hipcub/hipcub.hpp>
+__device__ __forceinline__ uint32_t kzPart1By2(uint32_t x) { x &= 0x3ffu; x = (x | (x << 16)) & 0x30000ffu; x = (x | (x << 8)) & 0x300f00fu; x = (x | (x << 4)) & 0x30c30c3u; x = (x | (x << 2)) & 0x9249249u; return x; }
+__global__ void kz_sort_keys(KzWf W, int shadow, const uint32_t *__restrict__ q, uint32_t n, float lx, float ly, float lz, float sx, float sy, float sz, int bits, int useDir, uint32_t *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = q[i];
+    const float4 a = shadow ? W.shA[slot] : W.rayA[slot], b = shadow ? W.shB[slot] : W.rayB[slot];
+    const uint32_t qx = (uint32_t)fminf(fmaxf((a.x - lx) * sx, 0.f), 1023.f), qy = (uint32_t)fminf(fmaxf((a.y - ly) * sy, 0.f), 1023.f), qz = (uint32_t)fminf(fmaxf((a.z - lz) * sz, 0.f), 1023.f);
+    uint32_t m = (kzPart1By2(qx) | (kzPart1By2(qy) << 1) | (kzPart1By2(qz) << 2)) >> (30 - 3 * bits);
+    const uint32_t oct = (b.x < 0.f ? 1u : 0u) | (b.y < 0.f ? 2u : 0u) | (b.z < 0.f ? 4u : 0u);
+    keys[i] = useDir == 2 ? ((oct << (3 * bits)) | m) : useDir == 1 ? ((m << 3) | oct) : m;
+}
+struct KzSortExp {
+    uint32_t *keysIn = nullptr, *keysOut = nullptr, *qOut[2] = {nullptr, nullptr}; void *temp = nullptr; size_t tempBytes = 0, cap = 0;
+    float lo[3], sc[3]; int bits = 6, useDir = 1; bool on = true; double sortMs = 0; hipEvent_t e0 = nullptr, e1 = nullptr;
+    int ensure(KzScene *scene, size_t need) {
+        if (const char *e = std::getenv("KZ_SORT_BITS")) bits = std::max(1, std::min(10, atoi(e)));
+        if (const char *e = std::getenv("KZ_SORT_DIR")) useDir = atoi(e);
+        if (const char *e = std::getenv("KZ_SORT_ON")) on = atoi(e) != 0;
+        if (need <= cap) return KZ_OK;
+        const KzNode &r = scene->nodes[scene->prm.rootRef & 0x7fffffffu];
+        const float blo[3] = {std::min(r.q[0], r.q[6]), std::min(r.q[1], r.q[7]), std::min(r.q[2], r.q[8])}, bhi[3] = {std::max(r.q[3], r.q[9]), std::max(r.q[4], r.q[10]), std::max(r.q[5], r.q[11])};
+        for (int a = 0; a < 3; ++a) { lo[a] = blo[a]; sc[a] = 1024.0f / std::max(1e-20f, bhi[a] - blo[a]); }
+        HIP_TRY(hipDeviceSynchronize());
+        for (void *p_ : {(void *)keysIn, (void *)keysOut, (void *)qOut[0], (void *)qOut[1], temp}) if (p_) (void)hipFree(p_);
+        KZ_ALLOC(&keysIn, need * 4); KZ_ALLOC(&keysOut, need * 4); KZ_ALLOC(&qOut[0], need * 4); KZ_ALLOC(&qOut[1], need * 4);
+        tempBytes = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keysIn, keysOut, qOut[0], qOut[1], (int)need, 0, 32, (hipStream_t)0);
+        KZ_ALLOC(&temp, tempBytes);
+        cap = need;
+        if (!e0) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
+        return KZ_OK;
+    }
+    // sorted copy of queue q (count at *countPtr on the device) -> qOut[which]; returns the host copy of the count
+    int sort(hipStream_t stream, const KzWf &W, int shadow, const uint32_t *q, const uint32_t *countPtr, int which, uint32_t *nOut) {
+        uint32_t n = 0;
+        HIP_TRY(hipMemcpyAsync(&n, countPtr, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *nOut = n;
+        if (!n) return KZ_OK;
+        HIP_TRY(hipEventRecord(e0, stream));
+        hipLaunchKernelGGL(kz_sort_keys, dim3((n + 255) / 256), dim3(256), 0, stream, W, shadow, q, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], bits, useDir, keysIn);
+        size_t tb = tempBytes;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, tb, keysIn, keysOut, q, qOut[which], (int)n, 0, 3 * bits + (useDir ? 3 : 0), stream));
+        HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1)); sortMs += ms;
+        return KZ_OK;
+    }
+};
+static KzSortExp g_sortExp;
+#endif

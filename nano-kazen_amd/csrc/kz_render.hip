@@ -533,63 +533,6 @@ static KzTraceFn traceFn(int mode, bool stats) {
     return tab[mode][stats ? 1 : 0];
 }
 
-#ifdef KZ_SORT_EXPERIMENT
-// Development build only (-DKZ_SORT_EXPERIMENT; profiles/r04d_sorted_queues): the UPPER BOUND of what ray reordering can buy the per-lane traversal kernels
-// ("dual queues"). After shade(k) the bounce-ray queue and the shadow-ray queue are each sorted by (Morton code of the ray origin in the
-// scene box, direction octant) with hipcub's radix sort into SEPARATE queues that only the traversal launches read - the next shade keeps the slot-order
-// queue. The count is fetched with a host sync: this measures the traversal on sorted input, not a pipeline one would ship.
-#include <hipcub/hipcub.hpp>
-__device__ __forceinline__ uint32_t kzPart1By2(uint32_t x) { x &= 0x3ffu; x = (x | (x << 16)) & 0x30000ffu; x = (x | (x << 8)) & 0x300f00fu; x = (x | (x << 4)) & 0x30c30c3u; x = (x | (x << 2)) & 0x9249249u; return x; }
-__global__ void kz_sort_keys(KzWf W, int shadow, const uint32_t *__restrict__ q, uint32_t n, float lx, float ly, float lz, float sx, float sy, float sz, int bits, int useDir, uint32_t *__restrict__ keys) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = q[i];
-    const float4 a = shadow ? W.shA[slot] : W.rayA[slot], b = shadow ? W.shB[slot] : W.rayB[slot];
-    const uint32_t qx = (uint32_t)fminf(fmaxf((a.x - lx) * sx, 0.f), 1023.f), qy = (uint32_t)fminf(fmaxf((a.y - ly) * sy, 0.f), 1023.f), qz = (uint32_t)fminf(fmaxf((a.z - lz) * sz, 0.f), 1023.f);
-    uint32_t m = (kzPart1By2(qx) | (kzPart1By2(qy) << 1) | (kzPart1By2(qz) << 2)) >> (30 - 3 * bits);
-    const uint32_t oct = (b.x < 0.f ? 1u : 0u) | (b.y < 0.f ? 2u : 0u) | (b.z < 0.f ? 4u : 0u);
-    keys[i] = useDir == 2 ? ((oct << (3 * bits)) | m) : useDir == 1 ? ((m << 3) | oct) : m;
-}
-struct KzSortExp {
-    uint32_t *keysIn = nullptr, *keysOut = nullptr, *qOut[2] = {nullptr, nullptr}; void *temp = nullptr; size_t tempBytes = 0, cap = 0;
-    float lo[3], sc[3]; int bits = 6, useDir = 1; bool on = true; double sortMs = 0; hipEvent_t e0 = nullptr, e1 = nullptr;
-    int ensure(KzScene *scene, size_t need) {
-        if (const char *e = std::getenv("KZ_SORT_BITS")) bits = std::max(1, std::min(10, atoi(e)));
-        if (const char *e = std::getenv("KZ_SORT_DIR")) useDir = atoi(e);
-        if (const char *e = std::getenv("KZ_SORT_ON")) on = atoi(e) != 0;
-        if (need <= cap) return KZ_OK;
-        const KzNode &r = scene->nodes[scene->prm.rootRef & 0x7fffffffu];
-        const float blo[3] = {std::min(r.q[0], r.q[6]), std::min(r.q[1], r.q[7]), std::min(r.q[2], r.q[8])}, bhi[3] = {std::max(r.q[3], r.q[9]), std::max(r.q[4], r.q[10]), std::max(r.q[5], r.q[11])};
-        for (int a = 0; a < 3; ++a) { lo[a] = blo[a]; sc[a] = 1024.0f / std::max(1e-20f, bhi[a] - blo[a]); }
-        HIP_TRY(hipDeviceSynchronize());
-        for (void *p_ : {(void *)keysIn, (void *)keysOut, (void *)qOut[0], (void *)qOut[1], temp}) if (p_) (void)hipFree(p_);
-        KZ_ALLOC(&keysIn, need * 4); KZ_ALLOC(&keysOut, need * 4); KZ_ALLOC(&qOut[0], need * 4); KZ_ALLOC(&qOut[1], need * 4);
-        tempBytes = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keysIn, keysOut, qOut[0], qOut[1], (int)need, 0, 32, (hipStream_t)0);
-        KZ_ALLOC(&temp, tempBytes);
-        cap = need;
-        if (!e0) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
-        return KZ_OK;
-    }
-    // sorted copy of queue q (count at *countPtr on the device) -> qOut[which]; returns the host copy of the count
-    int sort(hipStream_t stream, const KzWf &W, int shadow, const uint32_t *q, const uint32_t *countPtr, int which, uint32_t *nOut) {
-        uint32_t n = 0;
-        HIP_TRY(hipMemcpyAsync(&n, countPtr, 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        *nOut = n;
-        if (!n) return KZ_OK;
-        HIP_TRY(hipEventRecord(e0, stream));
-        hipLaunchKernelGGL(kz_sort_keys, dim3((n + 255) / 256), dim3(256), 0, stream, W, shadow, q, n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], bits, useDir, keysIn);
-        size_t tb = tempBytes;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, tb, keysIn, keysOut, q, qOut[which], (int)n, 0, 3 * bits + (useDir ? 3 : 0), stream));
-        HIP_TRY(hipEventRecord(e1, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1)); sortMs += ms;
-        return KZ_OK;
-    }
-};
-static KzSortExp g_sortExp;
-#endif
 
 // Beam lists for pixels [p0, p0 + n) of the current pixel list: launched on `stream` (the call's stream) unless that range of this list has been
 // handed to the kernel before; the kernel itself skips pixels that already have a list (from another tile set or chunk). evBeam / beamSeq tell the

@@ -446,105 +446,6 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
     sst.flush(W.stats);
 }
 
-#ifdef KZ_EXPERIMENTS
-// TWO kernels per bounce (round 4; development builds only: -DKZ_EXPERIMENTS -DKZ_SHADE_SPLIT=1): pass A as a kernel of its own at
-// 8 waves per SIMD writes the slots of the surviving paths to a dense queue; pass B runs on full waves from that queue, rebuilds the intersection
-// record from the hit record and needs neither the 40-KB LDS record stack of the one-kernel form nor its two barriers per round. MEASURED AND REJECTED
-// (profiles/r04b_shade_split, same gpurun call, films bit-identical): C4 shade 18.1 -> 20.9 ms per pass (classification 6.1 ms - no faster at 8 or 7 waves
-// per SIMD than as pass A of the one kernel, 5.7 - and pass B 14.8 ms against 9.4 + 3.3 of compaction and barriers: the second walk down
-// queue -> hit record -> shading record costs more than the record stack did), C3 23.5 -> 28.5 ms. The kernel is bound by the DEPTH of its chains
-// of dependent loads, and a split adds two levels.
-#ifndef KZ_CLASSIFY_WAVES
-#define KZ_CLASSIFY_WAVES 8
-#endif
-template <bool STATS, bool EXT>
-__global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_CLASSIFY_WAVES, KZ_CLASSIFY_WAVES))) void kz_wf_classify(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
-                                                           uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
-                                                           const uint32_t *__restrict__ countPtr, uint32_t countImm,
-                                                           uint32_t *__restrict__ survQueue, uint32_t *__restrict__ survCount) {
-    __shared__ uint32_t s_buf[KZ_WF_QCAP]; __shared__ uint32_t s_n, s_gb;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    WfAppender ap = {s_buf, &s_n, &s_gb, survQueue, survCount};
-    const uint32_t count = countPtr ? *countPtr : countImm;
-    const bool compact = !EXT && !P.regularization;
-    Counters cn = {0, 0, 0, 0, 0, 0};
-    KzSst sst;
-    int round = 0;
-    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
-        bool survivor = false;
-        uint32_t slot = 0;
-        if (base + threadIdx.x < count) {
-            const uint32_t qi = base + threadIdx.x;
-            slot = queue ? queue[qi] : qi;
-            Its its;
-            survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, cn, sst);
-        }
-        sst.mark(0);
-        ap.push(survivor, slot);
-        // The staging buffer takes KZ_WF_ROUNDS rounds of 256 entries: it is flushed every so many rounds whatever it holds, so the decision needs
-        // no look at the shared count (a wave that has run ahead into the next round may already be adding to it) and the rounds between two
-        // flushes need no barrier at all.
-        if (++round == KZ_WF_ROUNDS) {
-            round = 0;
-            __syncthreads();
-            const uint32_t n = s_n;                         // (stable: every wave's next push is behind the barriers below)
-            if (threadIdx.x == 0) s_gb = atomicAdd(survCount, n);
-            __syncthreads();
-            const uint32_t gb = s_gb;
-            for (uint32_t i = threadIdx.x; i < n; i += KZ_BLOCK) survQueue[gb + i] = s_buf[i];
-            __syncthreads();
-            if (threadIdx.x == 0) s_n = 0;
-            __syncthreads();
-        }
-        sst.mark(1);
-    }
-    ap.maybeFlush(true);
-    if (STATS) wfStatsFlush(W.stats, cn, 0);
-    sst.flush(W.stats);
-}
-
-template <bool STATS, bool EXT>
-__global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade_b(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
-                                                        uint32_t sampleBegin, int iter, const uint32_t *__restrict__ survQueue, const uint32_t *__restrict__ survCount,
-                                                        uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
-                                                        uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
-    __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
-    if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; }
-    __syncthreads();
-    WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
-    WfQueuePair qp = {s_bufN, s_bufS, &s_nN, &s_nS, &s_gbN, &s_gbS, nextQueue, nextCount, shadowQueue, shadowCount};
-    const uint32_t count = *survCount;
-    const bool compact = !EXT && !P.regularization;
-    Counters cn = {0, 0, 0, 0, 0, 0};
-    KzSst sst;
-    int round = 0;
-    for (uint32_t base = blockIdx.x * KZ_BLOCK; base < count; base += gridDim.x * KZ_BLOCK) {
-        bool pushNext = false, pushShadow = false;
-        uint32_t slot = 0;
-        if (base + threadIdx.x < count) {
-            slot = kzLoadStream(survQueue + base + threadIdx.x);
-            const float4 h = kzLoadStream(&W.hit[slot]);
-            RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
-            Its its; postIntersect<false>(T, rh, its);                 // (counted by kz_wf_classify)
-            sst.markw(12);
-            wfShadeSurvivor<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, pushNext, pushShadow, cn, sst);
-        }
-        sst.mark(7);
-        apN.push(pushNext, slot); apS.push(pushShadow, slot);
-        if (++round == KZ_WF_ROUNDS) {                     // (see kz_wf_classify)
-            round = 0;
-            __syncthreads();
-            qp.flushAll();
-        }
-        sst.mark(8);
-    }
-    __syncthreads();
-    qp.flush(true);
-    if (STATS) wfStatsFlush(W.stats, cn, 0);
-    sst.flush(W.stats);
-}
-#endif
 
 
 // ---- persistent traversal kernel -----------------------------------------------------------------------------------------
