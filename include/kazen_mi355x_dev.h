@@ -125,6 +125,12 @@ int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *
  * (oracle/kat_ref_fresnel.cpp): form 0 = fresnel(cosThetaI, extIOR = a, intIOR = b) (common.cpp:447-475), form 1 = fresnelDielectric(cosThetaI, eta = a,
  * cosThetaT) (:492-518; b unused). out = n x (F, cosThetaT). */
 int kz_debug_fresnel(int device, uint32_t n, int form, const float *cosThetaI, const float *a, const float *b, float *out);
+/* The transcendental functions of the path as the kernels compute them (nano-kazen_amd/csrc/kz_crmath.h: each a fixed sequence of IEEE double operations
+ * and one narrowing, standing in for the reference's libm calls - warp.cpp:41-129, bsdf.cpp:728-734, common.cpp:368-400, texture.cpp:66-80,
+ * camera.cpp:191-223), on arrays: fn 0 sin(x), 1 cos(x), 2 exp(x), 3 log(x), 4 atan(x), 5 atan2(x, y), 6 acos(x), 7 tan(x), 8 pow(x, y), 9 hypot(x, y),
+ * 10 x^3, 11 cos(x) through the cos-only entry. The oracle states the same sequences independently; the results must be equal bit for bit. y may
+ * be NULL for the one-argument functions. */
+int kz_debug_math(int device, int fn, uint32_t n, const float *x, const float *y, float *out);
 
 
 #ifdef __cplusplus

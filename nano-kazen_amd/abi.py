@@ -152,7 +152,7 @@ EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
            "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8",
            "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
-           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check", "kz_debug_permute", "kz_debug_fresnel", "kz_build_flags",
+           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check", "kz_debug_permute", "kz_debug_fresnel", "kz_debug_math", "kz_build_flags",
            "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -217,6 +217,8 @@ def load_library():
     lib.kz_debug_fail_alloc.argtypes = [C.c_int]
     lib.kz_debug_fail_alloc.restype = None
     lib.kz_device_mem_info.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    if hasattr(lib, "kz_debug_math"):
+        lib.kz_debug_math.argtypes = [C.c_int, C.c_int, C.c_uint32, f32p, f32p, f32p]
     if hasattr(lib, "kz_debug_fresnel"):
         lib.kz_debug_fresnel.argtypes = [C.c_int, C.c_uint32, C.c_int, f32p, f32p, f32p, f32p]
     if hasattr(lib, "kz_debug_permute"):

@@ -127,6 +127,29 @@ __global__ void kz_exact_math_kernel(unsigned long long base, unsigned long long
     }
 }
 
+// the path's transcendental functions (kz_crmath.h) on arrays: the oracle states the same sequences and must give the same bits
+__global__ void kz_math_kernel(uint32_t n, int fn, const float *x, const float *y, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = x[i], b = y[i];
+    float r, s, c;
+    switch (fn) {
+    case 0: kzSinCos(a, &s, &c); r = s; break;
+    case 1: kzSinCos(a, &s, &c); r = c; break;
+    case 2: r = kzExp(a); break;
+    case 3: r = kzLog(a); break;
+    case 4: r = kzAtan(a); break;
+    case 5: r = kzAtan2(a, b); break;
+    case 6: r = kzAcos(a); break;
+    case 7: r = kzTan(a); break;
+    case 8: r = kzPow(a, b); break;
+    case 9: r = kzHypot(a, b); break;
+    case 10: r = kzCube(a); break;
+    default: r = kzCos(a); break;
+    }
+    out[i] = r;
+}
+
 extern "C" {
 
 // random::permute on the device (the function the sampler kernels call), for the known-answer vectors minted from the reference's own text
@@ -160,6 +183,22 @@ int kz_debug_fresnel(int device, uint32_t n, int form, const float *cosThetaI, c
     hipLaunchKernelGGL(kz_fresnel_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, form, dC.as<float>(), dA.as<float>(), dB.as<float>(), dO.as<float>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dO.p, 2 * bytes, hipMemcpyDeviceToHost));
+    return KZ_OK;
+}
+
+int kz_debug_math(int device, int fn, uint32_t n, const float *x, const float *y, float *out) {
+    int nd = kz_device_count();
+    if (device < 0 || device >= nd) return kz_fail(nd ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, nd);
+    if (!n) return KZ_OK;
+    if (!x || !out || fn < 0 || fn > 11) return kz_fail(KZ_ERR_INVALID_ARG, "null argument or function %d (0..11)", fn);
+    HIP_TRY(hipSetDevice(device));
+    DevMem dX, dY, dO;
+    const size_t bytes = (size_t)n * sizeof(float);
+    KZ_ALLOC(&dX.p, bytes); KZ_ALLOC(&dY.p, bytes); KZ_ALLOC(&dO.p, bytes);
+    HIP_TRY(hipMemcpy(dX.p, x, bytes, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dY.p, y ? y : x, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kz_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, fn, dX.as<float>(), dY.as<float>(), dO.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dO.p, bytes, hipMemcpyDeviceToHost));
     return KZ_OK;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kz_internal.h"
+#include "kz_crmath.h"
 
 #define KZ_BLOCK 256
 #define KZ_INF __builtin_huge_valf()
@@ -566,7 +567,7 @@ __device__ __forceinline__ V3 squareToCosineHemisphere(float sx, float sy) {
     if (r1 == 0 && r2 == 0) { r = phi = 0; }
     else if (r1 * r1 > r2 * r2) { r = r1; phi = (KZ_PI_F / 4.0f) * (r2 / r1); }
     else { r = r2; phi = (KZ_PI_F / 2.0f) - (r1 / r2) * (KZ_PI_F / 4.0f); }
-    float sinPhi, cosPhi; sincosf(phi, &sinPhi, &cosPhi);             // one argument reduction for both (the values of sinf / cosf)
+    float sinPhi, cosPhi; kzSinCos(phi, &sinPhi, &cosPhi);             // kz_crmath.h: sin and cos as defined double sequences, the oracle's bit for bit
     float px = r * cosPhi, py = r * sinPhi;
     float z = sqrtExact(1.0f - px * px - py * py);
     if (z == 0) z = 1e-10f;
@@ -611,7 +612,7 @@ __device__ __forceinline__ V3 sampleGGXVNDF(V3 V, A2 a, float rx, float ry) {   
     V3 T2 = normalized(cross(Vh, T1));
     float r = sqrtExact(rx);
     float phi = 2.0f * KZ_PI_F * ry;
-    float sinPhi, cosPhi; sincosf(phi, &sinPhi, &cosPhi);
+    float sinPhi, cosPhi; kzSinCos(phi, &sinPhi, &cosPhi);
     float t1 = r * cosPhi, t2 = r * sinPhi;
     float s = 0.5f * (1.0f + Vh.z);
     t2 = (1.0f - s) * sqrtExact(1.0f - t1 * t1) + s * t2;
@@ -723,7 +724,7 @@ __device__ __forceinline__ float tanThetaV(V3 v) { float temp = 1 - v.z * v.z; i
 __device__ __forceinline__ float alphaOf(float x) { return fmaxf(0.001f, sqr(x)); }
 __device__ __forceinline__ float evalBeckmann(V3 m, float alpha) {
     float temp = tanThetaV(m) / alpha, ct = m.z, ct2 = ct * ct;
-    return expf(-temp * temp) / (KZ_PI_F * alpha * alpha * ct2 * ct2);
+    return kzExp(-temp * temp) / (KZ_PI_F * alpha * alpha * ct2 * ct2);
 }
 __device__ __forceinline__ float smithBeckmannG1(V3 v, V3 m, float alpha) {
     if (dot(v, m) * v.z <= 0.0f) return 0.0f;
@@ -736,14 +737,15 @@ __device__ __forceinline__ float smithBeckmannG1(V3 v, V3 m, float alpha) {
 }
 __device__ __forceinline__ V3 squareToBeckmann(float sx, float sy, float alpha) {
     float phi = 2 * KZ_PI_F * sx;
-    float theta = atanf(alpha * sqrtExact(logf(rcpExact(1 - sy))));
-    float sinTheta, cosTheta, sinPhi, cosPhi; sincosf(theta, &sinTheta, &cosTheta); sincosf(phi, &sinPhi, &cosPhi);
+    float theta = kzAtan(alpha * sqrtExact(kzLog(rcpExact(1 - sy))));
+    float sinTheta, cosTheta, sinPhi, cosPhi; kzSinCos(theta, &sinTheta, &cosTheta); kzSinCos(phi, &sinPhi, &cosPhi);
     return mk(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 __device__ __forceinline__ float squareToBeckmannPdf(V3 m, float alpha) {
-    float theta = acosf(m.z / norm(m));
+    float theta = kzAcos(m.z / norm(m));
     float ok = (fabsf(norm(m) - 1) < KZ_EPSILON && m.z >= 0) ? 1.f : 0.f;
-    return ok * expf(-powf(tanf(theta), 2.f) / (alpha * alpha)) / (KZ_PI_F * alpha * alpha * powf(cosf(theta), 3.f));
+    const float tt = kzTan(theta);                                                 // pow(x, 2) is the rounded product, pow(x, 3) the rounded cube
+    return ok * kzExp(-(tt * tt) / (alpha * alpha)) / (KZ_PI_F * alpha * alpha * kzCube(kzCos(theta)));
 }
 __device__ __forceinline__ float fresnelDielectricT(float cosThetaI_, float eta, float &cosThetaT_) {        // common.cpp:492-518
     float scale = (cosThetaI_ > 0.f) ? rcpExact(eta) : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
@@ -953,7 +955,7 @@ __device__ __forceinline__ float texelAt(const KzImageRow &im, const uint8_t *ba
 }
 __device__ __forceinline__ int wrapPeriodic(int i, int n) { i %= n; return i < 0 ? i + n : i; }
 __device__ __forceinline__ float srgbToLinear(float v) {                           // Color3f::toLinearRGB, common.cpp:368-382
-    return v <= 0.04045f ? v * (1.0f / 12.92f) : powf((v + 0.055f) * (1.0f / 1.055f), 2.4f);
+    return v <= 0.04045f ? v * (1.0f / 12.92f) : kzPow((v + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
 // Taps and weights of one axis of an image lookup at continuous texel coordinate x (texel centres at i + 0.5, so x = s * res - 0.5): the two taps of the
 // bilinear filter (N = 2) or the four of the cubic B-spline (N = 4; KzTexture.filter). The 2-tap form is the arithmetic the lookup had before the filter
@@ -1013,8 +1015,8 @@ __device__ V3 imageLookup(const Tables &T, uint32_t image, float scale, uint32_t
 __device__ V3 envLookup(const KzDevTables &T, uint32_t image, int filter, V3 d) {
     const KzImageRow im = T.images[image];
     const uint8_t *base = T.texels + im.offset;
-    float s = atan2f(-d.x, d.z) / (2.0f * KZ_PI_F) + 0.5f;
-    float t = 0.5f - atan2f(d.y, hypotf(d.z, -d.x)) / KZ_PI_F;
+    float s = kzAtan2(-d.x, d.z) / (2.0f * KZ_PI_F) + 0.5f;
+    float t = 0.5f - kzAtan2(d.y, kzHypot(d.z, -d.x)) / KZ_PI_F;
     if (isnan(s)) s = 0.0f;
     if (isnan(t)) t = 0.0f;
     const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
@@ -1221,7 +1223,7 @@ __device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy,
     if (P.cameraType == KZ_CAMERA_THINLENS) {                                      // camera.cpp:191-223, warp.cpp:41-50
         const float r = sqrtExact(ax);
         const float ang = 2.0f * KZ_PI_F * ay;
-        float sinAng, cosAng; sincosf(ang, &sinAng, &cosAng);
+        float sinAng, cosAng; kzSinCos(ang, &sinAng, &cosAng);
         const float tx = cosAng * r * P.apertureRadius, ty = sinAng * r * P.apertureRadius;
         const V3 focusP = nearP * (P.focusDistance / nearP.z);
         dl = normalized(focusP - mk(tx, ty, 0.0f));

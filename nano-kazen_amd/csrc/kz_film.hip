@@ -256,7 +256,7 @@ __global__ void kz_film_srgb8(const float4 *__restrict__ film, int width, int he
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float v = c[k];
-        const float t = v <= 0.0031308f ? 12.92f * v : (1.0f + 0.055f) * powf(v, 1.0f / 2.4f) - 0.055f;
+        const float t = v <= 0.0031308f ? 12.92f * v : (1.0f + 0.055f) * kzPow(v, 1.0f / 2.4f) - 0.055f;
         const float s = 255.f * t;
         out[3 * (size_t)i + k] = (uint8_t)(s < 0.f ? 0.f : (s > 255.f ? 255.f : s));
     }

@@ -321,7 +321,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     else {
         float aspect = c.width / (float)c.height;
         float recip = 1.0f / (c.farClip - c.nearClip);
-        float cot = 1.0f / std::tan((float)((c.fov / 2.0f) * (M_PI / 180.0f)));
+        float cot = 1.0f / std::tan((c.fov / 2.0f) * (3.14159265358979323846f / 180.0f));      // common.h:222 degToRad; M_PI is the float literal of common.h:33
         double P[16] = {cot, 0, 0, 0, 0, cot, 0, 0, 0, 0, (double)(c.farClip * recip), (double)(-c.nearClip * c.farClip * recip), 0, 0, 1, 0};
         double T[16] = {1, 0, 0, -1, 0, 1, 0, (double)(-1.0f / aspect), 0, 0, 1, 0, 0, 0, 0, 1};
         double D[16] = {-0.5, 0, 0, 0, 0, (double)(-0.5f * aspect), 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};

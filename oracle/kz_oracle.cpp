@@ -34,6 +34,7 @@
 #include <vector>
 #include <xmmintrin.h>
 #include <pmmintrin.h>
+#include "kz_oracle_math.h"
 
 namespace kzo {
 
@@ -51,6 +52,7 @@ struct FtzScope {
 };
 static const float Epsilon = 1e-5f;
 static const float OneMinusEpsilon = float(0x1.fffffep-1);
+static const float kPi = 3.14159265358979323846f;      // M_PI as common.h:31-33 redefines it (a float literal, after <cmath>)
 static const float INV_PI = 0.31830988618379067154f;
 static const float kInf = std::numeric_limits<float>::infinity();
 
@@ -300,6 +302,7 @@ struct Scene {
     std::vector<BNode> nodes;
     uint32_t rootRef = 0;         // for degenerate 1-leaf scenes
     bool useBrute = false;
+    int tieMode = 0;              // test knob, see kzo_set_tie_mode
     uint32_t maxDepth = 0;
     Stats stats;
 };
@@ -596,16 +599,17 @@ static bool rayIntersect(const Scene &sc, const Ray &ray, Intersection &its, boo
 }
 
 // ---------------------------------------------------------------------------------
-// a23  Warp::squareToCosineHemisphere (src/kazen/warp.cpp:85-115). M_PI is a double in
-// the reference, so phi is evaluated in double and narrowed on assignment.
+// a23  Warp::squareToCosineHemisphere (src/kazen/warp.cpp:85-115). M_PI is the FLOAT literal of common.h:31-33 (<cmath> is
+// included above it, so the #undef / #define there is the definition every kazen source sees): the expressions are float throughout.
+// sin / cos: kz_oracle_math.h.
 // ---------------------------------------------------------------------------------
 static V3 squareToCosineHemisphere(float sx, float sy) {
     float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f;
     float phi, r;
     if (r1 == 0 && r2 == 0) { r = phi = 0; }
-    else if (r1 * r1 > r2 * r2) { r = r1; phi = (float)((M_PI / 4.0f) * (r2 / r1)); }
-    else { r = r2; phi = (float)((M_PI / 2.0f) - (r1 / r2) * (M_PI / 4.0f)); }
-    float sinPhi = std::sin(phi), cosPhi = std::cos(phi);     // common.h:228-231 math::sincosf
+    else if (r1 * r1 > r2 * r2) { r = r1; phi = (kPi / 4.0f) * (r2 / r1); }
+    else { r = r2; phi = (kPi / 2.0f) - (r1 / r2) * (kPi / 4.0f); }
+    float sinPhi, cosPhi; kzoSinCos(phi, &sinPhi, &cosPhi);   // common.h:228-231 math::sincosf
     float px = r * cosPhi, py = r * sinPhi;
     float z = std::sqrt(1.0f - px * px - py * py);
     if (z == 0) z = 1e-10f;
@@ -614,18 +618,21 @@ static V3 squareToCosineHemisphere(float sx, float sy) {
 // Warp::squareToUniformDisk (warp.cpp:41-50) — thin-lens, "next" row
 static void squareToUniformDisk(float sx, float sy, float &ox, float &oy) {
     float r = std::sqrt(sx);
-    float a = (float)(2.0f * M_PI * sy);
-    ox = std::cos(a) * r; oy = std::sin(a) * r;
+    float a = 2.0f * kPi * sy;
+    float sinA, cosA; kzoSinCos(a, &sinA, &cosA);
+    ox = cosA * r; oy = sinA * r;
 }
 
 // ---------------------------------------------------------------------------------
 // a22  GGX helpers (include/kazen/ggx_brdf.h). H3: unqualified abs/pow/cos/sin are taken
-// with float semantics; M_PI expressions are evaluated in double as the text says.
+// with float semantics; M_PI is common.h's float literal.
 // ---------------------------------------------------------------------------------
 static inline float sqr(float x) { return x * x; }
 struct A2 { float x, y; };
 static inline V3 schlickFresnel(V3 f0, float cosTheta) {                 // ggx_brdf.h:15-24
-    float t = std::pow(1.0f - cosTheta, 5.0f);
+    // pow(x, 5.0f): the fifth power in double, narrowed once (the correctly rounded float but for ~1 argument in 2^27)
+    const double xd = (double)(1.0f - cosTheta), xd2 = xd * xd;
+    float t = (float)(xd2 * xd2 * xd);
     return f0 * 1.0f + (V3(1.f) - f0) * t;
 }
 static inline A2 roughnessToAlpha(float roughness, float anisotropy) {   // ggx_brdf.h:28-37
@@ -646,7 +653,7 @@ static inline float smithG2(V3 V, V3 L, V3 H, A2 a) {                    // ggx_
 }
 static inline float ggxNDF(V3 H, A2 a) {                                 // ggx_brdf.h:71-75
     float ellipse = sqr(H.x) / sqr(a.x) + sqr(H.y) / sqr(a.y) + sqr(H.z);
-    return (float)(1.0f / (M_PI * a.x * a.y * sqr(ellipse)));
+    return 1.0f / (kPi * a.x * a.y * sqr(ellipse));
 }
 static inline float ggxSmithVNDF(V3 V, V3 H, A2 a) {                     // ggx_brdf.h:80-91
     float VDotH = dot(V, H);
@@ -661,9 +668,10 @@ static V3 sampleGGXSmithVNDF(V3 V, A2 a, float rx, float ry) {           // ggx_
     V3 T1 = lensq > 0.0f ? V3(-Vh.y, Vh.x, 0.0f) / std::sqrt(lensq) : V3(1.0f, 0.0f, 0.0f);
     V3 T2 = normalized(cross(Vh, T1));
     float r = std::sqrt(rx);
-    float phi = (float)(2.0f * M_PI * ry);
-    float t1 = r * std::cos(phi);
-    float t2 = r * std::sin(phi);
+    float phi = 2.0f * kPi * ry;
+    float sinPhi, cosPhi; kzoSinCos(phi, &sinPhi, &cosPhi);
+    float t1 = r * cosPhi;
+    float t2 = r * sinPhi;
     float s = 0.5f * (1.0f + Vh.z);
     t2 = (1.0f - s) * std::sqrt(1.0f - t1 * t1) + s * t2;
     V3 Nh = t1 * T1 + t2 * T2 + std::sqrt(std::max(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
@@ -720,7 +728,7 @@ static inline float texelAt(const Scene::Image &im, int x, int y, int c) {
 }
 static inline int wrapPeriodic(int i, int n) { i %= n; return i < 0 ? i + n : i; }
 static inline float srgbToLinear(float v) {                                      // Color3f::toLinearRGB, common.cpp:368-382
-    return v <= 0.04045f ? v * (1.0f / 12.92f) : std::pow((v + 0.055f) * (1.0f / 1.055f), 2.4f);
+    return v <= 0.04045f ? v * (1.0f / 12.92f) : kzoPow((v + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
 // taps and weights of one axis: the two of the bilinear lookup or the four of the cubic B-spline (KzTexture.filter, include/kazen_mi355x.h)
 struct Taps { int first, n; float w[4]; };
@@ -911,7 +919,7 @@ static inline float tanTheta(V3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0
 static inline float alphaOf(float x) { return std::max(0.001f, sqr(x)); }                                                         // bsdf.cpp:699-701, :820-823, :958-960
 static float evalBeckmann(V3 m, float alpha) {                                                                                    // bsdf.cpp:721-727
     float temp = tanTheta(m) / alpha, ct = m.z, ct2 = ct * ct;
-    return (float)(std::exp(-temp * temp) / (M_PI * alpha * alpha * ct2 * ct2));
+    return kzoExp(-temp * temp) / (kPi * alpha * alpha * ct2 * ct2);
 }
 static float smithBeckmannG1(V3 v, V3 m, float alpha) {                                                                           // bsdf.cpp:730-750
     if (dot(v, m) * v.z <= 0.0f) return 0.0f;
@@ -923,14 +931,16 @@ static float smithBeckmannG1(V3 v, V3 m, float alpha) {                         
     return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
 }
 static V3 squareToBeckmann(float sx, float sy, float alpha) {                                                                     // warp.cpp:120-124
-    float phi = (float)(2 * M_PI * sx);
-    float theta = std::atan(alpha * std::sqrt(std::log(1 / (1 - sy))));
-    return V3(std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta));
+    float phi = 2 * kPi * sx;
+    float theta = kzoAtan(alpha * std::sqrt(kzoLog(1 / (1 - sy))));
+    float sinTheta, cosTheta, sinPhi, cosPhi; kzoSinCos(theta, &sinTheta, &cosTheta); kzoSinCos(phi, &sinPhi, &cosPhi);
+    return V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 static float squareToBeckmannPdf(V3 m, float alpha) {                                                                             // warp.cpp:126-129
-    float theta = std::acos(m.z / norm(m));
+    float theta = kzoAcos(m.z / norm(m));
     float ok = (std::fabs(norm(m) - 1) < Epsilon && m.z >= 0) ? 1.f : 0.f;
-    return (float)(ok * std::exp(-std::pow(std::tan(theta), 2.f) / (alpha * alpha)) / (M_PI * alpha * alpha * std::pow(std::cos(theta), 3.f)));
+    const float tt = kzoTan(theta);                                       // pow(x, 2) is the rounded product, pow(x, 3) the rounded cube
+    return ok * kzoExp(-(tt * tt) / (alpha * alpha)) / (kPi * alpha * alpha * kzoCube(kzoCos(theta)));
 }
 static float fresnelDielectricT(float cosThetaI_, float eta, float &cosThetaT_) {                                                 // common.cpp:492-518
     float scale = (cosThetaI_ > 0.f) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
@@ -1342,7 +1352,7 @@ static int prepareCamera(Scene &sc) {
     if (c.sampleToCamera) { std::memcpy(sc.s2c, c.sampleToCamera, 64); return KZ_OK; }
     float aspect = c.width / (float)c.height;
     float recip = 1.0f / (c.farClip - c.nearClip);
-    float cot = 1.0f / std::tan((float)((c.fov / 2.0f) * (M_PI / 180.0f)));    // common.h:222 degToRad
+    float cot = 1.0f / std::tan((c.fov / 2.0f) * (kPi / 180.0f));               // common.h:222 degToRad, M_PI the float of common.h:33
     // Eigen's Matrix4f::inverse() is not available here; the product and inverse are formed in
     // double and narrowed once (differences to Eigen's float cofactor inverse are last-ulp).
     double P[16] = {cot, 0, 0, 0, 0, cot, 0, 0, 0, 0, (double)(c.farClip * recip), (double)(-c.nearClip * c.farClip * recip), 0, 0, 1, 0};
@@ -1510,8 +1520,8 @@ static V3 lightSample(const Scene &sc, const KzLight &l, const MeshData &md, LRe
 // the one include/kazen_mi355x.h declares (y-up latitude-longitude map, bilinear, s periodic, t clamped; no scale, no toLinearRGB)
 static V3 envLookup(const Scene &sc, int image, int filter, V3 d) {
     const Scene::Image &im = sc.images[image];
-    float s = std::atan2(-d.x, d.z) / (2.0f * 3.14159265358979323846f) + 0.5f;
-    float t = 0.5f - std::atan2(d.y, std::hypot(d.z, -d.x)) / 3.14159265358979323846f;
+    float s = kzoAtan2(-d.x, d.z) / (2.0f * kPi) + 0.5f;
+    float t = 0.5f - kzoAtan2(d.y, kzoHypot(d.z, -d.x)) / kPi;
     if (std::isnan(s)) s = 0.0f;
     if (std::isnan(t)) t = 0.0f;
     float x = s * (float)im.w - 0.5f, y = t * (float)im.h - 0.5f;
@@ -1580,13 +1590,22 @@ static V3 Li(const Scene &sc, Sampler &sampler, const Ray &ray_, LocalStats &ls)
             lr.shadowRay.mint = eps; lr.shadowRay.maxt -= eps;
             bool occluded = false;
             Ray tempRay = lr.shadowRay;
+            bool walked = false;
             for (;;) {                                                             // integrator.cpp:262-278
                 Intersection sh;
-                if (rayIntersect(sc, tempRay, sh, true, ls)) {
+                // After a walk-through the far end is maxt - t while the origin moved on by t + eps: in real arithmetic the
+                // segment now ends exactly ON the sampled light, so whether that light itself is reported is decided by the
+                // rounding of everything upstream (a tie in the reference, not a property of the scene). tieMode +1 / -1 move the
+                // far end out / in by 1e-5 of its length and so decide every such tie one way: the two renders bracket
+                // every rounding of the literal loop (tests only; 0 = the literal loop).
+                Ray q = tempRay;
+                if (walked && sc.tieMode != 0) q.maxt *= sc.tieMode > 0 ? 1.00001f : 0.99999f;
+                if (rayIntersect(sc, q, sh, true, ls)) {
                     const MeshData &om = sc.meshes[sh.mesh];
                     if (om.light < 0) { occluded = true; break; }
                     if (sc.lights[om.light].primaryVisibility) { occluded = true; break; }
                     tempRay = Ray(tempRay.o + tempRay.d * (sh.t + eps), tempRay.d, eps, tempRay.maxt - sh.t);
+                    walked = true;
                 } else break;
             }
             if (!occluded) {
@@ -1736,6 +1755,42 @@ int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) { FtzScope 
 }
 void kzo_scene_destroy(void *s) { delete (Scene *)s; }
 void kzo_set_brute(void *s, int brute) { ((Scene *)s)->useBrute = brute != 0; }
+void kzo_set_tie_mode(void *s, int mode) { ((Scene *)s)->tieMode = mode; }
+// the transcendental functions of kz_oracle_math.h on arrays (same numbering as kz_debug_math of the dev header)
+void kzo_math(int fn, uint32_t n, const float *x, const float *y, float *out) { FtzScope ftz_;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float a = x[i], b = y ? y[i] : x[i];
+        float r, s, c;
+        switch (fn) {
+        case 0: kzoSinCos(a, &s, &c); r = s; break;
+        case 1: kzoSinCos(a, &s, &c); r = c; break;
+        case 2: r = kzoExp(a); break;
+        case 3: r = kzoLog(a); break;
+        case 4: r = kzoAtan(a); break;
+        case 5: r = kzoAtan2(a, b); break;
+        case 6: r = kzoAcos(a); break;
+        case 7: r = kzoTan(a); break;
+        case 8: r = kzoPow(a, b); break;
+        case 9: r = kzoHypot(a, b); break;
+        case 10: r = kzoCube(a); break;
+        case 11: r = kzoCos(a); break;
+        // 100 + fn: the libm float function the reference's text calls, on this machine (for the census of tests/test_oracle_cpu.py)
+        case 100: r = std::sin(a); break;
+        case 101: r = std::cos(a); break;
+        case 102: r = std::exp(a); break;
+        case 103: r = std::log(a); break;
+        case 104: r = std::atan(a); break;
+        case 105: r = std::atan2(a, b); break;
+        case 106: r = std::acos(a); break;
+        case 107: r = std::tan(a); break;
+        case 108: r = std::pow(a, b); break;
+        case 109: r = std::hypot(a, b); break;
+        case 110: r = std::pow(a, 3.0f); break;
+        default: r = 0.f; break;
+        }
+        out[i] = r;
+    }
+}
 
 unsigned kzo_sample_count(void *s) { return ((Scene *)s)->sampleCount; }
 int kzo_film_dims(void *s, int *w, int *h, int *b) { Scene *sc = (Scene *)s; *w = sc->cam.width; *h = sc->cam.height; *b = sc->border; return 0; }
@@ -1832,7 +1887,7 @@ int kzo_film_to_rgb(const float *film, int w, int h, int b, float *rgb) { FtzSco
 int kzo_rgb_to_srgb8(const float *rgb, int w, int h, uint8_t *out) { FtzScope ftz_;
     for (size_t i = 0; i < (size_t)w * h * 3; ++i) {
         float value = rgb[i];
-        float t = value <= 0.0031308f ? 12.92f * value : (1.0f + 0.055f) * std::pow(value, 1.0f / 2.4f) - 0.055f;
+        float t = value <= 0.0031308f ? 12.92f * value : (1.0f + 0.055f) * kzoPow(value, 1.0f / 2.4f) - 0.055f;
         out[i] = (uint8_t)clampf(255.f * t, 0.f, 255.f);
     }
     return 0;

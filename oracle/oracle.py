@@ -37,6 +37,10 @@ def lib():
         L.kzo_scene_destroy.restype = None
         L.kzo_set_brute.argtypes = [C.c_void_p, C.c_int]
         L.kzo_set_brute.restype = None
+        L.kzo_math.argtypes = [C.c_int, C.c_uint32, abi.f32p, abi.f32p, abi.f32p]
+        L.kzo_math.restype = None
+        L.kzo_set_tie_mode.argtypes = [C.c_void_p, C.c_int]
+        L.kzo_set_tie_mode.restype = None
         L.kzo_film_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
         L.kzo_sample_count.argtypes = [C.c_void_p]
         L.kzo_sample_count.restype = C.c_uint
@@ -130,6 +134,11 @@ class OracleScene:
 
     def set_brute(self, brute):
         self.L.kzo_set_brute(self.h, 1 if brute else 0)
+
+    def set_tie_mode(self, mode):
+        """How the shadow loop decides the reference's built-in tie (the segment left after walking through an invisible light
+        ends exactly on the sampled light): 0 literal, +1 every tie occluded, -1 every tie unoccluded (kz_oracle.cpp Li)."""
+        self.L.kzo_set_tie_mode(self.h, int(mode))
 
     def render(self, sample_begin=0, sample_end=0, tiles=None, threads=0, film=None):
         if film is None:
@@ -249,3 +258,16 @@ def bsdf(params, which, wi, wo=None, acc_rough=0.0, s1=0.0, s2=(0.0, 0.0)):
     if which == "pdf":
         return float(out[0])
     return out[:3].copy(), out[3:6].copy(), bool(out[6])
+
+
+MATH_FN = {"sin": 0, "cos": 1, "exp": 2, "log": 3, "atan": 4, "atan2": 5, "acos": 6, "tan": 7, "pow": 8, "hypot": 9, "cube": 10, "cos1": 11}
+
+
+def math_fn(name, x, y=None, libm=False):
+    """The oracle's transcendental functions (kz_oracle_math.h) on float arrays; libm=True: the C library's float function instead (what the
+    reference's text calls on this machine)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = x if y is None else np.ascontiguousarray(y, np.float32)
+    out = np.zeros_like(x)
+    lib().kzo_math(MATH_FN[name] + (100 if libm else 0), x.size, _fp(x), _fp(y), _fp(out))
+    return out
