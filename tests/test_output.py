@@ -60,8 +60,7 @@ def test_device_tone_map_matches_oracle(gpu_lib, kz, O):
     sc.render()
     px = sc.srgb8()
     ref = O.OracleScene(d).srgb8(sc.film())                                          # the same film through the CPU restatement
-    diff = np.abs(px.astype(int) - ref.astype(int))
-    assert px.shape == (64, 96, 3) and diff.max() <= 1 and (diff != 0).mean() < 2e-3    # powf vs std::pow at a truncation edge
+    assert px.shape == (64, 96, 3) and np.array_equal(px, ref)                          # every byte: the sRGB curve's pow is the same arithmetic on both sides (kz_crmath.h)
     assert px.max() > 150 and px.min() < 30
 
 
