@@ -1,6 +1,6 @@
 """A wider randomized parity sweep than the CI suite carries (tests/test_gpu_parity.py::_fuzz_scene, other seeds): HIP film vs the CPU oracle, megakernel == wavefront bit
 for bit, counting == product kernels, tile sets / sample ranges / dealer == one shot. Run through gpurun when GPU minutes are to spare:
-    python scripts/dev/fuzz_sweep.py [first_seed] [n_scenes]"""
+    python scripts/dev/fuzz_sweep.py [first_seed] [n_scenes] [--rich]"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,11 +9,13 @@ kz = importlib.import_module("nano-kazen_amd")
 import oracle as O
 from test_gpu_parity import _fuzz_scene, tie_bracket
 
-first, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 60)
+rich = "--rich" in sys.argv                 # bicubic lookups and environment backgrounds on top (tests/test_gpu_parity.py _fuzz_scene)
+argv = [a for a in sys.argv if a != "--rich"]
+first, n = (int(argv[1]) if len(argv) > 1 else 5000), (int(argv[2]) if len(argv) > 2 else 60)
 bad = []
 t0 = time.time()
 for seed in range(first, first + n):
-    d = _fuzz_scene(kz.scenes, seed)
+    d = _fuzz_scene(kz.scenes, seed, rich)
     sc = kz.Scene(d, device=0)
     sc.render()
     film = sc.film()

@@ -354,9 +354,10 @@ def same_bits(a, b):
 
 
 # ---------------------------------------------------------------- randomized differential test
-def _fuzz_scene(S, seed):
+def _fuzz_scene(S, seed, rich=False):
     """A random small scene: triangle soup + room, random BSDF plugins on every mesh, random visible / invisible lights (some stacked so
-    shadow rays cross them), random camera / sampler / filter / integrator settings."""
+    shadow rays cross them), random camera / sampler / filter / integrator settings. rich: the same scene with (from a second generator, so the plain scene
+    of a seed does not change) bicubic image lookups and an environment image, colour ramp or constant behind the background (scripts/dev/fuzz_sweep.py --rich)."""
     rng = np.random.default_rng(seed)
     d = S.random_triangles(int(rng.integers(50, 3000)), int(rng.integers(24, 72)), int(rng.integers(24, 56)), 4, sampler="independent", s_edge=float(rng.uniform(0.05, 0.4)))
     makers = [lambda: S.diffuse(tuple(rng.uniform(0.1, 0.9, 3))),
@@ -394,6 +395,22 @@ def _fuzz_scene(S, seed):
         d.camera.update(type="thinlens", apertureRadius=float(rng.uniform(0, 0.2)), focusDistance=float(rng.uniform(1, 4)))
     if rng.random() < 0.5:
         d.background = {"color": tuple(rng.uniform(0, 1, 3)), "intensity": float(rng.uniform(0, 2))}
+    if rich:
+        r2 = np.random.default_rng(1_000_003 * (seed + 1))
+
+        def walk(node):
+            if isinstance(node, dict):
+                if node.get("type") == "imagetexture" and r2.random() < 0.5:
+                    node["filter"] = "bicubic"
+                for v in node.values():
+                    walk(v)
+        for m in d.meshes:
+            walk(m["bsdf"])
+        k = r2.random()
+        if k < 0.6:
+            env = r2.random((int(r2.integers(2, 9)), int(r2.integers(3, 17)), 3)).astype(np.float32) * float(r2.uniform(0.2, 3))
+            tex = S.imagetexture(env, 1.0, "linear", "bicubic" if r2.random() < 0.3 else "bilinear")
+            d.background = {"texture": tex if k < 0.45 else S.colorramp(tex, 0.1, 0.9), "intensity": float(r2.uniform(0.2, 2))}
     return d
 
 
