@@ -59,8 +59,10 @@
     X(59, "v_mov_b32_dpp", T_1DPP, "v_mov_b32_dpp d, m quad_perm") X(60, "v_add_f32_dpp", T_2DPP, "v_add_f32_dpp d, m, d quad_perm") X(61, "v_max_f32_dpp", T_2DPP, "v_max_f32_dpp d, m, d quad_perm") \
     X(62, "v_cvt_f32_u32_sdwa", T_1SDWA, "v_cvt_f32_u32_sdwa d, m src0_sel:BYTE_1") X(63, "v_xad_u32", T_3, "v_xad_u32 d, m, c, d") X(64, "v_cvt_pk_f32_fp8", T_1PK, "v_cvt_pk_f32_fp8 d[2], m") \
     X(65, "v_fma_f32", T_3D0, "v_fma_f32 d, d, m, c with m = 0.999, c = 1e-3 (values that move: valu_clock.hip's operands)") X(66, "v_fma_f32", T_3, "v_fma_f32 d, m, c, d with m = 0.999, c = 1e-3") \
-    X(67, "v_mul_f32", T_2, "v_mul_f32 d, m, d with m = 0.999") X(68, "v_max_f32", T_2, "v_max_f32 d, m, d with m = 0.999")
-#define N_OPS 69
+    X(67, "v_mul_f32", T_2, "v_mul_f32 d, m, d with m = 0.999") X(68, "v_max_f32", T_2, "v_max_f32 d, m, d with m = 0.999") \
+    X(69, "v_pk_fma_f16", T_3, "v_pk_fma_f16 d, m, c, d") X(70, "v_pk_max_f16", T_2, "v_pk_max_f16 d, m, d") X(71, "v_pk_min_f16", T_2, "v_pk_min_f16 d, m, d") X(72, "v_pk_mul_f16", T_2, "v_pk_mul_f16 d, m, d") \
+    X(73, "v_pk_add_f16", T_2, "v_pk_add_f16 d, m, d") X(74, "v_cvt_pkrtz_f16_f32", T_2, "v_cvt_pkrtz_f16_f32 d, m, d") X(75, "v_pk_min_u16", T_2, "v_pk_min_u16 d, m, d") X(76, "v_pk_add_u16", T_2, "v_pk_add_u16 d, m, d")
+#define N_OPS 77
 
 template <int V>
 __global__ __launch_bounds__(1024) void loop(int iters, float seed, unsigned sel, float *__restrict__ sink) {
