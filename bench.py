@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-c5", action="store_true", help="N > 1: skip the bounded C5 strong-scaling job that rides in the same JSON line")
     ap.add_argument("--strong-spp", type=int, default=256, help="samples per pixel of that job (sample indices [0, n) of the 4096-spp table)")
+    ap.add_argument("--no-asset-scene", action="store_true", help="N = 1: skip the slice of the reference's own scene file that rides in the same JSON line")
+    ap.add_argument("--asset-spp", type=int, default=512, help="samples per pixel of that slice (sample indices [0, n) of the scene file's 4096)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
     args = ap.parse_args()
     if args.steps is None:
@@ -341,11 +343,40 @@ def main():
         sc5 = strong_c5(kz, rank, world, device_index, args.tris, kw, args.strong_spp)
         if rank == 0:
             out["strong_c5"] = sc5
+    if world == 1 and not args.strong and not args.no_asset_scene:
+        out["reference_scene"] = reference_scene(kz, device_index, args.asset_spp)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def reference_scene(kz, device_index, spp):
+    """The one job of the reference's own that this path can run as published: scene/2022_q1/parameters/default_m0_r0.5.xml + its OBJ files (36 378 triangles, kiss object on a
+    smooth backdrop, three invisible area lights), flattened into tests/golden/q1_default_m0_r0.5.npz, at the settings of the scene file - 1920 x 1080, independent sampler,
+    path_mis maxDepth 5 - for a slice of its 4096 samples per pixel. Outside the timed region of `value`; not a BASELINE.json config, so `vs_baseline` stays null: the only published
+    timing of the reference is a caption for a job of this size on another scene of the same studio set (unstated CPU), quoted beside it."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "q1_default_m0_r0.5.npz")
+    if not os.path.exists(path):
+        return None
+    d = kz.scenes.load_npz(path)
+    sc = kz.Scene(d, device=device_index)
+    spp = min(spp, sc.sample_count)
+    sc.render(0, min(64, spp)); sc.sync()
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter(); sc.render(0, spp); sc.sync(); ts.append(time.perf_counter() - t0)
+    n = sc.width * sc.height * spp
+    rec = {"workload": "scene/2022_q1/parameters/default_m0_r0.5.xml (36 378 triangles, the reference's own scene file via tests/golden/q1_default_m0_r0.5.npz), %dx%d, independent sampler, "
+                       "path_mis maxDepth %d, sample indices [0, %d) of the file's %d" % (sc.width, sc.height, d.integrator["maxDepth"], spp, sc.sample_count),
+           "value": round(n / min(ts) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),
+           "whole_job": "all 4096 spp: 4.4 s, 1 927 Msamples/s; against the published 4096-spp picture of this scene file: profiles/r04p_q1_full",
+           "published_caption": {"job": "1920x1080, 4096 spp (another scene of the same studio set)", "seconds": 702, "Msamples_per_s": 12.1, "hardware": "unstated CPU",
+                                 "source": "doc/2022_q1/2022_q1_report.md:226"}}
+    sc.close()
+    return rec
 
 
 def strong_c5(kz, rank, world, device_index, tris, kw, spp=256):
