@@ -537,6 +537,27 @@ def test_sampled_directions_equal_oracle_bit_for_bit(gpu_lib, kz, O):
         assert np.array_equal(bits(ev), bits(e)) and np.array_equal(bits(pd), bits(p)), (r, "eval / pdf")
 
 
+def _named_scenes(S):
+    return {"cornell": lambda: S.cornell_box(48, 48, 8), "cornell_pmj": lambda: S.cornell_box(48, 48, 8, sampler="pmj02bn", seed=1), "hero": lambda: S.hero_scene(64, 36, 8, detail=0.3),
+            "sphere_env": lambda: S.sphere_env(48, 48, 8), "materials": lambda: S.materials_scene(64, 36, 8), "textured": lambda: S.textured_scene(64, 36, 8),
+            "random_triangles": lambda: S.random_triangles(20000, 64, 36, 8),
+            "q1_asset": lambda: S.load_npz(os.path.join(HERE, "golden", "q1_default_m0_r0.5.npz"), {"camera": {"width": 64, "height": 36}, "sampler": {"sampleCount": 8}})}
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_pmj", "hero", "sphere_env", "materials", "textured", "random_triangles", "q1_asset"])
+def test_every_sample_equals_the_oracle_bit_for_bit(gpu_lib, kz, O, name):
+    """renderSample of every (pixel, sample) of the configs' scenes - and of the reference's own asset scene (smooth normals: terminator offsets, interpolated frames) -
+    returns the oracle's position and radiance to the last bit: nothing on the path is compared by tolerance any more."""
+    d = _named_scenes(kz.scenes)[name]()
+    sc, ora = kz.Scene(d, device=0), O.OracleScene(d)
+    w, h, n = d.camera["width"], d.camera["height"], sc.sample_count
+    yy, xx, ii = np.meshgrid(np.arange(h), np.arange(w), np.arange(n), indexing="ij")
+    pxy, idx = np.stack([xx.ravel(), yy.ravel()], 1).astype(np.int32), ii.ravel().astype(np.uint32)
+    g, c = sc.render_samples(pxy, idx), ora.render_samples(pxy, idx)
+    assert same_bits(g, c), int((g.view(np.uint32) != c.view(np.uint32)).any(axis=1).sum())
+    assert np.abs(c[:, 2:]).max() > 0
+
+
 @pytest.mark.parametrize("seed", [5084, 5094, 5100])
 def test_reference_shadow_ties_are_bracketed(gpu_lib, kz, O, seed):
     """Scenes of the wider sweep (scripts/dev/fuzz_sweep.py) where visible lights are sampled THROUGH invisible ones: the literal films differ in the
