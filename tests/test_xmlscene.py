@@ -204,3 +204,17 @@ def test_flattened_asset_scene_fixture(kz, O):
                 assert (ma[k] is None) == (mb[k] is None) and (ma[k] is None or np.array_equal(ma[k], mb[k]))
             assert ma["bsdf"] == mb["bsdf"] or (ma["bsdf"] and {k: (list(v) if isinstance(v, tuple) else v) for k, v in mb["bsdf"].items()} == ma["bsdf"])
         assert np.array_equal(np.asarray(d.camera["toWorld"]), np.asarray(x.camera["toWorld"]))
+
+
+def test_parameter_sets_fixture(kz):
+    """tests/golden/q1_params.json: the kiss parameters of the 22 scene files of scene/2022_q1/parameters/ (which differ in nothing else: make_q1_scene.py checks it when
+    it writes the file). Where the reference is present every set is the loader's output for its file."""
+    import json
+    params = json.load(open(os.path.join(HERE, "golden", "q1_params.json")))["params"]
+    assert len(params) == 22 and set(PIN_IMAGES) <= set(params)
+    assert all(p["type"] == "kazenstandard" for p in params.values())
+    if os.path.isdir(REF):
+        for name, p in params.items():
+            x = kz.xmlscene.load_xml(os.path.join(REF, name + ".xml"), {"camera": {"width": 16, "height": 9}, "sampler": {"sampleCount": 1}})
+            want = {k: (list(v) if isinstance(v, tuple) else v) for k, v in x.meshes[4]["bsdf"].items()}
+            assert {k: v for k, v in p.items() if not k.startswith("_")} == want, name
