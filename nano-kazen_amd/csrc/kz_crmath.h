@@ -142,7 +142,10 @@ KZ_CR_CALL float kzLog(float x) {
 }
 // pow(x, y) = exp(y log x) for x > 0 (the path's uses: sRGB curves, bases in (0.003, 1e4), |y log x| < 25, relative error < 2^-47)
 KZ_CR_CALL float kzPow(float x, float y) {
-    if (!(x > 0.0f) || x == __builtin_inff() || y != y) return (x == 0.0f && y > 0.0f) ? 0.0f : __builtin_nanf("");
+    if (x != x || y != y || x < 0.0f) return __builtin_nanf("");                           // (negative bases: NaN, as powf gives for the non-integer exponents of the path)
+    if (x == 0.0f) return y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : __builtin_inff());
+    if (x == __builtin_inff()) return y > 0.0f ? x : (y == 0.0f ? 1.0f : 0.0f);
+    if (x == 1.0f) return 1.0f;
     const double z = (double)y * kzcrLogD((double)x);
     if (!(z > -104.0)) return 0.0f;
     if (z > 89.0) return __builtin_inff();
