@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); 6.29 TB/s measured copy
-SPP_PER_RANK_STEP = 128        # two passes of 64 spp per call at 1920x1080 (2^27 items per pass)
+SPP_PER_RANK_STEP = 512        # one pass of 2^30 (pixel, sample) items per call at 1920x1080: the library's default pass size on a 288 GB card (round 4; 128 = two passes of 2^27 before)
 W, H, NTRIS, SPP = 1920, 1080, 1000000, 1024
 W5, H5, SPP5 = 3840, 2160, 4096
 TILE = 64
@@ -160,24 +160,22 @@ def main():
     if args.strong:
         spp_step = spp_table                              # the whole job every step
     else:
-        spp_step = SPP_PER_RANK_STEP * world              # weak scaling: a rank owns 1/N of the pixels and renders N x the spp
-        if spp_step > spp_table:
-            raise SystemExit("bench.py: %d ranks x %d spp per step exceed the %d-spp sampler table (use <= %d ranks)"
-                             % (world, SPP_PER_RANK_STEP, spp_table, spp_table // SPP_PER_RANK_STEP))
+        # weak scaling: a rank owns 1/N of the pixels and renders N x the spp. From N = 4 on that is more than the 1024-entry table holds: the sample
+        # indices are taken modulo the table, every wrap its own call (the same work per sample; a call is then one pass of <= 2^28 items - a rank's
+        # pixels x the whole table - where N = 1 and 2 run passes of 2^30 and 2^29)
+        spp_step = SPP_PER_RANK_STEP * world
     stream = torch.cuda.current_stream().cuda_stream
     kw = {}
     if shared_device:
         kw["max_state_bytes"] = int(0.8 * torch.cuda.mem_get_info(device_index)[1] / world)
 
     def step(k, accumulate=True):
-        # sample indices [s0, s0 + spp_step) modulo the table: a slice that wraps is rendered as its two halves
-        s0 = (k * spp_step) % spp_table
-        s1 = s0 + spp_step
-        if s1 <= spp_table:
-            scene.render(s0, s1, tiles=render_tiles, accumulate=accumulate, stream=stream, **kw)
-        else:
-            scene.render(s0, spp_table, tiles=render_tiles, accumulate=accumulate, stream=stream, **kw)
-            scene.render(0, s1 - spp_table, tiles=render_tiles, accumulate=True, stream=stream, **kw)
+        # sample indices [s0, s0 + spp_step) modulo the table: a slice that wraps is rendered piece by piece
+        s0, left = (k * spp_step) % spp_table, spp_step
+        while left > 0:
+            n = min(left, spp_table - s0)
+            scene.render(s0, s0 + n, tiles=render_tiles, accumulate=accumulate, stream=stream, **kw)
+            accumulate, left, s0 = True, left - n, (s0 + n) % spp_table
 
     def barrier():
         # device first, then the ranks, then the device again: a rank must not start (or stop) its clock while its own earlier kernels still

@@ -297,8 +297,10 @@ typedef struct KzRenderOpts {
     void *stream;               /* hipStream_t to launch on (NULL = the null stream)                     */
     /* ---- ABI v3 (all zero = defaults) ---- */
     int32_t device;             /* the replica to render on: a HIP device index kz_scene_upload was called with */
-    int32_t passesInFlight;     /* passes kept in flight on internal streams: 0 = default (KZ_DEFAULT_PASSES_IN_FLIGHT), 1 .. 8 */
-    uint64_t passItems;         /* (pixel, sample) items per pass; 0 = default 2^27, lowered to fit maxStateBytes */
+    int32_t passesInFlight;     /* passes kept in flight on internal streams, 1 .. 8; 0 = default: with passItems also 0, ONE pass at a time as large as the
+                                   state budget allows (see passItems); with passItems given, or with a dealer, KZ_DEFAULT_PASSES_IN_FLIGHT */
+    uint64_t passItems;         /* (pixel, sample) items per pass, lowered to fit maxStateBytes; 0 = default: 2^30 (175 GB of path state on a 288 GB card: fewer, longer
+                                   kernels), 2^29 per context with a dealer, 2^27 when passesInFlight is given */
     uint64_t maxStateBytes;     /* cap on this replica's path state + sample records + film tap sums; 0 = min(3/4 of the device's
                                    memory, what is free + what the replica already holds for this purpose)       */
     KzTuning tune;

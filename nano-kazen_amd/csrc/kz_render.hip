@@ -735,7 +735,12 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     // fit; n > 0: n samples (or all the call asks for) of as many pixels as fit, pixel chunks in the order of the pixel list.
     // The state never takes more than the caller's limit; without one, not more than 3/4 of the device and not more than what
     // is free now plus what this replica already holds for the purpose (another process or replica may own the rest).
-    int nCtx = pipeline == 2 ? (opts->passesInFlight ? opts->passesInFlight : KZ_DEFAULT_PASSES_IN_FLIGHT) : 1;
+    // Round 4, sized for the 288 GB of the card: with NOTHING said (passItems = passesInFlight = 0, no dealer) a call runs ONE pass at a time, as large as the state
+    // budget allows up to 2^30 items (175 GB). Same-call sweeps (profiles/r04r_pass_size): C4 2 x 2^27 1 772, 2 x 2^28 1 804, 2 x 2^29 1 827, 1 x 2^30 1 849 Msamples/s; C5 1 821 -> 1 890;
+    // C3 1 831 -> 1 842; a 128-spp call of C4 (one pass of 2^28 instead of two of 2^27) 1 753 -> 1 797: fewer, longer kernels have shorter relative tails, and a second pass in
+    // flight buys less than the memory it takes is worth as pass size. A dealer keeps two contexts (its batches overlap through them) of up to 2^29 items.
+    const bool autoShape = pipeline == 2 && !opts->passItems && !opts->passesInFlight;
+    int nCtx = pipeline == 2 ? (opts->passesInFlight ? opts->passesInFlight : (autoShape && !opts->dealer ? 1 : KZ_DEFAULT_PASSES_IN_FLIGHT)) : 1;
     const size_t perItem = (pipeline == 2 ? KZ_STATE_BYTES_PER_ITEM : 0) + KZ_SAMPLE_BYTES_PER_ITEM;
     // camera rays by pixel beams: a pinhole camera with an affine sample map, a stack that fits LDS twice, unless the caller asks otherwise
     const bool beams = pipeline == 2 && P.beamOk && tune.packet != 1 && tune.packet != 2 && P.maxDepth > 0;
@@ -748,7 +753,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         else limit = (size_t)32 << 30;
     }
     const uint32_t nSamples = s1 - s0;
-    const size_t wantItems = std::max<size_t>(opts->passItems ? (size_t)opts->passItems : (size_t)1 << 27, 64);
+    const size_t wantItems = std::max<size_t>(opts->passItems ? (size_t)opts->passItems : (autoShape ? (size_t)1 << (opts->dealer ? 29 : 30) : (size_t)1 << 27), 64);
     // Dynamic dealing (opts->dealer, ABI v5): the tile set is the whole list, a batch of tiles is a range of its pixel list, and the pass shape is
     // chosen for the pixels of a BATCH instead of those of the set.
     const KzTileDealer *dealer = opts->dealer;
@@ -777,7 +782,9 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         // A frame too large for 64 samples of every pixel per pass (C5 on one GPU: 16) is rendered in pixel chunks of 256 samples instead: a wave of the
         // camera-ray kernels is then one pixel again (one shared list), the film stage touches a chunk per pass instead of the whole frame, and the paths of a pass
         // stay in a part of the scene (C5, same call: 1 586 Msamples/s at 16 x all pixels, 1 708 at 64 x 2 M, 1 734 at 256 x 512 K).
-        if (S < 64 && nSamples >= 64) { S = std::min<uint32_t>(256u, nSamples); pixPerPass = (uint32_t)std::min<size_t>(nPixSet, std::max<size_t>(64, wantItems / S / 64 * 64)); }
+        // (round 4, default pass size 2^30: C5 at 128 x all 8.3 M pixels 1 865 Msamples/s, at 256 x 4.2 M pixels 1 890: the chunks are taken below 256 samples then)
+        const uint32_t chunkBelow = autoShape ? 256u : 64u;
+        if (S < chunkBelow && nSamples >= chunkBelow) { S = std::min<uint32_t>(256u, nSamples); pixPerPass = (uint32_t)std::min<size_t>(nPixSet, std::max<size_t>(64, wantItems / S / 64 * 64)); }
         // a multiple of 64 samples per pixel keeps every wave of the camera-ray kernels inside one pixel (one shared leaf list) - taken when it costs no extra pass
         // (a rank's share of a frame: 2^27 / 1 036 800 pixels = 129 -> 128)
         else if (S > 64 && S % 64 && (nSamples + S / 64 * 64 - 1) / (S / 64 * 64) == (nSamples + S - 1) / S) S = S / 64 * 64;
@@ -787,7 +794,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         s = S; px = pixPerPass;
         if ((size_t)px * (s * perItem + perPixel) <= room) return;
         const size_t sFit = room / px > perPixel ? (room / px - perPixel) / perItem : 0;
-        if (sFit >= 1) s = (uint32_t)std::min<size_t>(s, sFit);
+        if (sFit >= 1) { s = (uint32_t)std::min<size_t>(s, sFit); if (s > 64) s = s / 64 * 64; }      // (whole waves of one pixel for the camera-ray kernels)
         else { s = 1; px = (uint32_t)std::min<size_t>(px, room / (perItem + perPixel) / 64 * 64); }
     };
     // as many contexts as wanted, but never more than there are passes (a call that is one pass runs it in one context at full size)

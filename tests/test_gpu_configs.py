@@ -323,10 +323,16 @@ def test_state_budget_and_pass_options(gpu_lib, kz, O):
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
     per_item, per_pixel = 8 * 16 + 16 + 12 + 20, 25 * 16                       # path state + sample record per item; film tap sums per pixel (the beam lists, one per FRAME pixel, are the replica's)
     cap = 2 * npx * (3 * per_item + per_pixel)
-    sc.render(max_state_bytes=cap)                                    # room for two contexts of 3 spp
+    sc.render(max_state_bytes=cap, passes_in_flight=2)                # room for two contexts of 3 spp
     info = sc.last_pass_info()
     assert info["sppPerPass"] == 3 and info["passes"] == 8 and info["stateBytes"] <= cap + (64 << 20)      # + the traversal kernels' overflow stacks
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    sc.render(max_state_bytes=cap)                                    # nothing said about the schedule: ONE pass at a time, as large as the cap allows (round 4)
+    info = sc.last_pass_info()
+    assert (info["passesInFlight"], info["sppPerPass"], info["passes"]) == (1, 8, 3) and info["stateBytes"] <= cap + (64 << 20)
+    assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
+    sc.render()                                                       # and without a cap: the whole call in one pass
+    assert (sc.last_pass_info()["passesInFlight"], sc.last_pass_info()["sppPerPass"], sc.last_pass_info()["passes"]) == (1, 24, 1)
     sc.render(max_state_bytes=npx * (per_item + per_pixel), passes_in_flight=1)           # one context of one sample
     assert sc.last_pass_info()["sppPerPass"] == 1 and sc.last_pass_info()["passesInFlight"] == 1 and sc.last_pass_info()["pixelsPerPass"] == npx
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
