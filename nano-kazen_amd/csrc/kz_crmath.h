@@ -65,19 +65,10 @@ KZ_CR_FN void kzcrSinCosD(double x, double &s, double &c) {
     s = (q & 2) ? -a : a;
     c = ((q + 1) & 2) ? -b : b;
 }
-struct KzSinCos { float s, c; };
-__device__ __noinline__ KzSinCos kzSinCosCall(float x) {
-    double sd, cd; kzcrSinCosD((double)x, sd, cd);
-    KzSinCos r; r.s = (float)sd; r.c = (float)cd;
-    return r;
-}
+// (inline: as a call it still costs kz_wf_shade 21 spilled VGPRs - the caller's live state around it - where the inlined sequence with pinned coefficients costs none)
 KZ_CR_FN void kzSinCos(float x, float *s, float *c) {
-#ifdef KZ_SINCOS_CALL
-    const KzSinCos r = kzSinCosCall(x); *s = r.s; *c = r.c;
-#else
     double sd, cd; kzcrSinCosD((double)x, sd, cd);
     *s = (float)sd; *c = (float)cd;
-#endif
 }
 KZ_CR_CALL float kzCos(float x) { double sd, cd; kzcrSinCosD((double)x, sd, cd); return (float)cd; }
 KZ_CR_CALL float kzTan(float x) { double sd, cd; kzcrSinCosD((double)x, sd, cd); return kzcrNarrow(sd / cd); }
