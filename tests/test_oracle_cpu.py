@@ -424,3 +424,29 @@ def test_transcendental_definitions_are_the_correctly_rounded_values(O):
         assert int((got.view(np.uint32) != cr.view(np.uint32)).sum()) <= 1, name
         libm = O.math_fn(name, *args, libm=True)
         print("%-6s libm float function differs from the correctly rounded value on %.3f %% of %d arguments" % (name, 100 * float((libm.view(np.uint32) != got.view(np.uint32)).mean()), n))
+
+
+def test_both_statements_of_the_transcendentals_are_the_same_sequences():
+    """csrc/kz_crmath.h (HIP) and oracle/kz_oracle_math.h (oracle) define the ten functions as the SAME sequences of double operations; the GPU test compares their results bit for bit,
+    this one compares the statements themselves (code lines with the device attributes, the prefixes and the coefficient pinning taken out), so that a drift shows on a box without a GPU."""
+    import re
+    root = os.path.dirname(HERE)
+
+    def norm(path, device):
+        src = open(path).read()
+        src = src[src.index("#pragma once"):]
+        lines = []
+        for l in src.splitlines():
+            l = l.split("//")[0].rstrip()
+            if not l.strip() or l.startswith("#"):
+                continue
+            if device:
+                l = re.sub(r"KZ_K\(([^()]*)\)", r"\1", l)
+                l = l.replace("kzcr", "kzom")
+                l = re.sub(r"\bKZ_CR_(FN|CALL)\b", "KZO_FN", l)
+                l = re.sub(r"\bkz(SinCos|Cos|Tan|Exp|Log|Pow|Atan2|Atan|Acos|Hypot|Cube)\b", r"kzo\1", l)
+            lines.append(re.sub(r"\s+", " ", l).strip())
+        return [l for l in lines if "kzomK(" not in l]                     # (the pinning helper exists on the device only)
+    dev = norm(os.path.join(root, "nano-kazen_amd", "csrc", "kz_crmath.h"), True)
+    ora = norm(os.path.join(root, "oracle", "kz_oracle_math.h"), False)
+    assert len(ora) > 100 and dev == ora, [(a, b) for a, b in zip(dev, ora) if a != b][:3]
