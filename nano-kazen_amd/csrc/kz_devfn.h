@@ -823,8 +823,32 @@ __device__ float roughPdf(const KzBSDF &m, V3 wi, V3 wo) {
     const float ks = 1 - fmaxf(m.albedo[0], fmaxf(m.albedo[1], m.albedo[2]));
     return ks * D * wh.z * (rcpExact(4.f * fabsf(dot(wh, wo)))) + (1 - ks) * wo.z * KZ_INV_PI;
 }
-__device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y, V3 &wo, bool &alive, float &etaScale) {
-    alive = true;
+// roughEval and roughPdf of one direction pair in ONE evaluation: the two functions of the reference form the same half vector and the same Beckmann D(wh, alpha)
+// (bsdf.cpp:756-780, :870-905) - same arguments, same bits - so they are formed once here (D is an exp through kz_crmath.h: a call and ~40 double operations).
+// Returns exactly (roughEval(m, wi, wo), roughPdf(m, wi, wo)).
+__device__ void roughEvalPdf(const KzBSDF &m, V3 wi, V3 wo, V3 &f, float &pdf) {
+    if (m.type == KZ_BSDF_ROUGHDIELECTRIC || m.type == KZ_BSDF_GGX) { f = roughEval(m, wi, wo); pdf = roughPdf(m, wi, wo); return; }
+    if (wi.z <= 0 || wo.z <= 0) { f = mk(0.f); pdf = 0.f; return; }
+    const float alpha = alphaOf(m.alpha);
+    const V3 wh = normalized(wi + wo);
+    const float D = evalBeckmann(wh, alpha);
+    if (m.type == KZ_BSDF_ROUGHCONDUCTOR) {
+        const V3 F = fresnelCond(dot(wh, wo), mk(m.condEta[0], m.condEta[1], m.condEta[2]), mk(m.condK[0], m.condK[1], m.condK[2]));
+        const float G = smithBeckmannG1(wi, wh, alpha) * smithBeckmannG1(wo, wh, alpha);
+        f = D * F * G / (4.f * wi.z);
+        pdf = D * wh.z * (rcpExact(4.f * dot(wh, wo)));
+        return;
+    }
+    const V3 kd = mk(m.albedo[0], m.albedo[1], m.albedo[2]);                                                 // roughplastic
+    const float ks = 1 - maxCoeff(kd);
+    const float F = fresnelIOR(dot(wh, wo), m.extIOR, m.intIOR);
+    const float G = smithBeckmannG1(wo, wh, alpha) * smithBeckmannG1(wi, wh, alpha);
+    f = kd * KZ_INV_PI * wo.z + mk(ks * (D * F * G) / (4.f * wi.z));
+    pdf = ks * D * wh.z * (rcpExact(4.f * fabsf(dot(wh, wo)))) + (1 - ks) * wo.z * KZ_INV_PI;
+}
+// pdfOut: roughPdf(m, wi, wo) at the sampled direction where sample() forms it on the way (roughconductor, roughplastic), else -1
+__device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y, V3 &wo, bool &alive, float &etaScale, float &pdfOut) {
+    alive = true; pdfOut = -1.f;
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {
         const float mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
         const float alpha = alphaOf(m.alpha) * (1.2f - 0.2f * sqrtExact(fabsf(wi.z)));
@@ -865,7 +889,9 @@ __device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y
         else wo = squareToCosineHemisphere(s2x, s2y);
     }
     if (wo.z <= 0) return mk(0.f);
-    return roughEval(m, wi, wo) / roughPdf(m, wi, wo);
+    V3 f; float pdf; roughEvalPdf(m, wi, wo, f, pdf);
+    pdfOut = pdf;
+    return f / pdf;
 }
 
 // returns the sample weight; wo is the sampled direction; alive=false when the path contributes nothing further;
@@ -888,7 +914,7 @@ __device__ V3 bsdfSample(const KzBSDF &m, const KissMat &km, V3 wi, float accRou
         etaScale = m.intIOR / m.extIOR;
         return mk(1.0f);
     }
-    if (EXT && m.type >= KZ_BSDF_GGX) return roughSample(m, wi, s1, s2x, s2y, wo, alive, etaScale);      // pdfOut stays -1: the caller evaluates pdf()
+    if (EXT && m.type >= KZ_BSDF_GGX) return roughSample(m, wi, s1, s2x, s2y, wo, alive, etaScale, pdfOut);   // (pdfOut -1 for ggx / roughdielectric: the caller evaluates pdf())
     if (wi.z <= 0) { alive = false; return mk(0.f); }                              // bsdf.cpp:60-61, :176-177, :1302-1303
     alive = true;
     if (EXT && m.type == KZ_BSDF_MIRROR) { wo = mk(-wi.x, -wi.y, wi.z); discrete = true; return mk(1.0f); }   // bsdf.cpp:175-191
@@ -938,7 +964,7 @@ __device__ __forceinline__ void bsdfEvalPdf(const KzBSDF &m, const KissMat &km, 
         const bool up = wi.z > 0 && wo.z > 0;
         f = up ? mk(m.albedo[0], m.albedo[1], m.albedo[2]) * KZ_INV_PI * wo.z : mk(0.f);
         pdf = up ? KZ_INV_PI * wo.z : 0.f;
-    } else if (EXT && m.type >= KZ_BSDF_GGX) { f = roughEval(m, wi, wo); pdf = roughPdf(m, wi, wo); }
+    } else if (EXT && m.type >= KZ_BSDF_GGX) roughEvalPdf(m, wi, wo, f, pdf);
     else if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) { f = mk(0.f); pdf = 0.f; }       // discrete BRDFs evaluate to zero
     else kissEvalPdf<true, true>(m, km, wi, wo, accRough, f, pdf);
 }
