@@ -827,7 +827,29 @@ __device__ float roughPdf(const KzBSDF &m, V3 wi, V3 wo) {
 // (bsdf.cpp:756-780, :870-905) - same arguments, same bits - so they are formed once here (D is an exp through kz_crmath.h: a call and ~40 double operations).
 // Returns exactly (roughEval(m, wi, wo), roughPdf(m, wi, wo)).
 __device__ void roughEvalPdf(const KzBSDF &m, V3 wi, V3 wo, V3 &f, float &pdf) {
-    if (m.type == KZ_BSDF_ROUGHDIELECTRIC || m.type == KZ_BSDF_GGX) { f = roughEval(m, wi, wo); pdf = roughPdf(m, wi, wo); return; }
+    if (m.type == KZ_BSDF_GGX) { f = roughEval(m, wi, wo); pdf = roughPdf(m, wi, wo); return; }
+    if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {                                     // (bsdf.cpp:985-1043: the same wm, Fresnel term and D in eval and pdf)
+        const float alpha = alphaOf(m.alpha), mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
+        const bool refl = wi.z * wo.z > 0.f;
+        const float eta = wi.z > 0.f ? mEta : mInvEta;
+        V3 wm = refl ? normalized(wi + wo) : normalized(wi + wo * eta);
+        float dwm_dwo;                                                            // (pdf forms it from the half vector BEFORE the flip to the upper hemisphere)
+        if (refl) dwm_dwo = rcpExact(4.0f * dot(wo, wm));
+        else { const float sd = dot(wi, wm) + eta * dot(wo, wm); dwm_dwo = (eta * eta * dot(wo, wm)) / (sd * sd); }
+        wm = wm * signf1(wm.z);
+        float ct; const float F = fresnelDielectricT(dot(wi, wm), mEta, ct);
+        const float D = evalBeckmann(wm, alpha);
+        float prob = D * wm.z;
+        prob *= refl ? F : (1 - F);
+        pdf = fabsf(prob * dwm_dwo);
+        if (wi.z == 0) { f = mk(0.f); return; }
+        const float G = smithBeckmannG1(wo, wm, alpha) * smithBeckmannG1(wi, wm, alpha);
+        if (refl) { f = mk((F * G * D) / (4.f * fabsf(wi.z))); return; }
+        const float denom = dot(wi, wm) + eta * dot(wo, wm);
+        const float value = ((1 - F) * D * G * eta * eta * dot(wi, wm) * dot(wo, wm)) / (wi.z * sqr(denom));
+        f = mk(fabsf(value));
+        return;
+    }
     if (wi.z <= 0 || wo.z <= 0) { f = mk(0.f); pdf = 0.f; return; }
     const float alpha = alphaOf(m.alpha);
     const V3 wh = normalized(wi + wo);
