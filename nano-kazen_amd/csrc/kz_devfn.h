@@ -1001,7 +1001,13 @@ __device__ __forceinline__ float texelAt(const KzImageRow &im, const uint8_t *ba
     const size_t i = ((size_t)y * (size_t)im.width + (size_t)x) * (size_t)im.channels + (size_t)c;
     return im.format == KZ_PIXEL_F32 ? reinterpret_cast<const float *>(base)[i] : (float)base[i] * (1.0f / 255.0f);
 }
-__device__ __forceinline__ int wrapPeriodic(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+__device__ __forceinline__ int wrapPeriodic(int i, int n) {
+    // a power-of-two size: the mask is the same residue, for negative i too. The runtime modulo is ~24 instructions, six of them per bilinear lookup; the empty asm keeps it
+    // behind a real branch (left alone the compiler evaluates both forms and selects: no gain) that waves whose lanes all look up power-of-two images skip.
+    if ((n & (n - 1)) == 0) return i & (n - 1);
+    asm volatile("" : "+v"(i));
+    i %= n; return i < 0 ? i + n : i;
+}
 __device__ __forceinline__ float srgbToLinear(float v) {                           // Color3f::toLinearRGB, common.cpp:368-382
     return v <= 0.04045f ? v * (1.0f / 12.92f) : kzPow((v + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
