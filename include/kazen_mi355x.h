@@ -132,7 +132,7 @@ typedef struct KzBSDF {
     float intIOR;               /* dielectric: "intIOR", default 1.5046               */
     float extIOR;               /* dielectric: "extIOR", default 1.000277             */
     float alpha;                /* roughconductor/roughplastic: "alpha" (default 0.1), roughdielectric: "roughness" (0.1), ggx: "roughness" (0.5);
-                                   the raw property: the library applies max(0.001, x^2) where the constructor does */
+                                   the raw property: the library applies max(0.001, x^2) where the constructor does - unless alphaResolved says otherwise */
     float condEta[3];           /* roughconductor: eta of "material" (Au default / Cu / Cr, bsdf.cpp:795-806) */
     float condK[3];             /* roughconductor: k                                    */
     int32_t albedoTex;          /* diffuse ("lambertian", bsdf.cpp:202-276) / ggx albedo, kiss baseColor: texture id or 0   */
@@ -140,7 +140,10 @@ typedef struct KzBSDF {
     int32_t metallicTex;        /* kiss metallic  (.r()): texture id or 0              */
     int32_t normalTex;          /* normalmap: texture id (required)                    */
     int32_t nested;             /* normalmap: index of the wrapped BSDF row (not itself a normalmap) */
-    int32_t pad_[2];
+    int32_t alphaResolved;      /* roughconductor / roughplastic / roughdielectric only: 1 = `alpha` already IS the constructor's m_alpha = max(0.001, sqr(property))
+                                   (bsdf.cpp:696-700, :818-822, :956-959) - what an adapter inside a kazen tree can read: the plugins keep m_alpha, not the property.
+                                   0 (zero-initialised rows, every earlier caller) = the raw property, as above */
+    int32_t pad_;
 } KzBSDF;                       /* 128 bytes */
 /* albedo doubles as: "kd" of roughplastic (default 0.5), the constanttexture albedo of ggx. */
 

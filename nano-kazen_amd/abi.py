@@ -36,7 +36,7 @@ class KzBSDF(C.Structure):
                 ("clearcoatRoughness", C.c_float), ("sheen", C.c_float), ("sheenTint", C.c_float),
                 ("intIOR", C.c_float), ("extIOR", C.c_float), ("alpha", C.c_float), ("condEta", C.c_float * 3),
                 ("condK", C.c_float * 3), ("albedoTex", C.c_int32), ("roughnessTex", C.c_int32), ("metallicTex", C.c_int32),
-                ("normalTex", C.c_int32), ("nested", C.c_int32), ("pad_", C.c_int32 * 2)]
+                ("normalTex", C.c_int32), ("nested", C.c_int32), ("alphaResolved", C.c_int32), ("pad_", C.c_int32)]
 
 
 class KzImage(C.Structure):

@@ -721,7 +721,7 @@ __device__ __forceinline__ V3 refractV(V3 wi, V3 n, float eta) {
 }
 // ---- Beckmann helpers of roughconductor / roughplastic / roughdielectric (bsdf.cpp:721-750, warp.cpp:120-129, frame.h:63-68)
 __device__ __forceinline__ float tanThetaV(V3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return sqrtExact(temp) / v.z; }
-__device__ __forceinline__ float alphaOf(float x) { return fmaxf(0.001f, sqr(x)); }
+__device__ __forceinline__ float alphaOf(float x) { return x; }      // the row carries m_alpha = max(0.001, sqr(property)) (kz_scene_create; KzBSDF.alphaResolved)
 __device__ __forceinline__ float evalBeckmann(V3 m, float alpha) {
     float temp = tanThetaV(m) / alpha, ct = m.z, ct2 = ct * ct;
     return kzExp(-temp * temp) / (KZ_PI_F * alpha * alpha * ct2 * ct2);

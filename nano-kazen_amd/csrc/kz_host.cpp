@@ -185,6 +185,9 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
         const bool takesAlbedo = b.type == KZ_BSDF_DIFFUSE || b.type == KZ_BSDF_GGX || b.type == KZ_BSDF_KAZENSTANDARD;
         if ((b.albedoTex && !takesAlbedo) || ((b.roughnessTex || b.metallicTex) && b.type != KZ_BSDF_KAZENSTANDARD) || (b.normalTex && b.type != KZ_BSDF_NORMALMAP))
             return kz_fail(KZ_ERR_INVALID_ARG, "bsdf %u (type %d): a texture id is set on a parameter this model does not read through a texture", i, b.type);
+        const bool rough = b.type == KZ_BSDF_ROUGHCONDUCTOR || b.type == KZ_BSDF_ROUGHPLASTIC || b.type == KZ_BSDF_ROUGHDIELECTRIC;
+        if ((b.alphaResolved != 0 && b.alphaResolved != 1) || (b.alphaResolved && !rough))
+            return kz_fail(KZ_ERR_INVALID_ARG, "bsdf %u (type %d): alphaResolved = %d (0 or 1, and only roughconductor / roughplastic / roughdielectric rows have a resolved alpha)", i, b.type, b.alphaResolved);
         if (b.type == KZ_BSDF_NORMALMAP) {                  // bsdf.cpp:391-404: one texture child + one nested BSDF
             if (b.normalTex == 0) return kz_fail(KZ_ERR_INVALID_ARG, "bsdf %u: normalmap without a normal texture", i);
             if (b.nested < 0 || b.nested >= (int32_t)d->nBsdfs || d->bsdfs[b.nested].type == KZ_BSDF_NORMALMAP)
@@ -195,6 +198,13 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
     KzScene *sc = new KzScene();
     std::memset(&sc->prm, 0, sizeof sc->prm);
     sc->bsdfs.assign(d->bsdfs, d->bsdfs + d->nBsdfs);
+    // the rough BSDFs' constructors keep m_alpha = max(MIN_ALPHA, sqr(roughness)) (bsdf.cpp:696-700, :818-822, :956-959): formed here once, in float, as they
+    // form it (rows that arrive with alphaResolved = 1 carry it already); the kernels read the row's alpha as it is
+    for (KzBSDF &b : sc->bsdfs)
+        if ((b.type == KZ_BSDF_ROUGHCONDUCTOR || b.type == KZ_BSDF_ROUGHPLASTIC || b.type == KZ_BSDF_ROUGHDIELECTRIC) && !b.alphaResolved) {
+            const float MIN_ALPHA = 0.001f, a2 = b.alpha * b.alpha;
+            b.alpha = std::max(MIN_ALPHA, a2); b.alphaResolved = 1;
+        }
     { int trc = flattenTextures(d, sc); if (trc != KZ_OK) { delete sc; return trc; } }
     int defaultBsdf = -1;
 

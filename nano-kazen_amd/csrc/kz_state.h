@@ -8,7 +8,12 @@
 #include <hip/hip_runtime.h>
 #include "kz_internal.h"
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 // Path state in HBM: one array per field (SoA; 16-B records, coalesced for the stages that sweep all slots). -DKZ_STATE_AOS=1 builds the
@@ -64,25 +69,69 @@ struct DevMem {
 };
 
 struct EventPair { hipEvent_t a, b; };
+// The path-state memory of one pass context (kz_arena.cpp): one reserved virtual range, physical memory mapped into it level by level on a side
+// thread; `mapped` items of EVERY array are usable at any moment, and only ever more (until shrinkTo / releaseAll, which the owner calls on an idle device).
+struct KzArena {
+    static constexpr int kArrays = 17;        // rayA rayB hit thr misc shA shB shL | smp | queue 0 1 2 | jx jy r g b
+    int device;
+    char *va = nullptr; size_t vaBytes = 0;
+    size_t capItems = 0;                      // items the virtual ranges are reserved for (the stride of the five sample planes)
+    char *base[kArrays]; size_t elem[kArrays];
+    struct Level { size_t firstItem, items; hipMemGenericAllocationHandle_t h[kArrays]; int mappedArrays; };
+    std::vector<Level> levels;
+    std::atomic<size_t> mapped{0};
+    std::mutex m; std::condition_variable cvWork, cvProgress; std::thread th;
+    bool stop = false, busy = false; size_t target = 0;
+    std::atomic<int> failCountdown{0};        // kz_debug_fail_alloc: the nth physical allocation from now on fails
+    int err = 0; std::string errMsg;
+    std::chrono::steady_clock::time_point lastProgress;
+    explicit KzArena(int dev);
+    ~KzArena();
+    KzArena(const KzArena &) = delete; KzArena &operator=(const KzArena &) = delete;
+    static size_t bytesPerItem();
+    size_t bytes() const { return mapped.load() * bytesPerItem(); }
+    int reserve(size_t cap);
+    int request(size_t items, size_t minItems, double graceMs, size_t *got);
+    void shrinkTo(size_t items);
+    void releaseAll();
+    template <class Tp> Tp *array(int a) const { return (Tp *)base[a]; }
+private:
+    void growLoop(); bool growOneLevel(size_t first, size_t items); void dropLevels(size_t keepLevels); void stopThread();
+};
 // path state + sample records + stage events of one pass in flight
 struct PassCtx {
-    KzWf wf{}; std::vector<void *> wfAllocs; size_t wfCap = 0;
-    float *samp = nullptr; size_t sampCap = 0;                   // five SoA planes: jx | jy | r | g | b
+    KzArena *arena = nullptr;                                    // the path-state arrays and the five sample planes (jx | jy | r | g | b)
+    KzWf wf{};                                                   // (pointers into the arena, set by ctxEnsure)
+    float *samp = nullptr; size_t sampCap = 0;                   // sample planes: plane k at samp + k * sampCap (sampCap = the arena's reserved items)
     float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: taps^2 float4 per pixel of the tile set
+    uint32_t *counts = nullptr;                                  // queue counters of a pass (8 x 520 words)
     uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
     uint64_t beamSeen = 0;                                       // the last beam-list build (KzDeviceState::beamSeq) this context's stream has waited for
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
-    size_t bytes() const { return wfCap * (8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t)) + sampCap * 5 * sizeof(float) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4; }
+    size_t items() const { return arena ? arena->mapped.load() : 0; }
+    size_t bytes() const { return (arena ? arena->bytes() : 0) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4; }
+    // gives the memory back (the context stays usable: it grows again on demand); the caller has synchronised the device
     void release() {
-        for (void *p : wfAllocs) (void)hipFree(p);
-        wfAllocs.clear(); wfCap = 0; wf = KzWf{};
-        if (samp) (void)hipFree(samp); samp = nullptr; sampCap = 0;
+        if (arena) arena->shrinkTo(0);
+        wf = KzWf{}; samp = nullptr; sampCap = 0;
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
         if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
         if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
     }
+    void destroy() {
+        release();
+        if (counts) (void)hipFree(counts); counts = nullptr;
+        delete arena; arena = nullptr;
+        for (auto &e : stageEv) (void)hipEventDestroy(e);
+        stageEv.clear(); stageKind.clear();
+    }
 };
+// Pass contexts live in a per-device pool between replicas (kz_arena.cpp): a replica takes them on first use and hands them back when it goes.
+PassCtx *kzCtxAcquire(int device);
+void kzCtxRelease(int device, PassCtx *c);
+size_t kzCtxPoolBytes(int device);
+size_t kzCtxPoolTrim(int device, size_t keepBytes);
 struct KzDeviceState {
     int device = -1;
     KzDevTables T{};
@@ -100,7 +149,8 @@ struct KzDeviceState {
     unsigned long long *stats = nullptr; bool statsOn = false;
     hipStream_t lastStream = nullptr;
     int numCU = 256; size_t totalMem = 0;
-    PassCtx ctx[KZ_MAX_PASSES_IN_FLIGHT];
+    PassCtx *ctx[KZ_MAX_PASSES_IN_FLIGHT] = {};                  // taken from the device's pool on first use (ctxAt), handed back by releaseReplica
+    PassCtx &ctxAt(int i) { if (!ctx[i]) ctx[i] = kzCtxAcquire(device); return *ctx[i]; }
     std::vector<EventPair> events; size_t eventsUsed = 0;
     hipStream_t passStream[KZ_MAX_PASSES_IN_FLIGHT] = {}; hipEvent_t evFork = nullptr, evFilm[KZ_MAX_PASSES_IN_FLIGHT] = {}, evCallA = nullptr, evCallB = nullptr;
     int lastCtx = 0; bool lastDual = false; int streamMode = 0;
@@ -110,7 +160,7 @@ struct KzDeviceState {
     uint2 *beamEntries = nullptr, *beamCount = nullptr; size_t beamCap = 0; hipEvent_t evBeam = nullptr; uint64_t beamSeq = 0;
     std::vector<std::pair<uint32_t, uint32_t>> beamDone; uint64_t beamDoneGen = 0;
     size_t beamBytes() const { return beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); }
-    size_t ctxBytes() const { size_t b = 0; for (const PassCtx &c : ctx) b += c.bytes(); return b; }
+    size_t ctxBytes() const { size_t b = 0; for (const PassCtx *c : ctx) if (c) b += c->bytes(); return b; }
     KzPassInfo lastInfo{};
 };
 struct KzReplicaSet { std::mutex m; std::vector<KzDeviceState *> v; };

@@ -9,13 +9,25 @@
 //   ConstantTexture("constanttexture"), BackgroundTexture("background"), GaussianFilter("gaussian"),
 //   MitchellNetravaliFilter("mitchell"), TentFilter("tent"), BoxFilter("box")
 //   renderer::render(Scene*, ...)                              include/kazen/renderer.h:10, src/kazen/renderer.cpp:72-153
-// The objects are DESCRIPTIONS: Scene::activate() flattens them into a KzSceneDesc (enum tags instead of vtables)
-// and renderer::render() hands that to the library, which does what renderer.cpp:85-133 did with TBB + Embree.
+// The objects are DESCRIPTIONS, and they keep their parameters PRIVATE exactly as the reference's plugin classes do (every one of them
+// is local to its .cpp there: bsdf.cpp:1157-1418, light.cpp:7-65, camera.cpp:14-131, sampler.cpp:18-390, integrator.cpp:185-355).
+// What leaves a plugin leaves it through the ONE virtual INTEGRATION.md adds to its interface - BSDF::describe(KzBSDF&, mi355x::Rows&),
+// Light::describe(KzLight&), Camera::describe(KzCamera&), ReconstructionFilter::describe(KzFilter&), Sampler::describe(KzSampler&),
+// Integrator::describe(KzIntegrator&), Texture<T>::describe(KzTexture&, mi355x::Rows&) / describeBackground(KzBackground&, ...) - and
+// Scene::getBackground(). The adapter a maintainer adds to a kazen tree (adapter/renderer_mi355x.cpp + adapter/kazen/mi355x.h, quoted
+// verbatim in INTEGRATION.md) is compiled UNCHANGED against this mirror (mirror_tree/kazen/*.h forward the reference's header names here):
+// tests/host_cpp builds it, so the adapter provably reads nothing the reference does not expose plus those virtuals.
 // Error behaviour follows the reference: kazen::Exception (std::runtime_error) from createInstance/addChild/activate
 // (scene.cpp:33-35, parser.cpp:295-298); a plugin name that exists in the reference but is outside the hot path throws
 // "... is not on the MI355X hot path" — never a silent fallback.
 #pragma once
 #include "../../include/kazen_mi355x.h"
+#if !defined(NAMESPACE_BEGIN)
+#  define NAMESPACE_BEGIN(name) namespace name {          /* include/kazen/define.h:64-69 */
+#endif
+#if !defined(NAMESPACE_END)
+#  define NAMESPACE_END(name) }
+#endif
 
 #include <algorithm>
 #include <array>
@@ -37,9 +49,18 @@
 
 namespace kazen {
 
-class Exception : public std::runtime_error {       // include/kazen/common.h:124-129
+class Exception : public std::runtime_error {       // include/kazen/common.h:124-129 (fmt-style "{}" placeholders, as the reference's variadic constructor takes them)
 public:
     explicit Exception(const std::string &m) : std::runtime_error(m) {}
+    template <typename... Args> Exception(const char *fmt, const Args &... args) : std::runtime_error(format(fmt, args...)) {}
+private:
+    static std::string format(const char *fmt) { return fmt; }
+    template <typename A, typename... Rest> static std::string format(const char *fmt, const A &a, const Rest &... rest) {
+        const char *br = std::strstr(fmt, "{}");
+        if (!br) return fmt;
+        std::ostringstream os; os << std::string(fmt, br) << a;
+        return os.str() + format(br + 2, rest...);
+    }
 };
 
 struct Color3f { float r = 0, g = 0, b = 0; Color3f() {} Color3f(float v) : r(v), g(v), b(v) {} Color3f(float r_, float g_, float b_) : r(r_), g(g_), b(b_) {} };
@@ -89,6 +110,17 @@ struct Transform {                                   // include/kazen/transform.
     }
 };
 using Vector3 = std::array<float, 3>;
+/// What the adapter reads of Eigen's Vector2i / MatrixXf / MatrixXu (include/kazen/vector.h, common.h:120-121): x() y(), data() size() cols()
+struct Vector2i { int v[2] = {0, 0}; Vector2i() {} Vector2i(int x_, int y_) { v[0] = x_; v[1] = y_; } int x() const { return v[0]; } int y() const { return v[1]; } int &x() { return v[0]; } int &y() { return v[1]; } };
+template <class S> struct ColMajorMatrix {                           // column-major r x n, contiguous: a mesh buffer of mesh.h:176-179
+    std::vector<S> a; size_t r = 3;
+    const S *data() const { return a.data(); }
+    size_t size() const { return a.size(); }
+    size_t rows() const { return r; }
+    size_t cols() const { return r ? a.size() / r : 0; }
+};
+using MatrixXf = ColMajorMatrix<float>;
+using MatrixXu = ColMajorMatrix<uint32_t>;
 /// File resolver (filesystem/resolver.h as main.cpp uses it: the scene file's directory is prepended before parsing)
 inline std::vector<std::string> &fileResolverPaths() { static std::vector<std::string> p; return p; }
 inline std::string resolveFile(const std::string &name) {
@@ -166,42 +198,34 @@ private:
 #define KAZEN_MI355X_REGISTER(cls, name) \
     inline bool cls##_registered = (::kazen::ObjectFactory::registerClass(name, [](const ::kazen::PropertyList &p) -> ::kazen::Object * { return new cls(p); }), true)
 
+} // namespace kazen
+// mi355x::Rows, mi355x::DeviceScene: the header INTEGRATION.md adds to a kazen tree, UNCHANGED. Its own includes are <kazen/common.h> (the
+// reference's header name; mirror_tree/kazen/common.h forwards it to this file) and <kazen_mi355x.h>: compile with
+//   -I include -I nano-kazen_amd/host/mirror_tree -I nano-kazen_amd/host/adapter
+#include <kazen/mi355x.h>
+namespace kazen {
+
 // ---- textures (src/kazen/texture.cpp) -------------------------------------------------------------------------------
-// Rows of one scene flattening: textures / images / the BSDF rows that normalmaps wrap (placed behind the per-mesh rows).
-class Texture;
-class BSDF;
-struct RowBuilder {
-    std::vector<KzTexture> textures; std::vector<KzImage> images;
-    std::map<const Texture *, int> seen;
-    int nestedBase = 0; std::vector<const BSDF *> nested;
-    int tex(const Texture *t);                       // 1-based texture id (0 for a null pointer)
-    int nestedRow(const BSDF *b) { nested.push_back(b); return nestedBase + (int)nested.size() - 1; }
-};
-class Texture : public Object {
+// include/kazen/texture.h:8-24 + the two virtuals INTEGRATION.md adds.
+template <typename T> class Texture : public Object {
 public:
     EClassType getClassType() const override { return ETexture; }
-    virtual KzTexture row(RowBuilder &rb) const = 0;
-    virtual bool isConstant() const { return false; }
+    /// ADDED: the texture's row for KzSceneDesc.textures; nested textures through rows.texture(child). false = not on the MI355X path
+    virtual bool describe(KzTexture &, mi355x::Rows &) const { return false; }
+    /// ADDED: only the "background" texture overrides this
+    virtual bool describeBackground(KzBackground &, mi355x::Rows &) const { return false; }
 };
-inline int RowBuilder::tex(const Texture *t) {
-    if (!t) return 0;
-    auto it = seen.find(t);
-    if (it != seen.end()) return it->second;
-    KzTexture k = t->row(*this);                     // children first
-    textures.push_back(k);
-    return seen[t] = (int)textures.size();
-}
-class ConstantTexture : public Texture {             // texture.cpp:10-32
+class ConstantTexture : public Texture<Color3f> {    // texture.cpp:10-32
 public:
     explicit ConstantTexture(const PropertyList &p) { m_color = p.getColor("color", Color3f(0.5f)); }
-    KzTexture row(RowBuilder &) const override { KzTexture k{}; k.type = KZ_TEX_CONSTANT; k.color[0] = m_color.r; k.color[1] = m_color.g; k.color[2] = m_color.b; k.child[0] = k.child[1] = k.child[2] = -1; return k; }
-    bool isConstant() const override { return true; }
+    bool describe(KzTexture &row, mi355x::Rows &) const override { row.type = KZ_TEX_CONSTANT; row.color[0] = m_color.r; row.color[1] = m_color.g; row.color[2] = m_color.b; return true; }
     std::string toString() const override { return "ConstantTexture[]"; }
+private:
     Color3f m_color;
 };
 /// "imagetexture" (texture.cpp:36-98). The reference decodes the file through OpenImageIO; this dependency-free mirror reads
 /// binary PGM / PPM (P5 / P6, 8 or 16 bit) and PFM, and takes any other format as an already decoded raster (setRaster).
-class ImageTexture : public Texture {
+class ImageTexture : public Texture<Color3f> {
 public:
     explicit ImageTexture(const PropertyList &p) {
         m_filename = p.getString("filename", ""); m_colorspace = p.getString("colorspace", "srgb"); m_scale = p.getFloat("scale", 1.0f);
@@ -216,14 +240,10 @@ public:
         size_t bytes = (size_t)width * height * channels * (format == KZ_PIXEL_F32 ? 4 : 1);
         m_px.assign((const uint8_t *)pixels, (const uint8_t *)pixels + bytes);
     }
-    KzTexture row(RowBuilder &rb) const override {
+    bool describe(KzTexture &row, mi355x::Rows &rows) const override {
         if (m_px.empty()) throw Exception("imagetexture \"" + m_filename + "\": no raster (decode the file in the host application and call setRaster)");
-        KzImage im{}; im.pixels = m_px.data(); im.width = m_w; im.height = m_h; im.channels = m_c; im.format = m_fmt;
-        rb.images.push_back(im);
-        KzTexture k{}; k.type = KZ_TEX_IMAGE; k.image = (int32_t)rb.images.size() - 1; k.scale = m_scale; k.srgb = m_colorspace == "srgb" ? 1 : 0;
-        k.filter = m_filter;
-        k.child[0] = k.child[1] = k.child[2] = -1;
-        return k;
+        row.type = KZ_TEX_IMAGE; row.image = rows.image(m_w, m_h, m_c, m_fmt, m_px.data()); row.scale = m_scale; row.srgb = m_colorspace == "srgb" ? 1 : 0; row.filter = m_filter;
+        return true;
     }
     std::string toString() const override { return "ImageTexture[]"; }
 private:
@@ -258,81 +278,84 @@ private:
     }
     std::string m_filename, m_colorspace; float m_scale; int m_filter = KZ_TEXFILTER_BILINEAR, m_w = 0, m_h = 0, m_c = 0, m_fmt = KZ_PIXEL_U8; std::vector<uint8_t> m_px;
 };
-class ColorRampTexture : public Texture {            // texture.cpp:149-195
+class ColorRampTexture : public Texture<Color3f> {   // texture.cpp:149-195
 public:
     explicit ColorRampTexture(const PropertyList &p) { m_min = p.getFloat("min", 0.0f); m_max = p.getFloat("max", 1.0f); }
     ~ColorRampTexture() override { delete m_nested; }
-    void addChild(Object *o) override { if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than nested Texture"); m_nested = static_cast<Texture *>(o); }
-    KzTexture row(RowBuilder &rb) const override { KzTexture k{}; k.type = KZ_TEX_COLORRAMP; k.rampMin = m_min; k.rampMax = m_max; k.child[0] = rb.tex(m_nested) - 1; k.child[1] = k.child[2] = -1; return k; }
+    void addChild(Object *o) override { if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than nested Texture"); m_nested = static_cast<Texture<Color3f> *>(o); }
+    bool describe(KzTexture &row, mi355x::Rows &rows) const override { row.type = KZ_TEX_COLORRAMP; row.rampMin = m_min; row.rampMax = m_max; row.child[0] = rows.texture(m_nested) - 1; return true; }
     std::string toString() const override { return "ColorRampTexture[]"; }
-    float m_min, m_max; Texture *m_nested = nullptr;
+private:
+    float m_min, m_max; Texture<Color3f> *m_nested = nullptr;
 };
-class BlendTexture : public Texture {                // texture.cpp:199-270
+class BlendTexture : public Texture<Color3f> {       // texture.cpp:199-270
 public:
     explicit BlendTexture(const PropertyList &p) { m_blendmode = p.getString("blendmode", "mix"); }
     ~BlendTexture() override { delete m_mask; delete m_input1; delete m_input2; }
     void addChild(Object *o) override {
         if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than nested Texture");
-        auto set = [&](Texture *&slot, const char *what) { if (slot) throw Exception(std::string("There is already an ") + what + " defined!"); slot = static_cast<Texture *>(o); };
+        auto set = [&](Texture<Color3f> *&slot, const char *what) { if (slot) throw Exception(std::string("There is already an ") + what + " defined!"); slot = static_cast<Texture<Color3f> *>(o); };
         if (o->getId() == "mask") set(m_mask, "mask");
         else if (o->getId() == "input1") set(m_input1, "input1");
         else if (o->getId() == "input2") set(m_input2, "input2");
         else throw Exception("The name of this texture does not match any field!");
     }
-    KzTexture row(RowBuilder &rb) const override {
-        KzTexture k{}; k.type = KZ_TEX_BLEND; k.blendMode = m_blendmode == "mix" ? KZ_BLEND_MIX : m_blendmode == "multiply" ? KZ_BLEND_MULTIPLY : KZ_BLEND_NONE;
-        k.child[0] = rb.tex(m_mask) - 1; k.child[1] = rb.tex(m_input1) - 1; k.child[2] = rb.tex(m_input2) - 1;
-        return k;
+    bool describe(KzTexture &row, mi355x::Rows &rows) const override {
+        row.type = KZ_TEX_BLEND; row.blendMode = m_blendmode == "mix" ? KZ_BLEND_MIX : m_blendmode == "multiply" ? KZ_BLEND_MULTIPLY : KZ_BLEND_NONE;
+        row.child[0] = rows.texture(m_mask) - 1; row.child[1] = rows.texture(m_input1) - 1; row.child[2] = rows.texture(m_input2) - 1;
+        return true;
     }
     std::string toString() const override { return "BlendTexture[]"; }
-    std::string m_blendmode; Texture *m_mask = nullptr, *m_input1 = nullptr, *m_input2 = nullptr;
+private:
+    std::string m_blendmode; Texture<Color3f> *m_mask = nullptr, *m_input1 = nullptr, *m_input2 = nullptr;
 };
-class BackgroundTexture : public Object {
+class BackgroundTexture : public Texture<Color3f> {  // texture.cpp:104-145
 public:
     explicit BackgroundTexture(const PropertyList &p) { m_intensity = p.getFloat("intensity", 1.0f); }
     ~BackgroundTexture() override { delete m_nested; }
     void addChild(Object *o) override {
         if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than nested Texture");
         delete m_nested;                       // texture.cpp:128-136: the last texture child is the nested one
-        m_nested = static_cast<Texture *>(o);  // constanttexture -> colour, imagetexture -> environment lookup, colorramp / blend -> 0 (texture.h:13)
+        m_nested = static_cast<Texture<Color3f> *>(o);  // constanttexture -> colour, imagetexture -> environment lookup, colorramp / blend -> 0 (texture.h:13)
     }
-    EClassType getClassType() const override { return ETexture; }
+    bool describeBackground(KzBackground &row, mi355x::Rows &rows) const override {
+        if (!m_nested) return true;                                     // (Scene::getBackgroundColor then evaluates nothing: present stays 0)
+        row.present = 1; row.intensity = m_intensity;
+        rows.color(m_nested, row.color, row.texture);                   // a constanttexture folds into the colour, anything else is the nested texture's row
+        return true;
+    }
     std::string toString() const override { return "Background[]"; }
-    float m_intensity; Texture *m_nested = nullptr;
+private:
+    float m_intensity; Texture<Color3f> *m_nested = nullptr;
 };
 
 // ---- BSDFs ----------------------------------------------------------------------------------------------------------
-// A texture child that is a constanttexture is folded into the row (texture id 0); any other texture goes through the table.
+// include/kazen/bsdf.h:80-125 + the virtual INTEGRATION.md adds. A texture child that is a constanttexture is folded into the row
+// (texture id 0) by rows.color / rows.scalar; any other texture goes through the table.
 class BSDF : public Object {
 public:
     EClassType getClassType() const override { return EBSDF; }
-    virtual KzBSDF row(RowBuilder &rb) const = 0;
-protected:
-    static void bind3(RowBuilder &rb, const Texture *t, float *dst, int32_t &id) {
-        if (t->isConstant()) { const Color3f &c = static_cast<const ConstantTexture *>(t)->m_color; dst[0] = c.r; dst[1] = c.g; dst[2] = c.b; id = 0; }
-        else id = rb.tex(t);
-    }
-    static void bind1(RowBuilder &rb, const Texture *t, float &dst, int32_t &id) {       // .r() of the colour (bsdf.cpp:1227,1231)
-        if (t->isConstant()) { dst = static_cast<const ConstantTexture *>(t)->m_color.r; id = 0; }
-        else id = rb.tex(t);
-    }
+    /// ADDED: this BSDF's row for KzSceneDesc.bsdfs; false = not on the MI355X path
+    virtual bool describe(KzBSDF &, mi355x::Rows &) const { return false; }
 };
 class Diffuse : public BSDF {                        // src/kazen/bsdf.cpp:20-92
 public:
     explicit Diffuse(const PropertyList &p) { m_albedo = p.getColor("albedo", Color3f(0.5f)); }
-    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_DIFFUSE; b.albedo[0] = m_albedo.r; b.albedo[1] = m_albedo.g; b.albedo[2] = m_albedo.b; return b; }
+    bool describe(KzBSDF &row, mi355x::Rows &) const override { row.type = KZ_BSDF_DIFFUSE; row.albedo[0] = m_albedo.r; row.albedo[1] = m_albedo.g; row.albedo[2] = m_albedo.b; return true; }
     std::string toString() const override { return "Diffuse[]"; }
+private:
     Color3f m_albedo;
 };
 class Lambertian : public BSDF {                     // src/kazen/bsdf.cpp:202-276: the diffuse model, albedo through a texture child
 public:
     explicit Lambertian(const PropertyList &) {}
     ~Lambertian() override { delete m_albedo; }
-    void addChild(Object *o) override { if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than albedi maps"); m_albedo = static_cast<Texture *>(o); }
+    void addChild(Object *o) override { if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than albedi maps"); m_albedo = static_cast<Texture<Color3f> *>(o); }
     void activate() override { if (!m_albedo) throw Exception("lambertian needs an albedo texture"); }
-    KzBSDF row(RowBuilder &rb) const override { KzBSDF b{}; b.type = KZ_BSDF_DIFFUSE; bind3(rb, m_albedo, b.albedo, b.albedoTex); return b; }
+    bool describe(KzBSDF &row, mi355x::Rows &rows) const override { row.type = KZ_BSDF_DIFFUSE; rows.color(m_albedo, row.albedo, row.albedoTex); return true; }
     std::string toString() const override { return "Lambertian[]"; }
-    Texture *m_albedo = nullptr;
+private:
+    Texture<Color3f> *m_albedo = nullptr;
 };
 class NormalMap : public BSDF {                      // src/kazen/bsdf.cpp:281-417
 public:
@@ -340,7 +363,7 @@ public:
     ~NormalMap() override { delete m_normalMap; delete m_nested; }
     void addChild(Object *o) override {
         switch (o->getClassType()) {
-        case ETexture: m_normalMap = static_cast<Texture *>(o); break;
+        case ETexture: m_normalMap = static_cast<Texture<Color3f> *>(o); break;
         case EBSDF: m_nested = static_cast<BSDF *>(o); break;
         default: throw Exception("addChild is not supported other than normal maps and nested BSDF");
         }
@@ -350,9 +373,10 @@ public:
         if (dynamic_cast<NormalMap *>(m_nested)) throw Exception("a normalmap nested in a normalmap is not on the MI355X hot path");
         m_nested->activate();
     }
-    KzBSDF row(RowBuilder &rb) const override { KzBSDF b{}; b.type = KZ_BSDF_NORMALMAP; b.normalTex = rb.tex(m_normalMap); b.nested = rb.nestedRow(m_nested); return b; }
+    bool describe(KzBSDF &row, mi355x::Rows &rows) const override { row.type = KZ_BSDF_NORMALMAP; row.normalTex = rows.texture(m_normalMap); row.nested = rows.nested(m_nested); return true; }
     std::string toString() const override { return "NormalMap[]"; }
-    Texture *m_normalMap = nullptr; BSDF *m_nested = nullptr;
+private:
+    Texture<Color3f> *m_normalMap = nullptr; BSDF *m_nested = nullptr;
 };
 class KazenStandardSurface : public BSDF {           // src/kazen/bsdf.cpp:1157-1418
 public:
@@ -364,37 +388,39 @@ public:
     ~KazenStandardSurface() override { delete m_baseColor; delete m_roughness; delete m_metallic; }
     void addChild(Object *o) override {              // bsdf.cpp:1373-1395: textures by id
         if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than baseColor maps");
-        auto *c = static_cast<Texture *>(o);
-        auto set = [&](Texture *&slot, const char *what) { if (slot) throw Exception(std::string("There is already an ") + what + " defined!"); slot = c; };
+        auto *c = static_cast<Texture<Color3f> *>(o);
+        auto set = [&](Texture<Color3f> *&slot, const char *what) { if (slot) throw Exception(std::string("There is already an ") + what + " defined!"); slot = c; };
         if (o->getId() == "baseColor") set(m_baseColor, "baseColor");
         else if (o->getId() == "metallic") set(m_metallic, "metallic");
         else if (o->getId() == "roughness") set(m_roughness, "roughness");
         else throw Exception("kazenstandard: texture id must be baseColor, metallic or roughness");
     }
     void activate() override { if (!m_baseColor || !m_roughness || !m_metallic) throw Exception("kazenstandard needs baseColor, roughness and metallic textures"); }
-    KzBSDF row(RowBuilder &rb) const override {
-        KzBSDF b{}; b.type = KZ_BSDF_KAZENSTANDARD;
-        bind3(rb, m_baseColor, b.baseColor, b.albedoTex); bind1(rb, m_roughness, b.roughness, b.roughnessTex); bind1(rb, m_metallic, b.metallic, b.metallicTex);
-        b.anisotropy = m_anisotropy; b.specular = m_specular; b.specularTint = m_specularTint; b.clearcoat = m_clearcoat;
-        b.clearcoatRoughness = m_clearcoatRoughness; b.sheen = m_sheen; b.sheenTint = m_sheenTint;
-        return b;
+    bool describe(KzBSDF &row, mi355x::Rows &rows) const override {
+        row.type = KZ_BSDF_KAZENSTANDARD;
+        rows.color(m_baseColor, row.baseColor, row.albedoTex); rows.scalar(m_roughness, row.roughness, row.roughnessTex); rows.scalar(m_metallic, row.metallic, row.metallicTex);
+        row.anisotropy = m_anisotropy; row.specular = m_specular; row.specularTint = m_specularTint; row.clearcoat = m_clearcoat;
+        row.clearcoatRoughness = m_clearcoatRoughness; row.sheen = m_sheen; row.sheenTint = m_sheenTint;
+        return true;
     }
     std::string toString() const override { return "KazenStandardSurface"; }
-    Texture *m_baseColor = nullptr, *m_roughness = nullptr, *m_metallic = nullptr;
+private:
+    Texture<Color3f> *m_baseColor = nullptr, *m_roughness = nullptr, *m_metallic = nullptr;
     float m_anisotropy, m_specular, m_specularTint, m_clearcoat, m_clearcoatRoughness, m_sheen, m_sheenTint;
 };
 
 class Mirror : public BSDF {                         // src/kazen/bsdf.cpp:161-196
 public:
     explicit Mirror(const PropertyList &) {}
-    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_MIRROR; return b; }
+    bool describe(KzBSDF &row, mi355x::Rows &) const override { row.type = KZ_BSDF_MIRROR; return true; }
     std::string toString() const override { return "Mirror[]"; }
 };
 class Dielectric : public BSDF {                     // src/kazen/bsdf.cpp:98-155
 public:
     explicit Dielectric(const PropertyList &p) { m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); }
-    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_DIELECTRIC; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
+    bool describe(KzBSDF &row, mi355x::Rows &) const override { row.type = KZ_BSDF_DIELECTRIC; row.intIOR = m_intIOR; row.extIOR = m_extIOR; return true; }
     std::string toString() const override { return "Dielectric[]"; }
+private:
     float m_intIOR, m_extIOR;
 };
 
@@ -404,17 +430,21 @@ public:
     ~GGX() override { delete m_albedo; }
     void addChild(Object *o) override {
         if (o->getClassType() != ETexture) throw Exception("addChild is not supported other than albedi maps");
-        m_albedo = static_cast<Texture *>(o);
+        m_albedo = static_cast<Texture<Color3f> *>(o);
     }
     void activate() override { if (!m_albedo) throw Exception("ggx needs an albedo texture"); }
-    KzBSDF row(RowBuilder &rb) const override { KzBSDF b{}; b.type = KZ_BSDF_GGX; bind3(rb, m_albedo, b.albedo, b.albedoTex); b.alpha = m_roughness; b.anisotropy = m_anisotropy; return b; }
+    bool describe(KzBSDF &row, mi355x::Rows &rows) const override { row.type = KZ_BSDF_GGX; rows.color(m_albedo, row.albedo, row.albedoTex); row.alpha = m_roughness; row.anisotropy = m_anisotropy; return true; }
     std::string toString() const override { return "GGX[]"; }
-    Texture *m_albedo = nullptr; float m_roughness, m_anisotropy;
+private:
+    Texture<Color3f> *m_albedo = nullptr; float m_roughness, m_anisotropy;
 };
+// The three rough BSDFs keep what the reference's constructors keep: m_alpha = max(0.001, sqr("alpha")) (bsdf.cpp:696-700, 818-822, 956-959), not
+// the property. Their rows say so with KzBSDF.alphaResolved = 1 (the library then takes `alpha` as it is).
+inline float roughAlpha(float roughness) { const float MIN_ALPHA = 0.001f; return std::max(MIN_ALPHA, roughness * roughness); }
 class RoughConductor : public BSDF {                 // src/kazen/bsdf.cpp:692-811
 public:
     explicit RoughConductor(const PropertyList &p) {
-        m_alpha = p.getFloat("alpha", 0.1f);
+        m_alpha = roughAlpha(p.getFloat("alpha", 0.1f));
         const std::string mat = p.getString("material", "Au");
         static const float T[3][6] = {{0.1431189557f, 0.3749570432f, 1.4424785571f, 3.9831604247f, 2.3857207478f, 1.6032152899f},
                                       {0.2004376970f, 0.9240334304f, 1.1022119527f, 3.9129485033f, 2.4528477015f, 2.1421879552f},
@@ -423,114 +453,203 @@ public:
         if (i < 0) throw Exception("roughconductor: unknown material \"" + mat + "\" (the reference leaves eta/k uninitialised here)");
         for (int a = 0; a < 3; ++a) { m_eta[a] = T[i][a]; m_k[a] = T[i][3 + a]; }
     }
-    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHCONDUCTOR; b.alpha = m_alpha; for (int a = 0; a < 3; ++a) { b.condEta[a] = m_eta[a]; b.condK[a] = m_k[a]; } return b; }
+    bool describe(KzBSDF &row, mi355x::Rows &) const override { row.type = KZ_BSDF_ROUGHCONDUCTOR; row.alpha = m_alpha; row.alphaResolved = 1; for (int a = 0; a < 3; ++a) { row.condEta[a] = m_eta[a]; row.condK[a] = m_k[a]; } return true; }
     std::string toString() const override { return "RoughConductor[]"; }
+private:
     float m_alpha, m_eta[3], m_k[3];
 };
 class RoughPlastic : public BSDF {                   // src/kazen/bsdf.cpp:814-943
 public:
-    explicit RoughPlastic(const PropertyList &p) { m_alpha = p.getFloat("alpha", 0.1f); m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); m_kd = p.getColor("kd", Color3f(0.5f)); }
-    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHPLASTIC; b.alpha = m_alpha; b.intIOR = m_intIOR; b.extIOR = m_extIOR; b.albedo[0] = m_kd.r; b.albedo[1] = m_kd.g; b.albedo[2] = m_kd.b; return b; }
+    explicit RoughPlastic(const PropertyList &p) { m_alpha = roughAlpha(p.getFloat("alpha", 0.1f)); m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); m_kd = p.getColor("kd", Color3f(0.5f)); }
+    bool describe(KzBSDF &row, mi355x::Rows &) const override { row.type = KZ_BSDF_ROUGHPLASTIC; row.alpha = m_alpha; row.alphaResolved = 1; row.intIOR = m_intIOR; row.extIOR = m_extIOR; row.albedo[0] = m_kd.r; row.albedo[1] = m_kd.g; row.albedo[2] = m_kd.b; return true; }
     std::string toString() const override { return "RoughPlastic[]"; }
+private:
     float m_alpha, m_intIOR, m_extIOR; Color3f m_kd;
 };
 class RoughDielectric : public BSDF {                // src/kazen/bsdf.cpp:947-1145
 public:
-    explicit RoughDielectric(const PropertyList &p) { m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); m_roughness = p.getFloat("roughness", 0.1f); }
-    KzBSDF row(RowBuilder &) const override { KzBSDF b{}; b.type = KZ_BSDF_ROUGHDIELECTRIC; b.alpha = m_roughness; b.intIOR = m_intIOR; b.extIOR = m_extIOR; return b; }
+    explicit RoughDielectric(const PropertyList &p) { m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); m_alpha = roughAlpha(p.getFloat("roughness", 0.1f)); }
+    bool describe(KzBSDF &row, mi355x::Rows &) const override { row.type = KZ_BSDF_ROUGHDIELECTRIC; row.alpha = m_alpha; row.alphaResolved = 1; row.intIOR = m_intIOR; row.extIOR = m_extIOR; return true; }
     std::string toString() const override { return "RoughDielectric"; }
-    float m_intIOR, m_extIOR, m_roughness;
+private:
+    float m_intIOR, m_extIOR, m_alpha;
 };
 
 // ---- light / filter / sampler / integrator / camera -------------------------------------------------------------------
-class AreaLight : public Object {                    // src/kazen/light.cpp:7-70
+class Light : public Object {                        // include/kazen/light.h:43-63 + the virtual INTEGRATION.md adds
 public:
-    explicit AreaLight(const PropertyList &p) { m_color = p.getColor("color", Color3f(1.f)); m_intensity = p.getFloat("intensity", 1.f); m_vis = p.getBoolean("lightPrimaryVisibility", false); }
     EClassType getClassType() const override { return ELight; }
-    bool getPrimaryVisibility() const { return m_vis; }
-    KzLight row() const { KzLight l{}; l.color[0] = m_color.r; l.color[1] = m_color.g; l.color[2] = m_color.b; l.intensity = m_intensity; l.primaryVisibility = m_vis ? 1 : 0; return l; }
+    virtual bool getPrimaryVisibility() const { return false; }
+    /// ADDED: this light's row for KzSceneDesc.lights; false = not on the MI355X path
+    virtual bool describe(KzLight &) const { return false; }
+};
+class AreaLight : public Light {                     // src/kazen/light.cpp:7-70
+public:
+    explicit AreaLight(const PropertyList &p) { m_color = p.getColor("color", Color3f(1.f)); m_intensity = p.getFloat("intensity", 1.f); m_lightPrimaryVisibility = p.getBoolean("lightPrimaryVisibility", false); }
+    bool getPrimaryVisibility() const override { return m_lightPrimaryVisibility; }
+    bool describe(KzLight &row) const override { row.color[0] = m_color.r; row.color[1] = m_color.g; row.color[2] = m_color.b; row.intensity = m_intensity; row.primaryVisibility = m_lightPrimaryVisibility ? 1 : 0; return true; }
     std::string toString() const override { return "AreaLight[]"; }
-    Color3f m_color; float m_intensity; bool m_vis;
+private:
+    Color3f m_color; float m_intensity; bool m_lightPrimaryVisibility;
 };
 class ReconstructionFilter : public Object {         // include/kazen/rfilter.h:22-37, src/kazen/rfilter.cpp
 public:
     EClassType getClassType() const override { return EReconstructionFilter; }
-    float getRadius() const { return m_f.radius; }
-    KzFilter m_f{};
+    float getRadius() const { return m_radius; }
+    /// ADDED: the filter's parameters (the library tabulates it exactly as block.cpp:13-21 does); false = not on the MI355X path
+    virtual bool describe(KzFilter &) const { return false; }
+protected:
+    float m_radius = 0.f;
 };
-class GaussianFilter : public ReconstructionFilter { public: explicit GaussianFilter(const PropertyList &p) { m_f.type = KZ_FILTER_GAUSSIAN; m_f.radius = p.getFloat("radius", 2.0f); m_f.stddev = p.getFloat("stddev", 0.5f); } std::string toString() const override { return "GaussianFilter[]"; } };
-class MitchellNetravaliFilter : public ReconstructionFilter { public: explicit MitchellNetravaliFilter(const PropertyList &p) { m_f.type = KZ_FILTER_MITCHELL; m_f.radius = p.getFloat("radius", 2.0f); m_f.B = p.getFloat("B", 1.0f / 3.0f); m_f.C = p.getFloat("C", 1.0f / 3.0f); } std::string toString() const override { return "MitchellNetravaliFilter[]"; } };
-class TentFilter : public ReconstructionFilter { public: explicit TentFilter(const PropertyList &) { m_f.type = KZ_FILTER_TENT; m_f.radius = 1.0f; } std::string toString() const override { return "TentFilter[]"; } };
-class BoxFilter : public ReconstructionFilter { public: explicit BoxFilter(const PropertyList &) { m_f.type = KZ_FILTER_BOX; m_f.radius = 0.5f; } std::string toString() const override { return "BoxFilter[]"; } };
+class GaussianFilter : public ReconstructionFilter {           // rfilter.cpp:10-31
+public:
+    explicit GaussianFilter(const PropertyList &p) { m_radius = p.getFloat("radius", 2.0f); m_stddev = p.getFloat("stddev", 0.5f); }
+    bool describe(KzFilter &row) const override { row.type = KZ_FILTER_GAUSSIAN; row.radius = m_radius; row.stddev = m_stddev; return true; }
+    std::string toString() const override { return "GaussianFilter[]"; }
+private:
+    float m_stddev;
+};
+class MitchellNetravaliFilter : public ReconstructionFilter {  // rfilter.cpp:39-70
+public:
+    explicit MitchellNetravaliFilter(const PropertyList &p) { m_radius = p.getFloat("radius", 2.0f); m_B = p.getFloat("B", 1.0f / 3.0f); m_C = p.getFloat("C", 1.0f / 3.0f); }
+    bool describe(KzFilter &row) const override { row.type = KZ_FILTER_MITCHELL; row.radius = m_radius; row.B = m_B; row.C = m_C; return true; }
+    std::string toString() const override { return "MitchellNetravaliFilter[]"; }
+private:
+    float m_B, m_C;
+};
+class TentFilter : public ReconstructionFilter {               // rfilter.cpp:73-86
+public:
+    explicit TentFilter(const PropertyList &) { m_radius = 1.0f; }
+    bool describe(KzFilter &row) const override { row.type = KZ_FILTER_TENT; row.radius = m_radius; return true; }
+    std::string toString() const override { return "TentFilter[]"; }
+};
+class BoxFilter : public ReconstructionFilter {                // rfilter.cpp:89-102
+public:
+    explicit BoxFilter(const PropertyList &) { m_radius = 0.5f; }
+    bool describe(KzFilter &row) const override { row.type = KZ_FILTER_BOX; row.radius = m_radius; return true; }
+    std::string toString() const override { return "BoxFilter[]"; }
+};
 
-class Sampler : public Object {                      // include/kazen/sampler.h:44-107
+class Sampler : public Object {                      // include/kazen/sampler.h:44-107 + the virtual INTEGRATION.md adds
 public:
     EClassType getClassType() const override { return ESampler; }
-    uint32_t getSampleCount() const { return m_s.sampleCount; }
-    KzSampler m_s{};
+    virtual uint32_t getSampleCount() const { return m_sampleCount; }
+    /// ADDED: type, sample count, seed (and tables) for KzSceneDesc.sampler; false = not on the MI355X path
+    virtual bool describe(KzSampler &) const { return false; }
+protected:
+    uint64_t m_seed = 0; uint32_t m_sampleCount = 0;
 };
 class Independent : public Sampler {                 // src/kazen/sampler.cpp:18-71 (seed: the reference leaves it uninitialised; 0 here, H2)
 public:
-    explicit Independent(const PropertyList &p) { m_s.type = KZ_SAMPLER_INDEPENDENT; m_s.sampleCount = (uint32_t)p.getInteger("sampleCount", 1); m_s.seed = (uint64_t)p.getInteger("seed", 0); }
-    std::string toString() const override { return "Independent[sampleCount=" + std::to_string(m_s.sampleCount) + "]"; }
+    explicit Independent(const PropertyList &p) { m_sampleCount = (uint32_t)p.getInteger("sampleCount", 1); m_seed = (uint64_t)p.getInteger("seed", 0); }
+    bool describe(KzSampler &row) const override { row.type = KZ_SAMPLER_INDEPENDENT; row.sampleCount = m_sampleCount; row.seed = m_seed; return true; }
+    std::string toString() const override { return "Independent[sampleCount=" + std::to_string(m_sampleCount) + "]"; }
 };
 class PMJ02BN : public Sampler {                     // src/kazen/sampler.cpp:273-390; tables = the arrays of pmj02table.cpp / bluenoise.cpp
 public:
-    explicit PMJ02BN(const PropertyList &p) { m_s.type = KZ_SAMPLER_PMJ02BN; m_s.seed = (uint64_t)p.getInteger("seed", 1); m_s.sampleCount = (uint32_t)p.getInteger("sampleCount", 16); }
-    void setTables(const uint32_t *pmj02bnSamples, const uint16_t *blueNoiseTextures) { m_s.pmj02bnSamples = pmj02bnSamples; m_s.blueNoise = blueNoiseTextures; }
+    explicit PMJ02BN(const PropertyList &p) { m_seed = (uint64_t)p.getInteger("seed", 1); m_sampleCount = (uint32_t)p.getInteger("sampleCount", 16); }
+    /// (the reference links its tables - kazen::pmj02bnSamples, kazen::BlueNoiseTextures - and its override passes those; they are missing from the checkout, so the mirror is handed them)
+    void setTables(const uint32_t *pmj02bnSamples, const uint16_t *blueNoiseTextures) { m_pmj = pmj02bnSamples; m_bn = blueNoiseTextures; }
+    bool describe(KzSampler &row) const override { row.type = KZ_SAMPLER_PMJ02BN; row.sampleCount = m_sampleCount; row.seed = m_seed; row.pmj02bnSamples = m_pmj; row.blueNoise = m_bn; return true; }
     std::string toString() const override { return "PMJ02BN"; }
+private:
+    const uint32_t *m_pmj = nullptr; const uint16_t *m_bn = nullptr;
 };
-class Stratified : public Sampler {                  // src/kazen/sampler.cpp:81-156 (the library applies the constructor's rounding)
+class Stratified : public Sampler {                  // src/kazen/sampler.cpp:81-156 (the constructor's rounding: :87-92)
 public:
-    explicit Stratified(const PropertyList &p) { m_s.type = KZ_SAMPLER_STRATIFIED; m_s.seed = (uint64_t)p.getInteger("seed", 1); m_s.sampleCount = (uint32_t)p.getInteger("sampleCount", 16); m_s.resolution = p.getInteger("resolution", 4); }
+    explicit Stratified(const PropertyList &p) {
+        m_seed = (uint64_t)p.getInteger("seed", 1); m_sampleCount = (uint32_t)p.getInteger("sampleCount", 16); m_resolution = p.getInteger("resolution", 4);
+        while ((uint32_t)(m_resolution * m_resolution) < m_sampleCount) m_resolution++;
+        m_sampleCount = (uint32_t)(m_resolution * m_resolution);
+    }
+    bool describe(KzSampler &row) const override { row.type = KZ_SAMPLER_STRATIFIED; row.sampleCount = m_sampleCount; row.resolution = m_resolution; row.seed = m_seed; return true; }
     std::string toString() const override { return "Stratified"; }
+private:
+    int m_resolution;
 };
-class Correlated : public Sampler {                  // src/kazen/sampler.cpp:176-269
+class Correlated : public Sampler {                  // src/kazen/sampler.cpp:176-269 (the constructor's rounding: :181-187)
 public:
-    explicit Correlated(const PropertyList &p) { m_s.type = KZ_SAMPLER_CORRELATED; m_s.seed = (uint64_t)p.getInteger("seed", 1); m_s.sampleCount = (uint32_t)p.getInteger("sampleCount", 16); m_s.resolution = 4; }
+    explicit Correlated(const PropertyList &p) {
+        m_seed = (uint64_t)p.getInteger("seed", 1); m_sampleCount = (uint32_t)p.getInteger("sampleCount", 16);
+        m_resolution[1] = (int)std::sqrt((double)m_sampleCount); m_resolution[0] = (int)((m_sampleCount + m_resolution[1] - 1) / m_resolution[1]);
+        m_sampleCount = (uint32_t)(m_resolution[0] * m_resolution[1]);
+    }
+    bool describe(KzSampler &row) const override { row.type = KZ_SAMPLER_CORRELATED; row.sampleCount = m_sampleCount; row.resolution = 4; row.seed = m_seed; return true; }
     std::string toString() const override { return "Correlated"; }
+private:
+    int m_resolution[2];
 };
-class Integrator : public Object { public: EClassType getClassType() const override { return EIntegrator; } virtual void preprocess(const class Scene *) {} KzIntegrator m_i{}; };
+class Integrator : public Object {                   // include/kazen/integrator.h:14-43 + the virtual INTEGRATION.md adds
+public:
+    EClassType getClassType() const override { return EIntegrator; }
+    virtual void preprocess(const class Scene *) {}
+    /// ADDED: the integrator's parameters for KzSceneDesc.integrator; false = not on the MI355X path (only path_mis is)
+    virtual bool describe(KzIntegrator &) const { return false; }
+};
 class PathMisIntegrator : public Integrator {        // src/kazen/integrator.cpp:185-355
 public:
     explicit PathMisIntegrator(const PropertyList &p) {
-        m_i.type = KZ_INTEGRATOR_PATH_MIS; m_i.maxDepth = std::min(512, p.getInteger("maxDepth", 5)); m_i.traceBias = p.getFloat("traceBias", 0.001f);
-        m_i.regularization = p.getBoolean("regularization", false) ? 1 : 0; m_i.accumulatedRoughness = p.getFloat("accumulatedRoughness", 0.5f);
+        m_maxDepth = std::min(512, p.getInteger("maxDepth", 5)); m_rayEpsilon = p.getFloat("traceBias", 0.001f);
+        m_regularization = p.getBoolean("regularization", false); m_accumulatedRoughness = p.getFloat("accumulatedRoughness", 0.5f);
     }
+    bool describe(KzIntegrator &row) const override { row.type = KZ_INTEGRATOR_PATH_MIS; row.maxDepth = m_maxDepth; row.traceBias = m_rayEpsilon; row.regularization = m_regularization ? 1 : 0; row.accumulatedRoughness = m_accumulatedRoughness; return true; }
     std::string toString() const override { return "PathMisIntegrator[]"; }
+private:
+    int m_maxDepth; float m_rayEpsilon; bool m_regularization; float m_accumulatedRoughness;
 };
-class Camera : public Object { public: EClassType getClassType() const override { return ECamera; } KzCamera m_c{}; ReconstructionFilter *m_rfilter = nullptr; ~Camera() override { delete m_rfilter; } };
+class Camera : public Object {                       // include/kazen/camera.h:16-56 + the virtual INTEGRATION.md adds
+public:
+    ~Camera() override { delete m_rfilter; }
+    EClassType getClassType() const override { return ECamera; }
+    const Vector2i &getOutputSize() const { return m_outputSize; }
+    const ReconstructionFilter *getReconstructionFilter() const { return m_rfilter; }
+    /// ADDED: size, projection, clips, toWorld and the reconstruction filter for KzSceneDesc.camera; false = not on the MI355X path
+    virtual bool describe(KzCamera &) const { return false; }
+protected:
+    Vector2i m_outputSize; ReconstructionFilter *m_rfilter = nullptr;
+};
 class PerspectiveCamera : public Camera {            // src/kazen/camera.cpp:14-131
 public:
     explicit PerspectiveCamera(const PropertyList &p) {
-        m_c.type = KZ_CAMERA_PERSPECTIVE; m_c.width = p.getInteger("width", 1280); m_c.height = p.getInteger("height", 720);
-        Transform t = p.getTransform("toWorld", Transform());
-        for (int i = 0; i < 16; ++i) m_c.toWorld[i] = t.m[i];
-        m_c.fov = p.getFloat("fov", 30.0f); m_c.nearClip = p.getFloat("nearClip", 1e-4f); m_c.farClip = p.getFloat("farClip", 1e4f);
+        m_outputSize.x() = p.getInteger("width", 1280); m_outputSize.y() = p.getInteger("height", 720);
+        m_cameraToWorld = p.getTransform("toWorld", Transform());
+        m_fov = p.getFloat("fov", 30.0f); m_nearClip = p.getFloat("nearClip", 1e-4f); m_farClip = p.getFloat("farClip", 1e4f);
     }
     void addChild(Object *o) override {
         if (o->getClassType() != EReconstructionFilter) throw Exception("Camera::addChild(<" + classTypeName(o->getClassType()) + ">) is not supported!");
         if (m_rfilter) throw Exception("Camera: tried to register multiple reconstruction filters!");
         m_rfilter = static_cast<ReconstructionFilter *>(o);
     }
-    void activate() override { if (!m_rfilter) m_rfilter = static_cast<ReconstructionFilter *>(ObjectFactory::createInstance("gaussian", PropertyList())); m_c.rfilter = m_rfilter->m_f; }
+    void activate() override { if (!m_rfilter) m_rfilter = static_cast<ReconstructionFilter *>(ObjectFactory::createInstance("gaussian", PropertyList())); }     // camera.cpp:64-67
+    bool describe(KzCamera &row) const override {
+        row.type = KZ_CAMERA_PERSPECTIVE; row.width = m_outputSize.x(); row.height = m_outputSize.y();
+        for (int i = 0; i < 16; ++i) row.toWorld[i] = m_cameraToWorld.m[i];
+        row.fov = m_fov; row.nearClip = m_nearClip; row.farClip = m_farClip;
+        return m_rfilter && m_rfilter->describe(row.rfilter);
+    }
     std::string toString() const override { return "PerspectiveCamera[]"; }
+private:
+    Transform m_cameraToWorld; float m_fov, m_nearClip, m_farClip;
 };
 
 class ThinlensCamera : public PerspectiveCamera {    // src/kazen/camera.cpp:133-270
 public:
-    explicit ThinlensCamera(const PropertyList &p) : PerspectiveCamera(p) { m_c.type = KZ_CAMERA_THINLENS; m_c.apertureRadius = p.getFloat("apertureRadius", 1.0f); m_c.focusDistance = p.getFloat("focusDistance", 0.0f); }
+    explicit ThinlensCamera(const PropertyList &p) : PerspectiveCamera(p) { m_apertureRadius = p.getFloat("apertureRadius", 1.0f); m_focusDistance = p.getFloat("focusDistance", 0.0f); }
+    bool describe(KzCamera &row) const override { if (!PerspectiveCamera::describe(row)) return false; row.type = KZ_CAMERA_THINLENS; row.apertureRadius = m_apertureRadius; row.focusDistance = m_focusDistance; return true; }
     std::string toString() const override { return "ThinlensCamera[]"; }
+private:
+    float m_apertureRadius, m_focusDistance;
 };
 
 // ---- mesh: buffers in the layout of kazen::Mesh (mesh.h:176-179); the OBJ loader itself is host scene I/O, out of scope ----
 class Mesh : public Object {
 public:
-    Mesh() {}
+    Mesh() { m_UV.r = 2; }
     /// "obj" (WavefrontOBJ, mesh.cpp:200-343): with a "filename" property the file is loaded exactly as the reference does —
     /// v transformed by toWorld, vn by its inverse transpose and normalised, (p, uv, n) triples de-duplicated in encounter
     /// order, quads split into (0,1,2) and (3,0,2); without one the buffers are handed over through setBuffers.
     explicit Mesh(const PropertyList &props) {
+        m_UV.r = 2;
         if (!props.has("filename")) return;
         const std::string filename = resolveFile(props.getString("filename", ""));
         std::ifstream is(filename);
@@ -568,35 +687,47 @@ public:
                 if (!v[3].empty()) { verts[3] = parseKey(v[3]); verts[4] = verts[0]; verts[5] = verts[2]; nVertices = 6; }
                 for (int i = 0; i < nVertices; ++i) {
                     auto it = vertexMap.find(verts[i]);
-                    if (it == vertexMap.end()) { vertexMap[verts[i]] = (uint32_t)vertices.size(); m_F.push_back((uint32_t)vertices.size()); vertices.push_back(verts[i]); }
-                    else m_F.push_back(it->second);
+                    if (it == vertexMap.end()) { vertexMap[verts[i]] = (uint32_t)vertices.size(); m_F.a.push_back((uint32_t)vertices.size()); vertices.push_back(verts[i]); }
+                    else m_F.a.push_back(it->second);
                 }
             }
         }
-        for (const Key &k : vertices) { const Vector3 &p = positions.at(k.p - 1); m_V.insert(m_V.end(), p.begin(), p.end()); }
-        if (!normals.empty()) for (const Key &k : vertices) { const Vector3 &n = normals.at(k.n - 1); m_N.insert(m_N.end(), n.begin(), n.end()); }
-        if (!texcoords.empty()) for (const Key &k : vertices) { const auto &t = texcoords.at(k.uv - 1); m_UV.insert(m_UV.end(), t.begin(), t.end()); }
+        for (const Key &k : vertices) { const Vector3 &p = positions.at(k.p - 1); m_V.a.insert(m_V.a.end(), p.begin(), p.end()); }
+        if (!normals.empty()) for (const Key &k : vertices) { const Vector3 &n = normals.at(k.n - 1); m_N.a.insert(m_N.a.end(), n.begin(), n.end()); }
+        if (!texcoords.empty()) for (const Key &k : vertices) { const auto &t = texcoords.at(k.uv - 1); m_UV.a.insert(m_UV.a.end(), t.begin(), t.end()); }
     }
     ~Mesh() override { delete m_bsdf; delete m_light; }
-    void setBuffers(std::vector<float> V, std::vector<uint32_t> F, std::vector<float> N = {}, std::vector<float> UV = {}) { m_V = std::move(V); m_F = std::move(F); m_N = std::move(N); m_UV = std::move(UV); }
+    void setBuffers(std::vector<float> V, std::vector<uint32_t> F, std::vector<float> N = {}, std::vector<float> UV = {}) { m_V.a = std::move(V); m_F.a = std::move(F); m_N.a = std::move(N); m_UV.a = std::move(UV); }
     void addChild(Object *o) override {              // mesh.cpp:135-165
         switch (o->getClassType()) {
         case EBSDF: if (m_bsdf) throw Exception("Mesh: tried to register multiple BSDF instances!"); m_bsdf = static_cast<BSDF *>(o); break;
-        case ELight: if (m_light) throw Exception("Mesh: tried to register multiple light instances!"); m_light = static_cast<AreaLight *>(o); break;
+        case ELight: if (m_light) throw Exception("Mesh: tried to register multiple light instances!"); m_light = static_cast<Light *>(o); break;
         default: throw Exception("Mesh::addChild(<" + classTypeName(o->getClassType()) + ">) is not supported!");
         }
     }
+    /// mesh.cpp:24-28: a mesh without a BSDF gets the default diffuse one
+    void activate() override { if (!m_bsdf) m_bsdf = static_cast<BSDF *>(ObjectFactory::createInstance("diffuse", PropertyList())); m_bsdf->activate(); }
+    // the accessors of include/kazen/mesh.h:66-130 the adapter reads
+    uint32_t getTriangleCount() const { return (uint32_t)m_F.cols(); }
+    uint32_t getVertexCount() const { return (uint32_t)m_V.cols(); }
+    const MatrixXf &getVertexPositions() const { return m_V; }
+    const MatrixXf &getVertexNormals() const { return m_N; }
+    const MatrixXf &getVertexTexCoords() const { return m_UV; }
+    const MatrixXu &getIndices() const { return m_F; }
     bool isLight() const { return m_light != nullptr; }
+    const Light *getLight() const { return m_light; }
+    const BSDF *getBSDF() const { return m_bsdf; }
     EClassType getClassType() const override { return EMesh; }
     std::string toString() const override { return "Mesh[]"; }
-    std::vector<float> m_V, m_N, m_UV; std::vector<uint32_t> m_F; BSDF *m_bsdf = nullptr; AreaLight *m_light = nullptr;
+protected:
+    MatrixXf m_V, m_N, m_UV; MatrixXu m_F; BSDF *m_bsdf = nullptr; Light *m_light = nullptr;
 };
 
 // ---- scene ---------------------------------------------------------------------------------------------------------------
 class Scene : public Object {                        // src/kazen/scene.cpp, include/kazen/scene.h
 public:
     explicit Scene(const PropertyList & = PropertyList()) {}
-    ~Scene() override { if (m_handle) kz_scene_destroy(m_handle); for (auto *m : m_meshes) delete m; delete m_sampler; delete m_camera; delete m_integrator; delete m_background; }
+    ~Scene() override { for (auto *m : m_meshes) delete m; delete m_sampler; delete m_camera; delete m_integrator; delete m_background; }
     void addChild(Object *o) override {              // scene.cpp:81-130
         switch (o->getClassType()) {
         case EMesh: m_meshes.push_back(static_cast<Mesh *>(o)); break;
@@ -604,67 +735,37 @@ public:
         case ECamera: if (m_camera) throw Exception("There can only be one camera per scene!"); m_camera = static_cast<Camera *>(o); break;
         case EIntegrator: if (m_integrator) throw Exception("There can only be one integrator per scene!"); m_integrator = static_cast<Integrator *>(o); break;
         case ETexture: {
-            auto *b = dynamic_cast<BackgroundTexture *>(o);
-            if (!b) throw Exception("Scene::addChild(<texture>): only \"background\" is supported");
-            m_background = b; break;
+            KzBackground probe{}; mi355x::Rows rows;
+            auto *t = static_cast<Texture<Color3f> *>(o);
+            if (!t->describeBackground(probe, rows)) throw Exception("Scene::addChild(<texture>): only \"background\" is supported");
+            m_background = t; break;
         }
         default: throw Exception("Scene::addChild(<" + classTypeName(o->getClassType()) + ">) is not supported!");
         }
     }
-    /// scene.cpp:29-52 + the flattening: builds the KzSceneDesc and the library scene (host BVH build included)
+    /// scene.cpp:29-52: checks, the default sampler, the list of emitters. (The reference builds its Embree scene here; the library's host
+    /// BVH is built by mi355x::DeviceScene, the adapter's object, from what the describe() virtuals hand over.)
     void activate() override {
         if (!m_integrator) throw Exception("No integrator was specified!");
         if (!m_camera) throw Exception("No camera was specified!");
         if (!m_sampler) m_sampler = static_cast<Sampler *>(ObjectFactory::createInstance("independent", PropertyList()));
-        m_bsdfRows.clear(); m_lightRows.clear(); m_meshRows.clear();
-        m_rb = RowBuilder();
-        for (Mesh *m : m_meshes) if (m->m_bsdf) m_rb.nestedBase++;                     // rows wrapped by normalmaps go behind the per-mesh rows
-        for (Mesh *m : m_meshes) {
-            KzMesh k{}; k.V = m->m_V.data(); k.F = m->m_F.data(); k.N = m->m_N.empty() ? nullptr : m->m_N.data(); k.UV = m->m_UV.empty() ? nullptr : m->m_UV.data();
-            k.nV = (uint32_t)(m->m_V.size() / 3); k.nF = (uint32_t)(m->m_F.size() / 3);
-            k.bsdf = -1; k.light = -1;
-            if (m->m_bsdf) { m->m_bsdf->activate(); k.bsdf = (int32_t)m_bsdfRows.size(); m_bsdfRows.push_back(m->m_bsdf->row(m_rb)); }   // no bsdf: default diffuse (mesh.cpp:25-28)
-            if (m->m_light) { k.light = (int32_t)m_lightRows.size(); m_lightRows.push_back(m->m_light->row()); }
-            m_meshRows.push_back(k);
-        }
-        for (size_t i = 0; i < m_rb.nested.size(); ++i) m_bsdfRows.push_back(m_rb.nested[i]->row(m_rb));
         m_camera->activate();
-        KzSceneDesc d{};
-        d.abiVersion = KZ_ABI_VERSION;
-        d.meshes = m_meshRows.data(); d.nMeshes = (uint32_t)m_meshRows.size();
-        d.bsdfs = m_bsdfRows.data(); d.nBsdfs = (uint32_t)m_bsdfRows.size();
-        d.lights = m_lightRows.data(); d.nLights = (uint32_t)m_lightRows.size();
-        d.textures = m_rb.textures.data(); d.nTextures = (uint32_t)m_rb.textures.size();
-        d.images = m_rb.images.data(); d.nImages = (uint32_t)m_rb.images.size();
-        d.camera = m_camera->m_c; d.sampler = m_sampler->m_s; d.integrator = m_integrator->m_i;
-        if (m_background && m_background->m_nested) {
-            d.background.present = 1; d.background.intensity = m_background->m_intensity;
-            if (auto *c = dynamic_cast<ConstantTexture *>(m_background->m_nested)) {
-                d.background.color[0] = c->m_color.r; d.background.color[1] = c->m_color.g; d.background.color[2] = c->m_color.b;
-            } else {
-                d.background.texture = m_rb.tex(m_background->m_nested);                                // 1-based id of the nested texture's row
-                d.textures = m_rb.textures.data(); d.nTextures = (uint32_t)m_rb.textures.size();
-                d.images = m_rb.images.data(); d.nImages = (uint32_t)m_rb.images.size();
-            }
-        }
-        m_desc = d;
-        if (m_handle) { kz_scene_destroy(m_handle); m_handle = nullptr; }
-        int rc = kz_scene_create(&m_desc, &m_handle);
-        if (rc != KZ_OK) throw Exception(std::string("kz_scene_create: ") + kz_last_error());
+        m_lights.clear();
+        for (Mesh *m : m_meshes) { m->activate(); if (m->isLight()) m_lights.push_back(m); }
     }
+    // include/kazen/scene.h:24-60
     const std::vector<Mesh *> &getMeshes() const { return m_meshes; }
+    const std::vector<Mesh *> &getLights() const { return m_lights; }
     const Camera *getCamera() const { return m_camera; }
     const Sampler *getSampler() const { return m_sampler; }
     const Integrator *getIntegrator() const { return m_integrator; }
-    size_t getNumLights() const { return m_lightRows.size(); }
-    const KzSceneDesc &desc() const { return m_desc; }
-    KzScene *handle() const { return m_handle; }
+    size_t getNumLights() const { return m_lights.size(); }
+    /// ADDED: scene.h has no accessor for m_background (only getBackgroundColor(dir))
+    const Texture<Color3f> *getBackground() const { return m_background; }
     EClassType getClassType() const override { return EScene; }
     std::string toString() const override { return "Scene[]"; }
 private:
-    std::vector<Mesh *> m_meshes; Sampler *m_sampler = nullptr; Camera *m_camera = nullptr; Integrator *m_integrator = nullptr; BackgroundTexture *m_background = nullptr;
-    std::vector<KzMesh> m_meshRows; std::vector<KzBSDF> m_bsdfRows; std::vector<KzLight> m_lightRows; RowBuilder m_rb;
-    KzSceneDesc m_desc{}; KzScene *m_handle = nullptr;
+    std::vector<Mesh *> m_meshes, m_lights; Sampler *m_sampler = nullptr; Camera *m_camera = nullptr; Integrator *m_integrator = nullptr; Texture<Color3f> *m_background = nullptr;
 };
 
 KAZEN_MI355X_REGISTER(Scene, "scene");
@@ -780,59 +881,33 @@ private:
     int m_w, m_h; std::vector<float> m_rgb; std::vector<uint8_t> m_rgb8;
 };
 
-namespace renderer {
-/// The drop-in for kazen::renderer::render (renderer.cpp:72-153): render every sample of every pixel on `device` and
-/// return the normalised bitmap (h x w x rgb, linear) — what result.toBitmap() holds before savePNG.
-inline std::vector<float> render(Scene *scene, int device = 0) {
-    KzScene *h = scene->handle();
-    if (!h) throw Exception("renderer::render: scene was not activated");
-    if (kz_scene_upload(h, device) != KZ_OK) throw Exception(std::string("kz_scene_upload: ") + kz_last_error());
-    KzRenderOpts o{};
-    o.device = device;
-    if (kz_render(h, &o) != KZ_OK) throw Exception(std::string("kz_render: ") + kz_last_error());
-    int32_t w, hh, b;
-    kz_film_dims(h, &w, &hh, &b);
-    std::vector<float> film((size_t)(w + 2 * b) * (hh + 2 * b) * 4), rgb((size_t)w * hh * 3);
-    if (kz_film_download(h, film.data(), film.size()) != KZ_OK)      // (the scene is resident on that one device: its primary replica)
-        throw Exception(std::string("kz_film_download: ") + kz_last_error());
-    kz_film_to_rgb(film.data(), w, hh, b, rgb.data());
-    return rgb;
-}
-/// The same over several GPUs of one node, the reference's own decomposition one level up (renderer.cpp:94-127 runs one
-/// task per 32x32 block and merges with ImageBlock::put(ImageBlock&) under a mutex, block.cpp:87-96): ONE scene (one host
-/// BVH) resident on every device of `devices`, one host thread per device rendering its share of 64x64 tiles
-/// (kz_deal_tiles: by area), per-device films summed on the host in the order of `devices`. No collective.
-/// An empty list means every visible device.
-inline std::vector<float> render(Scene *scene, std::vector<int> devices, std::vector<float> *deviceMs = nullptr) {
-    KzScene *h = scene->handle();
-    if (!h) throw Exception("renderer::render: scene was not activated");
-    if (devices.empty()) for (int d = 0; d < kz_device_count(); ++d) devices.push_back(d);
-    if (devices.empty()) throw Exception("renderer::render: no HIP device visible (the MI355X path has no CPU fallback)");
-    int32_t w, hh, b;
-    kz_film_dims(h, &w, &hh, &b);
-    std::vector<float> film((size_t)(w + 2 * b) * (hh + 2 * b) * 4), rgb((size_t)w * hh * 3), ms(devices.size());
-    std::vector<int32_t> devs(devices.begin(), devices.end());
-    if (kz_render_multi(h, nullptr, devs.data(), (uint32_t)devs.size(), 0, film.data(), film.size(), ms.data()) != KZ_OK)
-        throw Exception(std::string("kz_render_multi: ") + kz_last_error());
-    if (deviceMs) *deviceMs = ms;
-    kz_film_to_rgb(film.data(), w, hh, b, rgb.data());
-    return rgb;
-}
-inline void saveBitmap(Scene *scene, std::vector<float> rgb, const std::string &filename, bool deviceToneMap) {
-    int32_t w, hh, b;
-    kz_film_dims(scene->handle(), &w, &hh, &b);
-    Bitmap bitmap(w, hh, std::move(rgb));
-    if (deviceToneMap) {
-        std::vector<uint8_t> px((size_t)w * hh * 3);
-        if (kz_film_to_srgb8(scene->handle(), px.data(), px.size()) != KZ_OK) throw Exception(std::string("kz_film_to_srgb8: ") + kz_last_error());
-        bitmap.setSRGB8(std::move(px));
+/// include/kazen/block.h:12-85 as far as the adapter needs it: the full-frame accumulation buffer of renderer.cpp:81 - row-major
+/// Color4f (rgb x weight, weight), (h + 2 border) x (w + 2 border), border = ceil(radius - 0.5) (block.cpp:13-14,30) - and toBitmap().
+struct Color4f { float r = 0, g = 0, b = 0, w = 0; };
+class ImageBlock {
+public:
+    ImageBlock(const Vector2i &size, const ReconstructionFilter *filter) : m_size(size) {
+        m_borderSize = filter ? (int)std::ceil(filter->getRadius() - 0.5f) : 0;
+        m_px.assign((size_t)(size.x() + 2 * m_borderSize) * (size_t)(size.y() + 2 * m_borderSize), Color4f());
     }
-    const size_t lastdot = filename.find_last_of(".");
-    bitmap.savePNG(lastdot == std::string::npos ? filename : filename.substr(0, lastdot));
-}
-/// renderer.cpp:72-153 including the file: renders and writes `<stem of filename>.png` (renderer.cpp:143-152), tone-mapped on the device
-inline void render(Scene *scene, const std::string &filename, int device = 0) { saveBitmap(scene, render(scene, device), filename, true); }
-/// multi-GPU form; the merged film lives on the host, so Bitmap::savePNG applies the reference's tone map there (bitmap.cpp:45-52)
-inline void render(Scene *scene, const std::string &filename, const std::vector<int> &devices) { saveBitmap(scene, render(scene, devices), filename, false); }
+    Color4f *data() { return m_px.data(); }
+    const Color4f *data() const { return m_px.data(); }
+    size_t size() const { return m_px.size(); }
+    const Vector2i &getSize() const { return m_size; }
+    int getBorderSize() const { return m_borderSize; }
+    /// block.cpp:39-45 + Color4f::divideByFilterWeight (color.h:94-99): rgb / weight, 0 where the weight is 0 (the library's kz_film_to_rgb)
+    Bitmap *toBitmap() const {
+        std::vector<float> rgb((size_t)m_size.x() * m_size.y() * 3);
+        kz_film_to_rgb((const float *)m_px.data(), m_size.x(), m_size.y(), m_borderSize, rgb.data());
+        return new Bitmap(m_size.x(), m_size.y(), std::move(rgb));
+    }
+private:
+    Vector2i m_size; int m_borderSize = 0; std::vector<Color4f> m_px;
+};
+
+namespace renderer {
+/// include/kazen/renderer.h:10 - defined by adapter/renderer_mi355x.cpp (the file INTEGRATION.md adds to a kazen tree), which a program
+/// using this mirror compiles and links unchanged
+void render(Scene *scene, const std::string &filename);
 } // namespace renderer
 } // namespace kazen

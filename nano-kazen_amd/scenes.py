@@ -272,6 +272,7 @@ class SceneDescription:
                 k.nested = b["_nested"]
             else:
                 k.type = 99      # unsupported plugin: the library must answer KZ_ERR_UNSUPPORTED
+            k.alphaResolved = 1 if b.get("alphaResolved") else 0      # the value under "alpha" / "roughness" is then the constructor's m_alpha (KzBSDF.alphaResolved)
         bg_tex = tex_id(self.background.get("texture")) if self.background is not None else 0
         ct = (abi.KzTexture * max(1, len(textures)))()
         for i, row in enumerate(textures):

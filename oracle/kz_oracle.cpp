@@ -916,7 +916,7 @@ static V3 dielectricSample(const KzBSDF &m, BRec &b, float sample1, bool &ok) {
 
 // ---- Beckmann helpers shared by roughconductor / roughplastic / roughdielectric --------------------------------------
 static inline float tanTheta(V3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return std::sqrt(temp) / v.z; }   // frame.h:63-68
-static inline float alphaOf(float x) { return std::max(0.001f, sqr(x)); }                                                         // bsdf.cpp:699-701, :820-823, :958-960
+static inline float alphaOf(float x) { return x; }      // the row carries m_alpha = max(0.001, sqr(property)), formed at kzo_scene_create as the constructors form it: bsdf.cpp:699-701, :820-823, :958-960
 static float evalBeckmann(V3 m, float alpha) {                                                                                    // bsdf.cpp:721-727
     float temp = tanTheta(m) / alpha, ct = m.z, ct2 = ct * ct;
     return kzoExp(-temp * temp) / (kPi * alpha * alpha * ct2 * ct2);
@@ -1098,7 +1098,7 @@ static V3 rdielSample(const KzBSDF &m, BRec &b, float s1, float s2x, float s2y, 
 }
 
 static const KzBSDF &meshBsdf(const Scene &sc, int mesh) {
-    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f, 1.5046f, 1.000277f, 0.1f, {0, 0, 0}, {0, 0, 0}, 0, 0, 0, 0, 0, {0, 0}};
+    static const KzBSDF dflt = {KZ_BSDF_DIFFUSE, {0.5f, 0.5f, 0.5f}, {0, 0, 0}, 0, 0, 0, 0.5f, 0.5f, 0, 0.5f, 0, 0.5f, 1.5046f, 1.000277f, 0.1f, {0, 0, 0}, {0, 0, 0}, 0, 0, 0, 0, 0, 0, 0};
     int b = sc.meshes[mesh].bsdf;
     return b < 0 ? dflt : sc.bsdfs[b];
 }
@@ -1708,6 +1708,9 @@ int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) { FtzScope 
     }
     for (auto &b : sc->bsdfs) {
         if (b.type < KZ_BSDF_DIFFUSE || b.type > KZ_BSDF_NORMALMAP) { delete sc; return fail(KZ_ERR_UNSUPPORTED, "bsdf type"); }
+        const bool rough = b.type == KZ_BSDF_ROUGHCONDUCTOR || b.type == KZ_BSDF_ROUGHPLASTIC || b.type == KZ_BSDF_ROUGHDIELECTRIC;
+        if ((b.alphaResolved != 0 && b.alphaResolved != 1) || (b.alphaResolved && !rough)) { delete sc; return fail(KZ_ERR_INVALID_ARG, "alphaResolved"); }
+        if (rough && !b.alphaResolved) { b.alpha = std::max(0.001f, sqr(b.alpha)); b.alphaResolved = 1; }                              // bsdf.cpp:696-700, :818-822, :956-959
         const int ids[4] = {b.albedoTex, b.roughnessTex, b.metallicTex, b.normalTex};
         for (int id : ids) if (id < 0 || id > (int)d->nTextures) { delete sc; return fail(KZ_ERR_INVALID_ARG, "bsdf texture id"); }
         if (b.type == KZ_BSDF_NORMALMAP && (b.normalTex == 0 || b.nested < 0 || b.nested >= (int)d->nBsdfs || d->bsdfs[b.nested].type == KZ_BSDF_NORMALMAP)) { delete sc; return fail(KZ_ERR_INVALID_ARG, "normalmap row"); }
@@ -1968,7 +1971,9 @@ void kzo_cosine_hemisphere(float sx, float sy, float *o3) { FtzScope ftz_; V3 v 
 void kzo_uniform_disk(float sx, float sy, float *o2) { FtzScope ftz_; squareToUniformDisk(sx, sy, o2[0], o2[1]); }
 void kzo_frame(const float *n, float *s3, float *t3) { FtzScope ftz_; Frame f(V3(n[0], n[1], n[2])); s3[0] = f.s.x; s3[1] = f.s.y; s3[2] = f.s.z; t3[0] = f.t.x; t3[1] = f.t.y; t3[2] = f.t.z; }
 // BSDF: which = 0 eval (3 floats), 1 pdf (1 float), 2 sample (weight 3 + wo 3 + ok 1)
-void kzo_bsdf(const KzBSDF *m, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float *out) { FtzScope ftz_;
+void kzo_bsdf(const KzBSDF *row, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float *out) { FtzScope ftz_;
+    KzBSDF resolved = *row, *m = &resolved;                // a bare row: resolve the rough BSDFs' alpha as kzo_scene_create does (the constructors' m_alpha)
+    if ((m->type == KZ_BSDF_ROUGHCONDUCTOR || m->type == KZ_BSDF_ROUGHPLASTIC || m->type == KZ_BSDF_ROUGHDIELECTRIC) && !m->alphaResolved) { m->alpha = std::max(0.001f, sqr(m->alpha)); m->alphaResolved = 1; }
     BRec b; b.wi = V3(wi[0], wi[1], wi[2]); b.accumulatedRoughness = accRough;
     if (which == 2) {
         bool ok; V3 w = bsdfSample(*m, b, s1, s2x, s2y, ok);

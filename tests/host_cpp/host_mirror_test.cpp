@@ -1,8 +1,16 @@
 // Drives the C++ host mirror (nano-kazen_amd/host/kazen_host.hpp) the way nano-kazen's parser drives its object
-// model (parser.cpp:116-301: children first, createInstance, addChild, activate), then either dumps the flattened
-// description as JSON (no GPU needed) or renders on GPU 0 and writes the linear rgb bitmap to a file.
-#include "../../nano-kazen_amd/host/kazen_host.hpp"
-#include "../../include/kazen_mi355x_dev.h"      // (the test also reads the BVH statistics: development surface)
+// model (parser.cpp:116-301: children first, createInstance, addChild, activate), then hands the activated Scene to the ADAPTER a maintainer
+// adds to a kazen tree - nano-kazen_amd/host/adapter/renderer_mi355x.cpp + adapter/kazen/mi355x.h, compiled UNCHANGED into this program (the
+// mirror answers to the reference's header names through mirror_tree/kazen/*.h) - and either dumps the description the adapter produced as
+// JSON (no GPU needed) or renders on the GPU and writes the linear rgb bitmap to a file. The mirror's plugin classes keep their parameters
+// private like the reference's: whatever this program prints came out through the describe() virtuals INTEGRATION.md lists.
+// Build: g++ -std=c++17 -I include -I nano-kazen_amd/host/mirror_tree -I nano-kazen_amd/host/adapter host_mirror_test.cpp nano-kazen_amd/host/adapter/renderer_mi355x.cpp -lkazen_mi355x
+#include <kazen/renderer.h>
+#include <kazen/scene.h>
+#include <kazen/block.h>
+#include <kazen/bitmap.h>
+#include <kazen/mi355x.h>
+#include <kazen_mi355x_dev.h>                    // (the test also reads the BVH statistics: development surface)
 #include "../../nano-kazen_amd/host/kazen_sceneio.hpp"
 
 #include <cstdio>
@@ -91,12 +99,21 @@ static Scene *buildTexturedScene(const char *ppm) {
     return scene;
 }
 
+// what renderer::render does before it writes the file: the adapter's DeviceScene, the full-frame ImageBlock, toBitmap
+static std::vector<float> renderRgb(mi355x::DeviceScene &ds, const Scene *scene, const std::vector<int> &devices) {
+    ImageBlock result(scene->getCamera()->getOutputSize(), scene->getCamera()->getReconstructionFilter());
+    ds.render(result, devices);
+    std::unique_ptr<Bitmap> bm(result.toBitmap());
+    return std::vector<float>(bm->data(), bm->data() + (size_t)bm->cols() * bm->rows() * 3);
+}
+
 template <class F> static std::string thrown(F f) { try { f(); } catch (const Exception &e) { return e.what(); } return ""; }
 
 int main(int argc, char **argv) {
     if (argc >= 3 && !std::strcmp(argv[1], "--render")) {
         std::unique_ptr<Scene> scene(buildScene());
-        std::vector<float> rgb = renderer::render(scene.get(), 0);
+        mi355x::DeviceScene ds(scene.get());
+        std::vector<float> rgb = renderRgb(ds, scene.get(), {0});
         std::ofstream(argv[2], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
         double s = 0; for (float v : rgb) s += v;
         std::printf("{\"pixels\": %zu, \"mean\": %.6f}\n", rgb.size() / 3, s / rgb.size());
@@ -108,9 +125,13 @@ int main(int argc, char **argv) {
         try { root.reset(loadFromXML(argv[2])); } catch (const Exception &e) { err = e.what(); }
         if (!root) { for (auto &c : err) if (c == '"') c = '\''; std::printf("{\"error\": \"%s\"}\n", err.c_str()); return 0; }
         Scene *scene = static_cast<Scene *>(root.get());
-        const KzSceneDesc &d = scene->desc();
+        std::unique_ptr<mi355x::DeviceScene> dsp;
+        try { dsp.reset(new mi355x::DeviceScene(scene)); } catch (const Exception &e) { err = e.what(); }
+        if (!dsp) { for (auto &c : err) if (c == '"') c = '\''; std::printf("{\"error\": \"%s\"}\n", err.c_str()); return 0; }
+        mi355x::DeviceScene &ds = *dsp;
+        const KzSceneDesc &d = ds.desc();
         if (argc >= 4) {
-            std::vector<float> rgb = renderer::render(scene, 0);
+            std::vector<float> rgb = renderRgb(ds, scene, {0});
             std::ofstream(argv[3], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
         }
         std::printf("{\"nMeshes\": %u, \"nBsdfs\": %u, \"nLights\": %u, \"nTextures\": %u, \"nImages\": %u, \"meshes\": [", d.nMeshes, d.nBsdfs, d.nLights, d.nTextures, d.nImages);
@@ -147,22 +168,23 @@ int main(int argc, char **argv) {
         std::unique_ptr<Scene> scene(buildScene());
         std::vector<int> devs;
         for (const char *c = argv[3]; *c;) { devs.push_back(std::atoi(c)); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
-        std::vector<float> ms;
-        std::vector<float> rgb = renderer::render(scene.get(), devs, &ms);
+        mi355x::DeviceScene ds(scene.get());
+        std::vector<float> rgb = renderRgb(ds, scene.get(), devs);
         std::ofstream(argv[2], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
-        std::printf("{\"pixels\": %zu, \"devices\": %zu}\n", rgb.size() / 3, ms.size());
+        std::printf("{\"pixels\": %zu, \"devices\": %zu}\n", rgb.size() / 3, devs.size());
         return 0;
     }
     if (argc >= 3 && !std::strcmp(argv[1], "--render-png")) {        // renderer::render(scene, filename) (renderer.cpp:72-153)
         std::unique_ptr<Scene> scene(buildScene());
-        renderer::render(scene.get(), std::string(argv[2]), 0);
+        renderer::render(scene.get(), std::string(argv[2]));          // the adapter's drop-in itself: every visible GPU, <stem>.png
         return 0;
     }
     if (argc >= 3 && !std::strcmp(argv[1], "--textured")) {
         std::unique_ptr<Scene> scene(buildTexturedScene(argv[2]));
-        const KzSceneDesc &d = scene->desc();
+        mi355x::DeviceScene ds(scene.get());
+        const KzSceneDesc &d = ds.desc();
         if (argc >= 4) {
-            std::vector<float> rgb = renderer::render(scene.get(), 0);
+            std::vector<float> rgb = renderRgb(ds, scene.get(), {0});
             std::ofstream(argv[3], std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
         }
         std::printf("{\"nBsdfs\": %u, \"nTextures\": %u, \"nImages\": %u, \"bsdfs\": [", d.nBsdfs, d.nTextures, d.nImages);
@@ -182,8 +204,9 @@ int main(int argc, char **argv) {
         return 0;
     }
     std::unique_ptr<Scene> scene(buildScene());
-    const KzSceneDesc &d = scene->desc();
-    KzBvhInfo info; kz_scene_bvh_info(scene->handle(), &info);
+    mi355x::DeviceScene ds(scene.get());
+    const KzSceneDesc &d = ds.desc();
+    KzBvhInfo info; kz_scene_bvh_info(ds.handle(), &info);
     std::string e1 = thrown([] { ObjectFactory::createInstance("whitted", PropertyList()); });
     std::string e2 = thrown([] { ObjectFactory::createInstance("nosuchclass", PropertyList()); });
     std::string e3 = thrown([] { Scene s; s.addChild(ObjectFactory::createInstance("path_mis", PropertyList())); s.activate(); });
@@ -193,9 +216,9 @@ int main(int argc, char **argv) {
     std::printf("{\"nMeshes\": %u, \"nBsdfs\": %u, \"nLights\": %u, \"meshBsdf\": [%d, %d, %d, %d], \"meshLight\": [%d, %d, %d, %d],\n",
                 d.nMeshes, d.nBsdfs, d.nLights, d.meshes[0].bsdf, d.meshes[1].bsdf, d.meshes[2].bsdf, d.meshes[3].bsdf,
                 d.meshes[0].light, d.meshes[1].light, d.meshes[2].light, d.meshes[3].light);
-    std::printf(" \"kiss\": [%d, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g], \"light\": [%g, %g, %g, %g, %d],\n", d.bsdfs[1].type, d.bsdfs[1].baseColor[0],
-                d.bsdfs[1].baseColor[1], d.bsdfs[1].baseColor[2], d.bsdfs[1].roughness, d.bsdfs[1].metallic, d.bsdfs[1].anisotropy, d.bsdfs[1].specular, d.bsdfs[1].specularTint,
-                d.bsdfs[1].clearcoat, d.bsdfs[1].clearcoatRoughness, d.bsdfs[1].sheen, d.bsdfs[1].sheenTint, d.lights[0].color[0], d.lights[0].color[1], d.lights[0].color[2],
+    std::printf(" \"kiss\": [%d, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g, %g], \"light\": [%g, %g, %g, %g, %d],\n", d.bsdfs[2].type, d.bsdfs[2].baseColor[0],
+                d.bsdfs[2].baseColor[1], d.bsdfs[2].baseColor[2], d.bsdfs[2].roughness, d.bsdfs[2].metallic, d.bsdfs[2].anisotropy, d.bsdfs[2].specular, d.bsdfs[2].specularTint,
+                d.bsdfs[2].clearcoat, d.bsdfs[2].clearcoatRoughness, d.bsdfs[2].sheen, d.bsdfs[2].sheenTint, d.lights[0].color[0], d.lights[0].color[1], d.lights[0].color[2],
                 d.lights[0].intensity, d.lights[0].primaryVisibility);
     std::printf(" \"camera\": [%d, %d, %g, %g, %g, %d, %g, %g], \"sampler\": [%d, %u, %llu], \"integrator\": [%d, %d, %g, %d, %g], \"background\": [%d, %g, %g, %g, %g],\n",
                 d.camera.width, d.camera.height, d.camera.fov, d.camera.nearClip, d.camera.farClip, d.camera.rfilter.type, d.camera.rfilter.radius, d.camera.rfilter.stddev,

@@ -11,13 +11,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "host_cpp", "host_mirror_test.cpp")
 LIBDIR = os.path.join(ROOT, "nano-kazen_amd", "csrc")
+HOST = os.path.join(ROOT, "nano-kazen_amd", "host")
+# the two files INTEGRATION.md adds to a kazen tree, compiled unchanged against the mirror (mirror_tree/kazen/*.h answer to the reference's header names)
+ADAPTER = os.path.join(HOST, "adapter", "renderer_mi355x.cpp")
+INCLUDES = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HOST, "mirror_tree"), "-I" + os.path.join(HOST, "adapter")]
 
 
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory, kz):
     kz.abi.load_library()
     out = str(tmp_path_factory.mktemp("host") / "host_mirror_test")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", out, SRC, "-L" + LIBDIR, "-lkazen_mi355x", "-Wl,-rpath," + LIBDIR])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror"] + INCLUDES + ["-o", out, SRC, ADAPTER, "-L" + LIBDIR, "-lkazen_mi355x", "-Wl,-rpath," + LIBDIR])
     return out
 
 
@@ -42,8 +46,8 @@ def python_twin(kz):
 
 def test_flattened_description_and_errors(exe, kz):
     d = json.loads(subprocess.check_output([exe]).decode())
-    assert (d["nMeshes"], d["nBsdfs"], d["nLights"], d["bvhTris"]) == (4, 2, 1, 8)
-    assert d["meshBsdf"] == [-1, 0, 1, -1] and d["meshLight"] == [-1, -1, -1, 0]          # no bsdf child -> default diffuse
+    assert (d["nMeshes"], d["nBsdfs"], d["nLights"], d["bvhTris"]) == (4, 4, 1, 8)
+    assert d["meshBsdf"] == [0, 1, 2, 3] and d["meshLight"] == [-1, -1, -1, 0]            # no bsdf child -> Mesh::activate's default diffuse (mesh.cpp:25-28), described like any other
     assert np.allclose(d["kiss"], [1, 0.8, 0.6, 0.2, 0.4, 0, 0, 0.5, 0.5, 1, 0.5, 0.5, 0.5])     # reference defaults (bsdf.cpp:1160-1167)
     assert np.allclose(d["light"], [1, 0.9, 0.8, 12, 0])                                      # lightPrimaryVisibility defaults to false
     assert np.allclose(d["camera"], [64, 48, 40, 0.1, 100, 0, 2, 0.5]) and d["sampler"] == [0, 8, 0]
@@ -115,10 +119,10 @@ def test_texture_plugins_flatten_like_the_python_path(exe, kz, tmp_path):
     ppm = str(tmp_path / "checker.ppm")
     _write_ppm(ppm, kz.scenes._test_images()[0])
     d = json.loads(subprocess.check_output([exe, "--textured", ppm]).decode())
-    assert (d["nBsdfs"], d["nImages"]) == (3, 4)
-    lam, nm, kiss = d["bsdfs"]
+    assert (d["nBsdfs"], d["nImages"]) == (4, 4)
+    lam, nm, _light_mesh_default, kiss = d["bsdfs"]
     assert lam[0] == a.KZ_BSDF_DIFFUSE and lam[1] > 0
-    assert nm[0] == a.KZ_BSDF_NORMALMAP and nm[4] > 0 and nm[5] == 2                         # the wrapped row sits behind the per-mesh rows
+    assert nm[0] == a.KZ_BSDF_NORMALMAP and nm[4] > 0 and nm[5] == 3                         # the wrapped row sits behind the per-mesh rows
     assert kiss[0] == a.KZ_BSDF_KAZENSTANDARD and kiss[1] > 0 and kiss[2] > 0 and kiss[3] == 0 and kiss[6] == 0.0     # metallic: a folded constanttexture
     T = d["textures"]
     ramp = T[kiss[2] - 1]
@@ -166,7 +170,7 @@ def test_cpp_xml_loader_equals_the_python_one(exe, kz):
         assert cm[:4] == g[:4] and cm[9] == g[7]                                   # counts, presence of N / UV, the index buffer
         assert np.allclose(cm[6:9], g[4:7], rtol=1e-5, atol=1e-4)                      # vertex / normal / uv sums (transform applied in float)
     a = kz.abi
-    assert d["bsdfTypes"] == [a.KZ_BSDF_DIFFUSE, a.KZ_BSDF_KAZENSTANDARD]
+    assert d["bsdfTypes"] == [a.KZ_BSDF_DIFFUSE, a.KZ_BSDF_KAZENSTANDARD, a.KZ_BSDF_DIFFUSE]      # (the emitter mesh has no <bsdf>: Mesh::activate gives it the default diffuse one, mesh.cpp:25-28)
     assert d["camera"][:3] == [a.KZ_CAMERA_PERSPECTIVE, 48, 32] and np.allclose(d["camera"][3:6], [45, 0.1, 50]) and d["camera"][6] == a.KZ_FILTER_MITCHELL
     assert np.allclose(d["toWorld"], np.asarray(py.camera["toWorld"]).reshape(-1), atol=1e-6)
     assert d["sampler"] == [a.KZ_SAMPLER_CORRELATED, 9, 7] and d["integrator"][0] == 4 and np.isclose(d["integrator"][1], 0.002)
@@ -225,10 +229,36 @@ def test_cpp_xml_loader_on_reference_scene_files(exe, kz, rel):
 def test_example_main_builds_and_fails_loudly_without_a_gpu(kz, tmp_path):
     """nano-kazen_amd/host/example_main.cpp: main.cpp's shape on top of the library."""
     out = str(tmp_path / "kazen_mi355x")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "nano-kazen_amd", "host", "example_main.cpp"), "-L" + LIBDIR, "-lkazen_mi355x",
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + INCLUDES + [os.path.join(HOST, "example_main.cpp"), ADAPTER, "-L" + LIBDIR, "-lkazen_mi355x",
                            "-Wl,-rpath," + LIBDIR, "-o", out])
     r = subprocess.run([out, "/nonexistent/scene.xml"], capture_output=True, text=True)
     assert r.returncode != 0 and "file not found" in r.stderr
     if kz.abi.load_library().kz_device_count() == 0:
         r = subprocess.run([out, MINI], capture_output=True, text=True)
         assert r.returncode != 0 and "no HIP device" in r.stderr          # the product path has no CPU fallback
+
+
+# ---------------------------------------------------------------- the adapter INTEGRATION.md hands to a kazen maintainer
+def test_integration_md_quotes_the_adapter_verbatim():
+    """The two NEW files of INTEGRATION.md are the files this suite compiles against the mirror, byte for byte."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for title, path in (("### NEW file `include/kazen/mi355x.h`", os.path.join(HOST, "adapter", "kazen", "mi355x.h")),
+                        ("### NEW file `src/kazen/renderer_mi355x.cpp`", ADAPTER)):
+        at = md.index(title)
+        a = md.index("```cpp\n", at) + len("```cpp\n")
+        b = md.index("\n```\n", a) + 1
+        assert md[a:b] == open(path).read(), path
+
+
+def test_adapter_reads_nothing_the_reference_keeps_private(tmp_path):
+    """The mirror's plugin classes keep their parameters private, like the reference's (bsdf.cpp:1407-1418, light.cpp:61-65, integrator.cpp:350-354,
+    camera.cpp:122-128): a translation unit that reaches for one does not compile, so the adapter - which does - reads none."""
+    ok = tmp_path / "ok.cpp"
+    ok.write_text('#include <kazen/scene.h>\nint main() { kazen::PropertyList p; kazen::Diffuse d(p); KzBSDF row{}; kazen::mi355x::Rows rows; return d.describe(row, rows) ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only"] + INCLUDES + [str(ok)])
+    for cls, member in (("Diffuse", "m_albedo"), ("KazenStandardSurface", "m_specular"), ("AreaLight", "m_intensity"), ("PathMisIntegrator", "m_maxDepth"),
+                        ("PerspectiveCamera", "m_fov"), ("PMJ02BN", "m_seed"), ("GaussianFilter", "m_stddev"), ("ConstantTexture", "m_color"), ("RoughConductor", "m_alpha")):
+        bad = tmp_path / "bad.cpp"
+        bad.write_text('#include <kazen/scene.h>\nint main() { kazen::PropertyList p; kazen::%s o(p); return (int)sizeof(o.%s); }\n' % (cls, member))
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only"] + INCLUDES + [str(bad)], capture_output=True, text=True)
+        assert r.returncode != 0 and ("private" in r.stderr or "protected" in r.stderr), (cls, member, r.stderr[-400:])

@@ -450,3 +450,27 @@ def test_both_statements_of_the_transcendentals_are_the_same_sequences():
     dev = norm(os.path.join(root, "nano-kazen_amd", "csrc", "kz_crmath.h"), True)
     ora = norm(os.path.join(root, "oracle", "kz_oracle_math.h"), False)
     assert len(ora) > 100 and dev == ora, [(a, b) for a, b in zip(dev, ora) if a != b][:3]
+
+
+def test_resolved_alpha_rows_equal_raw_rows(kz, O):
+    """KzBSDF.alphaResolved (ABI v5, round 5): what an adapter inside a kazen tree can read of the three rough BSDFs is the constructor's
+    m_alpha = max(0.001, sqr(property)) (bsdf.cpp:696-700, :818-822, :956-959), not the property. A row that carries it (alphaResolved = 1) must be
+    the row that carries the property, bit for bit - and the flag on any other model is refused."""
+    S = kz.scenes
+    rng = np.random.default_rng(4)
+    wi = rng.normal(size=(24, 3)).astype(np.float32); wi[:, 2] = np.abs(wi[:, 2]) + 0.05; wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    wo = rng.normal(size=(24, 3)).astype(np.float32); wo[:, 2] = np.abs(wo[:, 2]) + 0.05; wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    for raw in (S.roughconductor(0.3, "Cu"), S.roughconductor(0.01), S.roughplastic(0.25, kd=(0.3, 0.5, 0.2)), S.roughdielectric(0.35)):
+        prop = np.float32(raw.get("alpha", raw.get("roughness")))
+        res = dict(raw, alphaResolved=True)
+        res["alpha" if "alpha" in raw else "roughness"] = float(np.maximum(np.float32(0.001), prop * prop))
+        for k in range(24):
+            assert (O.bsdf(raw, "eval", wi[k], wo[k]).view(np.uint32) == O.bsdf(res, "eval", wi[k], wo[k]).view(np.uint32)).all()
+            assert O.bsdf(raw, "pdf", wi[k], wo[k]) == O.bsdf(res, "pdf", wi[k], wo[k])
+    s = S.SceneDescription()
+    s.add_mesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 2]], np.uint32), bsdf=dict(S.ggx((0.5, 0.5, 0.5), 0.3, 0.0), alphaResolved=True))
+    s.camera.update(width=8, height=8)
+    with pytest.raises(Exception):
+        O.OracleScene(s)
+    with pytest.raises(Exception, match="alphaResolved"):
+        kz.Scene(s, device=None)
