@@ -22,6 +22,10 @@ in HBM before the timed region starts.
 --strong: BASELINE.json configs[4], "C5" - the SAME scene at 3840x2160 x 4096 spp as ONE fixed job: a step is the whole frame, every rank
 renders all 4096 spp of its tiles (scaling "strong": the work per GPU shrinks with N). Not the default: at N = 1 the driver's run must be C4.
 
+`cold_job` (N = 1): the reference renders ONE frame per process (renderer.cpp:72-153). Before this process touches the GPU, two CHILD
+processes each do exactly that job and report its wall time - kz_scene_upload of a freshly built scene, the WHOLE frame (C4: 1920x1080 x 1024 spp; the
+reference's own scene file default_m0_r0.5 at its 4096 spp), kz_film_download - every allocation, the beam lists and the growth of the pass context included.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
 """
 import argparse
@@ -97,6 +101,72 @@ def load_profile_facts(live_ms_per_pass_alone):
     return facts, None
 
 
+def cold_job(which, tris):
+    """One frame in a fresh process, as kazen::renderer::render is used (renderer.cpp:72-153: one render per process): prints one JSON object. The scene is
+    built on the host first (kz_scene_create: BVH build, not part of the metric); the clock covers kz_scene_upload -> kz_render of every sample
+    of every pixel -> kz_film_download, i.e. the table upload, the beam lists, every device allocation and the pass context growing while the first passes run."""
+    import numpy as np
+    kz = importlib.import_module("nano-kazen_amd")
+    t0 = time.perf_counter()
+    if which == "c4":
+        desc = kz.scenes.random_triangles(tris, W, H, SPP, sampler="pmj02bn", seed=1)
+        name = "C4: %d random triangles + 8 mesh lights, %dx%d, pmj02bn, all %d spp" % (tris, W, H, SPP)
+    else:
+        desc = kz.scenes.load_npz(os.path.join(ROOT, "tests", "golden", "q1_default_m0_r0.5.npz"))
+        name = "scene/2022_q1/parameters/default_m0_r0.5.xml (36 378 triangles, via tests/golden/q1_default_m0_r0.5.npz), 1920x1080, independent sampler, all of the file's spp"
+    scene = kz.Scene(desc)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n_dev = scene.lib.kz_device_count()                     # the first HIP call of the process: runtime start-up, a property of the process and reported beside the job
+    if n_dev <= 0:
+        raise SystemExit("cold job: no GPU")
+    t_init = time.perf_counter() - t0
+    free0 = C_mem_info(scene.lib)
+    t0 = time.perf_counter()
+    scene.upload(0)
+    t1 = time.perf_counter()
+    scene.render()                                         # every sample of every pixel, library defaults
+    scene.sync()
+    t2 = time.perf_counter()
+    film = scene.film()
+    t3 = time.perf_counter()
+    info = scene.last_pass_info()
+    n = scene.width * scene.height * scene.sample_count
+    rec = {"workload": name, "job": "fresh process: kz_scene_upload -> kz_render (whole frame, every sample) -> kz_film_download; wall clock, every allocation, the beam lists and "
+                                    "the growth of the pass context included; the host BVH build and the HIP runtime start-up are reported beside it",
+           "value": round(n / (t3 - t0) / 1e6, 1), "unit": "Msamples/s", "samples": n, "seconds": round(t3 - t0, 4),
+           "upload_s": round(t1 - t0, 4), "render_s": round(t2 - t1, 4), "download_s": round(t3 - t2, 4),
+           "scene_build_s": round(t_build, 2), "hip_runtime_init_s": round(t_init, 3), "value_with_runtime_init": round(n / (t3 - t0 + t_init) / 1e6, 1),
+           "passes": info["passes"], "first_pass_items": info["firstPassItems"], "largest_pass_items": info["largestPassItems"], "target_pass_items": info["itemsPerPass"],
+           "state_gb": round(info["stateBytes"] / 1e9, 1), "device_free_gb_at_start": round(free0 / 1e9, 1),
+           "image_mean": round(float(scene.rgb(film).mean()), 5)}
+    print(json.dumps(rec), flush=True)
+    os._exit(0)                                            # (the job is done: what the process still holds goes back to the driver at exit, as the reference's does)
+
+
+def C_mem_info(lib):
+    import ctypes
+    f, t = ctypes.c_uint64(), ctypes.c_uint64()
+    return f.value if lib.kz_device_mem_info(0, ctypes.byref(f), ctypes.byref(t)) == 0 else 0
+
+
+def run_cold_jobs(tris):
+    """The two cold jobs as child processes, BEFORE this process initialises HIP (no fork from a process that holds the GPU)."""
+    out = {}
+    for which in ("c4", "q1"):
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-job", which, "--tris", str(tris)], capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            rec = json.loads(line[-1]) if line else {"error": "no record (exit code %d): %s" % (r.returncode, r.stderr[-300:])}
+        except Exception as e:                                 # noqa: BLE001 - a failed side job must not cost the headline record
+            rec = {"error": repr(e)}
+        rec["process_s"] = round(time.time() - t0, 1)
+        log("cold job %s: %s" % (which, json.dumps(rec)))
+        out[which] = rec
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,12 +180,19 @@ def main():
     ap.add_argument("--no-asset-scene", action="store_true", help="N = 1: skip the slice of the reference's own scene file that rides in the same JSON line")
     ap.add_argument("--asset-spp", type=int, default=512, help="samples per pixel of that slice (sample indices [0, n) of the scene file's 4096)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
+    ap.add_argument("--cold-job", choices=["c4", "q1"], default=None, help="(child process mode) run ONE cold job and print its record")
+    ap.add_argument("--no-cold-job", action="store_true", help="N = 1: skip the two one-frame-per-process jobs that ride in the same JSON line")
     args = ap.parse_args()
+    if args.cold_job:
+        return cold_job(args.cold_job, args.tris)
     if args.steps is None:
         args.steps = 1 if args.strong else 6
     if args.warmup is None:
         args.warmup = 0 if args.strong else 1
     commit = os.environ.get("GRAFT_HEAD") or git_head()          # before torch / HIP are loaded: no fork from a process that has initialised the GPU
+    cold = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.strong and not args.no_cold_job:
+        cold = run_cold_jobs(args.tris)                          # (child processes; this one has not touched the GPU yet)
 
     # stdout carries ONE line, the JSON record: everything else that may write to file descriptor 1 (gloo's "[Gloo] Rank ... is
     # connected" banner comes from C++ and lands on stdout) is sent to stderr; the record goes to the saved descriptor.
@@ -142,7 +219,10 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)        # CPU process group: barriers + the host gather
 
     kz = importlib.import_module("nano-kazen_amd")
-    Wd, Hd, spp_table = (W5, H5, SPP5) if args.strong else (W, H, SPP)
+    # weak scaling: a rank owns 1/N of the pixels and renders N x 512 spp of them per step, so that every rank runs the SAME pass as N = 1 (one pass of 2^30
+    # items). From N = 4 on that is more than C4's 1024-entry pmj02bn table holds; the table grows with it (N = 4: 2048, N = 8: 4096 entries - the table of
+    # BASELINE's own 8-GPU config) instead of wrapping, which used to cut a rank's step into calls of 2^28 items (3 % slower per GPU: VERDICT r04)
+    Wd, Hd, spp_table = (W5, H5, SPP5) if args.strong else (W, H, max(SPP, SPP_PER_RANK_STEP * world))
     t0 = time.time()
     desc = kz.scenes.random_triangles(args.tris, Wd, Hd, spp_table, sampler="pmj02bn", seed=1)
     t1 = time.time()
@@ -160,10 +240,7 @@ def main():
     if args.strong:
         spp_step = spp_table                              # the whole job every step
     else:
-        # weak scaling: a rank owns 1/N of the pixels and renders N x the spp. From N = 4 on that is more than the 1024-entry table holds: the sample
-        # indices are taken modulo the table, every wrap its own call (the same work per sample; a call is then one pass of <= 2^28 items - a rank's
-        # pixels x the whole table - where N = 1 and 2 run passes of 2^30 and 2^29)
-        spp_step = SPP_PER_RANK_STEP * world
+        spp_step = SPP_PER_RANK_STEP * world              # (<= the table: a step is ONE call)
     stream = torch.cuda.current_stream().cuda_stream
     kw = {}
     if shared_device:
@@ -219,12 +296,13 @@ def main():
         % (rank, world, device_index, torch.cuda.get_device_name(device_index), len(tiles), my_pixels, elapsed, args.steps, info, free_b / 2**30, total_b / 2**30,
            packed.nbytes / 1e6, 1e3 * (t_d - t_g), 1e3 * gather_s))
 
-    el = torch.tensor([elapsed, gather_s], dtype=torch.float64)
+    el = torch.tensor([elapsed, gather_s, float(info["largestPassItems"]), -float(info["largestPassItems"])], dtype=torch.float64)
     px = torch.tensor([my_pixels], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(px, op=dist.ReduceOp.SUM)
     elapsed, gather_max = float(el[0].item()), float(el[1].item())
+    items_per_pass_per_rank = [int(-el[3].item()), int(el[2].item())]          # [min, max] over the ranks: the pass every rank really ran in the last timed step
     total_samples = float(px.item()) * spp_step * args.steps
     value = total_samples / elapsed / 1e6
 
@@ -332,22 +410,36 @@ def main():
                                       % (name, args.tris, Wd, Hd, spp_table, spp_step, info["passes"], info["passesInFlight"], TILE, TILE),
                           "samples_per_step": int(float(px.item()) * spp_step), "bvh_nodes": bvh["nNodes"], "bvh_depth": bvh["maxDepth"],
                           "image_mean": round(float(rgb.mean()), 5), "commit": commit,
-                          "first_call_ms": first_call_ms, "first_call": "the first (warm-up) step: beam lists of every pixel (kz_wf_beam, once per pixel and replica), "
-                                                                        "path-state allocation, then the step itself; a timed step is ms_per_step"},
-               "roofline": roofline, "cpu_baseline": cpu}
+                          "items_per_pass_per_rank": items_per_pass_per_rank, "sampler_table_spp": spp_table,
+                          "first_call_ms": first_call_ms, "first_call": "the first (warm-up) step: beam lists of every pixel (kz_wf_beam, once per pixel and replica), the pass context "
+                                                                        "growing (its memory is mapped on a side thread while the first passes run), then the step itself; a timed step is ms_per_step"},
+               "roofline": roofline, "cpu_baseline": cpu, "cold_job": cold}
+    # ---- side jobs. The headline record above is complete: a failure below lands in the sub-record as {"error": ...} and never costs the measurement
+    # (ADVICE r04). A collective side job is entered only when EVERY rank is fit for it, and every step of it checks the ranks' status first.
     if world > 1 and not args.strong and not args.no_strong_c5:
-        # the same launch also carries the strong-scaling job (collective: every rank); this rank's C4 replica makes room first
-        scene.close()
-        sc5 = strong_c5(kz, rank, world, device_index, args.tris, kw, args.strong_spp)
+        # the same launch also carries the strong-scaling job (collective: every rank); this rank's C4 replica goes first - its pass contexts stay in the
+        # device's pool and the C5 replica renders in them
+        try:
+            scene.close()
+            sc5 = strong_c5(kz, rank, world, device_index, args.tris, kw, args.strong_spp)
+        except Exception as e:                                 # noqa: BLE001
+            sc5 = {"error": repr(e)}
+            log("rank %d: strong_c5 failed: %r" % (rank, e))
         if rank == 0:
             out["strong_c5"] = sc5
     if world == 1 and not args.strong and not args.no_asset_scene:
-        out["reference_scene"] = reference_scene(kz, device_index, args.asset_spp)
+        try:
+            out["reference_scene"] = reference_scene(kz, device_index, args.asset_spp)
+        except Exception as e:                                 # noqa: BLE001
+            out["reference_scene"] = {"error": repr(e)}
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                                 # noqa: BLE001 - the record is out
+            log("rank %d: shutdown: %r" % (rank, e))
 
 
 def reference_scene(kz, device_index, spp):
@@ -399,31 +491,58 @@ def strong_c5(kz, rank, world, device_index, tris, kw, spp=256):
         if world > 1:
             dist.barrier()
 
+    def all_fit(ok):
+        """every rank says whether it can go on; a rank that cannot makes every rank bail out instead of leaving the others in the next collective"""
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        if not int(f[0]):
+            raise RuntimeError("strong_c5: a rank failed%s" % ("" if ok else " (this one)"))
+
     def run(dynamic):
         counter = cpath = None
         if dynamic:
             counter, cpath = kz.shard.shared_counter(rank, world)
+        session = kz.shard.open_gather(rank, world)            # (collective, before the clock: the gather itself then needs none in front of the merge)
         sync()
         t = time.perf_counter()
-        if dynamic:
-            took = scene.render_dealt(all_tiles, counter, takers=world, device=device_index, sample_begin=0, sample_end=spp, **kw)
-        else:
-            took = mine
-            scene.render_tiles(mine, device=device_index, sample_begin=0, sample_end=spp, download=False, **kw)
+        err = None
+        took, packed = [], np.zeros(0, np.float32)
+        try:
+            if dynamic:
+                took = scene.render_dealt(all_tiles, counter, takers=world, device=device_index, sample_begin=0, sample_end=spp, **kw)
+            else:
+                took = mine
+                scene.render_tiles(mine, device=device_index, sample_begin=0, sample_end=spp, download=False, **kw)
+        except Exception as e:                                 # noqa: BLE001 - every rank still enters the gather: it carries the failure to all
+            err, took = e, []
         mine_s = time.perf_counter() - t                     # (kz_render_tiles is blocking: this rank's tiles are on its film)
-        sync()
-        render_s = time.perf_counter() - t
-        t = time.perf_counter()
-        packed = scene.film_tiles(took, device=device_index) if took else np.zeros(0, np.float32)
-        film = kz.shard.gather_tiles(scene, took, packed, rank, world)
-        gather_s = time.perf_counter() - t
-        v = torch.tensor([render_s, gather_s, mine_s, -mine_s, float(len(took)), -float(len(took))], dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        info = scene.last_pass_info() if err is None else {"largestPassItems": 0}
+        # the gather starts here, per rank, with no barrier in front of it: rank 0 merges the ranks' rects as they land (shard.gather_tiles), so it overlaps
+        # the tail of the slower ranks' renders; `end_to_end` is the one clock from the common start to the merged frame on rank 0
+        t_g = time.perf_counter()
+        film = None
+        try:
+            if err is None:
+                if took:
+                    packed = scene.film_tiles(took, device=device_index)
+                film = kz.shard.gather_tiles(scene, took, packed, rank, world, session=session)
+            else:                                              # this rank's render failed: a buffer of the wrong size fails the gather on EVERY rank, nobody waits for this one
+                kz.shard.gather_tiles(scene, [(0, 0, 1, 1)], np.zeros(0, np.float32), rank, world, session=session)
+        except Exception as e:                                 # noqa: BLE001
+            err = err or e
+        total_s = time.perf_counter() - t
+        gather_own_s = time.perf_counter() - t_g
         if rank == 0 and cpath:
             os.unlink(cpath)
-        rec = {"value": round(samples / v[0].item() / 1e6, 1), "end_to_end": round(samples / (v[0].item() + v[1].item()) / 1e6, 1), "render_s": round(v[0].item(), 4),
-               "gather_s": round(v[1].item(), 4), "per_rank_ms": [round(-1e3 * v[3].item(), 1), round(1e3 * v[2].item(), 1)], "tiles_per_rank": [int(-v[5].item()), int(v[4].item())]}
+        all_fit(err is None)
+        v = torch.tensor([mine_s, total_s, -mine_s, float(len(took)), -float(len(took)), gather_own_s, float(info["largestPassItems"]), -float(info["largestPassItems"])], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        rec = {"value": round(samples / v[0].item() / 1e6, 1), "end_to_end": round(samples / v[1].item() / 1e6, 1), "render_s": round(v[0].item(), 4),
+               "end_to_end_s": round(v[1].item(), 4), "gather_after_last_render_s": round(v[1].item() - v[0].item(), 4), "gather_s_slowest_rank": round(v[5].item(), 4),
+               "per_rank_ms": [round(-1e3 * v[2].item(), 1), round(1e3 * v[0].item(), 1)], "tiles_per_rank": [int(-v[4].item()), int(v[3].item())],
+               "items_per_pass_per_rank": [int(-v[7].item()), int(v[6].item())]}
         return rec, film
 
     run(False)                                                # warm-up: allocations, beam lists of this rank's tiles, pinned staging, /dev/shm pages

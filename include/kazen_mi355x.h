@@ -288,6 +288,11 @@ typedef struct KzTileDealer {
     uint32_t *taken;            /* out: begin0, end0, begin1, end1, ... */
     uint32_t takenCap;          /* capacity of `taken` in uint32 (2 per batch): a call stops taking batches when it is full */
     uint32_t *nTaken;           /* out: uint32 written to `taken` */
+    volatile uint32_t *agreed;  /* optional (NULL: unchecked): a second word the takers share, zeroed with the counter. The counter only ever advances by the batch
+                                   size, which every taker resolves for itself (batchTiles, or the default from its pass size, sample range and `takers`): takers
+                                   whose options differ would deal overlapping or misaligned batches without an error. The first taker publishes what it resolved
+                                   (batch size and length of the list) in this word; a taker that resolved anything else fails with KZ_ERR_INVALID_ARG before it
+                                   takes a tile. REQUIREMENT either way: all takers of one counter pass the same list, sample range, pass options and `takers`. */
 } KzTileDealer;
 
 typedef struct KzRenderOpts {
@@ -396,6 +401,11 @@ const char *kz_last_error(void);
 int kz_abi_version(void);
 /* HIP devices visible to the process (0 without a GPU: kz_scene_upload then fails with KZ_ERR_NO_DEVICE - there is no CPU path). */
 int kz_device_count(void);
+/* Path-state memory outlives the replica that grew it: kz_scene_evict / kz_scene_destroy hand a replica's pass contexts (up to 3/4 of the device for
+ * one default pass) to a per-device pool, and the next replica uploaded to that device - the next scene of the same process - renders in them at once
+ * instead of waiting for the driver to wipe what its predecessor released. kz_device_trim gives the pooled memory of `device` back to the
+ * driver: for a process that keeps running without rendering. */
+int kz_device_trim(int device);
 
 /* Everything else the library exports - per-replica forms of the calls above, counters and timings, the function-level query kernels and
  * known-answer checks the parity tests use, the names of the development tuning words - is declared in kazen_mi355x_dev.h. */

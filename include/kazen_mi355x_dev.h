@@ -100,14 +100,25 @@ int kz_last_kernel_ms(KzScene *scene, float *ms);
  * rocprofv3 --kernel-trace of the same run shows. */
 int kz_last_stage_ms(KzScene *scene, float *out6);
 
-/* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass, passes in flight. */
+/* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass (the TARGET: a pass context grows while the first passes
+ * of a job already run - firstPassItems / largestPassItems say what the passes of this call really were), passes in flight, bytes of path state mapped. */
 typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes;
-                            uint32_t pixelsPerPass; uint32_t reserved; } KzPassInfo;
+                            uint32_t pixelsPerPass; uint32_t reserved; uint64_t firstPassItems; uint64_t largestPassItems; } KzPassInfo;
 int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
 
 /* Test hook: the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off). Used by
  * the error-path tests to show that a failure in the middle of a call releases what the call had allocated. */
 void kz_debug_fail_alloc(int nth);
+
+/* Test hook: the thread that maps a pass context's memory (kz_arena.cpp) sleeps `ms` milliseconds before every level (0 = off): "the context is still
+ * growing while the first passes of a job run" - what happens behind the driver's wipe of recently released memory - on demand. Process-wide. */
+void kz_debug_grow_delay(int ms);
+
+/* Known answers for the host code of kz_scene_create (no GPU): the area CDF of a light mesh - DiscretePDF::append + normalize, dpdf.h:35-37,77-89 - for n
+ * pdf values (cdf: n + 1 floats; sumAndNormalization: 2 floats), and, for a sample count, { isPowerOf4, roundUpPow4, log4i of that, PMJ02BN's pixel tile }
+ * (common.h:271-319, sampler.cpp:291). tests/golden/int_kats.json holds vectors minted from the reference's own text of both (oracle/kat_ref_dpdf.cpp). */
+int kz_debug_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNormalization);
+int kz_debug_pow4(int32_t spp, int32_t *out4);
 
 /* How the library was built: bit 0 (KZ_BUILD_EXPERIMENTS) = it contains the kernels of kz_experiments.h. */
 #define KZ_BUILD_EXPERIMENTS 1

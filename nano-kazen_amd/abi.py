@@ -105,7 +105,7 @@ class KzTuning(C.Structure):
 
 
 class KzTileDealer(C.Structure):
-    _fields_ = [("counter", u32p), ("batchTiles", C.c_uint32), ("takers", C.c_uint32), ("taken", u32p), ("takenCap", C.c_uint32), ("nTaken", u32p)]
+    _fields_ = [("counter", u32p), ("batchTiles", C.c_uint32), ("takers", C.c_uint32), ("taken", u32p), ("takenCap", C.c_uint32), ("nTaken", u32p), ("agreed", u32p)]
 
 
 class KzRenderOpts(C.Structure):
@@ -117,7 +117,8 @@ class KzRenderOpts(C.Structure):
 
 class KzPassInfo(C.Structure):
     _fields_ = [("passes", C.c_uint32), ("passesInFlight", C.c_uint32), ("itemsPerPass", C.c_uint64), ("sppPerPass", C.c_uint32),
-                ("pixels", C.c_uint32), ("stateBytes", C.c_uint64), ("pixelsPerPass", C.c_uint32), ("reserved", C.c_uint32)]
+                ("pixels", C.c_uint32), ("stateBytes", C.c_uint64), ("pixelsPerPass", C.c_uint32), ("reserved", C.c_uint32),
+                ("firstPassItems", C.c_uint64), ("largestPassItems", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -146,14 +147,14 @@ class KzBvhInfo(C.Structure):
 # every symbol include/kazen_mi355x.h (the product surface, PRODUCT_EXPORTS) and include/kazen_mi355x_dev.h declare (checked by tests/test_abi_cpu.py)
 PRODUCT_EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_upload", "kz_scene_evict", "kz_render", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles",
                    "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb",
-                   "kz_film_to_srgb8", "kz_sync", "kz_last_error", "kz_abi_version", "kz_device_count"]
+                   "kz_film_to_srgb8", "kz_sync", "kz_last_error", "kz_abi_version", "kz_device_count", "kz_device_trim"]
 EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
            "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
            "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8",
            "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
            "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check", "kz_debug_permute", "kz_debug_fresnel", "kz_debug_math", "kz_build_flags",
-           "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles"]
+           "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_device_trim", "kz_debug_grow_delay", "kz_debug_dpdf", "kz_debug_pow4"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KZ_LIB_PATH: a development build of the library (scripts/build_variant.sh) instead of the in-tree one; probes only
@@ -217,6 +218,11 @@ def load_library():
     lib.kz_debug_fail_alloc.argtypes = [C.c_int]
     lib.kz_debug_fail_alloc.restype = None
     lib.kz_device_mem_info.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.kz_device_trim.argtypes = [C.c_int]
+    lib.kz_debug_grow_delay.argtypes = [C.c_int]
+    lib.kz_debug_grow_delay.restype = None
+    lib.kz_debug_dpdf.argtypes = [C.c_uint32, f32p, f32p, f32p]
+    lib.kz_debug_pow4.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
     if hasattr(lib, "kz_debug_math"):
         lib.kz_debug_math.argtypes = [C.c_int, C.c_int, C.c_uint32, f32p, f32p, f32p]
     if hasattr(lib, "kz_debug_fresnel"):

@@ -11,11 +11,19 @@ OUT=${1:-.}
 mkdir -p "$OUT"
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
 DEV="--offload-arch=gfx950 -fgpu-flush-denormals-to-zero -fno-slp-vectorize ${KZ_EXTRA_HIPFLAGS}"
-# the translation units compile side by side (kz_state.h says what lives where)
-for u in kz_render kz_film kz_debug; do hipcc $FLAGS $DEV -c $u.hip -o "$OUT/$u.o" & done
-for u in kz_multi kz_host kz_bvh; do hipcc $FLAGS ${KZ_EXTRA_HIPFLAGS} -c $u.cpp -o "$OUT/$u.o" & done
-wait
-for u in kz_render kz_film kz_debug kz_multi kz_host kz_bvh; do [ -f "$OUT/$u.o" ] || { echo "build failed: $u"; exit 1; }; done
-hipcc -shared -fPIC -o "$OUT/libkazen_mi355x.so" "$OUT/kz_render.o" "$OUT/kz_film.o" "$OUT/kz_debug.o" "$OUT/kz_multi.o" "$OUT/kz_host.o" "$OUT/kz_bvh.o" -pthread
-rm -f "$OUT"/kz_render.o "$OUT"/kz_film.o "$OUT"/kz_debug.o "$OUT"/kz_multi.o "$OUT"/kz_host.o "$OUT"/kz_bvh.o
+# the translation units compile side by side (kz_state.h says what lives where); every job's exit status is checked and no object of an earlier
+# build can stand in for one that failed to compile now
+DEVICE_UNITS="kz_render kz_film kz_debug"
+HOST_UNITS="kz_multi kz_host kz_bvh kz_arena"
+for u in $DEVICE_UNITS $HOST_UNITS; do rm -f "$OUT/$u.o"; done
+PIDS=""
+for u in $DEVICE_UNITS; do hipcc $FLAGS $DEV -c $u.hip -o "$OUT/$u.o" & PIDS="$PIDS $!"; done
+for u in $HOST_UNITS; do hipcc $FLAGS ${KZ_EXTRA_HIPFLAGS} -c $u.cpp -o "$OUT/$u.o" & PIDS="$PIDS $!"; done
+FAILED=0
+for p in $PIDS; do wait $p || FAILED=1; done
+[ $FAILED -eq 0 ] || { echo "build failed: a translation unit did not compile"; exit 1; }
+OBJS=""
+for u in $DEVICE_UNITS $HOST_UNITS; do [ -f "$OUT/$u.o" ] || { echo "build failed: $u"; exit 1; }; OBJS="$OBJS $OUT/$u.o"; done
+hipcc -shared -fPIC -o "$OUT/libkazen_mi355x.so" $OBJS -pthread
+rm -f $OBJS
 echo "built $(cd "$OUT" && pwd)/libkazen_mi355x.so"

@@ -1,15 +1,19 @@
-// kz_arena.cpp - the path-state memory of a pass context: ONE reserved virtual range per context, physical memory mapped into it level by level
-// on a side thread while the passes already run on what is there (host code only).
+// kz_arena.cpp - the path-state memory of a pass context (host code only). A context that holds more than 2^23 items lives in reserved virtual
+// ranges - one per array - into which a side thread maps physical memory level by level while the passes already run on what is there.
 //
 // Why (round 5, profiles/r05a_alloc): a hipMalloc of the 13 state arrays of a 2^30-item pass (175 GB) took anything between 6 ms and 5.8 s. The cost is
 // not the allocation - a GB of CLEAN memory maps in ~15 us whether it comes from hipMalloc or hipMemCreate, 176 GB in 10 ms - it is the driver's
 // asynchronous wipe of memory some process (this one or the one before it) has just released (~33 GB/s): an allocation that needs more than what is
 // clean at that moment blocks in ONE call until the wipe has got far enough. A renderer cannot know how much is clean. So the context is not allocated,
 // it GROWS: the virtual ranges of its arrays are reserved for the largest pass (reserving is free), a side thread maps physical chunks into all of them
-// level by level (hipMemCreate + hipMemMap + hipMemSetAccess; a level = the same item range of every array), and the pass schedule (kz_render.hip)
+// level by level (hipMemCreate + hipMemMap + hipMemSetAccess; a level = the same 2^23 items of every array), and the pass schedule (kz_render.hip)
 // sizes each pass by what is mapped at that moment. On clean memory the context is at full size before the first pass has been planned; behind a wipe
 // the first passes are small and the job is under way while the stall is served on the side thread. Memory mapped this way is as fast as hipMalloc
 // memory (copy 5.3 vs 4.8 TB/s, random 16-B gathers 48.5 vs 49.1 G/s over 32 GB: profiles/r05a_alloc/alloc_grow.json).
+// All chunks of one array have ONE size: on this ROCm (7.2) hipMemSetAccess answers "invalid argument" for some sequences of chunks of different sizes
+// in one reservation (scripts/micro/vmm_probe.hip -> profiles/r05a_alloc/vmm_probe.json: 4 MB behind 16 MB, 256 KB behind 4 MB), while thousands of equal
+// chunks map, unmap and map again without a fault (alloc_grow.hip). Contexts of up to 2^23 items (1.5 GB: every C1 / C2-sized job, every call under a
+// tight maxStateBytes) are plain hipMalloc arrays of exactly the size asked for - allocations of that size never waited in any measurement.
 // Contexts outlive the replica that grew them: releaseReplica hands them to a per-device pool, the next replica on that device takes them from there
 // (a process that renders scene after scene - the reference's 22 parameter pictures - would otherwise release 175 GB per scene and wait for its own wipe).
 #include "kz_state.h"
@@ -18,13 +22,18 @@
 #include <chrono>
 #include <cstring>
 
-static constexpr size_t KZ_ARENA_ALIGN_ITEMS = (size_t)1 << 20;      // levels and capacities are multiples of this: every array's chunk is a multiple of 4 MB
-static constexpr size_t KZ_ARENA_MAX_LEVEL_ITEMS = (size_t)1 << 25;  // a level maps at most this many items of every array (512 MB chunks for the float4 arrays)
+static constexpr size_t KZ_ARENA_SMALL_ALIGN = (size_t)1 << 12;      // small contexts: arrays of a multiple of 4096 items
+static constexpr size_t KZ_ARENA_RESERVE_ALIGN = (size_t)1 << 23;    // virtual capacities are whole levels
 
-static size_t roundUpItems(size_t n) { return (n + KZ_ARENA_ALIGN_ITEMS - 1) / KZ_ARENA_ALIGN_ITEMS * KZ_ARENA_ALIGN_ITEMS; }
+// kz_debug_grow_delay (kazen_mi355x_dev.h): the growth thread sleeps this long before every level - a test hook that makes "the context is still growing
+// while the passes run" happen on demand (on a quiet device the memory is there before the first pass is planned)
+static std::atomic<int> g_growDelayMs{0};
+extern "C" void kz_debug_grow_delay(int ms) { g_growDelayMs.store(ms > 0 ? ms : 0); }
+
+static size_t roundUp(size_t n, size_t a) { return (n + a - 1) / a * a; }
 
 KzArena::KzArena(int dev) : device(dev) {
-    // element sizes in the order the pass launcher reads them (kz_render.hip: wfPass): 8 float4 fields, the sampler record, 3 queues, 5 sample planes
+    // element sizes in the order the pass launcher reads them (kz_render.hip: ctxEnsure): 8 float4 fields, the sampler record, 3 queues, 5 sample planes
     const size_t e[kArrays] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 4, 4, 4, 4, 4, 4, 4, 4};
     std::memcpy(elem, e, sizeof e);
     std::memset(base, 0, sizeof base);
@@ -39,10 +48,10 @@ void KzArena::stopThread() {
     { std::lock_guard<std::mutex> g(m); stop = true; }
     cvWork.notify_all();
     th.join();
-    stop = false;
+    stop = false; busy = false;
 }
 
-// Unmaps and releases every level from `keepLevels` on. The caller has made sure that nothing on the device uses them.
+// Unmaps and releases every level from `keepLevels` on. The caller has made sure that nothing on the device uses them and that the growth thread is parked.
 void KzArena::dropLevels(size_t keepLevels) {
     while (levels.size() > keepLevels) {
         Level &L = levels.back();
@@ -52,38 +61,76 @@ void KzArena::dropLevels(size_t keepLevels) {
         }
         levels.pop_back();
     }
-    size_t mp = 0;
-    for (const Level &L : levels) mp = L.firstItem + L.items;
-    mapped.store(mp);
+    mapped.store(levels.empty() ? 0 : levels.back().firstItem + levels.back().items);
+}
+
+void KzArena::freeSmall() {
+    if (!smallItems) return;
+    for (int a = 0; a < kArrays; ++a) { if (base[a]) (void)hipFree(base[a]); base[a] = nullptr; }
+    smallItems = 0; mapped.store(0);
 }
 
 void KzArena::releaseAll() {
     stopThread();
     (void)hipSetDevice(device);
+    freeSmall();
     dropLevels(0);
-    if (va) { (void)hipMemAddressFree(va, vaBytes); va = nullptr; vaBytes = 0; }
-    capItems = 0; target = 0; err = 0; errMsg.clear();
+    for (int a = 0; a < kArrays; ++a) if (base[a]) { (void)hipMemAddressFree(base[a], capItems * elem[a]); base[a] = nullptr; }
+    capItems = 0; target = 0; err = 0; errMsg.clear(); growthFailed = false;
+}
+
+// True when serving `items` would free or re-reserve what the context holds now: the caller then waits for the device first.
+bool KzArena::wouldReallocate(size_t items) const {
+    if (items <= kSmallMax && !capItems) return smallItems > 0 && roundUp(items, KZ_ARENA_SMALL_ALIGN) > smallItems;
+    return smallItems > 0 || (capItems > 0 && items > capItems);
+}
+
+// hipMalloc arrays of exactly roundUp(items, 4096) items (a context of at most 2^23 items that has never been larger).
+int KzArena::requestSmall(size_t items, size_t *got) {
+    items = roundUp(items, KZ_ARENA_SMALL_ALIGN);
+    if (items > smallItems) {
+        freeSmall();
+        for (int a = 0; a < kArrays; ++a) {
+            void *p = nullptr;
+            int fc = failCountdown.load();
+            hipError_t e = (fc > 0 && failCountdown.compare_exchange_strong(fc, fc - 1) && fc == 1) ? hipErrorOutOfMemory : hipMalloc(&p, items * elem[a]);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                for (int b = 0; b < a; ++b) { (void)hipFree(base[b]); base[b] = nullptr; }
+                return kz_fail(e == hipErrorOutOfMemory ? KZ_ERR_OOM : KZ_ERR_HIP, "device allocation of %zu bytes of path state failed: %s", items * elem[a], hipGetErrorString(e));
+            }
+            base[a] = (char *)p;
+        }
+        smallItems = items; mapped.store(items);
+    }
+    *got = smallItems;
+    return KZ_OK;
 }
 
 // Reserves the virtual ranges for `cap` items (everything mapped so far is given up when the reservation has to grow: rare - the default
 // reservation covers the largest default pass).
 int KzArena::reserve(size_t cap) {
-    cap = roundUpItems(std::max<size_t>(cap, KZ_ARENA_ALIGN_ITEMS));
+    cap = roundUp(std::max<size_t>(cap, kLevelItems), KZ_ARENA_RESERVE_ALIGN);
     if (cap <= capItems) return KZ_OK;
     releaseAll();
     HIP_TRY(hipSetDevice(device));
-    const size_t bytes = cap * bytesPerItem();
-    void *p = nullptr;
-    hipError_t e = hipMemAddressReserve(&p, bytes, (size_t)2 << 20, nullptr, 0);
-    if (e != hipSuccess) return kz_fail(KZ_ERR_HIP, "hipMemAddressReserve of %zu bytes of virtual address space failed: %s", bytes, hipGetErrorString(e));
-    va = (char *)p; vaBytes = bytes; capItems = cap;
-    size_t off = 0;
-    for (int a = 0; a < kArrays; ++a) { base[a] = va + off; off += cap * elem[a]; }
+    // one range per array: the chunks of an array are mapped one behind the other from the start of ITS reservation, all of one size
+    for (int a = 0; a < kArrays; ++a) {
+        void *p = nullptr;
+        hipError_t e = hipMemAddressReserve(&p, cap * elem[a], (size_t)2 << 20, nullptr, 0);
+        if (e != hipSuccess) {
+            for (int b = 0; b < a; ++b) { (void)hipMemAddressFree(base[b], cap * elem[b]); base[b] = nullptr; }
+            return kz_fail(KZ_ERR_HIP, "hipMemAddressReserve of %zu bytes of virtual address space failed: %s", cap * elem[a], hipGetErrorString(e));
+        }
+        base[a] = (char *)p;
+    }
+    capItems = cap;
     return KZ_OK;
 }
 
-// One level: the item range [first, first + items) of every array. Runs on the growth thread.
-bool KzArena::growOneLevel(size_t first, size_t items) {
+// One level: the item range [first, first + kLevelItems) of every array. Runs on the growth thread.
+bool KzArena::growOneLevel(size_t first) {
+    const size_t items = kLevelItems;
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
     hipMemAccessDesc ad{};
@@ -106,9 +153,10 @@ bool KzArena::growOneLevel(size_t first, size_t items) {
         std::lock_guard<std::mutex> g(m);
         err = e == hipErrorOutOfMemory ? KZ_ERR_OOM : KZ_ERR_HIP;
         char buf[256];
-        std::snprintf(buf, sizeof buf, "%s of a path-state level (%zu items, %zu bytes over %d arrays) failed: %s", what, items, items * bytesPerItem(), kArrays, hipGetErrorString(e));
+        std::snprintf(buf, sizeof buf, "%s of a path-state level (items %zu .. %zu, %zu bytes over %d arrays) failed: %s", what, first, first + items, items * bytesPerItem(), kArrays, hipGetErrorString(e));
         errMsg = buf;
-        target = mapped.load();                                   // stop growing: the passes keep what there is
+        target = mapped.load();                                   // stop growing: the passes keep what there is, and nobody asks again until the context
+        growthFailed = true;                                      // has been shrunk or released (a retry per pass would cost every pass a failed attempt)
         return false;
     }
     std::lock_guard<std::mutex> g(m);
@@ -121,7 +169,7 @@ bool KzArena::growOneLevel(size_t first, size_t items) {
 void KzArena::growLoop() {
     (void)hipSetDevice(device);
     for (;;) {
-        size_t first, items;
+        size_t first;
         {
             std::unique_lock<std::mutex> lk(m);
             busy = false;
@@ -130,25 +178,29 @@ void KzArena::growLoop() {
             if (stop) return;
             busy = true;
             first = mapped.load();
-            // levels double from 2^20 items up to 2^25, so that a small job maps a small context and a large one needs few chunks
-            items = std::min({std::max(first, KZ_ARENA_ALIGN_ITEMS), KZ_ARENA_MAX_LEVEL_ITEMS, roundUpItems(target - first), capItems - first});
         }
-        (void)growOneLevel(first, items);
+        if (const int d = g_growDelayMs.load()) std::this_thread::sleep_for(std::chrono::milliseconds(d));
+        (void)growOneLevel(first);
         cvProgress.notify_all();
     }
 }
 
-// Asks for `items` items (the growth thread maps level after level until they are there) and waits
+// Asks for `items` items and tells how many there are (*got; whole levels, possibly more than asked for).
+//   up to 2^23 items, for a context that has never been larger: hipMalloc arrays of that size, at once;
+//   otherwise the growth thread maps level after level until they are there, and the call waits
 //   - until at least `minItems` are mapped (or growing has failed), and then
-//   - while the thread keeps making progress towards `items`: a level on clean memory takes ~0.3 ms, so on a fresh device the whole context is there
-//     after a few milliseconds; the wait ends as soon as a level takes longer than `graceMs` (the driver is wiping: go on with what there is) or the
-//     context is complete. graceMs < 0: wait for all of it.
-// Returns the items mapped; an error only when fewer than minItems can be had.
+//   - while the thread keeps making progress towards `items`: a level on clean memory takes well under a millisecond, so on a quiet device the whole
+//     context is there after a few milliseconds; the wait ends as soon as a level takes longer than `graceMs` (the driver is wiping: go on with what
+//     there is) or the context is complete. graceMs < 0: wait for all of it.
+// An error only when fewer than minItems can be had. The caller has waited for the device if wouldReallocate(items).
 int KzArena::request(size_t items, size_t minItems, double graceMs, size_t *got) {
-    items = std::min(roundUpItems(items), capItems);
+    if (items <= kSmallMax && !capItems) return requestSmall(items, got);
+    if (smallItems) freeSmall();
+    if (items > capItems) { const int rc = reserve(std::max<size_t>(items, (size_t)1 << 30)); if (rc) return rc; }
+    items = std::min(roundUp(items, kLevelItems), capItems);
     minItems = std::min(minItems, items);
     std::unique_lock<std::mutex> lk(m);
-    if (items > target) { target = items; err = 0; errMsg.clear(); }
+    if (items > target && !growthFailed) target = items;
     if (mapped.load() < target) {
         if (!th.joinable()) { lastProgress = std::chrono::steady_clock::now(); busy = true; th = std::thread([this] { growLoop(); }); }
         else { busy = true; cvWork.notify_all(); }
@@ -156,7 +208,7 @@ int KzArena::request(size_t items, size_t minItems, double graceMs, size_t *got)
     for (;;) {
         const size_t mp = mapped.load();
         if (mp >= items || (!busy && mp >= target)) break;                                    // complete, or growing has stopped (failure)
-        if (mp >= minItems && graceMs >= 0) {
+        if (mp >= minItems && mp > 0 && graceMs >= 0) {
             const double idle = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lastProgress).count();
             if (idle > graceMs) break;
             cvProgress.wait_for(lk, std::chrono::microseconds((long)((graceMs - idle) * 1000.0) + 50));
@@ -173,17 +225,19 @@ int KzArena::request(size_t items, size_t minItems, double graceMs, size_t *got)
 
 // Gives back everything beyond `items` (the caller has synchronised the device).
 void KzArena::shrinkTo(size_t items) {
+    if (smallItems) { if (items == 0) freeSmall(); return; }
+    if (!capItems) return;
     {
         std::unique_lock<std::mutex> lk(m);
-        target = std::min(target, roundUpItems(items));
+        target = std::min(target, roundUp(items, kLevelItems));
         cvProgress.wait(lk, [&] { return !busy || !th.joinable(); });          // the growth thread parks when mapped >= target
     }
     (void)hipSetDevice(device);
-    size_t keep = 0;
-    while (keep < levels.size() && levels[keep].firstItem < items) ++keep;
+    const size_t keep = std::min(levels.size(), (items + kLevelItems - 1) / kLevelItems);
     std::lock_guard<std::mutex> g(m);
     dropLevels(keep);
     target = std::min(target, mapped.load());
+    growthFailed = false; err = 0; errMsg.clear();
 }
 
 // ---- the per-device pool of pass contexts ----

@@ -34,6 +34,19 @@ bool isPowerOf4(int n) {
 int log2i(uint32_t v) { return 31 - __builtin_clz(v); }
 int log4i(uint32_t v) { return log2i(v) / 2; }
 int roundUpPow4(int v) { return isPowerOf4(v) ? v : (1 << (2 * (1 + log4i((uint32_t)v)))); }
+// PMJ02BN's pixel tile (sampler.cpp:291)
+int pmjPixelTile(uint32_t spp) { return 1 << (log4i(KZ_PMJ02BN_SAMPLES) - log4i((uint32_t)roundUpPow4((int)spp))); }
+// DiscretePDF::normalize (dpdf.h:77-89) on the table that starts at cdf[base] (cdf[base] = 0, then the running sums of append, dpdf.h:35-37):
+// multiplies by the reciprocal of the sum and FORCES the last entry to 1; a table that sums to 0 is left as it is. Returns the normalisation.
+float dpdfNormalize(std::vector<float> &cdf, size_t base, float *sumOut) {
+    const float sum = cdf.back();
+    if (sumOut) *sumOut = sum;
+    if (!(sum > 0)) return 0.0f;
+    const float normalization = 1.0f / sum;
+    for (size_t i = base + 1; i < cdf.size(); ++i) cdf[i] *= normalization;
+    cdf.back() = 1.0f;
+    return normalization;
+}
 
 void mat4mul(const double *a, const double *b, double *c) {
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
@@ -150,6 +163,22 @@ extern "C" {
 
 const char *kz_last_error(void) { return g_err; }
 int kz_abi_version(void) { return KZ_ABI_VERSION; }
+
+// (kazen_mi355x_dev.h) the host code of kz_scene_create behind a light's area CDF and behind PMJ02BN's pixel tile, for the vectors minted from the
+// reference's own dpdf.h / common.h (oracle/kat_ref_dpdf.cpp)
+int kz_debug_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNormalization) {
+    if ((n && !values) || !cdf || !sumAndNormalization) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
+    std::vector<float> t(1, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) t.push_back(t.back() + values[i]);
+    sumAndNormalization[1] = dpdfNormalize(t, 0, &sumAndNormalization[0]);
+    std::memcpy(cdf, t.data(), t.size() * sizeof(float));
+    return KZ_OK;
+}
+int kz_debug_pow4(int32_t spp, int32_t *out4) {
+    if (spp < 1 || !out4) return kz_fail(KZ_ERR_INVALID_ARG, "kz_debug_pow4(%d)", spp);
+    out4[0] = isPowerOf4(spp) ? 1 : 0; out4[1] = roundUpPow4(spp); out4[2] = log4i((uint32_t)out4[1]); out4[3] = pmjPixelTile((uint32_t)spp);
+    return KZ_OK;
+}
 int kz_build_flags(void) {
 #ifdef KZ_EXPERIMENTS
     return KZ_BUILD_EXPERIMENTS;
@@ -266,12 +295,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
                 float area = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);          // mesh.cpp:47-53
                 sc->cdf.push_back(sc->cdf.back() + area);
             }
-            float sum = sc->cdf.back();
-            if (sum > 0) {
-                lr.normalization = 1.0f / sum;
-                for (size_t i = base + 1; i < sc->cdf.size(); ++i) sc->cdf[i] *= lr.normalization;
-                sc->cdf.back() = 1.0f;
-            } else lr.normalization = 0.0f;
+            lr.normalization = dpdfNormalize(sc->cdf, base, nullptr);
             row.light = (int32_t)sc->lightRows.size();
             sc->lightRows.push_back(lr);
         }
@@ -425,7 +449,7 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
         for (size_t i = 0; i < nBn; ++i) sc->bn[i] = (float)d->sampler.blueNoise[i] / 65535.f;
         // PMJ02BN constructor: sort set 0 into a tile x tile x spp pixel table (sampler.cpp:291-309)
         uint32_t spp = p.sampleCount;
-        int tile = 1 << (log4i(KZ_PMJ02BN_SAMPLES) - log4i((uint32_t)roundUpPow4((int)spp)));
+        int tile = pmjPixelTile(spp);
         p.pixelTileSize = tile;
         sc->pixelSamples.assign((size_t)tile * tile * spp * 2, 0.f);
         std::vector<uint32_t> nStored((size_t)tile * tile, 0);

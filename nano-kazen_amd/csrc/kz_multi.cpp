@@ -121,7 +121,7 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
     // on a shared counter. Every device prepares the frame's whole tile list as its tile set once and takes batches of it - about two passes' worth of
     // (pixel, sample) items each - whenever one of its pass contexts comes free; its passes stay in flight across batch boundaries (no per-batch
     // synchronisation, tile-set change or beam rebuild), and a slow device simply comes back to the counter less often.
-    volatile uint32_t nextTile = 0;
+    volatile uint32_t nextTile = 0, agreedWord = 0;
     // one host thread per device (renderer.cpp:94-127 runs one TBB task per block; here a task is a GPU's share of the tiles)
     std::vector<std::thread> threads;
     for (uint32_t i = 0; i < nDevices; ++i) {
@@ -135,7 +135,7 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
                 std::vector<uint32_t> taken(2 * (size_t)nAll + 2);
                 uint32_t nTaken = 0;
                 KzTileDealer dl{};
-                dl.counter = &nextTile; dl.batchTiles = 0; dl.takers = nDevices; dl.taken = taken.data(); dl.takenCap = (uint32_t)taken.size(); dl.nTaken = &nTaken;
+                dl.counter = &nextTile; dl.batchTiles = 0; dl.takers = nDevices; dl.taken = taken.data(); dl.takenCap = (uint32_t)taken.size(); dl.nTaken = &nTaken; dl.agreed = &agreedWord;
                 o.dealer = &dl;
                 j.rc = kz_render_tiles(scene, &o, all.data(), nAll, devices[i], nullptr, 0);
                 for (uint32_t k = 0; !j.rc && k + 1 < nTaken; k += 2) j.tiles.insert(j.tiles.end(), all.begin() + taken[k], all.begin() + taken[k + 1]);

@@ -99,7 +99,7 @@ static void releaseReplica(KzDeviceState *ds) {
     if (ds->evTiles) (void)hipEventDestroy(ds->evTiles);
     if (ds->evBeam) (void)hipEventDestroy(ds->evBeam);
     if (ds->packHost) (void)hipHostFree(ds->packHost);
-    for (auto &c : ds->ctx) { c.release(); for (auto &e : c.stageEv) (void)hipEventDestroy(e); }
+    for (PassCtx *&c : ds->ctx) if (c) { kzCtxRelease(ds->device, c); c = nullptr; }      // (the device is idle: the contexts go back to its pool, memory and all)
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipStream_t st : ds->passStream) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : ds->evFilm) if (e) (void)hipEventDestroy(e);
@@ -381,8 +381,10 @@ static constexpr size_t KZ_STATE_BYTES_PER_ITEM = 8 * sizeof(float4) + sizeof(ui
 static constexpr size_t KZ_SAMPLE_BYTES_PER_ITEM = 5 * sizeof(float);
 static constexpr size_t KZ_TAP_BYTES_PER_PIXEL = (size_t)KZ_TAPS_MAX * KZ_TAPS_MAX * sizeof(float4);
 
-// ---- buffers of one pass context: sized for `need` items of `nPix` pixels; nothing is left half-allocated on failure ----
-static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool tapSums, hipStream_t stream) {
+// ---- buffers of one pass context. The path-state arrays and the sample planes live in the context's arena (kz_arena.cpp), which GROWS on a side
+// thread: `want` items are asked for, the call returns as soon as `minItems` are there and the arena has stopped making quick progress (graceMs; < 0: wait
+// for everything), and tells how many items a pass may use now (*usable, never more than `want`). Nothing is left half-allocated on failure. ----
+static int ctxEnsure(PassCtx &c, size_t want, size_t minItems, double graceMs, size_t nPix, bool tapSums, hipStream_t stream, size_t *usable) {
     if (tapSums && nPix > c.tapsCap) {                               // (only the tap-sum film path has this buffer)
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.taps) (void)hipFree(c.taps);
@@ -390,32 +392,26 @@ static int ctxEnsure(PassCtx &c, size_t need, size_t nPix, bool wavefront, bool 
         KZ_ALLOC(&c.taps, nPix * KZ_TAP_BYTES_PER_PIXEL);
         c.tapsCap = nPix;
     }
-    if (need > c.sampCap) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (c.samp) (void)hipFree(c.samp);
-        c.samp = nullptr; c.sampCap = 0;
-        KZ_ALLOC(&c.samp, need * KZ_SAMPLE_BYTES_PER_ITEM);
-        c.sampCap = need;
+    if (!c.counts) { KZ_ALLOC(&c.counts, 8 * 520 * sizeof(uint32_t)); }
+    KzArena &A = *c.arena;
+    if (A.wouldReallocate(want)) HIP_TRY(hipDeviceSynchronize());      // (a small context outgrown, or a pass beyond the reserved ranges: what is there is given up first)
+    A.failCountdown.store(g_failAlloc); g_failAlloc = 0;             // (kz_debug_fail_alloc counts the arena's physical allocations as this thread's)
+    size_t got = 0;
+    const int rc = A.request(want, minItems, graceMs, &got);
+    g_failAlloc = A.failCountdown.exchange(0);
+    if (rc) return rc;
+    KzWf W{};
+    if (KZ_STATE_AOS) {                                             // (development build: two 64-B records per slot laid over arrays 0-3 and 4-7 - not supported by the arena's SoA ranges)
+        return kz_fail(KZ_ERR_UNSUPPORTED, "-DKZ_STATE_AOS=1 predates the growing pass context (round 5): build a revision before it to repeat profiles/r03h_state_layout");
     }
-    if (wavefront && (need > c.wfCap || c.wfAllocs.empty())) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (void *p : c.wfAllocs) (void)hipFree(p);
-        c.wfAllocs.clear(); c.wfCap = 0; c.wf = KzWf{};
-        KzWf W{};
-        auto alloc = [&](void **p, size_t bytes) -> int { KZ_ALLOC(p, bytes); c.wfAllocs.push_back(*p); return KZ_OK; };
-        int rc = KZ_OK;
-        if (KZ_STATE_AOS) {                                             // two 64-B records per slot: (rayA rayB hit thr) and (shA shB shL misc)
-            float4 *rec[2] = {nullptr, nullptr};
-            for (int k = 0; k < 2; ++k) if (!rc) rc = alloc((void **)&rec[k], need * 4 * sizeof(float4));
-            if (!rc) { W.rayA.p = rec[0]; W.rayB.p = rec[0] + 1; W.hit.p = rec[0] + 2; W.thr.p = rec[0] + 3; W.shA.p = rec[1]; W.shB.p = rec[1] + 1; W.shL.p = rec[1] + 2; W.misc.p = rec[1] + 3; }
-        } else
-            for (KzField<float4> *f : {&W.rayA, &W.rayB, &W.hit, &W.thr, &W.misc, &W.shA, &W.shB, &W.shL}) if (!rc) rc = alloc((void **)&f->p, need * sizeof(float4));
-        if (!rc) rc = alloc((void **)&W.smp, need * sizeof(uint4));
-        for (int q = 0; q < 3; ++q) if (!rc) rc = alloc((void **)&W.queue[q], need * sizeof(uint32_t));
-        if (!rc) rc = alloc((void **)&W.counts, 8 * 520 * sizeof(uint32_t));
-        if (rc) { for (void *p : c.wfAllocs) (void)hipFree(p); c.wfAllocs.clear(); return rc; }
-        c.wf = W; c.wfCap = need;
-    }
+    W.rayA.p = A.array<float4>(0); W.rayB.p = A.array<float4>(1); W.hit.p = A.array<float4>(2); W.thr.p = A.array<float4>(3);
+    W.misc.p = A.array<float4>(4); W.shA.p = A.array<float4>(5); W.shB.p = A.array<float4>(6); W.shL.p = A.array<float4>(7);
+    W.smp = A.array<uint4>(8);
+    for (int q = 0; q < 3; ++q) W.queue[q] = A.array<uint32_t>(9 + q);
+    W.counts = c.counts;
+    c.wf = W;
+    for (int k = 0; k < 5; ++k) c.plane[k] = A.array<float>(12 + k);
+    *usable = std::min(got, want);
     return KZ_OK;
 }
 
@@ -567,7 +563,7 @@ static int ensureBeams(KzScene *scene, KzDeviceState *ds, hipStream_t stream, ui
 static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune, bool beams) {
     const KzParams &P = scene->prm;
     KzWf W = c.wf;
-    W.outJx = c.samp; W.outJy = c.samp + c.sampCap; W.outR = c.samp + 2 * c.sampCap; W.outG = c.samp + 3 * c.sampCap; W.outB = c.samp + 4 * c.sampCap; W.stats = ds->stats;
+    W.outJx = c.plane[0]; W.outJy = c.plane[1]; W.outR = c.plane[2]; W.outG = c.plane[3]; W.outB = c.plane[4]; W.stats = ds->stats;
     const bool st = ds->statsOn;
     const dim3 blk(KZ_BLOCK);
     // shade: the lean variant runs 4 workgroups per CU at once (its launch bounds), so the default grid is exactly those, each looping over
@@ -748,7 +744,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     size_t limit = opts->maxStateBytes;
     if (!limit) {
         size_t freeB = 0, totalB = 0;
-        const size_t held = ds->ctxBytes();          // (the beam lists - one per frame pixel, 264 B each - are the replica's, not part of this budget)
+        const size_t held = ds->ctxBytes() + kzCtxPoolBytes(ds->device);          // what this replica's contexts and the device's idle pooled contexts hold (the beam lists - one per frame pixel, 264 B each - are the replica's, not part of this budget)
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) limit = std::min(totalB / 4 * 3, freeB + held - std::min(freeB + held, (size_t)256 << 20));
         else limit = (size_t)32 << 30;
     }
@@ -769,26 +765,36 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         batchTiles = dealer->batchTiles ? dealer->batchTiles
                    : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(2 * (uint64_t)wantItems / std::max<uint64_t>(1, maxTile * nSamples), std::max<uint32_t>(1, nTilesSet / (4 * std::max<uint32_t>(1, dealer->takers)))));
         if (dealer->nTaken) *dealer->nTaken = 0;
+        if (dealer->agreed) {                                // the takers of one counter must have resolved the same batch size for the same list
+            const uint32_t mine = ((batchTiles * 0x9E3779B1u) ^ (nTilesSet * 0x85EBCA6Bu)) | 1u;
+            uint32_t seen = 0;
+            if (!__atomic_compare_exchange_n((uint32_t *)dealer->agreed, &seen, mine, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) && seen != mine)
+                return kz_fail(KZ_ERR_INVALID_ARG, "KzTileDealer: this taker resolved batches of %u tiles of a list of %u, another taker of the same counter resolved something else "
+                                                   "(all takers must pass the same tile list, sample range, pass options and `takers`)", batchTiles, nTilesSet);
+        }
     }
     uint32_t nPixSet = ds->nPix;
     if (dealer) {                                            // (batches start at multiples of batchTiles: the counter only ever advances by that)
         nPixSet = 1;
         for (uint32_t tb = 0; tb < nTilesSet; tb += batchTiles) nPixSet = std::max(nPixSet, ds->tilePixOffset[std::min(nTilesSet, tb + batchTiles)] - ds->tilePixOffset[tb]);
     }
-    uint32_t S, pixPerPass;
-    if (opts->tune.sppPerPass > 0) { S = std::min<uint32_t>((uint32_t)opts->tune.sppPerPass, nSamples); pixPerPass = (uint32_t)std::min<size_t>(nPixSet, std::max<size_t>(64, wantItems / S / 64 * 64)); }
-    else {
-        pixPerPass = nPixSet; S = (uint32_t)std::min<size_t>(std::max<size_t>(1, wantItems / std::max<uint32_t>(1, nPixSet)), nSamples);
+    // the shape of a pass of `want` items over `nPixRange` pixels: sample count s, pixel count px
+    auto shapeFor = [&](size_t want, uint32_t nPixRange, uint32_t &s, uint32_t &px) {
+        want = std::max<size_t>(want, 64);
+        if (opts->tune.sppPerPass > 0) { s = std::min<uint32_t>((uint32_t)opts->tune.sppPerPass, nSamples); px = (uint32_t)std::min<size_t>(nPixRange, std::max<size_t>(64, want / s / 64 * 64)); return; }
+        px = nPixRange; s = (uint32_t)std::min<size_t>(std::max<size_t>(1, want / std::max<uint32_t>(1, nPixRange)), nSamples);
         // A frame too large for 64 samples of every pixel per pass (C5 on one GPU: 16) is rendered in pixel chunks of 256 samples instead: a wave of the
         // camera-ray kernels is then one pixel again (one shared list), the film stage touches a chunk per pass instead of the whole frame, and the paths of a pass
         // stay in a part of the scene (C5, same call: 1 586 Msamples/s at 16 x all pixels, 1 708 at 64 x 2 M, 1 734 at 256 x 512 K).
         // (round 4, default pass size 2^30: C5 at 128 x all 8.3 M pixels 1 865 Msamples/s, at 256 x 4.2 M pixels 1 890: the chunks are taken below 256 samples then)
         const uint32_t chunkBelow = autoShape ? 256u : 64u;
-        if (S < chunkBelow && nSamples >= chunkBelow) { S = std::min<uint32_t>(256u, nSamples); pixPerPass = (uint32_t)std::min<size_t>(nPixSet, std::max<size_t>(64, wantItems / S / 64 * 64)); }
+        if (s < chunkBelow && nSamples >= chunkBelow) { s = std::min<uint32_t>(256u, nSamples); px = (uint32_t)std::min<size_t>(nPixRange, std::max<size_t>(64, want / s / 64 * 64)); }
         // a multiple of 64 samples per pixel keeps every wave of the camera-ray kernels inside one pixel (one shared leaf list) - taken when it costs no extra pass
         // (a rank's share of a frame: 2^27 / 1 036 800 pixels = 129 -> 128)
-        else if (S > 64 && S % 64 && (nSamples + S / 64 * 64 - 1) / (S / 64 * 64) == (nSamples + S - 1) / S) S = S / 64 * 64;
-    }
+        else if (s > 64 && s % 64 && (nSamples + s / 64 * 64 - 1) / (s / 64 * 64) == (nSamples + s - 1) / s) s = s / 64 * 64;
+    };
+    uint32_t S, pixPerPass;
+    shapeFor(wantItems, nPixSet, S, pixPerPass);
     // the largest pass of the wanted shape that fits `room` bytes: fewer samples first, then (from one sample) fewer pixels
     auto shape = [&](size_t room, uint32_t &s, uint32_t &px) {
         s = S; px = pixPerPass;
@@ -815,11 +821,18 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     // film, whose read-modify-write kernel is chained with events in pass order.
     const bool multi = pipeline == 2 && nPasses >= 2 && nCtx >= 2;
     if (!multi) nCtx = 1;
-    {   // contexts this call does not use are released when their memory is needed
+    {   // memory this call does not use is given back when the call needs it: contexts beyond nCtx, what the device's pool holds idle, and - under a
+        // limit below what an earlier call grew them to - the tails of the contexts it does use
+        const size_t perCtx = need * perItem + pixPerPass * perPixel;
         size_t keep = 0;
-        for (int i = 0; i < nCtx; ++i) keep += std::max(ds->ctx[i].bytes(), need * perItem + pixPerPass * perPixel);
-        for (int i = KZ_MAX_PASSES_IN_FLIGHT - 1; i >= nCtx; --i)
-            if (ds->ctx[i].bytes() && keep + ds->ctx[i].bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i].release(); } else keep += ds->ctx[i].bytes();
+        for (int i = 0; i < nCtx; ++i) keep += std::max(ds->ctx[i] ? ds->ctx[i]->bytes() : 0, perCtx);
+        for (int i = KZ_MAX_PASSES_IN_FLIGHT - 1; i >= nCtx; --i) {
+            if (!ds->ctx[i] || !ds->ctx[i]->bytes()) continue;
+            if (keep + ds->ctx[i]->bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i]->release(); } else keep += ds->ctx[i]->bytes();
+        }
+        if (keep + kzCtxPoolBytes(ds->device) > limit) (void)kzCtxPoolTrim(ds->device, limit > keep ? limit - keep : 0);
+        if (keep > limit)
+            for (int i = 0; i < nCtx; ++i) if (ds->ctx[i] && ds->ctx[i]->items() > need) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i]->arena->shrinkTo(need); }
     }
     if (!ds->evCallA) { HIP_TRY(hipEventCreate(&ds->evCallA)); HIP_TRY(hipEventCreate(&ds->evCallB)); }
     if (multi) {
@@ -850,20 +863,36 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         HIP_TRY(hipEventRecord(ds->evFork, stream));
         for (int i = 0; i < nCtx; ++i) HIP_TRY(hipStreamWaitEvent(ds->passStream[i], ds->evFork, 0));
     }
+    // A pass context GROWS (kz_arena.cpp): its memory is mapped on a side thread while the passes already run. With everything left to the library
+    // (autoShape) a pass takes what its context holds at that moment - the first passes of a job that starts behind the driver's wipe of recently released
+    // memory are small, on clean memory the context is complete before the first pass - and with an explicit pass size or number of passes in flight the
+    // call waits for the size it was asked for (the pass structure, hence the grouping of the film's float additions, is then the same from run to run).
+    const bool grow = pipeline == 2 && autoShape && need > ((size_t)1 << 26);
+    const size_t minStart = grow ? std::min<size_t>(need, (size_t)1 << 20) : need;
+    const double graceMs = grow ? 5.0 : -1.0;
     // evFilm[i] of a context that has not run a pass in this call must not be waited for: inFlight marks the ones that have
     bool inFlight[KZ_MAX_PASSES_IN_FLIGHT] = {};
     uint32_t pass = 0;
-    // one pass: pixels [p0, p0 + nPixPass) of the pixel list x sample indices [s, s + Sp)
-    auto onePass = [&](uint32_t p0, uint32_t nPixPass, uint32_t s, uint32_t Sp) -> int {
-        const uint32_t *pixList = ds->pixList + p0;
-        const size_t items = (size_t)nPixPass * Sp;
+    size_t firstPassItems = 0, largestPassItems = 0;
+    // the context the next pass runs in, with what a pass may use of it now
+    auto nextCtx = [&](size_t *usable) -> int {
         const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
-        PassCtx &c = ds->ctx[ci];
+        PassCtx &c = ds->ctxAt(ci);
         hipStream_t pst = multi ? ds->passStream[ci] : stream;
         // Back-pressure of dynamic dealing: the host takes the next batch only when the context it needs has finished its previous pass, so a device
         // holds at most nCtx passes - never the whole frame - and a slower device simply comes back to the counter less often.
         if (dealer && inFlight[ci]) HIP_TRY(hipEventSynchronize(ds->evFilm[ci]));
-        if ((rc = ctxEnsure(c, need, pixPerPass, pipeline == 2, tapSums, pst))) return rc;
+        return ctxEnsure(c, need, minStart, graceMs, pixPerPass, tapSums, pst, usable);
+    };
+    // one pass: pixels [p0, p0 + nPixPass) of the pixel list x sample indices [s, s + Sp), in the context nextCtx has prepared
+    auto onePass = [&](uint32_t p0, uint32_t nPixPass, uint32_t s, uint32_t Sp) -> int {
+        const uint32_t *pixList = ds->pixList + p0;
+        const size_t items = (size_t)nPixPass * Sp;
+        const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
+        PassCtx &c = ds->ctxAt(ci);
+        hipStream_t pst = multi ? ds->passStream[ci] : stream;
+        if (!firstPassItems) firstPassItems = items;
+        largestPassItems = std::max(largestPassItems, items);
         if (beams) {
             if ((rc = ensureBeams(scene, ds, stream, p0, nPixPass))) return rc;
             if (pst != stream && c.beamSeen != ds->beamSeq) { HIP_TRY(hipStreamWaitEvent(pst, ds->evBeam, 0)); c.beamSeen = ds->beamSeq; }
@@ -876,7 +905,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         HIP_TRY(hipEventRecord(ep.a, pst));
         if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams))) return rc; }
         else {
-            float *sJx = c.samp, *sJy = c.samp + c.sampCap, *sR = c.samp + 2 * c.sampCap, *sG = c.samp + 3 * c.sampCap, *sB = c.samp + 4 * c.sampCap;
+            float *sJx = c.plane[0], *sJy = c.plane[1], *sR = c.plane[2], *sG = c.plane[3], *sB = c.plane[4];
 #define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, pixList, (uint32_t)items, Sp, s, \
                                        (const uint32_t *)nullptr, sJx, sJy, sR, sG, sB, ds->stats)
             if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, true); else KZ_MEGA(true, false); }
@@ -893,11 +922,27 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         ++pass;
         return KZ_OK;
     };
-    // the passes of pixels [b0, b1) of the list: pixel chunks x sample ranges
+    // The passes of pixels [b0, b1) of the list: columns of pixel chunks, each rendered in sample ranges. A column's width and every pass's sample count
+    // follow what the context holds when the pass is planned, never beyond the call's target shape (pixPerPass x S): with the context complete this is the
+    // fixed schedule "pixel chunks x sample ranges of S".
     auto passesOf = [&](uint32_t b0, uint32_t b1) -> int {
-        for (uint32_t p0 = b0; p0 < b1; p0 += pixPerPass) {
-            const uint32_t nPixPass = std::min(pixPerPass, b1 - p0);
-            for (uint32_t s = s0; s < s1; s += S) if ((rc = onePass(p0, nPixPass, s, std::min(S, s1 - s)))) return rc;
+        for (uint32_t p0 = b0; p0 < b1;) {
+            size_t avail = 0;
+            if ((rc = nextCtx(&avail))) return rc;
+            uint32_t w = std::min(pixPerPass, b1 - p0);
+            if (avail < (size_t)w * std::min<uint32_t>(S, nSamples)) {                   // the context is still growing: the column it can serve now
+                uint32_t sCol = 0, wCol = 0;
+                shapeFor(avail, b1 - p0, sCol, wCol);
+                w = std::max<uint32_t>(1, std::min(w, wCol));
+            }
+            for (uint32_t s = s0; s < s1;) {
+                if (s != s0 && (rc = nextCtx(&avail))) return rc;
+                uint32_t Sp = (uint32_t)std::min<size_t>({(size_t)(s1 - s), (size_t)S, std::max<size_t>(1, avail / w)});
+                if (Sp > 64 && Sp < s1 - s) Sp = Sp / 64 * 64;                           // (whole waves of one pixel for the camera-ray kernels)
+                if ((rc = onePass(p0, w, s, Sp))) return rc;
+                s += Sp;
+            }
+            p0 += w;
         }
         return KZ_OK;
     };
@@ -919,6 +964,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     ds->lastDual = multi;
     ds->lastInfo.passes = pass; ds->lastInfo.passesInFlight = (uint32_t)nCtx; ds->lastInfo.itemsPerPass = need; ds->lastInfo.sppPerPass = S;
     ds->lastInfo.pixels = ds->nPix; ds->lastInfo.stateBytes = ds->ctxBytes(); ds->lastInfo.pixelsPerPass = pixPerPass;
+    ds->lastInfo.firstPassItems = firstPassItems; ds->lastInfo.largestPassItems = largestPassItems;
     return KZ_OK;
 }
 
@@ -970,7 +1016,7 @@ int kz_last_stage_ms(KzScene *scene, float *out6) {
     if (!out6) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
     for (int i = 0; i < 6; ++i) out6[i] = 0.f;
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
-    const PassCtx &c = ds->ctx[ds->lastCtx];
+    const PassCtx &c = ds->ctxAt(ds->lastCtx);
     for (size_t i = 1; i < c.stageUsed; ++i) {
         float t = 0; HIP_TRY(hipEventElapsedTime(&t, c.stageEv[i - 1], c.stageEv[i]));
         const int k = c.stageKind[i];

@@ -69,19 +69,22 @@ struct DevMem {
 };
 
 struct EventPair { hipEvent_t a, b; };
-// The path-state memory of one pass context (kz_arena.cpp): one reserved virtual range, physical memory mapped into it level by level on a side
-// thread; `mapped` items of EVERY array are usable at any moment, and only ever more (until shrinkTo / releaseAll, which the owner calls on an idle device).
+// The path-state memory of one pass context (kz_arena.cpp). Up to 2^23 items: hipMalloc arrays of the size asked for. Beyond: one reserved virtual range
+// per array, physical memory mapped into them in levels of 2^23 items on a side thread; `mapped` items of EVERY array are usable at any moment, and only
+// ever more (until shrinkTo / releaseAll, which the owner calls on an idle device).
 struct KzArena {
     static constexpr int kArrays = 17;        // rayA rayB hit thr misc shA shB shL | smp | queue 0 1 2 | jx jy r g b
+    static constexpr size_t kLevelItems = (size_t)1 << 23;      // one level: 128 MB chunks for the 16-B arrays, 32 MB for the 4-B ones, every chunk of an array the same size
+    static constexpr size_t kSmallMax = (size_t)1 << 23;
     int device;
-    char *va = nullptr; size_t vaBytes = 0;
-    size_t capItems = 0;                      // items the virtual ranges are reserved for (the stride of the five sample planes)
+    size_t capItems = 0;                      // items the virtual ranges (one per array) are reserved for; 0: no reservation (a small or empty context)
+    size_t smallItems = 0;                    // items of the hipMalloc arrays of a small context
     char *base[kArrays]; size_t elem[kArrays];
     struct Level { size_t firstItem, items; hipMemGenericAllocationHandle_t h[kArrays]; int mappedArrays; };
     std::vector<Level> levels;
     std::atomic<size_t> mapped{0};
     std::mutex m; std::condition_variable cvWork, cvProgress; std::thread th;
-    bool stop = false, busy = false; size_t target = 0;
+    bool stop = false, busy = false, growthFailed = false; size_t target = 0;
     std::atomic<int> failCountdown{0};        // kz_debug_fail_alloc: the nth physical allocation from now on fails
     int err = 0; std::string errMsg;
     std::chrono::steady_clock::time_point lastProgress;
@@ -90,19 +93,20 @@ struct KzArena {
     KzArena(const KzArena &) = delete; KzArena &operator=(const KzArena &) = delete;
     static size_t bytesPerItem();
     size_t bytes() const { return mapped.load() * bytesPerItem(); }
-    int reserve(size_t cap);
+    bool wouldReallocate(size_t items) const;
     int request(size_t items, size_t minItems, double graceMs, size_t *got);
     void shrinkTo(size_t items);
     void releaseAll();
     template <class Tp> Tp *array(int a) const { return (Tp *)base[a]; }
 private:
-    void growLoop(); bool growOneLevel(size_t first, size_t items); void dropLevels(size_t keepLevels); void stopThread();
+    int reserve(size_t cap); int requestSmall(size_t items, size_t *got); void freeSmall();
+    void growLoop(); bool growOneLevel(size_t first); void dropLevels(size_t keepLevels); void stopThread();
 };
 // path state + sample records + stage events of one pass in flight
 struct PassCtx {
     KzArena *arena = nullptr;                                    // the path-state arrays and the five sample planes (jx | jy | r | g | b)
     KzWf wf{};                                                   // (pointers into the arena, set by ctxEnsure)
-    float *samp = nullptr; size_t sampCap = 0;                   // sample planes: plane k at samp + k * sampCap (sampCap = the arena's reserved items)
+    float *plane[5] = {};                                        // the five sample planes jx | jy | r | g | b (each its own range of the arena)
     float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: taps^2 float4 per pixel of the tile set
     uint32_t *counts = nullptr;                                  // queue counters of a pass (8 x 520 words)
     uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
@@ -114,7 +118,7 @@ struct PassCtx {
     // gives the memory back (the context stays usable: it grows again on demand); the caller has synchronised the device
     void release() {
         if (arena) arena->shrinkTo(0);
-        wf = KzWf{}; samp = nullptr; sampCap = 0;
+        wf = KzWf{}; for (float *&q : plane) q = nullptr;
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
         if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
         if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;

@@ -108,7 +108,9 @@ class Scene:
         taken = np.zeros(2 * len(tiles) + 2, np.uint32)
         n_taken = np.zeros(1, np.uint32)
         assert counter.dtype == np.uint32 and counter.size >= 1
-        dl = abi.KzTileDealer(counter.ctypes.data_as(abi.u32p), int(batch_tiles), int(takers), taken.ctypes.data_as(abi.u32p), taken.size, n_taken.ctypes.data_as(abi.u32p))
+        # (a counter array of two or more words: word 1 is the takers' agreement word, KzTileDealer.agreed)
+        agreed = C.cast(counter.ctypes.data + 4, abi.u32p) if counter.size >= 2 else None
+        dl = abi.KzTileDealer(counter.ctypes.data_as(abi.u32p), int(batch_tiles), int(takers), taken.ctypes.data_as(abi.u32p), taken.size, n_taken.ctypes.data_as(abi.u32p), agreed)
         o.dealer = C.pointer(dl)
         abi.check(self.lib, self.lib.kz_render_tiles(self.h, C.byref(o), arr, len(tiles), dev, None, 0))
         out = []

@@ -54,14 +54,30 @@ def gather_films(film, rank, world):
     return None
 
 
-def gather_tiles(scene, tiles, packed, rank, world, tile=None):
+def open_gather(rank, world):
+    """Collective, BEFORE the clocks: the ranks agree on the names of the /dev/shm files of one gather_tiles (a token from rank 0). A gather that is
+    handed the session needs no collective of its own before rank 0 starts merging, so a rank that finishes early does not wait for the slowest."""
+    import os
+    import torch.distributed as dist
+    token = [os.urandom(6).hex() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(token, src=0)
+    return token[0]
+
+
+def gather_tiles(scene, tiles, packed, rank, world, tile=None, session=None):
     """The host gather of a multi-process launch (one rank per GPU of ONE node), SURVEY 8e: every rank hands the PACKED film rects of the tiles IT
     rendered (kz_film_download_tiles: each tile with its filter apron, 1.13 x the tile's texels) to rank 0, and rank 0 adds them into one film, rank
     after rank, tiles in each rank's list order (kz_film_merge_tiles = ImageBlock::put(ImageBlock&), block.cpp:87-96, over row bands on host threads).
-    `tiles` is THIS rank's list - whatever dealt it (kz_deal_tiles, or the batches a KzTileDealer handed out): the lists travel with the rects, nothing
-    is recomputed on rank 0. The rects go through shared memory (/dev/shm: the ranks share a host), the CPU process group (gloo) carries the tile lists
-    and the flags; without /dev/shm the rects travel by gloo too. No RCCL, no device collective; the volume is one film in all, however many ranks.
-    A failure on any rank (or on rank 0 while it merges) is raised on EVERY rank instead of leaving the others in a barrier.
+    `tiles` is THIS rank's list - whatever dealt it (kz_deal_tiles, or the batches a KzTileDealer handed out): the list travels with the rects (one file
+    per rank in /dev/shm: the ranks share a host), nothing is recomputed on rank 0.
+    PIPELINED (round 5): a rank writes its file as soon as it has its rects and tells rank 0 with one point-to-point message; rank 0 merges its own rects,
+    then rank 1's as soon as that message is there, then rank 2's ... - while later ranks may still be rendering. There is no collective in front of the
+    merge (given a `session` from open_gather; without one the token broadcast is that collective), so the gather overlaps the tail of the render instead
+    of starting behind a barrier. The order of the additions is the rank order whatever the order of arrival (H10). Without /dev/shm the list and the rects
+    travel by gloo, point to point. No RCCL, no device collective; the volume is one film in all, however many ranks.
+    A failure on ANY rank - a packed buffer of the wrong size, a file that cannot be written, the merge on rank 0 - is raised on EVERY rank: each rank sends
+    exactly one status message and then waits for rank 0's verdict, rank 0 always receives world - 1 of them before it broadcasts it, nobody is left waiting.
     Returns the film on rank 0, None elsewhere. (`tile` is accepted for callers of the round-3 signature and ignored.)"""
     import os
     import numpy as np
@@ -71,57 +87,70 @@ def gather_tiles(scene, tiles, packed, rank, world, tile=None):
     packed = np.ascontiguousarray(packed, np.float32)
     if world == 1:
         return scene.merge_tiles(scene.empty_film(), tiles, packed)
-    if packed.size != scene.packed_floats(tiles):
-        raise ValueError("gather_tiles: %d floats for %d tiles, kz_tiles_packed_floats says %d" % (packed.size, len(tiles), scene.packed_floats(tiles)))
-    token = [os.urandom(6).hex() if rank == 0 else None]
-    dist.broadcast_object_list(token, src=0)
-    lists = [None] * world
-    dist.all_gather_object(lists, tiles)                       # every rank's tile list, as rendered
-    path = lambda r: "/dev/shm/kz_gather_%s_%d.f32" % (token[0], r)
-    ok = torch.ones(1, dtype=torch.int32)
+    token = session or open_gather(rank, world)
+    path = lambda r: "/dev/shm/kz_gather_%s_%d.bin" % (token, r)
+    SHM, GLOO, FAILED = 1, 2, -1
+    err = None
     try:
-        if packed.size:
-            packed.tofile(path(rank))
-    except OSError:
-        ok[0] = 0
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                  # every rank wrote its file (this is also the barrier behind the writes)
-    film, err = None, None
-    try:
-        if int(ok[0]):
-            if rank == 0:
-                try:
-                    film = scene.empty_film()
-                    for r in range(world):
-                        if lists[r]:
-                            scene.merge_tiles(film, lists[r], np.memmap(path(r), dtype=np.float32, mode="r"))      # (mapped, not copied; ranks without tiles wrote no file)
-                except Exception as e:                         # noqa: BLE001 - reported to every rank below
-                    err, film = e, None
-        else:                                                  # no shared memory: the rects go through the process group
-            sizes = [scene.packed_floats(lists[r]) if lists[r] else 0 for r in range(world)]
-            buf = np.zeros(max(max(sizes), 1), np.float32)
-            buf[:packed.size] = packed
-            t = torch.from_numpy(buf)
-            if rank == 0:
-                bufs = [torch.empty_like(t) for _ in range(world)]
-                dist.gather(t, bufs, dst=0)
-                try:
-                    film = scene.empty_film()
-                    for r in range(world):
-                        if lists[r]:
-                            scene.merge_tiles(film, lists[r], bufs[r].numpy()[:sizes[r]])
-                except Exception as e:                         # noqa: BLE001
-                    err, film = e, None
-            else:
-                dist.gather(t, None, dst=0)
-        done = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
-        dist.broadcast(done, src=0)                            # rank 0 has read everything - or failed: every rank learns which
-        if not int(done[0]):
-            raise RuntimeError("gather_tiles: the merge on rank 0 failed%s" % (": %s" % err if err is not None else ""))
-    finally:
+        want = scene.packed_floats(tiles) if tiles else 0
+        if packed.size != want:
+            raise ValueError("gather_tiles: rank %d hands over %d floats for %d tiles, kz_tiles_packed_floats says %d" % (rank, packed.size, len(tiles), want))
+    except Exception as e:                                     # noqa: BLE001 - reported to every rank below
+        err = e
+    if rank != 0:
+        mode = FAILED if err is not None else SHM
+        if mode == SHM and tiles:
+            try:
+                with open(path(rank), "wb") as f:
+                    np.asarray(tiles, np.int32).tofile(f)
+                    packed.tofile(f)
+            except OSError:
+                mode = GLOO
+        dist.send(torch.tensor([mode, len(tiles), packed.size], dtype=torch.int64), dst=0)
+        if mode == GLOO and tiles:
+            dist.send(torch.from_numpy(np.asarray(tiles, np.int32).reshape(-1).copy()), dst=0)
+            dist.send(torch.from_numpy(packed), dst=0)
+        film = None
+    else:
+        film = None
         try:
-            os.unlink(path(rank))
-        except OSError:
-            pass
+            if err is None:
+                film = scene.empty_film()
+                if tiles:
+                    scene.merge_tiles(film, tiles, packed)
+        except Exception as e:                                 # noqa: BLE001
+            err = e
+        for r in range(1, world):                              # rank order = the order of the additions; a rank's message is there when its file is
+            head = torch.zeros(3, dtype=torch.int64)
+            dist.recv(head, src=r)
+            mode, n_tiles, n_floats = (int(v) for v in head)
+            try:
+                if mode == FAILED:
+                    raise RuntimeError("rank %d could not hand over its tile rects" % r)
+                if n_tiles == 0:
+                    continue
+                if mode == GLOO:
+                    tl, fl = torch.zeros(4 * n_tiles, dtype=torch.int32), torch.zeros(n_floats, dtype=torch.float32)
+                    dist.recv(tl, src=r)
+                    dist.recv(fl, src=r)
+                    tl, fl = tl.numpy(), fl.numpy()
+                else:
+                    raw = np.memmap(path(r), dtype=np.uint8, mode="r")      # (mapped, not copied)
+                    tl, fl = np.frombuffer(raw, np.int32, 4 * n_tiles), np.frombuffer(raw, np.float32, n_floats, 16 * n_tiles)
+                if err is None:
+                    scene.merge_tiles(film, [tuple(int(v) for v in t) for t in tl.reshape(-1, 4)], fl)
+            except Exception as e:                             # noqa: BLE001
+                err = err or e
+        if err is not None:
+            film = None
+    done = torch.tensor([0 if (rank == 0 and err is not None) else 1], dtype=torch.int32)
+    dist.broadcast(done, src=0)                                # rank 0 has read everything - or something failed somewhere: every rank learns which
+    try:
+        os.unlink(path(rank))
+    except OSError:
+        pass
+    if not int(done[0]) or err is not None:
+        raise RuntimeError("gather_tiles failed%s" % (": %s" % err if err is not None else " on another rank"))
     return film
 
 

@@ -199,6 +199,7 @@ static inline bool isPowerOf4(int n) {
 static inline int log2i(uint32_t v) { return 31 - __builtin_clz(v); }
 static inline int log4i(uint32_t v) { return log2i(v) / 2; }
 static inline int roundUpPow4(int v) { return isPowerOf4(v) ? v : (1 << (2 * (1 + log4i((uint32_t)v)))); }
+static inline int pmjPixelTile(uint32_t spp) { return 1 << (log4i(KZ_PMJ02BN_SAMPLES) - log4i((uint32_t)roundUpPow4((int)spp))); }      // sampler.cpp:291
 
 // ---------------------------------------------------------------------------------
 // a17  Frame / coordinateSystem (include/kazen/frame.h:14-51, src/kazen/common.cpp:436-445)
@@ -1302,7 +1303,7 @@ static int preparePmj(Scene &sc) {
     uint32_t spp = sc.smp.sampleCount;
     if (spp > KZ_PMJ02BN_SAMPLES) spp = KZ_PMJ02BN_SAMPLES;              // sampler.cpp:284-287
     sc.sampleCount = spp;
-    int tile = 1 << (log4i(KZ_PMJ02BN_SAMPLES) - log4i((uint32_t)roundUpPow4((int)spp)));
+    int tile = pmjPixelTile(spp);
     sc.pixelTileSize = tile;
     size_t nPix = (size_t)tile * tile * spp;
     sc.pixelSamples.assign(nPix * 2, 0.f);
@@ -1460,6 +1461,22 @@ static bool filmPut(const Scene &sc, float *film, int cols, int rows, int offx, 
 // ---------------------------------------------------------------------------------
 // a18/a19 lights (src/kazen/light.cpp, src/kazen/mesh.cpp:24-53,108-133, dpdf.h)
 // ---------------------------------------------------------------------------------
+static float dpdfNormalize(std::vector<float> &cdf, float *sumOut) {             // DiscretePDF::normalize, dpdf.h:77-89: returns m_normalization
+    float sum = cdf.back();
+    if (sumOut) *sumOut = sum;
+    if (sum > 0) {
+        float normalization = 1.0f / sum;
+        for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= normalization;
+        cdf.back() = 1.0f;
+        return normalization;
+    }
+    return 0.f;
+}
+static size_t dpdfSampleTable(const std::vector<float> &cdf, float v) {          // DiscretePDF::sample, dpdf.h:99-104
+    auto entry = std::lower_bound(cdf.begin(), cdf.end(), v);
+    ptrdiff_t idx = std::max((ptrdiff_t)0, (ptrdiff_t)(entry - cdf.begin()) - 1);
+    return std::min((size_t)idx, cdf.size() - 2);
+}
 static void prepareLightMesh(MeshData &md) {
     md.cdf.clear(); md.cdf.push_back(0.0f);                                      // dpdf.h:23-27
     for (uint32_t i = 0; i < md.nF; ++i) {
@@ -1468,18 +1485,9 @@ static void prepareLightMesh(MeshData &md) {
         float area = 0.5f * norm(cross(p1 - p0, p2 - p0));                       // mesh.cpp:47-53
         md.cdf.push_back(md.cdf.back() + area);                                  // dpdf.h:35-37
     }
-    float sum = md.cdf.back();                                                   // dpdf.h:77-89
-    if (sum > 0) {
-        md.normalization = 1.0f / sum;
-        for (size_t i = 1; i < md.cdf.size(); ++i) md.cdf[i] *= md.normalization;
-        md.cdf.back() = 1.0f;
-    } else md.normalization = 0.f;
+    md.normalization = dpdfNormalize(md.cdf, nullptr);
 }
-static size_t dpdfSample(const MeshData &md, float v) {                          // dpdf.h:99-104
-    auto entry = std::lower_bound(md.cdf.begin(), md.cdf.end(), v);
-    ptrdiff_t idx = std::max((ptrdiff_t)0, (ptrdiff_t)(entry - md.cdf.begin()) - 1);
-    return std::min((size_t)idx, md.cdf.size() - 2);
-}
+static size_t dpdfSample(const MeshData &md, float v) { return dpdfSampleTable(md.cdf, v); }
 struct LRec { V3 ref, wi, p, n; Ray shadowRay; float pdf = 0; };
 static inline V3 lightRadiance(const KzLight &l) { return l.intensity * V3(l.color[0], l.color[1], l.color[2]); }   // light.cpp:13
 static V3 lightEval(const KzLight &l, const LRec &r) {                            // light.cpp:16-19
@@ -1971,6 +1979,17 @@ void kzo_cosine_hemisphere(float sx, float sy, float *o3) { FtzScope ftz_; V3 v 
 void kzo_uniform_disk(float sx, float sy, float *o2) { FtzScope ftz_; squareToUniformDisk(sx, sy, o2[0], o2[1]); }
 void kzo_frame(const float *n, float *s3, float *t3) { FtzScope ftz_; Frame f(V3(n[0], n[1], n[2])); s3[0] = f.s.x; s3[1] = f.s.y; s3[2] = f.s.z; t3[0] = f.t.x; t3[1] = f.t.y; t3[2] = f.t.z; }
 // BSDF: which = 0 eval (3 floats), 1 pdf (1 float), 2 sample (weight 3 + wo 3 + ok 1)
+// known answers against vectors minted from the reference's own dpdf.h / common.h (oracle/kat_ref_dpdf.cpp): the functions the light set-up and the
+// PMJ02BN constructor above call
+void kzo_debug_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNormalization) { FtzScope ftz_;
+    std::vector<float> t(1, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) t.push_back(t.back() + values[i]);                                                                // dpdf.h:35-37
+    sumAndNormalization[1] = dpdfNormalize(t, &sumAndNormalization[0]);
+    std::memcpy(cdf, t.data(), t.size() * sizeof(float));
+}
+uint32_t kzo_debug_dpdf_sample(uint32_t nCdf, const float *cdf, float v) { return (uint32_t)dpdfSampleTable(std::vector<float>(cdf, cdf + nCdf), v); }
+void kzo_debug_pow4(int spp, int *out4) { out4[0] = isPowerOf4(spp) ? 1 : 0; out4[1] = roundUpPow4(spp); out4[2] = log4i((uint32_t)out4[1]); out4[3] = pmjPixelTile((uint32_t)spp); }
+
 void kzo_bsdf(const KzBSDF *row, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float *out) { FtzScope ftz_;
     KzBSDF resolved = *row, *m = &resolved;                // a bare row: resolve the rough BSDFs' alpha as kzo_scene_create does (the constructors' m_alpha)
     if ((m->type == KZ_BSDF_ROUGHCONDUCTOR || m->type == KZ_BSDF_ROUGHPLASTIC || m->type == KZ_BSDF_ROUGHDIELECTRIC) && !m->alphaResolved) { m->alpha = std::max(0.001f, sqr(m->alpha)); m->alphaResolved = 1; }

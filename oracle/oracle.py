@@ -64,6 +64,12 @@ def lib():
         L.kzo_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.kzo_fresnel_dielectric.restype = C.c_float
         L.kzo_tea32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        L.kzo_debug_dpdf.argtypes = [C.c_uint32, abi.f32p, abi.f32p, abi.f32p]
+        L.kzo_debug_dpdf.restype = None
+        L.kzo_debug_dpdf_sample.argtypes = [C.c_uint32, abi.f32p, C.c_float]
+        L.kzo_debug_dpdf_sample.restype = C.c_uint32
+        L.kzo_debug_pow4.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.kzo_debug_pow4.restype = None
         L.kzo_tea32.restype = C.c_uint64
         L.kzo_pcg32_stream.argtypes = [C.c_uint64, C.c_int64, C.c_int, abi.u32p, abi.f32p, C.POINTER(C.c_uint64)]
         L.kzo_pcg32_stream.restype = None

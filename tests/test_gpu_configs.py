@@ -447,3 +447,99 @@ def test_failed_calls_release_their_device_memory(gpu_lib, kz):
         sc2.upload(0)
     gpu_lib.kz_debug_fail_alloc(0)
     assert sc2.devices() == [] and free_now() == before
+
+
+# ---------------------------------------------------------------- round 5: the growing pass context and the benched pass size
+def _free_gb(gpu_lib):
+    f, t = C.c_uint64(), C.c_uint64()
+    assert gpu_lib.kz_device_mem_info(0, C.byref(f), C.byref(t)) == 0
+    return f.value / 1e9
+
+
+def test_c4_at_the_benched_pass_size(gpu_lib, kz, O):
+    """the configuration bench.py times - C4, sample indices [0, 512), ONE default pass of 2^30 (pixel, sample) items, 175 GB of path
+    state - against the same slice in passes of 2^27 items and, on a crop, against the oracle."""
+    if _free_gb(gpu_lib) < 200:
+        pytest.skip("needs 200 GB of free device memory (one default pass of 2^30 items)")
+    desc = kz.scenes.random_triangles(1000000, 1920, 1080, 1024, sampler="pmj02bn", seed=1)
+    sc = kz.Scene(desc, device=0)
+    sc.set_stats(True)
+    sc.render(0, 512)
+    big = sc.film()
+    st = sc.stats(reset=True)
+    info = sc.last_pass_info()
+    assert st["samples"] == 1920 * 1080 * 512 and st["droppedSamples"] == 0 and np.isfinite(big).all()
+    assert info["itemsPerPass"] == 1920 * 1080 * 512 and info["largestPassItems"] <= info["itemsPerPass"]
+    sc.render(0, 512, pass_items=1 << 27, passes_in_flight=2)
+    small = sc.film()
+    st2 = sc.stats(reset=True)
+    assert st2["samples"] == st["samples"] and st2["droppedSamples"] == 0 and sc.last_pass_info()["passes"] >= 8
+    # the same paths, the film's additions grouped by pass: equal to the rounding of those sums
+    scale = float(np.abs(big).max())
+    assert float(np.abs(big - small).max()) <= 1e-6 * scale, float(np.abs(big - small).max()) / scale
+    # a 64 x 64 crop of the same slice against the oracle
+    x0, y0, b = 928, 508, sc.border
+    ora = O.OracleScene(desc)
+    cpu = ora.render(0, 512, tiles=[(x0, y0, 64, 64)], threads=0)
+    tile = kz.Scene(desc, device=0)
+    tile.render(0, 512, tiles=[(x0, y0, 64, 64)])
+    g_rgb, g_w = _crop_rgb(tile.film(), x0, y0, 64, 64, b)
+    c_rgb, c_w = _crop_rgb(cpu, x0, y0, 64, 64, b)
+    inner = (slice(b + 2, -b - 2), slice(b + 2, -b - 2))
+    assert l2(g_rgb[inner], c_rgb[inner]) < L2_TOL and np.allclose(g_w[inner], c_w[inner], rtol=1e-5)
+    # ... and the crop of the whole-frame render agrees with the tile render where the tile's own samples decide the pixel
+    f_rgb, _ = _crop_rgb(big, x0, y0, 64, 64, b)
+    assert l2(f_rgb[inner], g_rgb[inner]) < L2_TOL
+
+
+def test_a_pass_context_that_is_still_growing_renders_the_same_film(gpu_lib, kz, O):
+    """The pass context grows on a side thread while the first passes of a job already run (kz_arena.cpp): behind the driver's wipe of recently released
+    memory the early passes are small and the later ones larger. kz_debug_grow_delay makes that happen on demand: the film is the fixed-size render's up to
+    the grouping of the additions, every sample is rendered exactly once, and the passes did grow."""
+    desc = kz.scenes.hero_scene(1280, 720, 256, detail=1.0)                   # 236 M items: four default levels and more
+    ref = kz.Scene(desc, device=0)
+    ref.render()
+    ref.render()                                                             # (the second call finds the context complete whatever the first one met: ONE pass)
+    assert ref.last_pass_info()["passes"] == 1
+    want = ref.film()
+    ref.close()
+    assert gpu_lib.kz_device_trim(0) == 0                                    # the next scene starts from an empty context
+    try:
+        gpu_lib.kz_debug_grow_delay(15)
+        sc = kz.Scene(desc, device=0)
+        sc.set_stats(True)
+        sc.render()
+        got = sc.film()
+        st = sc.stats(reset=True)
+        info = sc.last_pass_info()
+    finally:
+        gpu_lib.kz_debug_grow_delay(0)
+    assert st["samples"] == 1280 * 720 * 256 and st["droppedSamples"] == 0
+    assert info["passes"] >= 3 and info["firstPassItems"] < info["largestPassItems"] <= info["itemsPerPass"], info
+    scale = float(np.abs(want).max())
+    assert float(np.abs(got - want).max()) <= 1e-6 * scale
+    # the context the job grew is complete now: the same call again is ONE pass, bit-identical to the reference render
+    sc.render()
+    assert sc.last_pass_info()["passes"] == 1 and np.array_equal(sc.film(), want)
+
+
+def test_pass_contexts_outlive_their_replica(gpu_lib, kz):
+    """kz_scene_destroy hands the replica's pass contexts to the device's pool: the next scene renders in them (no allocation, no wait for the driver's wipe
+    of what the first one would have released); kz_device_trim gives the memory back."""
+    gpu_lib.kz_device_trim(0)
+    free0 = _free_gb(gpu_lib)
+    desc = kz.scenes.cornell_box(512, 512, 256)                               # 67 M items
+    a = kz.Scene(desc, device=0)
+    a.render()
+    film_a = a.film()
+    held = a.last_pass_info()["stateBytes"] / 1e9
+    assert held > 5
+    a.close()
+    assert _free_gb(gpu_lib) < free0 - 0.9 * held                            # still held: pooled
+    b = kz.Scene(desc, device=0)
+    t0 = time.perf_counter()
+    b.render(); b.sync()
+    assert np.array_equal(b.film(), film_a)
+    b.close()
+    assert gpu_lib.kz_device_trim(0) == 0
+    assert _free_gb(gpu_lib) > free0 - 0.5                                   # everything back

@@ -722,6 +722,40 @@ def test_light_samples_match_oracle(gpu_lib, kz, O, name):
     assert (got[z, 10:13] == 0).all()
 
 
+def test_device_cdf_draws_match_the_reference_discrete_pdf(gpu_lib, kz):
+    """a19 on the device against the REFERENCE'S OWN DiscretePDF (tests/golden/int_kats.json "dpdf": struct DiscretePDF of dpdf.h compiled where it lies,
+    oracle/kat_ref_dpdf.cpp): every table of the fixture becomes a light mesh whose triangles have exactly the fixture's areas - legs (a, 2) with a = m 2^e,
+    m < 2^11, so 0.5 * |e1 x e2| = a without rounding (zero areas: degenerate triangles) - and the triangle Mesh::sample picks for every minted draw (0,
+    every CDF entry and its two neighbours, 1 - ulp, 1) through kz_light_query, the function the shade kernel calls, is DiscretePDF::sample's index. The
+    tables have 1 .. 200 entries: both forms of the device search (counting for short tables, bisection for long ones)."""
+    import json
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "int_kats.json")))["dpdf"]
+    S = kz.scenes
+    s = S.SceneDescription()
+    tables = [t for t in kats if np.array(t["sum"], np.uint32).view(np.float32) > 0]          # (an all-zero table never normalises: nothing to draw from)
+    assert len(tables) >= 8
+    for t in tables:
+        a = np.array(t["values"], np.uint32).view(np.float32)
+        n = len(a)
+        V = np.zeros((3 * n, 3), np.float32)
+        V[1::3, 0] = a
+        V[2::3, 1] = 2.0
+        s.add_mesh(V, np.arange(3 * n, dtype=np.uint32).reshape(n, 3), np.tile(np.array([0, 0, 1], np.float32), (3 * n, 1)), light=S.area((1, 1, 1), 1.0, False))
+    s.camera.update(width=16, height=16)
+    sc = kz.Scene(s, device=0)
+    light, u0, want = [], [], []
+    for li, t in enumerate(tables):
+        for v_bits, idx in t["sample"]:
+            v = np.array(v_bits, np.uint32).view(np.float32)
+            if v < 1.0:                                             # (Sampler::next1D never returns 1)
+                light.append(li); u0.append(v); want.append(idx)
+    n = len(light)
+    u3 = np.full((n, 3), 0.5, np.float32)
+    u3[:, 0] = np.array(u0, np.float32)
+    got = sc.light_query(np.array(light, np.int32), np.tile(np.array([[0.3, 0.4, 5.0]], np.float32), (n, 1)), u3)
+    assert n > 800 and (got[:, 13].astype(np.int64) == np.array(want)).all(), np.nonzero(got[:, 13].astype(np.int64) != np.array(want))[0][:10]
+
+
 def test_exact_reciprocal_and_sqrt_equal_ieee_for_every_float(gpu_lib, kz):
     """rcpExact / sqrtExact (kz_devfn.h: v_rcp_f32 / v_rsq_f32 + Newton steps with a range guard) replace the compiler's IEEE division by
     1 and sqrtf in the triangle test, the ray set-up and the BSDFs. They must not change a single bit: the library checks them against

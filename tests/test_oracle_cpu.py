@@ -474,3 +474,52 @@ def test_resolved_alpha_rows_equal_raw_rows(kz, O):
         O.OracleScene(s)
     with pytest.raises(Exception, match="alphaResolved"):
         kz.Scene(s, device=None)
+
+
+# ---------------------------------------------------------------- round 5: DiscretePDF and the power-of-4 helpers, pinned to the reference's own text
+def _f32(bits):
+    return np.array(bits, np.uint32).view(np.float32)
+
+
+def test_discrete_pdf_matches_reference_text_bit_for_bit(O, kz, kats):
+    """a19: the area CDF of a light mesh. struct DiscretePDF of the reference's dpdf.h (append: running sums; normalize: multiply by the reciprocal of the
+    sum, last entry forced to 1, a zero sum left alone; sample: lower_bound - 1, clamped) was compiled where it lies (oracle/kat_ref_dpdf.cpp) on tables of
+    1 .. 200 entries spanning 2^-20 .. 2^10 with zero entries; the oracle's restatement AND the host code of kz_scene_create reproduce every bit."""
+    import ctypes as C
+    L, lib = O.lib(), kz.abi.load_library()
+    fp = lambda a: a.ctypes.data_as(kz.abi.f32p)
+    assert len(kats["dpdf"]) >= 9
+    n_samples = 0
+    for t in kats["dpdf"]:
+        vals, want = _f32(t["values"]), np.array(t["cdf"], np.uint32)
+        for which in ("oracle", "library"):
+            cdf, sn = np.zeros(len(vals) + 1, np.float32), np.zeros(2, np.float32)
+            if which == "oracle":
+                L.kzo_debug_dpdf(len(vals), fp(vals), fp(cdf), fp(sn))
+            else:
+                assert lib.kz_debug_dpdf(len(vals), fp(vals), fp(cdf), fp(sn)) == 0
+            assert (cdf.view(np.uint32) == want).all(), (which, len(vals))
+            assert sn.view(np.uint32).tolist() == [t["sum"], t["normalization"]], (which, len(vals))
+        assert t["normalized"] == (1 if _f32([t["sum"]])[0] > 0 else 0)
+        cdf = _f32(t["cdf"]).copy()
+        for v_bits, idx in t["sample"]:
+            assert L.kzo_debug_dpdf_sample(len(cdf), fp(cdf), float(_f32([v_bits])[0])) == idx, (len(vals), v_bits)
+            n_samples += 1
+    assert n_samples > 800
+
+
+def test_power_of_4_helpers_match_reference_text(O, kz, kats):
+    """a9: isPowerOf4 / log2i / log4i / roundUpPow4 (common.h:271-319) decide PMJ02BN's pixel tile (sampler.cpp:291); restated in the oracle AND in the
+    library's host code, both against the reference's own text for EVERY sample count 1 .. 65536."""
+    import ctypes as C
+    L, lib = O.lib(), kz.abi.load_library()
+    pw = set(kats["pow4"]["is_power_of_4"])
+    changes = {c[0]: c[1:] for c in kats["pow4"]["changes"]}
+    cur = None
+    o4, l4 = (C.c_int * 4)(), (C.c_int32 * 4)()
+    for spp in range(1, 65537):
+        cur = changes.get(spp, cur)
+        L.kzo_debug_pow4(spp, o4)
+        assert lib.kz_debug_pow4(spp, l4) == 0
+        want = [1 if spp in pw else 0] + cur
+        assert list(o4) == want and list(l4) == want, (spp, list(o4), list(l4), want)

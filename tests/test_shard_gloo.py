@@ -85,6 +85,47 @@ def _worker(rank, world, port, out, use_gpu, dynamic=False):
     dist.destroy_process_group()
 
 
+def _failing_worker(rank, world, port, out):
+    """rank 1 hands over a packed buffer that is one float short: BOTH ranks must get the error, nobody may be left waiting in a collective"""
+    import importlib
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    kz = importlib.import_module("nano-kazen_amd")
+    import oracle as O
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    desc = kz.scenes.cornell_box(W, H, SPP)
+    tiles = kz.shard.deal_tiles(W, H, world, rank, 32)
+    film = O.OracleScene(desc).render(tiles=tiles, threads=1)
+    sc = kz.Scene(desc)
+    packed = kz.shard.pack_rects_host(film, tiles, sc.border)
+    session = kz.shard.open_gather(rank, world)
+    try:
+        kz.shard.gather_tiles(sc, tiles, packed[:-1] if rank == 1 else packed, rank, world, session=session)
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open("%s.%d" % (out, rank), "w").write(msg)
+    # and the process group is still usable afterwards: a clean gather of the same data
+    merged = kz.shard.gather_tiles(sc, tiles, packed, rank, world)
+    if rank == 0:
+        np.save(out, merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_fails_the_gather_on_every_rank(kz, O, tmp_path):
+    """a size error used to be raised on the offending rank alone, before the first collective - the others then blocked forever."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "film.npy")
+    mp.spawn(_failing_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    m0, m1 = open(out + ".0").read(), open(out + ".1").read()
+    assert "gather_tiles failed" in m0 and "rank 1 could not hand over" in m0, m0
+    assert "gather_tiles failed" in m1 and "kz_tiles_packed_floats says" in m1, m1
+    whole = O.OracleScene(kz.scenes.cornell_box(W, H, SPP)).render(threads=1)
+    assert np.allclose(np.load(out), whole, rtol=1e-6, atol=1e-7)
+
+
 def test_two_rank_tile_sharding_matches_single_process(kz, O, tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "film.npy")
