@@ -116,6 +116,8 @@ def cold_job(which, tris):
         name = "scene/2022_q1/parameters/default_m0_r0.5.xml (36 378 triangles, via tests/golden/q1_default_m0_r0.5.npz), 1920x1080, independent sampler, all of the file's spp"
     scene = kz.Scene(desc)
     t_build = time.perf_counter() - t0
+    if os.environ.get("KZ_BENCH_TRACE"):
+        scene.lib.kz_debug_trace(1)                        # (development: the library's allocation / growth / pass timeline on stderr)
     t0 = time.perf_counter()
     n_dev = scene.lib.kz_device_count()                     # the first HIP call of the process: runtime start-up, a property of the process and reported beside the job
     if n_dev <= 0:
@@ -138,7 +140,7 @@ def cold_job(which, tris):
            "upload_s": round(t1 - t0, 4), "render_s": round(t2 - t1, 4), "download_s": round(t3 - t2, 4),
            "scene_build_s": round(t_build, 2), "hip_runtime_init_s": round(t_init, 3), "value_with_runtime_init": round(n / (t3 - t0 + t_init) / 1e6, 1),
            "passes": info["passes"], "first_pass_items": info["firstPassItems"], "largest_pass_items": info["largestPassItems"], "target_pass_items": info["itemsPerPass"],
-           "state_gb": round(info["stateBytes"] / 1e9, 1), "device_free_gb_at_start": round(free0 / 1e9, 1),
+           "state_gb": round(info["stateBytes"] / 1e9, 1), "device_free_gb_at_start": round(free0 / 1e9, 1), "grow_note": scene.last_grow_note(),
            "image_mean": round(float(scene.rgb(film).mean()), 5)}
     print(json.dumps(rec), flush=True)
     os._exit(0)                                            # (the job is done: what the process still holds goes back to the driver at exit, as the reference's does)
@@ -157,6 +159,8 @@ def run_cold_jobs(tris):
         t0 = time.time()
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-job", which, "--tris", str(tris)], capture_output=True, text=True, timeout=300)
+            if os.environ.get("KZ_BENCH_TRACE"):
+                log(r.stderr)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             rec = json.loads(line[-1]) if line else {"error": "no record (exit code %d): %s" % (r.returncode, r.stderr[-300:])}
         except Exception as e:                                 # noqa: BLE001 - a failed side job must not cost the headline record
@@ -280,6 +284,8 @@ def main():
     elapsed = time.perf_counter() - t_start
     kernel_ms_last = scene.last_kernel_ms()      # hipEvents on the launch stream around the last call / its passes
     info = scene.last_pass_info()
+    if scene.last_grow_note():
+        log("rank %d: the pass context stopped growing: %s" % (rank, scene.last_grow_note()))
     # the gather, once per render: packed rects of the rank's tiles (D2H through pinned memory), gloo to rank 0, merge in tile order
     t_g = time.perf_counter()
     if world > 1:

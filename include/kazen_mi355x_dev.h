@@ -105,6 +105,8 @@ int kz_last_stage_ms(KzScene *scene, float *out6);
 typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes;
                             uint32_t pixelsPerPass; uint32_t reserved; uint64_t firstPassItems; uint64_t largestPassItems; } KzPassInfo;
 int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
+/* Why the pass context of the last kz_render stopped growing short of its target ("" if it did not): such a call succeeds on what there is. */
+int kz_last_grow_note(KzScene *scene, char *buf, size_t cap);
 
 /* Test hook: the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off). Used by
  * the error-path tests to show that a failure in the middle of a call releases what the call had allocated. */
@@ -113,6 +115,8 @@ void kz_debug_fail_alloc(int nth);
 /* Test hook: the thread that maps a pass context's memory (kz_arena.cpp) sleeps `ms` milliseconds before every level (0 = off): "the context is still
  * growing while the first passes of a job run" - what happens behind the driver's wipe of recently released memory - on demand. Process-wide. */
 void kz_debug_grow_delay(int ms);
+/* Development aid: a timeline of the allocation, growth and pass-planning events of this process on stderr (0 = off). */
+void kz_debug_trace(int on);
 
 /* Known answers for the host code of kz_scene_create (no GPU): the area CDF of a light mesh - DiscretePDF::append + normalize, dpdf.h:35-37,77-89 - for n
  * pdf values (cdf: n + 1 floats; sumAndNormalization: 2 floats), and, for a sample count, { isPowerOf4, roundUpPow4, log4i of that, PMJ02BN's pixel tile }

@@ -154,7 +154,7 @@ EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene
            "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8",
            "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
            "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check", "kz_debug_permute", "kz_debug_fresnel", "kz_debug_math", "kz_build_flags",
-           "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_device_trim", "kz_debug_grow_delay", "kz_debug_dpdf", "kz_debug_pow4"]
+           "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_device_trim", "kz_debug_grow_delay", "kz_debug_dpdf", "kz_debug_pow4", "kz_last_grow_note", "kz_debug_trace"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KZ_LIB_PATH: a development build of the library (scripts/build_variant.sh) instead of the in-tree one; probes only
@@ -219,8 +219,11 @@ def load_library():
     lib.kz_debug_fail_alloc.restype = None
     lib.kz_device_mem_info.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.kz_device_trim.argtypes = [C.c_int]
+    lib.kz_last_grow_note.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.kz_debug_grow_delay.argtypes = [C.c_int]
     lib.kz_debug_grow_delay.restype = None
+    lib.kz_debug_trace.argtypes = [C.c_int]
+    lib.kz_debug_trace.restype = None
     lib.kz_debug_dpdf.argtypes = [C.c_uint32, f32p, f32p, f32p]
     lib.kz_debug_pow4.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
     if hasattr(lib, "kz_debug_math"):

@@ -20,10 +20,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdarg>
+#include <cstdio>
 #include <cstring>
 
 static constexpr size_t KZ_ARENA_SMALL_ALIGN = (size_t)1 << 12;      // small contexts: arrays of a multiple of 4096 items
-static constexpr size_t KZ_ARENA_RESERVE_ALIGN = (size_t)1 << 23;    // virtual capacities are whole levels
 
 // kz_debug_grow_delay (kazen_mi355x_dev.h): the growth thread sleeps this long before every level - a test hook that makes "the context is still growing
 // while the passes run" happen on demand (on a quiet device the memory is there before the first pass is planned)
@@ -32,21 +33,48 @@ extern "C" void kz_debug_grow_delay(int ms) { g_growDelayMs.store(ms > 0 ? ms : 
 
 static size_t roundUp(size_t n, size_t a) { return (n + a - 1) / a * a; }
 
+std::atomic<int> g_kzTrace{0};
+static const std::chrono::steady_clock::time_point g_traceT0 = std::chrono::steady_clock::now();
+extern "C" void kz_debug_trace(int on) { g_kzTrace.store(on ? 1 : 0); }
+void kzTraceLine(const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); std::vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    std::fprintf(stderr, "[kz %9.3f ms] %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_traceT0).count(), buf);
+}
+
+// Every arena of the process, so that ALL mapped path state is unmapped and released - and every growth thread joined - before the HIP runtime tears
+// itself down at exit (this library's static destructors run before those of libamdhip64, which it depends on): a process that exits with live
+// mappings in reserved ranges crashed inside the runtime's own exit handlers (round 5: bench.py wrote its record, then segfaulted).
+static std::mutex g_registryMutex;
+static std::vector<KzArena *> g_registry;
+static struct KzArenaJanitor {
+    ~KzArenaJanitor() {
+        std::vector<KzArena *> all;
+        { std::lock_guard<std::mutex> g(g_registryMutex); all = g_registry; }
+        for (KzArena *a : all) { (void)hipSetDevice(a->device); (void)hipDeviceSynchronize(); a->releaseAll(); }
+    }
+} g_janitor;
+
 KzArena::KzArena(int dev) : device(dev) {
     // element sizes in the order the pass launcher reads them (kz_render.hip: ctxEnsure): 8 float4 fields, the sampler record, 3 queues, 5 sample planes
     const size_t e[kArrays] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 4, 4, 4, 4, 4, 4, 4, 4};
     std::memcpy(elem, e, sizeof e);
     std::memset(base, 0, sizeof base);
+    std::lock_guard<std::mutex> g(g_registryMutex);
+    g_registry.push_back(this);
 }
 
-KzArena::~KzArena() { releaseAll(); }
+KzArena::~KzArena() {
+    releaseAll();
+    std::lock_guard<std::mutex> g(g_registryMutex);
+    g_registry.erase(std::remove(g_registry.begin(), g_registry.end(), this), g_registry.end());
+}
 
 size_t KzArena::bytesPerItem() { return 8 * 16 + 16 + 3 * 4 + 5 * 4; }
 
 void KzArena::stopThread() {
     if (!th.joinable()) return;
     { std::lock_guard<std::mutex> g(m); stop = true; }
-    cvWork.notify_all();
     th.join();
     stop = false; busy = false;
 }
@@ -109,10 +137,13 @@ int KzArena::requestSmall(size_t items, size_t *got) {
 
 // Reserves the virtual ranges for `cap` items (everything mapped so far is given up when the reservation has to grow: rare - the default
 // reservation covers the largest default pass).
-int KzArena::reserve(size_t cap) {
-    cap = roundUp(std::max<size_t>(cap, kLevelItems), KZ_ARENA_RESERVE_ALIGN);
+int KzArena::reserve(size_t cap, size_t firstTarget) {
     if (cap <= capItems) return KZ_OK;
     releaseAll();
+    // few, large chunks for a context that is going to be large (a 2^30-item context: 32 levels = 544 chunks, ~25 ms on clean memory; in levels of 2^23
+    // items it took ~100 ms), small ones where the caller's budget is small (a level is the granularity a context can be held to)
+    levelItems = firstTarget > ((size_t)1 << 27) ? (size_t)1 << 25 : (size_t)1 << 23;
+    cap = roundUp(std::max<size_t>(cap, levelItems), (size_t)1 << 25);
     HIP_TRY(hipSetDevice(device));
     // one range per array: the chunks of an array are mapped one behind the other from the start of ITS reservation, all of one size
     for (int a = 0; a < kArrays; ++a) {
@@ -128,9 +159,9 @@ int KzArena::reserve(size_t cap) {
     return KZ_OK;
 }
 
-// One level: the item range [first, first + kLevelItems) of every array. Runs on the growth thread.
+// One level: the item range [first, first + levelItems) of every array. Runs on the growth thread.
 bool KzArena::growOneLevel(size_t first) {
-    const size_t items = kLevelItems;
+    const size_t items = levelItems;
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
     hipMemAccessDesc ad{};
@@ -163,20 +194,19 @@ bool KzArena::growOneLevel(size_t first) {
     levels.push_back(L);
     mapped.store(first + items);
     lastProgress = std::chrono::steady_clock::now();
+    KZ_TRACE("arena %p: level %zu mapped (%zu M items, %.1f GB)", (void *)this, levels.size(), (first + items) >> 20, (first + items) * bytesPerItem() / 1e9);
     return true;
 }
 
+// The growth thread: level after level until the target is reached (or lowered to what is there: a failure, shrinkTo), then it ENDS - no thread is
+// parked while the process renders on a complete context, idles or exits; request() starts a new one when a larger context is asked for.
 void KzArena::growLoop() {
     (void)hipSetDevice(device);
     for (;;) {
         size_t first;
         {
-            std::unique_lock<std::mutex> lk(m);
-            busy = false;
-            cvProgress.notify_all();
-            cvWork.wait(lk, [&] { return stop || mapped.load() < target; });
-            if (stop) return;
-            busy = true;
+            std::lock_guard<std::mutex> lk(m);
+            if (stop || mapped.load() >= target) { busy = false; cvProgress.notify_all(); return; }
             first = mapped.load();
         }
         if (const int d = g_growDelayMs.load()) std::this_thread::sleep_for(std::chrono::milliseconds(d));
@@ -196,14 +226,15 @@ void KzArena::growLoop() {
 int KzArena::request(size_t items, size_t minItems, double graceMs, size_t *got) {
     if (items <= kSmallMax && !capItems) return requestSmall(items, got);
     if (smallItems) freeSmall();
-    if (items > capItems) { const int rc = reserve(std::max<size_t>(items, (size_t)1 << 30)); if (rc) return rc; }
-    items = std::min(roundUp(items, kLevelItems), capItems);
+    if (items > capItems) { const int rc = reserve(std::max<size_t>(items, (size_t)1 << 30), items); if (rc) return rc; }
+    items = std::min(roundUp(items, levelItems), capItems);
     minItems = std::min(minItems, items);
     std::unique_lock<std::mutex> lk(m);
     if (items > target && !growthFailed) target = items;
-    if (mapped.load() < target) {
-        if (!th.joinable()) { lastProgress = std::chrono::steady_clock::now(); busy = true; th = std::thread([this] { growLoop(); }); }
-        else { busy = true; cvWork.notify_all(); }
+    if (mapped.load() < target && !busy) {                            // (a running thread sees the new target under the mutex before it decides to end)
+        if (th.joinable()) { lk.unlock(); th.join(); lk.lock(); }     // the previous one has ended (busy is false): reap it
+        lastProgress = std::chrono::steady_clock::now(); busy = true;
+        th = std::thread([this] { growLoop(); });
     }
     for (;;) {
         const size_t mp = mapped.load();
@@ -229,11 +260,11 @@ void KzArena::shrinkTo(size_t items) {
     if (!capItems) return;
     {
         std::unique_lock<std::mutex> lk(m);
-        target = std::min(target, roundUp(items, kLevelItems));
-        cvProgress.wait(lk, [&] { return !busy || !th.joinable(); });          // the growth thread parks when mapped >= target
+        target = std::min(target, roundUp(items, levelItems));
+        cvProgress.wait(lk, [&] { return !busy; });                            // the growth thread ends when mapped >= target
     }
     (void)hipSetDevice(device);
-    const size_t keep = std::min(levels.size(), (items + kLevelItems - 1) / kLevelItems);
+    const size_t keep = std::min(levels.size(), (items + levelItems - 1) / levelItems);
     std::lock_guard<std::mutex> g(m);
     dropLevels(keep);
     target = std::min(target, mapped.load());

@@ -389,8 +389,10 @@ static int ctxEnsure(PassCtx &c, size_t want, size_t minItems, double graceMs, s
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.taps) (void)hipFree(c.taps);
         c.taps = nullptr; c.tapsCap = 0;
+        KZ_TRACE("ctxEnsure: tap sums, %.0f MB ...", nPix * KZ_TAP_BYTES_PER_PIXEL / 1e6);
         KZ_ALLOC(&c.taps, nPix * KZ_TAP_BYTES_PER_PIXEL);
         c.tapsCap = nPix;
+        KZ_TRACE("ctxEnsure: ... there");
     }
     if (!c.counts) { KZ_ALLOC(&c.counts, 8 * 520 * sizeof(uint32_t)); }
     KzArena &A = *c.arena;
@@ -533,17 +535,22 @@ static KzTraceFn traceFn(int mode, bool stats) {
 // Beam lists for pixels [p0, p0 + n) of the current pixel list: launched on `stream` (the call's stream) unless that range of this list has been
 // handed to the kernel before; the kernel itself skips pixels that already have a list (from another tile set or chunk). evBeam / beamSeq tell the
 // pass streams what to wait for.
-static int ensureBeams(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_t p0, uint32_t n) {
+static int ensureBeamBuffers(KzScene *scene, KzDeviceState *ds, hipStream_t stream) {
     const KzParams &P = scene->prm;
     const size_t framePix = (size_t)P.width * P.height;
     if (!ds->evBeam) HIP_TRY(hipEventCreateWithFlags(&ds->evBeam, hipEventDisableTiming));
-    if (!ds->beamEntries) {
-        KZ_ALLOC(&ds->beamEntries, framePix * KZ_BEAM_CAP * sizeof(uint2));
-        KZ_ALLOC(&ds->beamCount, framePix * sizeof(uint2));
+    if (!ds->beamEntries || !ds->beamCount) {
+        if (!ds->beamEntries) KZ_ALLOC(&ds->beamEntries, framePix * KZ_BEAM_CAP * sizeof(uint2));
+        if (!ds->beamCount) KZ_ALLOC(&ds->beamCount, framePix * sizeof(uint2));
         ds->beamCap = framePix;
         HIP_TRY(hipMemsetAsync(ds->beamCount, 0xFF, framePix * sizeof(uint2), stream));       // every pixel: KZ_BEAM_UNBUILT
         ds->beamDone.clear(); ds->beamDoneGen = ds->tileGen;
     }
+    return KZ_OK;
+}
+static int ensureBeams(KzScene *scene, KzDeviceState *ds, hipStream_t stream, uint32_t p0, uint32_t n) {
+    const KzParams &P = scene->prm;
+    { const int rc_ = ensureBeamBuffers(scene, ds, stream); if (rc_) return rc_; }
     if (ds->beamDoneGen != ds->tileGen) { ds->beamDone.clear(); ds->beamDoneGen = ds->tileGen; }
     for (const auto &r : ds->beamDone) if (r.first <= p0 && p0 + n <= r.first + r.second) return KZ_OK;
     const int LS = std::max(1, std::min(P.stackBound4, KZ_BEAM_STACK));      // a beam whose open set would grow beyond this leaves the rest unexplored (t_valid)
@@ -555,6 +562,22 @@ static int ensureBeams(KzScene *scene, KzDeviceState *ds, hipStream_t stream, ui
     HIP_TRY(hipEventRecord(ds->evBeam, stream));
     ++ds->beamSeq;
     ds->beamDone.emplace_back(p0, n);
+    return KZ_OK;
+}
+
+// The global overflow area of the traversal stacks (entries beyond tune.ldsStack per lane, sized from the builder's worst-case bound) of one pass context.
+static int ensureOverflow(KzScene *scene, KzDeviceState *ds, PassCtx &c, const KzTune &tune, hipStream_t stream) {
+    const KzParams &P = scene->prm;
+    const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
+    const int ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
+    const size_t stride = (size_t)(ds->numCU * tune.travBlocksPerCU) * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - ldsStack) * 2;      // (x 2: the key stack of kz_experiments.h)
+    if (needOvf > c.ovfCap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c.ovf) (void)hipFree(c.ovf);
+        c.ovf = nullptr; c.ovfCap = 0;
+        KZ_ALLOC(&c.ovf, needOvf * sizeof(uint32_t));
+        c.ovfCap = needOvf;
+    }
     return KZ_OK;
 }
 
@@ -578,15 +601,9 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     tune.ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
     const size_t traceLds = (size_t)(tune.ldsStack + 1) * KZ_BLOCK * sizeof(uint32_t);      // + one scratch slot per lane (branch-free pushes)
     {
-        const size_t stride = (size_t)gTrav.x * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - tune.ldsStack) * 2;      // (x 2: the key stack of kz_experiments.h)
-        if (needOvf > c.ovfCap) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (c.ovf) (void)hipFree(c.ovf);
-            c.ovf = nullptr; c.ovfCap = 0;
-            KZ_ALLOC(&c.ovf, needOvf * sizeof(uint32_t));
-            c.ovfCap = needOvf;
-        }
-        tune.ovf = c.ovf; tune.ovfStride = (uint32_t)stride;
+        const int rc_ = ensureOverflow(scene, ds, c, tune, stream);
+        if (rc_) return rc_;
+        tune.ovf = c.ovf; tune.ovfStride = (uint32_t)((size_t)gTrav.x * KZ_BLOCK);
     }
     const int maxDepth = P.maxDepth;
     c.stageUsed = 0;
@@ -644,6 +661,11 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     if (P.anyInvisibleLight) trace(1, W.queue[2], W.counts + 0, 0u, W.counts + 3, nullptr, nullptr);      // H6 walk-through of the first hit
     { int rc_ = stageMark(c, stream, 5); if (rc_) return rc_; }
     const uint32_t *cur = nullptr, *curCount = nullptr;
+#ifdef KZ_SHADE_CONST_ARGS
+    int shadeArgSlot = 0;
+    for (int i = 0; i < KZ_MAX_PASSES_IN_FLIGHT; ++i) if (ds->ctx[i] == &c) shadeArgSlot = i;
+    { KzShadeArgs a{P, ds->T, W}; HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_kzShadeArgs), &a, sizeof a, (size_t)shadeArgSlot * sizeof a, hipMemcpyHostToDevice, stream)); }
+#endif
     const bool split = tune.shadeSplit != 0;
     const dim3 gClassify((unsigned)(ds->numCU * 8));
     for (int iter = 0; iter < maxDepth; ++iter) {
@@ -662,7 +684,11 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
         } else
 #endif
         {
+#ifdef KZ_SHADE_CONST_ARGS
+#define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, shadeArgSlot, pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
+#else
 #define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
+#endif
             if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
             else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
 #undef KZ_SHADE
@@ -825,14 +851,19 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         // limit below what an earlier call grew them to - the tails of the contexts it does use
         const size_t perCtx = need * perItem + pixPerPass * perPixel;
         size_t keep = 0;
-        for (int i = 0; i < nCtx; ++i) keep += std::max(ds->ctx[i] ? ds->ctx[i]->bytes() : 0, perCtx);
+        for (int i = 0; i < nCtx; ++i) keep += std::max(ds->ctxAt(i).bytes(), perCtx);            // (taken from the device's pool here, with whatever they hold)
         for (int i = KZ_MAX_PASSES_IN_FLIGHT - 1; i >= nCtx; --i) {
             if (!ds->ctx[i] || !ds->ctx[i]->bytes()) continue;
             if (keep + ds->ctx[i]->bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i]->release(); } else keep += ds->ctx[i]->bytes();
         }
         if (keep + kzCtxPoolBytes(ds->device) > limit) (void)kzCtxPoolTrim(ds->device, limit > keep ? limit - keep : 0);
         if (keep > limit)
-            for (int i = 0; i < nCtx; ++i) if (ds->ctx[i] && ds->ctx[i]->items() > need) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i]->arena->shrinkTo(need); }
+            for (int i = 0; i < nCtx; ++i) if (ds->ctx[i] && ds->ctx[i]->bytes() > perCtx) {
+                HIP_TRY(hipDeviceSynchronize());
+                // (a context that has grown into mapped levels cannot hold fewer than one of them - 1.5 GB -: under a cap below that it starts over as a small one)
+                if (need <= KzArena::kSmallMax) ds->ctx[i]->arena->releaseAll(); else ds->ctx[i]->arena->shrinkTo(need);
+                ds->ctx[i]->trimAux(tapSums ? pixPerPass : 0);                                     // (a pooled context may carry another frame's tap sums and overflow stacks)
+            }
     }
     if (!ds->evCallA) { HIP_TRY(hipEventCreate(&ds->evCallA)); HIP_TRY(hipEventCreate(&ds->evCallB)); }
     if (multi) {
@@ -867,6 +898,13 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     // (autoShape) a pass takes what its context holds at that moment - the first passes of a job that starts behind the driver's wipe of recently released
     // memory are small, on clean memory the context is complete before the first pass - and with an explicit pass size or number of passes in flight the
     // call waits for the size it was asked for (the pass structure, hence the grouping of the film's float additions, is then the same from run to run).
+    // Everything ELSE the call allocates is allocated now, before the first context is asked to grow: behind a wipe the growth thread takes whatever
+    // clean memory there is the moment it appears, and a hipMalloc of this thread issued after that waits for the wipe like any other (round 5: the beam
+    // lists, allocated inside the first pass, held the first call of a job for seconds while its context was already 80 GB large).
+    KZ_TRACE("renderOn: %u pixels x samples [%u, %u), target pass %zu items (%u px x %u spp), limit %.1f GB, %d context(s)", ds->nPix, s0, s1, need, pixPerPass, S, limit / 1e9, nCtx);
+    if (beams && (rc = ensureBeamBuffers(scene, ds, stream))) return rc;
+    if (pipeline == 2) for (int i = 0; i < nCtx; ++i) if ((rc = ensureOverflow(scene, ds, ds->ctxAt(i), tune, multi ? ds->passStream[i] : stream))) return rc;
+    KZ_TRACE("renderOn: beam / overflow buffers there");
     const bool grow = pipeline == 2 && autoShape && need > ((size_t)1 << 26);
     const size_t minStart = grow ? std::min<size_t>(need, (size_t)1 << 20) : need;
     const double graceMs = grow ? 5.0 : -1.0;
@@ -875,14 +913,21 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     uint32_t pass = 0;
     size_t firstPassItems = 0, largestPassItems = 0;
     // the context the next pass runs in, with what a pass may use of it now
+    size_t lastAvail = need;
     auto nextCtx = [&](size_t *usable) -> int {
         const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
         PassCtx &c = ds->ctxAt(ci);
         hipStream_t pst = multi ? ds->passStream[ci] : stream;
+        // While the context is still growing the host must not plan the whole job on what is mapped NOW (it queues passes a thousand times faster than
+        // the device runs them): it stays one pass ahead - pass k + 1 is planned when pass k - 1 has finished, with what has been mapped by then.
+        if (grow && !dealer && lastAvail < need && pass >= 2) HIP_TRY(hipEventSynchronize(ds->events[pass - 2].b));
         // Back-pressure of dynamic dealing: the host takes the next batch only when the context it needs has finished its previous pass, so a device
         // holds at most nCtx passes - never the whole frame - and a slower device simply comes back to the counter less often.
         if (dealer && inFlight[ci]) HIP_TRY(hipEventSynchronize(ds->evFilm[ci]));
-        return ctxEnsure(c, need, minStart, graceMs, pixPerPass, tapSums, pst, usable);
+        const int rc_ = ctxEnsure(c, need, minStart, graceMs, pixPerPass, tapSums, pst, usable);
+        lastAvail = *usable;
+        KZ_TRACE("pass %u: context %d holds %zu M items", pass, ci, *usable >> 20);
+        return rc_;
     };
     // one pass: pixels [p0, p0 + nPixPass) of the pixel list x sample indices [s, s + Sp), in the context nextCtx has prepared
     auto onePass = [&](uint32_t p0, uint32_t nPixPass, uint32_t s, uint32_t Sp) -> int {
@@ -965,6 +1010,8 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     ds->lastInfo.passes = pass; ds->lastInfo.passesInFlight = (uint32_t)nCtx; ds->lastInfo.itemsPerPass = need; ds->lastInfo.sppPerPass = S;
     ds->lastInfo.pixels = ds->nPix; ds->lastInfo.stateBytes = ds->ctxBytes(); ds->lastInfo.pixelsPerPass = pixPerPass;
     ds->lastInfo.firstPassItems = firstPassItems; ds->lastInfo.largestPassItems = largestPassItems;
+    ds->growNote.clear();
+    for (int i = 0; i < nCtx; ++i) if (ds->ctx[i] && ds->ctx[i]->arena) { std::lock_guard<std::mutex> g(ds->ctx[i]->arena->m); if (ds->ctx[i]->arena->growthFailed) ds->growNote = ds->ctx[i]->arena->errMsg; }
     return KZ_OK;
 }
 
@@ -1022,6 +1069,15 @@ int kz_last_stage_ms(KzScene *scene, float *out6) {
         const int k = c.stageKind[i];
         if (k >= 0 && k < 6) out6[k] += t;
     }
+    return KZ_OK;
+}
+
+// Why the pass context of the last kz_render stopped growing short of its target, if it did ("" otherwise): the call itself succeeds on what there is.
+int kz_last_grow_note(KzScene *scene, char *buf, size_t cap) {
+    KzDeviceState *ds; int rc;
+    if ((rc = requireDevice(scene, &ds))) return rc;
+    if (!buf || !cap) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
+    std::snprintf(buf, cap, "%s", ds->growNote.c_str());
     return KZ_OK;
 }
 

@@ -68,13 +68,19 @@ struct DevMem {
     template <class Tp> Tp *as() const { return (Tp *)p; }
 };
 
+// kz_debug_trace (kazen_mi355x_dev.h): a timeline of the allocation / growth / pass-planning events of the calling process on stderr (development aid)
+extern std::atomic<int> g_kzTrace;
+void kzTraceLine(const char *fmt, ...);
+#define KZ_TRACE(...) do { if (g_kzTrace.load(std::memory_order_relaxed)) kzTraceLine(__VA_ARGS__); } while (0)
+
 struct EventPair { hipEvent_t a, b; };
 // The path-state memory of one pass context (kz_arena.cpp). Up to 2^23 items: hipMalloc arrays of the size asked for. Beyond: one reserved virtual range
 // per array, physical memory mapped into them in levels of 2^23 items on a side thread; `mapped` items of EVERY array are usable at any moment, and only
 // ever more (until shrinkTo / releaseAll, which the owner calls on an idle device).
 struct KzArena {
     static constexpr int kArrays = 17;        // rayA rayB hit thr misc shA shB shL | smp | queue 0 1 2 | jx jy r g b
-    static constexpr size_t kLevelItems = (size_t)1 << 23;      // one level: 128 MB chunks for the 16-B arrays, 32 MB for the 4-B ones, every chunk of an array the same size
+    size_t levelItems = (size_t)1 << 23;      // items of one level, fixed while the ranges are reserved (every chunk of an array has the same size): 2^23 (128 MB chunks for the
+                                              // 16-B arrays, 32 MB for the 4-B ones) for a context asked to hold up to 2^27 items, 2^25 (512 / 128 MB) for a larger one
     static constexpr size_t kSmallMax = (size_t)1 << 23;
     int device;
     size_t capItems = 0;                      // items the virtual ranges (one per array) are reserved for; 0: no reservation (a small or empty context)
@@ -83,7 +89,7 @@ struct KzArena {
     struct Level { size_t firstItem, items; hipMemGenericAllocationHandle_t h[kArrays]; int mappedArrays; };
     std::vector<Level> levels;
     std::atomic<size_t> mapped{0};
-    std::mutex m; std::condition_variable cvWork, cvProgress; std::thread th;
+    std::mutex m; std::condition_variable cvProgress; std::thread th;
     bool stop = false, busy = false, growthFailed = false; size_t target = 0;
     std::atomic<int> failCountdown{0};        // kz_debug_fail_alloc: the nth physical allocation from now on fails
     int err = 0; std::string errMsg;
@@ -99,7 +105,7 @@ struct KzArena {
     void releaseAll();
     template <class Tp> Tp *array(int a) const { return (Tp *)base[a]; }
 private:
-    int reserve(size_t cap); int requestSmall(size_t items, size_t *got); void freeSmall();
+    int reserve(size_t cap, size_t firstTarget); int requestSmall(size_t items, size_t *got); void freeSmall();
     void growLoop(); bool growOneLevel(size_t first); void dropLevels(size_t keepLevels); void stopThread();
 };
 // path state + sample records + stage events of one pass in flight
@@ -122,6 +128,12 @@ struct PassCtx {
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
         if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
         if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
+    }
+    // buffers sized for another frame (a pooled context): given back when a call is short of memory (the caller has synchronised the device)
+    void trimAux(size_t pixNeeded) {
+        if (tapsCap > pixNeeded) { if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0; }
+        if (ovf) { (void)hipFree(ovf); ovf = nullptr; ovfCap = 0; }
+        if (litQueue) { (void)hipFree(litQueue); litQueue = nullptr; litCap = 0; }
     }
     void destroy() {
         release();
@@ -165,7 +177,7 @@ struct KzDeviceState {
     std::vector<std::pair<uint32_t, uint32_t>> beamDone; uint64_t beamDoneGen = 0;
     size_t beamBytes() const { return beamCap * (KZ_BEAM_CAP + 1) * sizeof(uint2); }
     size_t ctxBytes() const { size_t b = 0; for (const PassCtx *c : ctx) if (c) b += c->bytes(); return b; }
-    KzPassInfo lastInfo{};
+    KzPassInfo lastInfo{}; std::string growNote;
 };
 struct KzReplicaSet { std::mutex m; std::vector<KzDeviceState *> v; };
 

@@ -359,12 +359,24 @@ struct WfQueuePair {
 // the entries that still need the light sample and the BSDF sample are compacted through LDS (record = slot + frame + uv),
 // and pass B — which carries ~85 % of the kernel's instructions — only ever runs on full waves.
 #define KZ_SV_CAP (2 * KZ_BLOCK)
+// -DKZ_SHADE_CONST_ARGS (development build): the three argument structs of the shade kernel (KzParams 300 B, KzDevTables, KzWf) in
+// __constant__ memory, one slot per pass context, instead of in the kernel-argument segment - measured in profiles/r05c_shade_args.
+#ifdef KZ_SHADE_CONST_ARGS
+struct KzShadeArgs { KzParams P; KzDevTables T; KzWf W; };
+__constant__ KzShadeArgs g_kzShadeArgs[KZ_MAX_PASSES_IN_FLIGHT];
+#define KZ_SHADE_PARAMS int argSlot
+#define KZ_SHADE_BIND const KzParams &P = g_kzShadeArgs[argSlot].P; const KzDevTables &T = g_kzShadeArgs[argSlot].T; const KzWf &W = g_kzShadeArgs[argSlot].W;
+#else
+#define KZ_SHADE_PARAMS KzParams P, KzDevTables T, KzWf W
+#define KZ_SHADE_BIND
+#endif
 template <bool STATS, bool EXT>
-__global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
+__global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade(KZ_SHADE_PARAMS, const uint32_t *__restrict__ pixList, uint32_t S,
                                                         uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm,
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
                                                         uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
+    KZ_SHADE_BIND
     constexpr int SVW = EXT ? 20 : 16;                       // words per survivor: slot, p, s, t, n, uv, bsdf row (+ dpdu)
     __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
     // The survivor table is a stack; its fill count is double-buffered by round (s_svCnt[round & 1]) so that the count for the NEXT round can

@@ -163,6 +163,12 @@ class Scene:
         abi.check(self.lib, self.lib.kz_last_pass_info(self.h, C.byref(info)))
         return info.as_dict()
 
+    def last_grow_note(self):
+        """Why the pass context of the last render stopped growing short of its target ('' if it did not)."""
+        buf = C.create_string_buffer(512)
+        abi.check(self.lib, self.lib.kz_last_grow_note(self.h, buf, 512))
+        return buf.value.decode()
+
     def sync(self):
         abi.check(self.lib, self.lib.kz_sync(self.h))
 

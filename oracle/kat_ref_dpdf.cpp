@@ -8,7 +8,7 @@
 // merges it into tests/golden/int_kats.json).
 //   dpdf: for each list of pdf values (areas exactly representable as small integers x powers of two from 2^-20 to 2^10, so that a test can BUILD triangles
 //   with these areas; zero entries included): after append() x n and normalize() the sum, the normalisation and the whole CDF as float bit patterns; then
-//   sample(v) for v = 0, every CDF entry and its two float neighbours, 1 - ulp, 1, and a spread of others.
+//   sample(v) for v = 0, every CDF entry and its two float neighbours, 1 - ulp, 1, and a spread of others - with FTZ | DAZ set as the reference's main() sets them.
 //   pow4: isPowerOf4 over 1 .. 65536 (the true ones), and (roundUpPow4, log4i of it, the pixel tile 1 << (log4i(65536) - log4i(roundUpPow4(spp)))) for every spp
 //   in 1 .. 65536 at which the triple changes (sampler.cpp:291).
 #include <algorithm>
@@ -20,6 +20,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <xmmintrin.h>
 
 #define NAMESPACE_BEGIN(name) namespace name {
 #define NAMESPACE_END(name) }
@@ -37,6 +38,9 @@ static float fromBits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 int main() {
     using namespace kazen;
+    // the reference's arithmetic environment: main.cpp:22-23 turns flush-to-zero and denormals-are-zero on before anything runs, so a
+    // denormal draw compares as 0 against the table - as it does on the device (-fgpu-flush-denormals-to-zero) and in the oracle (FtzScope)
+    _mm_setcsr(_mm_getcsr() | 0x8040u);
     // areas = m * 2^e: m < 2^11, so (2 * area)^2 is exact in float and a right triangle with legs (area, 2) has exactly this area in the library's arithmetic
     auto A = [](int m, int e) { return std::ldexp((float)m, e); };
     const std::vector<std::vector<float>> sets = {

@@ -1987,7 +1987,7 @@ void kzo_debug_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNo
     sumAndNormalization[1] = dpdfNormalize(t, &sumAndNormalization[0]);
     std::memcpy(cdf, t.data(), t.size() * sizeof(float));
 }
-uint32_t kzo_debug_dpdf_sample(uint32_t nCdf, const float *cdf, float v) { return (uint32_t)dpdfSampleTable(std::vector<float>(cdf, cdf + nCdf), v); }
+uint32_t kzo_debug_dpdf_sample(uint32_t nCdf, const float *cdf, float v) { FtzScope ftz_; return (uint32_t)dpdfSampleTable(std::vector<float>(cdf, cdf + nCdf), v); }
 void kzo_debug_pow4(int spp, int *out4) { out4[0] = isPowerOf4(spp) ? 1 : 0; out4[1] = roundUpPow4(spp); out4[2] = log4i((uint32_t)out4[1]); out4[3] = pmjPixelTile((uint32_t)spp); }
 
 void kzo_bsdf(const KzBSDF *row, int which, const float *wi, const float *wo, float accRough, float s1, float s2x, float s2y, float *out) { FtzScope ftz_;

@@ -429,13 +429,16 @@ def test_failed_calls_release_their_device_memory(gpu_lib, kz):
             assert free_now() == before, (name, nth)
         call()                                                        # and the call works again afterwards
     # a render whose state buffers fail half way: nothing half-allocated is used afterwards
+    gpu_lib.kz_device_trim(0)                 # (no pass context of an earlier scene in the device's pool: this one allocates everything itself)
     big = kz.Scene(kz.scenes.cornell_box(64, 64, 4), device=0)
     before = free_now()
-    for nth in (1, 2, 5, 6, 8):               # (beam lists, beam heads | path records | a queue | the overflow stacks: what is already there is kept)
+    for nth in (1, 2, 3, 4, 5, 6):            # (beam lists, beam heads, the overflow stacks, tap sums, queue counters, a path-state array: what is already there is kept)
         gpu_lib.kz_debug_fail_alloc(nth)
-        with pytest.raises(kz.abi.KzError):
-            big.render()
-        gpu_lib.kz_debug_fail_alloc(0)
+        try:
+            with pytest.raises(kz.abi.KzError):
+                big.render()
+        finally:
+            gpu_lib.kz_debug_fail_alloc(0)
     assert free_now() <= before
     big.render()
     assert np.array_equal(big.film(), good)
@@ -518,8 +521,13 @@ def test_a_pass_context_that_is_still_growing_renders_the_same_film(gpu_lib, kz,
     assert info["passes"] >= 3 and info["firstPassItems"] < info["largestPassItems"] <= info["itemsPerPass"], info
     scale = float(np.abs(want).max())
     assert float(np.abs(got - want).max()) <= 1e-6 * scale
-    # the context the job grew is complete now: the same call again is ONE pass, bit-identical to the reference render
-    sc.render()
+    # once the context the job grew is complete the same call is ONE pass, bit-identical to the reference render
+    for _ in range(8):
+        sc.render()
+        sc.sync()
+        if sc.last_pass_info()["passes"] == 1:
+            break
+        time.sleep(0.05)
     assert sc.last_pass_info()["passes"] == 1 and np.array_equal(sc.film(), want)
 
 
@@ -527,6 +535,7 @@ def test_pass_contexts_outlive_their_replica(gpu_lib, kz):
     """kz_scene_destroy hands the replica's pass contexts to the device's pool: the next scene renders in them (no allocation, no wait for the driver's wipe
     of what the first one would have released); kz_device_trim gives the memory back."""
     gpu_lib.kz_device_trim(0)
+    time.sleep(1.0)                                                          # (what earlier tests left in the pool is back with the driver)
     free0 = _free_gb(gpu_lib)
     desc = kz.scenes.cornell_box(512, 512, 256)                               # 67 M items
     a = kz.Scene(desc, device=0)
@@ -542,4 +551,7 @@ def test_pass_contexts_outlive_their_replica(gpu_lib, kz):
     assert np.array_equal(b.film(), film_a)
     b.close()
     assert gpu_lib.kz_device_trim(0) == 0
-    assert _free_gb(gpu_lib) > free0 - 0.5                                   # everything back
+    t0 = time.perf_counter()                                                 # everything back (the driver reports released memory as free once it has wiped it: ~30 ms per GB)
+    while _free_gb(gpu_lib) <= free0 - 0.5 and time.perf_counter() - t0 < 10.0:
+        time.sleep(0.05)
+    assert _free_gb(gpu_lib) > free0 - 0.5
