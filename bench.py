@@ -153,9 +153,14 @@ def C_mem_info(lib):
 
 
 def run_cold_jobs(tris):
-    """The two cold jobs as child processes, BEFORE this process initialises HIP (no fork from a process that holds the GPU)."""
-    out = {}
-    for which in ("c4", "q1"):
+    """The cold jobs as child processes, BEFORE this process initialises HIP (no fork from a process that holds the GPU). Each job is measured on a QUIET GPU:
+    the driver wipes what a process releases at ~33 GB/s, and a process that starts inside that window waits for the whole wipe in its first larger
+    allocation, its GPU work with it (profiles/r05a_alloc) - so bench.py waits `QUIET_S` seconds after a child before it starts the next. What a job started
+    right BEHIND another one's exit costs is measured too, once (`c4_behind_a_release`), and reported beside the quiet numbers."""
+    QUIET_S = 6.0
+    out = {"quiet_seconds_between_jobs": QUIET_S}
+
+    def child(which):
         t0 = time.time()
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-job", which, "--tris", str(tris)], capture_output=True, text=True, timeout=300)
@@ -166,8 +171,19 @@ def run_cold_jobs(tris):
         except Exception as e:                                 # noqa: BLE001 - a failed side job must not cost the headline record
             rec = {"error": repr(e)}
         rec["process_s"] = round(time.time() - t0, 1)
-        log("cold job %s: %s" % (which, json.dumps(rec)))
-        out[which] = rec
+        return rec
+
+    time.sleep(QUIET_S)                                        # (whatever ran on this GPU before bench.py)
+    out["c4"] = child("c4")
+    log("cold job c4: %s" % json.dumps(out["c4"]))
+    time.sleep(QUIET_S)
+    out["q1"] = child("q1")
+    log("cold job q1: %s" % json.dumps(out["q1"]))
+    behind = child("c4")                                       # at once: the q1 job's pass context (~95 GB) is being wiped
+    behind["job"] = "the C4 job again, started the moment the q1 job's process has exited (no quiet time): what the driver's wipe of the predecessor's memory costs a job"
+    out["c4_behind_a_release"] = behind
+    log("cold job c4 behind a release: %s" % json.dumps(behind))
+    time.sleep(QUIET_S)
     return out
 
 
@@ -192,7 +208,7 @@ def main():
     if args.steps is None:
         args.steps = 1 if args.strong else 6
     if args.warmup is None:
-        args.warmup = 0 if args.strong else 1
+        args.warmup = 0 if args.strong else 4          # (the default pass size is earned call by call: 2^27 items, then doubling - the fourth call runs passes of 2^30)
     commit = os.environ.get("GRAFT_HEAD") or git_head()          # before torch / HIP are loaded: no fork from a process that has initialised the GPU
     cold = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.strong and not args.no_cold_job:

@@ -299,6 +299,14 @@ void kzCtxRelease(int device, PassCtx *c) {
     g_pool[device & 63].push_back(c);
 }
 
+// items of the largest pooled context of `device` (what the next replica's first context will hold when it takes it)
+size_t kzCtxPoolMaxItems(int device) {
+    std::lock_guard<std::mutex> g(g_poolMutex);
+    size_t n = 0;
+    for (PassCtx *c : g_pool[device & 63]) n = std::max(n, c->items());
+    return n;
+}
+
 size_t kzCtxPoolBytes(int device) {
     std::lock_guard<std::mutex> g(g_poolMutex);
     size_t b = 0;

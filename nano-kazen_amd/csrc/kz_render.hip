@@ -775,7 +775,24 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         else limit = (size_t)32 << 30;
     }
     const uint32_t nSamples = s1 - s0;
-    const size_t wantItems = std::max<size_t>(opts->passItems ? (size_t)opts->passItems : (autoShape ? (size_t)1 << (opts->dealer ? 29 : 30) : (size_t)1 << 27), 64);
+    // The default pass size (autoShape) is EARNED. A pass of 2^30 items is 5 % faster than passes of 2^27 (profiles/r04r_pass_size), but its 175 GB have a price
+    // that someone pays: memory a process releases is wiped by the driver at ~33 GB/s, and whoever allocates it before the wipe is through - the next job of a
+    // batch, a second process, this process's next scene - waits for the WHOLE wipe inside one allocation call, and the GPU work of that process waits with it
+    // (profiles/r05a_alloc: a one-frame job started right behind another one's exit sat 5.1 s in its first pass; growing the context on a side thread does not
+    // help, the device side of the process stalls). So a call gets a context its own work amortises - its (pixel, sample) items / 8, at least 2^27 - and a
+    // context that is already there may double with every further call: a one-frame job renders in passes of <= 1/8 of the frame and leaves little behind, a
+    // process that keeps rendering (bench.py's steps, a batch of scenes through the device's pool) is at 2^30 after three calls.
+    size_t earned = (size_t)1 << (opts->dealer ? 29 : 30);
+    if (autoShape) {
+        const size_t callItems = (size_t)ds->nPix * (s1 - s0) / (opts->dealer ? std::max<uint32_t>(1, opts->dealer->takers) : 1u);
+        size_t byWork = (size_t)1 << 27;
+        while (byWork * 2 <= callItems / 8) byWork *= 2;
+        // (what the context was last ASKED to hold, not what it holds: a context that is still growing - or growing slowly - earns the same as a complete one;
+        //  a fresh replica takes the pool's largest context and goes on from what that holds)
+        const size_t before = ds->ctx[0] ? std::max(ds->ctx[0]->wanted, ds->ctx[0]->items()) : kzCtxPoolMaxItems(ds->device);
+        earned = std::min(earned, std::max(byWork, 2 * before));
+    }
+    const size_t wantItems = std::max<size_t>(opts->passItems ? (size_t)opts->passItems : (autoShape ? earned : (size_t)1 << 27), 64);
     // Dynamic dealing (opts->dealer, ABI v5): the tile set is the whole list, a batch of tiles is a range of its pixel list, and the pass shape is
     // chosen for the pixels of a BATCH instead of those of the set.
     const KzTileDealer *dealer = opts->dealer;
@@ -901,6 +918,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     // Everything ELSE the call allocates is allocated now, before the first context is asked to grow: behind a wipe the growth thread takes whatever
     // clean memory there is the moment it appears, and a hipMalloc of this thread issued after that waits for the wipe like any other (round 5: the beam
     // lists, allocated inside the first pass, held the first call of a job for seconds while its context was already 80 GB large).
+    if (autoShape) for (int i = 0; i < nCtx; ++i) ds->ctxAt(i).wanted = need;
     KZ_TRACE("renderOn: %u pixels x samples [%u, %u), target pass %zu items (%u px x %u spp), limit %.1f GB, %d context(s)", ds->nPix, s0, s1, need, pixPerPass, S, limit / 1e9, nCtx);
     if (beams && (rc = ensureBeamBuffers(scene, ds, stream))) return rc;
     if (pipeline == 2) for (int i = 0; i < nCtx; ++i) if ((rc = ensureOverflow(scene, ds, ds->ctxAt(i), tune, multi ? ds->passStream[i] : stream))) return rc;

@@ -117,6 +117,7 @@ struct PassCtx {
     uint32_t *counts = nullptr;                                  // queue counters of a pass (8 x 520 words)
     uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
+    size_t wanted = 0;                                           // items the last call with the default schedule asked this context to hold (kz_render.hip: `earned`)
     uint64_t beamSeen = 0;                                       // the last beam-list build (KzDeviceState::beamSeq) this context's stream has waited for
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
     size_t items() const { return arena ? arena->mapped.load() : 0; }
@@ -124,7 +125,7 @@ struct PassCtx {
     // gives the memory back (the context stays usable: it grows again on demand); the caller has synchronised the device
     void release() {
         if (arena) arena->shrinkTo(0);
-        wf = KzWf{}; for (float *&q : plane) q = nullptr;
+        wf = KzWf{}; for (float *&q : plane) q = nullptr; wanted = 0;
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
         if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
         if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
@@ -147,6 +148,7 @@ struct PassCtx {
 PassCtx *kzCtxAcquire(int device);
 void kzCtxRelease(int device, PassCtx *c);
 size_t kzCtxPoolBytes(int device);
+size_t kzCtxPoolMaxItems(int device);
 size_t kzCtxPoolTrim(int device, size_t keepBytes);
 struct KzDeviceState {
     int device = -1;
