@@ -284,12 +284,23 @@ def main():
 
     scene.film_clear(stream)
     first_call_ms = None
+    grow_wait_s = 0.0
     for k in range(args.warmup):
         t_w = time.perf_counter()
         step(k)
+        torch.cuda.synchronize()
         if k == 0:                                        # what the timed region leaves out: the first call builds the beam lists of the rank's pixels and allocates the pass contexts
-            torch.cuda.synchronize()
             first_call_ms = round(1e3 * (time.perf_counter() - t_w), 2)
+        # Warm-up means "until the steady state": the pass context earns its size call by call (2^27 items, then doubling) and the library maps it on a side thread - at
+        # ~33 GB/s on memory the driver still has to wipe when the GPU is idle, an eighth of that under a render (profiles/r05d_cold_job). bench.py gives it the idle
+        # GPU between warm-up steps (bounded), so that the timed steps run on the context a process that keeps rendering ends up with.
+        t_g = time.perf_counter()
+        while time.perf_counter() - t_g < 8.0:
+            i_ = scene.last_pass_info()
+            if i_["contextItems"] >= i_["itemsPerPass"] or scene.last_grow_note():
+                break
+            time.sleep(0.05)
+        grow_wait_s += time.perf_counter() - t_g
     if world > 1 and args.warmup:                         # the gather's one-time costs (pinned staging buffer, /dev/shm pages) belong to the warm-up too
         kz.shard.gather_tiles(scene, tiles, scene.film_tiles(tiles), rank, world)
     barrier()
@@ -432,7 +443,7 @@ def main():
                                       % (name, args.tris, Wd, Hd, spp_table, spp_step, info["passes"], info["passesInFlight"], TILE, TILE),
                           "samples_per_step": int(float(px.item()) * spp_step), "bvh_nodes": bvh["nNodes"], "bvh_depth": bvh["maxDepth"],
                           "image_mean": round(float(rgb.mean()), 5), "commit": commit,
-                          "items_per_pass_per_rank": items_per_pass_per_rank, "sampler_table_spp": spp_table,
+                          "items_per_pass_per_rank": items_per_pass_per_rank, "sampler_table_spp": spp_table, "warmup_wait_for_context_s": round(grow_wait_s, 2),
                           "first_call_ms": first_call_ms, "first_call": "the first (warm-up) step: beam lists of every pixel (kz_wf_beam, once per pixel and replica), the pass context "
                                                                         "growing (its memory is mapped on a side thread while the first passes run), then the step itself; a timed step is ms_per_step"},
                "roofline": roofline, "cpu_baseline": cpu, "cold_job": cold}

@@ -118,7 +118,7 @@ class KzRenderOpts(C.Structure):
 class KzPassInfo(C.Structure):
     _fields_ = [("passes", C.c_uint32), ("passesInFlight", C.c_uint32), ("itemsPerPass", C.c_uint64), ("sppPerPass", C.c_uint32),
                 ("pixels", C.c_uint32), ("stateBytes", C.c_uint64), ("pixelsPerPass", C.c_uint32), ("reserved", C.c_uint32),
-                ("firstPassItems", C.c_uint64), ("largestPassItems", C.c_uint64)]
+                ("firstPassItems", C.c_uint64), ("largestPassItems", C.c_uint64), ("contextItems", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

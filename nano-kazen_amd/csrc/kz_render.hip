@@ -776,17 +776,17 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     }
     const uint32_t nSamples = s1 - s0;
     // The default pass size (autoShape) is EARNED. A pass of 2^30 items is 5 % faster than passes of 2^27 (profiles/r04r_pass_size), but its 175 GB have a price
-    // that someone pays: memory a process releases is wiped by the driver at ~33 GB/s, and whoever allocates it before the wipe is through - the next job of a
-    // batch, a second process, this process's next scene - waits for the WHOLE wipe inside one allocation call, and the GPU work of that process waits with it
-    // (profiles/r05a_alloc: a one-frame job started right behind another one's exit sat 5.1 s in its first pass; growing the context on a side thread does not
-    // help, the device side of the process stalls). So a call gets a context its own work amortises - its (pixel, sample) items / 8, at least 2^27 - and a
-    // context that is already there may double with every further call: a one-frame job renders in passes of <= 1/8 of the frame and leaves little behind, a
-    // process that keeps rendering (bench.py's steps, a batch of scenes through the device's pool) is at 2^30 after three calls.
+    // that someone pays: memory a process releases is wiped by the driver at ~33 GB/s, and whoever allocates before the wipe is through - the next job of a batch
+    // of one-frame processes, a second process, this process's next scene - waits for the WHOLE wipe inside one allocation call, and the GPU work of that process
+    // waits with it (profiles/r05a_alloc, r05d_cold_job: a one-frame job started right behind another one's exit sat 4-5 s in its first pass whatever the size of ITS
+    // context; growing the context on a side thread does not help, the device side of the process stalls). What a job CAN do is leave little behind. So the first
+    // call on a context asks for what rounds 1-3 ran with - 2^28 items (47 GB: 1.4 s of wiping for whoever comes next, passes 3 % slower than 2^30) when the call
+    // has at least 2^30 items of work, 2^27 otherwise - and a context may double with every further call: a one-frame job is over before the large pass would
+    // have paid, a process that keeps rendering (bench.py's steps, scene after scene through the device's pool) runs passes of 2^30 from its third or fourth call.
     size_t earned = (size_t)1 << (opts->dealer ? 29 : 30);
     if (autoShape) {
         const size_t callItems = (size_t)ds->nPix * (s1 - s0) / (opts->dealer ? std::max<uint32_t>(1, opts->dealer->takers) : 1u);
-        size_t byWork = (size_t)1 << 27;
-        while (byWork * 2 <= callItems / 8) byWork *= 2;
+        const size_t byWork = (size_t)1 << (callItems >= ((size_t)1 << 30) ? 28 : 27);
         // (what the context was last ASKED to hold, not what it holds: a context that is still growing - or growing slowly - earns the same as a complete one;
         //  a fresh replica takes the pool's largest context and goes on from what that holds)
         const size_t before = ds->ctx[0] ? std::max(ds->ctx[0]->wanted, ds->ctx[0]->items()) : kzCtxPoolMaxItems(ds->device);
@@ -1104,6 +1104,7 @@ int kz_last_pass_info(KzScene *scene, KzPassInfo *out) {
     if ((rc = requireDevice(scene, &ds))) return rc;
     if (!out) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
     *out = ds->lastInfo;
+    out->contextItems = ds->ctx[0] ? ds->ctx[0]->items() : 0;
     return KZ_OK;
 }
 
