@@ -202,6 +202,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--cold-job", choices=["c4", "q1"], default=None, help="(child process mode) run ONE cold job and print its record")
     ap.add_argument("--no-cold-job", action="store_true", help="N = 1: skip the two one-frame-per-process jobs that ride in the same JSON line")
+    ap.add_argument("--profile-pass", action="store_true", help="(scripts/profile_bench.sh) every step asks for ONE pass of 2^30 items explicitly instead of earning it call by call: "
+                                                                "the counter runs profile the first step of a process, and the pass they see must be the steady state's")
     args = ap.parse_args()
     if args.cold_job:
         return cold_job(args.cold_job, args.tris)
@@ -265,6 +267,8 @@ def main():
     kw = {}
     if shared_device:
         kw["max_state_bytes"] = int(0.8 * torch.cuda.mem_get_info(device_index)[1] / world)
+    if args.profile_pass:
+        kw.update(pass_items=1 << 30, passes_in_flight=1)
 
     def step(k, accumulate=True):
         # sample indices [s0, s0 + spp_step) modulo the table: a slice that wraps is rendered piece by piece

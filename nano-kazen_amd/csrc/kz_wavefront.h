@@ -257,6 +257,85 @@ __device__ __forceinline__ bool wfClassify(const KzParams &P, const KzDevTables 
     return survivor;
 }
 
+// -DKZ_SHADE_LATE_POST=1 (the variant DESIGN 9.1 named): pass A classifies on the INTERPOLATED NORMAL alone - the three vertex
+// normals and the flag word of the shading record (64 B of its 112) instead of the whole post-intersection - the survivors travel through LDS as the
+// 20-B hit record (slot, t, u, v, triangle), and the whole post-intersection (terminator offset, frames, uv) runs in pass B on full waves, where the exact
+// back-face test of wfClassify is repeated. Conservative: pass A ends a path only when dot(-d, sum b_i n_i) is negative beyond any rounding of the
+// normalisation that the exact test applies afterwards (the sign of a dot product with n / |n| is the sign with n, up to a few ulps of the sum of the
+// terms' magnitudes); an emitter hit does the full post-intersection at once (it needs the hit point and the normal, and ends the path).
+#ifndef KZ_SHADE_LATE_POST
+#define KZ_SHADE_LATE_POST 0
+#endif
+template <bool EXT>
+__device__ __forceinline__ bool wfClassifyLight(const KzParams &P, const KzDevTables &T, const KzWf &W, const uint32_t *__restrict__ pixList, uint32_t S, uint32_t sampleBegin,
+                                                int iter, bool compact, uint32_t slot, float4 &hitOut, KzSst &sst) {
+    const float4 h = kzLoadStream(&W.hit[slot]);
+    const float4 rb = kzLoadStream(&W.rayB[slot]);
+    const V3 rd = mk(rb.x, rb.y, rb.z);
+    hitOut = h;
+    if (!(h.x < KZ_INF)) {
+        if (iter > 0 && P.bgPresent) {
+            const float4 th = kzLoadStream(&W.thr[slot]);
+            const V3 c = mk(th.x, th.y, th.z) * backgroundRadiance(P, T, rd);
+            unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);
+        }
+        return false;
+    }
+    const float4 *sp = reinterpret_cast<const float4 *>(T.shade + __float_as_uint(h.w));
+    const float4 s6 = sp[6];
+    const uint32_t lf = __float_as_uint(s6.w);
+    if ((int32_t)(lf >> 2) - 1 >= 0) {                                            // an emitter: integrator.cpp:226-231, 322-327, exactly as wfClassify does it
+        RawHit rh; rh.t = h.x; rh.u = h.y; rh.v = h.z; rh.tri = 0; rh.gid = __float_as_uint(h.w);
+        Its its; postIntersect<false>(T, rh, its);
+        const KzLightRow &lr = T.lights[its.light];
+        const float4 ra = kzLoadStream(&W.rayA[slot]);
+        const float4 th = iter == 0 ? make_float4(1.f, 1.f, 1.f, 1.f) : kzLoadStream(&W.thr[slot]);
+        const float4 mi = iter == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : (compact ? make_float4(th.w, 0.f, 0.f, 0.f) : kzLoadStream(&W.misc[slot]));
+        const V3 ro = mk(ra.x, ra.y, ra.z);
+        const V3 wi = normalized(its.p - ro);
+        float bsdfWeight = 1.f;
+        if (iter > 0 && mi.z == 0.f) bsdfWeight = powerHeuristic(mi.x, lightPdfSolidAngle(lr.normalization, its.sh.n, wi, its.p, ro));
+        if (dot(its.sh.n, -wi) > 0.f) {
+            const V3 c = (bsdfWeight * mk(th.x, th.y, th.z)) * mk(lr.radiance[0], lr.radiance[1], lr.radiance[2]);
+            unsafeAtomicAdd(W.outR + slot, c.x); unsafeAtomicAdd(W.outG + slot, c.y); unsafeAtomicAdd(W.outB + slot, c.z);
+        }
+        return false;
+    }
+    bool twoSided = false;
+    if (EXT) { const int bt = T.bsdfs[__float_as_uint(s6.z)].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
+    bool survivor = true;
+    if (!twoSided) {
+        V3 n;
+        if (lf & 1u) {                                                            // vertex normals: the direction of the shading normal is sum b_i n_i (accel.cpp:177-229)
+            const float4 s2 = sp[2], s3 = sp[3], s4 = sp[4];
+            const float bx = 1 - (h.y + h.z);
+            n = bx * mk(s2.y, s2.z, s2.w) + h.y * mk(s3.x, s3.y, s3.z) + h.z * mk(s3.w, s4.x, s4.y);
+        } else {                                                                  // none: the geometric frame (accel.cpp:231-233)
+            const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
+            const V3 p0 = mk(s0.x, s0.y, s0.z);
+            n = cross(mk(s0.w, s1.x, s1.y) - p0, mk(s1.z, s1.w, s2.x) - p0);
+        }
+        const float wzA = -(rd.x * n.x + rd.y * n.y + rd.z * n.z), mag = fabsf(rd.x * n.x) + fabsf(rd.y * n.y) + fabsf(rd.z * n.z);
+        if (wzA < -1e-5f * mag) survivor = false;                                 // certainly below the horizon (NaN compares false: survives, as in wfClassify)
+    }
+    if (survivor && iter >= 3) {                                                  // Russian roulette in front of the compaction, as in wfClassify
+        const uint32_t pl = slot / S; const uint32_t pxy = pixList[pl];
+        Sampler smp; wfLoadSampler(P, W, slot, (int)(pxy & 0xffffu), (int)(pxy >> 16), sampleBegin + (slot - pl * S), smp, wfPmjDim(P, iter));
+        const float4 th = kzLoadStream(&W.thr[slot]);
+        V3 throughput = mk(th.x, th.y, th.z);
+        const float etaA = compact ? 1.f : th.w;
+        const float probability = fminf(maxCoeff(throughput) * etaA * etaA, 0.95f);
+        if (probability <= smp.next1D(P, T)) survivor = false;
+        else {
+            throughput = throughput / probability;
+            kzStoreStream(&W.thr[slot], make_float4(throughput.x, throughput.y, throughput.z, th.w));
+            wfStoreSampler(P, W, slot, smp);
+        }
+    }
+    sst.mark(0);
+    return survivor;
+}
+
 // Pass B of shade(iter) for one surviving path: light sample + BSDF eval / pdf + MIS weight -> pending radiance and shadow ray
 // (integrator.cpp:247-295), BSDF sample -> throughput and next ray (:297-313). (The roulette of integrator.cpp:237-244 was played in pass A.)
 template <bool STATS, bool EXT>
@@ -377,7 +456,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
                                                         uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
     KZ_SHADE_BIND
-    constexpr int SVW = EXT ? 20 : 16;                       // words per survivor: slot, p, s, t, n, uv, bsdf row (+ dpdu)
+    constexpr bool LATE = KZ_SHADE_LATE_POST && !STATS;      // (the counting variant keeps the exact classification in pass A: its counters follow the reference's order of events)
+    constexpr int SVW = LATE ? 5 : (EXT ? 20 : 16);          // words per survivor: slot, p, s, t, n, uv, bsdf row (+ dpdu) | LATE: slot + the hit record
     __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
     // The survivor table is a stack; its fill count is double-buffered by round (s_svCnt[round & 1]) so that the count for the NEXT round can
     // be written while this round's is still being read: a round then needs two workgroup barriers (records written | records read, output
@@ -403,10 +483,12 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
         bool survivor = false;
         uint32_t slot = 0;
         Its its;
+        float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (more && base + threadIdx.x < count) {
             const uint32_t qi = base + threadIdx.x;
             slot = queue ? queue[qi] : qi;
-            survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, cn, sst);
+            if (LATE) survivor = wfClassifyLight<EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, hrec, sst);
+            else survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, cn, sst);
         }
         sst.mark(0);                                        // pass A
         {   // compaction of the survivors onto the LDS record stack
@@ -417,12 +499,15 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             if (survivor) {
                 const uint32_t e = b + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 uint32_t *r = s_sv + e;
+                if (LATE) { r[0] = slot; r[KZ_SV_CAP] = __float_as_uint(hrec.x); r[2 * KZ_SV_CAP] = __float_as_uint(hrec.y); r[3 * KZ_SV_CAP] = __float_as_uint(hrec.z); r[4 * KZ_SV_CAP] = __float_as_uint(hrec.w); }
+                else {
                 r[0] = slot; r[KZ_SV_CAP] = __float_as_uint(its.p.x); r[2 * KZ_SV_CAP] = __float_as_uint(its.p.y); r[3 * KZ_SV_CAP] = __float_as_uint(its.p.z);
                 r[4 * KZ_SV_CAP] = __float_as_uint(its.sh.s.x); r[5 * KZ_SV_CAP] = __float_as_uint(its.sh.s.y); r[6 * KZ_SV_CAP] = __float_as_uint(its.sh.s.z);
                 r[7 * KZ_SV_CAP] = __float_as_uint(its.sh.t.x); r[8 * KZ_SV_CAP] = __float_as_uint(its.sh.t.y); r[9 * KZ_SV_CAP] = __float_as_uint(its.sh.t.z);
                 r[10 * KZ_SV_CAP] = __float_as_uint(its.sh.n.x); r[11 * KZ_SV_CAP] = __float_as_uint(its.sh.n.y); r[12 * KZ_SV_CAP] = __float_as_uint(its.sh.n.z);
                 r[13 * KZ_SV_CAP] = __float_as_uint(its.uvx); r[14 * KZ_SV_CAP] = __float_as_uint(its.uvy); r[15 * KZ_SV_CAP] = its.bsdf;
                 if (EXT) { r[16 * KZ_SV_CAP] = __float_as_uint(its.dpdu.x); r[17 * KZ_SV_CAP] = __float_as_uint(its.dpdu.y); r[18 * KZ_SV_CAP] = __float_as_uint(its.dpdu.z); }
+                }
             }
         }
         __syncthreads();
@@ -436,13 +521,25 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
         if (threadIdx.x < take) {
             const uint32_t *r = s_sv + (n0 - take) + threadIdx.x;
             slot = r[0];
+            bool alive = true;
+            if (LATE) {
+                // the whole post-intersection on a full wave, then wfClassify's exact test (pass A kept every hit it could not rule out)
+                RawHit rh; rh.t = __uint_as_float(r[KZ_SV_CAP]); rh.u = __uint_as_float(r[2 * KZ_SV_CAP]); rh.v = __uint_as_float(r[3 * KZ_SV_CAP]); rh.tri = 0; rh.gid = r[4 * KZ_SV_CAP];
+                postIntersect<false>(T, rh, its);
+                const float4 rb = kzLoadStream(&W.rayB[slot]);
+                const float wz = dot(-mk(rb.x, rb.y, rb.z), its.sh.n);
+                bool twoSided = false;
+                if (EXT) { const int bt = T.bsdfs[its.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
+                alive = (wz > 0.f) || twoSided || isnan(wz);
+            } else {
             its.p = mk(__uint_as_float(r[KZ_SV_CAP]), __uint_as_float(r[2 * KZ_SV_CAP]), __uint_as_float(r[3 * KZ_SV_CAP]));
             its.sh.s = mk(__uint_as_float(r[4 * KZ_SV_CAP]), __uint_as_float(r[5 * KZ_SV_CAP]), __uint_as_float(r[6 * KZ_SV_CAP]));
             its.sh.t = mk(__uint_as_float(r[7 * KZ_SV_CAP]), __uint_as_float(r[8 * KZ_SV_CAP]), __uint_as_float(r[9 * KZ_SV_CAP]));
             its.sh.n = mk(__uint_as_float(r[10 * KZ_SV_CAP]), __uint_as_float(r[11 * KZ_SV_CAP]), __uint_as_float(r[12 * KZ_SV_CAP]));
             its.uvx = __uint_as_float(r[13 * KZ_SV_CAP]); its.uvy = __uint_as_float(r[14 * KZ_SV_CAP]); its.bsdf = r[15 * KZ_SV_CAP];
             if (EXT) its.dpdu = mk(__uint_as_float(r[16 * KZ_SV_CAP]), __uint_as_float(r[17 * KZ_SV_CAP]), __uint_as_float(r[18 * KZ_SV_CAP]));
-            wfShadeSurvivor<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, pushNext, pushShadow, cn, sst);
+            }
+            if (alive) wfShadeSurvivor<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, pushNext, pushShadow, cn, sst);
         }
         sst.mark(7);                                        // next-ray stores (and, for lanes without a survivor, nothing)
         apN.push(pushNext, slot); apS.push(pushShadow, slot);
