@@ -163,10 +163,38 @@ int findReplica(const KzScene *scene, int device, KzDeviceState **out) {
 
 static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     int rc;
-    if ((rc = uploadVec(ds, scene->nodes, &ds->T.nodes))) return rc;
-    if ((rc = uploadVec(ds, scene->nodes4, &ds->T.nodes4))) return rc;
-    if ((rc = uploadVec(ds, scene->tris, &ds->T.tris))) return rc;
-    if ((rc = uploadVec(ds, scene->shade, &ds->T.shade))) return rc;
+    KZ_TRACE("upload: start (%.1f MB of tables)", (scene->nodes.size() * sizeof(scene->nodes[0]) + scene->nodes4.size() * sizeof(scene->nodes4[0]) + scene->tris.size() * sizeof(scene->tris[0]) + scene->shade.size() * sizeof(scene->shade[0])) / 1e6);
+    // The four large tables (C4: 248 MB; their allocations first, in this thread, so that a failure is this call's) travel side by side: a pageable copy is
+    // a chain of host memcpys into the runtime's pinned staging buffers and DMA transfers out of them, one chain per calling thread - four threads in
+    // flight took the upload of C4 from 45 to 36 ms (profiles/r05d_cold_job; the FIRST process on a freshly leased box spends 170 ms here either way: the
+    // first transfers of a box wake something up that no later process pays for)
+    {
+        struct Job { const void *src; void *dst; size_t bytes; hipError_t err; };
+        Job jobs[4] = {};
+        auto prep = [&](auto &vec, auto **out, Job &j) -> int {
+            using Tp = typename std::remove_reference<decltype(vec)>::type::value_type;
+            *out = nullptr;
+            void *p = nullptr;
+            const size_t bytes = vec.empty() ? 256 : vec.size() * sizeof(Tp);
+            KZ_ALLOC(&p, bytes);
+            ds->allocs.push_back(p);
+            if (vec.empty()) HIP_TRY(hipMemset(p, 0, bytes));
+            *out = (const Tp *)p;
+            j = Job{vec.empty() ? nullptr : (const void *)vec.data(), p, bytes, hipSuccess};
+            return KZ_OK;
+        };
+        if ((rc = prep(scene->nodes, &ds->T.nodes, jobs[0]))) return rc;
+        if ((rc = prep(scene->nodes4, &ds->T.nodes4, jobs[1]))) return rc;
+        if ((rc = prep(scene->tris, &ds->T.tris, jobs[2]))) return rc;
+        if ((rc = prep(scene->shade, &ds->T.shade, jobs[3]))) return rc;
+        std::vector<std::thread> th;
+        const int dev = ds->device;
+        for (Job &j : jobs) if (j.src && j.bytes >= ((size_t)4 << 20)) th.emplace_back([&j, dev] { j.err = hipSetDevice(dev); if (j.err == hipSuccess) j.err = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice); });
+        for (Job &j : jobs) if (j.src && j.bytes < ((size_t)4 << 20)) j.err = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
+        for (std::thread &t : th) t.join();
+        for (Job &j : jobs) if (j.err != hipSuccess) return kz_fail(KZ_ERR_HIP, "upload of a scene table (%zu bytes) failed: %s", j.bytes, hipGetErrorString(j.err));
+    }
+    KZ_TRACE("upload: nodes, nodes4, tris, shade there");
     if ((rc = uploadVec(ds, scene->meshRows, &ds->T.meshes))) return rc;
     if ((rc = uploadVec(ds, scene->bsdfs, &ds->T.bsdfs))) return rc;
     if ((rc = uploadVec(ds, scene->lightRows, &ds->T.lights))) return rc;
@@ -184,13 +212,16 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     if ((rc = uploadVec(ds, scene->texels, &ds->T.texels))) return rc;
     const KzParams &P = scene->prm;
     ds->filmPixels = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border);
+    KZ_TRACE("upload: small tables there");
     KZ_ALLOC(&ds->film, ds->filmPixels * sizeof(float4));
     HIP_TRY(hipMemset(ds->film, 0, ds->filmPixels * sizeof(float4)));
     KZ_ALLOC(&ds->stats, 32 * sizeof(unsigned long long));             // 8 counters of KzStats + 16 lane statistics of the -DKZ_LANESTAT development build + 3 beam-list counters
     HIP_TRY(hipMemset(ds->stats, 0, 32 * sizeof(unsigned long long)));
     { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, ds->device)); ds->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; ds->totalMem = prop.totalGlobalMem; }
     { int rc_ = kzFilmInit(); if (rc_) return rc_; }
+    KZ_TRACE("upload: film + counters there");
     HIP_TRY(hipDeviceSynchronize());
+    KZ_TRACE("upload: done");
     return KZ_OK;
 }
 
@@ -225,7 +256,9 @@ int kz_scene_upload(KzScene *scene, int device) {
         std::lock_guard<std::mutex> g(rs->m);
         for (KzDeviceState *d : rs->v) if (d->device == device) return KZ_OK;       // already resident
     }
+    KZ_TRACE("kz_scene_upload(%d)", device);
     HIP_TRY(hipSetDevice(device));
+    KZ_TRACE("upload: hipSetDevice done");
     KzDeviceState *ds = new KzDeviceState();
     ds->device = device;
     const int rc = uploadReplica(scene, ds);
