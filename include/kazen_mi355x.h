@@ -263,8 +263,9 @@ typedef struct KzTuning {
     int32_t dev0;
     int32_t packetPrimary;      /* primary rays: 0 = default (pixel beams, else shared-stack packet traversal), 1 = per-lane, 2 = packet */
     int32_t dev1, dev2;
-    int32_t filmGather;         /* film reconstruction: 0 = default (per-pixel tap sums + apply for filters of <= 5 taps per axis, the staged
-                                   gather otherwise), 1 = always the staged gather kernel of round 1 */
+    int32_t filmGather;         /* film reconstruction: 0 = default (per-pixel tap sums + apply for filters of <= 5 taps per axis - two lanes per pixel since round 5 -,
+                                   the staged gather otherwise), 1 = always the staged gather kernel of round 1, 3 = the tap sums with one lane per pixel
+                                   (round 2's kernel, kept for comparison: the same sums bit for bit) */
     int32_t dev3;
     int32_t sppPerPass;         /* samples of a pixel per pass: 0 = default. A pass covers pixPerPass x sppPerPass = passItems (pixel, sample)
                                    items: sppPerPass = 0 means "every pixel of the tile set, as many samples as fit" - unless fewer than 64 would

@@ -189,6 +189,87 @@ __global__ __launch_bounds__(64) void kz_film_taps(KzParams P, const float *__re
     }
 }
 
+// kz_film_taps with TWO lanes per pixel (the default since round 5; KzTuning.filmGather = 3 selects the one-lane kernel above; profiles/r05h_film_taps): the 25 (rgb w, w)
+// accumulators of a pixel hold kz_film_taps<5> at 159 VGPRs and 3 waves per SIMD, and its staging area - 8 samples of 64 pixels - lets it read only 32-B pieces of the
+// sample rows: every 64-B HBM sector is fetched twice (42 GB per 2^30-item pass for 21 GB of records, L2 hit 1 %: profiles/r04z_round4). Here a wave is 32 pixels: lanes 0-31 carry the tap ROWS 0 .. ceil(TAPS / 2) - 1 of their pixel, lanes 32-63 the
+// remaining rows of the same 32 pixels - 15 and 10 accumulators instead of 25. Every accumulator still receives the same products in the same (sample) order, so the
+// tap sums are kz_film_taps' bit for bit; what is paid is the per-sample set-up (validity, footprint, the x weights) twice. With half the pixels per wave the same
+// 10.4 KB stage 16 samples a round: 64-B pieces, whole sectors. Film stage of a 2^30-item pass of C4 12.6 -> 10.5 ms, C3 (2^27 items) 1.98 -> 1.64 ms; occupancy alone
+// (8-sample rounds, two lanes) changed nothing: the one-lane kernel was bound by its doubled fetch.
+#ifndef KZ_TAPS2_CHUNK
+#define KZ_TAPS2_CHUNK 16                    // samples per staging round: 64-B pieces of every sample row = whole HBM sectors (the 32-B pieces of kz_film_taps fetch every sector twice)
+#endif
+template <int TAPS>
+__global__ __launch_bounds__(64) void kz_film_taps2(KzParams P, const float *__restrict__ filter, const uint32_t *__restrict__ pixList, uint32_t nPix, uint32_t S,
+                                                    const float *__restrict__ inJx, const float *__restrict__ inJy, const float *__restrict__ inR,
+                                                    const float *__restrict__ inG, const float *__restrict__ inB, float4 *__restrict__ tapSums) {
+    constexpr int R0 = (TAPS + 1) / 2;                                 // tap rows of the first half (the second half carries TAPS - R0 <= R0 rows)
+    __shared__ float s_filter[KZ_FILTER_RESOLUTION + 1];
+    __shared__ float s_in[5][KZ_TAPS2_CHUNK][33];
+    const int lane = threadIdx.x, pixLane = lane & 31, half = lane >> 5;
+    if (lane <= KZ_FILTER_RESOLUTION) s_filter[lane] = filter[lane];
+    const uint32_t pl0 = blockIdx.x * 32u, pl = pl0 + (uint32_t)pixLane;
+    const bool havePixel = pl < nPix;
+    const uint32_t pxy = havePixel ? pixList[pl] : 0u;
+    const int px = (int)(pxy & 0xffffu), py = (int)(pxy >> 16);
+    const int bx0 = px & ~31, by0 = py & ~31;
+    const float r = P.filterRadius, lf = P.lookupFactor;
+    const int ty0 = half ? R0 : 0, nRowsMine = half ? TAPS - R0 : R0;
+    float xb[TAPS], yb[R0];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) xb[t] = (float)(px + P.border - P.tapLo - t - bx0);
+#pragma unroll
+    for (int t = 0; t < R0; ++t) yb[t] = (float)(py + P.border - P.tapLo - (ty0 + t) - by0);
+    float4 acc[R0 * TAPS];
+#pragma unroll
+    for (int i = 0; i < R0 * TAPS; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *const in[5] = {inJx, inJy, inR, inG, inB};
+    const uint32_t nRows = min(32u, nPix - min(nPix, pl0));
+    for (uint32_t c0 = 0; c0 < S; c0 += KZ_TAPS2_CHUNK) {
+        const uint32_t n = min((uint32_t)KZ_TAPS2_CHUNK, S - c0);
+        __syncthreads();
+        for (uint32_t i = lane; i < nRows * KZ_TAPS2_CHUNK; i += 64u) {
+            const uint32_t p = i / KZ_TAPS2_CHUNK, k = i % KZ_TAPS2_CHUNK;
+            if (k < n) {
+                const size_t gi = (size_t)(pl0 + p) * S + c0 + k;
+#pragma unroll
+                for (int a = 0; a < 5; ++a) s_in[a][k][p] = in[a][gi];
+            }
+        }
+        __syncthreads();
+        if (havePixel) {
+            for (uint32_t k = 0; k < n; ++k) {
+                const float jx = s_in[0][k][pixLane], jy = s_in[1][k][pixLane];
+                float cr = s_in[2][k][pixLane], cg = s_in[3][k][pixLane], cb = s_in[4][k][pixLane];
+                const bool valid = cr >= 0.f && cg >= 0.f && cb >= 0.f && isfinite(cr) && isfinite(cg) && isfinite(cb);
+                if (!valid) continue;
+                const float posx = ((float)px + jx) - 0.5f - (float)(bx0 - P.border), posy = ((float)py + jy) - 0.5f - (float)(by0 - P.border);
+                const float lox = ceilf(posx - r), hix = floorf(posx + r), loy = ceilf(posy - r), hiy = floorf(posy + r);
+                float wx[TAPS], wy[R0];
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) wx[t] = !(xb[t] < lox || xb[t] > hix) ? s_filter[(int)(fabsf(xb[t] - posx) * lf)] : 0.f;
+#pragma unroll
+                for (int t = 0; t < R0; ++t) wy[t] = (t < nRowsMine && !(yb[t] < loy || yb[t] > hiy)) ? s_filter[(int)(fabsf(yb[t] - posy) * lf)] : 0.f;
+#pragma unroll
+                for (int ty = 0; ty < R0; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < TAPS; ++tx) {
+                        float4 &a = acc[ty * TAPS + tx];
+                        a.x += cr * wx[tx] * wy[ty]; a.y += cg * wx[tx] * wy[ty]; a.z += cb * wx[tx] * wy[ty]; a.w += 1.0f * wx[tx] * wy[ty];
+                    }
+            }
+        }
+    }
+    if (havePixel) {
+#pragma unroll
+        for (int ty = 0; ty < R0; ++ty)
+            if (ty < nRowsMine) {
+#pragma unroll
+                for (int tx = 0; tx < TAPS; ++tx) tapSums[(size_t)((ty0 + ty) * TAPS + tx) * nPix + pl] = acc[ty * TAPS + tx];
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void kz_film_apply(KzParams P, const int32_t *__restrict__ pixIndex, const float4 *__restrict__ tapSums, uint32_t p0, uint32_t nPix, float4 *__restrict__ film) {
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border;
     const int fx = blockIdx.x * 16 + (threadIdx.x & 15), fy = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -270,14 +351,17 @@ int kzFilmInit() {
 
 // The film stage of one pass (called by renderOn, kz_render.hip). With tap sums (filters of <= KZ_TAPS_MAX taps per axis): two kernels, every sample record
 // read once; the tap sums do not depend on the film, only kz_film_apply waits for the film of the pass before (`waitFilm`).
-int kzFilmStage(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t pst, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t Sp, bool tapSums, hipEvent_t waitFilm) {
+int kzFilmStage(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t pst, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t Sp, bool tapSums, hipEvent_t waitFilm, bool twoLanes) {
     const KzParams &P = scene->prm;
     const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border, ftaps = P.tapHi - P.tapLo + 1;
     float *sJx = c.plane[0], *sJy = c.plane[1], *sR = c.plane[2], *sG = c.plane[3], *sB = c.plane[4];
     const dim3 fgrid((cols + KZ_FILM_TILE - 1) / KZ_FILM_TILE, (rows + KZ_FILM_TILE - 1) / KZ_FILM_TILE);
     if (tapSums) {
 #define KZ_FILM_TAPS(N) hipLaunchKernelGGL(kz_film_taps<N>, dim3((nPixPass + 63) / 64), dim3(64), 0, pst, P, ds->T.filter, pixList, nPixPass, Sp, sJx, sJy, sR, sG, sB, (float4 *)c.taps)
-        switch (ftaps) { case 1: KZ_FILM_TAPS(1); break; case 2: KZ_FILM_TAPS(2); break; case 3: KZ_FILM_TAPS(3); break; case 4: KZ_FILM_TAPS(4); break; default: KZ_FILM_TAPS(5); break; }
+#define KZ_FILM_TAPS2(N) hipLaunchKernelGGL(kz_film_taps2<N>, dim3((nPixPass + 31) / 32), dim3(64), 0, pst, P, ds->T.filter, pixList, nPixPass, Sp, sJx, sJy, sR, sG, sB, (float4 *)c.taps)
+        if (twoLanes) switch (ftaps) { case 1: KZ_FILM_TAPS2(1); break; case 2: KZ_FILM_TAPS2(2); break; case 3: KZ_FILM_TAPS2(3); break; case 4: KZ_FILM_TAPS2(4); break; default: KZ_FILM_TAPS2(5); break; }
+        else switch (ftaps) { case 1: KZ_FILM_TAPS(1); break; case 2: KZ_FILM_TAPS(2); break; case 3: KZ_FILM_TAPS(3); break; case 4: KZ_FILM_TAPS(4); break; default: KZ_FILM_TAPS(5); break; }
+#undef KZ_FILM_TAPS2
 #undef KZ_FILM_TAPS
         if (waitFilm) HIP_TRY(hipStreamWaitEvent(pst, waitFilm, 0));
         hipLaunchKernelGGL(kz_film_apply, fgrid, dim3(256), 0, pst, P, ds->pixIndex, (const float4 *)c.taps, p0, nPixPass, ds->film);

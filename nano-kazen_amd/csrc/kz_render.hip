@@ -1011,7 +1011,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         HIP_TRY(hipEventRecord(ep.b, pst));
         HIP_TRY(hipGetLastError());
         const int prev = (ci + nCtx - 1) % nCtx;
-        if ((rc = kzFilmStage(scene, ds, c, pst, pixList, p0, nPixPass, Sp, tapSums, (multi && pass > 0) ? ds->evFilm[prev] : nullptr))) return rc;
+        if ((rc = kzFilmStage(scene, ds, c, pst, pixList, p0, nPixPass, Sp, tapSums, (multi && pass > 0) ? ds->evFilm[prev] : nullptr, tune.filmGather != 3))) return rc;
         if (multi || dealer) { HIP_TRY(hipEventRecord(ds->evFilm[ci], pst)); inFlight[ci] = true; }      // (a dealer paces itself on this event even with one context)
         if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
         ds->lastCtx = ci;

@@ -192,5 +192,5 @@ int checkTiles(const KzParams &P, const KzTile *tiles, uint32_t nTiles);
 int downloadTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, uint32_t nTiles, float *packed, size_t nFloats, hipStream_t stream);
 int kzFilmInit();
 // The film stage of one pass (ImageBlock::put for every sample record of the pass): launches on `pst`; `waitFilm` (or null) is the event the film's read-modify-write waits for.
-int kzFilmStage(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t pst, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t Sp, bool tapSums, hipEvent_t waitFilm);
+int kzFilmStage(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t pst, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t Sp, bool tapSums, hipEvent_t waitFilm, bool twoLanes = false);
 #define KZ_TAPS_MAX 5                        // gaussian / mitchell radius 2: taps -2..2

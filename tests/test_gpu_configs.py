@@ -351,7 +351,19 @@ def test_state_budget_and_pass_options(gpu_lib, kz, O):
     assert np.array_equal(sc.film(), one_at_a_time)
     sc.render(pass_items=npx * 4, tune={"packetPrimary": 2})
     assert np.array_equal(sc.film(), one_at_a_time)
-    # film reconstruction: per-pixel tap sums + apply (default) vs the staged gather of round 1: same weights, another summation order
+    # film reconstruction: the tap sums with two lanes per pixel (default, round 5) are the one-lane kernel's of round 2 bit for bit, for every filter width
+    sc.render(pass_items=npx * 4, tune={"filmGather": 3})
+    assert np.array_equal(sc.film(), one_at_a_time)
+    for filt in ("tent", "box", "mitchell"):
+        d2 = kz.scenes.cornell_box(96, 80, 8)
+        d2.camera["rfilter"] = {"type": filt}
+        s2 = kz.Scene(d2, device=0)
+        s2.render()
+        f2 = s2.film()
+        s2.render(tune={"filmGather": 3})
+        assert np.array_equal(s2.film(), f2), filt
+        s2.close()
+    # per-pixel tap sums + apply (default) vs the staged gather of round 1: same weights, another summation order
     sc.render(pass_items=npx * 4, tune={"filmGather": 1})
     assert np.allclose(sc.film(), one_at_a_time, rtol=2e-5, atol=1e-5)
     sc.render(pass_items=1920 * 4, passes_in_flight=2, tune={"filmGather": 1, "sppPerPass": 4})
