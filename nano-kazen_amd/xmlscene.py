@@ -217,22 +217,51 @@ def load_obj(path, to_world=None):
     pos, tex, nrm = [], [], []
     vmap, verts, idx = {}, [], []
     M = np.eye(4, dtype=np.float32) if to_world is None else np.asarray(to_world, np.float32)
-    Mn = np.linalg.inv(M.astype(np.float64))[:3, :3].T.astype(np.float32)       # Transform::operator*(Normal3f), transform.h:54-56
+    f32 = np.float32
+
+    def xf_point(p):
+        """Transform * Point3f (transform.h:59-62) in float, operation for operation what the C++ mirror's Transform::point does: the two loaders hand the
+        library the same vertices bit for bit (tests/test_host_mirror.py renders the XML fixtures through both)"""
+        q = [f32(f32(f32(f32(M[i, 0] * p[0]) + f32(M[i, 1] * p[1])) + f32(M[i, 2] * p[2])) + M[i, 3]) for i in range(4)]
+        return np.array([q[0] / q[3], q[1] / q[3], q[2] / q[3]], np.float32)
+
+    a = [float(v) for v in M.reshape(-1)]                    # Transform * Normal3f (transform.h:54-56): inverse transpose of the upper 3x3, the 4x4 inverse formed in
+    inv = {}                                                 # double by cofactors - the C++ mirror's Transform::normal, expression for expression
+    inv[0] = a[5]*a[10]*a[15]-a[5]*a[11]*a[14]-a[9]*a[6]*a[15]+a[9]*a[7]*a[14]+a[13]*a[6]*a[11]-a[13]*a[7]*a[10]
+    inv[4] = -a[4]*a[10]*a[15]+a[4]*a[11]*a[14]+a[8]*a[6]*a[15]-a[8]*a[7]*a[14]-a[12]*a[6]*a[11]+a[12]*a[7]*a[10]
+    inv[8] = a[4]*a[9]*a[15]-a[4]*a[11]*a[13]-a[8]*a[5]*a[15]+a[8]*a[7]*a[13]+a[12]*a[5]*a[11]-a[12]*a[7]*a[9]
+    inv[12] = -a[4]*a[9]*a[14]+a[4]*a[10]*a[13]+a[8]*a[5]*a[14]-a[8]*a[6]*a[13]-a[12]*a[5]*a[10]+a[12]*a[6]*a[9]
+    inv[1] = -a[1]*a[10]*a[15]+a[1]*a[11]*a[14]+a[9]*a[2]*a[15]-a[9]*a[3]*a[14]-a[13]*a[2]*a[11]+a[13]*a[3]*a[10]
+    inv[5] = a[0]*a[10]*a[15]-a[0]*a[11]*a[14]-a[8]*a[2]*a[15]+a[8]*a[3]*a[14]+a[12]*a[2]*a[11]-a[12]*a[3]*a[10]
+    inv[9] = -a[0]*a[9]*a[15]+a[0]*a[11]*a[13]+a[8]*a[1]*a[15]-a[8]*a[3]*a[13]-a[12]*a[1]*a[11]+a[12]*a[3]*a[9]
+    inv[2] = a[1]*a[6]*a[15]-a[1]*a[7]*a[14]-a[5]*a[2]*a[15]+a[5]*a[3]*a[14]+a[13]*a[2]*a[7]-a[13]*a[3]*a[6]
+    inv[6] = -a[0]*a[6]*a[15]+a[0]*a[7]*a[14]+a[4]*a[2]*a[15]-a[4]*a[3]*a[14]-a[12]*a[2]*a[7]+a[12]*a[3]*a[6]
+    inv[10] = a[0]*a[5]*a[15]-a[0]*a[7]*a[13]-a[4]*a[1]*a[15]+a[4]*a[3]*a[13]+a[12]*a[1]*a[7]-a[12]*a[3]*a[5]
+    det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12]
+
+    def xf_normal(n):
+        n = [float(v) for v in n]
+        if det == 0.0:
+            r = n
+        else:
+            r = [(inv[0] * n[0] + inv[4] * n[1] + inv[8] * n[2]) / det, (inv[1] * n[0] + inv[5] * n[1] + inv[9] * n[2]) / det, (inv[2] * n[0] + inv[6] * n[1] + inv[10] * n[2]) / det]
+        r = [f32(v) for v in r]
+        l2 = f32(f32(f32(r[0] * r[0]) + f32(r[1] * r[1])) + f32(r[2] * r[2]))
+        if l2 > 0:
+            ln = np.sqrt(l2, dtype=np.float32)
+            r = [r[0] / ln, r[1] / ln, r[2] / ln]
+        return np.array(r, np.float32)
     with open(path, "r") as f:
         for line in f:
             tok = line.split()
             if not tok:
                 continue
             if tok[0] == "v":
-                p = np.array([float(tok[1]), float(tok[2]), float(tok[3]), 1.0], np.float32)
-                q = M @ p
-                pos.append(q[:3] / q[3])
+                pos.append(xf_point([f32(tok[1]), f32(tok[2]), f32(tok[3])]))
             elif tok[0] == "vt":
                 tex.append((float(tok[1]), float(tok[2])))
             elif tok[0] == "vn":
-                n = Mn @ np.array([float(tok[1]), float(tok[2]), float(tok[3])], np.float32)
-                ln = np.linalg.norm(n)
-                nrm.append(n / ln if ln > 0 else n)
+                nrm.append(xf_normal([f32(tok[1]), f32(tok[2]), f32(tok[3])]))
             elif tok[0] == "f":
                 vs = tok[1:5]
                 keys = []

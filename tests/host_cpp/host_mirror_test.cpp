@@ -174,6 +174,18 @@ int main(int argc, char **argv) {
         std::printf("{\"pixels\": %zu, \"devices\": %zu}\n", rgb.size() / 3, devs.size());
         return 0;
     }
+    if (argc >= 4 && !std::strcmp(argv[1], "--render-in-turn")) {    // ONE DeviceScene rendered on each device of the list in turn: argv[2] = output stem, argv[3] = "0,1,.."
+        std::unique_ptr<Scene> scene(buildScene());
+        mi355x::DeviceScene ds(scene.get());
+        int n = 0;
+        for (const char *c = argv[3]; *c;) {
+            const int dev = std::atoi(c); while (*c && *c != ',') ++c; if (*c == ',') ++c;
+            std::vector<float> rgb = renderRgb(ds, scene.get(), {dev});            // (the film comes from the device that rendered it: kz_render_tiles hands it back)
+            std::ofstream(std::string(argv[2]) + "." + std::to_string(n++), std::ios::binary).write((const char *)rgb.data(), (std::streamsize)(rgb.size() * sizeof(float)));
+        }
+        std::printf("{\"renders\": %d}\n", n);
+        return 0;
+    }
     if (argc >= 3 && !std::strcmp(argv[1], "--render-png")) {        // renderer::render(scene, filename) (renderer.cpp:72-153)
         std::unique_ptr<Scene> scene(buildScene());
         renderer::render(scene.get(), std::string(argv[2]));          // the adapter's drop-in itself: every visible GPU, <stem>.png

@@ -87,6 +87,21 @@ def test_cpp_multi_device_render_equals_single_device(exe, kz, gpu_lib, tmp_path
     assert a.shape == b.shape and float(np.sqrt(np.mean((a - b) ** 2))) < 1e-5
 
 
+@pytest.mark.gpu
+def test_cpp_same_scene_on_each_device_in_turn(exe, kz, gpu_lib, tmp_path):
+    """ADVICE r04: renderer::render(scene, device) once read the film of the PRIMARY replica whatever device it had rendered on. The adapter's DeviceScene gets the film
+    from the device that rendered it (kz_render_tiles hands it back): one scene rendered on every device of the box in turn (twice on device 0 where there is only one:
+    a second render must not see the first one's film either) gives the same picture every time."""
+    n = min(gpu_lib.kz_device_count(), 8)
+    devs = ",".join(str(d) for d in range(n)) if n > 1 else "0,0"
+    stem = str(tmp_path / "turn")
+    info = json.loads(subprocess.check_output([exe, "--render-in-turn", stem, devs]).decode())
+    films = [np.fromfile("%s.%d" % (stem, k), np.float32) for k in range(info["renders"])]
+    assert len(films) == len(devs.split(",")) and films[0].mean() > 0.01
+    for f in films[1:]:
+        assert np.array_equal(f.view(np.uint32), films[0].view(np.uint32))
+
+
 # ---------------------------------------------------------------- SURVEY 8f rank 4 through the plugin surface
 def _write_ppm(path, img):
     with open(path, "wb") as f:
