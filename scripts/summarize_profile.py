@@ -16,12 +16,12 @@ dst = os.path.join(root, "profiles", name)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench.json"))
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-st = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+st = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if st:
     shutil.copy(st[0], os.path.join(dst, "kernel_stats.csv"))
 # With two passes in flight the kernel durations of the trace overlap; the per-pass figure comparable with bench.py's
 # roofline.pass_ms_in_flight is the steady-state distance between the ends of consecutive film kernels (one per pass).
-tr = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+tr = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
 if tr:
     ends = sorted(int(r["End_Timestamp"]) for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith(("kz_film_gather", "kz_film_apply")))
     gaps = sorted((b - a) / 1e6 for a, b in zip(ends, ends[1:]))
@@ -38,7 +38,13 @@ def short(k):
     k = k.split("(")[0].replace("void ", "")
     return k
 disp = defaultdict(dict); names = {}
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+def newest(pattern):
+    """One file per counter group: a tag profiled twice leaves both runs' CSVs behind, and summing them doubles every count."""
+    groups = defaultdict(list)
+    for f in glob.glob(pattern):
+        groups[os.path.dirname(f)].append(f)
+    return [max(fs, key=os.path.getmtime) for fs in groups.values()]
+for f in newest(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = short(row["Kernel_Name"])
         if not k.startswith("kz_"):
