@@ -368,7 +368,7 @@ def _owen_scramble(x, seed):
         return _reverse_bits32(x)
 
 
-def make_pmj02bn_tables(seed=2022):
+def make_pmj02bn_tables(seed=2022, dither="void_and_cluster"):
     """Build-generated stand-ins for pmj02bnSamples[5][65536][2] / BlueNoiseTextures[48][128][128].
 
     The reference's table sources (src/kazen/pmj02table.cpp, bluenoise.cpp) are missing from the
@@ -376,8 +376,10 @@ def make_pmj02bn_tables(seed=2022):
     Owen-scrambled (0,2)-sequences (base-2 Sobol' pair): every prefix of 4^k points is a (0,2k,2)-net,
     which is the stratification property the PMJ02BN constructor relies on (sampler.cpp:295-314).
     The low 8 bits are cleared so that value * 2^-32 never rounds to 1.0f (the reference would index
-    out of range there). The "blue noise" textures are plain white noise (hash) — spectral quality is
-    not on the parity path. A user of the real tables passes them through KzSampler unchanged.
+    out of range there). The dither textures are genuine blue noise since round 5 (void-and-cluster,
+    `blue_noise_textures`; rounds 1-4: white noise, still there as dither="white") — spectral quality is
+    not on the parity path, but it is what the sampler's per-pixel shifts exist for (bluenoise.h:16-23,
+    sampler.cpp:339-365). A user of the real tables passes them through KzSampler unchanged.
     """
     n = abi.KZ_PMJ02BN_SAMPLES
     i = np.arange(n, dtype=np.uint32)
@@ -392,7 +394,12 @@ def make_pmj02bn_tables(seed=2022):
         pmj[s, :, 0] = _owen_scramble(x0, (seed * 2654435761 + 2 * s + 1) & 0xFFFFFFFF)
         pmj[s, :, 1] = _owen_scramble(y0, (seed * 40503 + 7919 * (2 * s + 2)) & 0xFFFFFFFF)
     pmj &= np.uint32(0xFFFFFF00)
-    # white-noise "blue noise" via a 32-bit integer hash of the flat index
+    bn = blue_noise_textures() if dither == "void_and_cluster" else _white_noise_textures(seed)
+    return np.ascontiguousarray(pmj), np.ascontiguousarray(bn)
+
+
+def _white_noise_textures(seed):
+    """Rounds 1-4's stand-in: a 32-bit integer hash of the flat index (no spatial structure at all)."""
     m = abi.KZ_BLUENOISE_TEXTURES * abi.KZ_BLUENOISE_RES * abi.KZ_BLUENOISE_RES
     with np.errstate(over="ignore"):
         h = np.arange(m, dtype=np.uint32) + np.uint32(seed)
@@ -401,9 +408,98 @@ def make_pmj02bn_tables(seed=2022):
         h ^= h >> np.uint32(15)
         h *= np.uint32(0x846CA68B)
         h ^= h >> np.uint32(16)
-    bn = (h >> np.uint32(16)).astype(np.uint16).reshape(abi.KZ_BLUENOISE_TEXTURES, abi.KZ_BLUENOISE_RES,
-                                                         abi.KZ_BLUENOISE_RES)
-    return np.ascontiguousarray(pmj), np.ascontiguousarray(bn)
+    return (h >> np.uint32(16)).astype(np.uint16).reshape(abi.KZ_BLUENOISE_TEXTURES, abi.KZ_BLUENOISE_RES, abi.KZ_BLUENOISE_RES)
+
+
+def void_and_cluster(n, seed, sigma=1.9):
+    """One n x n blue-noise dither array by Ulichney's void-and-cluster method (Proc. SPIE 1913, 1993): returns the RANK of every cell (a permutation of
+    0 .. n*n - 1) - thresholding the ranks at any level leaves a point set without clusters or voids on the torus. The "energy" of a cell is the minority
+    pattern filtered by a toroidal Gaussian; the tightest cluster is the minority cell of largest energy, the largest void the majority cell of smallest."""
+    rng = np.random.default_rng(seed)
+    N = n * n
+    ax = np.minimum(np.arange(n), n - np.arange(n)).astype(np.float64)
+    k1 = np.exp(-ax * ax / (2.0 * sigma * sigma))
+    K2 = np.tile(np.outer(k1, k1), (2, 2))                         # the kernel centred on (y, x) is the window K2[n - y : 2n - y, n - x : 2n - x]
+
+    def kernel_at(y, x):
+        return K2[n - y:2 * n - y, n - x:2 * n - x]
+
+    ones0 = max(1, N // 10)
+    pat = np.zeros(N, bool)
+    pat[rng.permutation(N)[:ones0]] = True
+    pat = pat.reshape(n, n)
+    E = np.zeros((n, n))
+    for y, x in zip(*np.nonzero(pat)):
+        E += kernel_at(y, x)
+    BIG = 1e30
+    while True:                                                    # relax the random start: move the tightest cluster's point into the largest void
+        cy, cx = np.unravel_index(np.argmax(np.where(pat, E, -BIG)), E.shape)
+        pat[cy, cx] = False
+        E -= kernel_at(cy, cx)
+        vy, vx = np.unravel_index(np.argmin(np.where(pat, BIG, E)), E.shape)
+        pat[vy, vx] = True
+        E += kernel_at(vy, vx)
+        if (vy, vx) == (cy, cx):
+            break
+    rank = np.zeros((n, n), np.int64)
+    p, e = pat.copy(), E.copy()
+    for r in range(ones0 - 1, -1, -1):                             # phase 1: take the initial points away, tightest cluster first
+        y, x = np.unravel_index(np.argmax(np.where(p, e, -BIG)), e.shape)
+        p[y, x] = False
+        e -= kernel_at(y, x)
+        rank[y, x] = r
+    p, e = pat, E
+    for r in range(ones0, N // 2):                                 # phase 2: fill the largest voids up to half coverage
+        y, x = np.unravel_index(np.argmin(np.where(p, BIG, e)), e.shape)
+        p[y, x] = True
+        e += kernel_at(y, x)
+        rank[y, x] = r
+    q = ~p                                                         # phase 3: the zeros are the minority now: fill the tightest cluster of zeros
+    e = np.zeros((n, n))
+    for y, x in zip(*np.nonzero(q)):
+        e += kernel_at(y, x)
+    for r in range(N // 2, N):
+        y, x = np.unravel_index(np.argmax(np.where(q, e, -BIG)), e.shape)
+        q[y, x] = False
+        e -= kernel_at(y, x)
+        rank[y, x] = r
+    return rank
+
+
+_BLUE_NOISE = None
+
+
+def blue_noise_textures():
+    """BlueNoiseTextures[48][128][128] (bluenoise.h:8-11; the reference's blob is missing from the checkout): 48 independent void-and-cluster arrays, ranks
+    spread over the uint16 range. Minted once by scripts/make_bluenoise.py (~1 s per texture) into nano-kazen_amd/data/; regenerated here if the file is gone."""
+    global _BLUE_NOISE
+    if _BLUE_NOISE is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "bluenoise_vc_48x128.npz")
+        if os.path.exists(path):
+            bn = np.load(path)["bn"]
+        else:
+            bn = mint_blue_noise_textures()
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            np.savez_compressed(path, bn=bn)
+        if bn.shape != (abi.KZ_BLUENOISE_TEXTURES, abi.KZ_BLUENOISE_RES, abi.KZ_BLUENOISE_RES) or bn.dtype != np.uint16:
+            raise ValueError("%s: expected uint16 [%d][%d][%d]" % (path, abi.KZ_BLUENOISE_TEXTURES, abi.KZ_BLUENOISE_RES, abi.KZ_BLUENOISE_RES))
+        _BLUE_NOISE = np.ascontiguousarray(bn)
+    return _BLUE_NOISE
+
+
+def _mint_one(t):
+    n = abi.KZ_BLUENOISE_RES
+    r = void_and_cluster(n, 0x6b7a0000 + t)
+    return ((r * 65536 + 32768) // (n * n)).astype(np.uint16)      # rank -> the middle of its 1/(n*n) slice of [0, 65535]
+
+
+def mint_blue_noise_textures(workers=None):
+    import multiprocessing as mp
+    import os
+    workers = workers or min(8, os.cpu_count() or 1)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        return np.stack(pool.map(_mint_one, range(abi.KZ_BLUENOISE_TEXTURES)))
 
 
 # ----------------------------------------------------------------------------- geometry helpers

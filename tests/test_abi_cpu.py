@@ -185,6 +185,36 @@ def test_scene_generators(kz):
     assert float((pmj.astype(np.float64) * 2.0 ** -32).astype(np.float32).max()) < 1.0
 
 
+def test_dither_textures_are_blue_noise(kz):
+    """the stand-in for BlueNoiseTextures[48][128][128] (bluenoise.h:8-11, blob missing) is void-and-cluster blue noise, not the
+    white noise of rounds 1-4: every texture holds each rank once, its low-frequency power is a thousandth of white noise's, the committed file is what
+    the generator mints (texture 0 re-minted here), and thresholding at any level leaves no two points side by side that white noise would."""
+    S = kz.scenes
+    bn = S.blue_noise_textures()
+    n = kz.abi.KZ_BLUENOISE_RES
+    assert bn.shape == (48, n, n) and bn.dtype == np.uint16
+    assert np.array_equal(S._mint_one(0), bn[0])
+    white = S._white_noise_textures(2022)
+
+    def band_power(t, lo, hi):
+        f = np.abs(np.fft.fft2(t.astype(np.float64) / 65535 - 0.5)) ** 2
+        ky, kx = np.meshgrid(np.fft.fftfreq(n) * n, np.fft.fftfreq(n) * n, indexing="ij")
+        k = np.sqrt(kx * kx + ky * ky)
+        return f[(k >= lo) & (k < hi)].mean()
+    for t in (0, 17, 47):
+        assert len(np.unique(bn[t])) == n * n                                      # ranks: a permutation, spread over the uint16 range
+        assert band_power(bn[t], 1, 16) < 1e-3 * band_power(white[t], 1, 16)
+        assert band_power(bn[t], 32, 64) > band_power(white[t], 32, 64)            # the energy sits at high frequencies instead
+        for level in (0.03, 0.1):                                                 # no clusters: far fewer 4-neighbour pairs than a random set of that density
+            def pairs(tex):
+                m = tex < level * 65535
+                return int((m & np.roll(m, 1, 0)).sum() + (m & np.roll(m, 1, 1)).sum())
+            assert pairs(bn[t]) < 0.5 * pairs(white[t])
+    assert len({bn[t].tobytes() for t in range(48)}) == 48                          # 48 different textures
+    pmj, bn2 = S.make_pmj02bn_tables()
+    assert bn2 is bn and np.array_equal(S.make_pmj02bn_tables(dither="white")[1], white)
+
+
 def test_film_merge_tiles_adds_rects_in_list_order(kz):
     """kz_film_merge_tiles (host only): packed (h+2b) x (w+2b) rects are added into the film where the tiles sit, aprons overlapping;
     the result does not depend on the number of host threads."""
