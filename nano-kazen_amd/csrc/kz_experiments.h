@@ -575,7 +575,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 // queue -> hit record -> shading record costs more than the record stack did), C3 23.5 -> 28.5 ms. The kernel is bound by the DEPTH of its chains
 // of dependent loads, and a split adds two levels.
 #ifndef KZ_CLASSIFY_WAVES
-#define KZ_CLASSIFY_WAVES 8
+#define KZ_CLASSIFY_WAVES 4      // (8 when it was measured, profiles/r04b_shade_split; the double-precision transcendentals of r04m took it to 4: asking for 8 only earned a warning per instantiation)
 #endif
 template <bool STATS, bool EXT>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_CLASSIFY_WAVES, KZ_CLASSIFY_WAVES))) void kz_wf_classify(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
