@@ -117,7 +117,7 @@ def cold_job(which, tris):
     scene = kz.Scene(desc)
     t_build = time.perf_counter() - t0
     if os.environ.get("KZ_BENCH_TRACE"):
-        scene.lib.kz_debug_trace(1)                        # (development: the library's allocation / growth / pass timeline on stderr)
+        getattr(scene.lib, "kz_debug_trace", lambda on: None)(1)      # (development builds of the library, KZ_LIB_PATH: the allocation / growth / pass timeline on stderr)
     t0 = time.perf_counter()
     n_dev = scene.lib.kz_device_count()                     # the first HIP call of the process: runtime start-up, a property of the process and reported beside the job
     if n_dev <= 0:
@@ -150,6 +150,28 @@ def C_mem_info(lib):
     import ctypes
     f, t = ctypes.c_uint64(), ctypes.c_uint64()
     return f.value if lib.kz_device_mem_info(0, ctypes.byref(f), ctypes.byref(t)) == 0 else 0
+
+
+def profiler_attached():
+    """True under rocprofv3 / rocprof: the profiler's preloaded library initialises the GPU before this program starts (with --pmc it does), and a process that
+    holds the GPU must not start child processes on this pool."""
+    if any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_")) for k in os.environ):
+        return True
+    return any(w in os.environ.get("LD_PRELOAD", "") for w in ("rocprofiler", "rocprof", "roctracer"))
+
+
+def film_crc(rgbw_film, border, x0=928, y0=508, n=64):
+    """crc32 of a fixed n x n crop of a film (float32 bits, rgb * w and w): since round 6 the film does not depend on how the work was cut - pass size, number of
+    ranks, static or dynamic dealing - so the SAME value must appear at every N."""
+    import zlib
+    import numpy as np
+    c = np.ascontiguousarray(rgbw_film[y0 + border:y0 + border + n, x0 + border:x0 + border + n])
+    return "%08x" % (zlib.crc32(c.tobytes()) & 0xFFFFFFFF)
+
+
+# film_crc of the parity render below (C4, sample indices [0, 64), crop 64 x 64 at (928, 508)) on ONE GPU: the value every N must reproduce.
+# (written by the first N = 1 run of round 6 on the GPU box: profiles/r06a_film/parity_crc.json; None = not pinned yet)
+PARITY_CRC_N1 = None
 
 
 def run_cold_jobs(tris):
@@ -205,6 +227,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--cold-job", choices=["c4", "q1"], default=None, help="(child process mode) run ONE cold job and print its record")
     ap.add_argument("--no-cold-job", action="store_true", help="N = 1: skip the two one-frame-per-process jobs that ride in the same JSON line")
+    ap.add_argument("--no-ext-scenes", action="store_true", help="N = 1: skip the EXT-kernel scenes and C1 / C2 / C3 at their BASELINE sizes (each beside the oracle's CPU time) that ride in the same JSON line")
     ap.add_argument("--profile-pass", action="store_true", help="(scripts/profile_bench.sh) every step asks for ONE pass of 2^30 items explicitly instead of earning it call by call: "
                                                                 "the counter runs profile the first step of a process, and the pass they see must be the steady state's")
     args = ap.parse_args()
@@ -217,7 +240,12 @@ def main():
     commit = os.environ.get("GRAFT_HEAD") or git_head()          # before torch / HIP are loaded: no fork from a process that has initialised the GPU
     cold = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.strong and not args.no_cold_job:
-        cold = run_cold_jobs(args.tris)                          # (child processes; this one has not touched the GPU yet)
+        if profiler_attached():
+            cold = {"skipped": "a profiler is attached (ROCPROFILER_* / ROCP_* in the environment or a rocprofiler preload): its library has initialised the GPU before "
+                               "bench.py started, and a process that holds the GPU must not start child processes - pass --no-cold-job"}
+            log("cold jobs skipped: %s" % cold["skipped"])
+        else:
+            cold = run_cold_jobs(args.tris)                      # (child processes; this one has not touched the GPU yet)
 
     # stdout carries ONE line, the JSON record: everything else that may write to file descriptor 1 (gloo's "[Gloo] Rank ... is
     # connected" banner comes from C++ and lands on stdout) is sent to stderr; the record goes to the saved descriptor.
@@ -336,6 +364,21 @@ def main():
         % (rank, world, device_index, torch.cuda.get_device_name(device_index), len(tiles), my_pixels, elapsed, args.steps, info, free_b / 2**30, total_b / 2**30,
            packed.nbytes / 1e6, 1e3 * (t_d - t_g), 1e3 * gather_s))
 
+    # ---- parity render (every rank; outside the timed region): sample indices [0, 64) of the frame, tiles dealt as above, gathered on rank 0. The film does not
+    # depend on N, on the dealing or on the pass size (round 6: per-pixel running tap sums, rects merged in tile order), so the crc32 of a fixed crop is the same at
+    # every N - the scaling run carries its own parity check.
+    parity = None
+    if not args.strong:
+        scene.render(0, 64, tiles=render_tiles, accumulate=False, stream=stream, **kw)
+        torch.cuda.synchronize()
+        pf = kz.shard.gather_tiles(scene, tiles, scene.film_tiles(tiles), rank, world) if world > 1 else scene.film()
+        if rank == 0:
+            parity = {"film_crc": film_crc(pf, scene.border), "film_crc_n1": PARITY_CRC_N1, "render": "C4 sample indices [0, 64) of every pixel, %d rank(s), 64 x 64 tiles; crc32 of the "
+                      "float32 film texels (rgb * w, w) of the 64 x 64 crop at (928, 508)" % world}
+            parity["equals_n1"] = None if PARITY_CRC_N1 is None else parity["film_crc"] == PARITY_CRC_N1
+            log("parity render: %s" % json.dumps(parity))
+        scene.film_clear(stream)
+
     el = torch.tensor([elapsed, gather_s, float(info["largestPassItems"]), -float(info["largestPassItems"])], dtype=torch.float64)
     px = torch.tensor([my_pixels], dtype=torch.float64)
     if world > 1:
@@ -453,7 +496,7 @@ def main():
                           "items_per_pass_per_rank": items_per_pass_per_rank, "sampler_table_spp": spp_table, "warmup_wait_for_context_s": round(grow_wait_s, 2),
                           "first_call_ms": first_call_ms, "first_call": "the first (warm-up) step: beam lists of every pixel (kz_wf_beam, once per pixel and replica), the pass context "
                                                                         "growing (its memory is mapped on a side thread while the first passes run), then the step itself; a timed step is ms_per_step"},
-               "roofline": roofline, "cpu_baseline": cpu, "cold_job": cold}
+               "roofline": roofline, "cpu_baseline": cpu, "cold_job": cold, "parity": parity}
     # ---- side jobs. The headline record above is complete: a failure below lands in the sub-record as {"error": ...} and never costs the measurement
     # (ADVICE r04). A collective side job is entered only when EVERY rank is fit for it, and every step of it checks the ranks' status first.
     if world > 1 and not args.strong and not args.no_strong_c5:
@@ -472,6 +515,12 @@ def main():
             out["reference_scene"] = reference_scene(kz, device_index, args.asset_spp)
         except Exception as e:                                 # noqa: BLE001
             out["reference_scene"] = {"error": repr(e)}
+    if world == 1 and not args.strong and not args.no_ext_scenes:
+        try:
+            scene.close()                                      # (its pass contexts go to the device's pool: the scenes below render in them)
+            out["ext_scenes"] = ext_scenes(kz, device_index, cpu=not args.no_cpu_baseline)
+        except Exception as e:                                 # noqa: BLE001
+            out["ext_scenes"] = {"error": repr(e)}
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
@@ -480,6 +529,63 @@ def main():
             dist.destroy_process_group()
         except Exception as e:                                 # noqa: BLE001 - the record is out
             log("rank %d: shutdown: %r" % (rank, e))
+
+
+def ext_scenes(kz, device_index, cpu=True):
+    """VERDICT r05 item 2a / SURVEY 8(d) "time C1-C3 in full": whole jobs, driver-timed, outside the timed region of `value` - (i) the two scenes that run the EXT
+    shade kernels (rough BSDFs, mirror, dielectric; image textures, normal map, blend, ramp, environment map) at 1920 x 1080 x 256, and (ii)
+    BASELINE configs C1, C2, C3 at the sizes BASELINE.json quotes, each beside the oracle's time on the host cores for the SAME job (C1, C2 in full; C3 a centre crop,
+    scaled - the oracle needs minutes for 531 M samples). Every GPU figure is the best of the calls after the first on a resident scene (the first builds the beam lists)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    S = kz.scenes
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    jobs = [
+        ("materials_scene", "mirror, dielectric, ggx, roughconductor, roughplastic, roughdielectric spheres (EXT kernels, no textures), 1920x1080, 256 spp, independent", lambda: S.materials_scene(1920, 1080, 256), None),
+        ("textured_scene", "image textures, normal map, blend, colour ramp, environment map (EXT kernels + texture programs), 1920x1080, 256 spp, independent", lambda: S.textured_scene(1920, 1080, 256), None),
+        ("C1", "BASELINE configs[0]: scene/2022_q1 default_m0_r0.5 (36 378 triangles), 256x256, 16 spp, independent",
+         lambda: S.load_npz(os.path.join(ROOT, "tests", "golden", "q1_default_m0_r0.5.npz"), overrides={"camera": {"width": 256, "height": 256}, "sampler": {"type": "independent", "sampleCount": 16, "seed": 0}}), "full"),
+        ("C2", "BASELINE configs[1]: diffuse sphere (9 800 triangles) + constant environment, 512x512, 64 spp, independent", lambda: S.sphere_env(512, 512, 64), "full"),
+        ("C3", "BASELINE configs[2]: hero scene (508 k triangles), full kiss BSDF + 3 area lights, 1920x1080, 256 spp, independent", lambda: S.hero_scene(1920, 1080, 256, detail=2.0), "crop"),
+    ]
+    out = {"unit": "Msamples/s", "cpu_threads": threads, "note": "whole jobs on a resident scene (kz_render of every sample of every pixel + sync; best call after the first); C1 is 1 M samples - "
+           "a job of a millisecond, bound by its ~40 kernel launches, not by the kernels"}
+    t_all = time.perf_counter()
+    for name, what, make, cpu_mode in jobs:
+        try:
+            t0 = time.perf_counter()
+            desc = make()
+            sc = kz.Scene(desc, device=device_index)
+            build_s = time.perf_counter() - t0
+            n = sc.width * sc.height * sc.sample_count
+            ts = []
+            for _ in range(3 if n >= (1 << 28) else 5):
+                t0 = time.perf_counter(); sc.render(); sc.sync(); ts.append(time.perf_counter() - t0)
+            rec = {"workload": what, "samples": n, "value": round(n / min(ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
+                   "image_mean": round(float(sc.rgb().mean()), 5), "passes": sc.last_pass_info()["passes"], "tris": desc.n_tris()}
+            if cpu and cpu_mode:
+                import oracle as O
+                ora = O.OracleScene(desc)
+                if cpu_mode == "full":
+                    t0 = time.perf_counter(); ora.render(threads=threads); dt = time.perf_counter() - t0
+                    rec["cpu_oracle"] = {"value": round(n / dt / 1e6, 3), "seconds": round(dt, 2), "sample": "the whole job", "threads": threads, "kind": "port"}
+                else:
+                    tile = (sc.width // 2 - 192, sc.height // 2 - 108, 384, 216)
+                    t0 = time.perf_counter(); ora.render(0, 16, tiles=[tile], threads=threads); dt = time.perf_counter() - t0
+                    rate = tile[2] * tile[3] * 16 / dt
+                    rec["cpu_oracle"] = {"value": round(rate / 1e6, 3), "seconds": round(dt, 2), "threads": threads, "kind": "port",
+                                         "sample": "centre crop 384x216 at sample indices [0, 16) = %d samples; the whole job at this rate: %.0f s" % (tile[2] * tile[3] * 16, n / rate)}
+                rec["gpu_over_cpu"] = round(rec["value"] / max(1e-9, rec["cpu_oracle"]["value"]), 1)
+            sc.close()
+        except Exception as e:                                 # noqa: BLE001 - one scene must not cost the others
+            rec = {"workload": what, "error": repr(e)}
+        out[name] = rec
+        log("ext_scenes %s: %s" % (name, json.dumps(rec)))
+        if time.perf_counter() - t_all > 140.0:                # (bounded: the default bench run stays within a few minutes)
+            out["stopped"] = "time budget of 140 s used up after %s" % name
+            break
+    out["seconds"] = round(time.perf_counter() - t_all, 1)
+    return out
 
 
 def reference_scene(kz, device_index, spp):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 5
+#define KZ_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -263,9 +263,9 @@ typedef struct KzTuning {
     int32_t dev0;
     int32_t packetPrimary;      /* primary rays: 0 = default (pixel beams, else shared-stack packet traversal), 1 = per-lane, 2 = packet */
     int32_t dev1, dev2;
-    int32_t filmGather;         /* film reconstruction: 0 = default (per-pixel tap sums + apply for filters of <= 5 taps per axis - two lanes per pixel since round 5 -,
-                                   the staged gather otherwise), 1 = always the staged gather kernel of round 1, 3 = the tap sums with one lane per pixel
-                                   (round 2's kernel, kept for comparison: the same sums bit for bit) */
+    int32_t filmGather;         /* film reconstruction (running tap sums per pixel, resolved once per call): 0 = default (2 lane groups per pixel for filters of <= 5 taps
+                                   per axis, 4 beyond), 3 = one lane per pixel (round 2's kernel, <= 5 taps, kept for comparison: the same sums bit for bit).
+                                   1 (the staged gather kernel of rounds 1-5) is gone: KZ_ERR_UNSUPPORTED */
     int32_t dev3;
     int32_t sppPerPass;         /* samples of a pixel per pass: 0 = default. A pass covers pixPerPass x sppPerPass = passItems (pixel, sample)
                                    items: sppPerPass = 0 means "every pixel of the tile set, as many samples as fit" - unless fewer than 64 would
@@ -310,12 +310,13 @@ typedef struct KzRenderOpts {
                                    state budget allows (see passItems); with passItems given, or with a dealer, KZ_DEFAULT_PASSES_IN_FLIGHT */
     uint64_t passItems;         /* (pixel, sample) items per pass, lowered to fit maxStateBytes; 0 = default: 2^30 (175 GB of path state on a 288 GB card: fewer, longer
                                    kernels), 2^29 per context with a dealer, 2^27 when passesInFlight is given */
-    uint64_t maxStateBytes;     /* cap on this replica's path state + sample records + film tap sums; 0 = min(3/4 of the device's
-                                   memory, what is free + what the replica already holds for this purpose)       */
+    uint64_t maxStateBytes;     /* cap on this replica's pass contexts (path state + sample records); 0 = min(3/4 of the device's memory, what is free + what the
+                                   replica already holds for this purpose). The film and its running tap sums (taps^2 x 16 B per pixel of the frame: 829 MB at
+                                   1920x1080 with the default filter) belong to the replica like the scene tables and are not part of this budget */
     KzTuning tune;
     int32_t tileDealing;        /* kz_render_multi: 0 = static (kz_deal_tiles: by area), 1 = dynamic (the devices take batches of tiles from a shared counter,
-                                   the reference's BlockGenerator; the same paths and the same film up to the grouping of the float additions where the
-                                   shares of two devices or two batches meet, H10 - only static dealing is bit-reproducible from run to run) */
+                                   the reference's BlockGenerator). The same paths and - since round 6 - the same film BIT FOR BIT either way and for any number
+                                   of devices: a tile's rect holds what the tile's own pixels add, and the rects are added in tile order (H10) */
     int32_t packedOutput;       /* kz_render_tiles with a host buffer: 0 = the buffer receives the WHOLE film, 1 = the packed rects of the call's tiles
                                    (kz_tiles_packed_floats). Never inferred from the buffer's size. */
     /* ---- ABI v5 ---- */
@@ -350,10 +351,10 @@ int kz_render(KzScene *scene, const KzRenderOpts *opts);
 /* SURVEY 8b tile variant, the unit of multi-GPU sharding: render `tiles` on `device` (overriding opts->tiles / opts->device), wait for the
  * device, and hand back what those tiles produced. `film` may be NULL (nothing is copied: kz_film_download_tiles later), a buffer for the
  * PACKED film rects of the tiles (nFloats = kz_tiles_packed_floats: tile t is its (h + 2b) x (w + 2b) rect - the tile with its filter apron, the
- * extent of an ImageBlock of that size, block.cpp:14,30 - as consecutive rows, tiles in list order; where the rects of two tiles of the list
- * overlap, the texel travels with the EARLIER tile and is zero in the later one, so the sum of the rects is the replica's film over their union,
- * each texel once), or a whole-film buffer ((h+2b)*(w+2b)*4 floats).
- * The packed form moves the tiles' own texels only: 1.13 x the film for a frame of 64 x 64 tiles however many devices share it.
+ * extent of an ImageBlock of that size, block.cpp:14,30 - as consecutive rows, tiles in list order; a texel of a rect holds what the TILE'S OWN pixels
+ * add to it - the ImageBlock of that tile - so where the aprons of two tiles overlap both carry their share and the merge adds them, in tile order, exactly
+ * as the device's own film is resolved (block.cpp:87-96)), or a whole-film buffer ((h+2b)*(w+2b)*4 floats).
+ * The packed form moves 1.13 x the film for a frame of 64 x 64 tiles however many devices share it.
  * Blocking; re-entrant per (scene, device). opts may be NULL (all samples, defaults). */
 int kz_render_tiles(KzScene *scene, const KzRenderOpts *opts, const KzTile *tiles, uint32_t nTiles, int device,
                     float *film, size_t nFloats);
@@ -365,6 +366,10 @@ int kz_film_download_tiles(KzScene *scene, int device, const KzTile *tiles, uint
  * in LIST order, on nThreads host threads over disjoint row bands (0 = up to 16); the result does not depend on the number of threads. */
 int kz_film_merge_tiles(float *film, int32_t width, int32_t height, int32_t border, const KzTile *tiles, uint32_t nTiles, const float *packed,
                         size_t nFloats, int32_t nThreads);
+/* The same merge for rects that lie in different buffers (a multi-process launcher: every rank's packed rects where that rank put them): rects[t] points at the
+ * (h + 2b) x (w + 2b) x 4 floats of tiles[t]. In ROW-MAJOR tile order (y0, then x0) the result is, bit for bit, the film one device resolves for itself and the film
+ * kz_render_multi returns - whichever rank or device rendered which tile (H10). */
+int kz_film_merge_rects(float *film, int32_t width, int32_t height, int32_t border, const KzTile *tiles, const float *const *rects, uint32_t nTiles, int32_t nThreads);
 
 /* The analogue of the reference's driver (renderer.cpp:94-127: tbb::parallel_for over blocks, then ImageBlock::put(ImageBlock&)
  * under a mutex, block.cpp:87-96) one level up: the image is cut into tileSize x tileSize tiles (a multiple of the 32-px

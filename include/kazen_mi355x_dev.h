@@ -1,8 +1,9 @@
 /* kazen_mi355x_dev.h - the development and test surface of libkazen_mi355x.so. A renderer that adopts the library needs
  * kazen_mi355x.h only (its twenty entry points); this header adds what the parity tests, the benchmarks and the profiling
  * scripts use: per-replica forms of the product calls, counters and stage timings, function-level query kernels (the very
- * device functions the path kernels call, on caller-supplied inputs), known-answer self-checks, a failure-injection hook,
- * and the names of the KzTuning words that select kernels of rejected experiments in -DKZ_EXPERIMENTS builds. */
+ * device functions the path kernels call, on caller-supplied inputs), known-answer self-checks (kz_kat_*: stateless, in the product
+ * library, so that what they check IS the product's code), the pass planner as a pure function, and - in development builds of the library only - the hooks that
+ * are process-global state (failure injection, growth delay, trace, device aliasing) and the KzTuning words that select kernels of rejected experiments. */
 #ifndef KAZEN_MI355X_DEV_H
 #define KAZEN_MI355X_DEV_H
 #include "kazen_mi355x.h"
@@ -11,7 +12,7 @@ extern "C" {
 #endif
 
 /* KzTuning.dev*: honoured only by a library built with -DKZ_EXPERIMENTS (kz_build_flags() & KZ_BUILD_EXPERIMENTS); the product
- * library answers a non-zero value with KZ_ERR_UNSUPPORTED (nano-kazen_amd/csrc/kz_experiments.h holds the kernels). */
+ * library answers a non-zero value with KZ_ERR_UNSUPPORTED (nano-kazen_amd/csrc/variants/experiments/kz_experiments.h holds the kernels). */
 #define KZ_TUNE_BVH2         dev0   /* 1 = per-lane traversal of the BVH2 instead of the quantised BVH4 */
 #define KZ_TUNE_KEY_STACK    dev1   /* 1 = packet kernel without per-lane entry distances, 2 = per-lane kernel with them */
 #define KZ_TUNE_LDS_TOP      dev2   /* n = that many BVH4 packets of the top of the tree staged in LDS (<= 1536) */
@@ -110,21 +111,56 @@ int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
 /* Why the pass context of the last kz_render stopped growing short of its target ("" if it did not): such a call succeeds on what there is. */
 int kz_last_grow_note(KzScene *scene, char *buf, size_t cap);
 
-/* Test hook: the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off). Used by
- * the error-path tests to show that a failure in the middle of a call releases what the call had allocated. */
+/* ---- DEVELOPMENT BUILDS ONLY (a library compiled with -DKZ_EXPERIMENTS: kz_build_flags() & KZ_BUILD_EXPERIMENTS; nano-kazen_amd/csrc/variants/experiments).
+ * These four are process-global state - the product library does not contain them (`nm -D libkazen_mi355x.so | grep kz_debug` is empty), so that nothing behind the
+ * product ABI depends on state outside the objects the caller holds. The tests that need them load the development variant.
+ *   kz_debug_fail_alloc    the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off): a failure in the middle of a call
+ *                          releases what the call had allocated.
+ *   kz_debug_grow_delay    the thread that maps a pass context's memory (kz_arena.cpp) sleeps `ms` milliseconds before every level (0 = off): "the context is
+ *                          still growing while the first passes of a job run" - what happens behind the driver's wipe of recently released memory - on demand.
+ *   kz_debug_trace         a timeline of the allocation, growth and pass-planning events of this process on stderr (0 = off).
+ *   kz_debug_alias_devices the library presents n LOGICAL devices (kz_device_count() = n), logical d on physical device d % (devices really there): every
+ *                          replica, pass context, pool and growth thread is keyed by the logical index, every HIP call goes to the physical device - so
+ *                          kz_render_multi's one-host-thread-per-device driver runs with n threads on a box with ONE GPU (tests/test_gpu_multi.py). 0 = off.
+ *                          Call it before the first kz_scene_upload; give every replica an explicit maxStateBytes (the aliases share one card). */
 void kz_debug_fail_alloc(int nth);
-
-/* Test hook: the thread that maps a pass context's memory (kz_arena.cpp) sleeps `ms` milliseconds before every level (0 = off): "the context is still
- * growing while the first passes of a job run" - what happens behind the driver's wipe of recently released memory - on demand. Process-wide. */
 void kz_debug_grow_delay(int ms);
-/* Development aid: a timeline of the allocation, growth and pass-planning events of this process on stderr (0 = off). */
 void kz_debug_trace(int on);
+void kz_debug_alias_devices(int n);
+
+/* ---- the pass planner (nano-kazen_amd/csrc/kz_plan.cpp: pure host arithmetic, no GPU, no state) through the ABI: what kz_render would decide for a call.
+ * tests/test_plan_cpu.py tabulates it for the BASELINE configs - the table is the documentation of the pass policy. */
+typedef struct KzPlanQuery {
+    int32_t pipeline;           /* 0 / 2 = wavefront, 1 = megakernel */
+    uint32_t nPix;              /* pixels of the call's tile set */
+    uint32_t sampleBegin, sampleEnd;
+    uint64_t passItems;         /* KzRenderOpts.passItems */
+    int32_t passesInFlight;     /* KzRenderOpts.passesInFlight */
+    int32_t sppPerPass;         /* KzTuning.sppPerPass */
+    uint64_t limitBytes;        /* bytes the pass contexts may hold (KzRenderOpts.maxStateBytes, or what kz_render derives from the device's free memory) */
+    uint64_t bytesPerItem;      /* 0 = the wavefront pipeline's 176 */
+    int32_t dealer;             /* 1 = the call carries a KzTileDealer */
+    uint32_t takers, batchTiles, nTiles;
+    const uint32_t *tilePixOffset;   /* dealer: nTiles + 1 positions in the pixel list */
+    uint64_t heldItems;         /* items the replica's first pass context was last asked to hold (0: a fresh process) */
+} KzPlanQuery;
+typedef struct KzPlanAnswer {
+    int32_t autoShape, nCtx, multi, grow;
+    uint32_t S, pixPerPass, batchTiles, nPixSet, nPasses;
+    uint64_t need, wantItems, minStart;
+    double graceMs;
+} KzPlanAnswer;
+int kz_plan_passes(const KzPlanQuery *q, KzPlanAnswer *a);
+/* The passes of pixels [pixBegin, pixEnd) of the list for that call when the k-th "what does the context hold now" answers avail[min(k, nAvail - 1)] items:
+ * passes = 4 words per pass (first pixel, pixels, first sample, samples), *nPasses = how many there are (cap may be smaller). Fails with KZ_ERR_STATE if any pass
+ * would exceed what its context holds - the planner's invariant. */
+int kz_plan_schedule(const KzPlanQuery *q, const uint64_t *avail, uint32_t nAvail, uint32_t pixBegin, uint32_t pixEnd, uint32_t *passes, uint32_t cap, uint32_t *nPasses);
 
 /* Known answers for the host code of kz_scene_create (no GPU): the area CDF of a light mesh - DiscretePDF::append + normalize, dpdf.h:35-37,77-89 - for n
  * pdf values (cdf: n + 1 floats; sumAndNormalization: 2 floats), and, for a sample count, { isPowerOf4, roundUpPow4, log4i of that, PMJ02BN's pixel tile }
  * (common.h:271-319, sampler.cpp:291). tests/golden/int_kats.json holds vectors minted from the reference's own text of both (oracle/kat_ref_dpdf.cpp). */
-int kz_debug_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNormalization);
-int kz_debug_pow4(int32_t spp, int32_t *out4);
+int kz_kat_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNormalization);
+int kz_kat_pow4(int32_t spp, int32_t *out4);
 
 /* How the library was built: bit 0 (KZ_BUILD_EXPERIMENTS) = it contains the kernels of kz_experiments.h. */
 #define KZ_BUILD_EXPERIMENTS 1
@@ -134,20 +170,20 @@ int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes);
 /* Self-check of the library's exact reciprocal / square root (hardware v_rcp_f32 / v_rsq_f32 + Newton steps, used by the triangle test,
  * the ray set-up and the BSDFs in place of the compiler's IEEE division / sqrt sequences): runs BOTH on every one of the 2^32 float
  * bit patterns on the device and counts the inputs whose results differ in any bit (two NaNs count as equal). Both counts must be 0. */
-int kz_debug_exact_math_check(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked);
+int kz_kat_exact_math(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked);
 /* out[k] = random::permute(i[k], l[k], p[k]) (src/kazen/common.cpp:316-344) as the sampler kernels compute it: checked against vectors minted from
  * the reference's own text (oracle/kat_ref_permute.cpp -> tests/golden/int_kats.json). */
-int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out);
+int kz_kat_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out);
 /* The Fresnel functions of the dielectric / rough BSDFs as the kernels compute them, against vectors minted from the reference's own text
  * (oracle/kat_ref_fresnel.cpp): form 0 = fresnel(cosThetaI, extIOR = a, intIOR = b) (common.cpp:447-475), form 1 = fresnelDielectric(cosThetaI, eta = a,
  * cosThetaT) (:492-518; b unused). out = n x (F, cosThetaT). */
-int kz_debug_fresnel(int device, uint32_t n, int form, const float *cosThetaI, const float *a, const float *b, float *out);
+int kz_kat_fresnel(int device, uint32_t n, int form, const float *cosThetaI, const float *a, const float *b, float *out);
 /* The transcendental functions of the path as the kernels compute them (nano-kazen_amd/csrc/kz_crmath.h: each a fixed sequence of IEEE double operations
  * and one narrowing, standing in for the reference's libm calls - warp.cpp:41-129, bsdf.cpp:728-734, common.cpp:368-400, texture.cpp:66-80,
  * camera.cpp:191-223), on arrays: fn 0 sin(x), 1 cos(x), 2 exp(x), 3 log(x), 4 atan(x), 5 atan2(x, y), 6 acos(x), 7 tan(x), 8 pow(x, y), 9 hypot(x, y),
  * 10 x^3, 11 cos(x) through the cos-only entry. The oracle states the same sequences independently; the results must be equal bit for bit. y may
  * be NULL for the one-argument functions. */
-int kz_debug_math(int device, int fn, uint32_t n, const float *x, const float *y, float *out);
+int kz_kat_math(int device, int fn, uint32_t n, const float *x, const float *y, float *out);
 
 
 #ifdef __cplusplus

@@ -7,7 +7,7 @@ is missing: there is no CPU fallback in the product path.
 import ctypes as C
 import os
 
-KZ_ABI_VERSION = 5
+KZ_ABI_VERSION = 6
 
 KZ_OK, KZ_ERR_INVALID_ARG, KZ_ERR_UNSUPPORTED, KZ_ERR_NO_DEVICE, KZ_ERR_HIP, KZ_ERR_STATE, KZ_ERR_OOM = range(7)
 KZ_BSDF_DIFFUSE, KZ_BSDF_KAZENSTANDARD, KZ_BSDF_MIRROR, KZ_BSDF_DIELECTRIC = 0, 1, 2, 3
@@ -124,6 +124,21 @@ class KzPassInfo(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class KzPlanQuery(C.Structure):
+    _fields_ = [("pipeline", C.c_int32), ("nPix", C.c_uint32), ("sampleBegin", C.c_uint32), ("sampleEnd", C.c_uint32), ("passItems", C.c_uint64),
+                ("passesInFlight", C.c_int32), ("sppPerPass", C.c_int32), ("limitBytes", C.c_uint64), ("bytesPerItem", C.c_uint64), ("dealer", C.c_int32),
+                ("takers", C.c_uint32), ("batchTiles", C.c_uint32), ("nTiles", C.c_uint32), ("tilePixOffset", u32p), ("heldItems", C.c_uint64)]
+
+
+class KzPlanAnswer(C.Structure):
+    _fields_ = [("autoShape", C.c_int32), ("nCtx", C.c_int32), ("multi", C.c_int32), ("grow", C.c_int32), ("S", C.c_uint32), ("pixPerPass", C.c_uint32),
+                ("batchTiles", C.c_uint32), ("nPixSet", C.c_uint32), ("nPasses", C.c_uint32), ("need", C.c_uint64), ("wantItems", C.c_uint64),
+                ("minStart", C.c_uint64), ("graceMs", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class KzStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("nodeVisits", C.c_uint64), ("triTests", C.c_uint64),
                 ("shadedHits", C.c_uint64), ("lightSamples", C.c_uint64), ("droppedSamples", C.c_uint64),
@@ -146,20 +161,24 @@ class KzBvhInfo(C.Structure):
 
 # every symbol include/kazen_mi355x.h (the product surface, PRODUCT_EXPORTS) and include/kazen_mi355x_dev.h declare (checked by tests/test_abi_cpu.py)
 PRODUCT_EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_upload", "kz_scene_evict", "kz_render", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles",
-                   "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb",
+                   "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_film_merge_rects", "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb",
                    "kz_film_to_srgb8", "kz_sync", "kz_last_error", "kz_abi_version", "kz_device_count", "kz_device_trim"]
 EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene_upload", "kz_render",
            "kz_film_download", "kz_film_clear", "kz_film_dims", "kz_film_to_rgb", "kz_trace_rays",
            "kz_set_stats", "kz_get_stats", "kz_sync", "kz_last_kernel_ms", "kz_last_error", "kz_abi_version",
            "kz_device_count", "kz_render_samples", "kz_bsdf_query", "kz_scene_sample_count", "kz_last_stage_ms", "kz_texture_query", "kz_film_to_srgb8",
            "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
-           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_debug_fail_alloc", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_debug_exact_math_check", "kz_debug_permute", "kz_debug_fresnel", "kz_debug_math", "kz_build_flags",
-           "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_device_trim", "kz_debug_grow_delay", "kz_debug_dpdf", "kz_debug_pow4", "kz_last_grow_note", "kz_debug_trace"]
+           "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_kat_exact_math", "kz_kat_permute", "kz_kat_fresnel", "kz_kat_math", "kz_build_flags",
+           "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_film_merge_rects", "kz_device_trim", "kz_kat_dpdf", "kz_kat_pow4", "kz_last_grow_note",
+           "kz_plan_passes", "kz_plan_schedule"]
+# exported by DEVELOPMENT builds of the library only (-DKZ_EXPERIMENTS): the hooks that are process-global state. The product library must NOT export them.
+DEV_ONLY_EXPORTS = ["kz_debug_fail_alloc", "kz_debug_grow_delay", "kz_debug_trace", "kz_debug_alias_devices"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KZ_LIB_PATH: a development build of the library (scripts/build_variant.sh) instead of the in-tree one; probes only
 LIB_PATH = os.environ.get("KZ_LIB_PATH") or os.path.join(_HERE, "csrc", "libkazen_mi355x.so")
-_lib = None
+DEV_LIB_PATH = os.path.join(_HERE, "csrc", "variants", "experiments", "libkazen_mi355x.so")
+_libs = {}
 
 
 class KzError(RuntimeError):
@@ -168,15 +187,22 @@ class KzError(RuntimeError):
         self.code = code
 
 
-def load_library():
+def load_dev_library():
+    """The development variant of the library (-DKZ_EXPERIMENTS: the same sources plus the kernels of rejected experiments and the hooks that are process-global
+    state - kz_debug_fail_alloc / grow_delay / trace / alias_devices). Only tests load it; a second copy of the library in one process is a separate world
+    (its own device pools, its own replicas)."""
+    return load_library(DEV_LIB_PATH)
+
+
+def load_library(path=None):
     """Load the HIP extension. No fallback: a missing build is an error."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(the product path has no CPU fallback)" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                          "(the product path has no CPU fallback)" % path)
+    lib = C.CDLL(path)
     lib.kz_last_error.restype = C.c_char_p
     lib.kz_scene_create.argtypes = [C.POINTER(KzSceneDesc), C.POINTER(C.c_void_p)]
     lib.kz_scene_destroy.argtypes = [C.c_void_p]
@@ -211,30 +237,32 @@ def load_library():
     lib.kz_tiles_packed_floats.argtypes = [C.c_void_p, C.POINTER(KzTile), C.c_uint32, C.POINTER(C.c_size_t)]
     lib.kz_film_download_tiles.argtypes = [C.c_void_p, C.c_int, C.POINTER(KzTile), C.c_uint32, f32p, C.c_size_t]
     lib.kz_film_merge_tiles.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(KzTile), C.c_uint32, f32p, C.c_size_t, C.c_int32]
+    lib.kz_film_merge_rects.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(KzTile), C.POINTER(f32p), C.c_uint32, C.c_int32]
     lib.kz_film_download_on.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t]
     lib.kz_film_clear_on.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.kz_sync_on.argtypes = [C.c_void_p, C.c_int]
     lib.kz_last_pass_info.argtypes = [C.c_void_p, C.POINTER(KzPassInfo)]
-    lib.kz_debug_fail_alloc.argtypes = [C.c_int]
-    lib.kz_debug_fail_alloc.restype = None
     lib.kz_device_mem_info.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.kz_device_trim.argtypes = [C.c_int]
     lib.kz_last_grow_note.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
-    lib.kz_debug_grow_delay.argtypes = [C.c_int]
-    lib.kz_debug_grow_delay.restype = None
-    lib.kz_debug_trace.argtypes = [C.c_int]
-    lib.kz_debug_trace.restype = None
-    lib.kz_debug_dpdf.argtypes = [C.c_uint32, f32p, f32p, f32p]
-    lib.kz_debug_pow4.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
-    if hasattr(lib, "kz_debug_math"):
-        lib.kz_debug_math.argtypes = [C.c_int, C.c_int, C.c_uint32, f32p, f32p, f32p]
-    if hasattr(lib, "kz_debug_fresnel"):
-        lib.kz_debug_fresnel.argtypes = [C.c_int, C.c_uint32, C.c_int, f32p, f32p, f32p, f32p]
-    if hasattr(lib, "kz_debug_permute"):
-        lib.kz_debug_permute.argtypes = [C.c_int, C.c_uint32, u32p, u32p, u32p, u32p]
-    if hasattr(lib, "kz_debug_exact_math_check"):
-        lib.kz_debug_exact_math_check.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    _lib = lib
+    for hook in DEV_ONLY_EXPORTS:                 # development builds only
+        if hasattr(lib, hook):
+            getattr(lib, hook).argtypes = [C.c_int]
+            getattr(lib, hook).restype = None
+    if hasattr(lib, "kz_plan_passes"):
+        lib.kz_plan_passes.argtypes = [C.POINTER(KzPlanQuery), C.POINTER(KzPlanAnswer)]
+        lib.kz_plan_schedule.argtypes = [C.POINTER(KzPlanQuery), C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32, u32p]
+    lib.kz_kat_dpdf.argtypes = [C.c_uint32, f32p, f32p, f32p]
+    lib.kz_kat_pow4.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
+    if hasattr(lib, "kz_kat_math"):
+        lib.kz_kat_math.argtypes = [C.c_int, C.c_int, C.c_uint32, f32p, f32p, f32p]
+    if hasattr(lib, "kz_kat_fresnel"):
+        lib.kz_kat_fresnel.argtypes = [C.c_int, C.c_uint32, C.c_int, f32p, f32p, f32p, f32p]
+    if hasattr(lib, "kz_kat_permute"):
+        lib.kz_kat_permute.argtypes = [C.c_int, C.c_uint32, u32p, u32p, u32p, u32p]
+    if hasattr(lib, "kz_kat_exact_math"):
+        lib.kz_kat_exact_math.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    _libs[path] = lib
     return lib
 
 

@@ -14,7 +14,7 @@ DEV="--offload-arch=gfx950 -fgpu-flush-denormals-to-zero -fno-slp-vectorize ${KZ
 # the translation units compile side by side (kz_state.h says what lives where); every job's exit status is checked and no object of an earlier
 # build can stand in for one that failed to compile now
 DEVICE_UNITS="kz_render kz_film kz_debug"
-HOST_UNITS="kz_multi kz_host kz_bvh kz_arena"
+HOST_UNITS="kz_multi kz_host kz_bvh kz_arena kz_plan"
 for u in $DEVICE_UNITS $HOST_UNITS; do rm -f "$OUT/$u.o"; done
 PIDS=""
 for u in $DEVICE_UNITS; do hipcc $FLAGS $DEV -c $u.hip -o "$OUT/$u.o" & PIDS="$PIDS $!"; done

@@ -26,12 +26,16 @@
 
 static constexpr size_t KZ_ARENA_SMALL_ALIGN = (size_t)1 << 12;      // small contexts: arrays of a multiple of 4096 items
 
-// kz_debug_grow_delay (kazen_mi355x_dev.h): the growth thread sleeps this long before every level - a test hook that makes "the context is still growing
-// while the passes run" happen on demand (on a quiet device the memory is there before the first pass is planned)
+static size_t roundUp(size_t n, size_t a) { return (n + a - 1) / a * a; }
+
+// ---- development builds only (-DKZ_EXPERIMENTS, kazen_mi355x_dev.h): the hooks that ARE process-global state. The product library contains none of them
+// (nm -D libkazen_mi355x.so | grep kz_debug is empty): nothing behind its ABI depends on state outside the objects the caller holds. ----
+#ifdef KZ_EXPERIMENTS
+// kz_debug_grow_delay: the growth thread sleeps this long before every level - a test hook that makes "the context is still growing while the passes run"
+// happen on demand (on a quiet device the memory is there before the first pass is planned)
 static std::atomic<int> g_growDelayMs{0};
 extern "C" void kz_debug_grow_delay(int ms) { g_growDelayMs.store(ms > 0 ? ms : 0); }
-
-static size_t roundUp(size_t n, size_t a) { return (n + a - 1) / a * a; }
+static inline int growDelayMs() { return g_growDelayMs.load(); }
 
 std::atomic<int> g_kzTrace{0};
 static const std::chrono::steady_clock::time_point g_traceT0 = std::chrono::steady_clock::now();
@@ -41,6 +45,32 @@ void kzTraceLine(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); std::vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     std::fprintf(stderr, "[kz %9.3f ms] %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_traceT0).count(), buf);
 }
+
+// kz_debug_alias_devices(n): the library then presents n LOGICAL devices, logical d living on physical device d % (devices really there). Every replica, pass
+// context, pool and growth thread is keyed by the logical index, every HIP call goes to the physical one: kz_render_multi's one-host-thread-per-device driver
+// runs with real concurrency on a box with ONE GPU (tests/test_gpu_multi.py) - the only way that path can be executed before an 8-GPU node exists.
+static std::atomic<int> g_aliasCount{0};
+extern "C" void kz_debug_alias_devices(int n) { g_aliasCount.store(n > 0 ? std::min(n, 64) : 0); }
+int kzLogicalDeviceCount() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    const int a = g_aliasCount.load();
+    return a > 0 ? a : n;
+}
+int kzPhysicalDevice(int logical) {
+    if (g_aliasCount.load() <= 0) return logical;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return logical;
+    return logical % n;
+}
+#else
+static inline int growDelayMs() { return 0; }
+int kzLogicalDeviceCount() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+#endif
 
 // Every arena of the process, so that ALL mapped path state is unmapped and released - and every growth thread joined - before the HIP runtime tears
 // itself down at exit (this library's static destructors run before those of libamdhip64, which it depends on): a process that exits with live
@@ -120,8 +150,7 @@ int KzArena::requestSmall(size_t items, size_t *got) {
         freeSmall();
         for (int a = 0; a < kArrays; ++a) {
             void *p = nullptr;
-            int fc = failCountdown.load();
-            hipError_t e = (fc > 0 && failCountdown.compare_exchange_strong(fc, fc - 1) && fc == 1) ? hipErrorOutOfMemory : hipMalloc(&p, items * elem[a]);
+            hipError_t e = injectedFailure() ? hipErrorOutOfMemory : hipMalloc(&p, items * elem[a]);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 for (int b = 0; b < a; ++b) { (void)hipFree(base[b]); base[b] = nullptr; }
@@ -171,8 +200,7 @@ bool KzArena::growOneLevel(size_t first) {
     hipError_t e = hipSuccess; const char *what = "";
     for (int a = 0; a < kArrays; ++a) {
         const size_t bytes = items * elem[a];
-        int fc = failCountdown.load();
-        if (fc > 0 && failCountdown.compare_exchange_strong(fc, fc - 1) && fc == 1) { e = hipErrorOutOfMemory; what = "hipMemCreate (kz_debug_fail_alloc)"; break; }
+        if (injectedFailure()) { e = hipErrorOutOfMemory; what = "hipMemCreate (kz_debug_fail_alloc)"; break; }
         if ((e = hipMemCreate(&L.h[a], bytes, &prop, 0)) != hipSuccess) { what = "hipMemCreate"; break; }
         if ((e = hipMemMap(base[a] + first * elem[a], bytes, 0, L.h[a], 0)) != hipSuccess) { (void)hipMemRelease(L.h[a]); what = "hipMemMap"; break; }
         if ((e = hipMemSetAccess(base[a] + first * elem[a], bytes, &ad, 1)) != hipSuccess) { (void)hipMemUnmap(base[a] + first * elem[a], bytes); (void)hipMemRelease(L.h[a]); what = "hipMemSetAccess"; break; }
@@ -209,7 +237,7 @@ void KzArena::growLoop() {
             if (stop || mapped.load() >= target) { busy = false; cvProgress.notify_all(); return; }
             first = mapped.load();
         }
-        if (const int d = g_growDelayMs.load()) std::this_thread::sleep_for(std::chrono::milliseconds(d));
+        if (const int d = growDelayMs()) std::this_thread::sleep_for(std::chrono::milliseconds(d));
         (void)growOneLevel(first);
         cvProgress.notify_all();
     }
@@ -254,6 +282,15 @@ int KzArena::request(size_t items, size_t minItems, double graceMs, size_t *got)
     return KZ_OK;
 }
 
+// A call that needs fewer items than an earlier one asked for: a growth thread that is still mapping towards the old target stops at the new one
+// (what is mapped already stays: shrinkTo gives memory back). Without this a context asked for 2^28 items behind a wipe kept mapping towards them
+// under a later call's smaller maxStateBytes.
+void KzArena::lowerTarget(size_t items) {
+    if (!capItems) return;
+    std::lock_guard<std::mutex> g(m);
+    target = std::min(target, std::max(mapped.load(), roundUp(items, levelItems)));
+}
+
 // Gives back everything beyond `items` (the caller has synchronised the device).
 void KzArena::shrinkTo(size_t items) {
     if (smallItems) { if (items == 0) freeSmall(); return; }
@@ -275,6 +312,7 @@ void KzArena::shrinkTo(size_t items) {
 static std::mutex g_poolMutex;
 static std::vector<PassCtx *> g_pool[64];
 
+// (`device` is the index the caller addresses the replica by; the arena lives on the physical device behind it)
 PassCtx *kzCtxAcquire(int device) {
     {
         std::lock_guard<std::mutex> g(g_poolMutex);
@@ -288,7 +326,7 @@ PassCtx *kzCtxAcquire(int device) {
         }
     }
     PassCtx *c = new PassCtx();
-    c->arena = new KzArena(device);
+    c->arena = new KzArena(kzPhysicalDevice(device));
     return c;
 }
 
@@ -326,14 +364,25 @@ size_t kzCtxPoolTrim(int device, size_t keepBytes) {
         if (keepBytes == 0) { gone.insert(gone.end(), v.begin(), v.end()); v.clear(); }
     }
     size_t freed = 0;
-    if (!gone.empty()) { (void)hipSetDevice(device); (void)hipDeviceSynchronize(); }
+    if (!gone.empty()) { (void)hipSetDevice(kzPhysicalDevice(device)); (void)hipDeviceSynchronize(); }
     for (PassCtx *c : gone) { freed += c->bytes(); c->destroy(); delete c; }
     return freed;
 }
 
+size_t kzCtxPoolTrimPhysical(int hipDevice) {
+    size_t freed = 0;
+    for (int l = 0; l < 64; ++l) {
+        if (kzPhysicalDevice(l) != hipDevice) continue;
+        bool any;
+        { std::lock_guard<std::mutex> g(g_poolMutex); any = !g_pool[l].empty(); }
+        if (any) freed += kzCtxPoolTrim(l, 0);
+    }
+    return freed;
+}
+
 extern "C" int kz_device_trim(int device) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return kz_fail(n ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    const int n = kzLogicalDeviceCount();
+    if (device < 0 || device >= n) return kz_fail(n ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
     (void)kzCtxPoolTrim(device, 0);
     return KZ_OK;
 }

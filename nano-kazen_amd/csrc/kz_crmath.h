@@ -6,7 +6,7 @@
 // of a sampled direction into another triangle (scripts/dev/bsdf_bits.py: with ocml's functions on this side and glibc's on the oracle's only
 // ~55 % of the sampled directions agreed to the last bit). So each function is DEFINED here as a short sequence of IEEE double operations
 // (+ - * / sqrt fma rint, all correctly rounded on gfx950 and on the host alike, no contraction) followed by ONE narrowing to float:
-//   * the oracle (oracle/kz_oracle_math.h) states the same sequences independently, and kz_debug_math / tests/test_gpu_parity.py compare the
+//   * the oracle (oracle/kz_oracle_math.h) states the same sequences independently, and kz_kat_math / tests/test_gpu_parity.py compare the
 //     two bit for bit on millions of arguments: same bits by construction, not by tolerance;
 //   * the double value is within ~2^-50 of the exact one, so the float IS the correctly rounded result except for about one argument in 2^25
 //     (tests/test_oracle_cpu.py checks this against libm's double functions, and counts the - rare - arguments where glibc's float functions,

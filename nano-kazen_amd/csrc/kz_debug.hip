@@ -153,12 +153,12 @@ __global__ void kz_math_kernel(uint32_t n, int fn, const float *x, const float *
 extern "C" {
 
 // random::permute on the device (the function the sampler kernels call), for the known-answer vectors minted from the reference's own text
-int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out) {
+int kz_kat_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *l, const uint32_t *p, uint32_t *out) {
     int nd = kz_device_count();
     if (device < 0 || device >= nd) return kz_fail(nd ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, nd);
     if (!n) return KZ_OK;
     if (!i || !l || !p || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(kzPhysicalDevice(device)));
     DevMem dI, dL, dP, dO;
     const size_t bytes = (size_t)n * sizeof(uint32_t);
     KZ_ALLOC(&dI.p, bytes); KZ_ALLOC(&dL.p, bytes); KZ_ALLOC(&dP.p, bytes); KZ_ALLOC(&dO.p, bytes);
@@ -169,12 +169,12 @@ int kz_debug_permute(int device, uint32_t n, const uint32_t *i, const uint32_t *
     return KZ_OK;
 }
 
-int kz_debug_fresnel(int device, uint32_t n, int form, const float *cosThetaI, const float *a, const float *b, float *out) {
+int kz_kat_fresnel(int device, uint32_t n, int form, const float *cosThetaI, const float *a, const float *b, float *out) {
     int nd = kz_device_count();
     if (device < 0 || device >= nd) return kz_fail(nd ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, nd);
     if (!n) return KZ_OK;
     if (!cosThetaI || !a || !out || (form == 0 && !b) || (form != 0 && form != 1)) return kz_fail(KZ_ERR_INVALID_ARG, "null argument or form %d (0 = fresnel(cos, extIOR, intIOR), 1 = fresnelDielectric(cos, eta))", form);
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(kzPhysicalDevice(device)));
     DevMem dC, dA, dB, dO;
     const size_t bytes = (size_t)n * sizeof(float);
     KZ_ALLOC(&dC.p, bytes); KZ_ALLOC(&dA.p, bytes); KZ_ALLOC(&dB.p, bytes); KZ_ALLOC(&dO.p, 2 * bytes);
@@ -186,12 +186,12 @@ int kz_debug_fresnel(int device, uint32_t n, int form, const float *cosThetaI, c
     return KZ_OK;
 }
 
-int kz_debug_math(int device, int fn, uint32_t n, const float *x, const float *y, float *out) {
+int kz_kat_math(int device, int fn, uint32_t n, const float *x, const float *y, float *out) {
     int nd = kz_device_count();
     if (device < 0 || device >= nd) return kz_fail(nd ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, nd);
     if (!n) return KZ_OK;
     if (!x || !out || fn < 0 || fn > 11) return kz_fail(KZ_ERR_INVALID_ARG, "null argument or function %d (0..11)", fn);
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(kzPhysicalDevice(device)));
     DevMem dX, dY, dO;
     const size_t bytes = (size_t)n * sizeof(float);
     KZ_ALLOC(&dX.p, bytes); KZ_ALLOC(&dY.p, bytes); KZ_ALLOC(&dO.p, bytes);
@@ -202,10 +202,10 @@ int kz_debug_math(int device, int fn, uint32_t n, const float *x, const float *y
     return KZ_OK;
 }
 
-int kz_debug_exact_math_check(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked) {
+int kz_kat_exact_math(int device, uint64_t *rcpMismatches, uint64_t *sqrtMismatches, uint64_t *checked) {
     int n = kz_device_count();
     if (device < 0 || device >= n) return kz_fail(n ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(kzPhysicalDevice(device)));
     DevMem dC;
     KZ_ALLOC(&dC.p, 3 * sizeof(unsigned long long));
     HIP_TRY(hipMemset(dC.p, 0, 3 * sizeof(unsigned long long)));

@@ -166,7 +166,7 @@ int kz_abi_version(void) { return KZ_ABI_VERSION; }
 
 // (kazen_mi355x_dev.h) the host code of kz_scene_create behind a light's area CDF and behind PMJ02BN's pixel tile, for the vectors minted from the
 // reference's own dpdf.h / common.h (oracle/kat_ref_dpdf.cpp)
-int kz_debug_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNormalization) {
+int kz_kat_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNormalization) {
     if ((n && !values) || !cdf || !sumAndNormalization) return kz_fail(KZ_ERR_INVALID_ARG, "null argument");
     std::vector<float> t(1, 0.0f);
     for (uint32_t i = 0; i < n; ++i) t.push_back(t.back() + values[i]);
@@ -174,8 +174,8 @@ int kz_debug_dpdf(uint32_t n, const float *values, float *cdf, float *sumAndNorm
     std::memcpy(cdf, t.data(), t.size() * sizeof(float));
     return KZ_OK;
 }
-int kz_debug_pow4(int32_t spp, int32_t *out4) {
-    if (spp < 1 || !out4) return kz_fail(KZ_ERR_INVALID_ARG, "kz_debug_pow4(%d)", spp);
+int kz_kat_pow4(int32_t spp, int32_t *out4) {
+    if (spp < 1 || !out4) return kz_fail(KZ_ERR_INVALID_ARG, "kz_kat_pow4(%d)", spp);
     out4[0] = isPowerOf4(spp) ? 1 : 0; out4[1] = roundUpPow4(spp); out4[2] = log4i((uint32_t)out4[1]); out4[3] = pmjPixelTile((uint32_t)spp);
     return KZ_OK;
 }

@@ -54,37 +54,58 @@ int kz_film_merge(float *dst, const float *src, size_t nFloats) {
     return KZ_OK;
 }
 
-// ImageBlock::put(ImageBlock&) (block.cpp:87-96) for a LIST of blocks: the packed rects of `tiles` are added to the film in list order.
-// Rows of the film are cut into bands, one host thread per band (disjoint destinations: no lock, and every film texel still receives
-// its rects in list order, so the result does not depend on the number of threads).
-int kz_film_merge_tiles(float *film, int32_t width, int32_t height, int32_t border, const KzTile *tiles, uint32_t nTiles, const float *packed, size_t nFloats, int32_t nThreads) {
-    if (!film || (nTiles && (!tiles || !packed)) || width <= 0 || height <= 0 || border < 0) return kz_fail(KZ_ERR_INVALID_ARG, "kz_film_merge_tiles: null or bad argument");
+// ImageBlock::put(ImageBlock&) (block.cpp:87-96) for a LIST of blocks: rect[t] (the packed (h + 2b) x (w + 2b) x 4 floats of tiles[t]) is added to the film in list
+// order. Rows of the film are cut into bands, one host thread per band (disjoint destinations: no lock, and every film texel still receives
+// its rects in list order, so the result does not depend on the number of threads). `clear`: every band zeroes itself first.
+static void mergeRects(float *film, int width, int height, int border, const KzTile *tiles, const float *const *rect, uint32_t nTiles, int nThreads, bool clear) {
     const int cols = width + 2 * border, rows = height + 2 * border;
-    std::vector<size_t> offs(nTiles);
-    size_t off = 0;
-    for (uint32_t t = 0; t < nTiles; ++t) {
-        const KzTile &tl = tiles[t];
-        if (tl.x0 < 0 || tl.y0 < 0 || tl.w <= 0 || tl.h <= 0 || tl.x0 + tl.w > width || tl.y0 + tl.h > height) return kz_fail(KZ_ERR_INVALID_ARG, "tile %u outside the %dx%d image", t, width, height);
-        offs[t] = off; off += (size_t)(tl.w + 2 * border) * (size_t)(tl.h + 2 * border) * 4;
-    }
-    if (off != nFloats) return kz_fail(KZ_ERR_INVALID_ARG, "packed buffer holds %zu floats, the tiles need %zu", nFloats, off);
     int nt = nThreads > 0 ? nThreads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     nt = std::max(1, std::min(nt, rows / 8 + 1));
     auto band = [&](int r0, int r1) {
+        if (clear) std::memset(film + (size_t)r0 * cols * 4, 0, (size_t)(r1 - r0) * cols * 4 * sizeof(float));      // (every thread clears its own band: 133 MB at C5)
         for (uint32_t t = 0; t < nTiles; ++t) {
             const KzTile &tl = tiles[t];
             const int rw = tl.w + 2 * border, y0 = std::max(tl.y0, r0), y1 = std::min(tl.y0 + tl.h + 2 * border, r1);
             for (int y = y0; y < y1; ++y) {
                 float *d = film + ((size_t)y * cols + tl.x0) * 4;
-                const float *s = packed + offs[t] + (size_t)(y - tl.y0) * rw * 4;
+                const float *s = rect[t] + (size_t)(y - tl.y0) * rw * 4;
                 for (int i = 0; i < rw * 4; ++i) d[i] += s[i];
             }
         }
     };
-    if (nt == 1) { band(0, rows); return KZ_OK; }
+    if (nt == 1) { band(0, rows); return; }
     std::vector<std::thread> th;
     for (int i = 0; i < nt; ++i) th.emplace_back(band, (int)((int64_t)rows * i / nt), (int)((int64_t)rows * (i + 1) / nt));
     for (auto &t : th) t.join();
+}
+
+static int checkMergeArgs(const float *film, int32_t width, int32_t height, int32_t border, const KzTile *tiles, uint32_t nTiles) {
+    if (!film || (nTiles && !tiles) || width <= 0 || height <= 0 || border < 0) return kz_fail(KZ_ERR_INVALID_ARG, "film merge: null or bad argument");
+    for (uint32_t t = 0; t < nTiles; ++t) {
+        const KzTile &tl = tiles[t];
+        if (tl.x0 < 0 || tl.y0 < 0 || tl.w <= 0 || tl.h <= 0 || tl.x0 + tl.w > width || tl.y0 + tl.h > height) return kz_fail(KZ_ERR_INVALID_ARG, "tile %u outside the %dx%d image", t, width, height);
+    }
+    return KZ_OK;
+}
+
+int kz_film_merge_tiles(float *film, int32_t width, int32_t height, int32_t border, const KzTile *tiles, uint32_t nTiles, const float *packed, size_t nFloats, int32_t nThreads) {
+    if (nTiles && !packed) return kz_fail(KZ_ERR_INVALID_ARG, "kz_film_merge_tiles: null packed buffer");
+    if (const int rc = checkMergeArgs(film, width, height, border, tiles, nTiles)) return rc;
+    std::vector<const float *> rect(nTiles);
+    size_t off = 0;
+    for (uint32_t t = 0; t < nTiles; ++t) { rect[t] = packed + off; off += (size_t)(tiles[t].w + 2 * border) * (size_t)(tiles[t].h + 2 * border) * 4; }
+    if (off != nFloats) return kz_fail(KZ_ERR_INVALID_ARG, "packed buffer holds %zu floats, the tiles need %zu", nFloats, off);
+    mergeRects(film, width, height, border, tiles, rect.data(), nTiles, nThreads, false);
+    return KZ_OK;
+}
+
+// The same merge for rects that lie in DIFFERENT buffers (a multi-process launcher: every rank's packed rects in that rank's shared-memory file): rects[t] points
+// at the rect of tiles[t]. The caller orders the list - row-major tile order gives the film every other path of the library gives (H10).
+int kz_film_merge_rects(float *film, int32_t width, int32_t height, int32_t border, const KzTile *tiles, const float *const *rects, uint32_t nTiles, int32_t nThreads) {
+    if (nTiles && !rects) return kz_fail(KZ_ERR_INVALID_ARG, "kz_film_merge_rects: null rect list");
+    if (const int rc = checkMergeArgs(film, width, height, border, tiles, nTiles)) return rc;
+    for (uint32_t t = 0; t < nTiles; ++t) if (!rects[t]) return kz_fail(KZ_ERR_INVALID_ARG, "kz_film_merge_rects: rect %u is null", t);
+    mergeRects(film, width, height, border, tiles, rects, nTiles, nThreads, false);
     return KZ_OK;
 }
 
@@ -95,9 +116,10 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
     const size_t filmFloats = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border) * 4;
     if (nFloats != filmFloats) return kz_fail(KZ_ERR_INVALID_ARG, "film buffer must hold %zu floats", filmFloats);
     for (uint32_t i = 0; i < nDevices; ++i) for (uint32_t j = 0; j < i; ++j) if (devices[i] == devices[j]) return kz_fail(KZ_ERR_INVALID_ARG, "device %d listed twice", devices[i]);
-    // the frame's tiles in row-major order: the unit of dealing AND of the merge. A film texel receives the rects that reach it in TILE order, but each
-    // device's rects carry that device's whole sum for an apron texel, so WHICH tiles shared a device groups the float additions: only static dealing is
-    // bit-reproducible from run to run (H10); dynamic dealing agrees with it to rounding
+    // the frame's tiles in row-major order: the unit of dealing AND of the merge. A tile's rect holds what the TILE'S OWN pixels add to each of its texels
+    // (kz_film_tile_rects, an ImageBlock of the tile), and a film texel receives the rects that reach it in TILE order - so the film does not depend on which
+    // device rendered which tile: static dealing, dynamic dealing and any number of devices give the same bits (H10; tests/test_gpu_multi.py, and
+    // tests/host_cpp/multi_tsan_test.cpp runs this very file under ThreadSanitizer)
     uint32_t nAll = 0;
     (void)kz_deal_tiles(P.width, P.height, tileSize, 1, 0, nullptr, 0, &nAll);
     std::vector<KzTile> all(nAll);
@@ -154,8 +176,7 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
         if (deviceMs) deviceMs[i] = jobs[i].ms;
         if (jobs[i].rc) return kz_fail(jobs[i].rc, "device %d: %s", devices[i], jobs[i].err.c_str());
     }
-    // ImageBlock::put(ImageBlock&) (block.cpp:87-96) in TILE order: a table (tile -> device, offset in that device's packed buffer), then one merge
-    // over row bands; the rects are gathered into one list so that kz_film_merge_tiles sees them in tile order
+    // ImageBlock::put(ImageBlock&) (block.cpp:87-96) in TILE order: the rects of every device gathered into one list, sorted row-major, merged over row bands
     struct Rect { KzTile t; const float *src; };
     std::vector<Rect> tab;
     for (uint32_t i = 0; i < nDevices; ++i) {
@@ -163,22 +184,10 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
         for (const KzTile &t : jobs[i].tiles) { tab.push_back(Rect{t, jobs[i].packed.get() + off}); off += (size_t)(t.w + 2 * P.border) * (size_t)(t.h + 2 * P.border) * 4; }
     }
     std::sort(tab.begin(), tab.end(), [](const Rect &a, const Rect &b) { return a.t.y0 != b.t.y0 ? a.t.y0 < b.t.y0 : a.t.x0 < b.t.x0; });
-    const int cols = P.width + 2 * P.border, rows = P.height + 2 * P.border, border = P.border;
-    const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    auto band = [&](int r0, int r1) {
-        std::memset(film + (size_t)r0 * cols * 4, 0, (size_t)(r1 - r0) * cols * 4 * sizeof(float));      // (every thread clears its own band: 133 MB at C5)
-        for (const Rect &e : tab) {
-            const int rw = e.t.w + 2 * border, y0 = std::max(e.t.y0, r0), y1 = std::min(e.t.y0 + e.t.h + 2 * border, r1);
-            for (int y = y0; y < y1; ++y) {
-                float *d = film + ((size_t)y * cols + e.t.x0) * 4;
-                const float *sp = e.src + (size_t)(y - e.t.y0) * rw * 4;
-                for (int k = 0; k < rw * 4; ++k) d[k] += sp[k];
-            }
-        }
-    };
-    std::vector<std::thread> th;
-    for (int i = 0; i < nt; ++i) th.emplace_back(band, (int)((int64_t)rows * i / nt), (int)((int64_t)rows * (i + 1) / nt));
-    for (auto &t : th) t.join();
+    std::vector<KzTile> mt(tab.size());
+    std::vector<const float *> mr(tab.size());
+    for (size_t k = 0; k < tab.size(); ++k) { mt[k] = tab[k].t; mr[k] = tab[k].src; }
+    mergeRects(film, P.width, P.height, P.border, mt.data(), mr.data(), (uint32_t)tab.size(), 0, true);
     return KZ_OK;
 }
 

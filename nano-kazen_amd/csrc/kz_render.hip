@@ -13,8 +13,9 @@
 #include "kz_internal.h"
 #include "kz_devfn.h"
 #include "kz_wavefront.h"
+#include "kz_plan.h"
 #ifdef KZ_EXPERIMENTS
-#include "kz_experiments.h"
+#include "variants/experiments/kz_experiments.h"
 #endif
 #include <algorithm>
 #include <atomic>
@@ -70,12 +71,24 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDev
 // ============================================================================================
 // host side: replicas (one device state per GPU the scene is resident on), upload, passes
 // ============================================================================================
-// Every device allocation of the library goes through here (kz_debug_fail_alloc can make the nth one fail).
+// Every device allocation of the library goes through here. Out of memory: the idle pass contexts of the device's pool (up to 3/4 of the card, parked there by
+// replicas that have gone) are given back and the allocation is tried once more - tables, film and beam lists of the NEXT scene must not fail because the
+// last one's path state is still mapped. (Development builds: kz_debug_fail_alloc makes the nth allocation of the calling thread fail.)
+#ifdef KZ_EXPERIMENTS
 static thread_local int g_failAlloc = 0;
+#endif
 hipError_t kzMalloc(void **p, size_t bytes) {
     *p = nullptr;
+#ifdef KZ_EXPERIMENTS
     if (g_failAlloc > 0 && --g_failAlloc == 0) return hipErrorOutOfMemory;
-    return hipMalloc(p, bytes);
+#endif
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && kzCtxPoolTrimPhysical(dev) > 0) e = hipMalloc(p, bytes);
+    }
+    return e;
 }
 
 template <class Tp> static int uploadVec(KzDeviceState *ds, const std::vector<Tp> &v, const Tp **out) {
@@ -91,10 +104,10 @@ template <class Tp> static int uploadVec(KzDeviceState *ds, const std::vector<Tp
 }
 
 static void releaseReplica(KzDeviceState *ds) {
-    (void)hipSetDevice(ds->device);
+    (void)hipSetDevice(ds->hipDevice);
     (void)hipDeviceSynchronize();
     for (void *p : ds->allocs) (void)hipFree(p);
-    for (void *p : {(void *)ds->film, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->pixIndex, (void *)ds->stats, (void *)ds->packDev, (void *)ds->rectsDev, (void *)ds->prevDev, (void *)ds->beamEntries, (void *)ds->beamCount, (void *)ds->tileDev}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)ds->film, (void *)ds->tapSums, (void *)ds->srgb, (void *)ds->pixList, (void *)ds->stats, (void *)ds->packDev, (void *)ds->rectsDev, (void *)ds->beamEntries, (void *)ds->beamCount, (void *)ds->tileDev}) if (p) (void)hipFree(p);
     if (ds->tileHost) (void)hipHostFree(ds->tileHost);
     if (ds->evTiles) (void)hipEventDestroy(ds->evTiles);
     if (ds->evBeam) (void)hipEventDestroy(ds->evBeam);
@@ -154,8 +167,8 @@ int findReplica(const KzScene *scene, int device, KzDeviceState **out) {
         if (device < 0 || !rs || rs->v.empty()) return kz_fail(KZ_ERR_STATE, "scene is not on a device: call kz_scene_upload first");
         return kz_fail(KZ_ERR_STATE, "scene is not resident on device %d: call kz_scene_upload(scene, %d) first", device, device);
     }
-    hipError_t e = hipSetDevice(ds->device);
-    if (e != hipSuccess) return kz_fail(KZ_ERR_HIP, "hipSetDevice(%d): %s", ds->device, hipGetErrorString(e));
+    hipError_t e = hipSetDevice(ds->hipDevice);
+    if (e != hipSuccess) return kz_fail(KZ_ERR_HIP, "hipSetDevice(%d): %s", ds->hipDevice, hipGetErrorString(e));
     *out = ds;
     return KZ_OK;
 }
@@ -188,7 +201,7 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
         if ((rc = prep(scene->tris, &ds->T.tris, jobs[2]))) return rc;
         if ((rc = prep(scene->shade, &ds->T.shade, jobs[3]))) return rc;
         std::vector<std::thread> th;
-        const int dev = ds->device;
+        const int dev = ds->hipDevice;
         for (Job &j : jobs) if (j.src && j.bytes >= ((size_t)4 << 20)) th.emplace_back([&j, dev] { j.err = hipSetDevice(dev); if (j.err == hipSuccess) j.err = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice); });
         for (Job &j : jobs) if (j.src && j.bytes < ((size_t)4 << 20)) j.err = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
         for (std::thread &t : th) t.join();
@@ -217,8 +230,7 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     HIP_TRY(hipMemset(ds->film, 0, ds->filmPixels * sizeof(float4)));
     KZ_ALLOC(&ds->stats, 32 * sizeof(unsigned long long));             // 8 counters of KzStats + 16 lane statistics of the -DKZ_LANESTAT development build + 3 beam-list counters
     HIP_TRY(hipMemset(ds->stats, 0, 32 * sizeof(unsigned long long)));
-    { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, ds->device)); ds->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; ds->totalMem = prop.totalGlobalMem; }
-    { int rc_ = kzFilmInit(); if (rc_) return rc_; }
+    { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, ds->hipDevice)); ds->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; ds->totalMem = prop.totalGlobalMem; }
     KZ_TRACE("upload: film + counters there");
     HIP_TRY(hipDeviceSynchronize());
     KZ_TRACE("upload: done");
@@ -227,18 +239,16 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
 
 extern "C" {
 
+#ifdef KZ_EXPERIMENTS
 void kz_debug_fail_alloc(int nth) { g_failAlloc = nth > 0 ? nth : 0; }
+#endif
 
-int kz_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
+int kz_device_count(void) { return kzLogicalDeviceCount(); }
 
 int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes) {
     int n = kz_device_count();
     if (device < 0 || device >= n) return kz_fail(n ? KZ_ERR_INVALID_ARG : KZ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(kzPhysicalDevice(device)));
     size_t f = 0, t = 0;
     HIP_TRY(hipMemGetInfo(&f, &t));
     if (freeBytes) *freeBytes = f;
@@ -248,8 +258,8 @@ int kz_device_mem_info(int device, uint64_t *freeBytes, uint64_t *totalBytes) {
 
 int kz_scene_upload(KzScene *scene, int device) {
     if (!scene) return kz_fail(KZ_ERR_INVALID_ARG, "null scene");
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return kz_fail(KZ_ERR_NO_DEVICE, "no HIP device visible (the product path has no CPU fallback)");
+    const int n = kzLogicalDeviceCount();
+    if (n <= 0) return kz_fail(KZ_ERR_NO_DEVICE, "no HIP device visible (the product path has no CPU fallback)");
     if (device < 0 || device >= n) return kz_fail(KZ_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, n);
     KzReplicaSet *rs = replicaSet(scene);
     {
@@ -257,10 +267,10 @@ int kz_scene_upload(KzScene *scene, int device) {
         for (KzDeviceState *d : rs->v) if (d->device == device) return KZ_OK;       // already resident
     }
     KZ_TRACE("kz_scene_upload(%d)", device);
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(kzPhysicalDevice(device)));
     KZ_TRACE("upload: hipSetDevice done");
     KzDeviceState *ds = new KzDeviceState();
-    ds->device = device;
+    ds->device = device; ds->hipDevice = kzPhysicalDevice(device);
     const int rc = uploadReplica(scene, ds);
     if (rc) { releaseReplica(ds); return rc; }
     std::lock_guard<std::mutex> g(rs->m);
@@ -296,10 +306,9 @@ int kz_scene_devices(const KzScene *scene, int32_t *devices, uint32_t cap, uint3
 } // extern "C"
 
 // The pixel list of a tile set (tile after tile; 8x8 blocks row-major inside a tile, row-major inside a block: a wave of 64 list entries is an 8x8
-// block of the image) and the frame-sized index map (pixel -> list position, -1 outside the set), written on the device from the tile descriptors:
-// one thread per list entry finds its tile by bisection over the tiles' first positions.
+// block of the image), written on the device from the tile descriptors: one thread per list entry finds its tile by bisection over the tiles' first positions.
 __global__ __launch_bounds__(256) void kz_tiles_expand(const KzTileDesc *__restrict__ tiles, uint32_t nTiles, uint32_t nPix, int width,
-                                                       uint32_t *__restrict__ pixList, int32_t *__restrict__ pixIndex) {
+                                                       uint32_t *__restrict__ pixList) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nPix) return;
     uint32_t lo = 0, hi = nTiles;                          // the last tile whose pixOffset <= i
@@ -311,12 +320,11 @@ __global__ __launch_bounds__(256) void kz_tiles_expand(const KzTileDesc *__restr
     const uint32_t yl = rem2 / wb, xl = rem2 - yl * wb;
     const uint32_t x = (uint32_t)t.x0 + 8u * c + xl, y = (uint32_t)t.y0 + 8u * r + yl;
     pixList[i] = x | (y << 16);
-    pixIndex[(size_t)y * (uint32_t)width + x] = (int32_t)i;
 }
 
 // Makes `tiles` the replica's tile set. Nothing here waits for the device: the descriptors go up through the call's stream, behind the end of the
 // previous call (evCallB), and the expansion kernel runs there - a change of tile set costs a few microseconds of host time and ~30 us of device
-// time (C5: 33 MB of index map), where it used to synchronise every stream, build both arrays on the host and copy them with blocking pageable copies.
+// time, where it used to synchronise every stream, build the list on the host and copy it with a blocking pageable copy.
 static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, uint32_t nTiles, hipStream_t stream) {
     const KzParams &P = scene->prm;
     KzTile whole = {0, 0, P.width, P.height};
@@ -359,9 +367,8 @@ static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, 
         }
     }
     const size_t framePix = (size_t)P.width * P.height;
-    if (!ds->pixIndex || ds->pixCap < framePix || ds->tileDevCap < nTiles) {          // first use (or a longer tile list than ever before): allocate
+    if (ds->pixCap < framePix || ds->tileDevCap < nTiles) {          // first use (or a longer tile list than ever before): allocate
         HIP_TRY(hipDeviceSynchronize());
-        if (!ds->pixIndex) KZ_ALLOC(&ds->pixIndex, framePix * sizeof(int32_t));
         if (ds->pixCap < framePix) {
             if (ds->pixList) (void)hipFree(ds->pixList);
             ds->pixList = nullptr; ds->pixCap = 0;
@@ -392,8 +399,7 @@ static int prepareTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, 
     std::memcpy(ds->tileHost, desc.data(), nTiles * sizeof(KzTileDesc));
     HIP_TRY(hipMemcpyAsync(ds->tileDev, ds->tileHost, nTiles * sizeof(KzTileDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(ds->evTiles, stream));
-    HIP_TRY(hipMemsetAsync(ds->pixIndex, 0xFF, framePix * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(kz_tiles_expand, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const KzTileDesc *)ds->tileDev, nTiles, (uint32_t)total, P.width, ds->pixList, ds->pixIndex);
+    hipLaunchKernelGGL(kz_tiles_expand, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const KzTileDesc *)ds->tileDev, nTiles, (uint32_t)total, P.width, ds->pixList);
     HIP_TRY(hipGetLastError());
     ds->nPix = (uint32_t)total;
     ds->curTiles.assign(tiles, tiles + nTiles);
@@ -412,28 +418,24 @@ static int stageMark(PassCtx &c, hipStream_t stream, int kind) {
 // Path state per (pixel, sample) item of a pass in flight: 8 float4 + uint4 + 3 queue words (wavefront) + 5 sample floats.
 static constexpr size_t KZ_STATE_BYTES_PER_ITEM = 8 * sizeof(float4) + sizeof(uint4) + 3 * sizeof(uint32_t);
 static constexpr size_t KZ_SAMPLE_BYTES_PER_ITEM = 5 * sizeof(float);
-static constexpr size_t KZ_TAP_BYTES_PER_PIXEL = (size_t)KZ_TAPS_MAX * KZ_TAPS_MAX * sizeof(float4);
 
 // ---- buffers of one pass context. The path-state arrays and the sample planes live in the context's arena (kz_arena.cpp), which GROWS on a side
 // thread: `want` items are asked for, the call returns as soon as `minItems` are there and the arena has stopped making quick progress (graceMs; < 0: wait
 // for everything), and tells how many items a pass may use now (*usable, never more than `want`). Nothing is left half-allocated on failure. ----
-static int ctxEnsure(PassCtx &c, size_t want, size_t minItems, double graceMs, size_t nPix, bool tapSums, hipStream_t stream, size_t *usable) {
-    if (tapSums && nPix > c.tapsCap) {                               // (only the tap-sum film path has this buffer)
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (c.taps) (void)hipFree(c.taps);
-        c.taps = nullptr; c.tapsCap = 0;
-        KZ_TRACE("ctxEnsure: tap sums, %.0f MB ...", nPix * KZ_TAP_BYTES_PER_PIXEL / 1e6);
-        KZ_ALLOC(&c.taps, nPix * KZ_TAP_BYTES_PER_PIXEL);
-        c.tapsCap = nPix;
-        KZ_TRACE("ctxEnsure: ... there");
-    }
+static int ctxEnsure(PassCtx &c, size_t want, size_t minItems, double graceMs, hipStream_t stream, size_t *usable) {
     if (!c.counts) { KZ_ALLOC(&c.counts, 8 * 520 * sizeof(uint32_t)); }
     KzArena &A = *c.arena;
     if (A.wouldReallocate(want)) HIP_TRY(hipDeviceSynchronize());      // (a small context outgrown, or a pass beyond the reserved ranges: what is there is given up first)
-    A.failCountdown.store(g_failAlloc); g_failAlloc = 0;             // (kz_debug_fail_alloc counts the arena's physical allocations as this thread's)
+#ifdef KZ_EXPERIMENTS
+    if (g_failAlloc > 0) { A.failCountdown.store(g_failAlloc); g_failAlloc = 0; }      // (kz_debug_fail_alloc counts the arena's physical allocations as this thread's)
+#endif
     size_t got = 0;
     const int rc = A.request(want, minItems, graceMs, &got);
-    g_failAlloc = A.failCountdown.exchange(0);
+#ifdef KZ_EXPERIMENTS
+    // what the call did not use up stays armed ON THE ARENA while its growth thread is still mapping levels (the thread is where the allocations of a growing
+    // context happen: ADVICE r05 - the count used to be taken back here, so a failure injected beyond the first levels never fired)
+    { std::lock_guard<std::mutex> g(A.m); if (!A.busy) g_failAlloc = A.failCountdown.exchange(0); }
+#endif
     if (rc) return rc;
     KzWf W{};
     if (KZ_STATE_AOS) {                                             // (development build: two 64-B records per slot laid over arrays 0-3 and 4-7 - not supported by the arena's SoA ranges)
@@ -766,6 +768,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     return KZ_OK;
 }
 
+// kz_render / kz_render_tiles on one replica: plan (kz_plan.cpp: pure arithmetic, tabulated by tests/test_plan_cpu.py) -> make room -> launch.
 static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts) {
     int rc;
     const KzParams &P = scene->prm;
@@ -778,130 +781,54 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     if (s0 >= s1 || s1 > P.sampleCount) return kz_fail(KZ_ERR_INVALID_ARG, "sample range [%u,%u) outside [0,%u)", s0, s1, P.sampleCount);
     hipStream_t stream = (hipStream_t)opts->stream;
     ds->lastStream = stream;
-    if ((rc = prepareTiles(scene, ds, opts->tiles, opts->nTiles, stream))) return rc;
-    if (!opts->accumulate) HIP_TRY(hipMemsetAsync(ds->film, 0, ds->filmPixels * sizeof(float4), stream));
     KzTune tune;
     if ((rc = resolveTune(opts->tune, tune))) return rc;
-    const int ftaps = P.tapHi - P.tapLo + 1;
-    const bool tapSums = ftaps <= KZ_TAPS_MAX && tune.filmGather != 1;
-    // ---- pass geometry. A pass is pixPerPass pixels x S samples of each = up to passItems (pixel, sample) items (default 2^27: 23.6 GB of
-    // path state + sample records per pass in flight; 2^25 -> 981, 2^26 -> 1031, 2^27 -> 1061-1066, 2^28 -> 1071 Msamples/s on C4 in round 1:
-    // fewer launches and shorter relative tails per sample). opts->tune.sppPerPass = 0: every pixel of the tile set and as many samples as
-    // fit; n > 0: n samples (or all the call asks for) of as many pixels as fit, pixel chunks in the order of the pixel list.
-    // The state never takes more than the caller's limit; without one, not more than 3/4 of the device and not more than what
-    // is free now plus what this replica already holds for the purpose (another process or replica may own the rest).
-    // Round 4, sized for the 288 GB of the card: with NOTHING said (passItems = passesInFlight = 0, no dealer) a call runs ONE pass at a time, as large as the state
-    // budget allows up to 2^30 items (175 GB). Same-call sweeps (profiles/r04r_pass_size): C4 2 x 2^27 1 772, 2 x 2^28 1 804, 2 x 2^29 1 827, 1 x 2^30 1 849 Msamples/s; C5 1 821 -> 1 890;
-    // C3 1 831 -> 1 842; a 128-spp call of C4 (one pass of 2^28 instead of two of 2^27) 1 753 -> 1 797: fewer, longer kernels have shorter relative tails, and a second pass in
-    // flight buys less than the memory it takes is worth as pass size. A dealer keeps two contexts (its batches overlap through them) of up to 2^29 items.
-    const bool autoShape = pipeline == 2 && !opts->passItems && !opts->passesInFlight;
-    int nCtx = pipeline == 2 ? (opts->passesInFlight ? opts->passesInFlight : (autoShape && !opts->dealer ? 1 : KZ_DEFAULT_PASSES_IN_FLIGHT)) : 1;
-    const size_t perItem = (pipeline == 2 ? KZ_STATE_BYTES_PER_ITEM : 0) + KZ_SAMPLE_BYTES_PER_ITEM;
-    // camera rays by pixel beams: a pinhole camera with an affine sample map, a stack that fits LDS twice, unless the caller asks otherwise
-    const bool beams = pipeline == 2 && P.beamOk && tune.packet != 1 && tune.packet != 2 && P.maxDepth > 0;
-    const size_t perPixel = tapSums ? KZ_TAP_BYTES_PER_PIXEL : 0;
-    size_t limit = opts->maxStateBytes;
-    if (!limit) {
-        size_t freeB = 0, totalB = 0;
-        const size_t held = ds->ctxBytes() + kzCtxPoolBytes(ds->device);          // what this replica's contexts and the device's idle pooled contexts hold (the beam lists - one per frame pixel, 264 B each - are the replica's, not part of this budget)
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) limit = std::min(totalB / 4 * 3, freeB + held - std::min(freeB + held, (size_t)256 << 20));
-        else limit = (size_t)32 << 30;
-    }
-    const uint32_t nSamples = s1 - s0;
-    // The default pass size (autoShape) is EARNED. A pass of 2^30 items is 5 % faster than passes of 2^27 (profiles/r04r_pass_size), but its 175 GB have a price
-    // that someone pays: memory a process releases is wiped by the driver at ~33 GB/s, and whoever allocates before the wipe is through - the next job of a batch
-    // of one-frame processes, a second process, this process's next scene - waits for the WHOLE wipe inside one allocation call, and the GPU work of that process
-    // waits with it (profiles/r05a_alloc, r05d_cold_job: a one-frame job started right behind another one's exit sat 4-5 s in its first pass whatever the size of ITS
-    // context; growing the context on a side thread does not help, the device side of the process stalls). What a job CAN do is leave little behind. So the first
-    // call on a context asks for what rounds 1-3 ran with - 2^28 items (47 GB: 1.4 s of wiping for whoever comes next, passes 3 % slower than 2^30) when the call
-    // has at least 2^30 items of work, 2^27 otherwise - and a context may double with every further call: a one-frame job is over before the large pass would
-    // have paid, a process that keeps rendering (bench.py's steps, scene after scene through the device's pool) runs passes of 2^30 from its third or fourth call.
-    size_t earned = (size_t)1 << (opts->dealer ? 29 : 30);
-    if (autoShape) {
-        const size_t callItems = (size_t)ds->nPix * (s1 - s0) / (opts->dealer ? std::max<uint32_t>(1, opts->dealer->takers) : 1u);
-        const size_t byWork = (size_t)1 << (callItems >= ((size_t)1 << 30) ? 28 : 27);
-        // (what the context was last ASKED to hold, not what it holds: a context that is still growing - or growing slowly - earns the same as a complete one;
-        //  a fresh replica takes the pool's largest context and goes on from what that holds)
-        const size_t before = ds->ctx[0] ? std::max(ds->ctx[0]->wanted, ds->ctx[0]->items()) : kzCtxPoolMaxItems(ds->device);
-        earned = std::min(earned, std::max(byWork, 2 * before));
-    }
-    const size_t wantItems = std::max<size_t>(opts->passItems ? (size_t)opts->passItems : (autoShape ? earned : (size_t)1 << 27), 64);
-    // Dynamic dealing (opts->dealer, ABI v5): the tile set is the whole list, a batch of tiles is a range of its pixel list, and the pass shape is
-    // chosen for the pixels of a BATCH instead of those of the set.
+    if (tune.filmGather != 0 && tune.filmGather != 3) return kz_fail(KZ_ERR_UNSUPPORTED, "KzTuning.filmGather %d: the staged gather kernel of round 1 is gone (round 6: the film is resolved from running tap sums for every filter); 0 = default, 3 = one lane per pixel", tune.filmGather);
+    if ((rc = prepareTiles(scene, ds, opts->tiles, opts->nTiles, stream))) return rc;
+    // the film: running tap sums of the frame's pixels (kz_film.hip), part of the replica like the film itself - cleared unless the call accumulates
+    { const bool fresh = !ds->tapSums; if ((rc = kzFilmEnsureTapSums(scene, ds, stream))) return rc; if (!opts->accumulate && !fresh) HIP_TRY(hipMemsetAsync(ds->tapSums, 0, ds->tapSumsBytes, stream)); }
     const KzTileDealer *dealer = opts->dealer;
-    const uint32_t nTilesSet = (uint32_t)ds->curTiles.size();
-    uint32_t batchTiles = 0;
     if (dealer) {
         if (!dealer->counter || (dealer->takenCap && (!dealer->taken || !dealer->nTaken))) return kz_fail(KZ_ERR_INVALID_ARG, "KzTileDealer: null counter / taken buffer");
         if (pipeline != 2) return kz_fail(KZ_ERR_UNSUPPORTED, "dynamic tile dealing needs the wavefront pipeline");
-        // a batch = about two passes' worth of (pixel, sample) items, never more (so that its pixels x half its samples fill a pass exactly when the
-        // tiles are equal), at most 1 / (4 x takers) of the list; counted with the LARGEST tile, and the pass shape below with the largest batch
-        uint64_t maxTile = 1;
-        for (uint32_t t = 0; t < nTilesSet; ++t) maxTile = std::max<uint64_t>(maxTile, ds->tilePixOffset[t + 1] - ds->tilePixOffset[t]);
-        batchTiles = dealer->batchTiles ? dealer->batchTiles
-                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(2 * (uint64_t)wantItems / std::max<uint64_t>(1, maxTile * nSamples), std::max<uint32_t>(1, nTilesSet / (4 * std::max<uint32_t>(1, dealer->takers)))));
         if (dealer->nTaken) *dealer->nTaken = 0;
-        if (dealer->agreed) {                                // the takers of one counter must have resolved the same batch size for the same list
-            const uint32_t mine = ((batchTiles * 0x9E3779B1u) ^ (nTilesSet * 0x85EBCA6Bu)) | 1u;
-            uint32_t seen = 0;
-            if (!__atomic_compare_exchange_n((uint32_t *)dealer->agreed, &seen, mine, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) && seen != mine)
-                return kz_fail(KZ_ERR_INVALID_ARG, "KzTileDealer: this taker resolved batches of %u tiles of a list of %u, another taker of the same counter resolved something else "
-                                                   "(all takers must pass the same tile list, sample range, pass options and `takers`)", batchTiles, nTilesSet);
-        }
     }
-    uint32_t nPixSet = ds->nPix;
-    if (dealer) {                                            // (batches start at multiples of batchTiles: the counter only ever advances by that)
-        nPixSet = 1;
-        for (uint32_t tb = 0; tb < nTilesSet; tb += batchTiles) nPixSet = std::max(nPixSet, ds->tilePixOffset[std::min(nTilesSet, tb + batchTiles)] - ds->tilePixOffset[tb]);
+    // ---- plan. The pass contexts never take more than the caller's limit; without one, not more than 3/4 of the device and not more than what is free now plus
+    // what this replica already holds for the purpose (another process or replica may own the rest).
+    KzPlanIn in;
+    in.pipeline = pipeline; in.nPix = ds->nPix; in.s0 = s0; in.s1 = s1;
+    in.passItems = opts->passItems; in.passesInFlight = opts->passesInFlight; in.sppPerPass = opts->tune.sppPerPass;
+    in.perItem = (pipeline == 2 ? KZ_STATE_BYTES_PER_ITEM : 0) + KZ_SAMPLE_BYTES_PER_ITEM;
+    in.limit = opts->maxStateBytes;
+    if (!in.limit) {
+        size_t freeB = 0, totalB = 0;
+        const size_t held = ds->ctxBytes() + kzCtxPoolBytes(ds->device);          // what this replica's contexts and the device's idle pooled contexts hold (the beam lists - one per frame pixel, 264 B each - and the film's tap sums are the replica's, not part of this budget)
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) in.limit = std::min(totalB / 4 * 3, freeB + held - std::min(freeB + held, (size_t)256 << 20));
+        else in.limit = (size_t)32 << 30;
     }
-    // the shape of a pass of `want` items over `nPixRange` pixels: sample count s, pixel count px
-    auto shapeFor = [&](size_t want, uint32_t nPixRange, uint32_t &s, uint32_t &px) {
-        want = std::max<size_t>(want, 64);
-        if (opts->tune.sppPerPass > 0) { s = std::min<uint32_t>((uint32_t)opts->tune.sppPerPass, nSamples); px = (uint32_t)std::min<size_t>(nPixRange, std::max<size_t>(64, want / s / 64 * 64)); return; }
-        px = nPixRange; s = (uint32_t)std::min<size_t>(std::max<size_t>(1, want / std::max<uint32_t>(1, nPixRange)), nSamples);
-        // A frame too large for 64 samples of every pixel per pass (C5 on one GPU: 16) is rendered in pixel chunks of 256 samples instead: a wave of the
-        // camera-ray kernels is then one pixel again (one shared list), the film stage touches a chunk per pass instead of the whole frame, and the paths of a pass
-        // stay in a part of the scene (C5, same call: 1 586 Msamples/s at 16 x all pixels, 1 708 at 64 x 2 M, 1 734 at 256 x 512 K).
-        // (round 4, default pass size 2^30: C5 at 128 x all 8.3 M pixels 1 865 Msamples/s, at 256 x 4.2 M pixels 1 890: the chunks are taken below 256 samples then)
-        const uint32_t chunkBelow = autoShape ? 256u : 64u;
-        if (s < chunkBelow && nSamples >= chunkBelow) { s = std::min<uint32_t>(256u, nSamples); px = (uint32_t)std::min<size_t>(nPixRange, std::max<size_t>(64, want / s / 64 * 64)); }
-        // a multiple of 64 samples per pixel keeps every wave of the camera-ray kernels inside one pixel (one shared leaf list) - taken when it costs no extra pass
-        // (a rank's share of a frame: 2^27 / 1 036 800 pixels = 129 -> 128)
-        else if (s > 64 && s % 64 && (nSamples + s / 64 * 64 - 1) / (s / 64 * 64) == (nSamples + s - 1) / s) s = s / 64 * 64;
-    };
-    uint32_t S, pixPerPass;
-    shapeFor(wantItems, nPixSet, S, pixPerPass);
-    // the largest pass of the wanted shape that fits `room` bytes: fewer samples first, then (from one sample) fewer pixels
-    auto shape = [&](size_t room, uint32_t &s, uint32_t &px) {
-        s = S; px = pixPerPass;
-        if ((size_t)px * (s * perItem + perPixel) <= room) return;
-        const size_t sFit = room / px > perPixel ? (room / px - perPixel) / perItem : 0;
-        if (sFit >= 1) { s = (uint32_t)std::min<size_t>(s, sFit); if (s > 64) s = s / 64 * 64; }      // (whole waves of one pixel for the camera-ray kernels)
-        else { s = 1; px = (uint32_t)std::min<size_t>(px, room / (perItem + perPixel) / 64 * 64); }
-    };
-    // as many contexts as wanted, but never more than there are passes (a call that is one pass runs it in one context at full size)
-    uint32_t nPasses = 0;
-    for (;; --nCtx) {
-        uint32_t s, px;
-        shape(limit / (size_t)nCtx, s, px);
-        if (px > 0) nPasses = dealer ? 0xFFFFu : ((ds->nPix + px - 1) / px) * ((nSamples + s - 1) / s);      // (a dealer: not known, assume many)
-        if (nCtx > 1 && (px == 0 || nPasses < (uint32_t)nCtx)) continue;
-        if (px == 0) return kz_fail(KZ_ERR_OOM, "64 (pixel, sample) items need %zu bytes of path state, the limit is %zu", (size_t)64 * (perItem + perPixel), limit);
-        S = s; pixPerPass = px;
-        break;
-    }
-    const size_t need = (size_t)pixPerPass * S;
-    if (need >= (1ull << 32)) return kz_fail(KZ_ERR_UNSUPPORTED, "pass of %zu items (limit 2^32)", need);
-    // Several passes in flight on internal streams when the call has at least two: the persistent traversal kernels of one pass
-    // drain (fewer and fewer busy waves) while the other passes keep the machine full. The passes are independent except for the
-    // film, whose read-modify-write kernel is chained with events in pass order.
-    const bool multi = pipeline == 2 && nPasses >= 2 && nCtx >= 2;
-    if (!multi) nCtx = 1;
+    const uint32_t nTilesSet = (uint32_t)ds->curTiles.size();
+    in.dealer = dealer != nullptr;
+    if (dealer) { in.takers = dealer->takers; in.dealerBatchTiles = dealer->batchTiles; in.nTiles = nTilesSet; in.tilePixOffset = ds->tilePixOffset.data(); }
+    // (what the first context was last ASKED to hold, not what it holds: a context that is still growing - or growing slowly - earns the same as a complete one;
+    //  a fresh replica takes the pool's largest context and goes on from what that holds)
+    in.heldBefore = ds->ctx[0] ? std::max(ds->ctx[0]->wanted, ds->ctx[0]->items()) : kzCtxPoolMaxItems(ds->device);
+    KzPlan pl;
+    { std::string why; if ((rc = kzPlanCall(in, pl, why))) return kz_fail(rc, "%s", why.c_str()); }
+    const int nCtx = pl.nCtx;
+    const bool multi = pl.multi;
+    const size_t need = pl.need, limit = in.limit, perItem = in.perItem;
+    const uint32_t batchTiles = pl.batchTiles;
+    if (dealer && !kzDealerAgree(dealer, batchTiles, nTilesSet))
+        return kz_fail(KZ_ERR_INVALID_ARG, "KzTileDealer: this taker resolved batches of %u tiles of a list of %u, another taker of the same counter resolved something else "
+                                           "(all takers must pass the same tile list, sample range, pass options and `takers`)", batchTiles, nTilesSet);
+    // camera rays by pixel beams: a pinhole camera with an affine sample map, a stack that fits LDS twice, unless the caller asks otherwise
+    const bool beams = pipeline == 2 && P.beamOk && tune.packet != 1 && tune.packet != 2 && P.maxDepth > 0;
     {   // memory this call does not use is given back when the call needs it: contexts beyond nCtx, what the device's pool holds idle, and - under a
-        // limit below what an earlier call grew them to - the tails of the contexts it does use
-        const size_t perCtx = need * perItem + pixPerPass * perPixel;
+        // limit below what an earlier call grew them to - the tails of the contexts it does use (a growth thread still mapping towards an earlier, larger
+        // target is told the new one first: ADVICE r05)
+        const size_t perCtx = need * perItem;
         size_t keep = 0;
-        for (int i = 0; i < nCtx; ++i) keep += std::max(ds->ctxAt(i).bytes(), perCtx);            // (taken from the device's pool here, with whatever they hold)
+        for (int i = 0; i < nCtx; ++i) { PassCtx &c = ds->ctxAt(i); if (c.arena) c.arena->lowerTarget(need); keep += std::max(c.bytes(), perCtx); }      // (taken from the device's pool here, with whatever they hold)
         for (int i = KZ_MAX_PASSES_IN_FLIGHT - 1; i >= nCtx; --i) {
             if (!ds->ctx[i] || !ds->ctx[i]->bytes()) continue;
             if (keep + ds->ctx[i]->bytes() > limit) { HIP_TRY(hipDeviceSynchronize()); ds->ctx[i]->release(); } else keep += ds->ctx[i]->bytes();
@@ -912,7 +839,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
                 HIP_TRY(hipDeviceSynchronize());
                 // (a context that has grown into mapped levels cannot hold fewer than one of them - 1.5 GB -: under a cap below that it starts over as a small one)
                 if (need <= KzArena::kSmallMax) ds->ctx[i]->arena->releaseAll(); else ds->ctx[i]->arena->shrinkTo(need);
-                ds->ctx[i]->trimAux(tapSums ? pixPerPass : 0);                                     // (a pooled context may carry another frame's tap sums and overflow stacks)
+                ds->ctx[i]->trimAux();                                                             // (a pooled context may carry another frame's overflow stacks)
             }
     }
     if (!ds->evCallA) { HIP_TRY(hipEventCreate(&ds->evCallA)); HIP_TRY(hipEventCreate(&ds->evCallB)); }
@@ -944,21 +871,14 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         HIP_TRY(hipEventRecord(ds->evFork, stream));
         for (int i = 0; i < nCtx; ++i) HIP_TRY(hipStreamWaitEvent(ds->passStream[i], ds->evFork, 0));
     }
-    // A pass context GROWS (kz_arena.cpp): its memory is mapped on a side thread while the passes already run. With everything left to the library
-    // (autoShape) a pass takes what its context holds at that moment - the first passes of a job that starts behind the driver's wipe of recently released
-    // memory are small, on clean memory the context is complete before the first pass - and with an explicit pass size or number of passes in flight the
-    // call waits for the size it was asked for (the pass structure, hence the grouping of the film's float additions, is then the same from run to run).
     // Everything ELSE the call allocates is allocated now, before the first context is asked to grow: behind a wipe the growth thread takes whatever
     // clean memory there is the moment it appears, and a hipMalloc of this thread issued after that waits for the wipe like any other (round 5: the beam
     // lists, allocated inside the first pass, held the first call of a job for seconds while its context was already 80 GB large).
-    if (autoShape) for (int i = 0; i < nCtx; ++i) ds->ctxAt(i).wanted = need;
-    KZ_TRACE("renderOn: %u pixels x samples [%u, %u), target pass %zu items (%u px x %u spp), limit %.1f GB, %d context(s)", ds->nPix, s0, s1, need, pixPerPass, S, limit / 1e9, nCtx);
+    if (pl.autoShape) for (int i = 0; i < nCtx; ++i) ds->ctxAt(i).wanted = need;
+    KZ_TRACE("renderOn: %u pixels x samples [%u, %u), target pass %zu items (%u px x %u spp), limit %.1f GB, %d context(s)", ds->nPix, s0, s1, need, pl.pixPerPass, pl.S, limit / 1e9, nCtx);
     if (beams && (rc = ensureBeamBuffers(scene, ds, stream))) return rc;
     if (pipeline == 2) for (int i = 0; i < nCtx; ++i) if ((rc = ensureOverflow(scene, ds, ds->ctxAt(i), tune, multi ? ds->passStream[i] : stream))) return rc;
     KZ_TRACE("renderOn: beam / overflow buffers there");
-    const bool grow = pipeline == 2 && autoShape && need > ((size_t)1 << 26);
-    const size_t minStart = grow ? std::min<size_t>(need, (size_t)1 << 20) : need;
-    const double graceMs = grow ? 5.0 : -1.0;
     // evFilm[i] of a context that has not run a pass in this call must not be waited for: inFlight marks the ones that have
     bool inFlight[KZ_MAX_PASSES_IN_FLIGHT] = {};
     uint32_t pass = 0;
@@ -971,11 +891,11 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         hipStream_t pst = multi ? ds->passStream[ci] : stream;
         // While the context is still growing the host must not plan the whole job on what is mapped NOW (it queues passes a thousand times faster than
         // the device runs them): it stays one pass ahead - pass k + 1 is planned when pass k - 1 has finished, with what has been mapped by then.
-        if (grow && !dealer && lastAvail < need && pass >= 2) HIP_TRY(hipEventSynchronize(ds->events[pass - 2].b));
+        if (pl.grow && !dealer && lastAvail < need && pass >= 2) HIP_TRY(hipEventSynchronize(ds->events[pass - 2].b));
         // Back-pressure of dynamic dealing: the host takes the next batch only when the context it needs has finished its previous pass, so a device
         // holds at most nCtx passes - never the whole frame - and a slower device simply comes back to the counter less often.
         if (dealer && inFlight[ci]) HIP_TRY(hipEventSynchronize(ds->evFilm[ci]));
-        const int rc_ = ctxEnsure(c, need, minStart, graceMs, pixPerPass, tapSums, pst, usable);
+        const int rc_ = ctxEnsure(c, need, pl.minStart, pl.graceMs, pst, usable);
         lastAvail = *usable;
         KZ_TRACE("pass %u: context %d holds %zu M items", pass, ci, *usable >> 20);
         return rc_;
@@ -987,6 +907,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         const int ci = multi ? (int)(pass % (uint32_t)nCtx) : 0;
         PassCtx &c = ds->ctxAt(ci);
         hipStream_t pst = multi ? ds->passStream[ci] : stream;
+        if (items > c.items()) return kz_fail(KZ_ERR_STATE, "pass of %zu items planned on a context that holds %zu", items, c.items());      // (the planner's invariant, kz_plan.h: never a write beyond what is mapped)
         if (!firstPassItems) firstPassItems = items;
         largestPassItems = std::max(largestPassItems, items);
         if (beams) {
@@ -1010,56 +931,28 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         }
         HIP_TRY(hipEventRecord(ep.b, pst));
         HIP_TRY(hipGetLastError());
+        // the film stage adds this pass's samples to the running tap sums of its pixels, behind the film stage of the pass before it (another stream's)
         const int prev = (ci + nCtx - 1) % nCtx;
-        if ((rc = kzFilmStage(scene, ds, c, pst, pixList, p0, nPixPass, Sp, tapSums, (multi && pass > 0) ? ds->evFilm[prev] : nullptr, tune.filmGather != 3))) return rc;
+        if ((rc = kzFilmStage(scene, ds, c, pst, pixList, nPixPass, Sp, (multi && pass > 0) ? ds->evFilm[prev] : nullptr, tune.filmGather == 3 ? 1 : 0))) return rc;
         if (multi || dealer) { HIP_TRY(hipEventRecord(ds->evFilm[ci], pst)); inFlight[ci] = true; }      // (a dealer paces itself on this event even with one context)
         if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
         ds->lastCtx = ci;
         ++pass;
         return KZ_OK;
     };
-    // The passes of pixels [b0, b1) of the list: columns of pixel chunks, each rendered in sample ranges. A column's width and every pass's sample count
-    // follow what the context holds when the pass is planned, never beyond the call's target shape (pixPerPass x S): with the context complete this is the
-    // fixed schedule "pixel chunks x sample ranges of S".
-    auto passesOf = [&](uint32_t b0, uint32_t b1) -> int {
-        for (uint32_t p0 = b0; p0 < b1;) {
-            size_t avail = 0;
-            if ((rc = nextCtx(&avail))) return rc;
-            uint32_t w = std::min(pixPerPass, b1 - p0);
-            if (avail < (size_t)w * std::min<uint32_t>(S, nSamples)) {                   // the context is still growing: the column it can serve now
-                uint32_t sCol = 0, wCol = 0;
-                shapeFor(avail, b1 - p0, sCol, wCol);
-                w = std::max<uint32_t>(1, std::min(w, wCol));
-            }
-            for (uint32_t s = s0; s < s1;) {
-                if (s != s0 && (rc = nextCtx(&avail))) return rc;
-                uint32_t Sp = (uint32_t)std::min<size_t>({(size_t)(s1 - s), (size_t)S, std::max<size_t>(1, avail / w)});
-                if (Sp > 64 && Sp < s1 - s) Sp = Sp / 64 * 64;                           // (whole waves of one pixel for the camera-ray kernels)
-                if ((rc = onePass(p0, w, s, Sp))) return rc;
-                s += Sp;
-            }
-            p0 += w;
-        }
-        return KZ_OK;
-    };
-    if (!dealer) { if ((rc = passesOf(0, ds->nPix))) return rc; }
+    if (!dealer) { if ((rc = kzPlanRun(pl, 0u, ds->nPix, s0, s1, nextCtx, onePass))) return rc; }
     else {
         // BlockGenerator::next (block.cpp:117-148): batches of the tile list from the shared counter (it may live in memory shared between processes)
-        for (;;) {
-            if (dealer->takenCap && *dealer->nTaken + 2 > dealer->takenCap) break;
-            const uint32_t tb = __atomic_fetch_add((uint32_t *)dealer->counter, batchTiles, __ATOMIC_RELAXED);
-            if (tb >= nTilesSet) break;
-            const uint32_t te = std::min(nTilesSet, tb + batchTiles);
-            if (dealer->takenCap) { dealer->taken[*dealer->nTaken] = tb; dealer->taken[*dealer->nTaken + 1] = te; *dealer->nTaken += 2; }
-            if ((rc = passesOf(ds->tilePixOffset[tb], ds->tilePixOffset[te]))) return rc;
-        }
+        for (uint32_t tb, te; kzDealerTake(dealer, batchTiles, nTilesSet, tb, te);)
+            if ((rc = kzPlanRun(pl, ds->tilePixOffset[tb], ds->tilePixOffset[te], s0, s1, nextCtx, onePass))) return rc;
     }
     if (multi)                                                         // join: everything after this call on `stream` sees the film
         for (int i = 0; i < nCtx; ++i) if (inFlight[i]) HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[i], 0));
+    if ((rc = kzFilmResolve(scene, ds, stream))) return rc;           // the film texels from the tap sums: once per call
     HIP_TRY(hipEventRecord(ds->evCallB, stream));
     ds->lastDual = multi;
-    ds->lastInfo.passes = pass; ds->lastInfo.passesInFlight = (uint32_t)nCtx; ds->lastInfo.itemsPerPass = need; ds->lastInfo.sppPerPass = S;
-    ds->lastInfo.pixels = ds->nPix; ds->lastInfo.stateBytes = ds->ctxBytes(); ds->lastInfo.pixelsPerPass = pixPerPass;
+    ds->lastInfo.passes = pass; ds->lastInfo.passesInFlight = (uint32_t)nCtx; ds->lastInfo.itemsPerPass = need; ds->lastInfo.sppPerPass = pl.S;
+    ds->lastInfo.pixels = ds->nPix; ds->lastInfo.stateBytes = ds->ctxBytes(); ds->lastInfo.pixelsPerPass = pl.pixPerPass;
     ds->lastInfo.firstPassItems = firstPassItems; ds->lastInfo.largestPassItems = largestPassItems;
     ds->growNote.clear();
     for (int i = 0; i < nCtx; ++i) if (ds->ctx[i] && ds->ctx[i]->arena) { std::lock_guard<std::mutex> g(ds->ctx[i]->arena->m); if (ds->ctx[i]->arena->growthFailed) ds->growNote = ds->ctx[i]->arena->errMsg; }

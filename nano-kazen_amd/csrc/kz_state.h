@@ -50,7 +50,7 @@ struct KzTune { int refill, postpone, batch, travBlocksPerCU, shadeBlocksPerCU, 
 #define KZ_BEAM_CAP 32                // leaves per pixel list (16 / 24 / 48 measured in r03o: 32 stays)
 #endif
 
-struct KzTileRect { int32_t x0, y0, w, h; uint32_t offset; uint32_t prevStart, prevCount; };
+struct KzTileRect { int32_t x0, y0, w, h; uint32_t offset; };
 struct KzTileDesc { int32_t x0, y0, w, h; uint32_t pixOffset; };      // a tile of the current set and the position of its first pixel in the pixel list
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return kz_fail(KZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
@@ -68,10 +68,17 @@ struct DevMem {
     template <class Tp> Tp *as() const { return (Tp *)p; }
 };
 
-// kz_debug_trace (kazen_mi355x_dev.h): a timeline of the allocation / growth / pass-planning events of the calling process on stderr (development aid)
+// kz_debug_trace (kazen_mi355x_dev.h, development builds): a timeline of the allocation / growth / pass-planning events of the calling process on stderr
+#ifdef KZ_EXPERIMENTS
 extern std::atomic<int> g_kzTrace;
 void kzTraceLine(const char *fmt, ...);
 #define KZ_TRACE(...) do { if (g_kzTrace.load(std::memory_order_relaxed)) kzTraceLine(__VA_ARGS__); } while (0)
+int kzPhysicalDevice(int logical);            // kz_debug_alias_devices: the HIP device behind the index a replica is addressed by
+#else
+#define KZ_TRACE(...) do { } while (0)
+static inline int kzPhysicalDevice(int logical) { return logical; }
+#endif
+int kzLogicalDeviceCount();                   // kz_arena.cpp: devices the library presents (= hipGetDeviceCount unless a development build aliases them)
 
 struct EventPair { hipEvent_t a, b; };
 // The path-state memory of one pass context (kz_arena.cpp). Up to 2^23 items: hipMalloc arrays of the size asked for. Beyond: one reserved virtual range
@@ -91,7 +98,15 @@ struct KzArena {
     std::atomic<size_t> mapped{0};
     std::mutex m; std::condition_variable cvProgress; std::thread th;
     bool stop = false, busy = false, growthFailed = false; size_t target = 0;
-    std::atomic<int> failCountdown{0};        // kz_debug_fail_alloc: the nth physical allocation from now on fails
+    std::atomic<int> failCountdown{0};        // kz_debug_fail_alloc (development builds): the nth physical allocation from now on fails
+    bool injectedFailure() {
+#ifdef KZ_EXPERIMENTS
+        int fc = failCountdown.load();
+        return fc > 0 && failCountdown.compare_exchange_strong(fc, fc - 1) && fc == 1;
+#else
+        return false;
+#endif
+    }
     int err = 0; std::string errMsg;
     std::chrono::steady_clock::time_point lastProgress;
     explicit KzArena(int dev);
@@ -102,6 +117,7 @@ struct KzArena {
     bool wouldReallocate(size_t items) const;
     int request(size_t items, size_t minItems, double graceMs, size_t *got);
     void shrinkTo(size_t items);
+    void lowerTarget(size_t items);
     void releaseAll();
     template <class Tp> Tp *array(int a) const { return (Tp *)base[a]; }
 private:
@@ -113,7 +129,6 @@ struct PassCtx {
     KzArena *arena = nullptr;                                    // the path-state arrays and the five sample planes (jx | jy | r | g | b)
     KzWf wf{};                                                   // (pointers into the arena, set by ctxEnsure)
     float *plane[5] = {};                                        // the five sample planes jx | jy | r | g | b (each its own range of the arena)
-    float *taps = nullptr; size_t tapsCap = 0;                   // kz_film_taps: taps^2 float4 per pixel of the tile set
     uint32_t *counts = nullptr;                                  // queue counters of a pass (8 x 520 words)
     uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
@@ -121,18 +136,16 @@ struct PassCtx {
     uint64_t beamSeen = 0;                                       // the last beam-list build (KzDeviceState::beamSeq) this context's stream has waited for
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
     size_t items() const { return arena ? arena->mapped.load() : 0; }
-    size_t bytes() const { return (arena ? arena->bytes() : 0) + ovfCap * sizeof(uint32_t) + tapsCap * 400 + litCap * 4; }
+    size_t bytes() const { return (arena ? arena->bytes() : 0) + ovfCap * sizeof(uint32_t) + litCap * 4; }
     // gives the memory back (the context stays usable: it grows again on demand); the caller has synchronised the device
     void release() {
         if (arena) arena->shrinkTo(0);
         wf = KzWf{}; for (float *&q : plane) q = nullptr; wanted = 0;
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
-        if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0;
         if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
     }
     // buffers sized for another frame (a pooled context): given back when a call is short of memory (the caller has synchronised the device)
-    void trimAux(size_t pixNeeded) {
-        if (tapsCap > pixNeeded) { if (taps) (void)hipFree(taps); taps = nullptr; tapsCap = 0; }
+    void trimAux() {
         if (ovf) { (void)hipFree(ovf); ovf = nullptr; ovfCap = 0; }
         if (litQueue) { (void)hipFree(litQueue); litQueue = nullptr; litCap = 0; }
     }
@@ -150,17 +163,20 @@ void kzCtxRelease(int device, PassCtx *c);
 size_t kzCtxPoolBytes(int device);
 size_t kzCtxPoolMaxItems(int device);
 size_t kzCtxPoolTrim(int device, size_t keepBytes);
+size_t kzCtxPoolTrimPhysical(int hipDevice);      // every idle pooled context that lives on that HIP device (kzMalloc's answer to an out-of-memory)
 struct KzDeviceState {
-    int device = -1;
+    int device = -1;                                             // the index the caller addresses this replica by
+    int hipDevice = -1;                                          // the HIP device it lives on (the same number, unless a development build aliases devices: kz_debug_alias_devices)
     KzDevTables T{};
     std::vector<void *> allocs;
     float4 *film = nullptr; size_t filmPixels = 0;
+    float4 *tapSums = nullptr; size_t tapSumsBytes = 0;          // the running tap sums of every pixel of the frame, [tap][y * width + x] (kz_film.hip): what the film is resolved from
     uint8_t *srgb = nullptr;                                     // staging raster of kz_film_to_srgb8 (allocated on first use)
-    float4 *packDev = nullptr; size_t packCap = 0; KzTileRect *rectsDev = nullptr; size_t rectsCap = 0; uint32_t *prevDev = nullptr; size_t prevCap = 0;      // kz_film_download_tiles: packed tile rects + their tables
+    float4 *packDev = nullptr; size_t packCap = 0; KzTileRect *rectsDev = nullptr; size_t rectsCap = 0;      // kz_film_download_tiles: packed tile rects + their table
     float4 *packHost = nullptr; size_t packHostCap = 0;           // pinned staging of the same (D2H at link rate)
-    // The tile set: pixList = its pixels (tile after tile, 8x8 blocks row-major inside a tile, row-major inside a block), pixIndex = the position of
-    // every pixel of the frame in that list (-1: not in the set). Both are written on the device from the tile descriptors (kz_tiles_expand).
-    uint32_t *pixList = nullptr; int32_t *pixIndex = nullptr; size_t pixCap = 0; uint32_t nPix = 0;
+    // The tile set: pixList = its pixels (tile after tile, 8x8 blocks row-major inside a tile, row-major inside a block), written on the device from the
+    // tile descriptors (kz_tiles_expand).
+    uint32_t *pixList = nullptr; size_t pixCap = 0; uint32_t nPix = 0;
     KzTileDesc *tileDev = nullptr; size_t tileDevCap = 0; KzTileDesc *tileHost = nullptr; size_t tileHostCap = 0; hipEvent_t evTiles = nullptr;
     std::vector<KzTile> curTiles; std::vector<uint32_t> tilePixOffset;      // tilePixOffset[t]: first list position of tile t (+ the total at the end)
     bool tilesValid = false; uint64_t tileGen = 0;                          // tileGen: bumped whenever the pixel list changes
@@ -190,7 +206,10 @@ static inline int requireDevice(KzScene *scene, KzDeviceState **out) { return fi
 size_t packedFloats(const KzParams &P, const KzTile *tiles, uint32_t nTiles);
 int checkTiles(const KzParams &P, const KzTile *tiles, uint32_t nTiles);
 int downloadTiles(KzScene *scene, KzDeviceState *ds, const KzTile *tiles, uint32_t nTiles, float *packed, size_t nFloats, hipStream_t stream);
-int kzFilmInit();
-// The film stage of one pass (ImageBlock::put for every sample record of the pass): launches on `pst`; `waitFilm` (or null) is the event the film's read-modify-write waits for.
-int kzFilmStage(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t pst, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t Sp, bool tapSums, hipEvent_t waitFilm, bool twoLanes = false);
-#define KZ_TAPS_MAX 5                        // gaussian / mitchell radius 2: taps -2..2
+// The film (kz_film.hip): running tap sums per frame pixel, fed by every pass (kzFilmStage: ImageBlock::put for the sample records of the pass, launched on `pst` behind
+// `waitFilm`), resolved into the film texels once per call (kzFilmResolve).
+#define KZ_FILM_GRID 64                      // the canonical tile grid of the resolve = kz_deal_tiles' default tile: the film of one device equals the host merge of its tiles' rects bit for bit
+int kzFilmEnsureTapSums(KzScene *scene, KzDeviceState *ds, hipStream_t stream);
+int kzFilmClear(KzDeviceState *ds, hipStream_t stream);
+int kzFilmStage(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t pst, const uint32_t *pixList, uint32_t nPixPass, uint32_t Sp, hipEvent_t waitFilm, int lanesPerPixel);
+int kzFilmResolve(KzScene *scene, KzDeviceState *ds, hipStream_t stream);

@@ -7,7 +7,7 @@
 //                                 stack (KEYS), LDS top-of-tree (TOP), mixed closest-hit + shadow launches (MODE 3), full sibling sort
 //   kz_wf_trace_dq                decoupled leaf phase (per-wave LDS job queue)
 #pragma once
-#include "kz_wavefront.h"
+#include "../../kz_wavefront.h"
 
 // ---- extend: closest hit for the rays of a queue (queue == nullptr: identity over [0, count)) --------------------------
 // KEEP: leave the previous hit record in place on a miss and read the ray from the shA/shB pair (walk-through, H6).

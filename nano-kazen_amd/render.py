@@ -9,8 +9,8 @@ from . import abi
 class Scene:
     """kz_scene_create -> [kz_scene_upload] -> kz_render* -> kz_film_download."""
 
-    def __init__(self, desc, device=None):
-        self.lib = abi.load_library()
+    def __init__(self, desc, device=None, lib=None):
+        self.lib = lib or abi.load_library()      # (lib: a development build of the library, abi.load_dev_library() - tests only)
         self.desc = desc
         cdesc = desc.to_c()
         h = C.c_void_p()
@@ -139,6 +139,19 @@ class Scene:
         assert film.dtype == np.float32 and film.flags["C_CONTIGUOUS"]
         abi.check(self.lib, self.lib.kz_film_merge_tiles(film.ctypes.data_as(abi.f32p), self.width, self.height, self.border, arr, len(tiles),
                                                           packed.ctypes.data_as(abi.f32p), packed.size, int(threads)))
+        return film
+
+    def merge_rects(self, film, entries, threads=0):
+        """kz_film_merge_rects: entries = [(tile, float32 array holding that tile's packed rect)], added to `film` in list order (row-major tile order = the
+        film every other path gives). The arrays may be views into different buffers: nothing is copied."""
+        n = len(entries)
+        arr = (abi.KzTile * n)(*[abi.KzTile(*t) for t, _ in entries])
+        ptrs = (abi.f32p * n)(*[C.cast(r.ctypes.data, abi.f32p) for _, r in entries])
+        b = self.border
+        for t, r in entries:
+            if r.dtype != np.float32 or r.size != (t[2] + 2 * b) * (t[3] + 2 * b) * 4 or not r.flags["C_CONTIGUOUS"]:
+                raise ValueError("merge_rects: the rect of tile %s must be %d contiguous float32" % (t, (t[2] + 2 * b) * (t[3] + 2 * b) * 4))
+        abi.check(self.lib, self.lib.kz_film_merge_rects(film.ctypes.data_as(abi.f32p), self.width, self.height, self.border, arr, ptrs, n, int(threads)))
         return film
 
     def empty_film(self):

@@ -4,7 +4,7 @@ tbb::parallel_for over 32x32 ImageBlocks (src/kazen/renderer.cpp:94-127), one le
 Every (pixel, sample) path is independent and samplers re-seed per (pixel, sample index)
 (sampler.cpp:43-46, 333-337), so a tile renders to the same values on any GPU. Each rank
 accumulates its tiles (with their filter aprons) into its own full-size film; the films are then
-summed - ImageBlock::put(ImageBlock&) (block.cpp:87-96) - in rank order. No data-path collective.
+summed - ImageBlock::put(ImageBlock&) (block.cpp:87-96) - in tile order. No data-path collective.
 """
 
 
@@ -65,17 +65,29 @@ def open_gather(rank, world):
     return token[0]
 
 
+def _rects_of(tiles, packed, border):
+    """[(tile, view of its packed rect)] for a rank's list."""
+    out, off = [], 0
+    for t in tiles:
+        n = (t[2] + 2 * border) * (t[3] + 2 * border) * 4
+        out.append((t, packed[off:off + n]))
+        off += n
+    return out
+
+
 def gather_tiles(scene, tiles, packed, rank, world, tile=None, session=None):
     """The host gather of a multi-process launch (one rank per GPU of ONE node), SURVEY 8e: every rank hands the PACKED film rects of the tiles IT
-    rendered (kz_film_download_tiles: each tile with its filter apron, 1.13 x the tile's texels) to rank 0, and rank 0 adds them into one film, rank
-    after rank, tiles in each rank's list order (kz_film_merge_tiles = ImageBlock::put(ImageBlock&), block.cpp:87-96, over row bands on host threads).
-    `tiles` is THIS rank's list - whatever dealt it (kz_deal_tiles, or the batches a KzTileDealer handed out): the list travels with the rects (one file
-    per rank in /dev/shm: the ranks share a host), nothing is recomputed on rank 0.
-    PIPELINED (round 5): a rank writes its file as soon as it has its rects and tells rank 0 with one point-to-point message; rank 0 merges its own rects,
-    then rank 1's as soon as that message is there, then rank 2's ... - while later ranks may still be rendering. There is no collective in front of the
-    merge (given a `session` from open_gather; without one the token broadcast is that collective), so the gather overlaps the tail of the render instead
-    of starting behind a barrier. The order of the additions is the rank order whatever the order of arrival (H10). Without /dev/shm the list and the rects
-    travel by gloo, point to point. No RCCL, no device collective; the volume is one film in all, however many ranks.
+    rendered (kz_film_download_tiles: each tile with its filter apron - what the tile's own pixels add, an ImageBlock of the tile - 1.13 x the tile's texels) to
+    rank 0, and rank 0 adds ALL rects into one film in ROW-MAJOR TILE ORDER (kz_film_merge_rects = ImageBlock::put(ImageBlock&), block.cpp:87-96, over row bands
+    on host threads). `tiles` is THIS rank's list - whatever dealt it (kz_deal_tiles, or the batches a KzTileDealer handed out): the list travels with the
+    rects (one file per rank in /dev/shm: the ranks share a host), nothing is recomputed on rank 0.
+    Round 6: the order of the additions is the TILE order whatever rank rendered a tile and whenever its file arrived - the merged film is, bit for bit, the
+    film ONE device resolves for the same frame (64-px tiles) and the film kz_render_multi returns, for any number of ranks, static or dynamic dealing (H10).
+    (Rounds 3-5 merged rank after rank as the files arrived - overlapping the tail of the render by a few milliseconds, at the price of a film whose last bits
+    depended on the dealing.) A rank writes its file as soon as it has its rects and tells rank 0 with one point-to-point message; rank 0 maps the files as the
+    messages arrive and merges once the last one is there. There is no collective in front of the merge (given a `session` from open_gather; without one the
+    token broadcast is that collective). Without /dev/shm the list and the rects travel by gloo, point to point. No RCCL, no device collective; the volume is
+    one film in all, however many ranks.
     A failure on ANY rank - a packed buffer of the wrong size, a file that cannot be written, the merge on rank 0 - is raised on EVERY rank: each rank sends
     exactly one status message and then waits for rank 0's verdict, rank 0 always receives world - 1 of them before it broadcasts it, nobody is left waiting.
     Returns the film on rank 0, None elsewhere. (`tile` is accepted for callers of the round-3 signature and ignored.)"""
@@ -85,8 +97,9 @@ def gather_tiles(scene, tiles, packed, rank, world, tile=None, session=None):
     import torch.distributed as dist
     tiles = [tuple(int(v) for v in t) for t in tiles]
     packed = np.ascontiguousarray(packed, np.float32)
+    order = lambda e: (e[0][1], e[0][0])
     if world == 1:
-        return scene.merge_tiles(scene.empty_film(), tiles, packed)
+        return scene.merge_rects(scene.empty_film(), sorted(_rects_of(tiles, packed, scene.border), key=order))
     token = session or open_gather(rank, world)
     path = lambda r: "/dev/shm/kz_gather_%s_%d.bin" % (token, r)
     SHM, GLOO, FAILED = 1, 2, -1
@@ -113,14 +126,9 @@ def gather_tiles(scene, tiles, packed, rank, world, tile=None, session=None):
         film = None
     else:
         film = None
-        try:
-            if err is None:
-                film = scene.empty_film()
-                if tiles:
-                    scene.merge_tiles(film, tiles, packed)
-        except Exception as e:                                 # noqa: BLE001
-            err = e
-        for r in range(1, world):                              # rank order = the order of the additions; a rank's message is there when its file is
+        entries = [] if err is not None else _rects_of(tiles, packed, scene.border)
+        keep = []                                              # the mapped files / received buffers stay alive until the merge is done
+        for r in range(1, world):                              # a rank's message is there when its file is
             head = torch.zeros(3, dtype=torch.int64)
             dist.recv(head, src=r)
             mode, n_tiles, n_floats = (int(v) for v in head)
@@ -137,10 +145,18 @@ def gather_tiles(scene, tiles, packed, rank, world, tile=None, session=None):
                 else:
                     raw = np.memmap(path(r), dtype=np.uint8, mode="r")      # (mapped, not copied)
                     tl, fl = np.frombuffer(raw, np.int32, 4 * n_tiles), np.frombuffer(raw, np.float32, n_floats, 16 * n_tiles)
-                if err is None:
-                    scene.merge_tiles(film, [tuple(int(v) for v in t) for t in tl.reshape(-1, 4)], fl)
+                    keep.append(raw)
+                keep.append(fl)
+                if scene.packed_floats([tuple(int(v) for v in t) for t in tl.reshape(-1, 4)]) != n_floats:
+                    raise ValueError("rank %d sent %d floats for its %d tiles" % (r, n_floats, n_tiles))
+                entries += _rects_of([tuple(int(v) for v in t) for t in tl.reshape(-1, 4)], fl, scene.border)
             except Exception as e:                             # noqa: BLE001
                 err = err or e
+        try:
+            if err is None:
+                film = scene.merge_rects(scene.empty_film(), sorted(entries, key=order))
+        except Exception as e:                                 # noqa: BLE001
+            err = e
         if err is not None:
             film = None
     done = torch.tensor([0 if (rank == 0 and err is not None) else 1], dtype=torch.int32)

@@ -1767,7 +1767,7 @@ int kzo_scene_create(const KzSceneDesc *d, int useBrute, void **out) { FtzScope 
 void kzo_scene_destroy(void *s) { delete (Scene *)s; }
 void kzo_set_brute(void *s, int brute) { ((Scene *)s)->useBrute = brute != 0; }
 void kzo_set_tie_mode(void *s, int mode) { ((Scene *)s)->tieMode = mode; }
-// the transcendental functions of kz_oracle_math.h on arrays (same numbering as kz_debug_math of the dev header)
+// the transcendental functions of kz_oracle_math.h on arrays (same numbering as kz_kat_math of the dev header)
 void kzo_math(int fn, uint32_t n, const float *x, const float *y, float *out) { FtzScope ftz_;
     for (uint32_t i = 0; i < n; ++i) {
         const float a = x[i], b = y ? y[i] : x[i];

@@ -33,3 +33,16 @@ def gpu_lib(kz):
     lib = kz.abi.load_library()
     assert lib.kz_device_count() >= 1, "no HIP device visible: -m gpu tests must run on the GPU box"
     return lib
+
+
+@pytest.fixture(scope="session")
+def dev_lib(kz, gpu_lib):
+    """The development variant of the library (-DKZ_EXPERIMENTS: same sources + the hooks that are process-global state - failure injection, growth delay,
+    trace, device aliasing - and the kernels of rejected experiments). A second copy of the library in this process: its replicas, pools and device state are its
+    own. The product library is asked to give its pooled path state back first (the two copies share one card)."""
+    if not os.path.exists(kz.abi.DEV_LIB_PATH):
+        pytest.fail("development variant not built: python -c 'import __graft_entry__ as g; g.build()'")
+    gpu_lib.kz_device_trim(0)
+    lib = kz.abi.load_dev_library()
+    assert lib.kz_build_flags() & 1 and lib.kz_device_count() >= 1
+    return lib

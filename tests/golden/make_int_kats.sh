@@ -5,13 +5,14 @@
 set -e
 cd "$(dirname "$0")/../../oracle"
 make ref
-./_ref/kat_ref > _ref/a.json
-./_ref/kat_ref_permute > _ref/b.json
-./_ref/kat_ref_fresnel > _ref/c.json
-./_ref/kat_ref_dpdf > _ref/d.json
+T=$(mktemp -d); trap 'rm -rf "$T"' EXIT
+./_ref/kat_ref > $T/a.json
+./_ref/kat_ref_permute > $T/b.json
+./_ref/kat_ref_fresnel > $T/c.json
+./_ref/kat_ref_dpdf > $T/d.json
 python3 -c "
 import json
-a = json.load(open('_ref/a.json')); a.update(json.load(open('_ref/b.json'))); a.update(json.load(open('_ref/c.json'))); a.update(json.load(open('_ref/d.json')))
+a = json.load(open('$T/a.json')); a.update(json.load(open('$T/b.json'))); a.update(json.load(open('$T/c.json'))); a.update(json.load(open('$T/d.json')))
 open('../tests/golden/int_kats.json', 'w').write(json.dumps(a, indent=None, separators=(',', ':')).replace('],[', '],\n[').replace('},{', '},\n{') + '\n')
 "
 echo "wrote tests/golden/int_kats.json"

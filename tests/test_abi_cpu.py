@@ -14,14 +14,24 @@ def test_library_exports_every_declared_symbol(kz):
     lib = kz.abi.load_library()
     decl = lambda name: set(re.findall(r"^(?:int|void|const char \*)\s*\*?(kz_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", name)).read(), re.M))
     product, dev = decl("kazen_mi355x.h"), decl("kazen_mi355x_dev.h")
-    # the product header is what a maintainer's adapter includes: at most twenty-one entry points (round 5: + kz_device_trim); everything else is the development surface
-    assert product == set(kz.abi.PRODUCT_EXPORTS) and len(product) <= 21, product ^ set(kz.abi.PRODUCT_EXPORTS)
+    # the product header is what a maintainer's adapter includes: at most twenty-two entry points (round 5: + kz_device_trim; round 6: + kz_film_merge_rects); everything else is the development surface
+    assert product == set(kz.abi.PRODUCT_EXPORTS) and len(product) <= 22, product ^ set(kz.abi.PRODUCT_EXPORTS)
     declared = product | dev
     assert not (product & dev)
-    assert declared == set(kz.abi.EXPORTS), declared ^ set(kz.abi.EXPORTS)
-    for sym in declared:
+    hooks = set(kz.abi.DEV_ONLY_EXPORTS)
+    assert declared == set(kz.abi.EXPORTS) | hooks, declared ^ (set(kz.abi.EXPORTS) | hooks)
+    for sym in declared - hooks:
         assert getattr(lib, sym) is not None
-    assert lib.kz_abi_version() == kz.abi.KZ_ABI_VERSION
+    assert lib.kz_abi_version() == kz.abi.KZ_ABI_VERSION == 6
+    # the hooks that are process-global state (failure injection, growth delay, trace, device aliasing) are NOT in the product library ...
+    import subprocess
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", kz.abi.LIB_PATH], text=True)
+    assert "kz_debug" not in exported
+    assert lib.kz_build_flags() == 0
+    # ... they live in the development variant, which exports everything the dev header declares
+    if os.path.exists(kz.abi.DEV_LIB_PATH):
+        dev_exported = set(re.findall(r" T (kz_[a-z0-9_]+)", subprocess.check_output(["nm", "-D", "--defined-only", kz.abi.DEV_LIB_PATH], text=True)))
+        assert declared <= dev_exported, declared - dev_exported
 
 
 def test_struct_sizes_match_the_header(kz, tmp_path):
@@ -29,7 +39,7 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
     import subprocess
     a = kz.abi
     names = ["KzBSDF", "KzImage", "KzTexture", "KzLight", "KzMesh", "KzFilter", "KzCamera", "KzSampler", "KzIntegrator", "KzBackground",
-             "KzSceneDesc", "KzTile", "KzTuning", "KzTileDealer", "KzRenderOpts", "KzPassInfo", "KzStats", "KzHit", "KzBvhInfo"]
+             "KzSceneDesc", "KzTile", "KzTuning", "KzTileDealer", "KzRenderOpts", "KzPassInfo", "KzStats", "KzHit", "KzBvhInfo", "KzPlanQuery", "KzPlanAnswer"]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "kazen_mi355x_dev.h"\nint main(void){' +
                    "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}\n")
@@ -39,6 +49,8 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
     for n in names:
         assert C.sizeof(getattr(a, n)) == int(sizes[n]), n
     assert C.sizeof(a.KzBSDF) == 128 and C.sizeof(a.KzTexture) == 64
+    # structures the library reads or writes THROUGH a caller's pointer carry no size field - their sizes are pinned to the ABI version (6)
+    assert C.sizeof(a.KzTileDealer) == 48 and C.sizeof(a.KzPassInfo) == 64 and C.sizeof(a.KzRenderOpts) == 144
 
 
 def test_render_opts_layout_v5(kz):
