@@ -170,8 +170,10 @@ def film_crc(rgbw_film, border, x0=928, y0=508, n=64):
 
 
 # film_crc of the parity render below (C4, sample indices [0, 64), crop 64 x 64 at (928, 508)) on ONE GPU: the value every N must reproduce.
-# (written by the first N = 1 run of round 6 on the GPU box: profiles/r06a_film/parity_crc.json; None = not pinned yet)
-PARITY_CRC_N1 = None
+# (measured at N = 1 on the GPU box in round 6, profiles/r06a_film/bench_n1.json; tests/test_gpu_multi.py::test_bench_parity_crc_is_independent_of_the_cut
+# reproduces it through 2, 4 and 8 aliased replicas and through two ranks)
+PARITY_CRC_N1 = "431bcc3e"
+PARITY_SPP_TABLE = 1024        # the parity render's sampler table: pmj02bn's permutations depend on the table length, so every N renders THIS scene
 
 
 def run_cold_jobs(tris):
@@ -369,13 +371,17 @@ def main():
     # every N - the scaling run carries its own parity check.
     parity = None
     if not args.strong:
-        scene.render(0, 64, tiles=render_tiles, accumulate=False, stream=stream, **kw)
+        # (weak scaling lengthens the sampler table from N = 4 on: those ranks build the 1024-entry scene for this render - outside every clock)
+        psc = scene if spp_table == PARITY_SPP_TABLE else kz.Scene(kz.scenes.random_triangles(args.tris, Wd, Hd, PARITY_SPP_TABLE, sampler="pmj02bn", seed=1), device=device_index)
+        psc.render(0, 64, tiles=render_tiles, accumulate=False, stream=stream, **kw)
         torch.cuda.synchronize()
-        pf = kz.shard.gather_tiles(scene, tiles, scene.film_tiles(tiles), rank, world) if world > 1 else scene.film()
+        pf = kz.shard.gather_tiles(psc, tiles, psc.film_tiles(tiles), rank, world) if world > 1 else psc.film()
+        if psc is not scene:
+            psc.close()
         if rank == 0:
-            parity = {"film_crc": film_crc(pf, scene.border), "film_crc_n1": PARITY_CRC_N1, "render": "C4 sample indices [0, 64) of every pixel, %d rank(s), 64 x 64 tiles; crc32 of the "
-                      "float32 film texels (rgb * w, w) of the 64 x 64 crop at (928, 508)" % world}
-            parity["equals_n1"] = None if PARITY_CRC_N1 is None else parity["film_crc"] == PARITY_CRC_N1
+            parity = {"film_crc": film_crc(pf, scene.border), "film_crc_n1": PARITY_CRC_N1, "render": "C4 (%d triangles, %d-entry pmj02bn table) sample indices [0, 64) of every pixel, %d rank(s), "
+                      "64 x 64 tiles; crc32 of the float32 film texels (rgb * w, w) of the 64 x 64 crop at (928, 508)" % (args.tris, PARITY_SPP_TABLE, world)}
+            parity["equals_n1"] = (parity["film_crc"] == PARITY_CRC_N1) if args.tris == NTRIS else None
             log("parity render: %s" % json.dumps(parity))
         scene.film_clear(stream)
 

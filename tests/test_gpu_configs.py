@@ -550,6 +550,8 @@ def test_a_pass_context_that_is_still_growing_renders_the_same_film(dev_lib, kz,
     want = ref.film()
     ref.close()
     assert gpu_lib.kz_device_trim(0) == 0                                    # the next scene starts from an empty context
+    from conftest import wait_for_wipe
+    wait_for_wipe(gpu_lib)                                                   # (... on memory the driver has finished wiping: what is under test is the delay hook's schedule)
     try:
         gpu_lib.kz_debug_grow_delay(15)
         sc = kz.Scene(desc, device=0, lib=dev_lib)

@@ -127,18 +127,20 @@ def test_injected_allocation_failure_inside_a_growing_context(dev_lib, kz):
     """kz_debug_fail_alloc used to be taken back from the arena when the call returned while the growth thread was still mapping - a failure
     injected beyond the first levels never fired. It stays armed on the arena now: the context stops growing where the failure hits, the call succeeds on what
     there is, and the note says why."""
+    from conftest import wait_for_wipe
     dev_lib.kz_device_trim(0)
+    wait_for_wipe(dev_lib)
     desc = kz.scenes.hero_scene(1280, 720, 256, detail=1.0)                # 236 M items: 28 levels of 2^23
     sc = kz.Scene(desc, device=0, lib=dev_lib)
     try:
         dev_lib.kz_debug_grow_delay(5)
-        dev_lib.kz_debug_fail_alloc(17 * 6 + 3)                           # (17 arrays per level: fails in the seventh level, long after the first pass has started)
+        dev_lib.kz_debug_fail_alloc(17 * 6 + 3)                           # (17 arrays per level, a handful of other allocations of the call first: fails in the sixth or seventh level, long after the first pass has started)
         sc.render()
         info, note = sc.last_pass_info(), sc.last_grow_note()
     finally:
         dev_lib.kz_debug_fail_alloc(0)
         dev_lib.kz_debug_grow_delay(0)
-    assert "kz_debug_fail_alloc" in note and info["contextItems"] == 6 << 23 and info["largestPassItems"] <= 6 << 23, (info, note)
+    assert "kz_debug_fail_alloc" in note and info["contextItems"] in (5 << 23, 6 << 23) and info["firstPassItems"] < info["largestPassItems"] <= info["contextItems"], (info, note)
     got = sc.film()
     sc.close()
     dev_lib.kz_device_trim(0)
