@@ -55,17 +55,17 @@ __global__ void kz_bsdf_kernel(KzDevTables T, uint32_t n, const int32_t *__restr
     its.p = mk(0.f); its.t = 0.f; its.uvx = uv ? uv[2 * i] : 0.f; its.uvy = uv ? uv[2 * i + 1] : 0.f;
     its.sh.s = mk(1.f, 0.f, 0.f); its.sh.t = mk(0.f, 1.f, 0.f); its.sh.n = mk(0.f, 0.f, 1.f); its.geoN = its.sh.n; its.dpdu = its.sh.s;
     its.mesh = 0; its.prim = 0; its.bu = its.bv = 0.f;
-    NMap nm; surfaceSetup<true>(T, its, m, nm);
+    NMap nm; surfaceSetup<KZ_X_ALL>(T, its, m, nm);
     const V3 a = mk(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), b = mk(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
-    V3 e = surfEval<true>(m, nm, its, a, b, acc[i]);
+    V3 e = surfEval<KZ_X_ALL>(m, nm, its, a, b, acc[i]);
     evalOut[3 * i] = e.x; evalOut[3 * i + 1] = e.y; evalOut[3 * i + 2] = e.z;
-    pdfOut[i] = surfPdf<true>(m, nm, its, a, b, acc[i], true);
+    pdfOut[i] = surfPdf<KZ_X_ALL>(m, nm, its, a, b, acc[i], true);
     V3 d; bool alive, discrete, solid; float etaScale, pdfS;
-    V3 w = surfSample<true>(m, nm, its, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive, discrete, etaScale, pdfS, solid);
+    V3 w = surfSample<KZ_X_ALL>(m, nm, its, a, acc[i], s3[3 * i], s3[3 * i + 1], s3[3 * i + 2], d, alive, discrete, etaScale, pdfS, solid);
     const bool zero = w.x == 0.f && w.y == 0.f && w.z == 0.f;
     float *o = sampleOut + 8 * i;
     o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = d.x; o[4] = d.y; o[5] = d.z; o[6] = alive ? 1.f : 0.f;
-    o[7] = (!alive || zero) ? 0.f : (pdfS >= 0.f ? pdfS : surfPdf<true>(m, nm, its, a, d, acc[i], solid));      // integrator.cpp:314
+    o[7] = (!alive || zero) ? 0.f : (pdfS >= 0.f ? pdfS : surfPdf<KZ_X_ALL>(m, nm, its, a, d, acc[i], solid));      // integrator.cpp:314
 }
 __global__ void kz_texture_kernel(KzDevTables T, uint32_t n, const int32_t *__restrict__ tex, const float *__restrict__ uv, float *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -768,8 +768,22 @@ __device__ __forceinline__ V3 fresnelCond(float c, V3 eta, V3 k) {              
     return (Rparl2 + Rperp2) / 2.0f;
 }
 __device__ __forceinline__ float signf1(float v) { return (v > 0.f) ? 1.f : -1.f; }
-// "ggx" (bsdf.cpp:629-689), "roughconductor" (:692-811), "roughplastic" (:814-943), "roughdielectric" (:947-1145)
-__device__ V3 roughEval(const KzBSDF &m, V3 wi, V3 wo) {
+// "ggx" (bsdf.cpp:629-689), "roughconductor" (:692-811), "roughplastic" (:814-943), "roughdielectric" (:947-1145).
+// These models are real CALLS (each is big, and inlined at every use they cost the extended kernels hundreds of spilled registers), so what they need of a BSDF
+// row travels BY VALUE, in registers (round 6): as `const KzBSDF &` the calls forced the caller's 128-byte copy of the row into scratch memory - for every hit of
+// an extended kernel, whatever its model - and every field was read back from there.
+struct RoughRow { int32_t type; float alpha, anisotropy, intIOR, extIOR; float albedo[3], condEta[3], condK[3]; };
+__device__ __forceinline__ RoughRow roughRowOf(const KzBSDF &b) {
+    RoughRow r;
+    r.type = b.type; r.alpha = b.alpha; r.anisotropy = b.anisotropy; r.intIOR = b.intIOR; r.extIOR = b.extIOR;
+    r.albedo[0] = b.albedo[0]; r.albedo[1] = b.albedo[1]; r.albedo[2] = b.albedo[2];
+    r.condEta[0] = b.condEta[0]; r.condEta[1] = b.condEta[1]; r.condEta[2] = b.condEta[2];
+    r.condK[0] = b.condK[0]; r.condK[1] = b.condK[1]; r.condK[2] = b.condK[2];
+    return r;
+}
+struct RoughEvalPdfOut { V3 f; float pdf; };
+struct RoughSampleOut { V3 w, wo; float etaScale, pdfOut; int32_t alive; };
+__device__ V3 roughEval(const RoughRow m, V3 wi, V3 wo) {
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {
         if (wi.z == 0) return mk(0.f);
         const float alpha = alphaOf(m.alpha), mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
@@ -801,7 +815,7 @@ __device__ V3 roughEval(const KzBSDF &m, V3 wi, V3 wo) {
     const float G = smithBeckmannG1(wo, wh, alpha) * smithBeckmannG1(wi, wh, alpha);
     return kd * KZ_INV_PI * wo.z + mk(ks * (D * F * G) / (4.f * wi.z));
 }
-__device__ float roughPdf(const KzBSDF &m, V3 wi, V3 wo) {
+__device__ float roughPdf(const RoughRow m, V3 wi, V3 wo) {
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {
         const float mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
         const bool refl = wi.z * wo.z > 0.f;
@@ -826,7 +840,7 @@ __device__ float roughPdf(const KzBSDF &m, V3 wi, V3 wo) {
 // roughEval and roughPdf of one direction pair in ONE evaluation: the two functions of the reference form the same half vector and the same Beckmann D(wh, alpha)
 // (bsdf.cpp:756-780, :870-905) - same arguments, same bits - so they are formed once here (D is an exp through kz_crmath.h: a call and ~40 double operations).
 // Returns exactly (roughEval(m, wi, wo), roughPdf(m, wi, wo)).
-__device__ void roughEvalPdf(const KzBSDF &m, V3 wi, V3 wo, V3 &f, float &pdf) {
+__device__ __forceinline__ void roughEvalPdfImpl(const RoughRow &m, V3 wi, V3 wo, V3 &f, float &pdf) {
     if (m.type == KZ_BSDF_GGX) { f = roughEval(m, wi, wo); pdf = roughPdf(m, wi, wo); return; }
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {                                     // (bsdf.cpp:985-1043: the same wm, Fresnel term and D in eval and pdf)
         const float alpha = alphaOf(m.alpha), mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
@@ -868,8 +882,9 @@ __device__ void roughEvalPdf(const KzBSDF &m, V3 wi, V3 wo, V3 &f, float &pdf) {
     f = kd * KZ_INV_PI * wo.z + mk(ks * (D * F * G) / (4.f * wi.z));
     pdf = ks * D * wh.z * (rcpExact(4.f * fabsf(dot(wh, wo)))) + (1 - ks) * wo.z * KZ_INV_PI;
 }
+__device__ RoughEvalPdfOut roughEvalPdf(const RoughRow m, V3 wi, V3 wo) { RoughEvalPdfOut o; roughEvalPdfImpl(m, wi, wo, o.f, o.pdf); return o; }
 // pdfOut: roughPdf(m, wi, wo) at the sampled direction where sample() forms it on the way (roughconductor, roughplastic), else -1
-__device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y, V3 &wo, bool &alive, float &etaScale, float &pdfOut) {
+__device__ __forceinline__ V3 roughSampleImpl(const RoughRow &m, V3 wi, float s1, float s2x, float s2y, V3 &wo, bool &alive, float &etaScale, float &pdfOut) {
     alive = true; pdfOut = -1.f;
     if (m.type == KZ_BSDF_ROUGHDIELECTRIC) {
         const float mEta = m.intIOR / m.extIOR, mInvEta = m.extIOR / m.intIOR;
@@ -911,22 +926,37 @@ __device__ V3 roughSample(const KzBSDF &m, V3 wi, float s1, float s2x, float s2y
         else wo = squareToCosineHemisphere(s2x, s2y);
     }
     if (wo.z <= 0) return mk(0.f);
-    V3 f; float pdf; roughEvalPdf(m, wi, wo, f, pdf);
+    V3 f; float pdf; roughEvalPdfImpl(m, wi, wo, f, pdf);
     pdfOut = pdf;
     return f / pdf;
+}
+__device__ RoughSampleOut roughSample(const RoughRow m, V3 wi, float s1, float s2x, float s2y, float etaScaleIn) {
+    RoughSampleOut o; bool alive;
+    o.wo = mk(0.f, 0.f, 1.f); o.etaScale = etaScaleIn;
+    o.w = roughSampleImpl(m, wi, s1, s2x, s2y, o.wo, alive, o.etaScale, o.pdfOut);
+    o.alive = alive ? 1 : 0;
+    return o;
 }
 
 // returns the sample weight; wo is the sampled direction; alive=false when the path contributes nothing further;
 // discrete = bRec.measure == EDiscrete; etaScale = bRec.eta
-// EXT = false compiles only diffuse + kazenstandard (the BASELINE configs): the scene-level switch keeps the shade kernel at
-// ~70 VGPRs instead of ~160 when no mirror / dielectric / ggx / rough* row is present.
-template <bool EXT>
+// EXT (KzParams::bsdfExt) says what the SCENE contains beyond constant diffuse / kazenstandard rows - a bit mask, so that a kernel is compiled for what a
+// scene needs and nothing else (round 6; it was one flag before):
+//   KZ_X_MODELS  rows of other models: mirror, dielectric, ggx, roughconductor, roughplastic, roughdielectric
+//   KZ_X_TEX     texture-backed parameters (texture programs: image / ramp / blend)
+//   KZ_X_NMAP    normalmap rows (a texture lookup + the perturbed frame; implies KZ_X_TEX)
+// EXT = 0 compiles only diffuse + kazenstandard (the BASELINE configs): the shade kernel stays at 123 VGPRs instead of ~168.
+#define KZ_X_MODELS 1
+#define KZ_X_TEX 2
+#define KZ_X_NMAP 4
+#define KZ_X_ALL 7
+template <int EXT>
 // pdfOut: BSDF::pdf at the sampled direction when the model computes it on the way (diffuse, kiss) — the integrator's own
 // pdf(bRec) call right after sample() (integrator.cpp:314) is the same function of the same arguments, so it is reused, not
 // recomputed; pdfOut < 0 means "not provided".
-__device__ V3 bsdfSample(const KzBSDF &m, const KissMat &km, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive, bool &discrete, float &etaScale, float &pdfOut) {
+__device__ __forceinline__ V3 bsdfSample(const KzBSDF &m, const KissMat &km, V3 wi, float accRough, float s1, float s2x, float s2y, V3 &wo, bool &alive, bool &discrete, float &etaScale, float &pdfOut) {
     wo = mk(0.f, 0.f, 1.f); discrete = false; etaScale = 1.0f; pdfOut = -1.f;
-    if (EXT && m.type == KZ_BSDF_DIELECTRIC) {                                            // bsdf.cpp:119-143 (no back-side test)
+    if ((EXT & KZ_X_MODELS) && m.type == KZ_BSDF_DIELECTRIC) {                                            // bsdf.cpp:119-143 (no back-side test)
         alive = true; discrete = true;
         if (s1 < fresnelIOR(wi.z, m.extIOR, m.intIOR)) { wo = mk(-wi.x, -wi.y, wi.z); return mk(1.0f); }
         V3 n = mk(0.0f, 0.0f, 1.0f);
@@ -936,10 +966,14 @@ __device__ V3 bsdfSample(const KzBSDF &m, const KissMat &km, V3 wi, float accRou
         etaScale = m.intIOR / m.extIOR;
         return mk(1.0f);
     }
-    if (EXT && m.type >= KZ_BSDF_GGX) return roughSample(m, wi, s1, s2x, s2y, wo, alive, etaScale, pdfOut);   // (pdfOut -1 for ggx / roughdielectric: the caller evaluates pdf())
+    if ((EXT & KZ_X_MODELS) && m.type >= KZ_BSDF_GGX) {                                   // (pdfOut -1 for ggx / roughdielectric: the caller evaluates pdf())
+        const RoughSampleOut o = roughSample(roughRowOf(m), wi, s1, s2x, s2y, etaScale);
+        wo = o.wo; alive = o.alive != 0; etaScale = o.etaScale; pdfOut = o.pdfOut;
+        return o.w;
+    }
     if (wi.z <= 0) { alive = false; return mk(0.f); }                              // bsdf.cpp:60-61, :176-177, :1302-1303
     alive = true;
-    if (EXT && m.type == KZ_BSDF_MIRROR) { wo = mk(-wi.x, -wi.y, wi.z); discrete = true; return mk(1.0f); }   // bsdf.cpp:175-191
+    if ((EXT & KZ_X_MODELS) && m.type == KZ_BSDF_MIRROR) { wo = mk(-wi.x, -wi.y, wi.z); discrete = true; return mk(1.0f); }   // bsdf.cpp:175-191
     if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:59-75
         wo = squareToCosineHemisphere(s2x, s2y);
         pdfOut = wo.z <= 0 ? 0.f : KZ_INV_PI * wo.z;                              // Diffuse::pdf (bsdf.cpp:40-56), wi.z > 0 here
@@ -962,32 +996,32 @@ __device__ V3 bsdfSample(const KzBSDF &m, const KissMat &km, V3 wi, float accRou
     pdfOut = pdf;
     return f / pdf;
 }
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ V3 bsdfEval(const KzBSDF &m, const KissMat &km, V3 wi, V3 wo, float accRough) {
     if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:27-37 (measure is ESolidAngle at every call site)
         if (wi.z <= 0 || wo.z <= 0) return mk(0.f);
         return mk(m.albedo[0], m.albedo[1], m.albedo[2]) * KZ_INV_PI * wo.z;
     }
-    if (EXT && m.type >= KZ_BSDF_GGX) return roughEval(m, wi, wo);
-    if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) return mk(0.f);                           // discrete BRDFs evaluate to zero
+    if ((EXT & KZ_X_MODELS) && m.type >= KZ_BSDF_GGX) return roughEval(roughRowOf(m), wi, wo);
+    if ((EXT & KZ_X_MODELS) && m.type != KZ_BSDF_KAZENSTANDARD) return mk(0.f);                           // discrete BRDFs evaluate to zero
     return kissEval(m, km, wi, wo, accRough);
 }
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ float bsdfPdf(const KzBSDF &m, const KissMat &km, V3 wi, V3 wo, float accRough) {
     if (m.type == KZ_BSDF_DIFFUSE) { if (wi.z <= 0 || wo.z <= 0) return 0.f; return KZ_INV_PI * wo.z; }   // bsdf.cpp:40-56
-    if (EXT && m.type >= KZ_BSDF_GGX) return roughPdf(m, wi, wo);
-    if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) return 0.f;
+    if ((EXT & KZ_X_MODELS) && m.type >= KZ_BSDF_GGX) return roughPdf(roughRowOf(m), wi, wo);
+    if ((EXT & KZ_X_MODELS) && m.type != KZ_BSDF_KAZENSTANDARD) return 0.f;
     return kissPdf(m, km, wi, wo, accRough);
 }
 // eval and pdf of one direction pair (the light sample of a bounce asks for both): the kiss row shares its half-vector terms between the two
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ void bsdfEvalPdf(const KzBSDF &m, const KissMat &km, V3 wi, V3 wo, float accRough, V3 &f, float &pdf) {
     if (m.type == KZ_BSDF_DIFFUSE) {                                               // bsdf.cpp:27-37, 40-56
         const bool up = wi.z > 0 && wo.z > 0;
         f = up ? mk(m.albedo[0], m.albedo[1], m.albedo[2]) * KZ_INV_PI * wo.z : mk(0.f);
         pdf = up ? KZ_INV_PI * wo.z : 0.f;
-    } else if (EXT && m.type >= KZ_BSDF_GGX) roughEvalPdf(m, wi, wo, f, pdf);
-    else if (EXT && m.type != KZ_BSDF_KAZENSTANDARD) { f = mk(0.f); pdf = 0.f; }       // discrete BRDFs evaluate to zero
+    } else if ((EXT & KZ_X_MODELS) && m.type >= KZ_BSDF_GGX) { const RoughEvalPdfOut o = roughEvalPdf(roughRowOf(m), wi, wo); f = o.f; pdf = o.pdf; }
+    else if ((EXT & KZ_X_MODELS) && m.type != KZ_BSDF_KAZENSTANDARD) { f = mk(0.f); pdf = 0.f; }       // discrete BRDFs evaluate to zero
     else kissEvalPdf<true, true>(m, km, wi, wo, accRough, f, pdf);
 }
 
@@ -996,11 +1030,6 @@ __device__ __forceinline__ void bsdfEvalPdf(const KzBSDF &m, const KissMat &km, 
 // Texture<Color3f> trees (texture.cpp:10-270) and the NormalMap wrapper (bsdf.cpp:281-417).
 // Only reachable from the EXT kernel variants (KzParams::bsdfExt).
 // ============================================================================================
-__device__ __forceinline__ float texelAt(const KzImageRow &im, const uint8_t *base, int x, int y, int c) {
-    if (c >= im.channels) return 0.0f;                                             // missing channels: TextureOpt::fill = 0
-    const size_t i = ((size_t)y * (size_t)im.width + (size_t)x) * (size_t)im.channels + (size_t)c;
-    return im.format == KZ_PIXEL_F32 ? reinterpret_cast<const float *>(base)[i] : (float)base[i] * (1.0f / 255.0f);
-}
 __device__ __forceinline__ int wrapPeriodic(int i, int n) {
     // a power-of-two size: the mask is the same residue, for negative i too. The runtime modulo is ~24 instructions, six of them per bilinear lookup; the empty asm keeps it
     // behind a real branch (left alone the compiler evaluates both forms and selects: no gain) that waves whose lanes all look up power-of-two images skip.
@@ -1028,39 +1057,67 @@ template <int N> __device__ __forceinline__ KzTaps<N> filterTaps(float x) {
     } else { t.first = (int)x0; t.w[0] = 1.0f - f; t.w[1] = f; }
     return t;
 }
-// the filtered texel of channel c: rows left to right, then the rows top to bottom (the oracle adds in the same order)
-template <int N, bool CLAMP_Y>
-__device__ __forceinline__ float filteredTexel(const KzImageRow &im, const uint8_t *base, const KzTaps<N> &tx, const KzTaps<N> &ty, int c) {
-    float r = 0.0f;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const int y = CLAMP_Y ? min(max(ty.first + j, 0), im.height - 1) : wrapPeriodic(ty.first + j, im.height);
-        float row = tx.w[0] * texelAt(im, base, wrapPeriodic(tx.first, im.width), y, c);
-#pragma unroll
-        for (int i = 1; i < N; ++i) row = row + tx.w[i] * texelAt(im, base, wrapPeriodic(tx.first + i, im.width), y, c);
-        r = j == 0 ? ty.w[0] * row : r + ty.w[j] * row;
+// The three colour channels of texel (x, y): one address for the texel, the channels behind it (a missing channel reads 0: TextureOpt::fill)
+__device__ __forceinline__ void texel3(const KzImageRow &im, const uint8_t *base, int x, int y, float &t0, float &t1, float &t2) {
+    const size_t i = ((size_t)y * (size_t)im.width + (size_t)x) * (size_t)im.channels;
+    if (im.format == KZ_PIXEL_F32) {
+        const float *p = reinterpret_cast<const float *>(base) + i;
+        t0 = p[0]; t1 = im.channels > 1 ? p[1] : 0.0f; t2 = im.channels > 2 ? p[2] : 0.0f;
+    } else {
+        const uint8_t *p = base + i;
+        t0 = (float)p[0] * (1.0f / 255.0f); t1 = im.channels > 1 ? (float)p[1] * (1.0f / 255.0f) : 0.0f; t2 = im.channels > 2 ? (float)p[2] * (1.0f / 255.0f) : 0.0f;
     }
-    return r;
 }
-template <int N, bool CLAMP_Y>
+// The filtered rgb of an image at continuous texel coordinates (x, y): per channel, the taps of a row left to right, then the rows top to bottom (the oracle adds in
+// the same order). Round 6: the N x N taps are addressed ONCE for the three channels (it was once per channel: three times the wraps and the address arithmetic), and
+// POW2 - every image of the scene has power-of-two sides, known at kz_scene_create - wraps with a mask, no modulo in the code at all (profiles/r04i_ext: the run-time
+// modulo was ~24 instructions, six per bilinear lookup).
+template <int N, bool CLAMP_Y, bool POW2>
 __device__ __forceinline__ V3 filteredRgb(const KzImageRow &im, const uint8_t *base, float x, float y) {
     const KzTaps<N> tx = filterTaps<N>(x), ty = filterTaps<N>(y);
-    return mk(filteredTexel<N, CLAMP_Y>(im, base, tx, ty, 0), filteredTexel<N, CLAMP_Y>(im, base, tx, ty, 1), filteredTexel<N, CLAMP_Y>(im, base, tx, ty, 2));
+    int xs[N], ys[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) xs[i] = POW2 ? ((tx.first + i) & (im.width - 1)) : wrapPeriodic(tx.first + i, im.width);
+#pragma unroll
+    for (int j = 0; j < N; ++j) ys[j] = CLAMP_Y ? min(max(ty.first + j, 0), im.height - 1) : (POW2 ? ((ty.first + j) & (im.height - 1)) : wrapPeriodic(ty.first + j, im.height));
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float row0 = 0.0f, row1 = 0.0f, row2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float t0, t1, t2;
+            texel3(im, base, xs[i], ys[j], t0, t1, t2);
+            if (i == 0) { row0 = tx.w[0] * t0; row1 = tx.w[0] * t1; row2 = tx.w[0] * t2; }
+            else { row0 = row0 + tx.w[i] * t0; row1 = row1 + tx.w[i] * t1; row2 = row2 + tx.w[i] * t2; }
+        }
+        if (j == 0) { r0 = ty.w[0] * row0; r1 = ty.w[0] * row1; r2 = ty.w[0] * row2; }
+        else { r0 = r0 + ty.w[j] * row0; r1 = r1 + ty.w[j] * row1; r2 = r2 + ty.w[j] * row2; }
+    }
+    return mk(r0, r1, r2);
 }
 // the 4 x 4 lookup is a CALL: inlined next to the 2 x 2 one it cost the path kernels registers (the lean megakernel went from 139 to 248 VGPRs) for a
 // filter that is off by default
 template <bool CLAMP_Y>
-__device__ __attribute__((noinline)) V3 filteredRgbCubic(KzImageRow im, const uint8_t *base, float x, float y) { return filteredRgb<4, CLAMP_Y>(im, base, x, y); }
-// ImageTexture::eval (texture.cpp:46-64): s = u*scale, t = (1-v)*scale, periodic wrap; the filter is KzTexture.filter (kazen_mi355x.h)
-template <class Tables>
-__device__ V3 imageLookup(const Tables &T, uint32_t image, float scale, uint32_t flags, float u, float v) {
-    const KzImageRow im = T.images[image];
-    const uint8_t *base = T.texels + im.offset;
-    const uint32_t srgb = flags & 1u; const int filter = (int)(flags >> 1);
+__device__ __attribute__((noinline)) V3 filteredRgbCubic(KzImageRow im, const uint8_t *base, float x, float y) { return filteredRgb<4, CLAMP_Y, false>(im, base, x, y); }
+// ImageTexture::eval (texture.cpp:46-64): s = u*scale, t = (1-v)*scale, periodic wrap; the filter is KzTexture.filter (kazen_mi355x.h).
+// The IMAGE op of a texture program carries its image row (kz_scene_create packs it: f1 = texel offset / 16, f2 = (width - 1) | (height - 1) << 16,
+// b = srgb | filter << 1 | channels << 8 | format << 16): one load fewer on the dependent chain program -> op -> image row -> texels.
+__device__ __forceinline__ V3 imageLookupOp(const uint8_t *texels, const KzTexOp &op, uint32_t pow2, float u, float v) {
+    KzImageRow im;
+    const uint32_t wh = __float_as_uint(op.f2);
+    im.offset = (uint64_t)__float_as_uint(op.f1) << 4; im.width = (int32_t)(wh & 0xffffu) + 1; im.height = (int32_t)(wh >> 16) + 1;
+    im.channels = (int32_t)((op.b >> 8) & 0xffu); im.format = (int32_t)((op.b >> 16) & 0xffu);
+    const uint8_t *base = texels + im.offset;
+    const uint32_t srgb = op.b & 1u; const int filter = (int)((op.b >> 1) & 0x7fu);
+    const float scale = op.f0;
     const float s = u * scale, t = (1.0f - v) * scale;
     const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
     if (!(fabsf(x) < 1.0e9f) || !(fabsf(y) < 1.0e9f)) return mk(0.f);             // non-finite uv: defined as black
-    V3 r = filter == KZ_TEXFILTER_BICUBIC ? filteredRgbCubic<false>(im, base, x, y) : filteredRgb<2, false>(im, base, x, y);
+    V3 r;
+    if (filter == KZ_TEXFILTER_BICUBIC) r = filteredRgbCubic<false>(im, base, x, y);
+    else if (pow2) r = filteredRgb<2, false, true>(im, base, x, y);               // (uniform over the launch: a scalar branch)
+    else r = filteredRgb<2, false, false>(im, base, x, y);
     if (srgb) r = mk(srgbToLinear(r.x), srgbToLinear(r.y), srgbToLinear(r.z));
     return r;
 }
@@ -1074,7 +1131,7 @@ __device__ V3 envLookup(const KzDevTables &T, uint32_t image, int filter, V3 d) 
     if (isnan(s)) s = 0.0f;
     if (isnan(t)) t = 0.0f;
     const float x = s * (float)im.width - 0.5f, y = t * (float)im.height - 0.5f;
-    return filter == KZ_TEXFILTER_BICUBIC ? filteredRgbCubic<true>(im, base, x, y) : filteredRgb<2, true>(im, base, x, y);
+    return filter == KZ_TEXFILTER_BICUBIC ? filteredRgbCubic<true>(im, base, x, y) : filteredRgb<2, true, false>(im, base, x, y);
 }
 // Scene::getBackgroundColor (scene.cpp:54-79) -> BackgroundTexture::eval(Vector3f) (texture.cpp:121-126); the caller has checked bgPresent
 __device__ __forceinline__ V3 backgroundRadiance(const KzParams &P, const KzDevTables &T, V3 d) {
@@ -1085,32 +1142,45 @@ __device__ __forceinline__ V3 backgroundRadiance(const KzParams &P, const KzDevT
 __device__ __forceinline__ float clampRef(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   // common.h:237-243
 // texId is 1-based (KzBSDF::*Tex); the postfix program was flattened by kz_scene_create
 // (a real call - the tree walk is big - so it takes the four tables it reads BY VALUE: a `const KzDevTables &` would force the caller's copy into scratch)
-struct KzTexTables { const KzTexProg *texProgs; const KzTexOp *texOps; const KzImageRow *images; const uint8_t *texels; };
+struct KzTexTables { const KzTexProg *texProgs; const KzTexOp *texOps; const uint8_t *texels; uint32_t pow2; };
 __device__ V3 texEvalT(const KzTexTables T, int32_t texId, float u, float v);
 __device__ __forceinline__ V3 texEval(const KzDevTables &T, int32_t texId, float u, float v) {
-    const KzTexTables tt = {T.texProgs, T.texOps, T.images, T.texels};
+    const KzTexTables tt = {T.texProgs, T.texOps, T.texels, T.texPow2};
     return texEvalT(tt, texId, u, v);
 }
+__device__ __forceinline__ V3 texRamp(const KzTexOp &op, V3 c) {                 // texture.cpp:162-172
+    return mk(op.f0 + (op.f1 - op.f0) * clampRef(c.x, 0.0f, 1.0f), op.f0 + (op.f1 - op.f0) * clampRef(c.y, 0.0f, 1.0f), op.f0 + (op.f1 - op.f0) * clampRef(c.z, 0.0f, 1.0f));
+}
+__device__ __forceinline__ V3 texBlend(const KzTexOp &op, V3 mask, V3 in1, V3 in2) {   // texture.cpp:211-237
+    if (op.a == KZ_BLEND_MIX) return mk(lerpf(mask.x, in1.x, in2.x), lerpf(mask.x, in1.y, in2.y), lerpf(mask.x, in1.z, in2.z));
+    if (op.a == KZ_BLEND_MULTIPLY) return in1 * in2;
+    return mk(0.f);
+}
+// The operand stack of a program lives in REGISTERS when the program needs at most four entries (kz_scene_create records the depth in the high half of
+// KzTexProg::count; every tree of the reference's scenes and of the test scenes does): a stack that shifts - the top is always s0 - so that every access is to a
+// named register. A dynamically indexed array (the deeper programs: up to KZ_TEX_MAX_DEPTH) lives in scratch memory, a store and a dependent load per operand.
 __device__ V3 texEvalT(const KzTexTables T, int32_t texId, float u, float v) {
     const KzTexProg pr = T.texProgs[texId - 1];
+    const uint32_t count = pr.count & 0xffffu, depth = pr.count >> 16;
+    if (depth <= 4u) {
+        V3 s0 = mk(0.f), s1 = mk(0.f), s2 = mk(0.f), s3 = mk(0.f);
+        for (uint32_t i = 0; i < count; ++i) {
+            const KzTexOp op = T.texOps[pr.start + i];
+            if (op.op == KZ_TOP_CONST) { s3 = s2; s2 = s1; s1 = s0; s0 = mk(op.f0, op.f1, op.f2); }
+            else if (op.op == KZ_TOP_IMAGE) { const V3 c = imageLookupOp(T.texels, op, T.pow2, u, v); s3 = s2; s2 = s1; s1 = s0; s0 = c; }
+            else if (op.op == KZ_TOP_RAMP) s0 = texRamp(op, s0);
+            else { s0 = texBlend(op, s2, s1, s0); s1 = s3; s2 = mk(0.f); s3 = mk(0.f); }      // mask, input1, input2 = the three top entries
+        }
+        return s0;
+    }
     V3 st[KZ_TEX_MAX_DEPTH];
     int sp = 0;
-    for (uint32_t i = 0; i < pr.count; ++i) {
+    for (uint32_t i = 0; i < count; ++i) {
         const KzTexOp op = T.texOps[pr.start + i];
         if (op.op == KZ_TOP_CONST) st[sp++] = mk(op.f0, op.f1, op.f2);
-        else if (op.op == KZ_TOP_IMAGE) st[sp++] = imageLookup(T, op.a, op.f0, op.b, u, v);
-        else if (op.op == KZ_TOP_RAMP) {                                           // texture.cpp:162-172
-            const V3 c = st[sp - 1];
-            st[sp - 1] = mk(op.f0 + (op.f1 - op.f0) * clampRef(c.x, 0.0f, 1.0f), op.f0 + (op.f1 - op.f0) * clampRef(c.y, 0.0f, 1.0f),
-                            op.f0 + (op.f1 - op.f0) * clampRef(c.z, 0.0f, 1.0f));
-        } else {                                                                   // texture.cpp:211-237
-            const V3 in2 = st[sp - 1], in1 = st[sp - 2], mask = st[sp - 3];
-            sp -= 3;
-            V3 r = mk(0.f);
-            if (op.a == KZ_BLEND_MIX) r = mk(lerpf(mask.x, in1.x, in2.x), lerpf(mask.x, in1.y, in2.y), lerpf(mask.x, in1.z, in2.z));
-            else if (op.a == KZ_BLEND_MULTIPLY) r = in1 * in2;
-            st[sp++] = r;
-        }
+        else if (op.op == KZ_TOP_IMAGE) st[sp++] = imageLookupOp(T.texels, op, T.pow2, u, v);
+        else if (op.op == KZ_TOP_RAMP) st[sp - 1] = texRamp(op, st[sp - 1]);
+        else { const V3 r = texBlend(op, st[sp - 3], st[sp - 2], st[sp - 1]); sp -= 3; st[sp++] = r; }
     }
     return st[0];
 }
@@ -1138,54 +1208,56 @@ __device__ __forceinline__ void nmapSetup(const KzDevTables &T, const KzBSDF &ou
     nm.pf.t = normalized(cross(nm.pf.n, nm.pf.s));
 }
 // One hit's BSDF: the row (normalmap unwrapped to its nested row, textures folded) + the perturbed frame
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ void surfaceSetup(const KzDevTables &T, const Its &its, KzBSDF &b, NMap &nm) {
     nm.on = false;
-    if (EXT) {
-        if (b.type == KZ_BSDF_NORMALMAP) { nmapSetup(T, b, its, nm); b = T.bsdfs[b.nested]; }
-        resolveTextures(T, b, its.uvx, its.uvy);
-    }
+    if (EXT & KZ_X_NMAP) { if (b.type == KZ_BSDF_NORMALMAP) { nmapSetup(T, b, its, nm); b = T.bsdfs[b.nested]; } }
+    if (EXT & KZ_X_TEX) resolveTextures(T, b, its.uvx, its.uvy);
     if (b.type == KZ_BSDF_KAZENSTANDARD) nm.km = kissMat(b);
     else { nm.km.Cdlin = mk(0.f); nm.km.Cspec0 = mk(0.f); nm.km.Csheen = mk(0.f); }
 }
 // solid: bRec.measure == ESolidAngle. Only Diffuse checks it (bsdf.cpp:30,43,213,225); it is lost when NormalMap::sample goes
 // through the perturbed record, whose measure is never copied back (bsdf.cpp:348-362).
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ V3 surfEval(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, V3 wo, float accRough) {
-    if (!EXT || !nm.on) return bsdfEval<EXT>(b, nm.km, wi, wo, accRough);
-    if (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0) return bsdfEval<EXT>(b, nm.km, wi, wo, accRough);          // bsdf.cpp:295-296
-    const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi)), woP = toLocal(nm.pf, toWorld(its.sh, wo));
-    if (wo.z * woP.z <= 0) return mk(0.f);
-    return bsdfEval<EXT>(b, nm.km, wiP, woP, 0.0f);            // the perturbed record carries a fresh Intersection: accumulatedRoughness 0
+    if (!(EXT & KZ_X_NMAP)) return bsdfEval<EXT>(b, nm.km, wi, wo, accRough);
+    // (ONE call site of the model code for the three cases - no normal map | the map's fall-back to the unperturbed record, bsdf.cpp:295-296 | the perturbed record,
+    //  which carries a fresh Intersection: accumulatedRoughness 0 -: the inputs are selected, the code is not duplicated)
+    const bool plain = !nm.on || (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0);
+    V3 wiP = wi, woP = wo;
+    if (!plain) { wiP = toLocal(nm.pf, toWorld(its.sh, wi)); woP = toLocal(nm.pf, toWorld(its.sh, wo)); if (wo.z * woP.z <= 0) return mk(0.f); }
+    return bsdfEval<EXT>(b, nm.km, wiP, woP, plain ? accRough : 0.0f);
 }
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ float surfPdf(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, V3 wo, float accRough, bool solid) {
-    if (!EXT || !nm.on) return bsdfPdf<EXT>(b, nm.km, wi, wo, accRough);
-    if (!solid && b.type == KZ_BSDF_DIFFUSE) return 0.0f;
-    if (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0) return bsdfPdf<EXT>(b, nm.km, wi, wo, accRough);
-    const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi)), woP = toLocal(nm.pf, toWorld(its.sh, wo));
-    if (wo.z * woP.z <= 0) return 0.0f;
-    return bsdfPdf<EXT>(b, nm.km, wiP, woP, 0.0f);
+    if (!(EXT & KZ_X_NMAP)) return bsdfPdf<EXT>(b, nm.km, wi, wo, accRough);
+    if (nm.on && !solid && b.type == KZ_BSDF_DIFFUSE) return 0.0f;
+    const bool plain = !nm.on || (wi.z > 0 && wo.z > 0 && dot(nm.n, wi) <= 0);
+    V3 wiP = wi, woP = wo;
+    if (!plain) { wiP = toLocal(nm.pf, toWorld(its.sh, wi)); woP = toLocal(nm.pf, toWorld(its.sh, wo)); if (wo.z * woP.z <= 0) return 0.0f; }
+    return bsdfPdf<EXT>(b, nm.km, wiP, woP, plain ? accRough : 0.0f);
 }
 // surfEval and surfPdf (solid angle measure) of one direction pair
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ void surfEvalPdf(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, V3 wo, float accRough, V3 &f, float &pdf) {
-    if (!EXT || !nm.on) { bsdfEvalPdf<EXT>(b, nm.km, wi, wo, accRough, f, pdf); return; }
+    if (!(EXT & KZ_X_NMAP) || !nm.on) { bsdfEvalPdf<EXT>(b, nm.km, wi, wo, accRough, f, pdf); return; }
     f = surfEval<EXT>(b, nm, its, wi, wo, accRough); pdf = surfPdf<EXT>(b, nm, its, wi, wo, accRough, true);
 }
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ V3 surfSample(const KzBSDF &b, const NMap &nm, const Its &its, V3 wi, float accRough, float s1, float s2x, float s2y,
                                          V3 &wo, bool &alive, bool &discrete, float &etaScale, float &pdfOut, bool &solid) {
     solid = true;
-    if (!EXT || !nm.on) return bsdfSample<EXT>(b, nm.km, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
-    if (wi.z > 0 && dot(nm.n, wi) <= 0) {                                                                // bsdf.cpp:342-345
-        const V3 w = bsdfSample<EXT>(b, nm.km, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
-        pdfOut = -1.f;                                   // NormalMap::pdf may take the other branch: let the caller evaluate it
+    if (!(EXT & KZ_X_NMAP)) return bsdfSample<EXT>(b, nm.km, wi, accRough, s1, s2x, s2y, wo, alive, discrete, etaScale, pdfOut);
+    // one call site of the model code (see surfEval): no map | the map's fall-back (bsdf.cpp:342-345) | the perturbed record
+    const bool fallBack = nm.on && wi.z > 0 && dot(nm.n, wi) <= 0, plain = !nm.on || fallBack;
+    const V3 wiP = plain ? wi : toLocal(nm.pf, toWorld(its.sh, wi));
+    V3 woP; bool discN; float pdfN;
+    const V3 w = bsdfSample<EXT>(b, nm.km, wiP, plain ? accRough : 0.0f, s1, s2x, s2y, woP, alive, discN, etaScale, pdfN);
+    if (plain) {
+        wo = woP; discrete = discN;
+        pdfOut = fallBack ? -1.f : pdfN;                 // (fall-back: NormalMap::pdf may take the other branch - the caller evaluates it)
         return w;
     }
-    const V3 wiP = toLocal(nm.pf, toWorld(its.sh, wi));
-    V3 woP; bool discN; float pdfN;
-    const V3 w = bsdfSample<EXT>(b, nm.km, wiP, 0.0f, s1, s2x, s2y, woP, alive, discN, etaScale, pdfN);
     discrete = false; solid = false; pdfOut = -1.f;      // measure stays EUnknownMeasure in the caller's record
     if (!alive || (w.x == 0.f && w.y == 0.f && w.z == 0.f)) { wo = mk(0.f, 0.f, 1.f); return mk(0.f); }
     wo = toLocal(its.sh, toWorld(nm.pf, woP));
@@ -1297,7 +1369,7 @@ __device__ __forceinline__ void cameraRay(const KzParams &P, float sx, float sy,
 // ============================================================================================
 // a10 PathMisIntegrator::Li (integrator.cpp:195-338) — megakernel form, one lane per path
 // ============================================================================================
-template <bool STATS, bool EXT>
+template <bool STATS, int EXT>
 __device__ V3 pathLi(const KzParams &P, const KzDevTables &T, Sampler &smp, V3 ro, V3 rd, float rmint, float rmaxt,
                      uint32_t *stk, Counters &cn) {
     const float eps = P.traceBias;

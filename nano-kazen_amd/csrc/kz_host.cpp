@@ -113,6 +113,13 @@ static int emitTexture(const KzSceneDesc *d, KzScene *sc, int32_t t, int depthBu
         if (k.image < 0 || k.image >= (int32_t)d->nImages) return kz_fail(KZ_ERR_INVALID_ARG, "texture %d: image index %d out of range", t, k.image);
         if (k.filter != KZ_TEXFILTER_BILINEAR && k.filter != KZ_TEXFILTER_BICUBIC) return kz_fail(KZ_ERR_INVALID_ARG, "texture %d: filter %d (KZ_TEXFILTER_BILINEAR or KZ_TEXFILTER_BICUBIC)", t, k.filter);
         op.op = KZ_TOP_IMAGE; op.a = (uint32_t)k.image; op.f0 = k.scale; op.b = (k.srgb ? 1u : 0u) | ((uint32_t)k.filter << 1);
+        {   // the image row rides in the op (kz_internal.h KzTexOp): offset / 16, (width - 1) | (height - 1) << 16, channels, format
+            const KzImageRow &row = sc->images[(size_t)k.image];
+            const uint32_t off16 = (uint32_t)(row.offset >> 4), wh = (uint32_t)(row.width - 1) | ((uint32_t)(row.height - 1) << 16);
+            if ((row.offset >> 4) >> 32) return kz_fail(KZ_ERR_UNSUPPORTED, "more than 64 GB of texels");
+            std::memcpy(&op.f1, &off16, 4); std::memcpy(&op.f2, &wh, 4);
+            op.b |= ((uint32_t)row.channels << 8) | ((uint32_t)row.format << 16);
+        }
         sc->texOps.push_back(op); stackNow++; stackMax = std::max(stackMax, stackNow);
         return KZ_OK;
     case KZ_TEX_COLORRAMP: {
@@ -144,6 +151,7 @@ static int flattenTextures(const KzSceneDesc *d, KzScene *sc) {
         sc->texels.resize(row.offset + bytes);
         std::memcpy(sc->texels.data() + row.offset, im.pixels, bytes);
         sc->images.push_back(row);
+        if ((im.width & (im.width - 1)) || (im.height & (im.height - 1))) sc->texPow2 = 0;
     }
     for (uint32_t t = 0; t < d->nTextures; ++t) {
         KzTexProg pr; pr.start = (uint32_t)sc->texOps.size();
@@ -151,7 +159,7 @@ static int flattenTextures(const KzSceneDesc *d, KzScene *sc) {
         int rc = emitTexture(d, sc, (int32_t)t, 32, now, mx);
         if (rc != KZ_OK) return rc;
         if (mx > KZ_TEX_MAX_DEPTH) return kz_fail(KZ_ERR_UNSUPPORTED, "texture %u needs an operand stack of %d (limit %d)", t, mx, KZ_TEX_MAX_DEPTH);
-        pr.count = (uint32_t)sc->texOps.size() - pr.start;
+        pr.count = ((uint32_t)sc->texOps.size() - pr.start) | ((uint32_t)mx << 16);       // (<= 65536 ops in all: checked in emitTexture)
         sc->texProgs.push_back(pr);
     }
     return KZ_OK;
@@ -316,8 +324,13 @@ int kz_scene_create(const KzSceneDesc *d, KzScene **out) {
       if (sc->nodes4.size() > (size_t(1) << 26)) { delete sc; return kz_fail(KZ_ERR_UNSUPPORTED, "scene too large: %zu BVH4 packets (limit 2^26 = 4 GB of packets)", sc->nodes4.size()); }
       p.rootRef4 = r4; p.stackBound4 = sb; }
     p.stackDepth = (int32_t)std::max<uint32_t>(2u, sc->bvh.maxDepth + 1);
+    // what the scene's BSDF rows need beyond constant diffuse / kazenstandard (kz_devfn.h KZ_X_*): 1 = other models, 2 = texture-backed parameters, 4 = normal maps
     p.bsdfExt = 0;
-    for (const KzBSDF &b : sc->bsdfs) if (b.type > KZ_BSDF_KAZENSTANDARD || b.albedoTex || b.roughnessTex || b.metallicTex) p.bsdfExt = 1;
+    for (const KzBSDF &b : sc->bsdfs) {
+        if (b.type == KZ_BSDF_NORMALMAP) p.bsdfExt |= 4 | 2;
+        else if (b.type > KZ_BSDF_KAZENSTANDARD) p.bsdfExt |= 1;
+        if (b.albedoTex || b.roughnessTex || b.metallicTex) p.bsdfExt |= 2;
+    }
     // invisible-light triangles for the exact any-hit shadow test
     p.shadowFast = 1; p.nIlTris = 0; p.anyInvisibleLight = 0;
     uint32_t ilGidLo = 0xFFFFFFFFu, ilGidHi = 0;

@@ -68,12 +68,13 @@ enum { KZ_TOP_CONST = 0, KZ_TOP_IMAGE = 1, KZ_TOP_RAMP = 2, KZ_TOP_BLEND = 3 };
 struct KzTexOp {
     uint32_t op;           // KZ_TOP_*
     uint32_t a;            // IMAGE: image row; BLEND: KZ_BLEND_*
-    float f0, f1, f2;      // CONST: colour; IMAGE: f0 = scale; RAMP: f0 = min, f1 = max
-    uint32_t b;            // IMAGE: bit 0 = srgb, bits 1.. = KZ_TEXFILTER_*
+    float f0, f1, f2;      // CONST: colour; IMAGE: f0 = scale, f1 = bits(texel offset / 16), f2 = bits((width - 1) | (height - 1) << 16) - the image row, so that a lookup
+                           //   loads the op and then the texels, nothing in between; RAMP: f0 = min, f1 = max
+    uint32_t b;            // IMAGE: bit 0 = srgb, bits 1..7 = KZ_TEXFILTER_*, bits 8..15 = channels, bits 16..23 = KZ_PIXEL_*
     uint32_t pad[2];
 };
 static_assert(sizeof(KzTexOp) == 32, "texture op must be 32 B");
-struct KzTexProg { uint32_t start, count; };
+struct KzTexProg { uint32_t start, count; };      // count: low half = ops, high half = the operand stack depth the program needs
 struct KzImageRow { uint64_t offset; int32_t width, height, channels, format; };   // offset in bytes into the texel blob, 16-B aligned
 static_assert(sizeof(KzBSDF) == 128, "BSDF row must be 128 B");
 
@@ -113,7 +114,7 @@ struct KzParams {
     // pixel beams of a pinhole camera whose sample -> near-plane map is affine (kz_wf_beam): nearP(sx, sy) = beamA + sx * beamU + sy * beamV in WORLD
     // axes (the 3x3 of c2w applied), apex beamO
     int32_t beamOk; float beamO[3], beamA[3], beamU[3], beamV[3];
-    int32_t bsdfExt;                     // any BSDF row beyond constant diffuse / kazenstandard: other models, texture-backed
+    int32_t bsdfExt;                     // bit mask (kz_devfn.h KZ_X_*) of what the BSDF rows need beyond constant diffuse / kazenstandard: 1 other models, 2 texture-backed
                                          // parameters, normal maps (selects the larger kernel variants)
 };
 
@@ -137,6 +138,7 @@ struct KzDevTables {
     const KzTexOp *texOps;
     const KzImageRow *images;
     const uint8_t *texels;
+    uint32_t texPow2;           // every image has power-of-two sides: the periodic wrap of a texel coordinate is a mask (kz_scene_create)
 };
 
 struct KzScene {
@@ -160,6 +162,7 @@ struct KzScene {
     std::vector<uint8_t> texels;
     float filter[KZ_FILTER_RESOLUTION + 1];
     KzParams prm;
+    uint32_t texPow2 = 1;               // every image of the scene has power-of-two sides
     KzBvhInfo bvh;
     // device replicas, one per GPU the scene is resident on (KzReplicaSet, owned by kz_render.hip; created with the scene)
     void *dev = nullptr;

@@ -30,7 +30,7 @@
 #include <vector>
 
 // a1/a2 renderBlock + renderSample (renderer.cpp:20-69): item = pixLinear * S + sampleOffset
-template <bool STATS, bool EXT>
+template <bool STATS, int EXT>
 __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDevTables T, const uint32_t *__restrict__ pixList,
                                                                uint32_t nItems, uint32_t S, uint32_t sampleBegin, const uint32_t *__restrict__ itemSample,
                                                                float *__restrict__ outJx, float *__restrict__ outJy, float *__restrict__ outR,
@@ -223,6 +223,7 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     if ((rc = uploadVec(ds, scene->texOps, &ds->T.texOps))) return rc;
     if ((rc = uploadVec(ds, scene->images, &ds->T.images))) return rc;
     if ((rc = uploadVec(ds, scene->texels, &ds->T.texels))) return rc;
+    ds->T.texPow2 = scene->texPow2;
     const KzParams &P = scene->prm;
     ds->filmPixels = (size_t)(P.width + 2 * P.border) * (size_t)(P.height + 2 * P.border);
     KZ_TRACE("upload: small tables there");
@@ -713,8 +714,8 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
             uint32_t *svQ = W.queue[0], *svCount = W.counts + 6 * 520 + (iter + 1);
 #define KZ_SHADE2(ST, EX) do { hipLaunchKernelGGL((kz_wf_classify<ST, EX>), gClassify, blk, 0, stream, P, ds->T, W, pixList, Sp, sBegin, iter, cur, curCount, items, svQ, svCount); \
                                hipLaunchKernelGGL((kz_wf_shade_b<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, pixList, Sp, sBegin, iter, (const uint32_t *)svQ, (const uint32_t *)svCount, nextQ, nextCount, shQ, shCount); } while (0)
-            if (st) { if (P.bsdfExt) KZ_SHADE2(true, true); else KZ_SHADE2(true, false); }
-            else { if (P.bsdfExt) KZ_SHADE2(false, true); else KZ_SHADE2(false, false); }
+            if (st) { if (P.bsdfExt) KZ_SHADE2(true, KZ_X_ALL); else KZ_SHADE2(true, 0); }
+            else { if (P.bsdfExt) KZ_SHADE2(false, KZ_X_ALL); else KZ_SHADE2(false, 0); }
 #undef KZ_SHADE2
         } else
 #endif
@@ -724,8 +725,11 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #else
 #define KZ_SHADE(ST, EX) hipLaunchKernelGGL((kz_wf_shade<ST, EX>), gShade, blk, 0, stream, P, ds->T, W, pixList, Sp, sBegin, iter, cur, curCount, items, nextQ, nextCount, shQ, shCount)
 #endif
-            if (st) { if (P.bsdfExt) KZ_SHADE(true, true); else KZ_SHADE(true, false); }
-            else { if (P.bsdfExt) KZ_SHADE(false, true); else KZ_SHADE(false, false); }
+            // the kernel compiled for what the scene's BSDF rows need (KzParams::bsdfExt): nothing beyond diffuse / kiss; other models only (four workgroups per CU,
+            // no texture machinery); everything (textures, normal maps)
+            const int xsel = P.bsdfExt == 0 ? 0 : (P.bsdfExt == KZ_X_MODELS ? KZ_X_MODELS : KZ_X_ALL);
+            if (st) { if (xsel == KZ_X_ALL) KZ_SHADE(true, KZ_X_ALL); else if (xsel) KZ_SHADE(true, KZ_X_MODELS); else KZ_SHADE(true, 0); }
+            else { if (xsel == KZ_X_ALL) KZ_SHADE(false, KZ_X_ALL); else if (xsel) KZ_SHADE(false, KZ_X_MODELS); else KZ_SHADE(false, 0); }
 #undef KZ_SHADE
         }
         const bool lastIter = iter == maxDepth - 1;
@@ -925,8 +929,8 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
             float *sJx = c.plane[0], *sJy = c.plane[1], *sR = c.plane[2], *sG = c.plane[3], *sB = c.plane[4];
 #define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, pixList, (uint32_t)items, Sp, s, \
                                        (const uint32_t *)nullptr, sJx, sJy, sR, sG, sB, ds->stats)
-            if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, true); else KZ_MEGA(true, false); }
-            else { if (P.bsdfExt) KZ_MEGA(false, true); else KZ_MEGA(false, false); }
+            if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, KZ_X_ALL); else KZ_MEGA(true, 0); }
+            else { if (P.bsdfExt) KZ_MEGA(false, KZ_X_ALL); else KZ_MEGA(false, 0); }
 #undef KZ_MEGA
         }
         HIP_TRY(hipEventRecord(ep.b, pst));
@@ -1131,7 +1135,7 @@ int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint
     KZ_ALLOC(&dP.p, (size_t)n * 4); KZ_ALLOC(&dI.p, (size_t)n * 4); KZ_ALLOC(&dOut.p, (size_t)n * 20);
     float *dO = dOut.as<float>();
     HIP_TRY(hipMemcpy(dP.p, pl.data(), (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dI.p, idx, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL((kz_path_megakernel<false, true>), dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, P, ds->T, dP.as<uint32_t>(), n, 1u, 0u, dI.as<uint32_t>(),
+    hipLaunchKernelGGL((kz_path_megakernel<false, KZ_X_ALL>), dim3((n + KZ_BLOCK - 1) / KZ_BLOCK), dim3(KZ_BLOCK), 0, 0, P, ds->T, dP.as<uint32_t>(), n, 1u, 0u, dI.as<uint32_t>(),
                        dO, dO + n, dO + 2 * (size_t)n, dO + 3 * (size_t)n, dO + 4 * (size_t)n, ds->stats);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

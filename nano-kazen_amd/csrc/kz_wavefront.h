@@ -180,9 +180,9 @@ struct KzSst {
 // Pass A of shade(iter) for one queue entry: hit record -> intersection; a miss, an emitter hit and a one-sided BSDF seen from behind end the
 // path here (integrator.cpp:210-231, 315-327), the Russian roulette of integrator.cpp:237-244 is played. True = the path goes on to the light
 // sample and the BSDF sample (wfShadeSurvivor); `its` is then complete. `compact`: see kz_wf_shade.
-template <bool STATS, bool EXT>
+template <bool STATS, int EXT>
 __device__ __forceinline__ bool wfClassify(const KzParams &P, const KzDevTables &T, const KzWf &W, const uint32_t *__restrict__ pixList, uint32_t S, uint32_t sampleBegin,
-                                           int iter, bool compact, uint32_t slot, Its &its, Counters &cn, KzSst &sst) {
+                                           int iter, bool compact, uint32_t slot, Its &its, uint32_t &modelKey, Counters &cn, KzSst &sst) {
     bool survivor = false;
     const float4 h = kzLoadStream(&W.hit[slot]);
     const float4 rb = kzLoadStream(&W.rayB[slot]);
@@ -224,7 +224,13 @@ __device__ __forceinline__ bool wfClassify(const KzParams &P, const KzDevTables 
     // transmissive models go on; a normal map can turn a below-the-horizon wi into an above-the-horizon one.
     const float wz = dot(-rd, its.sh.n);                                       // toLocal(its.sh, -rd).z
     bool twoSided = false;
-    if (EXT) { const int bt = T.bsdfs[its.bsdf].type; twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP; }
+    if (EXT) {
+        // modelKey: which code pass B runs for this hit - the model of the row (of the row a normalmap wraps, + 8): pass B deals its lanes by it (kz_wf_shade)
+        const int bt = T.bsdfs[its.bsdf].type;
+        twoSided = bt == KZ_BSDF_DIELECTRIC || bt == KZ_BSDF_ROUGHDIELECTRIC || bt == KZ_BSDF_NORMALMAP;
+        modelKey = (uint32_t)bt;
+        if ((EXT & KZ_X_NMAP) && bt == KZ_BSDF_NORMALMAP) modelKey = 8u + ((uint32_t)T.bsdfs[T.bsdfs[its.bsdf].nested].type & 7u);
+    }
     survivor = (wz > 0.f) || twoSided || isnan(wz);
     if (survivor && iter >= 3) {
         // Russian roulette (integrator.cpp:237-244) here, in front of the compaction: a path it ends does not take a lane of
@@ -266,7 +272,7 @@ __device__ __forceinline__ bool wfClassify(const KzParams &P, const KzDevTables 
 #ifndef KZ_SHADE_LATE_POST
 #define KZ_SHADE_LATE_POST 0
 #endif
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ bool wfClassifyLight(const KzParams &P, const KzDevTables &T, const KzWf &W, const uint32_t *__restrict__ pixList, uint32_t S, uint32_t sampleBegin,
                                                 int iter, bool compact, uint32_t slot, float4 &hitOut, KzSst &sst) {
     const float4 h = kzLoadStream(&W.hit[slot]);
@@ -338,7 +344,7 @@ __device__ __forceinline__ bool wfClassifyLight(const KzParams &P, const KzDevTa
 
 // Pass B of shade(iter) for one surviving path: light sample + BSDF eval / pdf + MIS weight -> pending radiance and shadow ray
 // (integrator.cpp:247-295), BSDF sample -> throughput and next ray (:297-313). (The roulette of integrator.cpp:237-244 was played in pass A.)
-template <bool STATS, bool EXT>
+template <bool STATS, int EXT>
 __device__ __forceinline__ void wfShadeSurvivor(const KzParams &P, const KzDevTables &T, const KzWf &W, const uint32_t *__restrict__ pixList, uint32_t S, uint32_t sampleBegin,
                                                 int iter, bool compact, uint32_t slot, const Its &its, bool &pushNext, bool &pushShadow, Counters &cn, KzSst &sst) {
     const float eps = P.traceBias;
@@ -407,9 +413,10 @@ __device__ __forceinline__ void wfShadeSurvivor(const KzParams &P, const KzDevTa
 struct WfQueuePair {
     uint32_t *s_bufN, *s_bufS, *s_nN, *s_nS, *s_gbN, *s_gbS;
     uint32_t *nextQueue, *nextCount, *shadowQueue, *shadowCount;
+    uint32_t cap = KZ_WF_QCAP;                              // entries each staging buffer holds
     __device__ __forceinline__ void flush(bool force) {
         const uint32_t nN = *s_nN, nS = *s_nS;
-        const bool fN = force ? (nN > 0) : (nN > KZ_WF_QCAP - KZ_BLOCK), fS = force ? (nS > 0) : (nS > KZ_WF_QCAP - KZ_BLOCK);
+        const bool fN = force ? (nN > 0) : (nN > cap - KZ_BLOCK), fS = force ? (nS > 0) : (nS > cap - KZ_BLOCK);
         if (fN || fS) {                                     // uniform over the workgroup
             if (threadIdx.x == 0) { if (fN) *s_gbN = atomicAdd(nextCount, nN); if (fS) *s_gbS = atomicAdd(shadowCount, nS); }
             __syncthreads();
@@ -438,6 +445,9 @@ struct WfQueuePair {
 // the entries that still need the light sample and the BSDF sample are compacted through LDS (record = slot + frame + uv),
 // and pass B — which carries ~85 % of the kernel's instructions — only ever runs on full waves.
 #define KZ_SV_CAP (2 * KZ_BLOCK)
+#ifndef KZ_MODEL_SORT
+#define KZ_MODEL_SORT 1            // (0: pass B of the EXT variants takes its records in arrival order - the A/B of profiles/r06c_ext)
+#endif
 // -DKZ_SHADE_CONST_ARGS (development build): the three argument structs of the shade kernel (KzParams 300 B, KzDevTables, KzWf) in
 // __constant__ memory, one slot per pass context, instead of in the kernel-argument segment - measured in profiles/r05c_shade_args.
 #ifdef KZ_SHADE_CONST_ARGS
@@ -449,24 +459,31 @@ __constant__ KzShadeArgs g_kzShadeArgs[KZ_MAX_PASSES_IN_FLIGHT];
 #define KZ_SHADE_PARAMS KzParams P, KzDevTables T, KzWf W
 #define KZ_SHADE_BIND
 #endif
-template <bool STATS, bool EXT>
-__global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade(KZ_SHADE_PARAMS, const uint32_t *__restrict__ pixList, uint32_t S,
+template <bool STATS, int EXT>
+__global__ __launch_bounds__(KZ_BLOCK, ((EXT & (KZ_X_TEX | KZ_X_NMAP)) ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade(KZ_SHADE_PARAMS, const uint32_t *__restrict__ pixList, uint32_t S,
                                                         uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
                                                         const uint32_t *__restrict__ countPtr, uint32_t countImm,
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
                                                         uint32_t *__restrict__ shadowQueue, uint32_t *__restrict__ shadowCount) {
     KZ_SHADE_BIND
     constexpr bool LATE = KZ_SHADE_LATE_POST && !STATS;      // (the counting variant keeps the exact classification in pass A: its counters follow the reference's order of events)
-    constexpr int SVW = LATE ? 5 : (EXT ? 20 : 16);          // words per survivor: slot, p, s, t, n, uv, bsdf row (+ dpdu) | LATE: slot + the hit record
-    __shared__ uint32_t s_bufN[KZ_WF_QCAP], s_bufS[KZ_WF_QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
+    constexpr bool NMAPX = (EXT & KZ_X_NMAP) != 0;
+    constexpr int SVW = LATE ? 5 : (NMAPX ? 19 : 16);        // words per survivor: slot, p, s, t, n, uv, bsdf row | model key << 24 (+ dpdu: normal maps) | LATE: slot + the hit record
+    // the EXT variants stage 768 entries per output queue instead of 960: with the 576 B of the model sort below, the variant without textures still fits four workgroups per CU
+    constexpr uint32_t QCAP = EXT ? 768u : (uint32_t)KZ_WF_QCAP;
+    __shared__ uint32_t s_bufN[QCAP], s_bufS[QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
+    // EXT: pass B deals its 256 records to the lanes BY MODEL (a counting sort over 16 keys through LDS): a wave of pass B then runs one or two of the eleven
+    // BSDF models instead of all of them - with records in arrival order nearly every wave of a bounce held a lane of every model of the scene and paid for each
+    __shared__ uint32_t s_hist[EXT ? 16 : 1]; __shared__ uint16_t s_perm[EXT ? KZ_BLOCK : 1];
     // The survivor table is a stack; its fill count is double-buffered by round (s_svCnt[round & 1]) so that the count for the NEXT round can
     // be written while this round's is still being read: a round then needs two workgroup barriers (records written | records read, output
     // entries staged) instead of six; the two output queues are flushed together, with their own barriers, only when one of them is nearly full.
     __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svCnt[2];
     if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svCnt[0] = 0; s_svCnt[1] = 0; }
+    if (EXT && threadIdx.x < 16) s_hist[threadIdx.x] = 0;
     __syncthreads();
     WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
-    WfQueuePair qp = {s_bufN, s_bufS, &s_nN, &s_nS, &s_gbN, &s_gbS, nextQueue, nextCount, shadowQueue, shadowCount};
+    WfQueuePair qp = {s_bufN, s_bufS, &s_nN, &s_nS, &s_gbN, &s_gbS, nextQueue, nextCount, shadowQueue, shadowCount, QCAP};
     const uint32_t count = countPtr ? *countPtr : countImm;
     const int lane = threadIdx.x & 63;
     // Path state between bounces. The lean variant has no BSDF that changes eta or samples a discrete lobe, and without regularisation the
@@ -483,12 +500,13 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
         bool survivor = false;
         uint32_t slot = 0;
         Its its;
+        uint32_t modelKey = 0;
         float4 hrec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (more && base + threadIdx.x < count) {
             const uint32_t qi = base + threadIdx.x;
             slot = queue ? queue[qi] : qi;
             if (LATE) survivor = wfClassifyLight<EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, hrec, sst);
-            else survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, cn, sst);
+            else survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, modelKey, cn, sst);
         }
         sst.mark(0);                                        // pass A
         {   // compaction of the survivors onto the LDS record stack
@@ -505,8 +523,8 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
                 r[4 * KZ_SV_CAP] = __float_as_uint(its.sh.s.x); r[5 * KZ_SV_CAP] = __float_as_uint(its.sh.s.y); r[6 * KZ_SV_CAP] = __float_as_uint(its.sh.s.z);
                 r[7 * KZ_SV_CAP] = __float_as_uint(its.sh.t.x); r[8 * KZ_SV_CAP] = __float_as_uint(its.sh.t.y); r[9 * KZ_SV_CAP] = __float_as_uint(its.sh.t.z);
                 r[10 * KZ_SV_CAP] = __float_as_uint(its.sh.n.x); r[11 * KZ_SV_CAP] = __float_as_uint(its.sh.n.y); r[12 * KZ_SV_CAP] = __float_as_uint(its.sh.n.z);
-                r[13 * KZ_SV_CAP] = __float_as_uint(its.uvx); r[14 * KZ_SV_CAP] = __float_as_uint(its.uvy); r[15 * KZ_SV_CAP] = its.bsdf;
-                if (EXT) { r[16 * KZ_SV_CAP] = __float_as_uint(its.dpdu.x); r[17 * KZ_SV_CAP] = __float_as_uint(its.dpdu.y); r[18 * KZ_SV_CAP] = __float_as_uint(its.dpdu.z); }
+                r[13 * KZ_SV_CAP] = __float_as_uint(its.uvx); r[14 * KZ_SV_CAP] = __float_as_uint(its.uvy); r[15 * KZ_SV_CAP] = EXT ? (its.bsdf | (modelKey << 24)) : its.bsdf;      // (kz_scene_create: < 2^24 rows)
+                if (NMAPX) { r[16 * KZ_SV_CAP] = __float_as_uint(its.dpdu.x); r[17 * KZ_SV_CAP] = __float_as_uint(its.dpdu.y); r[18 * KZ_SV_CAP] = __float_as_uint(its.dpdu.z); }
                 }
             }
         }
@@ -518,8 +536,22 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
         bool pushNext = false, pushShadow = false;
         const uint32_t take = n0 >= KZ_BLOCK ? (uint32_t)KZ_BLOCK : (more ? 0u : n0);
         if (threadIdx.x == 0) s_svCnt[(round + 1u) & 1u] = n0 - take;        // what the next round's pass A appends to (visible behind the barrier below)
+        uint32_t mine = threadIdx.x;                                          // which of the `take` records this thread shades
+        if (KZ_MODEL_SORT && EXT && !LATE && take > 64u) {                    // (uniform; one wave's worth needs no dealing)
+            // counting sort of the taken records by model key: rank within the key by an LDS atomic, bucket bases by a 16-entry prefix, scatter of the record numbers
+            uint32_t key = 0, rank = 0;
+            if (threadIdx.x < take) { key = s_sv[15 * KZ_SV_CAP + (n0 - take) + threadIdx.x] >> 24; rank = atomicAdd(&s_hist[key & 15u], 1u); }
+            __syncthreads();
+            if (threadIdx.x < take) {
+                uint32_t basePos = 0;
+                for (uint32_t k = 0; k < (key & 15u); ++k) basePos += s_hist[k];
+                s_perm[basePos + rank] = (uint16_t)threadIdx.x;
+            }
+            __syncthreads();
+            if (threadIdx.x < take) mine = s_perm[threadIdx.x];
+        }
         if (threadIdx.x < take) {
-            const uint32_t *r = s_sv + (n0 - take) + threadIdx.x;
+            const uint32_t *r = s_sv + (n0 - take) + mine;
             slot = r[0];
             bool alive = true;
             if (LATE) {
@@ -536,14 +568,15 @@ __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_sh
             its.sh.s = mk(__uint_as_float(r[4 * KZ_SV_CAP]), __uint_as_float(r[5 * KZ_SV_CAP]), __uint_as_float(r[6 * KZ_SV_CAP]));
             its.sh.t = mk(__uint_as_float(r[7 * KZ_SV_CAP]), __uint_as_float(r[8 * KZ_SV_CAP]), __uint_as_float(r[9 * KZ_SV_CAP]));
             its.sh.n = mk(__uint_as_float(r[10 * KZ_SV_CAP]), __uint_as_float(r[11 * KZ_SV_CAP]), __uint_as_float(r[12 * KZ_SV_CAP]));
-            its.uvx = __uint_as_float(r[13 * KZ_SV_CAP]); its.uvy = __uint_as_float(r[14 * KZ_SV_CAP]); its.bsdf = r[15 * KZ_SV_CAP];
-            if (EXT) its.dpdu = mk(__uint_as_float(r[16 * KZ_SV_CAP]), __uint_as_float(r[17 * KZ_SV_CAP]), __uint_as_float(r[18 * KZ_SV_CAP]));
+            its.uvx = __uint_as_float(r[13 * KZ_SV_CAP]); its.uvy = __uint_as_float(r[14 * KZ_SV_CAP]); its.bsdf = EXT ? (r[15 * KZ_SV_CAP] & 0xFFFFFFu) : r[15 * KZ_SV_CAP];
+            if (NMAPX) its.dpdu = mk(__uint_as_float(r[16 * KZ_SV_CAP]), __uint_as_float(r[17 * KZ_SV_CAP]), __uint_as_float(r[18 * KZ_SV_CAP]));
             }
             if (alive) wfShadeSurvivor<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, pushNext, pushShadow, cn, sst);
         }
         sst.mark(7);                                        // next-ray stores (and, for lanes without a survivor, nothing)
         apN.push(pushNext, slot); apS.push(pushShadow, slot);
         __syncthreads();                                   // every record of this batch has been read, the output entries are staged
+        if (EXT && threadIdx.x < 16) s_hist[threadIdx.x] = 0;      // (read for the last time in front of the barrier above; counted into again behind the next round's first barrier)
         qp.flush(false);
         sst.mark(8);                                        // barrier + queue staging + flushes
         if (!more && n0 - take == 0) break;

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 #ifndef KZ_CLASSIFY_WAVES
 #define KZ_CLASSIFY_WAVES 4      // (8 when it was measured, profiles/r04b_shade_split; the double-precision transcendentals of r04m took it to 4: asking for 8 only earned a warning per instantiation)
 #endif
-template <bool STATS, bool EXT>
+template <bool STATS, int EXT>
 __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_CLASSIFY_WAVES, KZ_CLASSIFY_WAVES))) void kz_wf_classify(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
                                                            uint32_t sampleBegin, int iter, const uint32_t *__restrict__ queue,
                                                            const uint32_t *__restrict__ countPtr, uint32_t countImm,
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_CLA
             const uint32_t qi = base + threadIdx.x;
             slot = queue ? queue[qi] : qi;
             Its its;
-            survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, cn, sst);
+            { uint32_t modelKey_ = 0; survivor = wfClassify<STATS, EXT>(P, T, W, pixList, S, sampleBegin, iter, compact, slot, its, modelKey_, cn, sst); }
         }
         sst.mark(0);
         ap.push(survivor, slot);
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(KZ_BLOCK) __attribute__((amdgpu_waves_per_eu(KZ_CLA
     sst.flush(W.stats);
 }
 
-template <bool STATS, bool EXT>
+template <bool STATS, int EXT>
 __global__ __launch_bounds__(KZ_BLOCK, (EXT ? 3 : KZ_SHADE_WAVES)) void kz_wf_shade_b(KzParams P, KzDevTables T, KzWf W, const uint32_t *__restrict__ pixList, uint32_t S,
                                                         uint32_t sampleBegin, int iter, const uint32_t *__restrict__ survQueue, const uint32_t *__restrict__ survCount,
                                                         uint32_t *__restrict__ nextQueue, uint32_t *__restrict__ nextCount,
