@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--cold-job", choices=["c4", "q1"], default=None, help="(child process mode) run ONE cold job and print its record")
     ap.add_argument("--no-cold-job", action="store_true", help="N = 1: skip the two one-frame-per-process jobs that ride in the same JSON line")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity render (scripts/profile_bench.sh: the kernel statistics of a profiled run then hold the timed passes only)")
     ap.add_argument("--no-ext-scenes", action="store_true", help="N = 1: skip the EXT-kernel scenes and C1 / C2 / C3 at their BASELINE sizes (each beside the oracle's CPU time) that ride in the same JSON line")
     ap.add_argument("--profile-pass", action="store_true", help="(scripts/profile_bench.sh) every step asks for ONE pass of 2^30 items explicitly instead of earning it call by call: "
                                                                 "the counter runs profile the first step of a process, and the pass they see must be the steady state's")
@@ -370,7 +371,7 @@ def main():
     # depend on N, on the dealing or on the pass size (round 6: per-pixel running tap sums, rects merged in tile order), so the crc32 of a fixed crop is the same at
     # every N - the scaling run carries its own parity check.
     parity = None
-    if not args.strong:
+    if not args.strong and not args.no_parity:
         # (weak scaling lengthens the sampler table from N = 4 on: those ranks build the 1024-entry scene for this render - outside every clock)
         psc = scene if spp_table == PARITY_SPP_TABLE else kz.Scene(kz.scenes.random_triangles(args.tris, Wd, Hd, PARITY_SPP_TABLE, sampler="pmj02bn", seed=1), device=device_index)
         psc.render(0, 64, tiles=render_tiles, accumulate=False, stream=stream, **kw)

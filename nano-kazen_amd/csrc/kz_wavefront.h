@@ -469,18 +469,19 @@ __global__ __launch_bounds__(KZ_BLOCK, ((EXT & (KZ_X_TEX | KZ_X_NMAP)) ? 3 : KZ_
     constexpr bool LATE = KZ_SHADE_LATE_POST && !STATS;      // (the counting variant keeps the exact classification in pass A: its counters follow the reference's order of events)
     constexpr bool NMAPX = (EXT & KZ_X_NMAP) != 0;
     constexpr int SVW = LATE ? 5 : (NMAPX ? 19 : 16);        // words per survivor: slot, p, s, t, n, uv, bsdf row | model key << 24 (+ dpdu: normal maps) | LATE: slot + the hit record
-    // the EXT variants stage 768 entries per output queue instead of 960: with the 576 B of the model sort below, the variant without textures still fits four workgroups per CU
-    constexpr uint32_t QCAP = EXT ? 768u : (uint32_t)KZ_WF_QCAP;
+    constexpr uint32_t QCAP = (uint32_t)KZ_WF_QCAP;
     __shared__ uint32_t s_bufN[QCAP], s_bufS[QCAP]; __shared__ uint32_t s_nN, s_nS, s_gbN, s_gbS;
-    // EXT: pass B deals its 256 records to the lanes BY MODEL (a counting sort over 16 keys through LDS): a wave of pass B then runs one or two of the eleven
-    // BSDF models instead of all of them - with records in arrival order nearly every wave of a bounce held a lane of every model of the scene and paid for each
-    __shared__ uint32_t s_hist[EXT ? 16 : 1]; __shared__ uint16_t s_perm[EXT ? KZ_BLOCK : 1];
+    // The full variant (textures, normal maps) deals the 256 records of pass B to the lanes BY MODEL (a counting sort over 16 keys through LDS: a normal map sorts
+    // by the model it wraps, + 8): worth 2.5 % of the kernel on the textured scene, nothing on the scene of eleven constant-parameter models - the items of a pass
+    // are pixel-major and a queue keeps that order, so a batch already holds mostly ONE object's hits (profiles/r04q_ext_sorted, r06c_ext/ab_sort_vs_nosort.txt)
+    constexpr bool SORT = KZ_MODEL_SORT && NMAPX && !LATE;
+    __shared__ uint32_t s_hist[SORT ? 16 : 1]; __shared__ uint16_t s_perm[SORT ? KZ_BLOCK : 1];
     // The survivor table is a stack; its fill count is double-buffered by round (s_svCnt[round & 1]) so that the count for the NEXT round can
     // be written while this round's is still being read: a round then needs two workgroup barriers (records written | records read, output
     // entries staged) instead of six; the two output queues are flushed together, with their own barriers, only when one of them is nearly full.
     __shared__ uint32_t s_sv[SVW * KZ_SV_CAP]; __shared__ uint32_t s_svCnt[2];
     if (threadIdx.x == 0) { s_nN = 0; s_nS = 0; s_svCnt[0] = 0; s_svCnt[1] = 0; }
-    if (EXT && threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+    if (SORT && threadIdx.x < 16) s_hist[threadIdx.x] = 0;
     __syncthreads();
     WfAppender apN = {s_bufN, &s_nN, &s_gbN, nextQueue, nextCount}, apS = {s_bufS, &s_nS, &s_gbS, shadowQueue, shadowCount};
     WfQueuePair qp = {s_bufN, s_bufS, &s_nN, &s_nS, &s_gbN, &s_gbS, nextQueue, nextCount, shadowQueue, shadowCount, QCAP};
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(KZ_BLOCK, ((EXT & (KZ_X_TEX | KZ_X_NMAP)) ? 3 : KZ_
         const uint32_t take = n0 >= KZ_BLOCK ? (uint32_t)KZ_BLOCK : (more ? 0u : n0);
         if (threadIdx.x == 0) s_svCnt[(round + 1u) & 1u] = n0 - take;        // what the next round's pass A appends to (visible behind the barrier below)
         uint32_t mine = threadIdx.x;                                          // which of the `take` records this thread shades
-        if (KZ_MODEL_SORT && EXT && !LATE && take > 64u) {                    // (uniform; one wave's worth needs no dealing)
+        if (SORT && take > 64u) {                                             // (uniform; one wave's worth needs no dealing)
             // counting sort of the taken records by model key: rank within the key by an LDS atomic, bucket bases by a 16-entry prefix, scatter of the record numbers
             uint32_t key = 0, rank = 0;
             if (threadIdx.x < take) { key = s_sv[15 * KZ_SV_CAP + (n0 - take) + threadIdx.x] >> 24; rank = atomicAdd(&s_hist[key & 15u], 1u); }
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(KZ_BLOCK, ((EXT & (KZ_X_TEX | KZ_X_NMAP)) ? 3 : KZ_
         sst.mark(7);                                        // next-ray stores (and, for lanes without a survivor, nothing)
         apN.push(pushNext, slot); apS.push(pushShadow, slot);
         __syncthreads();                                   // every record of this batch has been read, the output entries are staged
-        if (EXT && threadIdx.x < 16) s_hist[threadIdx.x] = 0;      // (read for the last time in front of the barrier above; counted into again behind the next round's first barrier)
+        if (SORT && threadIdx.x < 16) s_hist[threadIdx.x] = 0;     // (read for the last time in front of the barrier above; counted into again behind the next round's first barrier)
         qp.flush(false);
         sst.mark(8);                                        // barrier + queue staging + flushes
         if (!more && n0 - take == 0) break;

@@ -7,8 +7,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmcab_$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-KZ_LIB_PATH=$R/nano-kazen_amd/csrc/variants/$NAME/libkazen_mi355x.so timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/variant -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-asset-scene --no-cold-job --no-ext-scenes > $OUT/variant.log 2>&1 || { tail -5 $OUT/variant.log; exit 1; }
-timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/tree -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-asset-scene --no-cold-job --no-ext-scenes > $OUT/tree.log 2>&1 || { tail -5 $OUT/tree.log; exit 1; }
+KZ_LIB_PATH=$R/nano-kazen_amd/csrc/variants/$NAME/libkazen_mi355x.so timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/variant -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-asset-scene --no-cold-job --no-ext-scenes --no-parity > $OUT/variant.log 2>&1 || { tail -5 $OUT/variant.log; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/tree -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-asset-scene --no-cold-job --no-ext-scenes --no-parity > $OUT/tree.log 2>&1 || { tail -5 $OUT/tree.log; exit 1; }
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

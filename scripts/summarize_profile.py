@@ -23,13 +23,13 @@ if st:
 # roofline.pass_ms_in_flight is the steady-state distance between the ends of consecutive film kernels (one per pass).
 tr = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
 if tr:
-    ends = sorted(int(r["End_Timestamp"]) for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith(("kz_film_gather", "kz_film_apply")))
+    ends = sorted(int(r["End_Timestamp"]) for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].replace("void ", "").startswith("kz_film_taps"))
     gaps = sorted((b - a) / 1e6 for a, b in zip(ends, ends[1:]))
     if gaps:
         med = gaps[len(gaps) // 2]
         loop = [g for g in gaps if g <= 2 * med]        # the counting legs after the loop (megakernel: hundreds of ms) are left out
         json.dump({"film_kernels": len(ends), "mean_ms_between_pass_ends": round(sum(loop) / len(loop), 3), "gaps_used": len(loop),
-                   "note": "rocprofv3 --kernel-trace of bench.py --steps 4 --warmup 1: time from the end of one pass (its kz_film_gather) to the end of "
+                   "note": "rocprofv3 --kernel-trace of bench.py --steps 4 --warmup 1: time from the end of one pass (its kz_film_taps) to the end of "
                            "the next, averaged over the timed loop; comparable with roofline.pass_ms_in_flight of bench.json"},
                   open(os.path.join(dst, "pass_span_from_trace.json"), "w"), indent=1)
         print("pass ends: n %d mean gap %.3f ms over %d gaps" % (len(ends), sum(loop) / len(loop), len(loop)))
@@ -53,9 +53,9 @@ for f in newest(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         disp[i][row["Counter_Name"]] = disp[i].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
         names[i] = k
 ids = sorted(disp)
-# bench.py --steps 1 --warmup 0: the first kz_wf_generate .. kz_film_gather run is pass 1 of the step
+# bench.py --steps 1 --warmup 0: the first kz_wf_generate .. kz_film_taps run is pass 1 of the step
 first = next((i for i in ids if names[i] == "kz_wf_generate"), None)
-last = next((i for i in ids if i > (first or 0) and names[i] in ("kz_film_gather", "kz_film_apply")), None)
+last = next((i for i in ids if i > (first or 0) and names[i].startswith("kz_film_taps")), None)
 one_pass = [i for i in ids if first is not None and last is not None and first <= i <= last]
 def derived(c):
     g = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
@@ -95,7 +95,7 @@ def group(prefix):
     return c
 kernels = {}
 for label, prefix in (("kz_wf_trace<0>", "kz_wf_trace<0"), ("kz_wf_trace<4> (shadow)", "kz_wf_trace<4"), ("kz_wf_trace<2> (deferred walk-through)", "kz_wf_trace<2"), ("kz_wf_shade", "kz_wf_shade"), ("kz_wf_trace_packet", "kz_wf_trace_packet"),
-                      ("kz_wf_trace_list", "kz_wf_trace_list"), ("kz_wf_beam", "kz_wf_beam"), ("kz_film_gather", "kz_film_gather"), ("kz_film_taps", "kz_film_taps"), ("kz_film_apply", "kz_film_apply"), ("kz_wf_generate", "kz_wf_generate")):
+                      ("kz_wf_trace_list", "kz_wf_trace_list"), ("kz_wf_beam", "kz_wf_beam"), ("kz_film_resolve", "kz_film_resolve"), ("kz_film_taps", "kz_film_taps"), ("kz_film_apply", "kz_film_apply"), ("kz_wf_generate", "kz_wf_generate")):
     c = group(prefix)
     if not c.get("SQ_INSTS_VALU"):
         continue

@@ -203,3 +203,31 @@ int main(int argc, char **argv) {
     sc.render(max_state_bytes=30 << 30)
     assert (sc.width, sc.height) == (200, 136) and np.array_equal(outs[0].reshape(sc.film().shape), sc.film())
     sc.close()
+
+
+def test_bench_parity_crc_is_independent_of_the_cut(aliased, gpu_lib, kz):
+    """bench.py's `parity` sub-record: the crc32 of a fixed 64 x 64 crop of C4's film at sample indices [0, 64) is ONE number (bench.PARITY_CRC_N1, measured at N = 1 on
+    the product library) however the frame was cut: here through the development library on one replica, through 2 / 4 / 8 aliased replicas with tiles dealt
+    beforehand and taken from a counter, and from the packed rects of eight tile shares merged in tile order (what eight ranks hand to rank 0)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    desc = kz.scenes.random_triangles(bench.NTRIS, bench.W, bench.H, bench.PARITY_SPP_TABLE, sampler="pmj02bn", seed=1)
+    prod = kz.Scene(desc, device=0)                                       # the product library, as bench.py at N = 1
+    prod.render(0, 64)
+    assert bench.film_crc(prod.film(), prod.border) == bench.PARITY_CRC_N1
+    entries = []                                                         # eight ranks' worth of rects, each rank rendering only ITS tiles
+    for part in range(8):
+        tiles = kz.shard.deal_tiles(bench.W, bench.H, 8, part, bench.TILE)
+        packed = prod.render_tiles(tiles, device=0, sample_begin=0, sample_end=64, packed=True)
+        entries += kz.shard._rects_of(tiles, packed, prod.border)
+    merged = prod.merge_rects(prod.empty_film(), sorted(entries, key=lambda e: (e[0][1], e[0][0])))
+    assert bench.film_crc(merged, prod.border) == bench.PARITY_CRC_N1
+    prod.close()
+    gpu_lib.kz_device_trim(0)
+    sc = kz.Scene(desc, lib=aliased)
+    for n in (1, 2, 4, 8):
+        cap = _budget(aliased, n)
+        for dealing in (0, 1):
+            film, _ = sc.render_multi(list(range(n)), sample_begin=0, sample_end=64, tile_dealing=dealing, max_state_bytes=cap)
+            assert bench.film_crc(film, sc.border) == bench.PARITY_CRC_N1, (n, dealing)
+    sc.close()
