@@ -37,13 +37,17 @@ for seed in range(first, first + n):
     tiles = kz.shard.deal_tiles(w, h, 1, 0, 32)
     counter = np.zeros(1, np.uint32)
     took = sc.render_dealt(tiles, counter, takers=1, batch_tiles=2, pass_items=4096)
-    ok_deal = took == tiles and np.allclose(sc.film(), film, rtol=2e-5, atol=1e-5)
+    ok_deal = took == tiles and np.array_equal(sc.film(), film)          # (round 6: the film does not depend on the cut - bit for bit)
     half = sc.sample_count // 2
     if half > 0:
         sc.render(0, half); sc.render(half, sc.sample_count, accumulate=True)
-        ok_rng = np.allclose(sc.film(), film, rtol=2e-5, atol=1e-5)
+        ok_rng = np.array_equal(sc.film(), film)
     else:
         ok_rng = True
+    # the packed rects of a 64-px tiling merged in tile order ARE the film (the resolve's canonical grid)
+    t64 = kz.shard.deal_tiles(w, h, 1, 0, 64)
+    sc.render()
+    ok_rng = ok_rng and np.array_equal(sc.merge_tiles(sc.empty_film(), t64, sc.film_tiles(t64)), film)
     line = "seed %d %s %dx%dx%d depth %d tris %d: L2 %.2e (scale %.1f) %s" % (seed, d.sampler["type"], w, h, sc.sample_count, d.integrator["maxDepth"], d.n_tris(), err, scale,
             ("ok" + note) if (ok and ok_mega and ok_stats and ok_deal and ok_rng) else "FAIL oracle=%s mega=%s stats=%s deal=%s ranges=%s%s" % (ok, ok_mega, ok_stats, ok_deal, ok_rng, note))
     print(line, flush=True)

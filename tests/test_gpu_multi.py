@@ -231,3 +231,35 @@ def test_bench_parity_crc_is_independent_of_the_cut(aliased, gpu_lib, kz):
             film, _ = sc.render_multi(list(range(n)), sample_begin=0, sample_end=64, tile_dealing=dealing, max_state_bytes=cap)
             assert bench.film_crc(film, sc.border) == bench.PARITY_CRC_N1, (n, dealing)
     sc.close()
+
+
+def test_a_frame_of_more_pixels_than_a_growing_context_holds(dev_lib, kz):
+    """frames above 2^23 pixels at 8 .. 255 spp kept EVERY pixel of the frame in a pass's column whatever the growing context held - one sample
+    of 8.8 M pixels planned on a context of 2^20 items: writes into reserved, unmapped address space. The planner now narrows the column to what is mapped
+    (tests/test_plan_cpu.py has the arithmetic); this is the same case on the device, slowed-down growth and all - alone and under a dealer with two contexts."""
+    from conftest import wait_for_wipe
+    dev_lib.kz_device_trim(0)
+    wait_for_wipe(dev_lib)
+    desc = kz.scenes.cornell_box(4096, 2160, 16, sampler="pmj02bn")       # 8.8 M pixels x 16 spp = 141 M items
+    ref = kz.Scene(desc, device=0, lib=dev_lib)
+    ref.render(pass_items=1 << 26, passes_in_flight=1)                    # (said: every pass waits for its full context)
+    want = ref.film()
+    ref.close()
+    dev_lib.kz_device_trim(0)
+    wait_for_wipe(dev_lib)
+    sc = kz.Scene(desc, device=0, lib=dev_lib)
+    try:
+        dev_lib.kz_debug_grow_delay(10)
+        sc.render()                                                        # library defaults: passes start on 2^20 mapped items
+        info = sc.last_pass_info()
+        got = sc.film()
+        assert info["firstPassItems"] <= 1 << 23 < 4096 * 2160 and info["passes"] > 2, info
+        assert np.array_equal(got, want)
+        tiles = kz.shard.deal_tiles(4096, 2160, 1, 0, 64)
+        counter = np.zeros(16, np.uint32)
+        dev_lib.kz_device_trim(0)
+        took = sc.render_dealt(tiles, counter, takers=1)                   # a dealer: two contexts growing at their own pace
+        assert sorted(took) == sorted(tiles) and np.array_equal(sc.film(), want)
+    finally:
+        dev_lib.kz_debug_grow_delay(0)
+    sc.close()
