@@ -375,8 +375,8 @@ int kz_film_merge_rects(float *film, int32_t width, int32_t height, int32_t bord
  * under a mutex, block.cpp:87-96) one level up: the image is cut into tileSize x tileSize tiles (a multiple of the 32-px
  * block; 0 = 64), ONE HOST THREAD PER DEVICE renders its tiles with kz_render_tiles - dealt by area beforehand (kz_deal_tiles) or, with
  * opts->tileDealing = 1, pulled in batches from a shared counter (the reference's BlockGenerator, block.cpp:117-148) - downloads the
- * packed rects of ITS tiles, and the rects are added into `film` in TILE order on the host (H10: deterministic for static dealing;
- * dynamic dealing regroups the additions where shares meet). No collective, no peer access. Replicas are uploaded on demand BEFORE the clocks start: deviceMs (may be NULL) receives
+ * packed rects of ITS tiles - each rect what the tile's own pixels add - and the rects are added into `film` in TILE order on the host (H10: the same film bit for bit
+ * for static and dynamic dealing and for any number of devices; with the default tile the film of kz_render on ONE device). No collective, no peer access. Replicas are uploaded on demand BEFORE the clocks start: deviceMs (may be NULL) receives
  * each device's wall time of render + gather in ms. opts->tiles / opts->device / opts->stream are ignored. */
 int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *devices, uint32_t nDevices, int32_t tileSize,
                     float *film, size_t nFloats, float *deviceMs);
