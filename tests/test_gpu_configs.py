@@ -596,3 +596,26 @@ def test_pass_contexts_outlive_their_replica(gpu_lib, kz):
     while _free_gb(gpu_lib) <= free0 - 0.5 and time.perf_counter() - t0 < 10.0:
         time.sleep(0.05)
     assert _free_gb(gpu_lib) > free0 - 0.5
+
+
+@pytest.mark.parametrize("radius,taps", [(0.25, 1), (1.5, 4), (2.5, 6), (3.5, 8), (4.0, 9)])
+def test_every_filter_width_runs_on_the_tap_sums(gpu_lib, kz, O, radius, taps):
+    """Round 6: every reconstruction filter of 1 .. 9 taps per axis (radius up to 4) runs on the running per-pixel tap sums - `kz_film_taps<TAPS, GROUPS>` with two lane
+    groups per pixel up to 5 taps, four beyond; the staged gather kernel of rounds 1-5 is gone. The widths the other tests do not reach (box 2, tent 3, default 5, gaussian
+    r3 7), each against the oracle, across schedules, and through the tile rects merged in tile order."""
+    desc = kz.scenes.cornell_box(100, 72, 12, sampler="pmj02bn")
+    desc.camera["rfilter"] = {"type": "gaussian", "radius": radius, "stddev": 0.4 * max(radius, 1.0)}
+    sc = kz.Scene(desc, device=0)
+    assert 2 * sc.border + 1 >= taps - 1                                  # (the apron holds the footprint)
+    sc.render()
+    film = sc.film()
+    ora = O.OracleScene(desc)
+    cpu = ora.render(threads=0)
+    assert np.allclose(film[..., 3], cpu[..., 3], rtol=1e-5, atol=1e-6) and l2(sc.rgb(film), ora.rgb(cpu)) < L2_TOL
+    sc.render(pass_items=100 * 72 * 4, passes_in_flight=3)
+    assert np.array_equal(sc.film(), film)
+    sc.render(0, 5); sc.render(5, 12, accumulate=True)
+    assert np.array_equal(sc.film(), film)
+    tiles = kz.shard.deal_tiles(100, 72, 1, 0, 64)
+    assert np.array_equal(sc.merge_tiles(sc.empty_film(), tiles, sc.film_tiles(tiles)), film)
+    sc.close()
