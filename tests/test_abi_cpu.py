@@ -248,3 +248,48 @@ def test_film_merge_tiles_adds_rects_in_list_order(kz):
     assert lib.kz_film_merge_tiles(film.ctypes.data_as(kz.abi.f32p), W, H, b, arr, len(tiles), packed.ctypes.data_as(kz.abi.f32p), packed.size - 4, 1) == kz.abi.KZ_ERR_INVALID_ARG
     bad = (kz.abi.KzTile * 1)(kz.abi.KzTile(90, 0, 64, 64))
     assert lib.kz_film_merge_tiles(film.ctypes.data_as(kz.abi.f32p), W, H, b, bad, 1, packed.ctypes.data_as(kz.abi.f32p), 68 * 68 * 4, 1) == kz.abi.KZ_ERR_INVALID_ARG
+
+
+def test_merge_rects_equals_merge_tiles_and_checks_its_arguments(kz):
+    """kz_film_merge_rects (round 6: the rects of a list may lie in different buffers - every rank's in that rank's shared-memory file) against kz_film_merge_tiles on the same
+    rects, ragged tiles and overlapping aprons included; any number of band threads; null and out-of-frame arguments are errors, never a crash."""
+    lib = kz.abi.load_library()
+    rng = np.random.default_rng(3)
+    w, h, b = 150, 100, 2
+    tiles = kz.shard.deal_tiles(w, h, 1, 0, 64)                           # 3 x 2 tiles, ragged at the right and bottom edges
+    rects = [rng.random((t[3] + 2 * b) * (t[2] + 2 * b) * 4, dtype=np.float32) for t in tiles]
+    arr = (kz.abi.KzTile * len(tiles))(*[kz.abi.KzTile(*t) for t in tiles])
+    packed = np.concatenate(rects)
+    f1 = np.zeros(((h + 2 * b), (w + 2 * b), 4), np.float32)
+    assert lib.kz_film_merge_tiles(f1.ctypes.data_as(kz.abi.f32p), w, h, b, arr, len(tiles), packed.ctypes.data_as(kz.abi.f32p), packed.size, 1) == 0
+    for threads in (1, 3, 16):
+        f2 = np.zeros_like(f1)
+        ptrs = (kz.abi.f32p * len(tiles))(*[C.cast(r.ctypes.data, kz.abi.f32p) for r in rects])
+        assert lib.kz_film_merge_rects(f2.ctypes.data_as(kz.abi.f32p), w, h, b, arr, ptrs, len(tiles), threads) == 0
+        assert np.array_equal(f1, f2)
+    # the order of the list is the order of the additions: reversed, the apron texels may differ in the last bit - and never by more
+    rev = (kz.abi.KzTile * len(tiles))(*[kz.abi.KzTile(*t) for t in tiles[::-1]])
+    ptrs = (kz.abi.f32p * len(tiles))(*[C.cast(r.ctypes.data, kz.abi.f32p) for r in rects[::-1]])
+    f3 = np.zeros_like(f1)
+    assert lib.kz_film_merge_rects(f3.ctypes.data_as(kz.abi.f32p), w, h, b, rev, ptrs, len(tiles), 0) == 0
+    assert np.allclose(f3, f1, rtol=1e-6, atol=0)
+    bad = (kz.abi.f32p * len(tiles))(*([C.cast(r.ctypes.data, kz.abi.f32p) for r in rects[:-1]] + [None]))
+    assert lib.kz_film_merge_rects(f3.ctypes.data_as(kz.abi.f32p), w, h, b, arr, bad, len(tiles), 0) == kz.abi.KZ_ERR_INVALID_ARG
+    out = (kz.abi.KzTile * 1)(kz.abi.KzTile(128, 64, 64, 64))
+    assert lib.kz_film_merge_rects(f3.ctypes.data_as(kz.abi.f32p), w, h, b, out, ptrs, 1, 0) == kz.abi.KZ_ERR_INVALID_ARG
+    assert lib.kz_film_merge_rects(None, w, h, b, arr, ptrs, len(tiles), 0) == kz.abi.KZ_ERR_INVALID_ARG
+    assert lib.kz_film_merge_rects(f3.ctypes.data_as(kz.abi.f32p), w, h, b, arr, None, len(tiles), 0) == kz.abi.KZ_ERR_INVALID_ARG
+
+
+def test_planner_entry_points_check_their_arguments(kz):
+    lib = kz.abi.load_library()
+    q, a = kz.abi.KzPlanQuery(), kz.abi.KzPlanAnswer()
+    assert lib.kz_plan_passes(None, C.byref(a)) == kz.abi.KZ_ERR_INVALID_ARG
+    assert lib.kz_plan_passes(C.byref(q), C.byref(a)) == kz.abi.KZ_ERR_INVALID_ARG            # an empty call
+    q.nPix, q.sampleBegin, q.sampleEnd, q.limitBytes, q.dealer = 1000, 0, 8, 1 << 30, 1          # a dealer without a tile list
+    assert lib.kz_plan_passes(C.byref(q), C.byref(a)) == kz.abi.KZ_ERR_INVALID_ARG
+    q.dealer = 0
+    assert lib.kz_plan_passes(C.byref(q), C.byref(a)) == 0 and a.need == 8000 and a.nPasses == 1
+    n = C.c_uint32()
+    av = (C.c_uint64 * 1)(0)                                                                    # a context that holds nothing: an error, not a loop
+    assert lib.kz_plan_schedule(C.byref(q), av, 1, 0, 1000, None, 0, C.byref(n)) != 0
