@@ -125,8 +125,17 @@ int kz_render_multi(KzScene *scene, const KzRenderOpts *opts, const int32_t *dev
     std::vector<KzTile> all(nAll);
     int rc = nAll ? kz_deal_tiles(P.width, P.height, tileSize, 1, 0, all.data(), nAll, &nAll) : KZ_OK;
     if (rc) return rc;
-    // replicas come up BEFORE the clocks start (deviceMs is render + gather; a first call pays the upload outside it)
-    for (uint32_t i = 0; i < nDevices; ++i) if ((rc = kz_scene_upload(scene, devices[i]))) { const std::string why = kz_last_error(); return kz_fail(rc, "device %d: %s", devices[i], why.c_str()); }
+    // replicas come up BEFORE the clocks start (deviceMs is render + gather; a first call pays the upload outside it) - side by side, one host thread per device: every
+    // device has its own link to the host, and eight uploads of a C4-sized scene one after the other were 0.36 s in front of a 2.4 s job (round 6)
+    {
+        std::vector<int> urc(nDevices, KZ_OK);
+        std::vector<std::string> uerr(nDevices);
+        std::vector<std::thread> up;
+        for (uint32_t i = 0; i < nDevices; ++i)
+            up.emplace_back([&, i]() { urc[i] = kz_scene_upload(scene, devices[i]); if (urc[i]) uerr[i] = kz_last_error(); });
+        for (auto &t : up) t.join();
+        for (uint32_t i = 0; i < nDevices; ++i) if (urc[i]) return kz_fail(urc[i], "device %d: %s", devices[i], uerr[i].c_str());
+    }
     const bool dynamic = opts && opts->tileDealing == 1;
     // (packed: new float[n] leaves the buffer uninitialised - a std::vector would zero 150 MB at C5 just to have the download overwrite them)
     struct Job { std::vector<KzTile> tiles; std::unique_ptr<float[]> packed; size_t nPacked = 0; int rc = KZ_OK; std::string err; float ms = 0.f; };

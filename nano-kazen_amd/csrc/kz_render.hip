@@ -1,13 +1,12 @@
-// kz_render.hip — hand-written HIP kernels (gfx950 / CDNA4) and their launch code for the path_mis hot path:
-//   primary-ray generation -> BVH2 traversal with Moeller-Trumbore leaf tests -> post-intersection ->
-//   kiss/diffuse BSDF eval+sample -> MIS NEE with the invisible-light walk-through -> Russian roulette
-//   -> per-sample radiance -> deterministic film reconstruction (ImageBlock::put semantics).
+// kz_render.hip - the device side of kz_render / kz_render_tiles for the path_mis hot path: replicas and their upload, the launch code of a pass (wfPass: the
+// wavefront pipeline of kz_wavefront.h - camera rays by pixel beams, persistent BVH4 traversal with Moeller-Trumbore leaf tests, post-intersection, BSDF
+// eval + sample, MIS next-event estimation with the invisible-light walk-through, Russian roulette - and the reference-shaped megakernel below), and renderOn:
+// plan (kz_plan.cpp) -> make room (kz_arena.cpp) -> launch -> film (kz_film.hip).
 // Reference region replaced: src/kazen/renderer.cpp:85-133 and everything it calls.
 //
-// Execution model (wave64): one lane = one (pixel, sample) path; items are ordered pixel-major so the lanes
-// of a wave share a pixel neighbourhood (coherent primary rays, shared top-of-tree node packets in L1/L2).
-// Per-lane traversal stacks live in LDS ([depth][lane] -> conflict-free columns). No MFMA: this is branchy
-// pointer chasing bound by HBM/L2 latency and bandwidth, not a contraction.
+// Execution model (wave64): one lane = one (pixel, sample) path; items are ordered pixel-major so the lanes of a wave share a pixel neighbourhood (coherent
+// camera rays, shared top-of-tree node packets in L1 / L2). Per-lane traversal stacks live in LDS ([entry][lane]: conflict-free columns). No MFMA: this is
+// branchy pointer chasing, bound by VALU issue and the CU's L1 gather rate, not a contraction.
 #include <hip/hip_runtime.h>
 
 #include "kz_internal.h"
