@@ -227,6 +227,7 @@ int kz_trace_rays(KzScene *scene, uint32_t n, const float *o, const float *d, co
     if ((rc = requireDevice(scene, &ds))) return rc;
     if (n == 0) return KZ_OK;
     if (!o || !d || !tmin || !tmax || !hits) return kz_fail(KZ_ERR_INVALID_ARG, "null ray buffer");
+    if ((rc = kzEnsureBvh2(scene, ds))) return rc;
     DevMem dO, dD, dA, dB, dH;
     KZ_ALLOC(&dO.p, (size_t)n * 12); KZ_ALLOC(&dD.p, (size_t)n * 12); KZ_ALLOC(&dA.p, (size_t)n * 4); KZ_ALLOC(&dB.p, (size_t)n * 4);
     KZ_ALLOC(&dH.p, (size_t)n * sizeof(KzHit));

@@ -177,8 +177,9 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     int rc;
     KZ_TRACE("upload: start (%.1f MB of tables)", (scene->nodes.size() * sizeof(scene->nodes[0]) + scene->nodes4.size() * sizeof(scene->nodes4[0]) + scene->tris.size() * sizeof(scene->tris[0]) + scene->shade.size() * sizeof(scene->shade[0])) / 1e6);
     // The four large tables (C4: 248 MB; their allocations first, in this thread, so that a failure is this call's) travel side by side: a pageable copy is
-    // a chain of host memcpys into the runtime's pinned staging buffers and DMA transfers out of them, one chain per calling thread - four threads in
-    // flight took the upload of C4 from 45 to 36 ms (profiles/r05d_cold_job; the FIRST process on a freshly leased box spends 170 ms here either way: the
+    // a chain of host memcpys into the runtime's pinned staging buffers and DMA transfers out of them, one chain per calling thread - one thread per table in
+    // flight took the upload of C4 from 45 to 36 ms (profiles/r05d_cold_job; finer pieces over eight threads change nothing - round 6: ~32 ms of an upload are
+    // fixed costs of a process's first allocations, the 8 MB scene of the reference's own file takes as long -; the FIRST process on a freshly leased box spends 170 ms here either way: the
     // first transfers of a box wake something up that no later process pays for)
     {
         struct Job { const void *src; void *dst; size_t bytes; hipError_t err; };
@@ -195,7 +196,10 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
             j = Job{vec.empty() ? nullptr : (const void *)vec.data(), p, bytes, hipSuccess};
             return KZ_OK;
         };
-        if ((rc = prep(scene->nodes, &ds->T.nodes, jobs[0]))) return rc;
+        // (the BVH2 - C4: 62 MB of the 248 - serves the reference-shaped megakernel, kz_trace_rays and kz_render_samples only: it goes up on the first of those
+        //  calls, kzEnsureBvh2; a one-frame job through the wavefront pipeline never pays for it)
+        static const std::vector<KzNode> noNodes;
+        if ((rc = prep(noNodes, &ds->T.nodes, jobs[0]))) return rc;
         if ((rc = prep(scene->nodes4, &ds->T.nodes4, jobs[1]))) return rc;
         if ((rc = prep(scene->tris, &ds->T.tris, jobs[2]))) return rc;
         if ((rc = prep(scene->shade, &ds->T.shade, jobs[3]))) return rc;
@@ -234,6 +238,19 @@ static int uploadReplica(KzScene *scene, KzDeviceState *ds) {
     KZ_TRACE("upload: film + counters there");
     HIP_TRY(hipDeviceSynchronize());
     KZ_TRACE("upload: done");
+    return KZ_OK;
+}
+
+// The BVH2 table of a replica, on first use (see uploadReplica). The caller has made the replica's device current.
+int kzEnsureBvh2(KzScene *scene, KzDeviceState *ds) {
+    if (ds->bvh2Resident || scene->nodes.empty()) return KZ_OK;
+    void *p = nullptr;
+    const size_t bytes = scene->nodes.size() * sizeof(KzNode);
+    KZ_ALLOC(&p, bytes);
+    ds->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, scene->nodes.data(), bytes, hipMemcpyHostToDevice));      // (blocking, behind everything queued on the device: a rare call)
+    ds->T.nodes = (const KzNode *)p;
+    ds->bvh2Resident = true;
     return KZ_OK;
 }
 
@@ -779,6 +796,11 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     if (opts->passesInFlight < 0 || opts->passesInFlight > KZ_MAX_PASSES_IN_FLIGHT)
         return kz_fail(KZ_ERR_INVALID_ARG, "passesInFlight %d (0 = default, 1 .. %d)", opts->passesInFlight, KZ_MAX_PASSES_IN_FLIGHT);
     const int pipeline = opts->pipeline ? opts->pipeline : 2;
+#ifdef KZ_EXPERIMENTS
+    if ((rc = kzEnsureBvh2(scene, ds))) return rc;          // (development builds: several experiment kernels walk the BVH2)
+#else
+    if (pipeline == 1 && (rc = kzEnsureBvh2(scene, ds))) return rc;
+#endif
     uint32_t s0 = opts->sampleBegin, s1 = opts->sampleEnd;
     if (s0 == 0 && s1 == 0) s1 = P.sampleCount;
     if (s0 >= s1 || s1 > P.sampleCount) return kz_fail(KZ_ERR_INVALID_ARG, "sample range [%u,%u) outside [0,%u)", s0, s1, P.sampleCount);
@@ -1123,6 +1145,7 @@ int kz_render_samples(KzScene *scene, uint32_t n, const int32_t *pxy, const uint
     if ((rc = requireDevice(scene, &ds))) return rc;
     if (n == 0) return KZ_OK;
     if (!pxy || !idx || !out) return kz_fail(KZ_ERR_INVALID_ARG, "null buffer");
+    if ((rc = kzEnsureBvh2(scene, ds))) return rc;
     const KzParams &P = scene->prm;
     std::vector<uint32_t> pl(n);
     for (uint32_t i = 0; i < n; ++i) {

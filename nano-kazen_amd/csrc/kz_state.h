@@ -169,6 +169,7 @@ struct KzDeviceState {
     int hipDevice = -1;                                          // the HIP device it lives on (the same number, unless a development build aliases devices: kz_debug_alias_devices)
     KzDevTables T{};
     std::vector<void *> allocs;
+    bool bvh2Resident = false;                                   // T.nodes holds the BVH2 (uploaded on first use: kzEnsureBvh2)
     float4 *film = nullptr; size_t filmPixels = 0;
     float4 *tapSums = nullptr; size_t tapSumsBytes = 0;          // the running tap sums of every pixel of the frame, [tap][y * width + x] (kz_film.hip): what the film is resolved from
     uint8_t *srgb = nullptr;                                     // staging raster of kz_film_to_srgb8 (allocated on first use)
@@ -201,6 +202,7 @@ struct KzReplicaSet { std::mutex m; std::vector<KzDeviceState *> v; };
 
 static inline KzReplicaSet *replicaSet(const KzScene *scene) { return (KzReplicaSet *)scene->dev; }
 int findReplica(const KzScene *scene, int device, KzDeviceState **out);                                   // kz_render.hip
+int kzEnsureBvh2(KzScene *scene, KzDeviceState *ds);                                                      // kz_render.hip: the BVH2 table, on first use
 static inline int requireDevice(KzScene *scene, KzDeviceState **out) { return findReplica(scene, -1, out); }
 // kz_film.hip
 size_t packedFloats(const KzParams &P, const KzTile *tiles, uint32_t nTiles);
