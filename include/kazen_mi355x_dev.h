@@ -112,10 +112,12 @@ int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
 int kz_last_grow_note(KzScene *scene, char *buf, size_t cap);
 
 /* ---- DEVELOPMENT BUILDS ONLY (a library compiled with -DKZ_EXPERIMENTS: kz_build_flags() & KZ_BUILD_EXPERIMENTS; nano-kazen_amd/csrc/variants/experiments).
- * These four are process-global state - the product library does not contain them (`nm -D libkazen_mi355x.so | grep kz_debug` is empty), so that nothing behind the
+ * These five are process-global state - the product library does not contain them (`nm -D libkazen_mi355x.so | grep kz_debug` is empty), so that nothing behind the
  * product ABI depends on state outside the objects the caller holds. The tests that need them load the development variant.
  *   kz_debug_fail_alloc    the nth device allocation made from now on by the calling thread fails with KZ_ERR_OOM (0 = off): a failure in the middle of a call
  *                          releases what the call had allocated.
+ *   kz_debug_fail_device   the same countdown for whichever thread addresses the replica on (logical) `device` next: fails an allocation inside ONE device thread of
+ *                          kz_render_multi (a caller's thread-local countdown does not reach those threads).
  *   kz_debug_grow_delay    the thread that maps a pass context's memory (kz_arena.cpp) sleeps `ms` milliseconds before every level (0 = off): "the context is
  *                          still growing while the first passes of a job run" - what happens behind the driver's wipe of recently released memory - on demand.
  *   kz_debug_trace         a timeline of the allocation, growth and pass-planning events of this process on stderr (0 = off).
@@ -124,6 +126,7 @@ int kz_last_grow_note(KzScene *scene, char *buf, size_t cap);
  *                          kz_render_multi's one-host-thread-per-device driver runs with n threads on a box with ONE GPU (tests/test_gpu_multi.py). 0 = off.
  *                          Call it before the first kz_scene_upload; give every replica an explicit maxStateBytes (the aliases share one card). */
 void kz_debug_fail_alloc(int nth);
+void kz_debug_fail_device(int device, int nth);
 void kz_debug_grow_delay(int ms);
 void kz_debug_trace(int on);
 void kz_debug_alias_devices(int n);

@@ -172,7 +172,7 @@ EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene
            "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_film_merge_rects", "kz_device_trim", "kz_kat_dpdf", "kz_kat_pow4", "kz_last_grow_note",
            "kz_plan_passes", "kz_plan_schedule"]
 # exported by DEVELOPMENT builds of the library only (-DKZ_EXPERIMENTS): the hooks that are process-global state. The product library must NOT export them.
-DEV_ONLY_EXPORTS = ["kz_debug_fail_alloc", "kz_debug_grow_delay", "kz_debug_trace", "kz_debug_alias_devices"]
+DEV_ONLY_EXPORTS = ["kz_debug_fail_alloc", "kz_debug_fail_device", "kz_debug_grow_delay", "kz_debug_trace", "kz_debug_alias_devices"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KZ_LIB_PATH: a development build of the library (scripts/build_variant.sh) instead of the in-tree one; probes only
@@ -247,7 +247,7 @@ def load_library(path=None):
     lib.kz_last_grow_note.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     for hook in DEV_ONLY_EXPORTS:                 # development builds only
         if hasattr(lib, hook):
-            getattr(lib, hook).argtypes = [C.c_int]
+            getattr(lib, hook).argtypes = [C.c_int, C.c_int] if hook == "kz_debug_fail_device" else [C.c_int]
             getattr(lib, hook).restype = None
     if hasattr(lib, "kz_plan_passes"):
         lib.kz_plan_passes.argtypes = [C.POINTER(KzPlanQuery), C.POINTER(KzPlanAnswer)]

@@ -75,6 +75,9 @@ __global__ __launch_bounds__(KZ_BLOCK) void kz_path_megakernel(KzParams P, KzDev
 // last one's path state is still mapped. (Development builds: kz_debug_fail_alloc makes the nth allocation of the calling thread fail.)
 #ifdef KZ_EXPERIMENTS
 static thread_local int g_failAlloc = 0;
+// kz_debug_fail_device: a countdown per (logical) device, handed to whichever thread addresses that device's replica next (findReplica) - so that a test can fail an
+// allocation inside ONE device thread of kz_render_multi, which no caller's thread-local countdown reaches
+static std::atomic<int> g_failDevice[64];
 #endif
 hipError_t kzMalloc(void **p, size_t bytes) {
     *p = nullptr;
@@ -168,6 +171,9 @@ int findReplica(const KzScene *scene, int device, KzDeviceState **out) {
     }
     hipError_t e = hipSetDevice(ds->hipDevice);
     if (e != hipSuccess) return kz_fail(KZ_ERR_HIP, "hipSetDevice(%d): %s", ds->hipDevice, hipGetErrorString(e));
+#ifdef KZ_EXPERIMENTS
+    { const int n = g_failDevice[ds->device & 63].exchange(0); if (n > 0) g_failAlloc = n; }
+#endif
     *out = ds;
     return KZ_OK;
 }
@@ -258,6 +264,7 @@ extern "C" {
 
 #ifdef KZ_EXPERIMENTS
 void kz_debug_fail_alloc(int nth) { g_failAlloc = nth > 0 ? nth : 0; }
+void kz_debug_fail_device(int device, int nth) { g_failDevice[device & 63].store(nth > 0 ? nth : 0); }
 #endif
 
 int kz_device_count(void) { return kzLogicalDeviceCount(); }

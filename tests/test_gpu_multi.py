@@ -106,6 +106,28 @@ def test_dealer_batches_partition_the_list_across_threads(aliased, kz):
     sc.close()
 
 
+def test_one_failing_device_thread_fails_the_call(aliased, kz):
+    """A device allocation fails inside ONE of the four device threads of kz_render_multi (kz_debug_fail_device: the countdown is handed to the thread that addresses
+    that replica) while the other three render: the call returns that device's KZ_ERR_OOM with its message, nobody hangs, and the next call renders the reference film."""
+    desc = kz.scenes.cornell_box(256, 192, 16, sampler="pmj02bn")
+    ref = kz.Scene(desc, lib=aliased)
+    good, _ = ref.render_multi([0], max_state_bytes=_budget(aliased, 4))
+    ref.close()
+    for dealing in (0, 1):
+        for nth in (1, 2, 4):                                            # the tile set's pixel list, ..., a later allocation of the first render on a fresh replica
+            sc = kz.Scene(desc, lib=aliased)
+            aliased.kz_debug_fail_device(2, nth)
+            try:
+                with pytest.raises(kz.abi.KzError) as e:
+                    sc.render_multi([0, 1, 2, 3], tile_dealing=dealing, max_state_bytes=_budget(aliased, 4))
+            finally:
+                aliased.kz_debug_fail_device(2, 0)
+            assert e.value.code == kz.abi.KZ_ERR_OOM and "device 2" in str(e.value), (dealing, nth, str(e.value))
+            again, ms = sc.render_multi([0, 1, 2, 3], tile_dealing=dealing, max_state_bytes=_budget(aliased, 4))
+            assert np.array_equal(again, good) and (ms > 0).all(), (dealing, nth)
+            sc.close()
+
+
 def test_a_failing_replica_fails_the_call_without_hanging_the_others(aliased, kz):
     """kz_debug_fail_alloc is per calling thread, so a failure is injected into ONE device's thread through its budget instead: a replica whose state cap cannot
     hold 64 items fails (KZ_ERR_OOM) while the other threads render; the call returns that device's error, the next call is whole again."""
