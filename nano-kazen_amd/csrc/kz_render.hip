@@ -812,6 +812,9 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     if (s0 == 0 && s1 == 0) s1 = P.sampleCount;
     if (s0 >= s1 || s1 > P.sampleCount) return kz_fail(KZ_ERR_INVALID_ARG, "sample range [%u,%u) outside [0,%u)", s0, s1, P.sampleCount);
     hipStream_t stream = (hipStream_t)opts->stream;
+    // a call is ordered behind the previous call on this replica WHATEVER stream that one was given: it clears or extends the tap sums the previous call's last
+    // kernels read (a caller that alternates streams used to be ordered only when the tile set changed)
+    if (ds->evCallB && stream != ds->lastStream) HIP_TRY(hipStreamWaitEvent(stream, ds->evCallB, 0));
     ds->lastStream = stream;
     KzTune tune;
     if ((rc = resolveTune(opts->tune, tune))) return rc;

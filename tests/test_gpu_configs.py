@@ -619,3 +619,23 @@ def test_every_filter_width_runs_on_the_tap_sums(gpu_lib, kz, O, radius, taps):
     tiles = kz.shard.deal_tiles(100, 72, 1, 0, 64)
     assert np.array_equal(sc.merge_tiles(sc.empty_film(), tiles, sc.film_tiles(tiles)), film)
     sc.close()
+
+
+def test_calls_on_alternating_caller_streams_are_ordered(gpu_lib, kz):
+    """kz_render is asynchronous on the caller's stream. A caller that alternates between two streams without synchronising still gets calls on ONE replica in call
+    order (each call clears or extends the running tap sums the previous call's last kernels read): the frame in four accumulated slices, streams alternating, equals the
+    one-shot film bit for bit - repeatedly."""
+    hip = C.CDLL("libamdhip64.so")                                      # (the runtime the library itself is linked against: two plain HIP streams)
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(s1)) == 0 and hip.hipStreamCreate(C.byref(s2)) == 0
+    desc = kz.scenes.cornell_box(320, 200, 32, sampler="pmj02bn")
+    sc = kz.Scene(desc, device=0)
+    sc.render()
+    whole = sc.film()
+    for _ in range(3):
+        for k in range(4):
+            sc.render(8 * k, 8 * k + 8, accumulate=k > 0, stream=(s1 if k % 2 == 0 else s2))
+        sc.sync()
+        assert np.array_equal(sc.film(), whole)
+    sc.close()
+    hip.hipStreamDestroy(s1); hip.hipStreamDestroy(s2)
