@@ -1882,6 +1882,101 @@ int kzo_render(void *s, uint32_t s0, uint32_t s1, const KzTile *tiles, uint32_t 
     return KZ_OK;
 }
 
+// The same render with the film's float additions in the order the HIP build FIXES (the reference's own order depends on its thread timing, so any fixed
+// order is a legitimate one): per pixel and filter tap the weighted samples are added in sample order - ImageBlock::put's weights and products, block.cpp:64-84,
+// with positions relative to the reference's 32 x 32 block - and a film texel is the sum, over the cells of a `grid`-pixel tile grid in row-major order, of each cell's
+// partial sum (taps in (row, column) order: ImageBlock::put(ImageBlock&) of the grid's blocks in tile order, block.cpp:87-96). With this order the HIP film and the
+// oracle's are the same BITS, not merely close (tests/test_gpu_parity.py::test_whole_films_equal_the_oracle_bit_for_bit). `film` is overwritten.
+int kzo_render_canonical(void *s, uint32_t s0, uint32_t s1, const KzTile *tiles, uint32_t nTiles, int threads, int grid, float *film) {
+    Scene *scp = (Scene *)s; if (!scp || !film || grid <= 0) return fail(KZ_ERR_INVALID_ARG, "null");
+    Scene &sc = *scp;
+    if (s0 == 0 && s1 == 0) s1 = sc.sampleCount;
+    const int W = sc.cam.width, H = sc.cam.height, B = sc.border;
+    const int cols = W + 2 * B, rows = H + 2 * B;
+    const float r = sc.filterRadius, lf = sc.lookupFactor;
+    const int tapLo = (int)std::floor(-r - 0.5f) + 1, tapHi = (int)std::floor(r + 0.5f), taps = tapHi - tapLo + 1;
+    if (taps < 1 || taps > 9) return fail(KZ_ERR_UNSUPPORTED, "filter taps");
+    const size_t framePix = (size_t)W * H;
+    std::vector<float> tapSums((size_t)taps * taps * framePix * 4, 0.f);           // [tap][y * W + x][rgb w, w]
+    struct Blk { int x0, y0, w, h; };
+    std::vector<Blk> blocks;
+    KzTile whole = {0, 0, W, H};
+    if (!tiles) { tiles = &whole; nTiles = 1; }
+    const int BS = 32;
+    for (uint32_t t = 0; t < nTiles; ++t) {
+        KzTile tl = tiles[t];
+        if (tl.x0 < 0 || tl.y0 < 0 || tl.x0 + tl.w > W || tl.y0 + tl.h > H) return fail(KZ_ERR_INVALID_ARG, "tile out of image");
+        for (int by = tl.y0; by < tl.y0 + tl.h; by += BS)
+            for (int bx = tl.x0; bx < tl.x0 + tl.w; bx += BS)
+                blocks.push_back(Blk{bx, by, std::min(BS, tl.x0 + tl.w - bx), std::min(BS, tl.y0 + tl.h - by)});
+    }
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    threads = std::max(1, std::min(threads, (int)blocks.size()));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);          // main.cpp:22-23 (H11)
+        _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+        Sampler sampler; sampler.sc = &sc; sampler.type = sc.smp.type;
+        LocalStats ls;
+        std::vector<float> acc((size_t)taps * taps * 4);
+        for (;;) {
+            size_t bi = next.fetch_add(1);
+            if (bi >= blocks.size()) break;
+            const Blk &bk = blocks[bi];
+            for (int i = 0; i < bk.w * bk.h; ++i) {
+                const int px = i % bk.w + bk.x0, py = i / bk.w + bk.y0;
+                const int bx0 = px & ~31, by0 = py & ~31;                       // the reference block this pixel is rendered in (KAZEN_BLOCK_SIZE)
+                std::fill(acc.begin(), acc.end(), 0.f);
+                for (uint32_t j = s0; j < s1; ++j) {
+                    float sx, sy;
+                    const V3 value = renderSample(sc, sampler, px, py, j, sx, sy, ls);
+                    if (!colorValid(value)) { ls.dropped++; continue; }
+                    const float posx = sx - 0.5f - (float)(bx0 - B), posy = sy - 0.5f - (float)(by0 - B);                     // block.cpp:64-67
+                    const float lox = std::ceil(posx - r), hix = std::floor(posx + r), loy = std::ceil(posy - r), hiy = std::floor(posy + r);   // block.cpp:70-73
+                    float wx[9], wy[9];
+                    for (int t = 0; t < taps; ++t) {                            // tap t reaches the (block-relative) film coordinate px + B - tapLo - t
+                        const float xb = (float)(px + B - tapLo - t - bx0), yb = (float)(py + B - tapLo - t - by0);
+                        wx[t] = !(xb < lox || xb > hix) ? sc.filter[(int)(std::fabs(xb - posx) * lf)] : 0.f;               // block.cpp:77-80
+                        wy[t] = !(yb < loy || yb > hiy) ? sc.filter[(int)(std::fabs(yb - posy) * lf)] : 0.f;
+                    }
+                    for (int ty = 0; ty < taps; ++ty)
+                        for (int tx = 0; tx < taps; ++tx) {
+                            float *a = &acc[(size_t)(ty * taps + tx) * 4];
+                            a[0] += value.x * wx[tx] * wy[ty]; a[1] += value.y * wx[tx] * wy[ty]; a[2] += value.z * wx[tx] * wy[ty]; a[3] += 1.0f * wx[tx] * wy[ty];   // block.cpp:84
+                        }
+                }
+                for (int k = 0; k < taps * taps; ++k) std::memcpy(&tapSums[((size_t)k * framePix + (size_t)py * W + px) * 4], &acc[(size_t)k * 4], 4 * sizeof(float));
+            }
+        }
+        mergeStats(sc, ls);
+    };
+    FtzScope ftz;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    // the resolve: texel = sum over grid cells (row-major) of the cell's partial sum, taps in (row, column) order
+    for (int fy = 0; fy < rows; ++fy)
+        for (int fx = 0; fx < cols; ++fx) {
+            const int x0s = fx - B + tapLo, y0s = fy - B + tapLo;                // the source pixel that reaches this texel through tap (0, 0)
+            const int xlo = std::max(x0s, 0), xhi = std::min(x0s + taps - 1, W - 1), ylo = std::max(y0s, 0), yhi = std::min(y0s + taps - 1, H - 1);
+            float total[4] = {0.f, 0.f, 0.f, 0.f};
+            if (xlo <= xhi && ylo <= yhi)
+                for (int tr = ylo / grid; tr <= yhi / grid; ++tr)
+                    for (int tc = xlo / grid; tc <= xhi / grid; ++tc) {
+                        float part[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int y = std::max(ylo, tr * grid); y <= std::min(yhi, tr * grid + grid - 1); ++y)
+                            for (int x = std::max(xlo, tc * grid); x <= std::min(xhi, tc * grid + grid - 1); ++x) {
+                                const float *t = &tapSums[((size_t)((y - y0s) * taps + (x - x0s)) * framePix + (size_t)y * W + x) * 4];
+                                part[0] += t[0]; part[1] += t[1]; part[2] += t[2]; part[3] += t[3];
+                            }
+                        total[0] += part[0]; total[1] += part[1]; total[2] += part[2]; total[3] += part[3];
+                    }
+            std::memcpy(&film[((size_t)fy * cols + fx) * 4], total, sizeof total);
+        }
+    return KZ_OK;
+}
+
 // ImageBlock::toBitmap (block.cpp:39-45) + Color4f::divideByFilterWeight (color.h:94-99)
 int kzo_film_to_rgb(const float *film, int w, int h, int b, float *rgb) { FtzScope ftz_;
     int cols = w + 2 * b;

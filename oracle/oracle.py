@@ -46,6 +46,7 @@ def lib():
         L.kzo_sample_count.restype = C.c_uint
         L.kzo_bvh_info.argtypes = [C.c_void_p, C.POINTER(abi.KzBvhInfo)]
         L.kzo_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.KzTile), C.c_uint32, C.c_int, abi.f32p]
+        L.kzo_render_canonical.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.KzTile), C.c_uint32, C.c_int, C.c_int, abi.f32p]
         L.kzo_film_to_rgb.argtypes = [abi.f32p, C.c_int, C.c_int, C.c_int, abi.f32p]
         L.kzo_get_stats.argtypes = [C.c_void_p, C.POINTER(abi.KzStats), C.c_int]
         L.kzo_trace_rays.argtypes = [C.c_void_p, C.c_uint32, abi.f32p, abi.f32p, abi.f32p, abi.f32p, C.POINTER(abi.KzHit)]
@@ -154,6 +155,19 @@ class OracleScene:
             tp = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
             nt = len(tiles)
         rc = self.L.kzo_render(self.h, sample_begin, sample_end, tp, nt, threads, _fp(film))
+        if rc != 0:
+            raise abi.KzError(rc, self.L.kzo_last_error().decode())
+        return film
+
+    def render_canonical(self, sample_begin=0, sample_end=0, tiles=None, threads=0, grid=64):
+        """The same samples with the film's float additions in the order the HIP build fixes (per pixel and tap in sample order, texels resolved over the 64-px tile grid in
+        tile order): the film the library must reproduce BIT FOR BIT."""
+        film = np.zeros((self.height + 2 * self.border, self.width + 2 * self.border, 4), np.float32)
+        tp, nt = None, 0
+        if tiles is not None:
+            tp = (abi.KzTile * len(tiles))(*[abi.KzTile(*t) for t in tiles])
+            nt = len(tiles)
+        rc = self.L.kzo_render_canonical(self.h, sample_begin, sample_end, tp, nt, threads, int(grid), _fp(film))
         if rc != 0:
             raise abi.KzError(rc, self.L.kzo_last_error().decode())
         return film

@@ -24,6 +24,7 @@ for seed in range(first, first + n):
     err = float(np.sqrt(np.mean((sc.rgb(film) - ora.rgb(fc)) ** 2)))
     scale = max(1.0, float(np.abs(ora.rgb(fc)).max()))
     ok = err < 1e-3 * scale and np.allclose(film[..., 3], fc[..., 3], rtol=1e-4, atol=1e-5)
+    bits = np.array_equal(film, ora.render_canonical(threads=0))           # round 6: the whole film in the build's fixed summation order (ties of the reference's shadow loop aside)
     note = ""
     if not ok and np.allclose(film[..., 3], fc[..., 3], rtol=1e-4, atol=1e-5):
         # the reference's shadow tie (tests/test_gpu_parity.py tie_bracket): inside the oracle's bracket is parity
@@ -48,7 +49,7 @@ for seed in range(first, first + n):
     t64 = kz.shard.deal_tiles(w, h, 1, 0, 64)
     sc.render()
     ok_rng = ok_rng and np.array_equal(sc.merge_tiles(sc.empty_film(), t64, sc.film_tiles(t64)), film)
-    line = "seed %d %s %dx%dx%d depth %d tris %d: L2 %.2e (scale %.1f) %s" % (seed, d.sampler["type"], w, h, sc.sample_count, d.integrator["maxDepth"], d.n_tris(), err, scale,
+    line = "seed %d %s %dx%dx%d depth %d tris %d: L2 %.2e (scale %.1f) film-bits %s %s" % (seed, d.sampler["type"], w, h, sc.sample_count, d.integrator["maxDepth"], d.n_tris(), err, scale, "equal" if bits else "DIFFER",
             ("ok" + note) if (ok and ok_mega and ok_stats and ok_deal and ok_rng) else "FAIL oracle=%s mega=%s stats=%s deal=%s ranges=%s%s" % (ok, ok_mega, ok_stats, ok_deal, ok_rng, note))
     print(line, flush=True)
     if "FAIL" in line:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: the new large-frame test, then the randomized parity sweeps on the final sources (progress lines keep the call alive)
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r06k_sweep; mkdir -p $OUT; cd $R
-timeout -k 10 600 python -m pytest tests/test_gpu_multi.py -m gpu -q -k "frame_of_more_pixels" 2>&1 | tail -15 || exit 1
+timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; RC=$?; tail -6 $OUT/tests.log; [ $RC -eq 0 ] || exit $RC
 timeout -k 10 900 python scripts/dev/fuzz_sweep.py ${1:-40000} ${2:-3000} --rich > $OUT/fuzz_sweep_rich.log 2>&1 &
 P=$!
 while kill -0 $P 2>/dev/null; do sleep 45; tail -1 $OUT/fuzz_sweep_rich.log | cut -c1-160; done

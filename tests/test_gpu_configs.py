@@ -41,6 +41,7 @@ def test_c2_full_spp_matches_oracle(gpu_lib, kz, O):
     cpu = ora.rgb(ora.render(threads=0))
     assert st["samples"] == 512 * 512 * 64 == ora.stats()["samples"] and st["droppedSamples"] == 0
     assert l2(sc.rgb(), cpu) < L2_TOL
+    assert np.array_equal(sc.film(), ora.render_canonical(threads=0))          # round 6: the WHOLE film of BASELINE configs[1] at its full size, bit for bit
 
 
 def test_c3_full_size_properties_and_crop(gpu_lib, kz, O):
@@ -77,6 +78,7 @@ def test_c3_full_size_properties_and_crop(gpu_lib, kz, O):
         rc, wc = _crop_rgb(film_c, x0, y0, 48, 48, b)
         assert np.allclose(wg, wc, rtol=1e-5, atol=1e-5)
         assert l2(rg, rc) < L2_TOL, (x0, y0)
+        assert np.array_equal(sc.film(), ora.render_canonical(tiles=tile, threads=0)), (x0, y0)      # ... and in the build's fixed summation order: the same bits
 
 
 def test_c5_workload_as_eight_tile_shares(gpu_lib, kz, O):
@@ -149,6 +151,7 @@ def test_c5_workload_as_eight_tile_shares(gpu_lib, kz, O):
     rc, wc = _crop_rgb(film_c, x0, y0, 64, 64, b)
     assert np.allclose(wg, wc, rtol=1e-5, atol=1e-6)
     assert l2(rg, rc) < L2_TOL
+    assert np.array_equal(sc.film(), ora.render_canonical(100, 104, tiles=[(x0, y0, 64, 64)], threads=0))
 
 
 def test_render_multi_equals_single_device(gpu_lib, kz, O):
@@ -528,6 +531,7 @@ def test_c4_at_the_benched_pass_size(gpu_lib, kz, O):
     cpu = ora.render(0, 512, tiles=[(x0, y0, 64, 64)], threads=0)
     tile = kz.Scene(desc, device=0)
     tile.render(0, 512, tiles=[(x0, y0, 64, 64)])
+    assert np.array_equal(tile.film(), ora.render_canonical(0, 512, tiles=[(x0, y0, 64, 64)], threads=0))      # 2 M samples of C4 at the benched sample range: the crop's film, bit for bit
     g_rgb, g_w = _crop_rgb(tile.film(), x0, y0, 64, 64, b)
     c_rgb, c_w = _crop_rgb(cpu, x0, y0, 64, 64, b)
     inner = (slice(b + 2, -b - 2), slice(b + 2, -b - 2))

@@ -799,6 +799,7 @@ def test_reference_asset_scene_through_the_hip_path(gpu_lib, kz, O):
     gpu = sc.rgb()
     assert gpu.mean() > 0.05
     assert float(np.sqrt(np.mean((gpu - cpu) ** 2))) < 1e-3
+    assert np.array_equal(sc.film(), ora.render_canonical(threads=0))     # BASELINE configs[0] (C1) - the reference's own asset at 256 x 256 x 16 -: the whole film, bit for bit
     sc.render(pipeline=1)                                                 # the reference-shaped megakernel: the same film bit for bit
     assert np.array_equal(sc.rgb(), gpu)
     # closest hits of 20 000 rays around the object against the brute-force Moeller-Trumbore search over all 36 378 triangles
@@ -835,3 +836,43 @@ def test_fresnel_on_the_device_matches_the_reference_text(gpu_lib, kz):
     out = np.zeros((len(rows), 2), np.float32)
     kz.abi.check(gpu_lib, gpu_lib.kz_kat_fresnel(0, len(rows), 1, f(c), f(e), None, f(out)))
     assert np.array_equal(out[:, 0].view(np.uint32), rows[:, 2]) and np.array_equal(out[:, 1].view(np.uint32), rows[:, 3])
+
+
+# ---------------------------------------------------------------- round 6: whole FILMS equal to the oracle's, bit for bit
+def _film_cases(S):
+    return {
+        "cornell_pmj": lambda: S.cornell_box(96, 72, 16, sampler="pmj02bn"),
+        "cornell_independent_ragged": lambda: S.cornell_box(77, 45, 9),
+        "hero_kiss": lambda: S.hero_scene(160, 96, 8, detail=0.4),
+        "materials": lambda: S.materials_scene(160, 96, 8),
+        "textured": lambda: S.textured_scene(128, 80, 8),
+        "sphere_env": lambda: S.sphere_env(96, 96, 8),
+        "random_triangles_pmj": lambda: S.random_triangles(20000, 192, 108, 16, sampler="pmj02bn", seed=1),
+    }
+
+
+@pytest.mark.parametrize("name", ["cornell_pmj", "cornell_independent_ragged", "hero_kiss", "materials", "textured", "sphere_env", "random_triangles_pmj"])
+def test_whole_films_equal_the_oracle_bit_for_bit(gpu_lib, kz, O, name):
+    """Every sample's radiance has been the oracle's to the last bit since round 4, and the filter weights are ImageBlock::put's by construction; what kept the FILMS apart
+    was the order of the float additions (H10: the reference's own depends on its thread timing). Round 6 fixes that order on the device - per pixel and tap in sample order,
+    texels resolved over the 64-px tile grid in tile order - and the oracle states the same order (kzo_render_canonical): the whole film, weights channel and apron included,
+    is now EQUAL - for the default gaussian, a tent and a 7-tap gaussian, under another pass schedule, and for a tile set."""
+    desc = _film_cases(kz.scenes)[name]()
+    ora = O.OracleScene(desc)
+    want = ora.render_canonical(threads=0)
+    sc = kz.Scene(desc, device=0)
+    sc.render()
+    assert np.array_equal(sc.film(), want)
+    sc.render(pass_items=4096, passes_in_flight=3)
+    assert np.array_equal(sc.film(), want)
+    w, h = desc.camera["width"], desc.camera["height"]
+    tiles = [(0, 0, min(64, w), min(40, h)), (min(64, w), 8, w - min(64, w), h - 8)] if w > 64 else [(0, 0, w, h // 2)]
+    sc.render(tiles=tiles)
+    assert np.array_equal(sc.film(), ora.render_canonical(tiles=tiles, threads=0))
+    sc.close()
+    for filt in ({"type": "tent"}, {"type": "gaussian", "radius": 3.0, "stddev": 0.8}):
+        desc.camera["rfilter"] = filt
+        s2 = kz.Scene(desc, device=0)
+        s2.render()
+        assert np.array_equal(s2.film(), O.OracleScene(desc).render_canonical(threads=0)), filt
+        s2.close()
