@@ -545,3 +545,25 @@ def test_no_reference_text_under_the_repository():
             for f in files:
                 if f.endswith((".cpp", ".h", ".hip", ".py")) and not f.startswith("kat_ref_"):
                     assert "NAMESPACE_BEGIN(" not in open(os.path.join(d, f), errors="ignore").read(), os.path.join(d, f)
+
+
+def test_canonical_film_order_of_the_oracle(kz, O):
+    """kzo_render_canonical: the same samples and weights as kzo_render (the reference-shaped blocks merged in block order), the float additions in the order the HIP build
+    fixes - per pixel and filter tap in sample order, texels resolved over the 64-px tile grid in tile order (SURVEY H10 leaves the order to the build). The two orders agree
+    to rounding; the canonical one does not depend on the number of threads, a tile subset leaves the other pixels' contributions out, and a sample range split in two is NOT
+    the same bits when added on the host (which is why the device keeps running sums)."""
+    desc = kz.scenes.cornell_box(80, 56, 6, sampler="pmj02bn")
+    desc.camera["rfilter"] = {"type": "gaussian", "radius": 2.0, "stddev": 0.5}
+    ora = O.OracleScene(desc)
+    blocks = ora.render(threads=0)
+    canon = ora.render_canonical(threads=0)
+    assert np.allclose(canon, blocks, rtol=2e-6, atol=1e-6) and abs(float(canon[..., 3].sum()) - float(blocks[..., 3].sum())) < 1e-2
+    assert np.array_equal(canon, ora.render_canonical(threads=1)) and np.array_equal(canon, ora.render_canonical(threads=3))
+    tiles = [(0, 0, 64, 56)]
+    part = ora.render_canonical(tiles=tiles, threads=0)
+    b = ora.border
+    assert (part[:, 64 + 2 * b:, 3] == 0).all() and np.array_equal(part[:, :64 - 2 * b], canon[:, :64 - 2 * b])       # texels only the tile's pixels reach: the same sums
+    halves = ora.render_canonical(0, 3, threads=0) + ora.render_canonical(3, 6, threads=0)
+    assert np.allclose(halves, canon, rtol=2e-6, atol=1e-6)
+    other = ora.render_canonical(threads=0, grid=32)                                 # another grid: another grouping where cells meet, the same film to rounding
+    assert np.allclose(other, canon, rtol=2e-6, atol=1e-6)
