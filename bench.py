@@ -417,7 +417,7 @@ def main():
         scene.set_stats(False)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(desc, args.cpu_seconds, Wd, Hd)
+            cpu = cpu_baseline(desc, args.cpu_seconds, Wd, Hd, scene)
         bps_gpu_ref = algorithmic_bytes_per_sample(st_ref)
         bps = cpu["bytes_per_sample_oracle"] if cpu else bps_gpu_ref          # SURVEY 8d takes the counts from the CPU oracle
         bps_exec = algorithmic_bytes_per_sample(st_exec)
@@ -713,7 +713,7 @@ def strong_c5(kz, rank, world, device_index, tris, kw, spp=256):
     return out
 
 
-def cpu_baseline(desc, target_seconds, Wd, Hd):
+def cpu_baseline(desc, target_seconds, Wd, Hd, scene=None):
     """The oracle (kind "port": the reference binary cannot be built here) timed on the host cores on a
     bounded sample of the SAME workload: a centre crop of the frame at the first sample indices."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -740,9 +740,20 @@ def cpu_baseline(desc, target_seconds, Wd, Hd):
     tile = (cx - tw // 2, cy - th // 2, tw, th)
     ora.stats(reset=True)
     t0 = time.time()
-    ora.render(0, spp, tiles=[tile], threads=threads)
+    cpu_film = ora.render(0, spp, tiles=[tile], threads=threads)
     dt = time.time() - t0
     st = ora.stats()
+    parity = None
+    if scene is not None:
+        # the SAME sample on the device, against the film the oracle has just been timed on (north_star: per-pixel L2 of normalised linear rgb < 1e-3): the oracle as the
+        # checker, after every clock has stopped. (Its reference-shaped film adds in block order; in the build's own order the films are equal bit for bit: tests/)
+        import numpy as np
+        scene.render(0, spp, tiles=[tile])
+        g, c = scene.rgb(scene.film()), ora.rgb(cpu_film)
+        x0, y0 = tile[0], tile[1]
+        g, c = g[y0:y0 + th, x0:x0 + tw], c[y0:y0 + th, x0:x0 + tw]
+        parity = {"l2_per_pixel_vs_cpu_oracle": float(np.sqrt(np.mean((g.astype(np.float64) - c.astype(np.float64)) ** 2))), "bar": 1e-3, "pixels": int(tw * th), "spp": spp,
+                  "max_abs": float(np.abs(g - c).max()), "image_mean": float(c.mean())}
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -754,7 +765,7 @@ def cpu_baseline(desc, target_seconds, Wd, Hd):
     return {"value": round(tw * th * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": "centre crop %dx%d px at sample indices [0,%d) of the same frame = %d samples in %.1f s "
                       "(oracle BVH build %.1f s excluded)" % (tw, th, spp, tw * th * spp, dt, build_s),
-            "cpu_model": model, "bytes_per_sample_oracle": round(algorithmic_bytes_per_sample(st), 1)}
+            "cpu_model": model, "bytes_per_sample_oracle": round(algorithmic_bytes_per_sample(st), 1), "parity": parity}
 
 
 if __name__ == "__main__":
