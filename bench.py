@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--cold-job", choices=["c4", "q1"], default=None, help="(child process mode) run ONE cold job and print its record")
     ap.add_argument("--no-cold-job", action="store_true", help="N = 1: skip the two one-frame-per-process jobs that ride in the same JSON line")
+    ap.add_argument("--shadow-beside", type=int, default=0, help="KzRenderOpts::shadowBeside of the timed steps (0 = library default, 1 = one stream, 2 = shadow rays beside the closest-hit rays: scripts/r06_beside_bench.sh)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity render (scripts/profile_bench.sh: the kernel statistics of a profiled run then hold the timed passes only)")
     ap.add_argument("--no-ext-scenes", action="store_true", help="N = 1: skip the EXT-kernel scenes and C1 / C2 / C3 at their BASELINE sizes (each beside the oracle's CPU time) that ride in the same JSON line")
     ap.add_argument("--profile-pass", action="store_true", help="(scripts/profile_bench.sh) every step asks for ONE pass of 2^30 items explicitly instead of earning it call by call: "
@@ -299,6 +300,8 @@ def main():
         spp_step = SPP_PER_RANK_STEP * world              # (<= the table: a step is ONE call)
     stream = torch.cuda.current_stream().cuda_stream
     kw = {}
+    if args.shadow_beside:
+        kw["shadow_beside"] = args.shadow_beside
     if shared_device:
         kw["max_state_bytes"] = int(0.8 * torch.cuda.mem_get_info(device_index)[1] / world)
     if args.profile_pass:
@@ -399,7 +402,7 @@ def main():
     if rank == 0:
         # ---- one pass run alone: per-stage device times (with two passes in flight the stage events of a pass overlap the other's)
         pass_spp = info["sppPerPass"]
-        scene.render(0, pass_spp, tiles=render_tiles, accumulate=True, stream=stream, **kw)
+        scene.render(0, pass_spp, tiles=render_tiles, accumulate=True, stream=stream, **dict(kw, shadow_beside=1))      # (one stream: the stage clock shows the shadow and the closest-hit kernels apart)
         scene.sync()
         stage_ms = scene.last_stage_ms()
         alone_ms = scene.last_kernel_ms()
@@ -612,9 +615,17 @@ def reference_scene(kz, device_index, spp):
     for _ in range(2):
         t0 = time.perf_counter(); sc.render(0, spp); sc.sync(); ts.append(time.perf_counter() - t0)
     n = sc.width * sc.height * spp
+    # the same slice with KzRenderOpts::shadowBeside = 2 (the shadow rays of a bounce beside its closest-hit rays): this scene's shadow rays are short-lived and its
+    # kernels do not fill the VALUs by themselves (profiles/r06v_shadow_beside) - the option a caller of such scenes sets; `value` stays the library default
+    film0 = sc.film()
+    tb = []
+    for _ in range(2):
+        t0 = time.perf_counter(); sc.render(0, spp, shadow_beside=2); sc.sync(); tb.append(time.perf_counter() - t0)
+    beside = {"value": round(n / min(tb) / 1e6, 1), "render_s": [round(t, 4) for t in tb], "film_equal": bool(np.array_equal(film0, sc.film())), "option": "KzRenderOpts::shadowBeside = 2"}
     rec = {"workload": "scene/2022_q1/parameters/default_m0_r0.5.xml (36 378 triangles, the reference's own scene file via tests/golden/q1_default_m0_r0.5.npz), %dx%d, independent sampler, "
                        "path_mis maxDepth %d, sample indices [0, %d) of the file's %d" % (sc.width, sc.height, d.integrator["maxDepth"], spp, sc.sample_count),
            "value": round(n / min(ts) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),
+           "shadow_beside": beside,
            "whole_job": "all 4096 spp: 4.4 s, 1 927 Msamples/s; against the published 4096-spp picture of this scene file: profiles/r04p_q1_full",
            "published_caption": {"job": "1920x1080, 4096 spp (another scene of the same studio set)", "seconds": 702, "Msamples_per_s": 12.1, "hardware": "unstated CPU",
                                  "source": "doc/2022_q1/2022_q1_report.md:226"}}

@@ -321,6 +321,13 @@ typedef struct KzRenderOpts {
                                    (kz_tiles_packed_floats). Never inferred from the buffer's size. */
     /* ---- ABI v5 ---- */
     const struct KzTileDealer *dealer;   /* kz_render_tiles: NULL = render every tile of the list; else take batches of it from the dealer's counter */
+    /* ---- ABI v6 ---- */
+    int32_t shadowBeside;       /* where the shadow rays of a bounce run: 1 = in front of the bounce's closest-hit rays (one stream), 2 = beside them (a side stream of the
+                                   pass context; the next shade waits for both), 0 = default: beside in passes of up to 2^26 items - a small job is a chain of launches each
+                                   as long as its slowest ray (BASELINE configs[0]: 2.47 -> 2.03 ms) - and in front otherwise: kernels that saturate the chip by themselves
+                                   lose ~1 % sharing it (C4), kernels that do not - short-lived shadow rays: the reference's scene/2022_q1 files - gain 7 - 12 % at any
+                                   size, so a caller who renders such scenes sets 2. The film is the same bits whatever this says. */
+    int32_t reserved0;
 } KzRenderOpts;
 #define KZ_MAX_PASSES_IN_FLIGHT 8
 #define KZ_DEFAULT_PASSES_IN_FLIGHT 2

@@ -98,13 +98,14 @@ int kz_get_stats(KzScene *scene, KzStats *out, int reset);
 int kz_last_kernel_ms(KzScene *scene, float *ms);
 /* Device time per stage of the last pass (wavefront pipeline): out6 = generate, closest-hit traversal of the bounce rays, shade, shadow
  * traversal, film, camera rays (beam lists / list kernel / packet kernel / first-hit walk-through) - the per-kernel sums a
- * rocprofv3 --kernel-trace of the same run shows. */
+ * rocprofv3 --kernel-trace of the same run shows. A pass whose shadow rays ran BESIDE its closest-hit rays (KzRenderOpts::shadowBeside; KzPassInfo::shadowBeside says
+ * whether the last pass did) shows the pair under the closest-hit traversal and ~0 under the shadow traversal: ask for shadowBeside = 1 to time them apart. */
 int kz_last_stage_ms(KzScene *scene, float *out6);
 
 /* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass (the TARGET: a pass context grows while the first passes
  * of a job already run - firstPassItems / largestPassItems say what the passes of this call really were), passes in flight, bytes of path state mapped. */
 typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes;
-                            uint32_t pixelsPerPass; uint32_t reserved; uint64_t firstPassItems; uint64_t largestPassItems;
+                            uint32_t pixelsPerPass; uint32_t shadowBeside /* the last pass ran its shadow rays beside its closest-hit rays (KzRenderOpts::shadowBeside) */; uint64_t firstPassItems; uint64_t largestPassItems;
                             uint64_t contextItems;      /* items the first pass context holds NOW (it may still be growing towards itemsPerPass) */
                           } KzPassInfo;
 int kz_last_pass_info(KzScene *scene, KzPassInfo *out);

@@ -112,12 +112,13 @@ class KzRenderOpts(C.Structure):
     _fields_ = [("sampleBegin", C.c_uint32), ("sampleEnd", C.c_uint32), ("tiles", C.POINTER(KzTile)),
                 ("nTiles", C.c_uint32), ("pipeline", C.c_int32), ("accumulate", C.c_int32), ("stream", C.c_void_p),
                 ("device", C.c_int32), ("passesInFlight", C.c_int32), ("passItems", C.c_uint64), ("maxStateBytes", C.c_uint64),
-                ("tune", KzTuning), ("tileDealing", C.c_int32), ("packedOutput", C.c_int32), ("dealer", C.POINTER(KzTileDealer))]
+                ("tune", KzTuning), ("tileDealing", C.c_int32), ("packedOutput", C.c_int32), ("dealer", C.POINTER(KzTileDealer)),
+                ("shadowBeside", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class KzPassInfo(C.Structure):
     _fields_ = [("passes", C.c_uint32), ("passesInFlight", C.c_uint32), ("itemsPerPass", C.c_uint64), ("sppPerPass", C.c_uint32),
-                ("pixels", C.c_uint32), ("stateBytes", C.c_uint64), ("pixelsPerPass", C.c_uint32), ("reserved", C.c_uint32),
+                ("pixels", C.c_uint32), ("stateBytes", C.c_uint64), ("pixelsPerPass", C.c_uint32), ("shadowBeside", C.c_uint32),
                 ("firstPassItems", C.c_uint64), ("largestPassItems", C.c_uint64), ("contextItems", C.c_uint64)]
 
     def as_dict(self):

@@ -629,7 +629,7 @@ static int ensureOverflow(KzScene *scene, KzDeviceState *ds, PassCtx &c, const K
     const KzParams &P = scene->prm;
     const int stackBound = std::max(tune.wide ? P.stackBound4 : P.stackDepth, 2);
     const int ldsStack = std::max(2, std::min(tune.ldsStack, stackBound));
-    const size_t stride = (size_t)(ds->numCU * tune.travBlocksPerCU) * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - ldsStack) * 2;      // (x 2: the key stack of kz_experiments.h)
+    const size_t stride = (size_t)(ds->numCU * tune.travBlocksPerCU) * KZ_BLOCK, needOvf = stride * (size_t)std::max(1, stackBound - ldsStack) * 3;      // (x 3: the key stack of kz_experiments.h; the shadow kernels of a small pass on the side stream, wfPass)
     if (needOvf > c.ovfCap) {
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.ovf) (void)hipFree(c.ovf);
@@ -640,9 +640,14 @@ static int ensureOverflow(KzScene *scene, KzDeviceState *ds, PassCtx &c, const K
     return KZ_OK;
 }
 
+// Passes of at most this many items put the shadow rays of a bounce beside its closest-hit rays by default (wfPass; KzRenderOpts::shadowBeside).
+#ifndef KZ_BESIDE_ITEMS
+#define KZ_BESIDE_ITEMS (1u << 26)
+#endif
+
 // One pass of the wavefront pipeline over `items` = nPixPass x Sp (pixel, sample) items: pixels pixList[0 .. nPixPass), sample indices
 // [sBegin, sBegin + Sp). Every launch goes to `stream`; queue counts stay on the device.
-static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune, bool beams) {
+static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t stream, const uint32_t *pixList, uint32_t p0, uint32_t nPixPass, uint32_t sBegin, uint32_t Sp, uint32_t items, KzTune tune, bool beams, int shadowBeside) {
     const KzParams &P = scene->prm;
     KzWf W = c.wf;
     W.outJx = c.plane[0]; W.outJy = c.plane[1]; W.outR = c.plane[2]; W.outG = c.plane[3]; W.outB = c.plane[4]; W.stats = ds->stats;
@@ -677,17 +682,20 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     if (int rc_ = X.prepare()) return rc_;
 #endif
     // mode 0 / 1 / 2 / 4 of kz_wf_trace on queue q (nullptr: identity) of *cptr (nullptr: cimm) entries
-    auto trace = [&](int mode, const uint32_t *q, const uint32_t *cptr, uint32_t cimm, uint32_t *head, uint32_t *qb, uint32_t *cb) {
+    const size_t ovfPart = (size_t)tune.ovfStride * (size_t)std::max(1, stackBound - tune.ldsStack);
+    auto trace = [&](int mode, const uint32_t *q, const uint32_t *cptr, uint32_t cimm, uint32_t *head, uint32_t *qb, uint32_t *cb, hipStream_t on = nullptr) {
 #ifdef KZ_EXPERIMENTS
         if (X.trace(mode, q, cptr, cimm, head, qb, cb)) return;
 #endif
         KzTune t = tune;
+        const bool side = on != nullptr;                 // (a launch beside the pass's own stream walks its own part of the overflow area)
+        if (side) t.ovf = tune.ovf + 2 * ovfPart; else on = stream;
         if (t.batch <= 0) t.batch = 128;                 // (the least a wave reserves per global atomic: kz_wf_trace asks for more while much is left)
         // idle lanes are refilled once fewer than this many are busy. A refill of the shadow kernel is the dearer one (the invisible-light test of every new
         // ray), so it waits for more idle lanes: same-call sweep, shadow stage 21.7 / 20.9 / 20.9 ms at 40 / 32 / 28 on C3, 20.3 / 20.0 / 20.3 on C4; the
         // closest-hit kernel 32.85 / 33.3 / 34.2 on C4
         if (t.refill <= 0) t.refill = (mode == 2 || mode == 4) ? 32 : 40;
-        hipLaunchKernelGGL(traceFn(mode, st), gTrav, blk, traceLds, stream, P, ds->T, W, q, cptr, cimm, head, t, qb, cb);
+        hipLaunchKernelGGL(traceFn(mode, st), gTrav, blk, traceLds, on, P, ds->T, W, q, cptr, cimm, head, t, qb, cb);
     };
     // camera rays: pixel beams + per-sample triangle tests (kz_wf_beam / kz_wf_trace_list), the wave-level packet traversal
     // (kz_wf_trace_packet) for what the beams cannot take, or the per-lane kernel on request
@@ -727,6 +735,22 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #endif
     const bool split = tune.shadeSplit != 0;
     const dim3 gClassify((unsigned)(ds->numCU * 8));
+    // A pass of a small job (C1: 1 M items on a chip of 524 288 lanes) is a chain of ~25 dependent launches, each of which lasts as long as its slowest ray
+    // whatever the number of rays: there the shadow rays of a bounce run BESIDE its closest-hit rays (the context's side stream) instead of in front of them
+    // (C1 2.47 -> 2.03 ms; the gain fades with the pass size: -4 .. -6 % at 2^22 - 2^23 items of C3 / C4-like scenes, -1 % at 2^25, nothing at 2^27: profiles/r06v_shadow_beside).
+    // A large pass keeps one stream by default: on C4 each kernel saturates the VALUs by itself and sharing the chip costs 1 % (bench 1 798 / 1 812 one stream,
+    // 1 788 / 1 782 beside) - but a scene whose shadow rays are short-lived (the reference's own q1 asset: an object on a backdrop under three lights, shadow kernel
+    // at 0.67 VALU busy) gains 7 - 12 % at EVERY pass size, which is what KzRenderOpts::shadowBeside = 2 is for. The film is the same bits either way.
+    bool beside = !split && P.nLights > 0 && maxDepth > 1 && (shadowBeside == 2 || (shadowBeside == 0 && items <= KZ_BESIDE_ITEMS));
+#ifdef KZ_EXPERIMENTS
+    if (X.any) beside = false;              // (an experiment kernel of kz_experiments.h is selected: one stream)
+#endif
+    ds->lastInfo.shadowBeside = beside ? 1u : 0u;      // (what the last pass did: kz_last_pass_info)
+    if (beside && !c.side) {
+        HIP_TRY(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c.evFork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c.evJoin, hipEventDisableTiming));
+    }
     for (int iter = 0; iter < maxDepth; ++iter) {
         // One kernel per bounce: the path queues ping-pong (W.queue[iter & 1] is written, the other one read). Two kernels (tune.shadeSplit): kz_wf_classify
         // reads the path queue and writes the survivors to W.queue[0]; kz_wf_shade_b reads those and writes the next path queue to W.queue[1], which
@@ -773,18 +797,29 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
 #ifdef KZ_EXPERIMENTS
         if (X.bounce(iter, needExtend, nextQ, nextCount, shQ, shCount)) { cur = nextQ; curCount = nextCount; continue; }
 #endif
+        // `beside` (above): this bounce's shadow rays go to the context's side stream and run beside its closest-hit rays; the next shade
+        // waits for both. (What the two kernels write is disjoint: the shadow kernels add to the sample sums and use the path queue the shade has just
+        // consumed; the closest-hit kernel stores hit records and reads the other path queue.)
+        hipStream_t shOn = nullptr;
+        if (beside && needExtend) {
+            HIP_TRY(hipEventRecord(c.evFork, stream));
+            HIP_TRY(hipStreamWaitEvent(c.side, c.evFork, 0));
+            shOn = c.side;
+        }
         if (P.nLights > 0) {
             if (P.shadowFast) {
                 // any-hit kernel without the walk-through machinery; the (rare) rays whose segment crosses an invisible-light triangle go to a
                 // queue - the ping-pong path queue this bounce's shade has just consumed - and are walked through by the general kernel
                 uint32_t *litQ = split ? W.queue[0] : W.queue[(iter & 1) ^ 1], *litCount = W.counts + 4 * 520 + 2 * (iter + 1), *litHead = litCount + 1;
-                trace(4, trShQ, shCount, 0u, nextCount + 3, litQ, litCount);
-                if (P.anyInvisibleLight) trace(2, litQ, litCount, 0u, litHead, nullptr, nullptr);
-            } else trace(2, trShQ, shCount, 0u, nextCount + 3, nullptr, nullptr);
+                trace(4, trShQ, shCount, 0u, nextCount + 3, litQ, litCount, shOn);
+                if (P.anyInvisibleLight) trace(2, litQ, litCount, 0u, litHead, nullptr, nullptr, shOn);
+            } else trace(2, trShQ, shCount, 0u, nextCount + 3, nullptr, nullptr, shOn);
         }
+        if (shOn) HIP_TRY(hipEventRecord(c.evJoin, c.side));
         { int rc_ = stageMark(c, stream, 3); if (rc_) return rc_; }
         if (needExtend) {
             trace(0, trQ, nextCount, 0u, nextCount + 2, nullptr, nullptr);
+            if (shOn) HIP_TRY(hipStreamWaitEvent(stream, c.evJoin, 0));          // (the stage clock then shows the pair under "trace_bounce" and nothing under "trace_shadow")
             int rc_ = stageMark(c, stream, 1); if (rc_) return rc_;
         }
         cur = nextQ; curCount = nextCount;
@@ -802,6 +837,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     if (opts->pipeline < 0 || opts->pipeline > 2) return kz_fail(KZ_ERR_INVALID_ARG, "pipeline %d (0 = default, 1 = megakernel, 2 = wavefront)", opts->pipeline);
     if (opts->passesInFlight < 0 || opts->passesInFlight > KZ_MAX_PASSES_IN_FLIGHT)
         return kz_fail(KZ_ERR_INVALID_ARG, "passesInFlight %d (0 = default, 1 .. %d)", opts->passesInFlight, KZ_MAX_PASSES_IN_FLIGHT);
+    if (opts->shadowBeside < 0 || opts->shadowBeside > 2) return kz_fail(KZ_ERR_INVALID_ARG, "shadowBeside %d (0 = default, 1 = never, 2 = always)", opts->shadowBeside);
     const int pipeline = opts->pipeline ? opts->pipeline : 2;
 #ifdef KZ_EXPERIMENTS
     if ((rc = kzEnsureBvh2(scene, ds))) return rc;          // (development builds: several experiment kernels walk the BVH2)
@@ -955,7 +991,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         EventPair &ep = ds->events[ds->eventsUsed++];
         const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
         HIP_TRY(hipEventRecord(ep.a, pst));
-        if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams))) return rc; }
+        if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams, opts->shadowBeside))) return rc; }
         else {
             float *sJx = c.plane[0], *sJy = c.plane[1], *sR = c.plane[2], *sG = c.plane[3], *sB = c.plane[4];
 #define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, pixList, (uint32_t)items, Sp, s, \

@@ -132,6 +132,7 @@ struct PassCtx {
     uint32_t *counts = nullptr;                                  // queue counters of a pass (8 x 520 words)
     uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
+    hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;      // small passes: the shadow rays of a bounce beside its closest-hit rays (wfPass)
     size_t wanted = 0;                                           // items the last call with the default schedule asked this context to hold (kz_render.hip: `earned`)
     uint64_t beamSeen = 0;                                       // the last beam-list build (KzDeviceState::beamSeq) this context's stream has waited for
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
@@ -155,6 +156,9 @@ struct PassCtx {
         delete arena; arena = nullptr;
         for (auto &e : stageEv) (void)hipEventDestroy(e);
         stageEv.clear(); stageKind.clear();
+        if (side) { (void)hipStreamDestroy(side); side = nullptr; }
+        if (evFork) { (void)hipEventDestroy(evFork); evFork = nullptr; }
+        if (evJoin) { (void)hipEventDestroy(evJoin); evJoin = nullptr; }
     }
 };
 // Pass contexts live in a per-device pool between replicas (kz_arena.cpp): a replica takes them on first use and hands them back when it goes.

@@ -8,3 +8,6 @@ sc = kz.Scene(d, device=0)
 for i in range(6):
     t0 = time.perf_counter(); sc.render(); sc.sync(); print("call %d: %.3f ms" % (i, 1e3 * (time.perf_counter() - t0)), flush=True)
 print("stages of the last pass:", sc.last_stage_ms(), flush=True)
+if os.environ.get("KZ_C1_MEGA"):
+    for i in range(4):
+        t0 = time.perf_counter(); sc.render(pipeline=1); sc.sync(); print("megakernel call %d: %.3f ms" % (i, 1e3 * (time.perf_counter() - t0)), flush=True)

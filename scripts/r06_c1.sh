@@ -1,9 +1,9 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r06h_c1; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-python3 $R/scripts/dev/c1_trace.py > $OUT/plain.txt 2>&1; cat $OUT/plain.txt
+KZ_C1_MEGA=1 python3 $R/scripts/dev/c1_trace.py > $OUT/plain.txt 2>&1; cat $OUT/plain.txt
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/scripts/dev/c1_trace.py > $OUT/traced.txt 2>&1
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
-python3 - $f <<'PY'
+python3 - $f > $OUT/launches.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -18,4 +18,5 @@ for r in last:
     busy += e - s; prev_end = max(prev_end, e)
 print("span %.1f us, kernels %.1f us, %d launches" % ((prev_end - t0) / 1e3, busy / 1e3, len(last)))
 PY
+tail -n 3 $OUT/launches.txt
 rm -rf $OUT/trace

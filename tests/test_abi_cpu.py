@@ -50,7 +50,7 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
         assert C.sizeof(getattr(a, n)) == int(sizes[n]), n
     assert C.sizeof(a.KzBSDF) == 128 and C.sizeof(a.KzTexture) == 64
     # structures the library reads or writes THROUGH a caller's pointer carry no size field - their sizes are pinned to the ABI version (6)
-    assert C.sizeof(a.KzTileDealer) == 48 and C.sizeof(a.KzPassInfo) == 64 and C.sizeof(a.KzRenderOpts) == 144
+    assert C.sizeof(a.KzTileDealer) == 48 and C.sizeof(a.KzPassInfo) == 64 and C.sizeof(a.KzRenderOpts) == 152
 
 
 def test_render_opts_layout_v5(kz):
@@ -59,7 +59,7 @@ def test_render_opts_layout_v5(kz):
     o = kz.abi.KzRenderOpts
     assert (o.sampleBegin.offset, o.sampleEnd.offset, o.tiles.offset, o.nTiles.offset, o.pipeline.offset, o.accumulate.offset, o.stream.offset) == (0, 4, 8, 16, 20, 24, 32)
     assert o.device.offset == 40 and o.passItems.offset == 48 and o.maxStateBytes.offset == 56 and o.tune.offset == 64
-    assert C.sizeof(kz.abi.KzTuning) == 64 and o.tileDealing.offset == 128 and o.packedOutput.offset == 132 and o.dealer.offset == 136 and C.sizeof(o) == 144
+    assert C.sizeof(kz.abi.KzTuning) == 64 and o.tileDealing.offset == 128 and o.packedOutput.offset == 132 and o.dealer.offset == 136 and o.shadowBeside.offset == 144 and C.sizeof(o) == 152
 
 
 @pytest.mark.parametrize("w,h,tile,parts", [(1920, 1080, 64, 8), (3840, 2160, 64, 8), (1920, 1080, 128, 3), (100, 70, 32, 5), (64, 64, 64, 4)])

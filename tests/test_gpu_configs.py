@@ -643,3 +643,43 @@ def test_calls_on_alternating_caller_streams_are_ordered(gpu_lib, kz):
         assert np.array_equal(sc.film(), whole)
     sc.close()
     hip.hipStreamDestroy(s1); hip.hipStreamDestroy(s2)
+
+
+def test_shadow_rays_beside_the_closest_hit_rays(gpu_lib, kz, O):
+    """KzRenderOpts::shadowBeside: the shadow kernels of a bounce on the pass context's side stream, beside the bounce's closest-hit kernel (2), in front of it on one
+    stream (1), or as the library decides (0: beside up to 2^26 items per pass). What the two kernels touch is disjoint and the next shade waits for both: the film is
+    the SAME BITS - on scenes with visible and invisible lights (the walk-through launch rides on the side stream too), with the EXT shade kernels, with a background
+    (the last bounce extends), with passes in flight, with the counting instantiations - and equals the oracle's."""
+    q1 = os.path.join(ROOT, "tests", "golden", "q1_default_m0_r0.5.npz")
+    cases = [("cornell (visible light)", kz.scenes.cornell_box(128, 96, 16, sampler="pmj02bn"), 1),
+             ("glass (EXT models)", kz.scenes.glass_scene(96, 96, 16), 1),
+             ("q1 asset (invisible lights)", kz.scenes.load_npz(q1, overrides={"camera": {"width": 160, "height": 120}, "sampler": {"type": "independent", "sampleCount": 8, "seed": 3}}), 1),
+             ("random triangles", kz.scenes.random_triangles(20000, 128, 96, 8, sampler="independent"), 1),
+             ("sphere + environment (no lights to sample)", kz.scenes.sphere_env(96, 96, 8), 0)]
+    for name, desc, expect in cases:
+        sc = kz.Scene(desc, device=0)
+        sc.render(shadow_beside=1)
+        one_stream = sc.film()
+        assert sc.last_pass_info()["shadowBeside"] == 0, name
+        for rep in range(3):                                          # (repeated: a missing wait would show as run-to-run differences)
+            sc.render(shadow_beside=2)
+            assert sc.last_pass_info()["shadowBeside"] == expect, name
+            assert np.array_equal(sc.film(), one_stream), (name, rep)
+        sc.render()
+        assert sc.last_pass_info()["shadowBeside"] == expect, name    # a small pass: the default is "beside"
+        assert np.array_equal(sc.film(), one_stream), name
+        npx = sc.width * sc.height
+        sc.render(shadow_beside=2, pass_items=npx * 2, passes_in_flight=3)              # every context has its own side stream
+        assert np.array_equal(sc.film(), one_stream), name
+        sc.set_stats(True)
+        sc.render(shadow_beside=2); s2 = sc.stats(reset=True)
+        assert np.array_equal(sc.film(), one_stream), name
+        sc.render(shadow_beside=1); s1 = sc.stats(reset=True)
+        sc.set_stats(False)
+        # (node visits and triangle tests are counted per wave step: with invisible lights they vary from run to run with the order the queues were filled in)
+        assert {k: v for k, v in s1.items() if k not in ("triTests", "nodeVisits")} == {k: v for k, v in s2.items() if k not in ("triTests", "nodeVisits")}, name
+        ora = O.OracleScene(desc)
+        assert np.array_equal(one_stream, ora.render_canonical(threads=0)), name
+        with pytest.raises(kz.abi.KzError):
+            sc.render(shadow_beside=3)
+        sc.close()
