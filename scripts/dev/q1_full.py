@@ -11,7 +11,8 @@ kz = importlib.import_module("nano-kazen_amd")
 OUT = os.path.join(ROOT, "gpurun_out", "q1_full"); os.makedirs(OUT, exist_ok=True)
 FACTORS = (0.976, 1.135, 1.034)
 ALL = "--all" in sys.argv
-argv = [a for a in sys.argv if a != "--all"]
+BESIDE = "--beside" in sys.argv           # --all --beside: every picture a second time with KzRenderOpts::shadowBeside = 2 (time, and that the picture is the same)
+argv = [a for a in sys.argv if a not in ("--all", "--beside")]
 over = {"sampler": {"sampleCount": int(argv[1])}} if len(argv) > 1 else None
 if ALL:
     params = json.load(open(os.path.join(ROOT, "tests", "golden", "q1_params.json")))["params"]
@@ -28,6 +29,10 @@ if ALL:
         t0 = time.perf_counter(); sc.render(); sc.sync(); dt = time.perf_counter() - t0
         kz.output.save_png(os.path.join(OUT, "all", name), sc.srgb8())
         res[name] = {"render_s": round(dt, 3), "Msamples_per_s": round(sc.width * sc.height * sc.sample_count / dt / 1e6, 1), "spp": sc.sample_count, "mean_linear_rgb": float(sc.rgb().mean())}
+        if BESIDE:
+            film = sc.film()
+            t0 = time.perf_counter(); sc.render(shadow_beside=2); sc.sync(); db = time.perf_counter() - t0
+            res[name]["shadow_beside"] = {"render_s": round(db, 3), "Msamples_per_s": round(sc.width * sc.height * sc.sample_count / db / 1e6, 1), "film_equal": bool(np.array_equal(film, sc.film()))}
         print(name, res[name], flush=True)
         sc.close()
     json.dump(res, open(os.path.join(OUT, "q1_all.json"), "w"), indent=1)
