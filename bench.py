@@ -503,7 +503,8 @@ def main():
                                       % (name, args.tris, Wd, Hd, spp_table, spp_step, info["passes"], info["passesInFlight"], TILE, TILE),
                           "samples_per_step": int(float(px.item()) * spp_step), "bvh_nodes": bvh["nNodes"], "bvh_depth": bvh["maxDepth"],
                           "image_mean": round(float(rgb.mean()), 5), "commit": commit,
-                          "items_per_pass_per_rank": items_per_pass_per_rank, "sampler_table_spp": spp_table, "warmup_wait_for_context_s": round(grow_wait_s, 2),
+                          "items_per_pass_per_rank": items_per_pass_per_rank, "sampler_table_spp": spp_table,
+                          "shadow_rays_of_the_last_timed_pass": "beside the closest-hit rays" if info["shadowBeside"] else "in front of the closest-hit rays (one stream)", "warmup_wait_for_context_s": round(grow_wait_s, 2),
                           "first_call_ms": first_call_ms, "first_call": "the first (warm-up) step: beam lists of every pixel (kz_wf_beam, once per pixel and replica), the pass context "
                                                                         "growing (its memory is mapped on a side thread while the first passes run), then the step itself; a timed step is ms_per_step"},
                "roofline": roofline, "cpu_baseline": cpu, "cold_job": cold, "parity": parity}
@@ -612,19 +613,24 @@ def reference_scene(kz, device_index, spp):
     spp = min(spp, sc.sample_count)
     sc.render(0, min(64, spp)); sc.sync()
     ts = []
-    for _ in range(2):
+    for _ in range(4):               # (the first two large passes of a replica are its two timed probes of KzRenderOpts::shadowBeside: the later calls run what it kept)
         t0 = time.perf_counter(); sc.render(0, spp); sc.sync(); ts.append(time.perf_counter() - t0)
+    kept = sc.last_pass_info()["shadowBeside"]
     n = sc.width * sc.height * spp
-    # the same slice with KzRenderOpts::shadowBeside = 2 (the shadow rays of a bounce beside its closest-hit rays): this scene's shadow rays are short-lived and its
-    # kernels do not fill the VALUs by themselves (profiles/r06v_shadow_beside) - the option a caller of such scenes sets; `value` stays the library default
+    # the same slice with KzRenderOpts::shadowBeside = 2 (the shadow rays of a bounce beside its closest-hit rays) and = 1 (in front): this scene's shadow rays are
+    # short-lived and its kernels do not fill the VALUs by themselves (profiles/r06v_shadow_beside); `value` is the library default, i.e. what the replica measured and kept
     film0 = sc.film()
     tb = []
-    for _ in range(2):
-        t0 = time.perf_counter(); sc.render(0, spp, shadow_beside=2); sc.sync(); tb.append(time.perf_counter() - t0)
-    beside = {"value": round(n / min(tb) / 1e6, 1), "render_s": [round(t, 4) for t in tb], "film_equal": bool(np.array_equal(film0, sc.film())), "option": "KzRenderOpts::shadowBeside = 2"}
+    t1 = []
+    for mode, out in ((2, tb), (1, t1)):
+        for _ in range(2):
+            t0 = time.perf_counter(); sc.render(0, spp, shadow_beside=mode); sc.sync(); out.append(time.perf_counter() - t0)
+    beside = {"value": round(n / min(tb) / 1e6, 1), "render_s": [round(t, 4) for t in tb], "film_equal": bool(np.array_equal(film0, sc.film())), "option": "KzRenderOpts::shadowBeside = 2",
+              "one_stream": {"value": round(n / min(t1) / 1e6, 1), "render_s": [round(t, 4) for t in t1], "option": "KzRenderOpts::shadowBeside = 1"},
+              "kept_by_the_replica": "beside" if kept else "one stream"}
     rec = {"workload": "scene/2022_q1/parameters/default_m0_r0.5.xml (36 378 triangles, the reference's own scene file via tests/golden/q1_default_m0_r0.5.npz), %dx%d, independent sampler, "
                        "path_mis maxDepth %d, sample indices [0, %d) of the file's %d" % (sc.width, sc.height, d.integrator["maxDepth"], spp, sc.sample_count),
-           "value": round(n / min(ts) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),
+           "value": round(n / min(ts[2:]) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),
            "shadow_beside": beside,
            "whole_job": "all 4096 spp: 4.4 s, 1 927 Msamples/s; against the published 4096-spp picture of this scene file: profiles/r04p_q1_full",
            "published_caption": {"job": "1920x1080, 4096 spp (another scene of the same studio set)", "seconds": 702, "Msamples_per_s": 12.1, "hardware": "unstated CPU",

@@ -324,9 +324,11 @@ typedef struct KzRenderOpts {
     /* ---- ABI v6 ---- */
     int32_t shadowBeside;       /* where the shadow rays of a bounce run: 1 = in front of the bounce's closest-hit rays (one stream), 2 = beside them (a side stream of the
                                    pass context; the next shade waits for both), 0 = default: beside in passes of up to 2^26 items - a small job is a chain of launches each
-                                   as long as its slowest ray (BASELINE configs[0]: 2.47 -> 2.03 ms) - and in front otherwise: kernels that saturate the chip by themselves
-                                   lose ~1 % sharing it (C4), kernels that do not - short-lived shadow rays: the reference's scene/2022_q1 files - gain 7 - 12 % at any
-                                   size, so a caller who renders such scenes sets 2. The film is the same bits whatever this says. */
+                                   as long as its slowest ray (BASELINE configs[0]: 2.47 -> 2.03 ms) - and MEASURED for larger ones: kernels that saturate the chip by
+                                   themselves lose ~1 % sharing it (C4), kernels that do not - short-lived shadow rays: all 22 of the reference's scene/2022_q1 files - gain
+                                   6 - 10 % at any size. The replica runs its first large pass beside, the next one of that size in front, waits for that one when a third
+                                   comes (kz_render is asynchronous but for such waits: it also stays one pass ahead of a context that is still growing) and keeps "beside"
+                                   if it was 3 % faster per item (with passes in flight, a dealer or the counters on: in front). The film is the same bits whatever this says. */
     int32_t reserved0;
 } KzRenderOpts;
 #define KZ_MAX_PASSES_IN_FLIGHT 8

@@ -118,7 +118,7 @@ static void releaseReplica(KzDeviceState *ds) {
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipStream_t st : ds->passStream) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : ds->evFilm) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {ds->evFork, ds->evCallA, ds->evCallB}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ds->evFork, ds->evCallA, ds->evCallB, ds->evProbe[0][0], ds->evProbe[0][1], ds->evProbe[1][0], ds->evProbe[1][1]}) if (e) (void)hipEventDestroy(e);
     delete ds;
 }
 
@@ -738,9 +738,10 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     // A pass of a small job (C1: 1 M items on a chip of 524 288 lanes) is a chain of ~25 dependent launches, each of which lasts as long as its slowest ray
     // whatever the number of rays: there the shadow rays of a bounce run BESIDE its closest-hit rays (the context's side stream) instead of in front of them
     // (C1 2.47 -> 2.03 ms; the gain fades with the pass size: -4 .. -6 % at 2^22 - 2^23 items of C3 / C4-like scenes, -1 % at 2^25, nothing at 2^27: profiles/r06v_shadow_beside).
-    // A large pass keeps one stream by default: on C4 each kernel saturates the VALUs by itself and sharing the chip costs 1 % (bench 1 798 / 1 812 one stream,
-    // 1 788 / 1 782 beside) - but a scene whose shadow rays are short-lived (the reference's own q1 asset: an object on a backdrop under three lights, shadow kernel
-    // at 0.67 VALU busy) gains 7 - 12 % at EVERY pass size, which is what KzRenderOpts::shadowBeside = 2 is for. The film is the same bits either way.
+    // A LARGE pass is another matter: on C4 each kernel saturates the VALUs by itself and sharing the chip costs 1 % (bench 1 798 / 1 812 one stream, 1 788 / 1 782
+    // beside) - but a scene whose shadow rays are short-lived (the reference's own q1 asset: an object on a backdrop under three lights, shadow kernel at 0.67 VALU
+    // busy) gains 6 - 10 % at EVERY pass size, all 22 scene files of the reference do. Nothing known at upload tells the two kinds apart, so renderOn MEASURES it
+    // (one large pass each way per replica) and passes 1 or 2 down here; 0 reaches this function for small passes only. The film is the same bits either way.
     bool beside = !split && P.nLights > 0 && maxDepth > 1 && (shadowBeside == 2 || (shadowBeside == 0 && items <= KZ_BESIDE_ITEMS));
 #ifdef KZ_EXPERIMENTS
     if (X.any) beside = false;              // (an experiment kernel of kz_experiments.h is selected: one stream)
@@ -991,7 +992,37 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         EventPair &ep = ds->events[ds->eventsUsed++];
         const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
         HIP_TRY(hipEventRecord(ep.a, pst));
-        if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams, opts->shadowBeside))) return rc; }
+        // Where the shadow rays of a LARGE pass run is measured, not guessed (wfPass tells why no rule of thumb separates the scenes that gain 6 - 10 % from those
+        // that lose 1 %): with the option left at 0, one pass at a time and nobody counting, the replica times one large pass with the shadow rays beside the closest-hit
+        // rays and one of the same size in front of them - the film is the same bits either way -, waits for the second when a third comes, and keeps "beside" for its
+        // scene only if that was 3 % faster per item. (Such a wait is nothing new: a call already stays one pass ahead of a context that is still growing.)
+        int sb = opts->shadowBeside, probe = -1;
+        if (pipeline == 2 && sb == 0 && items > KZ_BESIDE_ITEMS) {
+            if (multi || dealer || ds->statsOn) sb = 1;
+            else {
+                if (ds->besideLarge < 0 && ds->probeLaunched == 2) {
+                    float tA = 0.f, tB = 0.f;
+                    HIP_TRY(hipEventSynchronize(ds->evProbe[1][1]));
+                    HIP_TRY(hipEventElapsedTime(&tA, ds->evProbe[0][0], ds->evProbe[0][1]));
+                    HIP_TRY(hipEventElapsedTime(&tB, ds->evProbe[1][0], ds->evProbe[1][1]));
+                    ds->probeMs[0] = tA; ds->probeMs[1] = tB;
+                    ds->besideLarge = (double)tA / (double)ds->probeItems[0] < 0.97 * (double)tB / (double)ds->probeItems[1] ? 1 : 0;
+                    KZ_TRACE("large passes of %zu items: %.2f ms beside, %.2f ms one stream -> %s", ds->probeItems[0], tA, tB, ds->besideLarge ? "beside" : "one stream");
+                }
+                if (ds->besideLarge >= 0) sb = ds->besideLarge ? 2 : 1;
+                else if (ds->probeLaunched == 0 || items > ds->probeItems[0]) { probe = 0; sb = 2; ds->probeLaunched = 0; }      // (a larger pass than the one timed: the context has grown - start over at this size)
+                else if (items == ds->probeItems[0]) { probe = 1; sb = 1; }
+                else sb = 1;                                                  // (a remainder pass: not comparable)
+            }
+        }
+        if (probe >= 0) {
+            for (int k = 0; k < 2; ++k) if (!ds->evProbe[probe][k]) HIP_TRY(hipEventCreate(&ds->evProbe[probe][k]));
+            HIP_TRY(hipEventRecord(ds->evProbe[probe][0], pst));
+        }
+        if (pipeline == 2) {
+            if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams, sb))) return rc;
+            if (probe >= 0) { HIP_TRY(hipEventRecord(ds->evProbe[probe][1], pst)); ds->probeItems[probe] = items; ds->probeLaunched = probe + 1; }
+        }
         else {
             float *sJx = c.plane[0], *sJy = c.plane[1], *sR = c.plane[2], *sG = c.plane[3], *sB = c.plane[4];
 #define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, pixList, (uint32_t)items, Sp, s, \

@@ -192,6 +192,9 @@ struct KzDeviceState {
     PassCtx &ctxAt(int i) { if (!ctx[i]) ctx[i] = kzCtxAcquire(device); return *ctx[i]; }
     std::vector<EventPair> events; size_t eventsUsed = 0;
     hipStream_t passStream[KZ_MAX_PASSES_IN_FLIGHT] = {}; hipEvent_t evFork = nullptr, evFilm[KZ_MAX_PASSES_IN_FLIGHT] = {}, evCallA = nullptr, evCallB = nullptr;
+    // LARGE passes with KzRenderOpts::shadowBeside = 0: the replica times one pass with the shadow rays beside the closest-hit rays [0] and one of the same size with one
+    // stream [1], then keeps the faster order for its scene (renderOn). besideLarge: -1 = not known yet, 0 = one stream, 1 = beside.
+    hipEvent_t evProbe[2][2] = {}; size_t probeItems[2] = {}; int probeLaunched = 0; int besideLarge = -1; float probeMs[2] = {};
     int lastCtx = 0; bool lastDual = false; int streamMode = 0;
     // Beam lists (kz_wf_beam), one per pixel of the FRAME, built at most once per pixel and replica - the camera belongs to the scene - whatever tile
     // sets and pixel chunks the pixel is rendered in. They are built on the call's stream (evBeam / beamSeq: the passes wait for the latest build);

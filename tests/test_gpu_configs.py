@@ -683,3 +683,31 @@ def test_shadow_rays_beside_the_closest_hit_rays(gpu_lib, kz, O):
         with pytest.raises(kz.abi.KzError):
             sc.render(shadow_beside=3)
         sc.close()
+
+
+def test_large_passes_measure_where_their_shadow_rays_run(gpu_lib, kz):
+    """KzRenderOpts::shadowBeside = 0 on passes above 2^26 items: the replica runs its first large pass with the shadow rays beside the closest-hit rays, the next one of
+    that size in front of them, and keeps what was faster for every later one (the decision itself depends on the scene and the clock - the reference's q1 asset gains
+    7 - 10 % at this size, profiles/r06v_shadow_beside - so only its shape is asserted: probe, probe, then one answer for good). Explicit 1 / 2 bypass it; the film is the same bits."""
+    q1 = os.path.join(ROOT, "tests", "golden", "q1_default_m0_r0.5.npz")
+    desc = kz.scenes.load_npz(q1, overrides={"camera": {"width": 1920, "height": 1080}, "sampler": {"type": "independent", "sampleCount": 64, "seed": 0}})
+    sc = kz.Scene(desc, device=0)
+    sc.render(shadow_beside=1)                                        # (earns the context its size: the passes below are all one pass of 1920 x 1080 x 64 > 2^26 items)
+    sc.render(shadow_beside=1)
+    info = sc.last_pass_info()
+    assert info["passes"] == 1 and info["largestPassItems"] == 1920 * 1080 * 64 and info["shadowBeside"] == 0
+    one_stream = sc.film()
+    sc.render(); assert sc.last_pass_info()["shadowBeside"] == 1      # timed beside
+    assert np.array_equal(sc.film(), one_stream)
+    sc.render(); assert sc.last_pass_info()["shadowBeside"] == 0      # timed in front
+    sc.render(); kept = sc.last_pass_info()["shadowBeside"]           # waits for the second, decides
+    assert np.array_equal(sc.film(), one_stream)
+    for _ in range(2):
+        sc.render(); assert sc.last_pass_info()["shadowBeside"] == kept
+    print("q1 asset, passes of 2^27 items: the replica keeps its shadow rays", "beside" if kept else "in front of", "the closest-hit rays")
+    sc.render(shadow_beside=2); assert sc.last_pass_info()["shadowBeside"] == 1
+    sc.render(shadow_beside=1); assert sc.last_pass_info()["shadowBeside"] == 0
+    sc.set_stats(True); sc.render(); sc.set_stats(False)              # the counting kernels are not what was timed: in front
+    assert sc.last_pass_info()["shadowBeside"] == 0 and np.array_equal(sc.film(), one_stream)
+    sc.render(0, 16); assert sc.last_pass_info()["shadowBeside"] == 1  # a small pass (2^25 items): beside, whatever was decided for the large ones
+    sc.close()
