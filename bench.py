@@ -573,7 +573,8 @@ def ext_scenes(kz, device_index, cpu=True):
             for _ in range(3 if n >= (1 << 28) else 5):
                 t0 = time.perf_counter(); sc.render(); sc.sync(); ts.append(time.perf_counter() - t0)
             rec = {"workload": what, "samples": n, "value": round(n / min(ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
-                   "image_mean": round(float(sc.rgb().mean()), 5), "passes": sc.last_pass_info()["passes"], "tris": desc.n_tris()}
+                   "image_mean": round(float(sc.rgb().mean()), 5), "passes": sc.last_pass_info()["passes"], "tris": desc.n_tris(),
+                   "shadow_rays_of_the_last_pass": "beside" if sc.last_pass_info()["shadowBeside"] else "in front"}
             if cpu and cpu_mode:
                 import oracle as O
                 ora = O.OracleScene(desc)
