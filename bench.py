@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--cold-job", choices=["c4", "q1"], default=None, help="(child process mode) run ONE cold job and print its record")
     ap.add_argument("--no-cold-job", action="store_true", help="N = 1: skip the two one-frame-per-process jobs that ride in the same JSON line")
     ap.add_argument("--shadow-beside", type=int, default=0, help="KzRenderOpts::shadowBeside of the timed steps (0 = library default, 1 = one stream, 2 = shadow rays beside the closest-hit rays: scripts/r06_beside_bench.sh)")
+    ap.add_argument("--pass-halves", type=int, default=0, help="KzRenderOpts::passHalves of the timed steps (0 = library default, 1 = never, 2 = every pass as two halves side by side)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity render (scripts/profile_bench.sh: the kernel statistics of a profiled run then hold the timed passes only)")
     ap.add_argument("--no-ext-scenes", action="store_true", help="N = 1: skip the EXT-kernel scenes and C1 / C2 / C3 at their BASELINE sizes (each beside the oracle's CPU time) that ride in the same JSON line")
     ap.add_argument("--profile-pass", action="store_true", help="(scripts/profile_bench.sh) every step asks for ONE pass of 2^30 items explicitly instead of earning it call by call: "
@@ -302,6 +303,8 @@ def main():
     kw = {}
     if args.shadow_beside:
         kw["shadow_beside"] = args.shadow_beside
+    if args.pass_halves:
+        kw["pass_halves"] = args.pass_halves
     if shared_device:
         kw["max_state_bytes"] = int(0.8 * torch.cuda.mem_get_info(device_index)[1] / world)
     if args.profile_pass:
@@ -504,7 +507,7 @@ def main():
                           "samples_per_step": int(float(px.item()) * spp_step), "bvh_nodes": bvh["nNodes"], "bvh_depth": bvh["maxDepth"],
                           "image_mean": round(float(rgb.mean()), 5), "commit": commit,
                           "items_per_pass_per_rank": items_per_pass_per_rank, "sampler_table_spp": spp_table,
-                          "shadow_rays_of_the_last_timed_pass": "beside the closest-hit rays" if info["shadowBeside"] else "in front of the closest-hit rays (one stream)", "warmup_wait_for_context_s": round(grow_wait_s, 2),
+                          "how_the_last_timed_pass_ran": ("one stream", "its shadow rays beside its closest-hit rays", "as two halves side by side")[info["shadowBeside"]], "warmup_wait_for_context_s": round(grow_wait_s, 2),
                           "first_call_ms": first_call_ms, "first_call": "the first (warm-up) step: beam lists of every pixel (kz_wf_beam, once per pixel and replica), the pass context "
                                                                         "growing (its memory is mapped on a side thread while the first passes run), then the step itself; a timed step is ms_per_step"},
                "roofline": roofline, "cpu_baseline": cpu, "cold_job": cold, "parity": parity}
@@ -570,11 +573,11 @@ def ext_scenes(kz, device_index, cpu=True):
             build_s = time.perf_counter() - t0
             n = sc.width * sc.height * sc.sample_count
             ts = []
-            for _ in range(3 if n >= (1 << 28) else 5):
+            for _ in range(6):          # (a replica's first four large passes are its timed probes of how such a pass should run: the later calls run what it kept)
                 t0 = time.perf_counter(); sc.render(); sc.sync(); ts.append(time.perf_counter() - t0)
-            rec = {"workload": what, "samples": n, "value": round(n / min(ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
+            rec = {"workload": what, "samples": n, "value": round(n / min(ts[4:] if n > (1 << 26) else ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
                    "image_mean": round(float(sc.rgb().mean()), 5), "passes": sc.last_pass_info()["passes"], "tris": desc.n_tris(),
-                   "shadow_rays_of_the_last_pass": "beside" if sc.last_pass_info()["shadowBeside"] else "in front"}
+                   "how_the_last_pass_ran": ("one stream", "shadow rays beside", "halves")[sc.last_pass_info()["shadowBeside"]]}
             if cpu and cpu_mode:
                 import oracle as O
                 ora = O.OracleScene(desc)
@@ -614,7 +617,7 @@ def reference_scene(kz, device_index, spp):
     spp = min(spp, sc.sample_count)
     sc.render(0, min(64, spp)); sc.sync()
     ts = []
-    for _ in range(4):               # (the first two large passes of a replica are its two timed probes of KzRenderOpts::shadowBeside: the later calls run what it kept)
+    for _ in range(6):               # (the first four large passes of a replica are its timed probes - shadow rays beside, one stream, halves, one stream: the later calls run what it kept)
         t0 = time.perf_counter(); sc.render(0, spp); sc.sync(); ts.append(time.perf_counter() - t0)
     kept = sc.last_pass_info()["shadowBeside"]
     n = sc.width * sc.height * spp
@@ -628,10 +631,10 @@ def reference_scene(kz, device_index, spp):
             t0 = time.perf_counter(); sc.render(0, spp, shadow_beside=mode); sc.sync(); out.append(time.perf_counter() - t0)
     beside = {"value": round(n / min(tb) / 1e6, 1), "render_s": [round(t, 4) for t in tb], "film_equal": bool(np.array_equal(film0, sc.film())), "option": "KzRenderOpts::shadowBeside = 2",
               "one_stream": {"value": round(n / min(t1) / 1e6, 1), "render_s": [round(t, 4) for t in t1], "option": "KzRenderOpts::shadowBeside = 1"},
-              "kept_by_the_replica": "beside" if kept else "one stream"}
+              "kept_by_the_replica": ("one stream", "shadow rays beside", "halves")[kept]}
     rec = {"workload": "scene/2022_q1/parameters/default_m0_r0.5.xml (36 378 triangles, the reference's own scene file via tests/golden/q1_default_m0_r0.5.npz), %dx%d, independent sampler, "
                        "path_mis maxDepth %d, sample indices [0, %d) of the file's %d" % (sc.width, sc.height, d.integrator["maxDepth"], spp, sc.sample_count),
-           "value": round(n / min(ts[2:]) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),
+           "value": round(n / min(ts[4:]) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),
            "shadow_beside": beside,
            "whole_job": "all 4096 spp: 4.4 s, 1 927 Msamples/s; against the published 4096-spp picture of this scene file: profiles/r04p_q1_full",
            "published_caption": {"job": "1920x1080, 4096 spp (another scene of the same studio set)", "seconds": 702, "Msamples_per_s": 12.1, "hardware": "unstated CPU",

@@ -326,10 +326,15 @@ typedef struct KzRenderOpts {
                                    pass context; the next shade waits for both), 0 = default: beside in passes of up to 2^26 items - a small job is a chain of launches each
                                    as long as its slowest ray (BASELINE configs[0]: 2.47 -> 2.03 ms) - and MEASURED for larger ones: kernels that saturate the chip by
                                    themselves lose ~1 % sharing it (C4), kernels that do not - short-lived shadow rays: all 22 of the reference's scene/2022_q1 files - gain
-                                   6 - 10 % at any size. The replica runs its first large pass beside, the next one of that size in front, waits for that one when a third
-                                   comes (kz_render is asynchronous but for such waits: it also stays one pass ahead of a context that is still growing) and keeps "beside"
-                                   if it was 3 % faster per item (with passes in flight, a dealer or the counters on: in front). The film is the same bits whatever this says. */
-    int32_t reserved0;
+                                   6 - 10 % at any size. The replica runs its first large pass in front, the next one of that size beside, a third as halves (passHalves),
+                                   a fourth in front again, waits for that one when a fifth comes (kz_render is asynchronous but for such waits: it also stays one pass ahead of a context that is
+                                   still growing) and keeps what was fastest per item, "in front" unless beaten by 3 % (with passes in flight, a dealer or the counters
+                                   on: in front). The film is the same bits whatever this says. */
+    int32_t passHalves;         /* 2 = a pass runs as two halves of its pixels side by side (two views of the pass context's arrays, the second on a stream of its own;
+                                   disjoint pixels, so nothing orders their film stages): one half's shade kernel beside the other half's traversal - materials_scene + 7 %,
+                                   C3 + 2 %, textured_scene - 2 %, C4 - 1.4 %. 1 = never. 0 = default: never for passes of up to 2^26 items, MEASURED above together with
+                                   shadowBeside when that is 0 too (the third of four timed passes; the fastest of the three ways is kept, "one stream" unless beaten by 3 %).
+                                   Ignored with passes in flight or a dealer (they overlap already). The film is the same bits whatever this says. */
 } KzRenderOpts;
 #define KZ_MAX_PASSES_IN_FLIGHT 8
 #define KZ_DEFAULT_PASSES_IN_FLIGHT 2

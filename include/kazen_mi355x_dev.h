@@ -105,7 +105,7 @@ int kz_last_stage_ms(KzScene *scene, float *out6);
 /* What the last kz_render did on the primary replica: passes, (pixel, sample) items of a full pass (the TARGET: a pass context grows while the first passes
  * of a job already run - firstPassItems / largestPassItems say what the passes of this call really were), passes in flight, bytes of path state mapped. */
 typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t itemsPerPass; uint32_t sppPerPass; uint32_t pixels; uint64_t stateBytes;
-                            uint32_t pixelsPerPass; uint32_t shadowBeside /* the last pass ran its shadow rays beside its closest-hit rays (KzRenderOpts::shadowBeside) */; uint64_t firstPassItems; uint64_t largestPassItems;
+                            uint32_t pixelsPerPass; uint32_t shadowBeside /* how the last pass ran: 0 = one stream, 1 = its shadow rays beside its closest-hit rays (KzRenderOpts::shadowBeside), 2 = as two halves (passHalves) */; uint64_t firstPassItems; uint64_t largestPassItems;
                             uint64_t contextItems;      /* items the first pass context holds NOW (it may still be growing towards itemsPerPass) */
                           } KzPassInfo;
 int kz_last_pass_info(KzScene *scene, KzPassInfo *out);

@@ -113,7 +113,7 @@ class KzRenderOpts(C.Structure):
                 ("nTiles", C.c_uint32), ("pipeline", C.c_int32), ("accumulate", C.c_int32), ("stream", C.c_void_p),
                 ("device", C.c_int32), ("passesInFlight", C.c_int32), ("passItems", C.c_uint64), ("maxStateBytes", C.c_uint64),
                 ("tune", KzTuning), ("tileDealing", C.c_int32), ("packedOutput", C.c_int32), ("dealer", C.POINTER(KzTileDealer)),
-                ("shadowBeside", C.c_int32), ("reserved0", C.c_int32)]
+                ("shadowBeside", C.c_int32), ("passHalves", C.c_int32)]
 
 
 class KzPassInfo(C.Structure):

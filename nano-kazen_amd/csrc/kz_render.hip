@@ -118,7 +118,7 @@ static void releaseReplica(KzDeviceState *ds) {
     for (auto &e : ds->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipStream_t st : ds->passStream) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : ds->evFilm) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {ds->evFork, ds->evCallA, ds->evCallB, ds->evProbe[0][0], ds->evProbe[0][1], ds->evProbe[1][0], ds->evProbe[1][1]}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ds->evFork, ds->evCallA, ds->evCallB, ds->evProbe[0][0], ds->evProbe[0][1], ds->evProbe[1][0], ds->evProbe[1][1], ds->evProbe[2][0], ds->evProbe[2][1], ds->evProbe[3][0], ds->evProbe[3][1]}) if (e) (void)hipEventDestroy(e);
     delete ds;
 }
 
@@ -839,6 +839,7 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     if (opts->passesInFlight < 0 || opts->passesInFlight > KZ_MAX_PASSES_IN_FLIGHT)
         return kz_fail(KZ_ERR_INVALID_ARG, "passesInFlight %d (0 = default, 1 .. %d)", opts->passesInFlight, KZ_MAX_PASSES_IN_FLIGHT);
     if (opts->shadowBeside < 0 || opts->shadowBeside > 2) return kz_fail(KZ_ERR_INVALID_ARG, "shadowBeside %d (0 = default, 1 = never, 2 = always)", opts->shadowBeside);
+    if (opts->passHalves < 0 || opts->passHalves > 2) return kz_fail(KZ_ERR_INVALID_ARG, "passHalves %d (0 = default, 1 = never, 2 = always)", opts->passHalves);
     const int pipeline = opts->pipeline ? opts->pipeline : 2;
 #ifdef KZ_EXPERIMENTS
     if ((rc = kzEnsureBvh2(scene, ds))) return rc;          // (development builds: several experiment kernels walk the BVH2)
@@ -855,6 +856,8 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     ds->lastStream = stream;
     KzTune tune;
     if ((rc = resolveTune(opts->tune, tune))) return rc;
+    // (a development build asked for one of kz_experiments.h's kernels: such a call runs its passes plainly)
+    const bool expTune = !tune.wide || tune.keyStack || tune.ldsTop || tune.leafQueue || tune.legacyTrace || tune.mixed || tune.shadeSplit;
     if (tune.filmGather != 0 && tune.filmGather != 3) return kz_fail(KZ_ERR_UNSUPPORTED, "KzTuning.filmGather %d: the staged gather kernel of round 1 is gone (round 6: the film is resolved from running tap sums for every filter); 0 = default, 3 = one lane per pixel", tune.filmGather);
     if ((rc = prepareTiles(scene, ds, opts->tiles, opts->nTiles, stream))) return rc;
     // the film: running tap sums of the frame's pixels (kz_film.hip), part of the replica like the film itself - cleared unless the call accumulates
@@ -992,52 +995,102 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         EventPair &ep = ds->events[ds->eventsUsed++];
         const dim3 grid((unsigned)((items + KZ_BLOCK - 1) / KZ_BLOCK));
         HIP_TRY(hipEventRecord(ep.a, pst));
-        // Where the shadow rays of a LARGE pass run is measured, not guessed (wfPass tells why no rule of thumb separates the scenes that gain 6 - 10 % from those
-        // that lose 1 %): with the option left at 0, one pass at a time and nobody counting, the replica times one large pass with the shadow rays beside the closest-hit
-        // rays and one of the same size in front of them - the film is the same bits either way -, waits for the second when a third comes, and keeps "beside" for its
-        // scene only if that was 3 % faster per item. (Such a wait is nothing new: a call already stays one pass ahead of a context that is still growing.)
+        // How a LARGE pass runs is measured, not guessed. Three ways give the same film bit for bit: (0) one stream; (1) the shadow rays of a bounce beside its
+        // closest-hit rays (wfPass tells why no rule of thumb separates the scenes that gain 6 - 10 % from those that lose 1 %); (2) the pass as two HALVES of its
+        // pixels side by side - two views of the context's arrays, the second on a stream of its own, disjoint pixels and therefore disjoint tap sums -, which lets
+        // one half's shade kernel run beside the other half's traversal (materials_scene + 7 %, C4 - 1.4 %). With both options left at 0, one pass at a time and
+        // nobody counting, the replica times one large pass each way and one stream twice (equal sizes), waits for the fourth when a fifth comes, and keeps for its
+        // scene what was fastest per item - "one stream" unless something beat it by 3 %. (Such a wait is nothing new: a call already stays one pass ahead of a context that still grows.)
         int sb = opts->shadowBeside, probe = -1;
-        if (pipeline == 2 && sb == 0 && items > KZ_BESIDE_ITEMS) {
-            if (multi || dealer || ds->statsOn) sb = 1;
+        bool halves = opts->passHalves == 2;
+        if (pipeline == 2 && opts->shadowBeside == 0 && opts->passHalves == 0 && items > KZ_BESIDE_ITEMS) {
+            if (multi || dealer || ds->statsOn || expTune) sb = 1;
             else {
-                if (ds->besideLarge < 0 && ds->probeLaunched == 2) {
-                    float tA = 0.f, tB = 0.f;
-                    HIP_TRY(hipEventSynchronize(ds->evProbe[1][1]));
-                    HIP_TRY(hipEventElapsedTime(&tA, ds->evProbe[0][0], ds->evProbe[0][1]));
-                    HIP_TRY(hipEventElapsedTime(&tB, ds->evProbe[1][0], ds->evProbe[1][1]));
-                    ds->probeMs[0] = tA; ds->probeMs[1] = tB;
-                    ds->besideLarge = (double)tA / (double)ds->probeItems[0] < 0.97 * (double)tB / (double)ds->probeItems[1] ? 1 : 0;
-                    KZ_TRACE("large passes of %zu items: %.2f ms beside, %.2f ms one stream -> %s", ds->probeItems[0], tA, tB, ds->besideLarge ? "beside" : "one stream");
+                if (ds->largeMode < 0 && ds->probeLaunched == 4) {
+                    HIP_TRY(hipEventSynchronize(ds->evProbe[3][1]));
+                    double per[4];
+                    for (int k = 0; k < 4; ++k) { HIP_TRY(hipEventElapsedTime(&ds->probeMs[k], ds->evProbe[k][0], ds->evProbe[k][1])); per[k] = (double)ds->probeMs[k] / (double)ds->probeItems[k]; }
+                    // probe 0 ran on one stream, 1 beside, 2 as halves, 3 on one stream again: the yardstick is the better of its two timings - the first pass at a
+                    // size is often slow (its context has just grown, behind the driver's wipe), and one slow pass must neither hide a gain nor invent one
+                    const double one = std::min(per[0], per[3]);
+                    ds->largeMode = 0;
+                    if (per[1] < 0.97 * one) ds->largeMode = 1;
+                    if (per[2] < 0.97 * one && per[2] < per[1]) ds->largeMode = 2;
+                    KZ_TRACE("large passes of %zu items: %.2f / %.2f ms one stream, %.2f ms beside, %.2f ms as halves -> mode %d", ds->probeItems[0], ds->probeMs[0], ds->probeMs[3], ds->probeMs[1], ds->probeMs[2], ds->largeMode);
                 }
-                if (ds->besideLarge >= 0) sb = ds->besideLarge ? 2 : 1;
-                else if (ds->probeLaunched == 0 || items > ds->probeItems[0]) { probe = 0; sb = 2; ds->probeLaunched = 0; }      // (a larger pass than the one timed: the context has grown - start over at this size)
-                else if (items == ds->probeItems[0]) { probe = 1; sb = 1; }
-                else sb = 1;                                                  // (a remainder pass: not comparable)
+                int mode = 0;
+                if (ds->largeMode >= 0) mode = ds->largeMode;
+                else if (ds->probeLaunched == 0 || items > ds->probeItems[0]) { probe = 0; ds->probeLaunched = 0; mode = 0; }      // (a larger pass than the one timed: the context has grown - start over at this size)
+                else if (items == ds->probeItems[0]) { probe = ds->probeLaunched; mode = probe == 3 ? 0 : probe; }
+                sb = mode == 1 ? 2 : 1; halves = mode == 2;                   // (a remainder pass of another size: one stream, not comparable)
+            }
+        }
+        if (halves && (pipeline != 2 || multi || dealer || expTune || nPixPass < 256)) halves = false;      // (passes in flight and dealt batches overlap already)
+        if (halves) {                                                         // (what the halves need is made before the clock of a timed pass starts)
+            if (!c.halfStream) {
+                HIP_TRY(hipStreamCreateWithFlags(&c.halfStream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&c.evHalfFork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&c.evHalfJoin, hipEventDisableTiming));
+            }
+            for (int h = 0; h < 2; ++h) {
+                if (!c.view[h]) c.view[h] = new PassCtx();
+                if (!c.view[h]->counts) KZ_ALLOC(&c.view[h]->counts, 8 * 520 * sizeof(uint32_t));
+                if ((rc = ensureOverflow(scene, ds, *c.view[h], tune, h ? c.halfStream : pst))) return rc;
             }
         }
         if (probe >= 0) {
             for (int k = 0; k < 2; ++k) if (!ds->evProbe[probe][k]) HIP_TRY(hipEventCreate(&ds->evProbe[probe][k]));
             HIP_TRY(hipEventRecord(ds->evProbe[probe][0], pst));
         }
-        if (pipeline == 2) {
-            if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams, sb))) return rc;
-            if (probe >= 0) { HIP_TRY(hipEventRecord(ds->evProbe[probe][1], pst)); ds->probeItems[probe] = items; ds->probeLaunched = probe + 1; }
-        }
-        else {
-            float *sJx = c.plane[0], *sJy = c.plane[1], *sR = c.plane[2], *sG = c.plane[3], *sB = c.plane[4];
+        const int prev = (ci + nCtx - 1) % nCtx;
+        ds->lastStageCtx = nullptr;
+        if (halves) {
+            // pixels [0, nA) of the pass in the first part of every array, pixels [nA, nPixPass) behind them (nA a multiple of 64 pixels: aligned sub-arrays)
+            const uint32_t nA = std::min(nPixPass - 64u, ((nPixPass + 1u) / 2u + 63u) & ~63u), nB = nPixPass - nA;
+            const size_t itemsA = (size_t)nA * Sp, itemsB = (size_t)nB * Sp;
+            for (int h = 0; h < 2; ++h) {
+                PassCtx &v = *c.view[h];
+                const size_t off = h ? itemsA : 0;
+                v.wf = c.wf;
+                v.wf.rayA.p += off; v.wf.rayB.p += off; v.wf.hit.p += off; v.wf.thr.p += off; v.wf.misc.p += off; v.wf.shA.p += off; v.wf.shB.p += off; v.wf.shL.p += off;
+                v.wf.smp += off;
+                for (int q = 0; q < 3; ++q) v.wf.queue[q] += off;
+                v.wf.counts = v.counts;
+                for (int k = 0; k < 5; ++k) v.plane[k] = c.plane[k] + off;
+            }
+            PassCtx &va = *c.view[0], &vb = *c.view[1];
+            HIP_TRY(hipEventRecord(c.evHalfFork, pst));
+            HIP_TRY(hipStreamWaitEvent(c.halfStream, c.evHalfFork, 0));
+            if ((rc = wfPass(scene, ds, va, pst, pixList, p0, nA, s, Sp, (uint32_t)itemsA, tune, beams, sb))) return rc;
+            if ((rc = wfPass(scene, ds, vb, c.halfStream, pixList + nA, p0 + nA, nB, s, Sp, (uint32_t)itemsB, tune, beams, sb))) return rc;
+            ds->lastInfo.shadowBeside = 2u;                                   // (kz_last_pass_info: the last pass ran as halves)
+            // the halves' pixels are disjoint, so are their tap sums: the two film stages need no order between them
+            if ((rc = kzFilmStage(scene, ds, va, pst, pixList, nA, Sp, nullptr, tune.filmGather == 3 ? 1 : 0))) return rc;
+            if ((rc = kzFilmStage(scene, ds, vb, c.halfStream, pixList + nA, nB, Sp, nullptr, tune.filmGather == 3 ? 1 : 0))) return rc;
+            { int rc_ = stageMark(va, pst, 4); if (rc_) return rc_; }
+            HIP_TRY(hipEventRecord(c.evHalfJoin, c.halfStream));
+            HIP_TRY(hipStreamWaitEvent(pst, c.evHalfJoin, 0));
+            HIP_TRY(hipEventRecord(ep.b, pst));
+            HIP_TRY(hipGetLastError());
+            ds->lastStageCtx = &va;                                           // (the stage clock of a pass in halves is its first half's)
+        } else {
+            if (pipeline == 2) { if ((rc = wfPass(scene, ds, c, pst, pixList, p0, nPixPass, s, Sp, (uint32_t)items, tune, beams, sb))) return rc; }
+            else {
+                float *sJx = c.plane[0], *sJy = c.plane[1], *sR = c.plane[2], *sG = c.plane[3], *sB = c.plane[4];
 #define KZ_MEGA(ST, EX) hipLaunchKernelGGL((kz_path_megakernel<ST, EX>), grid, dim3(KZ_BLOCK), 0, pst, P, ds->T, pixList, (uint32_t)items, Sp, s, \
                                        (const uint32_t *)nullptr, sJx, sJy, sR, sG, sB, ds->stats)
-            if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, KZ_X_ALL); else KZ_MEGA(true, 0); }
-            else { if (P.bsdfExt) KZ_MEGA(false, KZ_X_ALL); else KZ_MEGA(false, 0); }
+                if (ds->statsOn) { if (P.bsdfExt) KZ_MEGA(true, KZ_X_ALL); else KZ_MEGA(true, 0); }
+                else { if (P.bsdfExt) KZ_MEGA(false, KZ_X_ALL); else KZ_MEGA(false, 0); }
 #undef KZ_MEGA
+            }
+            HIP_TRY(hipEventRecord(ep.b, pst));
+            HIP_TRY(hipGetLastError());
+            // the film stage adds this pass's samples to the running tap sums of its pixels, behind the film stage of the pass before it (another stream's)
+            if ((rc = kzFilmStage(scene, ds, c, pst, pixList, nPixPass, Sp, (multi && pass > 0) ? ds->evFilm[prev] : nullptr, tune.filmGather == 3 ? 1 : 0))) return rc;
+            if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
         }
-        HIP_TRY(hipEventRecord(ep.b, pst));
-        HIP_TRY(hipGetLastError());
-        // the film stage adds this pass's samples to the running tap sums of its pixels, behind the film stage of the pass before it (another stream's)
-        const int prev = (ci + nCtx - 1) % nCtx;
-        if ((rc = kzFilmStage(scene, ds, c, pst, pixList, nPixPass, Sp, (multi && pass > 0) ? ds->evFilm[prev] : nullptr, tune.filmGather == 3 ? 1 : 0))) return rc;
+        if (probe >= 0) { HIP_TRY(hipEventRecord(ds->evProbe[probe][1], pst)); ds->probeItems[probe] = items; ds->probeLaunched = probe + 1; }      // (film stage included, the same for all three)
         if (multi || dealer) { HIP_TRY(hipEventRecord(ds->evFilm[ci], pst)); inFlight[ci] = true; }      // (a dealer paces itself on this event even with one context)
-        if (pipeline == 2) { int rc_ = stageMark(c, pst, 4); if (rc_) return rc_; }
         ds->lastCtx = ci;
         ++pass;
         return KZ_OK;
@@ -1109,7 +1162,7 @@ int kz_last_stage_ms(KzScene *scene, float *out6) {
     if (!out6) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
     for (int i = 0; i < 6; ++i) out6[i] = 0.f;
     HIP_TRY(hipStreamSynchronize(ds->lastStream));
-    const PassCtx &c = ds->ctxAt(ds->lastCtx);
+    const PassCtx &c = ds->lastStageCtx ? *ds->lastStageCtx : ds->ctxAt(ds->lastCtx);
     for (size_t i = 1; i < c.stageUsed; ++i) {
         float t = 0; HIP_TRY(hipEventElapsedTime(&t, c.stageEv[i - 1], c.stageEv[i]));
         const int k = c.stageKind[i];

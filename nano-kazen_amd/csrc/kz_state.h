@@ -133,25 +133,34 @@ struct PassCtx {
     uint32_t *litQueue = nullptr; size_t litCap = 0;             // kz_wf_trace_dq<2>: shadow rays that need the literal walk-through
     uint32_t *ovf = nullptr; size_t ovfCap = 0;
     hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;      // small passes: the shadow rays of a bounce beside its closest-hit rays (wfPass)
+    // A pass run as two HALVES of its pixels side by side (renderOn: KzRenderOpts::passHalves): two views of this context's arrays - the first and the second part
+    // of every array - each with its own counters, overflow stacks, side stream and stage clock, the second on a stream of its own. A view owns no arena.
+    PassCtx *view[2] = {nullptr, nullptr}; hipStream_t halfStream = nullptr; hipEvent_t evHalfFork = nullptr, evHalfJoin = nullptr;
     size_t wanted = 0;                                           // items the last call with the default schedule asked this context to hold (kz_render.hip: `earned`)
     uint64_t beamSeen = 0;                                       // the last beam-list build (KzDeviceState::beamSeq) this context's stream has waited for
     std::vector<hipEvent_t> stageEv; std::vector<int> stageKind; size_t stageUsed = 0;
     size_t items() const { return arena ? arena->mapped.load() : 0; }
-    size_t bytes() const { return (arena ? arena->bytes() : 0) + ovfCap * sizeof(uint32_t) + litCap * 4; }
+    size_t bytes() const { return (arena ? arena->bytes() : 0) + ovfCap * sizeof(uint32_t) + litCap * 4 + (view[0] ? view[0]->bytes() : 0) + (view[1] ? view[1]->bytes() : 0); }
     // gives the memory back (the context stays usable: it grows again on demand); the caller has synchronised the device
     void release() {
         if (arena) arena->shrinkTo(0);
         wf = KzWf{}; for (float *&q : plane) q = nullptr; wanted = 0;
         if (ovf) (void)hipFree(ovf); ovf = nullptr; ovfCap = 0;
         if (litQueue) (void)hipFree(litQueue); litQueue = nullptr; litCap = 0;
+        for (PassCtx *v : view) if (v) v->release();
     }
     // buffers sized for another frame (a pooled context): given back when a call is short of memory (the caller has synchronised the device)
     void trimAux() {
         if (ovf) { (void)hipFree(ovf); ovf = nullptr; ovfCap = 0; }
         if (litQueue) { (void)hipFree(litQueue); litQueue = nullptr; litCap = 0; }
+        for (PassCtx *v : view) if (v) v->trimAux();
     }
     void destroy() {
         release();
+        for (PassCtx *&v : view) if (v) { v->destroy(); delete v; v = nullptr; }
+        if (halfStream) { (void)hipStreamDestroy(halfStream); halfStream = nullptr; }
+        if (evHalfFork) { (void)hipEventDestroy(evHalfFork); evHalfFork = nullptr; }
+        if (evHalfJoin) { (void)hipEventDestroy(evHalfJoin); evHalfJoin = nullptr; }
         if (counts) (void)hipFree(counts); counts = nullptr;
         delete arena; arena = nullptr;
         for (auto &e : stageEv) (void)hipEventDestroy(e);
@@ -192,10 +201,12 @@ struct KzDeviceState {
     PassCtx &ctxAt(int i) { if (!ctx[i]) ctx[i] = kzCtxAcquire(device); return *ctx[i]; }
     std::vector<EventPair> events; size_t eventsUsed = 0;
     hipStream_t passStream[KZ_MAX_PASSES_IN_FLIGHT] = {}; hipEvent_t evFork = nullptr, evFilm[KZ_MAX_PASSES_IN_FLIGHT] = {}, evCallA = nullptr, evCallB = nullptr;
-    // LARGE passes with KzRenderOpts::shadowBeside = 0: the replica times one pass with the shadow rays beside the closest-hit rays [0] and one of the same size with one
-    // stream [1], then keeps the faster order for its scene (renderOn). besideLarge: -1 = not known yet, 0 = one stream, 1 = beside.
-    hipEvent_t evProbe[2][2] = {}; size_t probeItems[2] = {}; int probeLaunched = 0; int besideLarge = -1; float probeMs[2] = {};
+    // LARGE passes with KzRenderOpts::shadowBeside = passHalves = 0: the replica times four passes of one size - one stream [0], the shadow rays beside the closest-hit
+    // rays [1], two halves of its pixels side by side [2], one stream again [3] - then keeps the fastest way for its scene (renderOn).
+    // largeMode: -1 = not known yet, 0 = one stream, 1 = shadow rays beside, 2 = halves.
+    hipEvent_t evProbe[4][2] = {}; size_t probeItems[4] = {}; int probeLaunched = 0; int largeMode = -1; float probeMs[4] = {};
     int lastCtx = 0; bool lastDual = false; int streamMode = 0;
+    PassCtx *lastStageCtx = nullptr;                             // whose stage clock kz_last_stage_ms reads (a view, when the last pass ran as halves)
     // Beam lists (kz_wf_beam), one per pixel of the FRAME, built at most once per pixel and replica - the camera belongs to the scene - whatever tile
     // sets and pixel chunks the pixel is rendered in. They are built on the call's stream (evBeam / beamSeq: the passes wait for the latest build);
     // beamDone remembers the ranges of the CURRENT pixel list that have been handed to the kernel (it skips pixels that already have a list).

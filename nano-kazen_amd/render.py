@@ -61,7 +61,7 @@ class Scene:
         return [int(buf[i]) for i in range(n.value)]
 
     def _opts(self, sample_begin=0, sample_end=0, tiles=None, accumulate=False, pipeline=0, stream=None, device=None,
-              passes_in_flight=0, pass_items=0, max_state_bytes=0, tune=None, tile_dealing=0, shadow_beside=0):
+              passes_in_flight=0, pass_items=0, max_state_bytes=0, tune=None, tile_dealing=0, shadow_beside=0, pass_halves=0):
         o = abi.KzRenderOpts()
         o.sampleBegin, o.sampleEnd = sample_begin, sample_end
         keep = None
@@ -75,12 +75,13 @@ class Scene:
         o.passesInFlight, o.passItems, o.maxStateBytes = int(passes_in_flight), int(pass_items), int(max_state_bytes)
         o.tileDealing = int(tile_dealing)
         o.shadowBeside = int(shadow_beside)
+        o.passHalves = int(pass_halves)
         for k, v in (tune or {}).items():
             setattr(o.tune, k, int(v))
         return o, keep
 
     def render(self, sample_begin=0, sample_end=0, tiles=None, accumulate=False, pipeline=0, stream=None, **kw):
-        """kz_render. Keywords: device, passes_in_flight, pass_items, max_state_bytes, shadow_beside, tune={KzTuning field: value}."""
+        """kz_render. Keywords: device, passes_in_flight, pass_items, max_state_bytes, shadow_beside, pass_halves, tune={KzTuning field: value}."""
         o, keep = self._opts(sample_begin, sample_end, tiles, accumulate, pipeline, stream, **kw)
         abi.check(self.lib, self.lib.kz_render(self.h, C.byref(o)))
 

@@ -1,11 +1,12 @@
 #!/bin/bash
-# bench.py with the shadow kernels of every pass in front of (--shadow-beside 1) / beside (2) the closest-hit kernel, alternating
+# bench.py with every pass of the timed steps on one stream / with its shadow rays beside / as two halves / as the library decides, alternating
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r06v; mkdir -p $OUT
-for rep in 1 2; do for mode in 1 2; do
-  timeout -k 10 400 python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity --no-ext-scenes --no-cold-job --shadow-beside $mode > $OUT/bench_sb${mode}_$rep.json 2> $OUT/bench_sb${mode}_$rep.err || { tail -n 5 $OUT/bench_sb${mode}_$rep.err; exit 1; }
-  python3 - $OUT/bench_sb${mode}_$rep.json $mode <<'PY'
+for rep in 1 2; do for mode in "--shadow-beside 1 --pass-halves 1" "--shadow-beside 2 --pass-halves 1" "--shadow-beside 1 --pass-halves 2" ""; do
+  tag=$(echo "m$mode" | tr -d ' -'); 
+  timeout -k 10 400 python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-parity --no-ext-scenes --no-cold-job --no-asset-scene $mode > $OUT/bench_${tag}_$rep.json 2> $OUT/bench_${tag}_$rep.err || { tail -n 5 $OUT/bench_${tag}_$rep.err; exit 1; }
+  python3 - $OUT/bench_${tag}_$rep.json "$mode" <<'PY'
 import json, sys
-d = json.load(open(sys.argv[1])); r = d.get("reference_scene") or {}
-print("--shadow-beside %s  value %8.1f  ms/step %7.2f   reference_scene %s / beside %s" % (sys.argv[2], d["value"], d["ms_per_step"], r.get("value"), (r.get("shadow_beside") or {}).get("value")), flush=True)
+d = json.load(open(sys.argv[1]))
+print("%-40s value %8.1f  ms/step %7.2f  %s" % (sys.argv[2] or "(defaults)", d["value"], d["ms_per_step"], d["config"].get("how_the_last_timed_pass_ran")), flush=True)
 PY
 done; done

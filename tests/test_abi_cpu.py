@@ -59,7 +59,7 @@ def test_render_opts_layout_v5(kz):
     o = kz.abi.KzRenderOpts
     assert (o.sampleBegin.offset, o.sampleEnd.offset, o.tiles.offset, o.nTiles.offset, o.pipeline.offset, o.accumulate.offset, o.stream.offset) == (0, 4, 8, 16, 20, 24, 32)
     assert o.device.offset == 40 and o.passItems.offset == 48 and o.maxStateBytes.offset == 56 and o.tune.offset == 64
-    assert C.sizeof(kz.abi.KzTuning) == 64 and o.tileDealing.offset == 128 and o.packedOutput.offset == 132 and o.dealer.offset == 136 and o.shadowBeside.offset == 144 and C.sizeof(o) == 152
+    assert C.sizeof(kz.abi.KzTuning) == 64 and o.tileDealing.offset == 128 and o.packedOutput.offset == 132 and o.dealer.offset == 136 and o.shadowBeside.offset == 144 and o.passHalves.offset == 148 and C.sizeof(o) == 152
 
 
 @pytest.mark.parametrize("w,h,tile,parts", [(1920, 1080, 64, 8), (3840, 2160, 64, 8), (1920, 1080, 128, 3), (100, 70, 32, 5), (64, 64, 64, 4)])

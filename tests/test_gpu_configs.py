@@ -671,6 +671,21 @@ def test_shadow_rays_beside_the_closest_hit_rays(gpu_lib, kz, O):
         npx = sc.width * sc.height
         sc.render(shadow_beside=2, pass_items=npx * 2, passes_in_flight=3)              # every context has its own side stream
         assert np.array_equal(sc.film(), one_stream), name
+        # KzRenderOpts::passHalves = 2: the pass as two halves of its pixels side by side (two views of the context's arrays, two streams) - with either placement of
+        # the shadow rays, over several passes, on a tile set, accumulating
+        for kw in (dict(pass_halves=2, shadow_beside=1), dict(pass_halves=2, shadow_beside=2), dict(pass_halves=2), dict(pass_halves=2, pass_items=npx * 3, passes_in_flight=1)):
+            sc.render(**kw)
+            assert sc.last_pass_info()["shadowBeside"] == 2, (name, kw)
+            assert np.array_equal(sc.film(), one_stream), (name, kw)
+        half = sc.sample_count // 2
+        sc.render(0, half, pass_halves=2); sc.render(half, sc.sample_count, accumulate=True, pass_halves=2, shadow_beside=2)
+        assert np.array_equal(sc.film(), one_stream), name
+        tiles = [(16, 8, 64, 48), (0, 56, 96, 32)]
+        sc.render(tiles=tiles, shadow_beside=1); on_tiles = sc.film()
+        sc.render(tiles=tiles, pass_halves=2)
+        assert sc.last_pass_info()["shadowBeside"] == 2 and np.array_equal(sc.film(), on_tiles), name
+        sc.render(pass_halves=2, pass_items=npx * 2, passes_in_flight=2)                # (ignored with passes in flight: they overlap already)
+        assert sc.last_pass_info()["shadowBeside"] != 2 and np.array_equal(sc.film(), one_stream), name
         sc.set_stats(True)
         sc.render(shadow_beside=2); s2 = sc.stats(reset=True)
         assert np.array_equal(sc.film(), one_stream), name
@@ -682,13 +697,16 @@ def test_shadow_rays_beside_the_closest_hit_rays(gpu_lib, kz, O):
         assert np.array_equal(one_stream, ora.render_canonical(threads=0)), name
         with pytest.raises(kz.abi.KzError):
             sc.render(shadow_beside=3)
+        with pytest.raises(kz.abi.KzError):
+            sc.render(pass_halves=3)
         sc.close()
 
 
-def test_large_passes_measure_where_their_shadow_rays_run(gpu_lib, kz):
-    """KzRenderOpts::shadowBeside = 0 on passes above 2^26 items: the replica runs its first large pass with the shadow rays beside the closest-hit rays, the next one of
-    that size in front of them, and keeps what was faster for every later one (the decision itself depends on the scene and the clock - the reference's q1 asset gains
-    7 - 10 % at this size, profiles/r06v_shadow_beside - so only its shape is asserted: probe, probe, then one answer for good). Explicit 1 / 2 bypass it; the film is the same bits."""
+def test_large_passes_measure_how_they_run(gpu_lib, kz):
+    """KzRenderOpts::shadowBeside = passHalves = 0 on passes above 2^26 items: the replica runs its first large pass on one stream, the next one of that size with the shadow
+    rays beside the closest-hit rays, a third as two halves, a fourth on one stream again, and keeps what was fastest for every later one (the decision itself depends on the scene and the clock -
+    the reference's q1 asset gains 7 - 10 % beside at this size, profiles/r06v_shadow_beside - so only its shape is asserted: four probes, then one answer for good).
+    Explicit values bypass it; the film is the same bits."""
     q1 = os.path.join(ROOT, "tests", "golden", "q1_default_m0_r0.5.npz")
     desc = kz.scenes.load_npz(q1, overrides={"camera": {"width": 1920, "height": 1080}, "sampler": {"type": "independent", "sampleCount": 64, "seed": 0}})
     sc = kz.Scene(desc, device=0)
@@ -697,16 +715,21 @@ def test_large_passes_measure_where_their_shadow_rays_run(gpu_lib, kz):
     info = sc.last_pass_info()
     assert info["passes"] == 1 and info["largestPassItems"] == 1920 * 1080 * 64 and info["shadowBeside"] == 0
     one_stream = sc.film()
+    sc.render(); assert sc.last_pass_info()["shadowBeside"] == 0      # timed in front
     sc.render(); assert sc.last_pass_info()["shadowBeside"] == 1      # timed beside
     assert np.array_equal(sc.film(), one_stream)
-    sc.render(); assert sc.last_pass_info()["shadowBeside"] == 0      # timed in front
-    sc.render(); kept = sc.last_pass_info()["shadowBeside"]           # waits for the second, decides
+    sc.render(); assert sc.last_pass_info()["shadowBeside"] == 2      # timed as halves
+    assert np.array_equal(sc.film(), one_stream)
+    sc.render(); assert sc.last_pass_info()["shadowBeside"] == 0      # timed in front once more (the yardstick is the better of the two)
+    sc.render(); kept = sc.last_pass_info()["shadowBeside"]           # waits for the fourth, decides
     assert np.array_equal(sc.film(), one_stream)
     for _ in range(2):
         sc.render(); assert sc.last_pass_info()["shadowBeside"] == kept
-    print("q1 asset, passes of 2^27 items: the replica keeps its shadow rays", "beside" if kept else "in front of", "the closest-hit rays")
+    print("q1 asset, passes of 2^27 items: the replica keeps", ("one stream", "its shadow rays beside the closest-hit rays", "halves")[kept])
     sc.render(shadow_beside=2); assert sc.last_pass_info()["shadowBeside"] == 1
     sc.render(shadow_beside=1); assert sc.last_pass_info()["shadowBeside"] == 0
+    sc.render(pass_halves=2); assert sc.last_pass_info()["shadowBeside"] == 2 and np.array_equal(sc.film(), one_stream)
+    sc.render(pass_halves=1); assert sc.last_pass_info()["shadowBeside"] == 0      # (one option said: the other follows its plain rule - small passes beside, large ones in front)
     sc.set_stats(True); sc.render(); sc.set_stats(False)              # the counting kernels are not what was timed: in front
     assert sc.last_pass_info()["shadowBeside"] == 0 and np.array_equal(sc.film(), one_stream)
     sc.render(0, 16); assert sc.last_pass_info()["shadowBeside"] == 1  # a small pass (2^25 items): beside, whatever was decided for the large ones
