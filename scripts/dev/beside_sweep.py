@@ -19,7 +19,8 @@ jobs = [("q1 asset 256x256x16 (C1)", lambda: q1_at(256, 256, 16)), ("q1 asset 25
         ("q1 asset 1920x1080x512", lambda: q1_at(1920, 1080, 512)),
         ("hero 960x540x16", lambda: S.hero_scene(960, 540, 16)), ("hero 1920x1080x64", lambda: S.hero_scene(1920, 1080, 64)), ("hero 1920x1080x256 (C3)", lambda: S.hero_scene(1920, 1080, 256))]
 if len(sys.argv) > 1: jobs = [j for j in jobs if any(k in j[0] for k in sys.argv[1:])]
-MODES = {"one stream": 1, "beside": 2, "default": 0}
+MODES = {"one stream": dict(shadow_beside=1, pass_halves=1), "beside": dict(shadow_beside=2, pass_halves=1), "halves": dict(shadow_beside=1, pass_halves=2),
+         "halves + beside": dict(shadow_beside=2, pass_halves=2), "default": {}}
 for name, make in jobs:
     d = make()
     sc = kz.Scene(d, device=0)
@@ -27,10 +28,10 @@ for name, make in jobs:
     res = {}
     for mode, sb in MODES.items():
         ts = []
-        for i in range(6):
-            t0 = time.perf_counter(); sc.render(shadow_beside=sb); sc.sync(); ts.append(time.perf_counter() - t0)
-        res[mode] = (min(ts[1:]), sc.film().copy())
-    a, b, c = res["one stream"], res["beside"], res["default"]
-    print("%-36s items 2^%.1f  one stream %8.3f ms  beside %8.3f ms (%+5.1f %%)  default %8.3f ms (%+5.1f %%)  films equal: %s" % (
-        name, np.log2(items), 1e3 * a[0], 1e3 * b[0], 100 * (b[0] / a[0] - 1), 1e3 * c[0], 100 * (c[0] / a[0] - 1), np.array_equal(a[1], b[1]) and np.array_equal(a[1], c[1])), flush=True)
+        for i in range(8 if mode == "default" else 6):
+            t0 = time.perf_counter(); sc.render(**sb); sc.sync(); ts.append(time.perf_counter() - t0)
+        res[mode] = (min(ts[5:] if mode == "default" else ts[1:]), sc.film().copy())
+    a = res["one stream"]
+    print("%-36s items 2^%.1f  one stream %8.3f ms  " % (name, np.log2(items), 1e3 * a[0]) + "  ".join("%s %8.3f ms (%+5.1f %%)" % (k, 1e3 * v[0], 100 * (v[0] / a[0] - 1)) for k, v in res.items() if k != "one stream")
+          + "  films equal: %s" % all(np.array_equal(a[1], v[1]) for v in res.values()), flush=True)
     del sc
