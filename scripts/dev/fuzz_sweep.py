@@ -1,5 +1,5 @@
 """A wider randomized parity sweep than the CI suite carries (tests/test_gpu_parity.py::_fuzz_scene, other seeds): HIP film vs the CPU oracle, megakernel == wavefront bit
-for bit, counting == product kernels, tile sets / sample ranges / dealer == one shot. Run through gpurun when GPU minutes are to spare:
+for bit, counting == product kernels, one stream / shadow rays beside / pass halves, tile sets / sample ranges / dealer == one shot. Run through gpurun when GPU minutes are to spare:
     python scripts/dev/fuzz_sweep.py [first_seed] [n_scenes] [--rich]"""
 import importlib, os, sys, time
 import numpy as np
@@ -34,6 +34,9 @@ for seed in range(first, first + n):
     sc.render(pipeline=1)
     ok_mega = np.array_equal(sc.film(), film)
     sc.set_stats(True); sc.render(); ok_stats = np.array_equal(sc.film(), film); sc.set_stats(False)
+    # how a pass runs (the first render above: shadow rays beside the closest-hit rays, the default of a small pass): one stream; two halves side by side
+    sc.render(shadow_beside=1, pass_halves=1); ok_modes = np.array_equal(sc.film(), film)
+    sc.render(shadow_beside=seed % 3, pass_halves=2); ok_modes = ok_modes and np.array_equal(sc.film(), film)
     w, h = d.camera["width"], d.camera["height"]
     tiles = kz.shard.deal_tiles(w, h, 1, 0, 32)
     counter = np.zeros(1, np.uint32)
@@ -50,7 +53,7 @@ for seed in range(first, first + n):
     sc.render()
     ok_rng = ok_rng and np.array_equal(sc.merge_tiles(sc.empty_film(), t64, sc.film_tiles(t64)), film)
     line = "seed %d %s %dx%dx%d depth %d tris %d: L2 %.2e (scale %.1f) film-bits %s %s" % (seed, d.sampler["type"], w, h, sc.sample_count, d.integrator["maxDepth"], d.n_tris(), err, scale, "equal" if bits else "DIFFER",
-            ("ok" + note) if (ok and ok_mega and ok_stats and ok_deal and ok_rng) else "FAIL oracle=%s mega=%s stats=%s deal=%s ranges=%s%s" % (ok, ok_mega, ok_stats, ok_deal, ok_rng, note))
+            ("ok" + note) if (ok and ok_mega and ok_stats and ok_deal and ok_rng and ok_modes) else "FAIL oracle=%s mega=%s stats=%s deal=%s ranges=%s modes=%s%s" % (ok, ok_mega, ok_stats, ok_deal, ok_rng, ok_modes, note))
     print(line, flush=True)
     if "FAIL" in line:
         bad.append(seed)
