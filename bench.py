@@ -507,7 +507,8 @@ def main():
                           "samples_per_step": int(float(px.item()) * spp_step), "bvh_nodes": bvh["nNodes"], "bvh_depth": bvh["maxDepth"],
                           "image_mean": round(float(rgb.mean()), 5), "commit": commit,
                           "items_per_pass_per_rank": items_per_pass_per_rank, "sampler_table_spp": spp_table,
-                          "how_the_last_timed_pass_ran": ("one stream", "its shadow rays beside its closest-hit rays", "as two halves side by side")[info["shadowBeside"]], "warmup_wait_for_context_s": round(grow_wait_s, 2),
+                          "how_the_last_timed_pass_ran": ("one stream", "its shadow rays beside its closest-hit rays", "as two halves side by side")[info["shadowBeside"]],
+                          "large_passes_measured_by_the_replica": scene.pass_mode_info(), "warmup_wait_for_context_s": round(grow_wait_s, 2),
                           "first_call_ms": first_call_ms, "first_call": "the first (warm-up) step: beam lists of every pixel (kz_wf_beam, once per pixel and replica), the pass context "
                                                                         "growing (its memory is mapped on a side thread while the first passes run), then the step itself; a timed step is ms_per_step"},
                "roofline": roofline, "cpu_baseline": cpu, "cold_job": cold, "parity": parity}
@@ -578,6 +579,8 @@ def ext_scenes(kz, device_index, cpu=True):
             rec = {"workload": what, "samples": n, "value": round(n / min(ts[4:] if n > (1 << 26) else ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
                    "image_mean": round(float(sc.rgb().mean()), 5), "passes": sc.last_pass_info()["passes"], "tris": desc.n_tris(),
                    "how_the_last_pass_ran": ("one stream", "shadow rays beside", "halves")[sc.last_pass_info()["shadowBeside"]]}
+            if n > (1 << 26):
+                rec["large_passes_measured_by_the_replica"] = sc.pass_mode_info()
             if cpu and cpu_mode:
                 import oracle as O
                 ora = O.OracleScene(desc)
@@ -631,7 +634,7 @@ def reference_scene(kz, device_index, spp):
             t0 = time.perf_counter(); sc.render(0, spp, shadow_beside=mode); sc.sync(); out.append(time.perf_counter() - t0)
     beside = {"value": round(n / min(tb) / 1e6, 1), "render_s": [round(t, 4) for t in tb], "film_equal": bool(np.array_equal(film0, sc.film())), "option": "KzRenderOpts::shadowBeside = 2",
               "one_stream": {"value": round(n / min(t1) / 1e6, 1), "render_s": [round(t, 4) for t in t1], "option": "KzRenderOpts::shadowBeside = 1"},
-              "kept_by_the_replica": ("one stream", "shadow rays beside", "halves")[kept]}
+              "kept_by_the_replica": ("one stream", "shadow rays beside", "halves")[kept], "large_passes_measured_by_the_replica": sc.pass_mode_info()}
     rec = {"workload": "scene/2022_q1/parameters/default_m0_r0.5.xml (36 378 triangles, the reference's own scene file via tests/golden/q1_default_m0_r0.5.npz), %dx%d, independent sampler, "
                        "path_mis maxDepth %d, sample indices [0, %d) of the file's %d" % (sc.width, sc.height, d.integrator["maxDepth"], spp, sc.sample_count),
            "value": round(n / min(ts[4:]) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),

@@ -109,6 +109,11 @@ typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t i
                             uint64_t contextItems;      /* items the first pass context holds NOW (it may still be growing towards itemsPerPass) */
                           } KzPassInfo;
 int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
+/* What the replica on `device` (-1: the primary one) has measured about its LARGE passes (above 2^26 items, KzRenderOpts::shadowBeside = passHalves = 0): the four timed passes
+ * of `items` items each and what it keeps for the scene. kept: -1 = not decided yet (timedPasses of the four have been launched), 0 = one stream, 1 = shadow rays beside the
+ * closest-hit rays, 2 = two halves side by side; the times (ms, film stage included) are there once it has decided. */
+typedef struct KzPassModeInfo { int32_t kept; uint32_t timedPasses; uint64_t items; float msOneStream[2]; float msShadowBeside; float msHalves; } KzPassModeInfo;
+int kz_pass_mode_info(KzScene *scene, int device, KzPassModeInfo *out);
 /* Why the pass context of the last kz_render stopped growing short of its target ("" if it did not): such a call succeeds on what there is. */
 int kz_last_grow_note(KzScene *scene, char *buf, size_t cap);
 

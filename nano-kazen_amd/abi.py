@@ -125,6 +125,10 @@ class KzPassInfo(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class KzPassModeInfo(C.Structure):
+    _fields_ = [("kept", C.c_int32), ("timedPasses", C.c_uint32), ("items", C.c_uint64), ("msOneStream", C.c_float * 2), ("msShadowBeside", C.c_float), ("msHalves", C.c_float)]
+
+
 class KzPlanQuery(C.Structure):
     _fields_ = [("pipeline", C.c_int32), ("nPix", C.c_uint32), ("sampleBegin", C.c_uint32), ("sampleEnd", C.c_uint32), ("passItems", C.c_uint64),
                 ("passesInFlight", C.c_int32), ("sppPerPass", C.c_int32), ("limitBytes", C.c_uint64), ("bytesPerItem", C.c_uint64), ("dealer", C.c_int32),
@@ -171,7 +175,7 @@ EXPORTS = ["kz_scene_create", "kz_scene_destroy", "kz_scene_bvh_info", "kz_scene
            "kz_scene_evict", "kz_scene_devices", "kz_render_tiles", "kz_render_multi", "kz_deal_tiles", "kz_film_merge", "kz_film_download_on",
            "kz_film_clear_on", "kz_sync_on", "kz_last_pass_info", "kz_device_mem_info", "kz_camera_rays", "kz_light_query", "kz_kat_exact_math", "kz_kat_permute", "kz_kat_fresnel", "kz_kat_math", "kz_build_flags",
            "kz_tiles_packed_floats", "kz_film_download_tiles", "kz_film_merge_tiles", "kz_film_merge_rects", "kz_device_trim", "kz_kat_dpdf", "kz_kat_pow4", "kz_last_grow_note",
-           "kz_plan_passes", "kz_plan_schedule"]
+           "kz_plan_passes", "kz_plan_schedule", "kz_pass_mode_info"]
 # exported by DEVELOPMENT builds of the library only (-DKZ_EXPERIMENTS): the hooks that are process-global state. The product library must NOT export them.
 DEV_ONLY_EXPORTS = ["kz_debug_fail_alloc", "kz_debug_fail_device", "kz_debug_grow_delay", "kz_debug_trace", "kz_debug_alias_devices"]
 
@@ -243,6 +247,7 @@ def load_library(path=None):
     lib.kz_film_clear_on.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.kz_sync_on.argtypes = [C.c_void_p, C.c_int]
     lib.kz_last_pass_info.argtypes = [C.c_void_p, C.POINTER(KzPassInfo)]
+    lib.kz_pass_mode_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KzPassModeInfo)]
     lib.kz_device_mem_info.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.kz_device_trim.argtypes = [C.c_int]
     lib.kz_last_grow_note.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]

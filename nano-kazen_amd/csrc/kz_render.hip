@@ -1189,6 +1189,17 @@ int kz_last_pass_info(KzScene *scene, KzPassInfo *out) {
     return KZ_OK;
 }
 
+// What the replica on `device` (-1: the primary one) has measured about its large passes (renderOn: KzRenderOpts::shadowBeside / passHalves at 0).
+int kz_pass_mode_info(KzScene *scene, int device, KzPassModeInfo *out) {
+    KzDeviceState *ds; int rc;
+    if ((rc = findReplica(scene, device, &ds))) return rc;
+    if (!out) return kz_fail(KZ_ERR_INVALID_ARG, "null out");
+    *out = KzPassModeInfo{};
+    out->kept = ds->largeMode; out->timedPasses = (uint32_t)ds->probeLaunched; out->items = ds->probeItems[0];
+    if (ds->largeMode >= 0) { out->msOneStream[0] = ds->probeMs[0]; out->msOneStream[1] = ds->probeMs[3]; out->msShadowBeside = ds->probeMs[1]; out->msHalves = ds->probeMs[2]; }
+    return KZ_OK;
+}
+
 int kz_sync_on(KzScene *scene, int device) {
     KzDeviceState *ds; int rc;
     if ((rc = findReplica(scene, device, &ds))) return rc;

@@ -178,6 +178,15 @@ class Scene:
         abi.check(self.lib, self.lib.kz_last_pass_info(self.h, C.byref(info)))
         return info.as_dict()
 
+    def pass_mode_info(self, device=-1):
+        """kz_pass_mode_info: what the replica measured about its large passes and what it keeps (None while undecided)."""
+        m = abi.KzPassModeInfo()
+        abi.check(self.lib, self.lib.kz_pass_mode_info(self.h, int(device), C.byref(m)))
+        d = {"kept": (None, "one stream", "shadow rays beside", "halves")[m.kept + 1], "timed_passes": int(m.timedPasses), "items": int(m.items)}
+        if m.kept >= 0:
+            d.update({"ms_one_stream": [round(float(m.msOneStream[0]), 2), round(float(m.msOneStream[1]), 2)], "ms_shadow_beside": round(float(m.msShadowBeside), 2), "ms_halves": round(float(m.msHalves), 2)})
+        return d
+
     def last_grow_note(self):
         """Why the pass context of the last render stopped growing short of its target ('' if it did not)."""
         buf = C.create_string_buffer(512)

@@ -39,7 +39,7 @@ def test_struct_sizes_match_the_header(kz, tmp_path):
     import subprocess
     a = kz.abi
     names = ["KzBSDF", "KzImage", "KzTexture", "KzLight", "KzMesh", "KzFilter", "KzCamera", "KzSampler", "KzIntegrator", "KzBackground",
-             "KzSceneDesc", "KzTile", "KzTuning", "KzTileDealer", "KzRenderOpts", "KzPassInfo", "KzStats", "KzHit", "KzBvhInfo", "KzPlanQuery", "KzPlanAnswer"]
+             "KzSceneDesc", "KzTile", "KzTuning", "KzTileDealer", "KzRenderOpts", "KzPassInfo", "KzStats", "KzHit", "KzBvhInfo", "KzPlanQuery", "KzPlanAnswer", "KzPassModeInfo"]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "kazen_mi355x_dev.h"\nint main(void){' +
                    "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}\n")

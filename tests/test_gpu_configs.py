@@ -721,11 +721,14 @@ def test_large_passes_measure_how_they_run(gpu_lib, kz):
     sc.render(); assert sc.last_pass_info()["shadowBeside"] == 2      # timed as halves
     assert np.array_equal(sc.film(), one_stream)
     sc.render(); assert sc.last_pass_info()["shadowBeside"] == 0      # timed in front once more (the yardstick is the better of the two)
+    assert sc.pass_mode_info()["kept"] is None and sc.pass_mode_info()["timed_passes"] == 4 and sc.pass_mode_info()["items"] == 1920 * 1080 * 64
     sc.render(); kept = sc.last_pass_info()["shadowBeside"]           # waits for the fourth, decides
+    m = sc.pass_mode_info()
+    assert m["kept"] == ("one stream", "shadow rays beside", "halves")[kept] and min(m["ms_one_stream"] + [m["ms_shadow_beside"], m["ms_halves"]]) > 10.0, m
     assert np.array_equal(sc.film(), one_stream)
     for _ in range(2):
         sc.render(); assert sc.last_pass_info()["shadowBeside"] == kept
-    print("q1 asset, passes of 2^27 items: the replica keeps", ("one stream", "its shadow rays beside the closest-hit rays", "halves")[kept])
+    print("q1 asset, passes of 2^27 items: the replica keeps", ("one stream", "its shadow rays beside the closest-hit rays", "halves")[kept], m)
     sc.render(shadow_beside=2); assert sc.last_pass_info()["shadowBeside"] == 1
     sc.render(shadow_beside=1); assert sc.last_pass_info()["shadowBeside"] == 0
     sc.render(pass_halves=2); assert sc.last_pass_info()["shadowBeside"] == 2 and np.array_equal(sc.film(), one_stream)
