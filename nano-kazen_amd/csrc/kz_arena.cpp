@@ -198,7 +198,15 @@ bool KzArena::growOneLevel(size_t first) {
     Level L{};
     L.firstItem = first; L.items = items; L.mappedArrays = 0;
     hipError_t e = hipSuccess; const char *what = "";
-    for (int a = 0; a < kArrays; ++a) {
+    // The HIP runtime allocates device memory of its own while kernels are being dispatched - the scratch of a queue's first kernel that spills (the packet kernel's
+    // 12 B, the EXT shade kernels' 32 - 240 B per lane), the signals of a new stream - and when THAT fails there is no error code to hand back: the queue aborts the
+    // process (HSA_STATUS_ERROR_OUT_OF_RESOURCES; seen with several replicas sharing one card, each growing into what the others had just released). A level is
+    // therefore only mapped while kRuntimeReserve bytes stay free behind it; otherwise the context stops growing and the passes run on what there is.
+    {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB < items * bytesPerItem() + kRuntimeReserve) { e = hipErrorOutOfMemory; what = "keeping a reserve for the HIP runtime: hipMemCreate not attempted,"; }
+    }
+    for (int a = 0; a < kArrays && e == hipSuccess; ++a) {
         const size_t bytes = items * elem[a];
         if (injectedFailure()) { e = hipErrorOutOfMemory; what = "hipMemCreate (kz_debug_fail_alloc)"; break; }
         if ((e = hipMemCreate(&L.h[a], bytes, &prop, 0)) != hipSuccess) { what = "hipMemCreate"; break; }

@@ -89,6 +89,7 @@ struct KzArena {
     size_t levelItems = (size_t)1 << 23;      // items of one level, fixed while the ranges are reserved (every chunk of an array has the same size): 2^23 (128 MB chunks for the
                                               // 16-B arrays, 32 MB for the 4-B ones) for a context asked to hold up to 2^27 items, 2^25 (512 / 128 MB) for a larger one
     static constexpr size_t kSmallMax = (size_t)1 << 23;
+    static constexpr size_t kRuntimeReserve = (size_t)2 << 30;     // bytes a growing context leaves free for the HIP runtime's own device allocations (growOneLevel)
     int device;
     size_t capItems = 0;                      // items the virtual ranges (one per array) are reserved for; 0: no reservation (a small or empty context)
     size_t smallItems = 0;                    // items of the hipMalloc arrays of a small context

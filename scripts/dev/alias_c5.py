@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 kz = importlib.import_module("nano-kazen_amd")
 lib = kz.abi.load_dev_library()
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+modes = dict(shadow_beside=1, pass_halves=1) if "--one-stream" in sys.argv else {}      # (--one-stream: no replica times its large passes)
 lib.kz_debug_alias_devices(8)
 desc = kz.scenes.random_triangles(1000000, 3840, 2160, 4096, sampler="pmj02bn", seed=1)
 sc = kz.Scene(desc, lib=lib)
@@ -17,7 +18,7 @@ for n in (1, 2, 4):
     cap = int(160e9 / n)                                               # the aliases share one card: each replica's pass contexts capped
     for dealing in (0, 1):
         t0 = time.perf_counter()
-        film, ms = sc.render_multi(list(range(n)), sample_begin=0, sample_end=spp, tile_dealing=dealing, max_state_bytes=cap)
+        film, ms = sc.render_multi(list(range(n)), sample_begin=0, sample_end=spp, tile_dealing=dealing, max_state_bytes=cap, **modes)
         dt = time.perf_counter() - t0
         if one is None:
             one = film
