@@ -202,9 +202,18 @@ bool KzArena::growOneLevel(size_t first) {
     // 12 B, the EXT shade kernels' 32 - 240 B per lane), the signals of a new stream - and when THAT fails there is no error code to hand back: the queue aborts the
     // process (HSA_STATUS_ERROR_OUT_OF_RESOURCES; seen with several replicas sharing one card, each growing into what the others had just released). A level is
     // therefore only mapped while kRuntimeReserve bytes stay free behind it; otherwise the context stops growing and the passes run on what there is.
+    // Memory that is being WIPED (released a moment ago, by anybody) is not reported free yet, and a hipMemCreate would simply wait for it: "too little free" only
+    // counts once the figure has stopped rising (the wipe moves ~33 GB/s; 100 ms without 64 MB more is a full card, not a wipe).
     {
-        size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB < items * bytesPerItem() + kRuntimeReserve) { e = hipErrorOutOfMemory; what = "keeping a reserve for the HIP runtime: hipMemCreate not attempted,"; }
+        const size_t needB = items * bytesPerItem() + kRuntimeReserve;
+        size_t freeB = 0, totalB = 0, best = 0; int still = 0;
+        while (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB < needB) {
+            still = freeB <= best + ((size_t)64 << 20) ? still + 1 : 0;
+            best = std::max(best, freeB);
+            if (still >= 10) { e = hipErrorOutOfMemory; what = "the device is full (2 GB are left to the HIP runtime's own allocations): mapping"; break; }
+            { std::lock_guard<std::mutex> g(m); if (stop || first >= target) return false; }      // (nobody wants this level any more)
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
     }
     for (int a = 0; a < kArrays && e == hipSuccess; ++a) {
         const size_t bytes = items * elem[a];

@@ -102,8 +102,12 @@ int kzPlanCall(const KzPlanIn &in, KzPlan &pl, std::string &err) {
     // (autoShape) a pass takes what its context holds at that moment - the first passes of a job that starts behind the driver's wipe of recently released
     // memory are small, on clean memory the context is complete before the first pass - and with an explicit pass size or number of passes in flight the
     // call waits for the size it was asked for. (Since round 6 the film does not depend on the pass structure either way.)
-    pl.grow = in.pipeline == 2 && pl.autoShape && pl.need > ((size_t)1 << 26);
-    pl.minStart = pl.grow ? std::min<size_t>(pl.need, (size_t)1 << 20) : pl.need;
+    // A call with everything left to the library also RUNS on what there is when its context cannot be completed - another process holds the card, or the arena
+    // stops short of the reserve it leaves to the HIP runtime (kz_arena.cpp): narrower columns, more passes, the same film. It only starts EARLY (5 ms of grace per
+    // level instead of waiting for the growth to end) when the context is large enough for the wait to matter.
+    const bool onWhatThereIs = in.pipeline == 2 && pl.autoShape;
+    pl.grow = onWhatThereIs && pl.need > ((size_t)1 << 26);
+    pl.minStart = onWhatThereIs ? std::min<size_t>(pl.need, (size_t)1 << 20) : pl.need;
     pl.graceMs = pl.grow ? 5.0 : -1.0;
     return KZ_OK;
 }

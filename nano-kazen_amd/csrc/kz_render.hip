@@ -878,8 +878,10 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
     if (!in.limit) {
         size_t freeB = 0, totalB = 0;
         const size_t held = ds->ctxBytes() + kzCtxPoolBytes(ds->device);          // what this replica's contexts and the device's idle pooled contexts hold (the beam lists - one per frame pixel, 264 B each - and the film's tap sums are the replica's, not part of this budget)
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) in.limit = std::min(totalB / 4 * 3, freeB + held - std::min(freeB + held, (size_t)256 << 20));
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) in.limit = std::min(totalB / 4 * 3, freeB + held - std::min(freeB + held, KzArena::kRuntimeReserve + ((size_t)256 << 20)));      // (what the arena will not map anyway: its reserve for the HIP runtime)
         else in.limit = (size_t)32 << 30;
+        if (in.limit == 0) return kz_fail(KZ_ERR_OOM, "the device has %.2f GB free and this replica holds no pass context: nothing is left for path state beyond the %.2f GB a context leaves to the HIP runtime's own allocations",
+                                          freeB / 1e9, (KzArena::kRuntimeReserve + ((size_t)256 << 20)) / 1e9);
     }
     const uint32_t nTilesSet = (uint32_t)ds->curTiles.size();
     in.dealer = dealer != nullptr;

@@ -737,3 +737,40 @@ def test_large_passes_measure_how_they_run(gpu_lib, kz):
     assert sc.last_pass_info()["shadowBeside"] == 0 and np.array_equal(sc.film(), one_stream)
     sc.render(0, 16); assert sc.last_pass_info()["shadowBeside"] == 1  # a small pass (2^25 items): beside, whatever was decided for the large ones
     sc.close()
+
+
+def test_rendering_on_a_card_that_is_nearly_full(gpu_lib, kz):
+    """Something else holds the card but for ~5 GB (a plain hipMalloc here): a pass context stops growing where 2 GB would no longer stay free for the HIP runtime's own
+    allocations (a queue's first scratch allocation that fails ABORTS the process, profiles/r06x_memory_pressure), the call runs on what there is - one level of 2^23
+    items, so 33 M items take several passes - and the film is the same bits; kz_last_grow_note says why the context stopped."""
+    from conftest import wait_for_wipe
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    desc = kz.scenes.cornell_box(1920, 1080, 16, sampler="independent")
+    sc = kz.Scene(desc, device=0)
+    sc.render()
+    roomy = sc.film()
+    assert sc.last_pass_info()["passes"] == 1
+    sc.close()
+    gpu_lib.kz_device_trim(0)                                           # the pooled path state goes back to the driver: what is held below is really gone
+    free = wait_for_wipe(gpu_lib)
+    block = C.c_void_p()
+    if hip.hipMalloc(C.byref(block), free - (5 << 30)) != 0:
+        pytest.skip("could not take the card's free memory in one allocation")
+    try:
+        sc = kz.Scene(desc, device=0)
+        sc.render()
+        info = sc.last_pass_info()
+        assert info["passes"] >= 4 and info["largestPassItems"] <= 1 << 23, info
+        assert "2 GB are left to the HIP runtime" in sc.last_grow_note(), sc.last_grow_note()
+        assert np.array_equal(sc.film(), roomy)
+        f, t = C.c_uint64(), C.c_uint64()
+        assert gpu_lib.kz_device_mem_info(0, C.byref(f), C.byref(t)) == 0 and f.value >= (3 << 29), f.value      # >= 1.5 GB still free
+        sc.render(pass_halves=2, shadow_beside=2)                       # (more streams, more queues: their first kernels find their scratch)
+        assert np.array_equal(sc.film(), roomy)
+        sc.close()
+    finally:
+        hip.hipFree(block)
+        gpu_lib.kz_device_trim(0)
+        wait_for_wipe(gpu_lib)                                          # (the driver wipes what was held: the tests behind this one start on a quiet card)

@@ -144,3 +144,19 @@ def test_schedule_with_two_contexts_of_different_size(kz):
     for p in range(b0, b1, 4099):                                          # samples of a pixel arrive in ascending order (the running tap sums need exactly that)
         mine = [s for p0, w, s, sp in passes if p0 <= p < p0 + w]
         assert mine == sorted(mine)
+
+
+def test_a_call_left_to_the_library_runs_on_what_there_is(kz):
+    """A small job (need <= 2^26 items) with everything left to the library waits for its context (grow = 0: nothing to gain from starting early) but does NOT fail
+    when the context stops short - the card is full, or the arena keeps its reserve for the HIP runtime: minStart is 2^20 items (or the whole need, if smaller), and
+    the schedule on a context that stopped at one level covers every (pixel, sample) once. An explicit pass size still insists on what it asked for."""
+    npx, spp = 1920 * 1080, 16                                             # 33 M items
+    rc, a, q, _ = plan(kz, nPix=npx, sampleBegin=0, sampleEnd=spp)
+    assert rc == 0 and a["autoShape"] == 1 and a["grow"] == 0 and a["minStart"] == 1 << 20 and a["graceMs"] < 0
+    rc, passes = schedule(kz, q, [1 << 23], 0, npx)                         # the context stopped at one level of 2^23 items
+    assert rc == 0 and len(passes) >= 4 and int((passes[:, 1].astype(np.int64) * passes[:, 3]).max()) <= 1 << 23
+    assert (_covered(passes, 0, npx, 0, spp) == 1).all()
+    rc, a, q, _ = plan(kz, nPix=64 * 64, sampleBegin=0, sampleEnd=4)       # 16 K items: the whole need
+    assert rc == 0 and a["minStart"] == a["need"] == 64 * 64 * 4
+    rc, a, q, _ = plan(kz, nPix=npx, sampleBegin=0, sampleEnd=spp, passItems=1 << 24)
+    assert rc == 0 and a["autoShape"] == 0 and a["minStart"] == a["need"]
