@@ -359,7 +359,9 @@ int kz_scene_upload(KzScene *scene, int device);
 int kz_scene_evict(KzScene *scene, int device);
 /* The replacement for renderer.cpp:85-133: accumulate samples into the DEVICE film of replica opts->device
  * ((h+2b) x (w+2b) float4 = rgb*w, w; ImageBlock convention, block.cpp:30,56-85).
- * Asynchronous on opts->stream. Re-entrant per (scene, device): one host thread per GPU may call it concurrently. */
+ * Asynchronous on opts->stream. Re-entrant per (scene, device): one host thread per GPU may call it concurrently.
+ * A call that FAILS has waited for whatever it had launched (nothing of it is still running when the error comes back) and may have added some of its samples to the
+ * film: render without `accumulate` (or kz_film_clear) before the film is used again. */
 int kz_render(KzScene *scene, const KzRenderOpts *opts);
 
 /* SURVEY 8b tile variant, the unit of multi-GPU sharding: render `tiles` on `device` (overriding opts->tiles / opts->device), wait for the

@@ -1097,11 +1097,15 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
         ++pass;
         return KZ_OK;
     };
-    if (!dealer) { if ((rc = kzPlanRun(pl, 0u, ds->nPix, s0, s1, nextCtx, onePass))) return rc; }
+    // A call that fails in the middle (an allocation of a later pass, typically) leaves NOTHING running: passes it has already launched on the internal streams - pass
+    // streams, a context's side streams - are not joined into `stream` on this path, and their film stages would add to tap sums that the next call has meanwhile
+    // cleared (found by injecting allocation failures under two passes in flight: the next film carried the failed call's first pass, scripts/dev/fail_sweep.py).
+    auto failed = [&](int code) -> int { (void)hipDeviceSynchronize(); return code; };
+    if (!dealer) { if ((rc = kzPlanRun(pl, 0u, ds->nPix, s0, s1, nextCtx, onePass))) return failed(rc); }
     else {
         // BlockGenerator::next (block.cpp:117-148): batches of the tile list from the shared counter (it may live in memory shared between processes)
         for (uint32_t tb, te; kzDealerTake(dealer, batchTiles, nTilesSet, tb, te);)
-            if ((rc = kzPlanRun(pl, ds->tilePixOffset[tb], ds->tilePixOffset[te], s0, s1, nextCtx, onePass))) return rc;
+            if ((rc = kzPlanRun(pl, ds->tilePixOffset[tb], ds->tilePixOffset[te], s0, s1, nextCtx, onePass))) return failed(rc);
     }
     if (multi)                                                         // join: everything after this call on `stream` sees the film
         for (int i = 0; i < nCtx; ++i) if (inFlight[i]) HIP_TRY(hipStreamWaitEvent(stream, ds->evFilm[i], 0));

@@ -285,3 +285,36 @@ def test_a_frame_of_more_pixels_than_a_growing_context_holds(dev_lib, kz):
     finally:
         dev_lib.kz_debug_grow_delay(0)
     sc.close()
+
+
+def test_a_call_that_fails_in_the_middle_leaves_nothing_running(dev_lib, kz):
+    """Found by scripts/dev/fail_sweep.py: with two passes in flight, a call whose SECOND context could not be allocated returned its error while the first pass was still
+    queued on an internal stream - and that pass's film stage then added to tap sums the next call had already cleared (the next film carried 10 samples per pixel instead
+    of 8). A failed call now waits for what it has launched. Swept over the allocations of a fresh scene's first call, with every pass mode: each call either goes through
+    or fails with KZ_ERR_OOM, and the render after it gives the film."""
+    desc = kz.scenes.glass_scene(160, 128, 8)
+    sc = kz.Scene(desc, device=0, lib=dev_lib)
+    sc.render(shadow_beside=1, pass_halves=1)
+    ref = sc.film()
+    sc.close()
+    failed = 0
+    try:
+        for kw in (dict(pass_items=160 * 128 * 2, passes_in_flight=2), dict(pass_items=160 * 128 * 2, passes_in_flight=2, pass_halves=2), dict(pass_halves=2, shadow_beside=2)):
+            for n in range(36, 60):
+                dev_lib.kz_device_trim(0)                                  # a fresh scene on an empty pool: its first call allocates everything
+                dev_lib.kz_debug_fail_alloc(n)
+                sc = kz.Scene(desc, device=0, lib=dev_lib)
+                try:
+                    sc.render(**kw)
+                    sc.sync()
+                    assert np.array_equal(sc.film(), ref), (kw, n)
+                except kz.abi.KzError as e:
+                    assert e.code == 6, (kw, n, str(e))                     # KZ_ERR_OOM
+                    failed += 1
+                dev_lib.kz_debug_fail_alloc(0)
+                sc.render(**kw)
+                assert np.array_equal(sc.film(), ref), (kw, n)
+                sc.close()
+    finally:
+        dev_lib.kz_debug_fail_alloc(0)
+    assert failed >= 10, failed
