@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 kz = importlib.import_module("nano-kazen_amd")
 lib = kz.abi.load_dev_library()
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-modes = dict(shadow_beside=1, pass_halves=1) if "--one-stream" in sys.argv else {}      # (--one-stream: no replica times its large passes)
+modes = dict(shadow_beside=1, pass_halves=1) if "--one-stream" in sys.argv else dict(shadow_beside=2, pass_halves=2) if "--halves-beside" in sys.argv else {}      # (--one-stream: no replica times its large passes; --halves-beside: every pass as halves with its shadow rays beside)
 lib.kz_debug_alias_devices(8)
 desc = kz.scenes.random_triangles(1000000, 3840, 2160, 4096, sampler="pmj02bn", seed=1)
 sc = kz.Scene(desc, lib=lib)
