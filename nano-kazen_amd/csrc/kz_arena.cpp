@@ -203,14 +203,14 @@ bool KzArena::growOneLevel(size_t first) {
     // process (HSA_STATUS_ERROR_OUT_OF_RESOURCES; seen with several replicas sharing one card, each growing into what the others had just released). A level is
     // therefore only mapped while kRuntimeReserve bytes stay free behind it; otherwise the context stops growing and the passes run on what there is.
     // Memory that is being WIPED (released a moment ago, by anybody) is not reported free yet, and a hipMemCreate would simply wait for it: "too little free" only
-    // counts once the figure has stopped rising (the wipe moves ~33 GB/s; 100 ms without 64 MB more is a full card, not a wipe).
+    // counts once the figure has stopped rising (the wipe moves ~33 GB/s, though not evenly: a second without 64 MB more is a full card, not a wipe).
     {
         const size_t needB = items * bytesPerItem() + kRuntimeReserve;
         size_t freeB = 0, totalB = 0, best = 0; int still = 0;
         while (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB < needB) {
             still = freeB <= best + ((size_t)64 << 20) ? still + 1 : 0;
             best = std::max(best, freeB);
-            if (still >= 10) { e = hipErrorOutOfMemory; what = "the device is full (2 GB are left to the HIP runtime's own allocations): mapping"; break; }
+            if (still >= 100) { e = hipErrorOutOfMemory; what = "the device is full (2 GB are left to the HIP runtime's own allocations): mapping"; break; }
             { std::lock_guard<std::mutex> g(m); if (stop || first >= target) return false; }      // (nobody wants this level any more)
             std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }

@@ -548,13 +548,18 @@ def test_a_pass_context_that_is_still_growing_renders_the_same_film(dev_lib, kz,
     gpu_lib = dev_lib
     desc = kz.scenes.hero_scene(1280, 720, 256, detail=1.0)                   # 236 M items: four default levels and more
     one_pass = dict(pass_items=1280 * 720 * 256, passes_in_flight=1)         # (said: the call waits for the whole context and renders ONE pass)
+    # The PRODUCT library is another copy of the library in this process, with a pool of its own: the test before this one left ~260 GB of pass contexts in it, and
+    # this library's default state limit is what the device reports free (round 6: minus the 2 GB a context leaves to the HIP runtime) - 41.5 GB for this job fitted
+    # by a margin that the reserve then ate, some runs. That pool goes back to the driver first.
+    from conftest import wait_for_wipe
+    kz.abi.load_library().kz_device_trim(0)
+    wait_for_wipe(gpu_lib)
     ref = kz.Scene(desc, device=0, lib=dev_lib)
     ref.render(**one_pass)
-    assert ref.last_pass_info()["passes"] == 1
+    assert ref.last_pass_info()["passes"] == 1, (ref.last_pass_info(), ref.last_grow_note())
     want = ref.film()
     ref.close()
     assert gpu_lib.kz_device_trim(0) == 0                                    # the next scene starts from an empty context
-    from conftest import wait_for_wipe
     wait_for_wipe(gpu_lib)                                                   # (... on memory the driver has finished wiping: what is under test is the delay hook's schedule)
     try:
         gpu_lib.kz_debug_grow_delay(15)
