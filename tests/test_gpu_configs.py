@@ -519,6 +519,12 @@ def test_c4_at_the_benched_pass_size(gpu_lib, kz, O):
     assert sizes[:2] == [1 << 27, 1 << 28] and sizes[1] <= sizes[2] <= 1920 * 1080 * 256, sizes      # (the third: 2^29 unless the memory `sc` leaves caps it)
     assert np.array_equal(dflt.film(), big)                                  # passes of 2^27 .. 2^29 earned call by call: the film of the one 2^30 pass, bit for bit
     dflt.close()
+    # the 2^30-item pass as two HALVES of its pixels side by side (views of the one context: the second half's arrays start 0.53 G items into the first's), its
+    # shadow rays beside its closest-hit rays: the same film, bit for bit
+    sc.set_stats(False)
+    sc.render(0, 512, pass_items=1 << 30, passes_in_flight=1, pass_halves=2, shadow_beside=2)
+    assert sc.last_pass_info()["shadowBeside"] == 2 and sc.last_pass_info()["passes"] == 1 and np.array_equal(sc.film(), big)
+    sc.set_stats(True); sc.stats(reset=True)
     sc.render(0, 512, pass_items=1 << 27, passes_in_flight=2)
     small = sc.film()
     st2 = sc.stats(reset=True)
