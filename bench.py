@@ -576,10 +576,10 @@ def ext_scenes(kz, device_index, cpu=True):
             ts = []
             for _ in range(6):          # (a replica's first four large passes are its timed probes of how such a pass should run: the later calls run what it kept)
                 t0 = time.perf_counter(); sc.render(); sc.sync(); ts.append(time.perf_counter() - t0)
-            rec = {"workload": what, "samples": n, "value": round(n / min(ts[4:] if n > (1 << 26) else ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
+            rec = {"workload": what, "samples": n, "value": round(n / min(ts[4:] if n > (1 << 27) else ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
                    "image_mean": round(float(sc.rgb().mean()), 5), "passes": sc.last_pass_info()["passes"], "tris": desc.n_tris(),
                    "how_the_last_pass_ran": ("one stream", "shadow rays beside", "halves")[sc.last_pass_info()["shadowBeside"]]}
-            if n > (1 << 26):
+            if n > (1 << 27):
                 rec["large_passes_measured_by_the_replica"] = sc.pass_mode_info()
             if cpu and cpu_mode:
                 import oracle as O

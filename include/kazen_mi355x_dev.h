@@ -109,7 +109,7 @@ typedef struct KzPassInfo { uint32_t passes; uint32_t passesInFlight; uint64_t i
                             uint64_t contextItems;      /* items the first pass context holds NOW (it may still be growing towards itemsPerPass) */
                           } KzPassInfo;
 int kz_last_pass_info(KzScene *scene, KzPassInfo *out);
-/* What the replica on `device` (-1: the primary one) has measured about its LARGE passes (above 2^26 items, KzRenderOpts::shadowBeside = passHalves = 0): the four timed passes
+/* What the replica on `device` (-1: the primary one) has measured about its LARGE passes (above 2^27 items, KzRenderOpts::shadowBeside = passHalves = 0): the four timed passes
  * of `items` items each and what it keeps for the scene. kept: -1 = not decided yet (timedPasses of the four have been launched), 0 = one stream, 1 = shadow rays beside the
  * closest-hit rays, 2 = two halves side by side; the times (ms, film stage included) are there once it has decided. */
 typedef struct KzPassModeInfo { int32_t kept; uint32_t timedPasses; uint64_t items; float msOneStream[2]; float msShadowBeside; float msHalves; } KzPassModeInfo;

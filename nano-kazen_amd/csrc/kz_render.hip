@@ -642,7 +642,7 @@ static int ensureOverflow(KzScene *scene, KzDeviceState *ds, PassCtx &c, const K
 
 // Passes of at most this many items put the shadow rays of a bounce beside its closest-hit rays by default (wfPass; KzRenderOpts::shadowBeside).
 #ifndef KZ_BESIDE_ITEMS
-#define KZ_BESIDE_ITEMS (1u << 26)
+#define KZ_BESIDE_ITEMS (1u << 27)
 #endif
 
 // One pass of the wavefront pipeline over `items` = nPixPass x Sp (pixel, sample) items: pixels pixList[0 .. nPixPass), sample indices
@@ -737,7 +737,7 @@ static int wfPass(KzScene *scene, KzDeviceState *ds, PassCtx &c, hipStream_t str
     const dim3 gClassify((unsigned)(ds->numCU * 8));
     // A pass of a small job (C1: 1 M items on a chip of 524 288 lanes) is a chain of ~25 dependent launches, each of which lasts as long as its slowest ray
     // whatever the number of rays: there the shadow rays of a bounce run BESIDE its closest-hit rays (the context's side stream) instead of in front of them
-    // (C1 2.47 -> 2.03 ms; the gain fades with the pass size: -4 .. -6 % at 2^22 - 2^23 items of C3 / C4-like scenes, -1 % at 2^25, nothing at 2^27: profiles/r06v_shadow_beside).
+    // (C1 2.47 -> 2.03 ms; the gain fades with the pass size: -4 .. -6 % at 2^22 - 2^23 items of C3 / C4-like scenes, -1 % at 2^25, nothing either way at 2^27 - where the q1 asset still gains 7 %, so the rule ends there: profiles/r06v_shadow_beside).
     // A LARGE pass is another matter: on C4 each kernel saturates the VALUs by itself and sharing the chip costs 1 % (bench 1 798 / 1 812 one stream, 1 788 / 1 782
     // beside) - but a scene whose shadow rays are short-lived (the reference's own q1 asset: an object on a backdrop under three lights, shadow kernel at 0.67 VALU
     // busy) gains 6 - 10 % at EVERY pass size, all 22 scene files of the reference do. Nothing known at upload tells the two kinds apart, so renderOn MEASURES it

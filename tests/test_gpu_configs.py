@@ -658,7 +658,7 @@ def test_calls_on_alternating_caller_streams_are_ordered(gpu_lib, kz):
 
 def test_shadow_rays_beside_the_closest_hit_rays(gpu_lib, kz, O):
     """KzRenderOpts::shadowBeside: the shadow kernels of a bounce on the pass context's side stream, beside the bounce's closest-hit kernel (2), in front of it on one
-    stream (1), or as the library decides (0: beside up to 2^26 items per pass). What the two kernels touch is disjoint and the next shade waits for both: the film is
+    stream (1), or as the library decides (0: beside up to 2^27 items per pass). What the two kernels touch is disjoint and the next shade waits for both: the film is
     the SAME BITS - on scenes with visible and invisible lights (the walk-through launch rides on the side stream too), with the EXT shade kernels, with a background
     (the last bounce extends), with passes in flight, with the counting instantiations - and equals the oracle's."""
     q1 = os.path.join(ROOT, "tests", "golden", "q1_default_m0_r0.5.npz")
@@ -714,17 +714,18 @@ def test_shadow_rays_beside_the_closest_hit_rays(gpu_lib, kz, O):
 
 
 def test_large_passes_measure_how_they_run(gpu_lib, kz):
-    """KzRenderOpts::shadowBeside = passHalves = 0 on passes above 2^26 items: the replica runs its first large pass on one stream, the next one of that size with the shadow
+    """KzRenderOpts::shadowBeside = passHalves = 0 on passes above 2^27 items: the replica runs its first large pass on one stream, the next one of that size with the shadow
     rays beside the closest-hit rays, a third as two halves, a fourth on one stream again, and keeps what was fastest for every later one (the decision itself depends on the scene and the clock -
     the reference's q1 asset gains 7 - 10 % beside at this size, profiles/r06v_shadow_beside - so only its shape is asserted: four probes, then one answer for good).
     Explicit values bypass it; the film is the same bits."""
     q1 = os.path.join(ROOT, "tests", "golden", "q1_default_m0_r0.5.npz")
-    desc = kz.scenes.load_npz(q1, overrides={"camera": {"width": 1920, "height": 1080}, "sampler": {"type": "independent", "sampleCount": 64, "seed": 0}})
+    desc = kz.scenes.load_npz(q1, overrides={"camera": {"width": 1920, "height": 1080}, "sampler": {"type": "independent", "sampleCount": 128, "seed": 0}})
     sc = kz.Scene(desc, device=0)
-    sc.render(shadow_beside=1)                                        # (earns the context its size: the passes below are all one pass of 1920 x 1080 x 64 > 2^26 items)
+    sc.render(shadow_beside=1)                                        # (earns the context its size: the passes below are all one pass of 1920 x 1080 x 128 > 2^27 items)
+    sc.render(shadow_beside=1)
     sc.render(shadow_beside=1)
     info = sc.last_pass_info()
-    assert info["passes"] == 1 and info["largestPassItems"] == 1920 * 1080 * 64 and info["shadowBeside"] == 0
+    assert info["passes"] == 1 and info["largestPassItems"] == 1920 * 1080 * 128 and info["shadowBeside"] == 0
     one_stream = sc.film()
     sc.render(); assert sc.last_pass_info()["shadowBeside"] == 0      # timed in front
     sc.render(); assert sc.last_pass_info()["shadowBeside"] == 1      # timed beside
@@ -732,21 +733,21 @@ def test_large_passes_measure_how_they_run(gpu_lib, kz):
     sc.render(); assert sc.last_pass_info()["shadowBeside"] == 2      # timed as halves
     assert np.array_equal(sc.film(), one_stream)
     sc.render(); assert sc.last_pass_info()["shadowBeside"] == 0      # timed in front once more (the yardstick is the better of the two)
-    assert sc.pass_mode_info()["kept"] is None and sc.pass_mode_info()["timed_passes"] == 4 and sc.pass_mode_info()["items"] == 1920 * 1080 * 64
+    assert sc.pass_mode_info()["kept"] is None and sc.pass_mode_info()["timed_passes"] == 4 and sc.pass_mode_info()["items"] == 1920 * 1080 * 128
     sc.render(); kept = sc.last_pass_info()["shadowBeside"]           # waits for the fourth, decides
     m = sc.pass_mode_info()
     assert m["kept"] == ("one stream", "shadow rays beside", "halves")[kept] and min(m["ms_one_stream"] + [m["ms_shadow_beside"], m["ms_halves"]]) > 10.0, m
     assert np.array_equal(sc.film(), one_stream)
     for _ in range(2):
         sc.render(); assert sc.last_pass_info()["shadowBeside"] == kept
-    print("q1 asset, passes of 2^27 items: the replica keeps", ("one stream", "its shadow rays beside the closest-hit rays", "halves")[kept], m)
+    print("q1 asset, passes of 2^28 items: the replica keeps", ("one stream", "its shadow rays beside the closest-hit rays", "halves")[kept], m)
     sc.render(shadow_beside=2); assert sc.last_pass_info()["shadowBeside"] == 1
     sc.render(shadow_beside=1); assert sc.last_pass_info()["shadowBeside"] == 0
     sc.render(pass_halves=2); assert sc.last_pass_info()["shadowBeside"] == 2 and np.array_equal(sc.film(), one_stream)
     sc.render(pass_halves=1); assert sc.last_pass_info()["shadowBeside"] == 0      # (one option said: the other follows its plain rule - small passes beside, large ones in front)
     sc.set_stats(True); sc.render(); sc.set_stats(False)              # the counting kernels are not what was timed: in front
     assert sc.last_pass_info()["shadowBeside"] == 0 and np.array_equal(sc.film(), one_stream)
-    sc.render(0, 16); assert sc.last_pass_info()["shadowBeside"] == 1  # a small pass (2^25 items): beside, whatever was decided for the large ones
+    sc.render(0, 64); assert sc.last_pass_info()["shadowBeside"] == 1  # a small pass (just under 2^27 items): beside, whatever was decided for the large ones
     sc.close()
 
 
