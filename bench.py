@@ -536,6 +536,9 @@ def main():
             log("rank %d: strong_c5 failed: %r" % (rank, e))
         if rank == 0:
             out["strong_c5"] = sc5
+    if world == 1 and not args.strong and not (args.no_asset_scene and args.no_ext_scenes):
+        scene.close()                                          # (its pass contexts go to the device's pool: the scenes below render in them - until round 6 the reference's
+                                                               #  scene ran BESIDE the benched one's 175 GB of path state, in passes a quarter of the size it would otherwise earn)
     if world == 1 and not args.strong and not args.no_asset_scene:
         try:
             out["reference_scene"] = reference_scene(kz, device_index, args.asset_spp)
@@ -543,7 +546,6 @@ def main():
             out["reference_scene"] = {"error": repr(e)}
     if world == 1 and not args.strong and not args.no_ext_scenes:
         try:
-            scene.close()                                      # (its pass contexts go to the device's pool: the scenes below render in them)
             out["ext_scenes"] = ext_scenes(kz, device_index, cpu=not args.no_cpu_baseline)
         except Exception as e:                                 # noqa: BLE001
             out["ext_scenes"] = {"error": repr(e)}
@@ -555,6 +557,18 @@ def main():
             dist.destroy_process_group()
         except Exception as e:                                 # noqa: BLE001 - the record is out
             log("rank %d: shutdown: %r" % (rank, e))
+
+
+def settled_calls(sc, call, most=14):
+    """Wall times of repeated whole jobs on a resident scene until it runs the way it will go on running: the pass context earns its size call by call, and a replica
+    whose passes are large then times four of them (one stream, shadow rays beside, halves, one stream) before it keeps the fastest way - then two more calls."""
+    ts, after = [], 0
+    while len(ts) < most and after < 2:
+        t0 = time.perf_counter(); call(); sc.sync(); ts.append(time.perf_counter() - t0)
+        m = sc.pass_mode_info()
+        if len(ts) >= 3 and (m["kept"] is not None or m["timed_passes"] == 0):
+            after += 1
+    return ts
 
 
 def ext_scenes(kz, device_index, cpu=True):
@@ -584,10 +598,8 @@ def ext_scenes(kz, device_index, cpu=True):
             sc = kz.Scene(desc, device=device_index)
             build_s = time.perf_counter() - t0
             n = sc.width * sc.height * sc.sample_count
-            ts = []
-            for _ in range(6):          # (a replica's first four large passes are its timed probes of how such a pass should run: the later calls run what it kept)
-                t0 = time.perf_counter(); sc.render(); sc.sync(); ts.append(time.perf_counter() - t0)
-            rec = {"workload": what, "samples": n, "value": round(n / min(ts[4:] if n > (1 << 27) else ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
+            ts = settled_calls(sc, lambda: sc.render())
+            rec = {"workload": what, "samples": n, "value": round(n / min(ts[-2:] if n > (1 << 27) else ts[1:]) / 1e6, 1), "render_s": [round(t, 5) for t in ts], "scene_build_upload_s": round(build_s, 2),
                    "image_mean": round(float(sc.rgb().mean()), 5), "passes": sc.last_pass_info()["passes"], "tris": desc.n_tris(),
                    "how_the_last_pass_ran": ("one stream", "shadow rays beside", "halves")[sc.last_pass_info()["shadowBeside"]]}
             if n > (1 << 27):
@@ -630,9 +642,7 @@ def reference_scene(kz, device_index, spp):
     sc = kz.Scene(d, device=device_index)
     spp = min(spp, sc.sample_count)
     sc.render(0, min(64, spp)); sc.sync()
-    ts = []
-    for _ in range(6):               # (the first four large passes of a replica are its timed probes - shadow rays beside, one stream, halves, one stream: the later calls run what it kept)
-        t0 = time.perf_counter(); sc.render(0, spp); sc.sync(); ts.append(time.perf_counter() - t0)
+    ts = settled_calls(sc, lambda: sc.render(0, spp))
     kept = sc.last_pass_info()["shadowBeside"]
     n = sc.width * sc.height * spp
     # the same slice with KzRenderOpts::shadowBeside = 2 (the shadow rays of a bounce beside its closest-hit rays) and = 1 (in front): this scene's shadow rays are
@@ -648,7 +658,7 @@ def reference_scene(kz, device_index, spp):
               "kept_by_the_replica": ("one stream", "shadow rays beside", "halves")[kept], "large_passes_measured_by_the_replica": sc.pass_mode_info()}
     rec = {"workload": "scene/2022_q1/parameters/default_m0_r0.5.xml (36 378 triangles, the reference's own scene file via tests/golden/q1_default_m0_r0.5.npz), %dx%d, independent sampler, "
                        "path_mis maxDepth %d, sample indices [0, %d) of the file's %d" % (sc.width, sc.height, d.integrator["maxDepth"], spp, sc.sample_count),
-           "value": round(n / min(ts[4:]) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),
+           "value": round(n / min(ts[-2:]) / 1e6, 1), "unit": "Msamples/s", "render_s": [round(t, 4) for t in ts], "image_mean": round(float(sc.rgb().mean()), 5),
            "shadow_beside": beside,
            "whole_job": "all 4096 spp: 4.4 s, 1 927 Msamples/s; against the published 4096-spp picture of this scene file: profiles/r04p_q1_full",
            "published_caption": {"job": "1920x1080, 4096 spp (another scene of the same studio set)", "seconds": 702, "Msamples_per_s": 12.1, "hardware": "unstated CPU",
