@@ -323,7 +323,7 @@ typedef struct KzRenderOpts {
     const struct KzTileDealer *dealer;   /* kz_render_tiles: NULL = render every tile of the list; else take batches of it from the dealer's counter */
     /* ---- ABI v6 ---- */
     int32_t shadowBeside;       /* where the shadow rays of a bounce run: 1 = in front of the bounce's closest-hit rays (one stream), 2 = beside them (a side stream of the
-                                   pass context; the next shade waits for both), 0 = default: beside in passes of up to 2^27 items - a small job is a chain of launches each
+                                   pass context; the next shade waits for both), 0 = default: beside in passes of up to 2^27 items (2^24 with passes in flight or a dealer: they overlap each other already) - a small job is a chain of launches each
                                    as long as its slowest ray (BASELINE configs[0]: 2.47 -> 2.03 ms) - and MEASURED for larger ones: kernels that saturate the chip by
                                    themselves lose ~1 % sharing it (C4), kernels that do not - short-lived shadow rays: all 22 of the reference's scene/2022_q1 files - gain
                                    6 - 10 % at any size. The replica runs its first large pass in front, the next one of that size beside, a third as halves (passHalves),

@@ -644,6 +644,9 @@ static int ensureOverflow(KzScene *scene, KzDeviceState *ds, PassCtx &c, const K
 #ifndef KZ_BESIDE_ITEMS
 #define KZ_BESIDE_ITEMS (1u << 27)
 #endif
+#ifndef KZ_BESIDE_ITEMS_IN_FLIGHT
+#define KZ_BESIDE_ITEMS_IN_FLIGHT (1u << 24)      // ... with passes in flight or a dealer (renderOn)
+#endif
 
 // One pass of the wavefront pipeline over `items` = nPixPass x Sp (pixel, sample) items: pixels pixList[0 .. nPixPass), sample indices
 // [sBegin, sBegin + Sp). Every launch goes to `stream`; queue counts stay on the device.
@@ -1028,6 +1031,9 @@ static int renderOn(KzScene *scene, KzDeviceState *ds, const KzRenderOpts *opts)
             }
         }
         if (halves && (pipeline != 2 || multi || dealer || expTune || nPixPass < 256)) halves = false;      // (passes in flight and dealt batches overlap already)
+        // ... and for the same reason the small-pass rule ends earlier under them: two passes of 2^22 items in flight still gain from "beside" (+1.5 .. +11 %), at
+        // 2^24 - 2^25 C3 / C4 are neutral, from 2^26 they lose 2 - 3 % (the q1 asset gains at every size: whoever renders such scenes that way says 2)
+        if (sb == 0 && (multi || dealer) && items > KZ_BESIDE_ITEMS_IN_FLIGHT) sb = 1;
         if (halves) {                                                         // (what the halves need is made before the clock of a timed pass starts)
             if (!c.halfStream) {
                 HIP_TRY(hipStreamCreateWithFlags(&c.halfStream, hipStreamNonBlocking));
